@@ -1,0 +1,302 @@
+/*
+ * ctl_amd.h — C-ABI drop-in boundary of the MI355X-native wavefront path tracer.
+ *
+ * The reference (hhergeth/CudaTracerLib) exposes its tracer plugins as C++ classes
+ * (`Tracer<true>` subclasses, Kernel/Tracer.h:193-294) fed by a `KernelDynamicScene`
+ * POD of device arrays (Engine/KernelDynamicScene.h:28-109).  This header is the
+ * plain-C restatement of exactly that boundary for the wavefront path-tracing hot
+ * path: the same arrays (bit-compatible element layouts, cited per struct), the same
+ * tracer life-cycle (Resize / InitializeScene / DoPass / counters / parameters) and
+ * the same `Image` accumulator (`PixelData`, Engine/Image.h:10-29).
+ *
+ * All pointers are plain host or device pointers, all sizes are element counts,
+ * no C++ or torch types appear.  Every function returns 0 on success or a negative
+ * ctl_status; ctl_last_error() gives the message the reference would have thrown
+ * as std::runtime_error (Defines.cpp:15-29).
+ *
+ * The library is libctl_amd.so (cudatracerlib_amd/csrc).  It needs a gfx950 device
+ * for every entry point that renders or intersects; those fail with CTL_ERR_NO_DEVICE
+ * instead of falling back to any CPU path.
+ */
+#ifndef CTL_AMD_H
+#define CTL_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+typedef enum {
+    CTL_OK = 0,
+    CTL_ERR_INVALID = -1,      /* bad argument / bad handle                       */
+    CTL_ERR_NO_DEVICE = -2,    /* no HIP device (product path never falls back)   */
+    CTL_ERR_HIP = -3,          /* hipError_t != hipSuccess, message in last_error */
+    CTL_ERR_OVERFLOW = -4,     /* ray queue overflow (DoubleRayBuffer.h:86-89)    */
+    CTL_ERR_UNSUPPORTED = -5,  /* e.g. participating media, unknown plugin name   */
+    CTL_ERR_IO = -6            /* scene loader: file / parse errors               */
+} ctl_status;
+
+const char* ctl_last_error(void);
+const char* ctl_version(void);
+/* number of visible HIP devices (0 on a CPU-only box; never an error) */
+int ctl_device_count(void);
+
+/* ------------------------------------------------ reference-layout elements */
+/* Engine/TriIntersectorData.h:42-117 — Aila–Laine node, 4 x float4 = 64 B.
+ * a = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y), b = (c1...), c = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)
+ * child >= 0: float4 index of an inner node (nodeIdx*4); child < 0: ~firstLeafEntry;
+ * 0x76543210: no child (SplitBVHBuilder.cpp:163-203). */
+typedef struct { float a[4], b[4], c[4]; int32_t child0, child1; uint32_t parent; uint32_t pad; } ctl_bvh_node;
+/* Engine/TriIntersectorData.h:30-40 — Woop unit-triangle rows, 48 B. */
+typedef struct { float a[4], b[4], c[4]; } ctl_woop_tri;
+/* Engine/TriIntersectorData.h:8-28 — (triangleIndex << 1) | lastInLeaf. */
+typedef struct { uint32_t index; } ctl_woop_index;
+/* Engine/TriangleData.h:10-54 (EXT_TRI, NUM_UV_SETS 1) — 32 B shading triangle. */
+typedef struct { uint32_t nor_mat_extra[2]; uint32_t dpdu_dpdv[3]; uint32_t uv[3]; } ctl_triangle_data;
+/* Engine/Mesh.h:12-19 */
+typedef struct { uint32_t tri_offset, bvh_node_offset, bvh_tri_offset, bvh_index_offset, std_material_offset; } ctl_kernel_mesh;
+/* SceneTypes/Node.h:13-24 (FixedSizeArray<unsigned,2>: buffer then length) — 24 B */
+typedef struct { uint32_t mesh_index, material_offset, instanciated_material; uint32_t lights[2]; uint32_t n_lights; } ctl_node;
+/* Math/float4x4.h:12-18 — row-major, column-vector convention */
+typedef struct { float m[16]; } ctl_float4x4;
+/* Kernel/TraceHelper.h:55-59 — a = (origin, tmin), b = (direction, tmax) */
+typedef struct { float a[4]; float b[4]; } ctl_ray;
+/* Kernel/TraceHelper.h:61-69 — dist, node, triangle, barycentrics.
+ * The reference packs the barycentrics into 2 x u16 (TraceHelper.cu:728-729); this build
+ * keeps them as full floats (the precision of the reference's single-ray traceRay,
+ * TraceHelper.cu:159) and so the record is 20 B wide on the C-ABI. */
+typedef struct { float dist; int32_t node_idx; int32_t tri_idx; float u, v; } ctl_hit;
+/* Engine/Image.h:10-29 — 28 B accumulator */
+typedef struct { float rgb[3]; float rgb_splat[3]; float weight_sum; } ctl_pixel_data;
+/* Engine/ShapeSet.h:19-30 — area-light triangle, 64 B, lives in the anim blob */
+typedef struct { float p[3][3]; float n[3]; float area; uint32_t i_dat; uint32_t t_dat; } ctl_shape_tri;
+
+/* --------------------------------------------- compact scene-type descriptors */
+/* The reference stores BSDFs / lights / sensors as tagged C++ unions (Material 3344 B,
+ * Light 592 B, Sensor 320 B) whose byte layout depends on the host compiler.  The
+ * boundary carries the same parameters as flat descriptors; INTEGRATION.md shows the
+ * conversion a maintainer adds next to DynamicScene::getKernelSceneData(). */
+/* ids = TYPE_FUNC ids of SceneTypes/Texture.h:107,127,159 */
+enum { CTL_TEX_CONSTANT = 2, CTL_TEX_CHECKER = 3, CTL_TEX_IMAGE = 4 };
+typedef struct {
+    uint32_t type;       /* CTL_TEX_*                                          */
+    float value[3];      /* constant colour / checker colour 0                  */
+    float value1[3];     /* checker colour 1                                    */
+    float uv_scale[2], uv_offset[2];
+    uint32_t image;      /* index into the scene's image table (CTL_TEX_IMAGE)  */
+} ctl_texture;           /* 48 B */
+
+/* ids = the reference's TYPE_FUNC ids (BSDF_Simple.h:6-401, BSDF_Complex.h:9-182) */
+enum { CTL_BSDF_DIFFUSE = 1, CTL_BSDF_ROUGHDIFFUSE = 2, CTL_BSDF_DIELECTRIC = 3, CTL_BSDF_THINDIELECTRIC = 4,
+       CTL_BSDF_ROUGHDIELECTRIC = 5, CTL_BSDF_CONDUCTOR = 6, CTL_BSDF_ROUGHCONDUCTOR = 7, CTL_BSDF_PLASTIC = 8,
+       CTL_BSDF_ROUGHPLASTIC = 9, CTL_BSDF_PHONG = 10, CTL_BSDF_WARD = 11, CTL_BSDF_HK = 12,
+       CTL_BSDF_COATING = 13, CTL_BSDF_ROUGHCOATING = 14, CTL_BSDF_BLEND = 15 };
+/* SceneTypes/Samples.h:31-95 lobe flags */
+enum { CTL_ENull = 0x1, CTL_EDiffuseReflection = 0x2, CTL_EDiffuseTransmission = 0x4, CTL_EGlossyReflection = 0x8,
+       CTL_EGlossyTransmission = 0x10, CTL_EDeltaReflection = 0x20, CTL_EDeltaTransmission = 0x40,
+       CTL_EDelta1DReflection = 0x80, CTL_EDelta1DTransmission = 0x100 };
+/* Engine/MicrofacetDistribution.h:14-21 */
+enum { CTL_MF_BECKMANN = 0, CTL_MF_GGX = 1, CTL_MF_PHONG = 2 };
+
+/* Parameter slots by bsdf_type:
+ *  diffuse        tex0 reflectance
+ *  roughdiffuse   tex0 reflectance, tex1 alpha, u0 useFastApprox
+ *  dielectric     tex0 specularTransmittance, tex1 specularReflectance, f0 Cauchy B (= eta), f1 Cauchy C
+ *  thindielectric tex0 specularTransmittance, tex1 specularReflectance, f0 eta
+ *  roughdielectric tex0 specT, tex1 specR, tex2 alphaU, tex3 alphaV, f0 eta, f1 invEta, u0 distribution, u1 sampleVisible
+ *  conductor      tex0 specularReflectance, f0..2 eta rgb, f3..5 k rgb
+ *  roughconductor tex0 specR, tex1 alphaU, tex2 alphaV, f0..2 eta, f3..5 k, u0 distribution, u1 sampleVisible
+ *  plastic        tex0 diffuseReflectance, tex1 specularReflectance, f0 fdrInt, f1 fdrExt, f2 eta, f3 invEta2,
+ *                 f4 specularSamplingWeight, u0 nonlinear
+ *  roughplastic   tex0 diffuse, tex1 specular, tex2 alpha, f0 eta, f1 invEta2, f2 specularSamplingWeight,
+ *                 u0 nonlinear, u1 sampleVisible, u2 distribution
+ *  phong          tex0 diffuse, tex1 specular, tex2 exponent, f0 specularSamplingWeight */
+typedef struct {
+    uint32_t bsdf_type;        /* CTL_BSDF_*                                       */
+    uint32_t combined_type;    /* BSDF::m_combinedType (SceneTypes/BSDF.h:24)      */
+    uint32_t two_sided;        /* BSDF::m_enableTwoSided (SceneTypes/BSDF.h:26)    */
+    uint32_t node_light_index; /* Material::NodeLightIndex, UINT32_MAX = none      */
+    ctl_texture tex[4];
+    float f[8];
+    uint32_t u[4];
+} ctl_material;                /* 256 B */
+
+/* ids = TYPE_FUNC ids of SceneTypes/Light.h:36,98,147,228,296 */
+enum { CTL_LIGHT_POINT = 1, CTL_LIGHT_DIFFUSE = 2, CTL_LIGHT_DISTANT = 3, CTL_LIGHT_SPOT = 4, CTL_LIGHT_INFINITE = 5 };
+typedef struct {
+    uint32_t type;                 /* CTL_LIGHT_*                                              */
+    float radiance[3];             /* DiffuseLight::m_rad_texture (constant) / intensity       */
+    /* DiffuseLight: ShapeSet (Engine/ShapeSet.h:61-66) — byte offsets into the anim blob */
+    uint32_t area_dist_index;      /* float[count+1] normalised area CDF                       */
+    uint32_t triangles_index;      /* ctl_shape_tri[count]                                     */
+    float sum_area;
+    uint32_t count;
+    uint32_t orthogonal;           /* DiffuseLight::m_bOrthogonal                              */
+    uint32_t node_idx;             /* DiffuseLight::m_uNodeIdx                                 */
+    /* Point / Spot / Distant */
+    float position[3];
+    float direction[3];
+    float cutoff_angle, beam_width, cos_cutoff_angle, cos_beam_width, inv_transition_width;
+    float to_world[16];            /* spot / envmap frame                                      */
+    /* InfiniteLight (round 2: image + row/col CDFs live in the image table) */
+    uint32_t env_image;
+    float env_scale[3];
+    float bsphere_center[3], bsphere_radius;
+} ctl_light;
+
+/* ids = TYPE_FUNC ids of SceneTypes/Sensor.h:107,191,272,364,445 */
+enum { CTL_SENSOR_SPHERICAL = 1, CTL_SENSOR_PERSPECTIVE = 2, CTL_SENSOR_THINLENS = 3, CTL_SENSOR_ORTHOGRAPHIC = 4, CTL_SENSOR_TELECENTRIC = 5 };
+typedef struct {
+    uint32_t type;
+    float to_world[16];            /* SensorBase::toWorld (row-major)                          */
+    float fov;                     /* radians, horizontal (SceneTypes/Sensor.h:72-76)          */
+    float near_depth, far_depth;   /* SensorBase::m_fNearFarDepths                             */
+    float resolution[2];           /* film size in pixels                                      */
+    float aperture_radius, focus_distance;
+} ctl_sensor;
+
+#define CTL_MAX_NUM_LIGHTS 16      /* Engine/KernelDynamicScene.h:26 */
+
+/* Engine/KernelDynamicScene.h:28-109 restated with plain pointers (HOST memory). */
+typedef struct {
+    const ctl_triangle_data* tri_data;   uint32_t n_tri_data;     /* m_sTriData       */
+    const ctl_woop_tri* woop;            uint32_t n_woop;         /* m_sBVHIntData    */
+    const ctl_woop_index* woop_index;                             /* m_sBVHIndexData (n_woop) */
+    const ctl_bvh_node* bvh_nodes;       uint32_t n_bvh_nodes;    /* m_sBVHNodeData   */
+    const ctl_kernel_mesh* meshes;       uint32_t n_meshes;       /* m_sMeshData      */
+    const ctl_node* nodes;               uint32_t n_nodes;        /* m_sNodeData      */
+    const ctl_material* materials;       uint32_t n_materials;    /* m_sMatData       */
+    const ctl_light* lights;             uint32_t n_lights_buf;   /* m_sLightBuf      */
+    const uint8_t* anim;                 uint32_t n_anim_bytes;   /* m_sAnimData      */
+    /* KernelSceneBVH (Engine/SceneBVH_device.h:8-15) */
+    int32_t scene_start_node;
+    const ctl_bvh_node* scene_bvh_nodes; uint32_t n_scene_bvh_nodes;
+    const ctl_float4x4* node_transforms;      /* n_nodes */
+    const ctl_float4x4* node_inv_transforms;  /* n_nodes */
+    uint32_t env_map_index;                   /* UINT32_MAX = none */
+    float box_min[3], box_max[3];             /* m_sBox */
+    ctl_sensor camera;                        /* m_Camera */
+    uint32_t num_lights;                      /* m_numLights */
+    uint32_t light_indices[CTL_MAX_NUM_LIGHTS];
+    float light_cdf[CTL_MAX_NUM_LIGHTS];
+    float ray_trace_eps;                      /* m_rayTraceEps = 1e-4 * |box diagonal| (DynamicScene.cpp:587) */
+} ctl_scene_desc;
+
+/* ------------------------------------------------------------- scene builder */
+/* Host-side mirror of the subset of DynamicScene the loader drives
+ * (Engine/DynamicScene.h:70-187; SURVEY §8b "Loader boundary"). */
+typedef struct ctl_builder ctl_builder;
+int ctl_builder_create(ctl_builder** out);
+void ctl_builder_destroy(ctl_builder* b);
+/* Mesh::CompileMesh (Engine/Mesh.cpp:199-290): positions[3*n_vert], indices[3*n_tri] (NULL = soup),
+ * normals[3*n_vert] or NULL (computed as Mesh.cpp:151-190), uvs[2*n_vert] or NULL, tri_material[n_tri] local
+ * material index or NULL (all 0), materials[n_mat]. Builds the mesh BVH (SAH, max leaf 8 as
+ * BVHBuilderHelper.cpp:119).  Returns the mesh index. */
+int ctl_builder_add_mesh(ctl_builder* b, const float* positions, uint32_t n_vert, const uint32_t* indices, uint32_t n_tri,
+                         const float* normals, const float* uvs, const uint8_t* tri_material,
+                         const ctl_material* materials, uint32_t n_mat, uint32_t* mesh_index_out);
+/* DynamicScene::CreateNode + SetNodeTransform (DynamicScene.cpp:269-346): one instance of a mesh. */
+int ctl_builder_add_node(ctl_builder* b, uint32_t mesh_index, const ctl_float4x4* to_world, uint32_t* node_index_out);
+/* DynamicScene::CreateLight(node, matName, L) (DynamicScene.cpp:689-711): all triangles of the node whose local
+ * material index is `local_material` become one DiffuseLight. */
+int ctl_builder_add_area_light(ctl_builder* b, uint32_t node_index, uint32_t local_material, const float radiance[3]);
+/* DynamicScene::CreateLight(Light) for point lights (SceneTypes/Light.h:31-94) */
+int ctl_builder_add_point_light(ctl_builder* b, const float position[3], const float intensity[3]);
+/* DynamicScene::setCamera — perspective sensor as built by the Mitsuba loader (ObjectParser.h:292-297): */
+int ctl_builder_set_camera_lookat(ctl_builder* b, const float pos[3], const float target[3], const float up[3],
+                                  float fov_degrees, uint32_t width, uint32_t height);
+int ctl_builder_set_camera(ctl_builder* b, const ctl_sensor* sensor);
+/* DynamicScene::UpdateScene + getKernelSceneData (DynamicScene.cpp:480-589): builds the scene BVH and fills
+ * `out` with pointers that stay valid until the builder is destroyed or finalized again. */
+int ctl_builder_finalize(ctl_builder* b, ctl_scene_desc* out);
+
+/* ------------------------------------------------------------------- scenes */
+typedef struct ctl_scene ctl_scene;
+/* UpdateKernel(scene) (Kernel/TraceHelper.cu:182-217): uploads + re-lays-out the arrays in HBM. */
+int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out);
+void ctl_scene_destroy(ctl_scene* s);
+/* ParseMitsubaScene (Engine/SceneLoader/Mitsuba/MitsubaLoader.h:13): fills a builder from a Mitsuba-0.5 XML file. */
+int ctl_parse_mitsuba_scene(ctl_builder* b, const char* xml_path, int32_t* width_inout, int32_t* height_inout);
+
+/* ------------------------------------------------------------------ sampler */
+/* SequenceSamplerData(4096, 30) (Kernel/Sampler_device.h:11-57). tables_1d[30*4096], tables_2d[30*4096*2]:
+ * element (seq, e) at e*4096+seq. */
+#define CTL_SAMPLER_NUM_SEQUENCES 4096
+#define CTL_SAMPLER_SEQUENCE_LENGTH 30
+typedef struct ctl_sequence_generator ctl_sequence_generator;
+/* IndependantSamplingSequenceGenerator (Kernel/Sampler.h:57-85): XORWOW curand_init(1234, 7539414, 0). */
+int ctl_sequence_generator_create(ctl_sequence_generator** out);
+void ctl_sequence_generator_destroy(ctl_sequence_generator* g);
+/* SamplingSequenceGeneratorHost::Compute (Kernel/Sampler.h:36-55): next pass's tables into host buffers. */
+int ctl_sequence_generator_compute(ctl_sequence_generator* g, float* tables_1d, float* tables_2d);
+
+/* -------------------------------------------------------------------- image */
+typedef struct ctl_image ctl_image;
+int ctl_image_create(uint32_t width, uint32_t height, ctl_image** out);   /* Image::Image (Engine/Image.h:34) */
+void ctl_image_destroy(ctl_image* img);
+int ctl_image_clear(ctl_image* img);                                        /* Image::Clear                    */
+int ctl_image_read_pixels(ctl_image* img, ctl_pixel_data* host_out);        /* D2H of the PixelData array      */
+int ctl_image_write_pixels(ctl_image* img, const ctl_pixel_data* host_in);
+void* ctl_image_device_ptr(ctl_image* img);                                 /* PixelData* in HBM (RCCL gather) */
+/* copySamplesToOutput (Kernel/ImagePipeline/ImagePipeline.cu:14-30): rgb/weight + splat*scale -> linear RGB float */
+int ctl_image_resolve_rgb(ctl_image* img, float splat_scale, float* host_rgb_out);
+
+/* ------------------------------------------------------------------- tracer */
+typedef struct ctl_tracer ctl_tracer;
+/* plugin names: "WavefrontPathTracer" (Integrators/PseudoRealtime/WavefrontPathTracer.h:24). */
+int ctl_tracer_create(const char* plugin, ctl_tracer** out);
+void ctl_tracer_destroy(ctl_tracer* t);
+/* TracerParameterCollection (Kernel/TracerSettings.h:221-350): keys Direct(bool), MaxPathLength(int>=1),
+ * RRStartDepth(int>=1) (WavefrontPathTracer.h:29-39). Out-of-interval values -> CTL_ERR_INVALID. */
+int ctl_tracer_set_param_bool(ctl_tracer* t, const char* key, int value);
+int ctl_tracer_set_param_int(ctl_tracer* t, const char* key, int value);
+int ctl_tracer_get_param_int(ctl_tracer* t, const char* key, int* value_out);
+int ctl_tracer_resize(ctl_tracer* t, uint32_t width, uint32_t height);       /* Tracer::Resize (Tracer.h:196-208)          */
+int ctl_tracer_initialize_scene(ctl_tracer* t, ctl_scene* s);                /* TracerBase::InitializeScene (Tracer.h:102) */
+/* image-tile sharding for multi-GPU: this tracer renders the 64x64 tiles t with t % world == rank. */
+int ctl_tracer_set_tile_shard(ctl_tracer* t, uint32_t rank, uint32_t world);
+/* Use caller-provided sampler tables for the next pass instead of the tracer's own generator (tests). */
+int ctl_tracer_set_sampler_tables(ctl_tracer* t, const float* tables_1d, const float* tables_2d);
+/* Tracer<true>::DoPass (Tracer.h:209-248). */
+int ctl_tracer_do_pass(ctl_tracer* t, ctl_image* img, int new_trace);
+/* n passes back-to-back without host synchronisation in between (throughput mode). */
+int ctl_tracer_do_passes(ctl_tracer* t, ctl_image* img, int new_trace, uint32_t n_passes);
+typedef struct {
+    uint64_t rays_last_pass;       /* getRaysInLastPass (64-bit; the reference wraps at 2^32)            */
+    uint64_t rays_total;           /* getAccRays                                                         */
+    double seconds_last_pass;      /* getLastTimeSpentRenderingSec                                       */
+    double seconds_total;          /* getAccTimeSpentRenderingSec                                        */
+    uint32_t passes_done;          /* getNumPassesDone                                                   */
+    /* per-kernel HIP-event timing of the last do_pass/do_passes call, milliseconds */
+    double ms_intersect, ms_shade, ms_raygen;
+    uint64_t intersect_rays;       /* rays through the intersect kernels in that call                    */
+    uint64_t intersect_launches;
+} ctl_tracer_stats;
+int ctl_tracer_get_stats(ctl_tracer* t, ctl_tracer_stats* out);
+
+/* ---------------------------------------------------- intersect (row a7 alone) */
+/* __internal__IntersectBuffers (Kernel/TraceHelper.cu:736-746): n rays -> n hits; host pointers.
+ * any_hit = 1 selects intersectKernel<true>. */
+int ctl_intersect(ctl_scene* s, const ctl_ray* rays, uint32_t n, ctl_hit* hits, int any_hit);
+/* device-pointer variant, asynchronous on the scene's stream; ms_out (may be NULL) = HIP-event time of the launch */
+int ctl_intersect_device(ctl_scene* s, const void* d_rays, uint32_t n, void* d_hits, int any_hit, float* ms_out);
+/* traversal statistics for the roofline: sums over the n rays of inner-node visits, triangle tests and
+ * instance entries (B_ray = 32 + 16 + 64*N_inner + 52*N_tri + 108*N_inst). */
+typedef struct { uint64_t n_inner, n_tri, n_inst; } ctl_traversal_counts;
+int ctl_intersect_count(ctl_scene* s, const ctl_ray* rays, uint32_t n, int any_hit, ctl_traversal_counts* out);
+
+/* device memory helpers so that Python callers need no HIP binding */
+int ctl_device_malloc(size_t bytes, void** out);
+int ctl_device_free(void* p);
+int ctl_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int ctl_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int ctl_device_synchronize(void);
+int ctl_set_device(int ordinal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTL_AMD_H */

@@ -1,0 +1,717 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see omath.h header).
+// ocore.h — scene access, Woop triangles, two-level BVH traversal, TriangleData / fillDG, sampler,
+// sensor, lights, BSDFs and the megakernel PathTrace<DIRECT> — the semantic oracle of the path.
+#pragma once
+#include "omath.h"
+#include "../include/ctl_amd.h"   // boundary structs only (data layout contract)
+#include <vector>
+#include <stdexcept>
+
+namespace orc {
+
+static const int EntrypointSentinel = 0x76543210;   // Kernel/TraceHelper.cu:20
+
+// --------------------------------------------------------------------------- Woop (Engine/TriIntersectorData.cu)
+// TriIntersectorData.cu:5-18
+inline void woopSetData(ctl_woop_tri& w, V3 a, V3 b, V3 c) {
+    M44 m;
+    V3 e0 = a - c, e1 = b - c, n = cross(a - c, b - c);
+    m(0, 0) = e0.x; m(1, 0) = e0.y; m(2, 0) = e0.z; m(3, 0) = 0;
+    m(0, 1) = e1.x; m(1, 1) = e1.y; m(2, 1) = e1.z; m(3, 1) = 0;
+    m(0, 2) = n.x;  m(1, 2) = n.y;  m(2, 2) = n.z;  m(3, 2) = 0;
+    m(0, 3) = c.x;  m(1, 3) = c.y;  m(2, 3) = c.z;  m(3, 3) = 1;
+    m = inverse(m);
+    w.a[0] = m(2, 0); w.a[1] = m(2, 1); w.a[2] = m(2, 2); w.a[3] = -m(2, 3);
+    for (int j = 0; j < 4; j++) { w.b[j] = m(0, j); w.c[j] = m(1, j); }
+}
+// TriIntersectorData.cu:20-32
+inline void woopGetData(const ctl_woop_tri& w, V3& v0, V3& v1, V3& v2) {
+    M44 m = M44::identity();
+    for (int j = 0; j < 4; j++) { m(0, j) = w.b[j]; m(1, j) = w.c[j]; m(2, j) = w.a[j]; }
+    m(2, 3) *= -1.0f;
+    m = inverse(m);
+    V3 e02(m(0, 0), m(1, 0), m(2, 0)), e12(m(0, 1), m(1, 1), m(2, 1));
+    v2 = V3(m(0, 3), m(1, 3), m(2, 3));
+    v0 = v2 + e02;
+    v1 = v2 + e12;
+}
+// The per-triangle test, identical in TriIntersectorData.cu:34-61, TraceHelper.cu:118-165 (host traceRay)
+// and TraceHelper.cu:646-682 (intersectKernel).  Returns true and updates (t,u,v) when accepted.
+inline bool woopIntersect(const ctl_woop_tri& w, V3 o, V3 d, float tmin, float tmax, float& t_out, float& u_out, float& v_out) {
+    float Oz = w.a[3] - o.x * w.a[0] - o.y * w.a[1] - o.z * w.a[2];
+    float invDz = 1.0f / (d.x * w.a[0] + d.y * w.a[1] + d.z * w.a[2]);
+    float t = Oz * invDz;
+    if (t > tmin && t < tmax) {
+        float Ox = w.b[3] + o.x * w.b[0] + o.y * w.b[1] + o.z * w.b[2];
+        float Dx = d.x * w.b[0] + d.y * w.b[1] + d.z * w.b[2];
+        float u = Ox + t * Dx;
+        if (u >= 0.0f) {
+            float Oy = w.c[3] + o.x * w.c[0] + o.y * w.c[1] + o.z * w.c[2];
+            float Dy = d.x * w.c[0] + d.y * w.c[1] + d.z * w.c[2];
+            float v = Oy + t * Dy;
+            if (v >= 0.0f && u + v <= 1.0f) { t_out = t; u_out = u; v_out = v; return true; }
+        }
+    }
+    return false;
+}
+
+// --------------------------------------------------------------------------- traversal
+struct Hit {   // Kernel/TraceResult.h:18-35
+    float dist; float u, v; uint32_t tri; uint32_t node;
+    bool hasHit() const { return tri != UINT32_MAX; }
+    void init() { dist = FLT_MAX; tri = UINT32_MAX; node = UINT32_MAX; u = v = 0; }
+};
+struct TravCounts { uint64_t n_inner = 0, n_tri = 0, n_inst = 0; };
+
+// Math/MathFunc.h:443-444 — integer min/max on float bit patterns; for tmin >= 0 and non-NaN inputs the decision
+// `cmax >= cmin` is the same as with float min/max (negative entries lose against d >= 0 in spanBegin and make
+// spanEnd negative either way), so the restatement uses float semantics.
+inline float spanBegin(float a0, float a1, float b0, float b1, float c0, float c1, float d) {
+    return fmax2(fmax2(fmin2(a0, a1), fmin2(b0, b1)), fmax2(fmin2(c0, c1), d));
+}
+inline float spanEnd(float a0, float a1, float b0, float b1, float c0, float c1, float d) {
+    return fmin2(fmin2(fmax2(a0, a1), fmax2(b0, b1)), fmin2(fmax2(c0, c1), d));
+}
+
+// Engine/SpatialStructures/BVH/BVHTraversal.h:122-232 (pointer overload).  `nodes` is a float4 view; node addresses
+// are float4 indices.  `node_tmin`: 0 on the single-ray path (BVHTraversal.h:169-176), the ray's tmin on the
+// wavefront path (TraceHelper.cu:469-476) — only culling differs, never the accepted hit.
+template <typename CLB>
+inline bool tracerayTemplate(V3 ori, V3 dir, float& rayT, float node_tmin, const CLB& clb, const float* nodes4, int bvhNodesOffset,
+                             int startNode, TravCounts* cnt, const bool* stop = nullptr) {
+    if (startNode < 0) return clb(~startNode);
+    bool found = false;
+    int stack[64]; stack[0] = EntrypointSentinel;
+    const float ooeps = exp2f(-80.0f);
+    float idirx = 1.0f / (fabsf(dir.x) > ooeps ? dir.x : copysign_bits(ooeps, dir.x));
+    float idiry = 1.0f / (fabsf(dir.y) > ooeps ? dir.y : copysign_bits(ooeps, dir.y));
+    float idirz = 1.0f / (fabsf(dir.z) > ooeps ? dir.z : copysign_bits(ooeps, dir.z));
+    float oodx = ori.x * idirx, oody = ori.y * idiry, oodz = ori.z * idirz;
+    int sp = 0, leafAddr = 0, nodeAddr = startNode;
+    while (nodeAddr != EntrypointSentinel && !(stop && *stop)) {
+        while ((unsigned)nodeAddr < (unsigned)EntrypointSentinel) {
+            const float* n = nodes4 + (size_t)(bvhNodesOffset + nodeAddr) * 4;
+            if (cnt) cnt->n_inner++;
+            const float c0lox = n[0] * idirx - oodx, c0hix = n[1] * idirx - oodx, c0loy = n[2] * idiry - oody, c0hiy = n[3] * idiry - oody;
+            const float c0loz = n[8] * idirz - oodz, c0hiz = n[9] * idirz - oodz, c1loz = n[10] * idirz - oodz, c1hiz = n[11] * idirz - oodz;
+            const float c0min = spanBegin(c0lox, c0hix, c0loy, c0hiy, c0loz, c0hiz, node_tmin);
+            const float c0max = spanEnd(c0lox, c0hix, c0loy, c0hiy, c0loz, c0hiz, rayT);
+            const float c1lox = n[4] * idirx - oodx, c1hix = n[5] * idirx - oodx, c1loy = n[6] * idiry - oody, c1hiy = n[7] * idiry - oody;
+            const float c1min = spanBegin(c1lox, c1hix, c1loy, c1hiy, c1loz, c1hiz, node_tmin);
+            const float c1max = spanEnd(c1lox, c1hix, c1loy, c1hiy, c1loz, c1hiz, rayT);
+            int cx, cy; std::memcpy(&cx, n + 12, 4); std::memcpy(&cy, n + 13, 4);
+            bool swp = (c1min < c0min), t0 = (c0max >= c0min), t1 = (c1max >= c1min);
+            if (!t0 && !t1) { nodeAddr = stack[sp]; sp--; }
+            else {
+                nodeAddr = t0 ? cx : cy;
+                if (t0 && t1) { if (swp) std::swap(nodeAddr, cy); sp++; stack[sp] = cy; }
+            }
+            if (nodeAddr < 0 && leafAddr >= 0) { leafAddr = nodeAddr; nodeAddr = stack[sp]; sp--; }
+            if (!(leafAddr >= 0)) break;   // host: mask = leafAddr >= 0 (BVHTraversal.h:209-213)
+        }
+        while (leafAddr < 0 && !(stop && *stop)) {
+            found |= clb(~leafAddr);
+            leafAddr = nodeAddr;
+            if (nodeAddr < 0) { nodeAddr = stack[sp]; sp--; }
+        }
+    }
+    return found;
+}
+
+struct Scene {
+    ctl_scene_desc d;
+    bool half_host_quirk = false;   // reproduce half::ToFloat's host branch (Math/half.h:76-83)
+};
+
+// Kernel/TraceHelper.cu:88-180 (__traceRay_internal__<false> + traceRay).  any_hit/tmax generalise it to the
+// wavefront kernel's interface (TraceHelper.cu:326-734): a ctl_ray carries tmin in a.w and tmax in b.w.
+inline bool traceRay(const Scene& S, V3 ori, V3 dir, float tmin_tri, float tmax, bool any_hit, float node_tmin, Hit& res, TravCounts* cnt = nullptr) {
+    const ctl_scene_desc& g = S.d;
+    res.init(); res.dist = tmax;
+    if (!g.n_nodes) return false;
+    bool stop = false;
+    auto nodeClb = [&](int nodeIdx) -> bool {
+        if (stop) return false;
+        if (cnt) cnt->n_inst++;
+        const ctl_node& N = g.nodes[nodeIdx];
+        const ctl_kernel_mesh& mesh = g.meshes[N.mesh_index];
+        M44 modl; std::memcpy(modl.d, g.node_inv_transforms[nodeIdx].m, 64);
+        V3 d = transformDir(modl, dir), o = transformPoint(modl, ori);
+        auto triClb = [&](int triIdx) -> bool {
+            if (stop) return false;
+            bool found = false;
+            for (int triAddr = triIdx;; triAddr++) {
+                const ctl_woop_tri& w = g.woop[mesh.bvh_tri_offset / 3 + triAddr];
+                uint32_t index = g.woop_index[mesh.bvh_index_offset + triAddr].index;
+                if (cnt) cnt->n_tri++;
+                float t, u, v;
+                if (woopIntersect(w, o, d, tmin_tri, res.dist, t, u, v)) {
+                    res.node = nodeIdx; res.tri = (index >> 1) + mesh.tri_offset; res.u = u; res.v = v; res.dist = t;
+                    found = true;
+                    if (any_hit) { stop = true; break; }
+                }
+                if (index & 1) break;
+            }
+            return found;
+        };
+        return tracerayTemplate(o, d, res.dist, node_tmin, triClb, (const float*)g.bvh_nodes, mesh.bvh_node_offset, 0, cnt, &stop);
+    };
+    // any-hit: `stop` ends both levels as intersectKernel<true> does (TraceHelper.cu:684-688)
+    return tracerayTemplate(ori, dir, res.dist, node_tmin, nodeClb, (const float*)g.scene_bvh_nodes, 0, g.scene_start_node, cnt, &stop);
+}
+inline Hit traceRayClosest(const Scene& S, V3 ori, V3 dir) {   // traceRay(const Ray&) TraceHelper.h:31-37
+    Hit h; traceRay(S, ori, dir, S.d.ray_trace_eps, FLT_MAX, false, 0.0f, h); if (!h.hasHit()) h.dist = FLT_MAX; return h;
+}
+// Engine/KernelDynamicScene.cu:70-80
+inline bool occluded(const Scene& S, V3 o, V3 d, float tmin, float tmax) {
+    Hit r2 = traceRayClosest(S, o, d);
+    bool end = r2.dist < tmax - S.d.ray_trace_eps;
+    if (std::isinf(tmax) && !r2.hasHit()) end = false;
+    return r2.dist > tmin + S.d.ray_trace_eps && end;
+}
+
+// --------------------------------------------------------------------------- TriangleData / fillDG
+struct DG {   // Engine/DifferentialGeometry.h:11-47
+    V3 P; Frame sys; V3 n; V3 dpdu, dpdv; V2 uv; V2 bary; uint8_t extraData;
+};
+// Engine/TriangleData.cu:22-32 + 34-65
+inline void triDataSetUV(ctl_triangle_data& T, V2 a, V2 b, V2 c) {
+    auto pk = [](V2 v) { return (uint32_t)floatToHalf(v.x) | ((uint32_t)floatToHalf(v.y) << 16); };   // ushort2 {x,y} little endian
+    T.uv[0] = pk(a); T.uv[1] = pk(b); T.uv[2] = pk(c);
+}
+inline void triDataSetData(ctl_triangle_data& T, V3 v0, V3 v1, V3 v2, V3 n0, V3 n1, V3 n2, bool quirk = false) {
+    auto h = [&](uint32_t bits) { return halfToFloat((uint16_t)bits, quirk); };
+    V2 t0{ h(T.uv[0]), h(T.uv[0] >> 16) }, t1{ h(T.uv[1]), h(T.uv[1] >> 16) }, t2{ h(T.uv[2]), h(T.uv[2] >> 16) };
+    V3 dP1 = v1 - v0, dP2 = v2 - v0;
+    V2 dUV1{ t1.x - t0.x, t1.y - t0.y }, dUV2{ t2.x - t0.x, t2.y - t0.y };
+    float determinant = dUV1.x * dUV2.y - dUV1.y * dUV2.x;
+    V3 dpdu, dpdv;
+    if (determinant == 0) {
+        V3 a, b, n = normalize(cross(dP1, dP2));
+        coordinateSystem(n, a, b);
+        dpdu = a; dpdv = b;
+    } else {
+        float invDet = 1.0f / determinant;
+        dpdu = ((dUV2.y * dP1 - dUV1.y * dP2) * invDet);
+        dpdv = ((-dUV2.x * dP1 + dUV1.x * dP2) * invDet);
+    }
+    uint32_t ax = floatToHalf(dpdu.x), ay = floatToHalf(dpdu.y), az = floatToHalf(dpdu.z);
+    uint32_t bx = floatToHalf(dpdv.x), by = floatToHalf(dpdv.y), bz = floatToHalf(dpdv.z);
+    T.nor_mat_extra[0] = (uint32_t)normalToUchar2(n0) | ((uint32_t)normalToUchar2(n1) << 16);
+    T.nor_mat_extra[1] = (uint32_t)normalToUchar2(n2) | (T.nor_mat_extra[1] & 0xffff0000);
+    T.dpdu_dpdv[0] = ax | (ay << 16); T.dpdu_dpdv[1] = az | (bx << 16); T.dpdu_dpdv[2] = by | (bz << 16);
+}
+inline uint32_t triMatIndex(const ctl_triangle_data& T, uint32_t off) { return ((T.nor_mat_extra[1] >> 16) & 0xff) + off; }   // TriangleData.h:40-44
+// Engine/TriangleData.cu:75-103
+inline void triDataFillDG(const ctl_triangle_data& T, const M44& localToWorld, DG& dg, bool quirk) {
+    auto h = [&](uint32_t bits) { return halfToFloat((uint16_t)bits, quirk); };
+    V3 na = uchar2ToNormal((uint16_t)T.nor_mat_extra[0]), nb = uchar2ToNormal((uint16_t)(T.nor_mat_extra[0] >> 16)), nc = uchar2ToNormal((uint16_t)T.nor_mat_extra[1]);
+    float w = 1.0f - dg.bary.x - dg.bary.y, u = dg.bary.x, v = dg.bary.y;
+    V3 n = normalize(u * na + v * nb + w * nc);
+    const uint32_t* dpd = T.dpdu_dpdv;
+    V3 dpdu(h(dpd[0]), h(dpd[0] >> 16), h(dpd[1]));
+    V3 dpdv(h(dpd[1] >> 16), h(dpd[2]), h(dpd[2] >> 16));
+    V3 s = dpdu - n * dot(n, dpdu);
+    V3 t = cross(s, n);
+    s = transformDir(localToWorld, s); t = transformDir(localToWorld, t);
+    dg.sys = Frame(normalize(s), normalize(t), normalize(cross(t, s)));
+    dg.dpdu = transformDir(localToWorld, dpdu);
+    dg.dpdv = transformDir(localToWorld, dpdv);
+    dg.n = normalize(cross(dg.dpdu, dg.dpdv));
+    V2 ta{ h(T.uv[0]), h(T.uv[0] >> 16) }, tb{ h(T.uv[1]), h(T.uv[1] >> 16) }, tc{ h(T.uv[2]), h(T.uv[2] >> 16) };
+    dg.uv = V2{ u * ta.x + v * tb.x + w * tc.x, u * ta.y + v * tb.y + w * tc.y };
+    dg.extraData = (uint8_t)(T.nor_mat_extra[1] >> 24);
+    if (dot(dg.n, dg.sys.n) < 0.0f) dg.n = -dg.n;
+}
+// Kernel/TraceHelper.cu:274-307 (host branch)
+inline void fillDG(const Scene& S, V2 bary, uint32_t triIdx, uint32_t nodeIdx, DG& dg) {
+    M44 l2w; std::memcpy(l2w.d, S.d.node_transforms[nodeIdx].m, 64);
+    dg.bary = bary;
+    triDataFillDG(S.d.tri_data[triIdx], l2w, dg, S.half_host_quirk);
+}
+
+// --------------------------------------------------------------------------- textures (SceneTypes/Texture.h, constant only + checker)
+inline Spec texEval(const ctl_texture& t, const DG& dg) {
+    if (t.type == CTL_TEX_CHECKER) {
+        float u = dg.uv.x * t.uv_scale[0] + t.uv_offset[0], v = dg.uv.y * t.uv_scale[1] + t.uv_offset[1];
+        auto modulo = [](int a, int b) { int r = a % b; return (r < 0) ? r + b : r; };   // MathFunc.h:120-124
+        int x = 2 * modulo((int)(u * 2), 2) - 1, y = 2 * modulo((int)(v * 2), 2) - 1;      // Texture.h:136-146
+        return (x * y == 1) ? Spec(t.value[0], t.value[1], t.value[2]) : Spec(t.value1[0], t.value1[1], t.value1[2]);
+    }
+    return Spec(t.value[0], t.value[1], t.value[2]);
+}
+
+// --------------------------------------------------------------------------- sampler (Kernel/Sampler_device.h:59-113)
+struct Sampler {
+    const float* t1; const float* t2; unsigned idx; unsigned d1 = 0, d2 = 0;
+    Sampler(const float* a, const float* b, unsigned i) : t1(a), t2(b), idx(i) {}
+    float randomFloat() {
+        unsigned e = d1 % CTL_SAMPLER_SEQUENCE_LENGTH, f = idx; float val = 0.0f;
+        for (int i = 0; i < 2; i++) { val += t1[e * CTL_SAMPLER_NUM_SEQUENCES + f % CTL_SAMPLER_NUM_SEQUENCES]; f /= CTL_SAMPLER_NUM_SEQUENCES; }
+        d1++; return fracf(val);
+    }
+    V2 randomFloat2() {
+        unsigned e = d2 % CTL_SAMPLER_SEQUENCE_LENGTH, f = idx; float vx = 0.0f, vy = 0.0f;
+        for (int i = 0; i < 2; i++) { const float* p = t2 + 2 * (e * CTL_SAMPLER_NUM_SEQUENCES + f % CTL_SAMPLER_NUM_SEQUENCES); vx += p[0]; vy += p[1]; f /= CTL_SAMPLER_NUM_SEQUENCES; }
+        d2++; return V2{ fracf(vx), fracf(vy) };
+    }
+    void skip(unsigned off) { d1 += off; d2 += off; }
+};
+
+// --------------------------------------------------------------------------- sensor (SceneTypes/Sensor.cu:76-128)
+struct PerspectiveSensor {
+    M44 toWorld, sampleToCamera; V2 invRes; V3 dx, dy;
+    void update(const ctl_sensor& s) {
+        std::memcpy(toWorld.d, s.to_world, 64);
+        float aspect = s.resolution[0] / s.resolution[1];
+        invRes = V2{ 1.0f / s.resolution[0], 1.0f / s.resolution[1] };
+        M44 c2s = mul(mul(scaleM(V3(-0.5f, -0.5f * aspect, 1.0f)), translateM(V3(-1.0f, -1.0f / aspect, 0.0f))), perspective(s.fov, s.near_depth, s.far_depth));
+        sampleToCamera = inverse(c2s);
+        dx = transformPoint(sampleToCamera, V3(invRes.x, 0.0f, 0.0f)) - transformPoint(sampleToCamera, V3(0.0f));
+        dy = transformPoint(sampleToCamera, V3(0.0f, invRes.y, 0.0f)) - transformPoint(sampleToCamera, V3(0.0f));
+    }
+    // Sensor.cu:116-128
+    void sampleRay(V2 pixelSample, V3& o, V3& d) const {
+        V3 nearP = transformPoint(sampleToCamera, V3(pixelSample.x * invRes.x, pixelSample.y * invRes.y, 0.0f));
+        V3 dn = normalize(nearP);
+        o = transformPoint(toWorld, V3(0.0f));   // toWorld.Translation() (float4x4.h:93-96)
+        d = transformDir(toWorld, dn);
+    }
+};
+
+// --------------------------------------------------------------------------- records (SceneTypes/Samples.h)
+enum EMeasure { EInvalidMeasure = 0, ESolidAngle = 1, ELength = 2, EArea = 3, EDiscrete = 4 };
+enum { EReflection = 0x2 | 0x20 | 0x80 | 0x8, EDiffuse = 0x2 | 0x4, EGlossy = 0x8 | 0x10, ESmooth = 0x2 | 0x4 | 0x8 | 0x10,
+       EDelta = 0x1 | 0x20 | 0x40, EDelta1D = 0x80 | 0x100, EAll = ESmooth | EDelta | EDelta1D };
+struct DirectRec {   // DirectSamplingRecord (Samples.h:133-149)
+    V3 p, n; float pdf; int measure; V2 uv; V3 ref, refN, d; float dist;
+    DirectRec() {}
+    DirectRec(V3 p_, V3 n_) : p(p_), n(n_), measure(EArea), ref(p_), refN(n_) {}
+};
+struct BRec {   // BSDFSamplingRecord (Samples.h:173-190)
+    DG dg; V3 wi, wo; float eta; unsigned typeMask, sampledType;
+};
+
+// --------------------------------------------------------------------------- lights
+// Math/MonteCarlo.cu:7-14 (STL_lower_bound = first element not less than `sample`)
+inline unsigned sampleReuse(const float* cdf, unsigned size, float& sample, float& pdf) {
+    const float* entry = std::lower_bound(cdf, cdf + size + 1, sample);
+    unsigned index = (unsigned)std::min(std::max(0, int(entry - cdf) - 1), int(size - 1));
+    pdf = cdf[index + 1] - cdf[index];
+    sample = (sample - cdf[index]) / pdf;
+    return index;
+}
+// Engine/ShapeSet.cu:51-69
+inline void shapeSamplePosition(const Scene& S, const ctl_light& L, DirectRec& pRec, V2 spatialSample) {
+    const float* areaDistribution = (const float*)(S.d.anim + L.area_dist_index);
+    const ctl_shape_tri* triangles = (const ctl_shape_tri*)(S.d.anim + L.triangles_index);
+    float pdf; V2 sample = spatialSample;
+    unsigned index = sampleReuse(areaDistribution, L.count, sample.y, pdf);
+    const ctl_shape_tri& sn = triangles[index];
+    V2 bary = squareToUniformTriangle(sample);
+    V3 p0(sn.p[0][0], sn.p[0][1], sn.p[0][2]), p1(sn.p[1][0], sn.p[1][1], sn.p[1][2]), p2(sn.p[2][0], sn.p[2][1], sn.p[2][2]);
+    pRec.p = bary.x * p0 + bary.y * p1 + (1.f - bary.x - bary.y) * p2;
+    pRec.n = V3(sn.n[0], sn.n[1], sn.n[2]);
+    pRec.pdf = 1.0f / L.sum_area;
+    pRec.measure = EArea;
+    pRec.uv = bary;
+}
+// SceneTypes/Light.cu:83-137 (m_bOrthogonal == false branch) and :13-31 (point)
+inline Spec lightSampleDirect(const Scene& S, const ctl_light& L, DirectRec& dRec, V2 sample) {
+    if (L.type == CTL_LIGHT_POINT) {
+        dRec.p = V3(L.position[0], L.position[1], L.position[2]);
+        V3 dir = dRec.p - dRec.ref;
+        dRec.dist = length(dir);
+        float invDist = 1.0f / dRec.dist;
+        dRec.d = dir * invDist; dRec.n = V3(0.0f); dRec.pdf = 1; dRec.measure = EDiscrete; dRec.uv = V2{ 0.5f, 0.5f };
+        return Spec(L.radiance[0], L.radiance[1], L.radiance[2]) * (invDist * invDist);
+    }
+    shapeSamplePosition(S, L, dRec, sample);
+    V3 dir = dRec.p - dRec.ref;
+    float distSquared = lenSqr(dir);
+    dRec.dist = std::sqrt(distSquared);
+    dRec.d = dir / dRec.dist;
+    float dp = absdot(dRec.d, dRec.n);
+    dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+    dRec.measure = ESolidAngle;
+    if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0)
+        return Spec(L.radiance[0], L.radiance[1], L.radiance[2]) / dRec.pdf * 1.0f;
+    dRec.pdf = 0.0f;
+    return Spec(0.0f);
+}
+// SceneTypes/Light.cu:139-159
+inline float lightPdfDirect(const ctl_light& L, const DirectRec& dRec) {
+    if (L.type == CTL_LIGHT_POINT) return dRec.measure == EDiscrete ? 1.0f : 0.0f;
+    if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
+        float pdfPos = 1.0f / L.sum_area;
+        if (dRec.measure == ESolidAngle) return pdfPos * (dRec.dist * dRec.dist) / absdot(dRec.d, dRec.n);
+        else if (dRec.measure == EArea) return pdfPos;
+        else return 0.0f;
+    }
+    return 0.0f;
+}
+// SceneTypes/Light.cu:67-81
+inline Spec lightEval(const ctl_light& L, const Frame& sys, V3 d) {
+    if (L.type != CTL_LIGHT_DIFFUSE) return Spec(0.0f);
+    if (dot(sys.n, d) <= 0) return Spec(0.0f);
+    return Spec(L.radiance[0], L.radiance[1], L.radiance[2]);
+}
+// Engine/KernelDynamicScene.cu:25-46
+inline const ctl_light* sampleEmitter(const Scene& S, float& emPdf, V2& sample) {
+    const ctl_scene_desc& g = S.d;
+    if (g.num_lights == 0) return nullptr;
+    unsigned idx = (unsigned)(std::upper_bound(g.light_cdf, g.light_cdf + g.num_lights, sample.x) - g.light_cdf);
+    if (idx >= g.num_lights) idx = g.num_lights - 1;
+    float fU = g.light_cdf[idx], fL = idx > 0 ? g.light_cdf[idx - 1] : 0.0f;
+    sample.x = (sample.x - fL) / (fU - fL);
+    emPdf = fU - fL;
+    return g.lights + g.light_indices[idx];
+}
+inline float pdfEmitter(const Scene& S, const ctl_light* L) {
+    unsigned idx = (unsigned)(L - S.d.lights);
+    return S.d.light_cdf[idx] - (idx == 0 ? 0.0f : S.d.light_cdf[idx - 1]);
+}
+
+// --------------------------------------------------------------------------- microfacet (Engine/MicrofacetDistribution.{h,cu})
+struct Microfacet {
+    int type; float alphaU, alphaV; bool sampleVis; float expU = 0, expV = 0;
+    Microfacet(int t, float aU, float aV, bool sv) : type(t), alphaU(fmax2(aU, 1e-4f)), alphaV(fmax2(aV, 1e-4f)), sampleVis(sv) {
+        if (type == CTL_MF_PHONG) { expU = fmax2(2.0f / (alphaU * alphaU) - 2.0f, 0.0f); expV = fmax2(2.0f / (alphaV * alphaV) - 2.0f, 0.0f); }
+    }
+    bool isIso() const { return alphaU == alphaV; }
+    float interpPhongExp(V3 v) const {   // MicrofacetDistribution.h interpolatePhongExponent
+        const float sinTheta2 = Frame::sinTheta2(v);
+        if (isIso() || sinTheta2 <= 2.93873587705571876e-39f /*RCPOVERFLOW*/) return expU;
+        float invSinTheta2 = 1 / sinTheta2, cosPhi2 = v.x * v.x * invSinTheta2, sinPhi2 = v.y * v.y * invSinTheta2;
+        return expU * cosPhi2 + expV * sinPhi2;
+    }
+    float eval(V3 m) const {   // MicrofacetDistribution.cu:6-42
+        if (Frame::cosTheta(m) <= 0) return 0.0f;
+        float cosTheta2 = m.z * m.z;
+        float beckmannExponent = ((m.x * m.x) / (alphaU * alphaU) + (m.y * m.y) / (alphaV * alphaV)) / cosTheta2;
+        float result;
+        if (type == CTL_MF_BECKMANN) result = expf(-beckmannExponent) / (PI * alphaU * alphaV * cosTheta2 * cosTheta2);
+        else if (type == CTL_MF_GGX) { float root = (1 + beckmannExponent) * cosTheta2; result = 1.0f / (PI * alphaU * alphaV * root * root); }
+        else { float e = interpPhongExp(m); result = std::sqrt((expU + 2) * (expV + 2)) * INV_TWOPI * powf(Frame::cosTheta(m), e); }
+        if (result < 1e-20f) result = 0;
+        return result;
+    }
+    float projectRoughness(V3 v) const {
+        float invSinTheta2 = 1 / Frame::sinTheta2(v);
+        if (isIso() || invSinTheta2 <= 0) return alphaU;
+        float cosPhi2 = v.x * v.x * invSinTheta2, sinPhi2 = v.y * v.y * invSinTheta2;
+        return std::sqrt(cosPhi2 * alphaU * alphaU + sinPhi2 * alphaV * alphaV);
+    }
+    float smithG1(V3 v, V3 m) const {   // MicrofacetDistribution.cu:309-343
+        if (dot(v, m) * Frame::cosTheta(v) <= 0) return 0.0f;
+        const float tanTheta = fabsf(Frame::tanTheta(v));
+        if (tanTheta == 0.0f) return 1.0f;
+        float alpha = projectRoughness(v);
+        if (type == CTL_MF_GGX) { const float root = alpha * tanTheta; return 2.0f / (1.0f + std::sqrt(1.0f * 1.0f + root * root)); }
+        float a = 1.0f / (alpha * tanTheta);
+        if (a >= 1.6f) return 1.0f;
+        float aSqr = a * a;
+        return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+    }
+    float G(V3 wi, V3 wo, V3 m) const { return smithG1(wi, m) * smithG1(wo, m); }
+    float pdfVisible(V3 wi, V3 m) const { if (Frame::cosTheta(wi) == 0) return 0.0f; return smithG1(wi, m) * absdot(wi, m) * eval(m) / fabsf(Frame::cosTheta(wi)); }
+    float pdfAll(V3 m) const { return eval(m) * Frame::cosTheta(m); }
+    float pdf(V3 wi, V3 m) const { return sampleVis ? pdfVisible(wi, m) : pdfAll(m); }
+    V3 sampleAll(V2 sample, float& pdf) const {   // MicrofacetDistribution.cu:44-149 (Beckmann / GGX)
+        float cosThetaM = 0.0f, sinPhiM, cosPhiM, alphaSqr;
+        if (isIso()) { float a = (2.0f * PI) * sample.y; sinPhiM = sinf(a); cosPhiM = cosf(a); alphaSqr = alphaU * alphaU; }
+        else {
+            float phiM = atanf(alphaV / alphaU * tanf(PI + 2 * PI * sample.y)) + PI * floorf(2 * sample.y + 0.5f);
+            sinPhiM = sinf(phiM); cosPhiM = cosf(phiM);
+            float cosSc = cosPhiM / alphaU, sinSc = sinPhiM / alphaV;
+            alphaSqr = 1.0f / (cosSc * cosSc + sinSc * sinSc);
+        }
+        if (type == CTL_MF_BECKMANN) {
+            float tanThetaMSqr = alphaSqr * -logf(1.0f - sample.x);
+            cosThetaM = 1.0f / std::sqrt(1.0f + tanThetaMSqr);
+            pdf = (1.0f - sample.x) / (PI * alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM);
+        } else {
+            float tanThetaMSqr = alphaSqr * sample.x / (1.0f - sample.x);
+            cosThetaM = 1.0f / std::sqrt(1.0f + tanThetaMSqr);
+            float temp = 1 + tanThetaMSqr / alphaSqr;
+            pdf = INV_PI / (alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM * temp * temp);
+        }
+        if (pdf < 1e-20f) pdf = 0;
+        float sinThetaM = std::sqrt(fmax2(0.0f, 1 - cosThetaM * cosThetaM));
+        return V3(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
+    }
+    V2 sampleVisible11(float thetaI, V2 sample) const {   // MicrofacetDistribution.cu:185-307 (GGX branch)
+        V2 slope;
+        if (thetaI < 1e-4f) {
+            float r = safe_sqrt(sample.x / (1 - sample.x)); float a = 2 * PI * sample.y;
+            return V2{ r * cosf(a), r * sinf(a) };
+        }
+        float tanThetaI = tanf(thetaI);
+        float a = 1 / tanThetaI;
+        float G1 = 2.0f / (1.0f + safe_sqrt(1.0f + 1.0f / (a * a)));
+        float A = 2.0f * sample.x / G1 - 1.0f;
+        if (fabsf(A) == 1) A -= copysign_bits(1.0f, A) * 1e-7f;
+        float tmp = 1.0f / (A * A - 1.0f);
+        float B = tanThetaI;
+        float D = safe_sqrt(B * B * tmp * tmp - (A * A - B * B) * tmp);
+        float slope_x_1 = B * tmp - D, slope_x_2 = B * tmp + D;
+        slope.x = (A < 0.0f || slope_x_2 > 1.0f / tanThetaI) ? slope_x_1 : slope_x_2;
+        float Sg;
+        if (sample.y > 0.5f) { Sg = 1.0f; sample.y = 2.0f * (sample.y - 0.5f); }
+        else { Sg = -1.0f; sample.y = 2.0f * (0.5f - sample.y); }
+        float z = (sample.y * (sample.y * (sample.y * (-0.365728915865723f) + 0.790235037209296f) - 0.424965825137544f) + 0.000152998850436920f) /
+                  (sample.y * (sample.y * (sample.y * (sample.y * 0.169507819808272f - 0.397203533833404f) - 0.232500544458471f) + 1.0f) - 0.539825872510702f);
+        slope.y = Sg * z * std::sqrt(1.0f + slope.x * slope.x);
+        return slope;
+    }
+    V3 sampleVisible(V3 _wi, V2 sample) const {   // MicrofacetDistribution.cu:151-183
+        V3 wi = normalize(V3(alphaU * _wi.x, alphaV * _wi.y, _wi.z));
+        float theta = 0, phi = 0;
+        if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
+        float sinPhi = sinf(phi), cosPhi = cosf(phi);
+        V2 slope = sampleVisible11(theta, sample);
+        slope = V2{ cosPhi * slope.x - sinPhi * slope.y, sinPhi * slope.x + cosPhi * slope.y };
+        slope.x *= alphaU; slope.y *= alphaV;
+        float normalization = 1.0f / std::sqrt(slope.x * slope.x + slope.y * slope.y + (float)1.0);
+        return V3(-slope.x * normalization, -slope.y * normalization, normalization);
+    }
+    V3 sample(V3 wi, V2 s, float& pdf) const {
+        if (sampleVis) { V3 m = sampleVisible(wi, s); pdf = pdfVisible(wi, m); return m; }
+        return sampleAll(s, pdf);
+    }
+};
+inline V3 reflectAbout(V3 wi, V3 n) { return normalize(2 * dot(wi, n) * n - wi); }   // FresnelHelper.h:148-151
+inline float avg3(Spec s) { float r = 0.0f; r += s.x; r += s.y; r += s.z; return r * (1.0f / 3); }   // Spectrum.h:180-190
+
+// --------------------------------------------------------------------------- BSDFs (SceneTypes/BSDF_Simple.cu)
+inline bool bsdfHasComponent(const ctl_material& M, unsigned type) { return (type & M.combined_type) != 0; }
+
+inline Spec bsdfSample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sample) {
+    switch (M.bsdf_type) {
+    case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:7-36
+        unsigned ct = M.combined_type;
+        if (!(bRec.typeMask & ct) || (ct == CTL_EDiffuseReflection && Frame::cosTheta(bRec.wi) <= 0)) return Spec(0.0f);
+        V2 sample = _sample;
+        bRec.sampledType = ct;
+        float sc = 1;
+        if (ct == (CTL_EDiffuseReflection | CTL_EDiffuseTransmission)) {
+            bRec.sampledType = sample.x < 0.5f ? CTL_EDiffuseReflection : CTL_EDiffuseTransmission;
+            sample.x = sample.x < 0.5f ? sample.x * 2 : (sample.x - 0.5f) * 2;
+            sc = 0.5f;
+        }
+        bRec.wo = squareToCosineHemisphere(sample);
+        if ((ct == CTL_EDiffuseTransmission || (ct == (CTL_EDiffuseReflection | CTL_EDiffuseTransmission) && bRec.sampledType == CTL_EDiffuseTransmission)) && Frame::cosTheta(bRec.wi) > 0)
+            bRec.wo.z *= -1;
+        bRec.eta = 1.0f;
+        pdf = fabsf(squareToCosineHemispherePdf(bRec.wo)) * sc;
+        return texEval(M.tex[0], bRec.dg) * sc;
+    }
+    case CTL_BSDF_DIELECTRIC: {   // BSDF_Simple.cu:174-224 ; Dispersion.h sample_eta without dispersion -> eta = B + C/0.6
+        bool sampleReflection = (bRec.typeMask & CTL_EDeltaReflection) != 0, sampleTransmission = (bRec.typeMask & CTL_EDeltaTransmission) != 0;
+        Spec f_o(1.0f); float eta_pdf = 1.0f;
+        float cosThetaT, eta = M.f[0] + M.f[1] / (600 / 1e3f), invEta = 1.0f / eta;
+        float F = fresnelDielectricExt(Frame::cosTheta(bRec.wi), cosThetaT, eta);
+        if (sampleTransmission && sampleReflection) {
+            if (_sample.x <= F) {
+                bRec.sampledType = CTL_EDeltaReflection; bRec.wo = Frame::reflect(bRec.wi); bRec.eta = 1.0f; pdf = F;
+                return texEval(M.tex[1], bRec.dg);
+            } else {
+                bRec.sampledType = CTL_EDeltaTransmission; bRec.wo = Frame::refract(bRec.wi, cosThetaT, eta, invEta);
+                bRec.eta = cosThetaT < 0 ? eta : invEta; pdf = (1 - F) * eta_pdf;
+                float factor = (cosThetaT < 0 ? invEta : eta);   // mode == ERadiance
+                return f_o * texEval(M.tex[0], bRec.dg) * (factor * factor);
+            }
+        } else if (sampleReflection) {
+            bRec.sampledType = CTL_EDeltaReflection; bRec.wo = Frame::reflect(bRec.wi); bRec.eta = 1.0f; pdf = 1.0f;
+            return texEval(M.tex[1], bRec.dg);
+        } else if (sampleTransmission) {
+            bRec.sampledType = CTL_EDeltaTransmission; bRec.wo = Frame::refract(bRec.wi, cosThetaT, eta, invEta);
+            bRec.eta = cosThetaT < 0 ? eta : invEta; pdf = 1.0f * eta_pdf;
+            float factor = (cosThetaT < 0 ? invEta : eta);
+            return f_o * texEval(M.tex[0], bRec.dg) * (factor * factor * (1 - F));
+        }
+        return Spec(0.0f);
+    }
+    case CTL_BSDF_CONDUCTOR: {   // BSDF_Simple.cu:617-630
+        bool sampleReflection = (bRec.typeMask & CTL_EDeltaReflection) != 0;
+        if (!sampleReflection || Frame::cosTheta(bRec.wi) <= 0) return Spec(0.0f);
+        bRec.sampledType = CTL_EDeltaReflection; bRec.wo = Frame::reflect(bRec.wi); bRec.eta = 1.0f; pdf = 1;
+        return texEval(M.tex[0], bRec.dg) * fresnelConductorExact(Frame::cosTheta(bRec.wi), Spec(M.f[0], M.f[1], M.f[2]), Spec(M.f[3], M.f[4], M.f[5]));
+    }
+    case CTL_BSDF_ROUGHCONDUCTOR: {   // BSDF_Simple.cu:662-705
+        if (Frame::cosTheta(bRec.wi) < 0 || !(bRec.typeMask & CTL_EGlossyReflection)) return Spec(0.0f);
+        Microfacet distr((int)M.u[0], avg3(texEval(M.tex[1], bRec.dg)), avg3(texEval(M.tex[2], bRec.dg)), M.u[1] != 0);
+        const V3 m = distr.sample(bRec.wi, _sample, pdf);
+        if (pdf == 0) return Spec(0.0f);
+        bRec.wo = reflectAbout(bRec.wi, m); bRec.eta = 1.0f; bRec.sampledType = CTL_EGlossyReflection;
+        if (Frame::cosTheta(bRec.wo) <= 0) return Spec(0.0f);
+        const Spec F = fresnelConductorExact(dot(bRec.wi, m), Spec(M.f[0], M.f[1], M.f[2]), Spec(M.f[3], M.f[4], M.f[5])) * texEval(M.tex[0], bRec.dg);
+        float weight;
+        if (distr.sampleVis) weight = distr.smithG1(bRec.wo, m);
+        else weight = distr.eval(m) * distr.G(bRec.wi, bRec.wo, m) * dot(bRec.wi, m) / (pdf * Frame::cosTheta(bRec.wi));
+        pdf /= 4.0f * dot(bRec.wo, m);
+        return F * weight;
+    }
+    default: throw std::runtime_error("oracle: bsdf type not restated");
+    }
+}
+
+inline Spec bsdfF(const ctl_material& M, const BRec& bRec, int measure = ESolidAngle) {
+    switch (M.bsdf_type) {
+    case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:38-56
+        unsigned ct = M.combined_type;
+        if (!(bRec.typeMask & ct) || measure != ESolidAngle) return Spec(0.0f);
+        bool validRefl = ct == CTL_EDiffuseReflection && Frame::cosTheta(bRec.wi) > 0 && Frame::cosTheta(bRec.wo) > 0;
+        bool validTrans = ct == CTL_EDiffuseTransmission && Frame::cosTheta(bRec.wi) * Frame::cosTheta(bRec.wo) < 0;
+        Spec s = texEval(M.tex[0], bRec.dg) * (INV_PI * fabsf(Frame::cosTheta(bRec.wo)));
+        if (validRefl || validTrans) return s;
+        else if (ct == (CTL_EDiffuseReflection | CTL_EDiffuseTransmission)) return s * 0.5f;
+        return Spec(0.0f);
+    }
+    case CTL_BSDF_DIELECTRIC: case CTL_BSDF_CONDUCTOR:
+        return Spec(0.0f);   // measure == ESolidAngle on every call site of the path (BSDF_Simple.cu:226-252, 632-646)
+    case CTL_BSDF_ROUGHCONDUCTOR: {   // BSDF_Simple.cu:707-740
+        if (measure != ESolidAngle || Frame::cosTheta(bRec.wi) < 0 || Frame::cosTheta(bRec.wo) < 0 || !(bRec.typeMask & CTL_EGlossyReflection)) return Spec(0.0f);
+        V3 H = normalize(bRec.wo + bRec.wi);
+        Microfacet distr((int)M.u[0], avg3(texEval(M.tex[1], bRec.dg)), avg3(texEval(M.tex[2], bRec.dg)), M.u[1] != 0);
+        const float D = distr.eval(H);
+        if (D == 0) return Spec(0.0f);
+        const Spec F = fresnelConductorExact(dot(bRec.wi, H), Spec(M.f[0], M.f[1], M.f[2]), Spec(M.f[3], M.f[4], M.f[5])) * texEval(M.tex[0], bRec.dg);
+        const float G = distr.G(bRec.wi, bRec.wo, H);
+        float value = D * G / (4.0f * Frame::cosTheta(bRec.wi));
+        return F * value;
+    }
+    default: throw std::runtime_error("oracle: bsdf type not restated");
+    }
+}
+
+inline float bsdfPdf(const ctl_material& M, const BRec& bRec, int measure = ESolidAngle) {
+    switch (M.bsdf_type) {
+    case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:58-75
+        unsigned ct = M.combined_type;
+        if (!(bRec.typeMask & ct) || measure != ESolidAngle) return 0.0f;
+        bool validRefl = ct == CTL_EDiffuseReflection && Frame::cosTheta(bRec.wi) > 0 && Frame::cosTheta(bRec.wo) > 0;
+        bool validTrans = ct == CTL_EDiffuseTransmission && Frame::cosTheta(bRec.wi) * Frame::cosTheta(bRec.wo) < 0;
+        float f = fabsf(squareToCosineHemispherePdf(bRec.wo));
+        if (validRefl || validTrans) return f;
+        else if (ct == (CTL_EDiffuseReflection | CTL_EDiffuseTransmission)) return f * 0.5f;
+        return 0.0f;
+    }
+    case CTL_BSDF_DIELECTRIC: case CTL_BSDF_CONDUCTOR: return 0.0f;
+    case CTL_BSDF_ROUGHCONDUCTOR: {   // BSDF_Simple.cu:742-763
+        if (measure != ESolidAngle || Frame::cosTheta(bRec.wi) < 0 || Frame::cosTheta(bRec.wo) < 0 || !(bRec.typeMask & CTL_EGlossyReflection)) return 0.0f;
+        V3 H = normalize(bRec.wo + bRec.wi);
+        Microfacet distr((int)M.u[0], avg3(texEval(M.tex[1], bRec.dg)), avg3(texEval(M.tex[2], bRec.dg)), M.u[1] != 0);
+        if (distr.sampleVis) return distr.eval(H) * distr.smithG1(bRec.wi, H) / (4.0f * Frame::cosTheta(bRec.wi));
+        return distr.pdf(bRec.wi, H) / (4 * absdot(bRec.wo, H));
+    }
+    default: throw std::runtime_error("oracle: bsdf type not restated");
+    }
+}
+
+// --------------------------------------------------------------------------- hit -> material / bRec (Kernel/TraceResult.cu)
+inline const ctl_material& hitMat(const Scene& S, const Hit& h) {   // TraceResult.cu:67-86
+    return S.d.materials[triMatIndex(S.d.tri_data[h.tri], S.d.nodes[h.node].material_offset)];
+}
+inline uint32_t hitLightIndex(const Scene& S, const Hit& h) {        // TraceResult.cu:52-58
+    uint32_t nli = hitMat(S, h).node_light_index;
+    if (nli == UINT32_MAX) return UINT32_MAX;
+    return S.d.nodes[h.node].lights[nli];
+}
+// TraceResult.cu:11-43 (no normal map in the descriptor set of this round)
+inline void getBsdfSample(const Scene& S, const Hit& h, V3 rayO, V3 rayD, BRec& bRec) {
+    bRec.eta = 1.0f; bRec.sampledType = 0; bRec.typeMask = EAll;
+    bRec.dg.P = rayO + rayD * h.dist;   // Ray::operator()(t) (Math/Ray.h)
+    fillDG(S, V2{ h.u, h.v }, h.tri, h.node, bRec.dg);
+    bRec.wi = bRec.dg.sys.toLocal(-rayD);
+    if (hitMat(S, h).two_sided && bRec.wi.z < 0) {
+        bRec.dg.n = -bRec.dg.n; bRec.dg.sys.n = -bRec.dg.sys.n; bRec.wi.z *= -1.0f;
+    }
+}
+
+// --------------------------------------------------------------------------- direct lighting (Kernel/TraceAlgorithms.cu:44-101)
+inline Spec estimateDirect(const Scene& S, BRec bRec, const ctl_material& mat, const ctl_light* light, float light_pdf, unsigned flags, Sampler& rng, uint64_t* rays) {
+    DirectRec dRec(bRec.dg.P, bRec.dg.sys.n);
+    Spec value = lightSampleDirect(S, *light, dRec, rng.randomFloat2());
+    Spec retVal(0.0f);
+    if (!isZero(value)) {
+        bRec.wo = bRec.dg.sys.toLocal(dRec.d);
+        bRec.typeMask = flags;
+        Spec bsdfVal = bsdfF(mat, bRec);
+        if (!isZero(bsdfVal)) {
+            if (rays) (*rays)++;
+            if (!occluded(S, dRec.ref, dRec.d, 0, dRec.dist)) {
+                float weight = 1.0f;
+                if (dRec.measure != EDiscrete) {
+                    const float bsdfPdf_ = bsdfPdf(mat, bRec);
+                    const float directPdf = (dRec.measure == EArea ? dRec.pdf * dRec.dist / fabsf(dot(dRec.n, dRec.d)) : dRec.pdf) * light_pdf;
+                    weight = powerHeuristic(1, directPdf, 1, bsdfPdf_);
+                }
+                retVal = value * bsdfVal * weight;
+            }
+        }
+    }
+    return retVal;
+}
+inline Spec uniformSampleOneLight(const Scene& S, const BRec& bRec, const ctl_material& mat, Sampler& rng, uint64_t* rays) {
+    if (!S.d.num_lights) return Spec(0.0f);
+    V2 sample = rng.randomFloat2();
+    float pdf;
+    const ctl_light* light = sampleEmitter(S, pdf, sample);
+    if (light == nullptr) return Spec(0.0f);
+    return estimateDirect(S, bRec, mat, light, pdf, EAll & ~EDelta, rng, rays) / pdf;
+}
+
+// --------------------------------------------------------------------------- PathTrace<DIRECT> (Integrators/PathTracer.cu:10-113), no volumes
+inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, int maxPathLength, int rrStartDepth, uint64_t* rays) {
+    Spec cl(0.0f), cf(1.0f);
+    int depth = 0; bool specularBounce = false;
+    BRec bRec; Hit r2; r2.init();
+    float brdf_scattering_pdf = 0; V3 last_nor;
+    while (depth++ < maxPathLength) {
+        r2 = traceRayClosest(S, ro, rd);
+        if (rays) (*rays)++;
+        if (r2.hasHit()) {
+            getBsdfSample(S, r2, ro, rd, bRec);
+            const ctl_material& mat = hitMat(S, r2);
+            uint32_t li = hitLightIndex(S, r2);
+            if (li != UINT32_MAX) {
+                float misWeight = 1.0f;
+                if (!DIRECT || depth == 1 || specularBounce) misWeight = 1.0f;
+                else {
+                    DirectRec dRec(ro, last_nor);   // DirectSamplingRecFromRay (TraceAlgorithms.cu:33-42)
+                    dRec.p = bRec.dg.P; dRec.n = bRec.dg.n; dRec.d = rd; dRec.dist = r2.dist; dRec.measure = ESolidAngle;
+                    const ctl_light* light = S.d.lights + li;
+                    float direct_pdf = lightPdfDirect(*light, dRec) * pdfEmitter(S, light);
+                    misWeight = powerHeuristic(1, brdf_scattering_pdf, 1, direct_pdf);
+                }
+                cl = cl + misWeight * cf * lightEval(S.d.lights[li], bRec.dg.sys, -rd);
+            }
+            Spec f = bsdfSample(mat, bRec, brdf_scattering_pdf, rnd.randomFloat2());
+            last_nor = bRec.dg.sys.n;
+            if (DIRECT && bsdfHasComponent(mat, ESmooth)) cl = cl + cf * uniformSampleOneLight(S, bRec, mat, rnd, rays);
+            specularBounce = (bRec.sampledType & EDelta) != 0;
+            cf = cf * f;
+            ro = bRec.dg.P; rd = bRec.dg.sys.toWorld(bRec.wo);   // BSDFSamplingRecord::getOutgoing (Samples.cu)
+        }
+        if (!r2.hasHit()) break;
+        if (depth > rrStartDepth && !specularBounce) {
+            if (rnd.randomFloat() >= vmax(cf)) break;
+            cf = cf / vmax(cf);
+        }
+    }
+    // miss: no environment map support in this round's descriptor set -> EvalEnvironment == 0 (KernelDynamicScene.cu:48-55)
+    return cl;
+}
+
+// Engine/Image.cu:22-44 (host branch)
+inline void addSample(ctl_pixel_data* img, int W, int H, float sx, float sy, Spec L) {
+    L = V3(fmax2(L.x, 0.0f), fmax2(L.y, 0.0f), fmax2(L.z, 0.0f));   // Spectrum::clampNegative
+    int x = floor2int(sx), y = floor2int(sy);
+    bool bad = std::isnan(L.x) || std::isnan(L.y) || std::isnan(L.z) || std::isinf(L.x) || std::isinf(L.y) || std::isinf(L.z);
+    if (x < 0 || x >= W || y < 0 || y >= H || bad) return;
+    ctl_pixel_data& r = img[(size_t)y * W + x];
+    r.rgb[0] += L.x; r.rgb[1] += L.y; r.rgb[2] += L.z; r.weight_sum += 1.0f;
+}
+
+} // namespace orc

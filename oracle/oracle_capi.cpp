@@ -1,0 +1,174 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see omath.h header).  C entry points for tests/ and bench.py's cpu_baseline.
+#include "ocore.h"
+#include "orng.h"
+#include <thread>
+#include <atomic>
+#include <vector>
+
+using namespace orc;
+
+extern "C" {
+
+// ---- primitives -----------------------------------------------------------------------------------------------
+void orc_woop_set_data(const float* v0, const float* v1, const float* v2, ctl_woop_tri* out) {
+    woopSetData(*out, V3(v0[0], v0[1], v0[2]), V3(v1[0], v1[1], v1[2]), V3(v2[0], v2[1], v2[2]));
+}
+void orc_woop_get_data(const ctl_woop_tri* w, float* v0, float* v1, float* v2) {
+    V3 a, b, c; woopGetData(*w, a, b, c);
+    v0[0] = a.x; v0[1] = a.y; v0[2] = a.z; v1[0] = b.x; v1[1] = b.y; v1[2] = b.z; v2[0] = c.x; v2[1] = c.y; v2[2] = c.z;
+}
+int orc_woop_intersect(const ctl_woop_tri* w, const float* o, const float* d, float tmin, float tmax, float* tuv) {
+    return woopIntersect(*w, V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), tmin, tmax, tuv[0], tuv[1], tuv[2]) ? 1 : 0;
+}
+uint16_t orc_float_to_half(float f) { return floatToHalf(f); }
+float orc_half_to_float(uint16_t h, int host_quirk) { return halfToFloat(h, host_quirk != 0); }
+uint16_t orc_normal_encode(const float* n) { return normalToUchar2(V3(n[0], n[1], n[2])); }
+void orc_normal_decode(uint16_t v, float* n) { V3 r = uchar2ToNormal(v); n[0] = r.x; n[1] = r.y; n[2] = r.z; }
+void orc_matrix_inverse(const float* m, float* out) { M44 a; std::memcpy(a.d, m, 64); M44 r = inverse(a); std::memcpy(out, r.d, 64); }
+
+// TriangleData(P, matIndex, T, N) (Engine/TriangleData.cu:11-16)
+void orc_triangle_data_pack(const float* P, const float* N, const float* T, uint32_t mat_index, int quirk, ctl_triangle_data* out) {
+    std::memset(out, 0, sizeof(*out));
+    out->nor_mat_extra[1] = (mat_index & 0xff) << 16;   // m_sHostData.MatIndex is byte 6
+    triDataSetUV(*out, V2{ T[0], T[1] }, V2{ T[2], T[3] }, V2{ T[4], T[5] });
+    triDataSetData(*out, V3(P[0], P[1], P[2]), V3(P[3], P[4], P[5]), V3(P[6], P[7], P[8]), V3(N[0], N[1], N[2]), V3(N[3], N[4], N[5]), V3(N[6], N[7], N[8]), quirk != 0);
+}
+// out[0..2]=P is not touched; out = sys.s(3) sys.t(3) sys.n(3) n(3) dpdu(3) dpdv(3) uv(2) extra(1) = 21 floats
+void orc_triangle_fill_dg(const ctl_triangle_data* T, const float* local_to_world, float u, float v, int quirk, float* out) {
+    M44 m; std::memcpy(m.d, local_to_world, 64);
+    DG dg; dg.bary = V2{ u, v };
+    triDataFillDG(*T, m, dg, quirk != 0);
+    const V3* vs[6] = { &dg.sys.s, &dg.sys.t, &dg.sys.n, &dg.n, &dg.dpdu, &dg.dpdv };
+    for (int i = 0; i < 6; i++) { out[i * 3] = vs[i]->x; out[i * 3 + 1] = vs[i]->y; out[i * 3 + 2] = vs[i]->z; }
+    out[18] = dg.uv.x; out[19] = dg.uv.y; out[20] = (float)dg.extraData;
+}
+
+// ---- warps / fresnel ------------------------------------------------------------------------------------------
+void orc_square_to_cosine_hemisphere(float x, float y, float* out) { V3 r = squareToCosineHemisphere(V2{ x, y }); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void orc_square_to_uniform_triangle(float x, float y, float* out) { V2 r = squareToUniformTriangle(V2{ x, y }); out[0] = r.x; out[1] = r.y; }
+void orc_square_to_uniform_disk_concentric(float x, float y, float* out) { V2 r = squareToUniformDiskConcentric(V2{ x, y }); out[0] = r.x; out[1] = r.y; }
+float orc_fresnel_dielectric_ext(float cosThetaI, float eta, float* cosThetaT) { return fresnelDielectricExt(cosThetaI, *cosThetaT, eta); }
+void orc_fresnel_conductor_exact(float cosThetaI, const float* eta, const float* k, float* out) {
+    Spec r = fresnelConductorExact(cosThetaI, Spec(eta[0], eta[1], eta[2]), Spec(k[0], k[1], k[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_coordinate_system(const float* a, float* s, float* t) { V3 S, T; coordinateSystem(V3(a[0], a[1], a[2]), S, T); s[0] = S.x; s[1] = S.y; s[2] = S.z; t[0] = T.x; t[1] = T.y; t[2] = T.z; }
+
+// microfacet: out = eval(m), smithG1(wi,m), pdf(wi,m)
+void orc_microfacet_eval(int type, float aU, float aV, int sampleVisible, const float* wi, const float* m, float* out) {
+    Microfacet d(type, aU, aV, sampleVisible != 0);
+    V3 WI(wi[0], wi[1], wi[2]), M(m[0], m[1], m[2]);
+    out[0] = d.eval(M); out[1] = d.smithG1(WI, M); out[2] = d.pdf(WI, M);
+}
+void orc_microfacet_sample(int type, float aU, float aV, int sampleVisible, const float* wi, float sx, float sy, float* out) {
+    Microfacet d(type, aU, aV, sampleVisible != 0);
+    float pdf; V3 m = d.sample(V3(wi[0], wi[1], wi[2]), V2{ sx, sy }, pdf);
+    out[0] = m.x; out[1] = m.y; out[2] = m.z; out[3] = pdf;
+}
+
+// ---- sampler --------------------------------------------------------------------------------------------------
+void* orc_seqgen_create() { return new SequenceGenerator(); }
+void orc_seqgen_destroy(void* g) { delete (SequenceGenerator*)g; }
+void orc_seqgen_compute(void* g, float* t1, float* t2) { ((SequenceGenerator*)g)->compute(t1, t2); }
+void orc_xorwow_init(uint64_t seed, uint64_t subsequence, uint32_t* state6) {
+    Xorwow s = xorwowInit(seed, subsequence); state6[0] = s.d; for (int i = 0; i < 5; i++) state6[1 + i] = s.v[i];
+}
+// 800 words of T^(2^log2pow) in the cuRAND / rocRAND precalc layout (row (i*32+j) = image of bit j of word i)
+void orc_xorwow_jump_matrix(int log2pow, uint32_t* out800) { XMat M = xmatPow2(log2pow); std::memcpy(out800, M.r, sizeof(M.r)); }
+float orc_sampler_float(const float* t1, const float* t2, uint32_t idx, uint32_t d1) { Sampler s(t1, t2, idx); s.d1 = d1; return s.randomFloat(); }
+void orc_sampler_float2(const float* t1, const float* t2, uint32_t idx, uint32_t d2, float* out) { Sampler s(t1, t2, idx); s.d2 = d2; V2 r = s.randomFloat2(); out[0] = r.x; out[1] = r.y; }
+
+// ---- sensor ---------------------------------------------------------------------------------------------------
+void orc_sensor_sample_ray(const ctl_sensor* s, float px, float py, float* o, float* d) {
+    PerspectiveSensor ps; ps.update(*s); V3 O, D; ps.sampleRay(V2{ px, py }, O, D);
+    o[0] = O.x; o[1] = O.y; o[2] = O.z; d[0] = D.x; d[1] = D.y; d[2] = D.z;
+}
+
+// ---- intersect ------------------------------------------------------------------------------------------------
+// intersectKernel semantics (TraceHelper.cu:326-734): tmin = ray.a.w at node and triangle level, tmax = ray.b.w.
+void orc_intersect(const ctl_scene_desc* desc, const ctl_ray* rays, uint32_t n, ctl_hit* hits, int any_hit, ctl_traversal_counts* counts, int n_threads) {
+    Scene S; S.d = *desc;
+    if (n_threads < 1) n_threads = 1;
+    std::vector<TravCounts> tc(n_threads);
+    auto work = [&](int tid) {
+        for (uint32_t i = tid; i < n; i += n_threads) {
+            Hit h;
+            traceRay(S, V3(rays[i].a[0], rays[i].a[1], rays[i].a[2]), V3(rays[i].b[0], rays[i].b[1], rays[i].b[2]), rays[i].a[3], rays[i].b[3], any_hit != 0, rays[i].a[3], h,
+                     counts ? &tc[tid] : nullptr);
+            hits[i].dist = h.dist; hits[i].node_idx = (int32_t)h.node; hits[i].tri_idx = (int32_t)h.tri; hits[i].u = h.u; hits[i].v = h.v;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    if (counts) { counts->n_inner = counts->n_tri = counts->n_inst = 0; for (auto& c : tc) { counts->n_inner += c.n_inner; counts->n_tri += c.n_tri; counts->n_inst += c.n_inst; } }
+}
+
+// ---- BSDF / light probes --------------------------------------------------------------------------------------
+// local-frame probe: dg is an identity frame at the origin with uv = (u,v).  out = f(3), pdf, wo(3), sampledType, eta
+void orc_bsdf_sample(const ctl_material* M, const float* wi, float sx, float sy, float* out) {
+    BRec b; b.dg.P = V3(0.0f); b.dg.sys = Frame(V3(1, 0, 0), V3(0, 1, 0), V3(0, 0, 1)); b.dg.n = V3(0, 0, 1); b.dg.uv = V2{ 0, 0 };
+    b.wi = V3(wi[0], wi[1], wi[2]); b.wo = V3(0.0f); b.eta = 1.0f; b.typeMask = EAll; b.sampledType = 0;
+    float pdf = 0; Spec f = bsdfSample(*M, b, pdf, V2{ sx, sy });
+    out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = pdf; out[4] = b.wo.x; out[5] = b.wo.y; out[6] = b.wo.z; out[7] = (float)b.sampledType; out[8] = b.eta;
+}
+void orc_bsdf_eval(const ctl_material* M, const float* wi, const float* wo, uint32_t typeMask, float* out) {
+    BRec b; b.dg.P = V3(0.0f); b.dg.sys = Frame(V3(1, 0, 0), V3(0, 1, 0), V3(0, 0, 1)); b.dg.n = V3(0, 0, 1); b.dg.uv = V2{ 0, 0 };
+    b.wi = V3(wi[0], wi[1], wi[2]); b.wo = V3(wo[0], wo[1], wo[2]); b.eta = 1.0f; b.typeMask = typeMask; b.sampledType = 0;
+    Spec f = bsdfF(*M, b); out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = bsdfPdf(*M, b);
+}
+// out = value(3), pdf, d(3), dist, p(3), n(3)
+void orc_light_sample_direct(const ctl_scene_desc* desc, uint32_t light, const float* ref, const float* refN, float sx, float sy, float* out) {
+    Scene S; S.d = *desc;
+    DirectRec d(V3(ref[0], ref[1], ref[2]), V3(refN[0], refN[1], refN[2]));
+    Spec v = lightSampleDirect(S, desc->lights[light], d, V2{ sx, sy });
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = d.pdf; out[4] = d.d.x; out[5] = d.d.y; out[6] = d.d.z; out[7] = d.dist;
+    out[8] = d.p.x; out[9] = d.p.y; out[10] = d.p.z; out[11] = d.n.x; out[12] = d.n.y; out[13] = d.n.z;
+}
+
+// ---- full render: pathKernel2<DIRECT,false> looped over all pixels (Integrators/PathTracer.cu:182-194) ---------
+// tables: n_passes consecutive (t1[30*4096], t2[30*4096*2]) pairs, or NULL -> own SequenceGenerator
+// (one Compute() per pass, as Tracer<true>::DoPass -> UpdateKernel does, Kernel/Tracer.h:229).
+// Renders rows [y0,y1) only (bounded CPU-baseline samples).  Returns the number of rays traced.
+uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t n_passes, const float* tables1, const float* tables2,
+                    int direct, int maxPathLength, int rrStart, ctl_pixel_data* img, int n_threads, uint32_t y0, uint32_t y1, int half_host_quirk) {
+    Scene S; S.d = *desc; S.half_host_quirk = half_host_quirk != 0;
+    PerspectiveSensor sensor; sensor.update(desc->camera);
+    if (n_threads < 1) n_threads = 1;
+    if (y1 > H) y1 = H;
+    SequenceGenerator gen;
+    std::vector<float> own1, own2;
+    const size_t N1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH, N2 = N1 * 2;
+    if (!tables1) { own1.resize(N1); own2.resize(N2); }
+    std::atomic<uint64_t> total(0);
+    for (uint32_t pass = 0; pass < n_passes; pass++) {
+        const float *t1, *t2;
+        if (tables1) { t1 = tables1 + pass * N1; t2 = tables2 + pass * N2; }
+        else { gen.compute(own1.data(), own2.data()); t1 = own1.data(); t2 = own2.data(); }
+        std::atomic<uint32_t> nextRow(y0);
+        auto work = [&]() {
+            uint64_t rays = 0;
+            for (;;) {
+                uint32_t y = nextRow.fetch_add(1);
+                if (y >= y1) break;
+                for (uint32_t x = 0; x < W; x++) {
+                    Sampler rng(t1, t2, y * W + x);   // TracerBase::getPixelIndex
+                    V2 j = rng.randomFloat2();
+                    V2 pX{ (float)x + j.x, (float)y + j.y };
+                    V2 ap = rng.randomFloat2(); (void)ap;
+                    V3 o, d; sensor.sampleRay(pX, o, d);
+                    Spec col = pathTrace(S, direct != 0, o, d, rng, maxPathLength, rrStart, &rays);   // imp == 1 (Sensor.cu:127)
+                    addSample(img, (int)W, (int)H, pX.x, pX.y, col);
+                }
+            }
+            total += rays;
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_threads; t++) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+    }
+    return total.load();
+}
+
+} // extern "C"

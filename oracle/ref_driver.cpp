@@ -1,0 +1,122 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+// ref_driver.cpp — thin extern "C" driver around the REFERENCE'S OWN host-compilable code, compiled from
+// /root/reference where it lies (oracle/Makefile target `ref`; output only into oracle/_ref/, git-ignored).
+// It contains no copy of reference source: it includes the reference headers and calls their functions.
+// Used by tests/ to pin the restatement in ocore.h/omath.h and to generate tests/golden/ fixtures.
+//
+// What could NOT be built from the reference here (needs curand_kernel.h from the CUDA toolkit, or
+// un-vendored boost/pugixml/FreeImage): BSDF_Simple.cu, Light.cu, KernelDynamicScene.cu, TraceHelper.cu,
+// Sampler/CudaRandom, DynamicScene, the Mitsuba loader.  See DESIGN.md "Oracle".
+#include <Engine/TriIntersectorData.h>
+#include <Engine/TriangleData.h>
+#include <Engine/DifferentialGeometry.h>
+#include <Engine/MicrofacetDistribution.h>
+#include <Engine/MeshLoader/BVHBuilderHelper.h>
+#include <Math/Compression.h>
+#include <Math/half.h>
+#include <Math/Warp.h>
+#include <Math/Frame.h>
+#include <Math/FresnelHelper.h>
+#include <Math/MonteCarlo.h>
+#include <Math/Ray.h>
+#include <SceneTypes/Sensor.h>
+#include <cstdint>
+#include <cstring>
+
+using namespace CudaTracerLib;
+
+extern "C" {
+
+void ref_woop_set_data(const float* v0, const float* v1, const float* v2, float* out12) {
+    TriIntersectorData t; t.setData(Vec3f(v0[0], v0[1], v0[2]), Vec3f(v1[0], v1[1], v1[2]), Vec3f(v2[0], v2[1], v2[2]));
+    std::memcpy(out12, &t, 48);
+}
+void ref_woop_get_data(const float* w12, float* v0, float* v1, float* v2) {
+    TriIntersectorData t; std::memcpy(&t, w12, 48);
+    Vec3f a, b, c; t.getData(a, b, c);
+    v0[0] = a.x; v0[1] = a.y; v0[2] = a.z; v1[0] = b.x; v1[1] = b.y; v1[2] = b.z; v2[0] = c.x; v2[1] = c.y; v2[2] = c.z;
+}
+// TriIntersectorData::Intersect uses the fixed tmin 1e-4 (TriIntersectorData.cu:40)
+int ref_woop_intersect(const float* w12, const float* o, const float* d, float tmax, float* tuv) {
+    TriIntersectorData t; std::memcpy(&t, w12, 48);
+    float dist = tmax; Vec2f bary;
+    bool h = t.Intersect(Ray(Vec3f(o[0], o[1], o[2]), Vec3f(d[0], d[1], d[2])), &dist, &bary);
+    tuv[0] = dist; tuv[1] = bary.x; tuv[2] = bary.y;
+    return h ? 1 : 0;
+}
+uint16_t ref_float_to_half(float f) { return (uint16_t)half(f).bits(); }
+float ref_half_to_float(uint16_t h) { return half((unsigned short)h).ToFloat(); }   // host branch (half.h:76-83)
+uint16_t ref_normal_encode(const float* n) { return NormalizedFloat3ToUchar2(NormalizedT<Vec3f>(Vec3f(n[0], n[1], n[2]))); }
+void ref_normal_decode(uint16_t v, float* n) { auto r = Uchar2ToNormalizedFloat3(v); n[0] = r.x; n[1] = r.y; n[2] = r.z; }
+void ref_matrix_inverse(const float* m, float* out) { float4x4 a; std::memcpy(a.data, m, 64); float4x4 r = a.inverse(); std::memcpy(out, r.data, 64); }
+
+void ref_triangle_data_pack(const float* P, const float* N, const float* T, uint32_t mat_index, uint32_t* out8) {
+    Vec3f p[3] = { Vec3f(P[0], P[1], P[2]), Vec3f(P[3], P[4], P[5]), Vec3f(P[6], P[7], P[8]) };
+    NormalizedT<Vec3f> n[3] = { NormalizedT<Vec3f>(Vec3f(N[0], N[1], N[2])), NormalizedT<Vec3f>(Vec3f(N[3], N[4], N[5])), NormalizedT<Vec3f>(Vec3f(N[6], N[7], N[8])) };
+    Vec2f t[3] = { Vec2f(T[0], T[1]), Vec2f(T[2], T[3]), Vec2f(T[4], T[5]) };
+    TriangleData td; std::memset(&td, 0, sizeof(td));
+    td = TriangleData(p, (unsigned char)mat_index, t, n);
+    std::memcpy(out8, &td, 32);
+}
+void ref_triangle_fill_dg(const uint32_t* td8, const float* local_to_world, float u, float v, float* out) {
+    TriangleData td; std::memcpy(&td, td8, 32);
+    float4x4 m; std::memcpy(m.data, local_to_world, 64);
+    DifferentialGeometry dg; dg.bary = Vec2f(u, v);
+    td.fillDG(m, dg);
+    const Vec3f vs[6] = { dg.sys.s, dg.sys.t, dg.sys.n, dg.n, dg.dpdu, dg.dpdv };
+    for (int i = 0; i < 6; i++) { out[i * 3] = vs[i].x; out[i * 3 + 1] = vs[i].y; out[i * 3 + 2] = vs[i].z; }
+    out[18] = dg.uv[0].x; out[19] = dg.uv[0].y; out[20] = (float)dg.extraData;
+}
+
+void ref_square_to_cosine_hemisphere(float x, float y, float* out) { auto r = Warp::squareToCosineHemisphere(Vec2f(x, y)); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void ref_square_to_uniform_triangle(float x, float y, float* out) { auto r = Warp::squareToUniformTriangle(Vec2f(x, y)); out[0] = r.x; out[1] = r.y; }
+void ref_square_to_uniform_disk_concentric(float x, float y, float* out) { auto r = Warp::squareToUniformDiskConcentric(Vec2f(x, y)); out[0] = r.x; out[1] = r.y; }
+float ref_fresnel_dielectric_ext(float cosThetaI, float eta, float* cosThetaT) { return FresnelHelper::fresnelDielectricExt(cosThetaI, *cosThetaT, eta); }
+void ref_fresnel_conductor_exact(float cosThetaI, const float* eta, const float* k, float* out) {
+    Spectrum r = FresnelHelper::fresnelConductorExact(cosThetaI, Spectrum(eta[0], eta[1], eta[2]), Spectrum(k[0], k[1], k[2]));
+    out[0] = r[0]; out[1] = r[1]; out[2] = r[2];
+}
+void ref_coordinate_system(const float* a, float* s, float* t) {
+    NormalizedT<Vec3f> S, T; coordinateSystem(NormalizedT<Vec3f>(Vec3f(a[0], a[1], a[2])), S, T);
+    s[0] = S.x; s[1] = S.y; s[2] = S.z; t[0] = T.x; t[1] = T.y; t[2] = T.z;
+}
+float ref_power_heuristic(float a, float b) { return MonteCarlo::PowerHeuristic(1, a, 1, b); }
+
+void ref_microfacet_eval(int type, float aU, float aV, int sampleVisible, const float* wi, const float* m, float* out) {
+    MicrofacetDistribution d((MicrofacetDistribution::EType)type, aU, aV, sampleVisible != 0);
+    NormalizedT<Vec3f> WI(Vec3f(wi[0], wi[1], wi[2])), M(Vec3f(m[0], m[1], m[2]));
+    out[0] = d.eval(M); out[1] = d.smithG1(WI, M); out[2] = d.pdf(WI, M);
+}
+void ref_microfacet_sample(int type, float aU, float aV, int sampleVisible, const float* wi, float sx, float sy, float* out) {
+    MicrofacetDistribution d((MicrofacetDistribution::EType)type, aU, aV, sampleVisible != 0);
+    float pdf; auto m = d.sample(NormalizedT<Vec3f>(Vec3f(wi[0], wi[1], wi[2])), Vec2f(sx, sy), pdf);
+    out[0] = m.x; out[1] = m.y; out[2] = m.z; out[3] = pdf;
+}
+
+// PerspectiveSensor::sampleRay (SceneTypes/Sensor.cu:116-128). to_world row-major, fov in radians.
+void ref_sensor_sample_ray(const float* to_world, float fov_rad, float nearD, float farD, int w, int h, float px, float py, float* o, float* d) {
+    PerspectiveSensor s(w, h, 90.0f);
+    s.SetNearFarDepth(nearD, farD);
+    s.fov = fov_rad;
+    NormalizedT<OrthogonalAffineMap> m; std::memcpy(m.data, to_world, 64);
+    s.SetToWorld(m);   // -> Update()
+    NormalizedT<Ray> r;
+    s.sampleRay(r, Vec2f(px, py), Vec2f(0.0f));
+    o[0] = r.ori().x; o[1] = r.ori().y; o[2] = r.ori().z; d[0] = r.dir().x; d[1] = r.dir().y; d[2] = r.dir().z;
+}
+
+// ConstructBVH (Engine/MeshLoader/BVHBuilderHelper.cpp:116-127): SBVH with max leaf size 8.
+// Two-call protocol: first with NULL outputs to get the counts, then with buffers.
+static BVH_Construction_Result g_last;
+void ref_construct_bvh(const float* vertices, const uint32_t* indices, uint32_t vCount, uint32_t iCount, uint32_t* n_nodes, uint32_t* n_tris) {
+    g_last = BVH_Construction_Result();
+    ConstructBVH((const Vec3f*)vertices, indices, vCount, iCount, g_last);
+    *n_nodes = (uint32_t)g_last.nodes.size(); *n_tris = (uint32_t)g_last.tris.size();
+}
+void ref_construct_bvh_fetch(void* nodes, void* tris, void* tris2) {
+    std::memcpy(nodes, g_last.nodes.data(), g_last.nodes.size() * sizeof(BVHNodeData));
+    std::memcpy(tris, g_last.tris.data(), g_last.tris.size() * sizeof(TriIntersectorData));
+    std::memcpy(tris2, g_last.tris2.data(), g_last.tris2.size() * sizeof(TriIntersectorData2));
+}
+
+} // extern "C"
