@@ -1,0 +1,411 @@
+"""ctypes binding of include/ctl_amd.h with the reference's class/method names.
+
+Every call goes through the C-ABI of libctl_amd.so; nothing here computes radiance, traverses a BVH
+or falls back to a CPU path.  Errors of the C layer are raised as ``CtlError`` carrying ``ctl_last_error()``
+(the text the reference would have thrown as std::runtime_error, Defines.cpp:15-29).
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libctl_amd.so")
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        "cudatracerlib_amd: %s is missing — build it with `python -m cudatracerlib_amd.build` "
+        "(hipcc --offload-arch=gfx950). There is no CPU fallback." % _LIB_PATH)
+lib = C.CDLL(_LIB_PATH)
+
+f32, u32, i32, u8, u64 = C.c_float, C.c_uint32, C.c_int32, C.c_uint8, C.c_uint64
+MAX_NUM_LIGHTS = 16
+SAMPLER_N1 = 4096 * 30
+
+
+class CtlError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ctl error %d: %s" % (code, msg))
+        self.code = code
+
+
+# ---------------------------------------------------------------- structs (include/ctl_amd.h)
+class ctl_texture(C.Structure):
+    _fields_ = [("type", u32), ("value", f32 * 3), ("value1", f32 * 3), ("uv_scale", f32 * 2), ("uv_offset", f32 * 2), ("image", u32)]
+
+
+class ctl_material(C.Structure):
+    _fields_ = [("bsdf_type", u32), ("combined_type", u32), ("two_sided", u32), ("node_light_index", u32),
+                ("tex", ctl_texture * 4), ("f", f32 * 8), ("u", u32 * 4)]
+
+
+class ctl_light(C.Structure):
+    _fields_ = [("type", u32), ("radiance", f32 * 3), ("area_dist_index", u32), ("triangles_index", u32), ("sum_area", f32), ("count", u32),
+                ("orthogonal", u32), ("node_idx", u32), ("position", f32 * 3), ("direction", f32 * 3),
+                ("cutoff_angle", f32), ("beam_width", f32), ("cos_cutoff_angle", f32), ("cos_beam_width", f32), ("inv_transition_width", f32),
+                ("to_world", f32 * 16), ("env_image", u32), ("env_scale", f32 * 3), ("bsphere_center", f32 * 3), ("bsphere_radius", f32)]
+
+
+class ctl_sensor(C.Structure):
+    _fields_ = [("type", u32), ("to_world", f32 * 16), ("fov", f32), ("near_depth", f32), ("far_depth", f32), ("resolution", f32 * 2),
+                ("aperture_radius", f32), ("focus_distance", f32)]
+
+
+class ctl_float4x4(C.Structure):
+    _fields_ = [("m", f32 * 16)]
+
+
+class ctl_ray(C.Structure):
+    _fields_ = [("a", f32 * 4), ("b", f32 * 4)]
+
+
+class ctl_hit(C.Structure):
+    _fields_ = [("dist", f32), ("node_idx", i32), ("tri_idx", i32), ("u", f32), ("v", f32)]
+
+
+class ctl_pixel_data(C.Structure):
+    _fields_ = [("rgb", f32 * 3), ("rgb_splat", f32 * 3), ("weight_sum", f32)]
+
+
+class ctl_traversal_counts(C.Structure):
+    _fields_ = [("n_inner", u64), ("n_tri", u64), ("n_inst", u64)]
+
+
+class ctl_tracer_stats(C.Structure):
+    _fields_ = [("rays_last_pass", u64), ("rays_total", u64), ("seconds_last_pass", C.c_double), ("seconds_total", C.c_double), ("passes_done", u32),
+                ("ms_intersect", C.c_double), ("ms_shade", C.c_double), ("ms_raygen", C.c_double), ("intersect_rays", u64), ("intersect_launches", u64)]
+
+
+class ctl_scene_desc(C.Structure):
+    _fields_ = [("tri_data", C.c_void_p), ("n_tri_data", u32), ("woop", C.c_void_p), ("n_woop", u32), ("woop_index", C.c_void_p),
+                ("bvh_nodes", C.c_void_p), ("n_bvh_nodes", u32), ("meshes", C.c_void_p), ("n_meshes", u32), ("nodes", C.c_void_p), ("n_nodes", u32),
+                ("materials", C.POINTER(ctl_material)), ("n_materials", u32), ("lights", C.POINTER(ctl_light)), ("n_lights_buf", u32),
+                ("anim", C.c_void_p), ("n_anim_bytes", u32), ("scene_start_node", i32), ("scene_bvh_nodes", C.c_void_p), ("n_scene_bvh_nodes", u32),
+                ("node_transforms", C.c_void_p), ("node_inv_transforms", C.c_void_p), ("env_map_index", u32),
+                ("box_min", f32 * 3), ("box_max", f32 * 3), ("camera", ctl_sensor), ("num_lights", u32),
+                ("light_indices", u32 * MAX_NUM_LIGHTS), ("light_cdf", f32 * MAX_NUM_LIGHTS), ("ray_trace_eps", f32)]
+
+    # numpy views of the reference-layout arrays (host memory owned by the builder)
+    def view(self, name, dtype, count, width):
+        ptr = getattr(self, name)
+        if not ptr or not count:
+            return np.zeros((0, width), dtype)
+        buf = (C.c_char * (count * width * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype).reshape(count, width)
+
+
+assert C.sizeof(ctl_texture) == 48 and C.sizeof(ctl_material) == 256 and C.sizeof(ctl_pixel_data) == 28 and C.sizeof(ctl_hit) == 20
+
+lib.ctl_last_error.restype = C.c_char_p
+lib.ctl_version.restype = C.c_char_p
+lib.ctl_image_device_ptr.restype = C.c_void_p
+lib.ctl_image_device_ptr.argtypes = [C.c_void_p]
+for _n in ("ctl_builder_destroy", "ctl_scene_destroy", "ctl_image_destroy", "ctl_tracer_destroy", "ctl_sequence_generator_destroy"):
+    getattr(lib, _n).restype = None
+    getattr(lib, _n).argtypes = [C.c_void_p]
+lib.ctl_device_malloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+lib.ctl_device_free.argtypes = [C.c_void_p]
+lib.ctl_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+lib.ctl_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+lib.ctl_intersect_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(f32)]
+lib.ctl_image_resolve_rgb.argtypes = [C.c_void_p, f32, C.c_void_p]
+lib.ctl_builder_set_camera_lookat.argtypes = [C.c_void_p, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), f32, u32, u32]
+
+
+def _check(code):
+    if code != 0:
+        raise CtlError(code, lib.ctl_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return int(lib.ctl_device_count())
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(f32))
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+# ---------------------------------------------------------------- material helpers (Mitsuba plugin defaults, ObjectParser.h:754-966)
+E = dict(Null=0x1, DiffuseReflection=0x2, DiffuseTransmission=0x4, GlossyReflection=0x8, GlossyTransmission=0x10, DeltaReflection=0x20, DeltaTransmission=0x40)
+TEX_CONSTANT, BSDF_DIFFUSE, BSDF_DIELECTRIC, BSDF_CONDUCTOR, BSDF_ROUGHCONDUCTOR = 2, 1, 3, 6, 7
+
+
+def _const_tex(rgb):
+    t = ctl_texture()
+    t.type = TEX_CONSTANT
+    rgb = (rgb, rgb, rgb) if np.isscalar(rgb) else rgb
+    t.value[:] = [float(x) for x in rgb]
+    t.uv_scale[:] = [1.0, 1.0]
+    return t
+
+
+def _material(bsdf_type, combined, two_sided=False):
+    m = ctl_material()
+    m.bsdf_type, m.combined_type, m.two_sided, m.node_light_index = bsdf_type, combined, 1 if two_sided else 0, 0xFFFFFFFF
+    for i in range(4):
+        m.tex[i] = _const_tex(0.0)
+    return m
+
+
+def diffuse(reflectance=(0.5, 0.5, 0.5), two_sided=False):
+    """diffuse(reflectance) — BSDF_Simple.h:6-24."""
+    m = _material(BSDF_DIFFUSE, E["DiffuseReflection"], two_sided)
+    m.tex[0] = _const_tex(reflectance)
+    return m
+
+
+def dielectric(int_ior=1.5046, ext_ior=1.000277, specular_transmittance=1.0, specular_reflectance=1.0):
+    """dielectric(eta = intIOR / extIOR) — BSDF_Simple.h:62-94, defaults bk7 / air (Utils.h:280-307)."""
+    m = _material(BSDF_DIELECTRIC, E["DeltaReflection"] | E["DeltaTransmission"])
+    m.tex[0], m.tex[1] = _const_tex(specular_transmittance), _const_tex(specular_reflectance)
+    m.f[0] = np.float32(np.float32(int_ior) / np.float32(ext_ior))
+    m.f[1] = 0.0
+    return m
+
+
+def conductor(eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0), specular_reflectance=1.0, two_sided=False):
+    """conductor(eta, k) — BSDF_Simple.h:165-193."""
+    m = _material(BSDF_CONDUCTOR, E["DeltaReflection"], two_sided)
+    m.tex[0] = _const_tex(specular_reflectance)
+    m.f[0:3] = [float(x) for x in eta]
+    m.f[3:6] = [float(x) for x in k]
+    return m
+
+
+def roughconductor(alpha=0.1, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), distribution=1, sample_visible=True, specular_reflectance=1.0, alpha_v=None, two_sided=False):
+    """roughconductor(type, eta, k, alphaU, alphaV) — BSDF_Simple.h:195-232 (distribution: 0 Beckmann, 1 GGX)."""
+    m = _material(BSDF_ROUGHCONDUCTOR, E["GlossyReflection"], two_sided)
+    m.tex[0], m.tex[1], m.tex[2] = _const_tex(specular_reflectance), _const_tex(alpha), _const_tex(alpha if alpha_v is None else alpha_v)
+    m.f[0:3] = [float(x) for x in eta]
+    m.f[3:6] = [float(x) for x in k]
+    m.u[0], m.u[1] = distribution, 1 if sample_visible else 0
+    return m
+
+
+# ---------------------------------------------------------------- DynamicScene (Engine/DynamicScene.h:70-187, loader-facing subset)
+class DynamicScene:
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(lib.ctl_builder_create(C.byref(self._h)))
+        self.desc = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.ctl_builder_destroy(self._h)
+            self._h = None
+
+    def add_mesh(self, positions, indices=None, normals=None, uvs=None, tri_material=None, materials=None):
+        """Mesh::CompileMesh (Engine/Mesh.cpp:199-290) -> mesh index."""
+        P = _f32(positions, (-1, 3))
+        I = None if indices is None else np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        n_tri = len(P) // 3 if I is None else len(I)
+        N = None if normals is None else _f32(normals, (-1, 3))
+        UV = None if uvs is None else _f32(uvs, (-1, 2))
+        TM = None if tri_material is None else np.ascontiguousarray(tri_material, dtype=np.uint8)
+        mats = materials if materials is not None else [diffuse()]
+        arr = (ctl_material * len(mats))(*mats)
+        out = u32()
+        _check(lib.ctl_builder_add_mesh(self._h, _fp(P), u32(len(P)), None if I is None else I.ctypes.data_as(C.c_void_p), u32(n_tri),
+                                        None if N is None else _fp(N), None if UV is None else _fp(UV),
+                                        None if TM is None else TM.ctypes.data_as(C.c_void_p), arr, u32(len(mats)), C.byref(out)))
+        return out.value
+
+    def CreateNode(self, mesh_index, to_world=None):
+        """DynamicScene::CreateNode + SetNodeTransform (DynamicScene.cpp:269-346)."""
+        out = u32()
+        m = None
+        if to_world is not None:
+            m = ctl_float4x4()
+            m.m[:] = [float(x) for x in np.asarray(to_world, dtype=np.float32).reshape(16)]
+        _check(lib.ctl_builder_add_node(self._h, u32(mesh_index), None if m is None else C.byref(m), C.byref(out)))
+        return out.value
+
+    def CreateLight(self, node, local_material, radiance):
+        """DynamicScene::CreateLight(node, materialName, L) (DynamicScene.cpp:689-711); materials are addressed by local index."""
+        L = (f32 * 3)(*[float(x) for x in radiance])
+        _check(lib.ctl_builder_add_area_light(self._h, u32(node), u32(local_material), L))
+
+    def CreatePointLight(self, position, intensity):
+        _check(lib.ctl_builder_add_point_light(self._h, (f32 * 3)(*map(float, position)), (f32 * 3)(*map(float, intensity))))
+
+    def setCamera(self, pos, target, up, fov_degrees, width, height):
+        _check(lib.ctl_builder_set_camera_lookat(self._h, (f32 * 3)(*map(float, pos)), (f32 * 3)(*map(float, target)), (f32 * 3)(*map(float, up)),
+                                                 f32(fov_degrees), u32(width), u32(height)))
+
+    def ParseMitsubaScene(self, path, width=-1, height=-1):
+        """ParseMitsubaScene (Engine/SceneLoader/Mitsuba/MitsubaLoader.h:13)."""
+        w, h = i32(width), i32(height)
+        _check(lib.ctl_parse_mitsuba_scene(self._h, path.encode(), C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def UpdateScene(self):
+        """DynamicScene::UpdateScene + getKernelSceneData(false) (DynamicScene.cpp:480-589): host-side KernelDynamicScene."""
+        self.desc = ctl_scene_desc()
+        _check(lib.ctl_builder_finalize(self._h, C.byref(self.desc)))
+        return self.desc
+
+    def getKernelSceneData(self):
+        return self.desc if self.desc is not None else self.UpdateScene()
+
+
+class Scene:
+    """The scene resident in HBM (UpdateKernel, Kernel/TraceHelper.cu:182-217)."""
+
+    def __init__(self, desc):
+        self._h = C.c_void_p()
+        self._keepalive = desc
+        _check(lib.ctl_scene_create(C.byref(desc), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.ctl_scene_destroy(self._h)
+            self._h = None
+
+
+def _rays_struct(rays):
+    r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+    return r, r.ctypes.data_as(C.c_void_p)
+
+
+def intersect(scene, rays, any_hit=False):
+    """__internal__IntersectBuffers (Kernel/TraceHelper.cu:736-746). rays: (n, 8) = ox oy oz tmin dx dy dz tmax.
+    Returns a structured array with dist, node_idx, tri_idx, u, v."""
+    r, rp = _rays_struct(rays)
+    hits = np.zeros(len(r), dtype=[("dist", "f4"), ("node_idx", "i4"), ("tri_idx", "i4"), ("u", "f4"), ("v", "f4")])
+    _check(lib.ctl_intersect(scene._h, rp, u32(len(r)), hits.ctypes.data_as(C.c_void_p), 1 if any_hit else 0))
+    return hits
+
+
+def intersect_count(scene, rays, any_hit=False):
+    r, rp = _rays_struct(rays)
+    c = ctl_traversal_counts()
+    _check(lib.ctl_intersect_count(scene._h, rp, u32(len(r)), 1 if any_hit else 0, C.byref(c)))
+    return dict(n_inner=c.n_inner, n_tri=c.n_tri, n_inst=c.n_inst)
+
+
+class Image:
+    """Engine/Image.h:31-91 — PixelData accumulator in HBM."""
+
+    def __init__(self, width, height):
+        self._h = C.c_void_p()
+        self.width, self.height = width, height
+        _check(lib.ctl_image_create(u32(width), u32(height), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.ctl_image_destroy(self._h)
+            self._h = None
+
+    def Clear(self):
+        _check(lib.ctl_image_clear(self._h))
+
+    def getPixelData(self):
+        """(h, w, 7) float32: rgb[3], rgbSplat[3], weightSum."""
+        a = np.zeros((self.height, self.width, 7), np.float32)
+        _check(lib.ctl_image_read_pixels(self._h, a.ctypes.data_as(C.c_void_p)))
+        return a
+
+    def setPixelData(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(self.height, self.width, 7)
+        _check(lib.ctl_image_write_pixels(self._h, a.ctypes.data_as(C.c_void_p)))
+
+    def device_ptr(self):
+        return lib.ctl_image_device_ptr(self._h)
+
+    def getRGB(self, splat_scale=0.0):
+        """copySamplesToOutput (Kernel/ImagePipeline/ImagePipeline.cu:14-30) up to linear RGB."""
+        a = np.zeros((self.height, self.width, 3), np.float32)
+        _check(lib.ctl_image_resolve_rgb(self._h, f32(splat_scale), a.ctypes.data_as(C.c_void_p)))
+        return a
+
+
+class _Parameters:
+    def __init__(self, tracer):
+        self._t = tracer
+
+    def setValue(self, key, value):
+        if isinstance(value, bool):
+            _check(lib.ctl_tracer_set_param_bool(self._t._h, key.encode(), 1 if value else 0))
+        else:
+            _check(lib.ctl_tracer_set_param_int(self._t._h, key.encode(), int(value)))
+
+    def getValue(self, key):
+        v = C.c_int()
+        _check(lib.ctl_tracer_get_param_int(self._t._h, key.encode(), C.byref(v)))
+        return v.value
+
+
+class WavefrontPathTracer:
+    """Integrators/PseudoRealtime/WavefrontPathTracer.h:24-67 behind Tracer<true> (Kernel/Tracer.h:193-294)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(lib.ctl_tracer_create(b"WavefrontPathTracer", C.byref(self._h)))
+        self._scene = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.ctl_tracer_destroy(self._h)
+            self._h = None
+
+    def getParameters(self):
+        return _Parameters(self)
+
+    def Resize(self, w, h):
+        _check(lib.ctl_tracer_resize(self._h, u32(w), u32(h)))
+
+    def InitializeScene(self, scene):
+        self._scene = scene
+        _check(lib.ctl_tracer_initialize_scene(self._h, scene._h))
+
+    def setTileShard(self, rank, world):
+        _check(lib.ctl_tracer_set_tile_shard(self._h, u32(rank), u32(world)))
+
+    def setSamplerTables(self, t1, t2):
+        t1, t2 = _f32(t1), _f32(t2)
+        assert t1.size == SAMPLER_N1 and t2.size == 2 * SAMPLER_N1
+        _check(lib.ctl_tracer_set_sampler_tables(self._h, _fp(t1), _fp(t2)))
+
+    def DoPass(self, image, new_trace=False):
+        _check(lib.ctl_tracer_do_pass(self._h, image._h, 1 if new_trace else 0))
+
+    def DoPasses(self, image, n, new_trace=False):
+        _check(lib.ctl_tracer_do_passes(self._h, image._h, 1 if new_trace else 0, u32(n)))
+
+    def stats(self):
+        s = ctl_tracer_stats()
+        _check(lib.ctl_tracer_get_stats(self._h, C.byref(s)))
+        return s
+
+    def getRaysInLastPass(self):
+        return self.stats().rays_last_pass
+
+    def getLastTimeSpentRenderingSec(self):
+        return self.stats().seconds_last_pass
+
+    def getNumPassesDone(self):
+        return self.stats().passes_done
+
+
+class SequenceGenerator:
+    """SamplingSequenceGeneratorHost<IndependantSamplingSequenceGenerator> (Kernel/Sampler.h:36-85)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(lib.ctl_sequence_generator_create(C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.ctl_sequence_generator_destroy(self._h)
+            self._h = None
+
+    def compute(self):
+        t1 = np.zeros(SAMPLER_N1, np.float32)
+        t2 = np.zeros(2 * SAMPLER_N1, np.float32)
+        _check(lib.ctl_sequence_generator_compute(self._h, _fp(t1), _fp(t2)))
+        return t1, t2

@@ -1,0 +1,162 @@
+// bvh_builder.cpp — binned-SAH BVH2 build (see bvh_builder.h).
+#include "bvh_builder.h"
+#include <algorithm>
+#include <atomic>
+#include <future>
+#include <cmath>
+#include <cstring>
+
+namespace ctl {
+namespace {
+
+constexpr int kBins = 32;
+constexpr int kEmptyChild = 0x76543210;
+
+struct tmp_node { aabb box; int left, right; uint32_t begin, end; };   // leaf: left == -1
+
+struct builder {
+    const std::vector<aabb>& boxes;
+    std::vector<float> cx, cy, cz;
+    std::vector<uint32_t> idx;
+    std::vector<tmp_node> pool;
+    std::atomic<int> pool_used{ 0 };
+    int max_leaf, depth_limit;
+    std::atomic<int> max_depth{ 0 };
+
+    explicit builder(const std::vector<aabb>& b, int ml, int dl) : boxes(b), max_leaf(ml), depth_limit(dl) {
+        size_t n = b.size();
+        cx.resize(n); cy.resize(n); cz.resize(n); idx.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            cx[i] = 0.5f * (b[i].lo[0] + b[i].hi[0]); cy[i] = 0.5f * (b[i].lo[1] + b[i].hi[1]); cz[i] = 0.5f * (b[i].lo[2] + b[i].hi[2]);
+            idx[i] = (uint32_t)i;
+        }
+        pool.resize(std::max<size_t>(2 * n, 2));
+    }
+    const float* cen(int axis) const { return axis == 0 ? cx.data() : (axis == 1 ? cy.data() : cz.data()); }
+
+    int build(uint32_t begin, uint32_t end, int depth, int par_budget) {
+        int me = pool_used.fetch_add(1);
+        tmp_node& nd = pool[me];
+        nd.begin = begin; nd.end = end; nd.left = nd.right = -1;
+        nd.box.reset();
+        aabb cb; cb.reset();
+        for (uint32_t i = begin; i < end; i++) { uint32_t p = idx[i]; nd.box.grow(boxes[p]); float c[3] = { cx[p], cy[p], cz[p] }; cb.grow(c); }
+        int d = max_depth.load();
+        while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
+        uint32_t n = end - begin;
+        if (n <= 1) return me;
+        // how many levels are left vs. how many a balanced tree still needs
+        int remaining = depth_limit - depth;
+        uint32_t leaves_needed = (n + max_leaf - 1) / max_leaf;
+        bool force_median = remaining <= 2 || leaves_needed > (1u << std::min(remaining - 2, 30));
+
+        int best_axis = -1, best_bin = -1; float best_cost = 3.402823466e+38f;
+        if (!force_median) {
+            for (int axis = 0; axis < 3; axis++) {
+                float lo = cb.lo[axis], hi = cb.hi[axis];
+                if (!(hi > lo)) continue;
+                const float* c = cen(axis);
+                float scale = kBins / (hi - lo);
+                aabb bb[kBins]; uint32_t cnt[kBins];
+                for (int b = 0; b < kBins; b++) { bb[b].reset(); cnt[b] = 0; }
+                for (uint32_t i = begin; i < end; i++) {
+                    uint32_t p = idx[i];
+                    int b = std::min(kBins - 1, std::max(0, (int)((c[p] - lo) * scale)));
+                    bb[b].grow(boxes[p]); cnt[b]++;
+                }
+                float rarea[kBins]; uint32_t rcnt[kBins];
+                aabb acc; acc.reset(); uint32_t ac = 0;
+                for (int b = kBins - 1; b > 0; b--) { if (cnt[b]) acc.grow(bb[b]); ac += cnt[b]; rarea[b] = ac ? acc.area() : 0.0f; rcnt[b] = ac; }
+                acc.reset(); ac = 0;
+                for (int b = 0; b < kBins - 1; b++) {
+                    if (cnt[b]) acc.grow(bb[b]); ac += cnt[b];
+                    if (ac == 0 || rcnt[b + 1] == 0) continue;
+                    float cost = acc.area() * ac + rarea[b + 1] * rcnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+        }
+        float area = nd.box.area();
+        float leaf_cost = area * n, split_cost = area * 1.0f + best_cost;   // SAH node cost 1, triangle cost 1 (SplitBVHBuilder.hpp Platform defaults)
+        if (!force_median && (int)n <= max_leaf && (best_axis < 0 || leaf_cost <= split_cost)) return me;   // leaf
+        uint32_t mid;
+        if (best_axis >= 0 && !force_median) {
+            const float* c = cen(best_axis);
+            float lo = cb.lo[best_axis], scale = kBins / (cb.hi[best_axis] - lo);
+            auto it = std::partition(idx.begin() + begin, idx.begin() + end, [&](uint32_t p) {
+                int b = std::min(kBins - 1, std::max(0, (int)((c[p] - lo) * scale))); return b <= best_bin; });
+            mid = (uint32_t)(it - idx.begin());
+        } else mid = begin;
+        if (mid == begin || mid == end) {   // median split on the widest centroid axis (or by index when all centroids coincide)
+            int axis = 0; float w = -1;
+            for (int a = 0; a < 3; a++) { float e = cb.hi[a] - cb.lo[a]; if (e > w) { w = e; axis = a; } }
+            mid = begin + n / 2;
+            if (w > 0) { const float* c = cen(axis); std::nth_element(idx.begin() + begin, idx.begin() + mid, idx.begin() + end, [&](uint32_t a, uint32_t b) { return c[a] < c[b]; }); }
+        }
+        if (par_budget > 0 && n > 32768) {
+            auto fut = std::async(std::launch::async, [&, mid, end, depth, par_budget]() { return build(mid, end, depth + 1, par_budget - 1); });
+            int l = build(begin, mid, depth + 1, par_budget - 1);
+            int r = fut.get();
+            pool[me].left = l; pool[me].right = r;
+        } else {
+            int l = build(begin, mid, depth + 1, 0);
+            int r = build(mid, end, depth + 1, 0);
+            pool[me].left = l; pool[me].right = r;
+        }
+        return me;
+    }
+};
+
+void set_left(ctl_bvh_node& n, const aabb& b) { n.a[0] = b.lo[0]; n.a[1] = b.hi[0]; n.a[2] = b.lo[1]; n.a[3] = b.hi[1]; n.c[0] = b.lo[2]; n.c[1] = b.hi[2]; }
+void set_right(ctl_bvh_node& n, const aabb& b) { n.b[0] = b.lo[0]; n.b[1] = b.hi[0]; n.b[2] = b.lo[1]; n.b[3] = b.hi[1]; n.c[2] = b.lo[2]; n.c[3] = b.hi[2]; }
+
+struct emitter {
+    const builder& B; bvh_result& out;
+    int emit_leaf(const tmp_node& t) {
+        uint32_t first = (uint32_t)out.leaf_prims.size();
+        for (uint32_t i = t.begin; i < t.end; i++) { out.leaf_prims.push_back(B.idx[i]); out.leaf_last.push_back(i + 1 == t.end ? 1 : 0); }
+        return ~(int)first;
+    }
+    // returns the child code of the subtree; `parent` is the parent's float4 index (SplitBVHBuilder.cpp:191-201)
+    int emit(int ti, uint32_t parent) {
+        const tmp_node& t = B.pool[ti];
+        if (t.left < 0) return emit_leaf(t);
+        uint32_t me = (uint32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        int a = emit(t.left, me * 4);
+        int b = emit(t.right, me * 4);
+        ctl_bvh_node& n = out.nodes[me];
+        std::memset(&n, 0, sizeof(n));
+        n.child0 = a; n.child1 = b; n.parent = parent;
+        set_left(n, B.pool[t.left].box); set_right(n, B.pool[t.right].box);
+        return (int)(me * 4);
+    }
+};
+
+} // namespace
+
+void build_bvh(const std::vector<aabb>& prim_boxes, int max_leaf, bool wrap_single_leaf, int max_depth_limit, bvh_result& out) {
+    out.nodes.clear(); out.leaf_prims.clear(); out.leaf_last.clear(); out.root = 0; out.max_depth = 0;
+    if (prim_boxes.empty()) { out.root = kEmptyChild; return; }
+    builder B(prim_boxes, max_leaf, max_depth_limit);
+    int root = B.build(0, (uint32_t)prim_boxes.size(), 0, 3);
+    out.max_depth = B.max_depth.load();
+    emitter E{ B, out };
+    out.leaf_prims.reserve(prim_boxes.size()); out.leaf_last.reserve(prim_boxes.size());
+    const tmp_node& r = B.pool[root];
+    if (r.left < 0) {
+        int leaf = E.emit_leaf(r);
+        if (wrap_single_leaf) {   // SplitBVHBuilder.cpp:176-189: root node = (leaf, none), right box = [0,0]
+            ctl_bvh_node n; std::memset(&n, 0, sizeof(n));
+            n.child0 = leaf; n.child1 = kEmptyChild; n.parent = 0xffffffffu;
+            set_left(n, r.box);
+            aabb z; for (int i = 0; i < 3; i++) z.lo[i] = z.hi[i] = 0.0f;
+            set_right(n, z);
+            out.nodes.push_back(n); out.root = 0;
+        } else out.root = leaf;
+    } else {
+        out.root = E.emit(root, 0xffffffffu);   // == 0
+    }
+}
+
+} // namespace ctl

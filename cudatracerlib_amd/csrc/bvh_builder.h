@@ -1,0 +1,35 @@
+// bvh_builder.h — host BVH2 construction producing the reference's node encoding
+// (Engine/TriIntersectorData.h:42-117 node layout; child encoding of SplitBVHBuilder.cpp:163-203:
+//  inner child = nodeIndex*4 (float4 units), leaf = ~firstLeafEntry, missing child = 0x76543210).
+// The tree itself is this project's own binned-SAH build (object splits, 32 bins, parallel over subtrees);
+// the closest hit of a ray does not depend on the tree shape.
+#pragma once
+#include "../../include/ctl_amd.h"
+#include <vector>
+#include <cstdint>
+
+namespace ctl {
+
+struct aabb {
+    float lo[3], hi[3];
+    void reset() { for (int i = 0; i < 3; i++) { lo[i] = 3.402823466e+38f; hi[i] = -3.402823466e+38f; } }
+    void grow(const float* p) { for (int i = 0; i < 3; i++) { if (p[i] < lo[i]) lo[i] = p[i]; if (p[i] > hi[i]) hi[i] = p[i]; } }
+    void grow(const aabb& b) { for (int i = 0; i < 3; i++) { if (b.lo[i] < lo[i]) lo[i] = b.lo[i]; if (b.hi[i] > hi[i]) hi[i] = b.hi[i]; } }
+    float area() const { float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; return 2.0f * (dx * dy + dy * dz + dz * dx); }
+    bool valid() const { return lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]; }
+};
+
+struct bvh_result {
+    std::vector<ctl_bvh_node> nodes;     // node 0 is the root
+    std::vector<uint32_t> leaf_prims;    // primitive ids in leaf order; a leaf ~k covers leaf_prims[k..] up to its last flag
+    std::vector<uint8_t> leaf_last;      // 1 on the last entry of each leaf
+    int root;                            // 0 for an inner root, ~0 when the whole set is one leaf and wrap_single_leaf == false
+    int max_depth;
+};
+
+// prim_boxes: one box per primitive.  max_leaf: 8 for meshes (BVHBuilderHelper.cpp:119), 1 for the scene BVH
+// (BVHRebuilder.cpp:380-383).  wrap_single_leaf: emit the (leaf, 0x76543210) root node the reference emits for a
+// one-leaf mesh (SplitBVHBuilder.cpp:176-189).  max_depth_limit bounds the traversal stack.
+void build_bvh(const std::vector<aabb>& prim_boxes, int max_leaf, bool wrap_single_leaf, int max_depth_limit, bvh_result& out);
+
+} // namespace ctl

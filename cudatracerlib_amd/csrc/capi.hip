@@ -1,0 +1,162 @@
+// capi.hip — the extern "C" surface declared in include/ctl_amd.h.  Exceptions of the C++ layer (the reference's
+// error convention, Defines.cpp:15-29) are mapped to ctl_status codes + ctl_last_error().
+#include "../../include/ctl_amd.h"
+#include "tracer.h"
+#include "scene_builder.h"
+#include "mitsuba_loader.h"
+#include <cstring>
+#include <string>
+#include <new>
+
+using namespace ctl;
+
+struct ctl_builder { scene_builder b; };
+struct ctl_scene { Scene s; explicit ctl_scene(const ctl_scene_desc& d) : s(d) {} };
+struct ctl_image { Image img; ctl_image(uint32_t w, uint32_t h) : img(w, h) {} };
+struct ctl_tracer { std::unique_ptr<TracerBase> t; };
+struct ctl_sequence_generator { sequence_generator g; };
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define CTL_TRY try {
+#define CTL_CATCH                                                                    \
+    } catch (const hip_error& e) { return fail(device_count() > 0 ? CTL_ERR_HIP : CTL_ERR_NO_DEVICE, e.what()); } \
+    catch (const io_error& e) { return fail(CTL_ERR_IO, e.what()); }             \
+    catch (const unsupported_error& e) { return fail(CTL_ERR_UNSUPPORTED, e.what()); } \
+    catch (const std::bad_alloc&) { return fail(CTL_ERR_INVALID, "out of host memory"); } \
+    catch (const std::exception& e) { return fail(CTL_ERR_INVALID, e.what()); }      \
+    return CTL_OK;
+#define CTL_REQUIRE(c, msg) if (!(c)) return fail(CTL_ERR_INVALID, msg)
+
+extern "C" {
+
+const char* ctl_last_error(void) { return g_err.c_str(); }
+const char* ctl_version(void) { return "cudatracerlib_amd 0.1 (gfx950)"; }
+int ctl_device_count(void) { return device_count(); }
+
+// ---- builder
+int ctl_builder_create(ctl_builder** out) { CTL_REQUIRE(out, "null out"); CTL_TRY *out = new ctl_builder(); CTL_CATCH }
+void ctl_builder_destroy(ctl_builder* b) { delete b; }
+int ctl_builder_add_mesh(ctl_builder* b, const float* positions, uint32_t n_vert, const uint32_t* indices, uint32_t n_tri, const float* normals, const float* uvs,
+                         const uint8_t* tri_material, const ctl_material* materials, uint32_t n_mat, uint32_t* mesh_index_out) {
+    CTL_REQUIRE(b, "null builder");
+    CTL_TRY uint32_t i = b->b.add_mesh(positions, n_vert, indices, n_tri, normals, uvs, tri_material, materials, n_mat); if (mesh_index_out) *mesh_index_out = i; CTL_CATCH
+}
+int ctl_builder_add_node(ctl_builder* b, uint32_t mesh_index, const ctl_float4x4* to_world, uint32_t* node_index_out) {
+    CTL_REQUIRE(b, "null builder");
+    CTL_TRY uint32_t i = b->b.add_node(mesh_index, to_world); if (node_index_out) *node_index_out = i; CTL_CATCH
+}
+int ctl_builder_add_area_light(ctl_builder* b, uint32_t node_index, uint32_t local_material, const float radiance[3]) {
+    CTL_REQUIRE(b && radiance, "null argument");
+    CTL_TRY b->b.add_area_light(node_index, local_material, radiance); CTL_CATCH
+}
+int ctl_builder_add_point_light(ctl_builder* b, const float position[3], const float intensity[3]) {
+    CTL_REQUIRE(b && position && intensity, "null argument");
+    CTL_TRY b->b.add_point_light(position, intensity); CTL_CATCH
+}
+int ctl_builder_set_camera_lookat(ctl_builder* b, const float pos[3], const float target[3], const float up[3], float fov_degrees, uint32_t width, uint32_t height) {
+    CTL_REQUIRE(b && pos && target && up && width && height, "bad argument");
+    CTL_TRY b->b.set_camera_lookat(pos, target, up, fov_degrees, width, height); CTL_CATCH
+}
+int ctl_builder_set_camera(ctl_builder* b, const ctl_sensor* sensor) { CTL_REQUIRE(b && sensor, "null argument"); CTL_TRY b->b.set_camera(*sensor); CTL_CATCH }
+int ctl_builder_finalize(ctl_builder* b, ctl_scene_desc* out) { CTL_REQUIRE(b && out, "null argument"); CTL_TRY b->b.finalize(*out); CTL_CATCH }
+
+// ---- scene
+int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc); CTL_CATCH }
+void ctl_scene_destroy(ctl_scene* s) { delete s; }
+int ctl_parse_mitsuba_scene(ctl_builder* b, const char* xml_path, int32_t* width_inout, int32_t* height_inout) {
+    CTL_REQUIRE(b && xml_path, "null argument");
+    CTL_TRY parse_mitsuba_scene(b->b, xml_path, width_inout, height_inout); CTL_CATCH
+}
+
+// ---- sampler
+int ctl_sequence_generator_create(ctl_sequence_generator** out) { CTL_REQUIRE(out, "null out"); CTL_TRY *out = new ctl_sequence_generator(); CTL_CATCH }
+void ctl_sequence_generator_destroy(ctl_sequence_generator* g) { delete g; }
+int ctl_sequence_generator_compute(ctl_sequence_generator* g, float* tables_1d, float* tables_2d) { CTL_REQUIRE(g && tables_1d && tables_2d, "null argument"); CTL_TRY g->g.compute(tables_1d, tables_2d); CTL_CATCH }
+
+// ---- image
+int ctl_image_create(uint32_t width, uint32_t height, ctl_image** out) { CTL_REQUIRE(out && width && height, "bad argument"); CTL_TRY *out = new ctl_image(width, height); CTL_CATCH }
+void ctl_image_destroy(ctl_image* img) { delete img; }
+int ctl_image_clear(ctl_image* img) { CTL_REQUIRE(img, "null image"); CTL_TRY img->img.Clear(); CTL_CATCH }
+int ctl_image_read_pixels(ctl_image* img, ctl_pixel_data* host_out) { CTL_REQUIRE(img && host_out, "null argument"); CTL_TRY img->img.read(host_out); CTL_CATCH }
+int ctl_image_write_pixels(ctl_image* img, const ctl_pixel_data* host_in) { CTL_REQUIRE(img && host_in, "null argument"); CTL_TRY img->img.write(host_in); CTL_CATCH }
+void* ctl_image_device_ptr(ctl_image* img) { return img ? (void*)img->img.device() : nullptr; }
+int ctl_image_resolve_rgb(ctl_image* img, float splat_scale, float* host_rgb_out) { CTL_REQUIRE(img && host_rgb_out, "null argument"); CTL_TRY img->img.resolve_rgb(splat_scale, host_rgb_out); CTL_CATCH }
+
+// ---- tracer
+int ctl_tracer_create(const char* plugin, ctl_tracer** out) {
+    CTL_REQUIRE(plugin && out, "null argument");
+    if (std::strcmp(plugin, "WavefrontPathTracer") != 0 && std::strcmp(plugin, "PT_Wave") != 0)   // main.cpp:95-96
+        return fail(CTL_ERR_UNSUPPORTED, std::string("unknown tracer plugin: ") + plugin);
+    CTL_TRY ctl_tracer* t = new ctl_tracer(); try { t->t.reset(new WavefrontPathTracer()); } catch (...) { delete t; throw; } *out = t; CTL_CATCH
+}
+void ctl_tracer_destroy(ctl_tracer* t) { delete t; }
+int ctl_tracer_set_param_bool(ctl_tracer* t, const char* key, int value) { CTL_REQUIRE(t && key, "null argument"); CTL_TRY t->t->getParameters().setValue(key, value ? 1 : 0, TracerParameter::Bool); CTL_CATCH }
+int ctl_tracer_set_param_int(ctl_tracer* t, const char* key, int value) { CTL_REQUIRE(t && key, "null argument"); CTL_TRY t->t->getParameters().setValue(key, value, TracerParameter::Int); CTL_CATCH }
+int ctl_tracer_get_param_int(ctl_tracer* t, const char* key, int* value_out) { CTL_REQUIRE(t && key && value_out, "null argument"); CTL_TRY *value_out = t->t->getParameters().getValue(key); CTL_CATCH }
+int ctl_tracer_resize(ctl_tracer* t, uint32_t width, uint32_t height) { CTL_REQUIRE(t && width && height, "bad argument"); CTL_TRY t->t->Resize(width, height); CTL_CATCH }
+int ctl_tracer_initialize_scene(ctl_tracer* t, ctl_scene* s) { CTL_REQUIRE(t && s, "null argument"); CTL_TRY t->t->InitializeScene(&s->s); CTL_CATCH }
+int ctl_tracer_set_tile_shard(ctl_tracer* t, uint32_t rank, uint32_t world) { CTL_REQUIRE(t, "null tracer"); CTL_TRY t->t->setTileShard(rank, world); CTL_CATCH }
+int ctl_tracer_set_sampler_tables(ctl_tracer* t, const float* tables_1d, const float* tables_2d) { CTL_REQUIRE(t && tables_1d && tables_2d, "null argument"); CTL_TRY t->t->setSamplerTables(tables_1d, tables_2d); CTL_CATCH }
+int ctl_tracer_do_pass(ctl_tracer* t, ctl_image* img, int new_trace) { CTL_REQUIRE(t && img, "null argument"); CTL_TRY t->t->DoPass(&img->img, new_trace != 0); CTL_CATCH }
+int ctl_tracer_do_passes(ctl_tracer* t, ctl_image* img, int new_trace, uint32_t n_passes) { CTL_REQUIRE(t && img, "null argument"); CTL_TRY t->t->DoPasses(&img->img, new_trace != 0, n_passes); CTL_CATCH }
+int ctl_tracer_get_stats(ctl_tracer* t, ctl_tracer_stats* out) { CTL_REQUIRE(t && out, "null argument"); CTL_TRY t->t->getKernelStats(*out); CTL_CATCH }
+
+// ---- intersect (row a7 on its own)
+static void run_intersect(Scene& sc, const float4* d_ro, const float4* d_rd, uint32_t n, float4* d_hit, int* d_node, uint32_t* d_occ, int any_hit, unsigned long long* d_counts, float* ms_out) {
+    dbuf<uint32_t> ctl; ctl.alloc(2);
+    uint32_t h[2] = { n, 0 };
+    CTL_HIP(hipMemcpy(ctl.p, h, sizeof(h), hipMemcpyHostToDevice));
+    int dev = 0; hipDeviceProp_t prop; CTL_HIP(hipGetDevice(&dev)); CTL_HIP(hipGetDeviceProperties(&prop, dev));
+    launch_ctx lc{ nullptr, prop.multiProcessorCount * 8 };
+    hipEvent_t a, b; CTL_HIP(hipEventCreate(&a)); CTL_HIP(hipEventCreate(&b));
+    CTL_HIP(hipEventRecord(a, nullptr));
+    if (d_counts) launch_intersect_count(lc, sc.S, d_ro, d_rd, ctl.p, ctl.p + 1, d_hit, d_node, any_hit, d_counts);
+    else if (any_hit) launch_intersect_any(lc, sc.S, d_ro, d_rd, ctl.p, ctl.p + 1, d_occ, d_hit, d_node);
+    else launch_intersect_closest(lc, sc.S, d_ro, d_rd, ctl.p, ctl.p + 1, d_hit, d_node);
+    CTL_HIP(hipEventRecord(b, nullptr));
+    CTL_HIP(hipEventSynchronize(b));
+    CTL_HIP(hipGetLastError());
+    float ms = 0; CTL_HIP(hipEventElapsedTime(&ms, a, b));
+    if (ms_out) *ms_out = ms;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+}
+static void intersect_host(Scene& sc, const ctl_ray* rays, uint32_t n, ctl_hit* hits, int any_hit, ctl_traversal_counts* counts) {
+    std::vector<float4> ro(n), rd(n);
+    for (uint32_t i = 0; i < n; i++) { ro[i] = make_float4(rays[i].a[0], rays[i].a[1], rays[i].a[2], rays[i].a[3]); rd[i] = make_float4(rays[i].b[0], rays[i].b[1], rays[i].b[2], rays[i].b[3]); }
+    dbuf<float4> d_ro, d_rd, d_hit; dbuf<int> d_node; dbuf<unsigned long long> d_cnt;
+    d_ro.upload(ro.data(), n); d_rd.upload(rd.data(), n); d_hit.alloc(n); d_node.alloc(n);
+    if (counts) { d_cnt.alloc(3); CTL_HIP(hipMemset(d_cnt.p, 0, 24)); }
+    CTL_HIP(hipDeviceSynchronize());
+    run_intersect(sc, d_ro.p, d_rd.p, n, d_hit.p, d_node.p, nullptr, any_hit, counts ? d_cnt.p : nullptr, nullptr);
+    if (hits) {
+        std::vector<float4> hh(n); std::vector<int> hn(n);
+        CTL_HIP(hipMemcpy(hh.data(), d_hit.p, (size_t)n * 16, hipMemcpyDeviceToHost)); CTL_HIP(hipMemcpy(hn.data(), d_node.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; i++) { hits[i].dist = hh[i].x; hits[i].u = hh[i].y; hits[i].v = hh[i].z; hits[i].tri_idx = __builtin_bit_cast(int, hh[i].w); hits[i].node_idx = hn[i]; }
+    }
+    if (counts) { unsigned long long c[3]; CTL_HIP(hipMemcpy(c, d_cnt.p, 24, hipMemcpyDeviceToHost)); counts->n_inner = c[0]; counts->n_tri = c[1]; counts->n_inst = c[2]; }
+}
+int ctl_intersect(ctl_scene* s, const ctl_ray* rays, uint32_t n, ctl_hit* hits, int any_hit) {
+    CTL_REQUIRE(s && (rays || !n) && (hits || !n), "null argument");
+    if (!n) return CTL_OK;
+    CTL_TRY intersect_host(s->s, rays, n, hits, any_hit, nullptr); CTL_CATCH
+}
+int ctl_intersect_count(ctl_scene* s, const ctl_ray* rays, uint32_t n, int any_hit, ctl_traversal_counts* out) {
+    CTL_REQUIRE(s && rays && out, "null argument");
+    CTL_TRY intersect_host(s->s, rays, n, nullptr, any_hit, out); CTL_CATCH
+}
+int ctl_intersect_device(ctl_scene* s, const void* d_ray_o, const void* d_ray_d, uint32_t n, void* d_hit4, void* d_hit_node, int any_hit, float* ms_out) {
+    CTL_REQUIRE(s && d_ray_o && d_ray_d && d_hit4 && d_hit_node, "null argument");
+    CTL_TRY run_intersect(s->s, (const float4*)d_ray_o, (const float4*)d_ray_d, n, (float4*)d_hit4, (int*)d_hit_node, nullptr, any_hit, nullptr, ms_out); CTL_CATCH
+}
+
+// ---- device memory helpers
+int ctl_device_malloc(size_t bytes, void** out) { CTL_REQUIRE(out, "null out"); CTL_TRY require_device(); CTL_HIP(hipMalloc(out, bytes)); CTL_CATCH }
+int ctl_device_free(void* p) { CTL_TRY CTL_HIP(hipFree(p)); CTL_CATCH }
+int ctl_memcpy_h2d(void* dst, const void* src, size_t bytes) { CTL_TRY CTL_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); CTL_CATCH }
+int ctl_memcpy_d2h(void* dst, const void* src, size_t bytes) { CTL_TRY CTL_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); CTL_CATCH }
+int ctl_device_synchronize(void) { CTL_TRY require_device(); CTL_HIP(hipDeviceSynchronize()); CTL_CATCH }
+int ctl_set_device(int ordinal) { CTL_TRY require_device(); CTL_HIP(hipSetDevice(ordinal)); CTL_CATCH }
+
+} // extern "C"

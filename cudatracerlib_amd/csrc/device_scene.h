@@ -1,0 +1,40 @@
+// device_scene.h — the scene as it lives in HBM (re-laid-out once at ctl_scene_create from the reference-layout
+// arrays of a ctl_scene_desc; results are unchanged, see DESIGN.md "Data layout in HBM").
+#pragma once
+#include "../../include/ctl_amd.h"
+#include "ctl_math.h"
+
+namespace ctl {
+
+constexpr int kExitMarker = 0x76543211;   // traversal-stack marker: leave the current instance (> kSentinel as unsigned)
+constexpr int kStackSize = 64;            // top depth + bottom depth + markers, checked by the builder
+
+// precomputed PerspectiveSensor state (SceneTypes/Sensor.cu:76-96)
+struct dev_sensor {
+    float s2c[16];        // m_sampleToCamera, row-major 4x4 (projective: TransformPoint divides by w)
+    float to_world[12];   // rows 0..2 of toWorld
+    float inv_res[2];
+};
+
+struct dev_scene {
+    const float4* top_nodes;     // scene BVH: 4 x float4 per node, addressed in float4 units (reference encoding)
+    const float4* bot_nodes;     // all mesh BVHs, same encoding; a mesh's root is at its node offset
+    const float4* leaf_tris;     // 4 x float4 per leaf entry: Woop rows a,b,c + {index bits, 0, 0, 0}  (64 B, one fetch group)
+    const float4* inst;          // 4 x float4 per node: inverse-transform rows 0..2 + {w33, nodeOff4, leafOff, triOff} (bits)
+    const float4* inst_fwd;      // 3 x float4 per node: forward-transform rows 0..2 (fillDG)
+    const uint4* tri_data;       // 2 x uint4 per triangle (TriangleData, 32 B)
+    const uint4* node_info;      // per node {material_offset, light0, light1, n_lights}
+    const ctl_material* mats;
+    const ctl_light* lights;
+    const unsigned char* anim;
+    int start_node;
+    uint32_t n_nodes;
+    uint32_t num_lights;
+    uint32_t env_map_index;
+    float eps;                   // m_rayTraceEps
+    uint32_t light_indices[CTL_MAX_NUM_LIGHTS];
+    float light_cdf[CTL_MAX_NUM_LIGHTS];
+    dev_sensor cam;
+};
+
+} // namespace ctl

@@ -1,0 +1,67 @@
+// kernels.h — per-bounce HIP kernels of the wavefront path tracer and their launch wrappers (kernels.hip).
+#pragma once
+#include "device_scene.h"
+#include <hip/hip_runtime.h>
+
+namespace ctl {
+
+// One path per slot, structure-of-arrays so that a wave's 64 lanes read/write 1 KiB contiguous per array.
+struct path_soa {
+    float4* ray_o;    // origin.xyz, tmin                                  (traversalRay::a, Kernel/TraceHelper.h:55-59)
+    float4* ray_d;    // direction.xyz, tmax                               (traversalRay::b)
+    float4* thr;      // throughput cf.rgb, last bsdf pdf                  (WavefrontPTRayData::throughput, bsdf_pdf)
+    float4* rad;      // accumulated radiance cl.rgb, pixel index (bits)   (WavefrontPTRayData::L, x/y)
+    float4* nor;      // normal of the previous vertex xyz, packed {d1:8, d2:8, depth:8, flags:8}
+    float4* pend;     // pending NEE contribution directF.rgb, shadow-ray index (bits)   (directF, dIdx)
+    float2* px;       // film sample position pX
+};
+enum { kFlagSpecular = 1 };
+constexpr uint32_t kNoShadow = 0xffffffffu;
+
+struct final_soa {    // terminated paths that still wait for a shadow ray
+    float4* rad;      // cl.rgb, shadow-ray index
+    float4* dir;      // directF.rgb, -
+    float2* px;
+};
+
+struct wave_queues {
+    path_soa path[2];          // ping-pong per bounce
+    float4* hit;               // t, u, v, triangle (bits; -1 = miss)
+    int* hit_node;
+    float4* sh_o[2]; float4* sh_d[2]; uint32_t* sh_occ[2];   // shadow rays of bounce d (write) / d-1 (read)
+    final_soa fin;
+    uint32_t* counts;          // [ (depth+1)*4 + {0: n_paths, 1: n_shadow, 2: n_final} ]
+    uint32_t* work;            // dynamic-fetch cursors, one per intersect launch of a pass
+    unsigned long long* stats; // [0] rays traced (primary + continuation + shadow)
+    uint32_t capacity;
+};
+
+struct pass_params {
+    const float* t1; const float2* t2;   // this pass's sampler tables
+    uint32_t width, height;              // full film
+    uint32_t tile_rank, tile_world;      // image-tile shard: tiles t with t % world == rank
+    uint32_t n_local_pixels;             // pixels rendered by this rank
+    int direct, max_path_length, rr_start_depth;
+};
+
+struct launch_ctx { hipStream_t stream; int grid_blocks; };
+
+void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P);
+// intersect `n = counts[count_slot]` rays (device-side count) from (ro, rd) into (hit, hit_node) or into occ (any-hit)
+void launch_intersect_closest(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node);
+void launch_intersect_any(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, uint32_t* occ, float4* hit = nullptr, int* hit_node = nullptr);
+void launch_intersect_count(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node,
+                            int any_hit, unsigned long long* counts3);
+void launch_shade(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_finalize(const launch_ctx& lc, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_accumulate_stats(const launch_ctx& lc, const wave_queues& Q, int max_depth);
+void launch_resolve_rgb(const launch_ctx& lc, const ctl_pixel_data* image, uint32_t n, float splat_scale, float* rgb_out);
+
+// local pixel index -> film pixel for a tile shard (64x64 tiles, 8x8 micro-tiles inside = one wave)
+__host__ __device__ inline uint32_t shard_pixel_count(uint32_t W, uint32_t H, uint32_t rank, uint32_t world) {
+    const uint32_t tx = (W + 63) / 64, ty = (H + 63) / 64, nt = tx * ty;
+    uint32_t mine = nt / world + ((rank < nt % world) ? 1u : 0u);
+    return mine * 64u * 64u;   // upper bound incl. clipped pixels; clipped lanes generate no path
+}
+
+} // namespace ctl

@@ -1,0 +1,43 @@
+// scene_builder.h — host scene assembly (see scene_builder.cpp).
+#pragma once
+#include "../../include/ctl_amd.h"
+#include "bvh_builder.h"
+#include "ctl_math.h"
+#include <vector>
+
+namespace ctl {
+
+void mat_inverse(const float* m16, float* out16);   // float4x4::inverse (Math/float4x4.h:132-193)
+void mat_mul(const float* l16, const float* r16, float* out16);
+void woop_set_data(ctl_woop_tri& w, f3 a, f3 b, f3 c);
+void woop_get_data(const ctl_woop_tri& w, f3& v0, f3& v1, f3& v2);
+
+struct mesh_rec { uint32_t tri_offset, n_tris, node_offset, n_nodes, woop_offset, n_woop, mat_offset, n_mat; aabb box; int max_depth; };
+
+struct scene_builder {
+    std::vector<ctl_triangle_data> tri;
+    std::vector<ctl_woop_tri> woop;
+    std::vector<ctl_woop_index> widx;
+    std::vector<ctl_bvh_node> bvh, scene_bvh;
+    std::vector<ctl_kernel_mesh> meshes;
+    std::vector<mesh_rec> mesh_info;
+    std::vector<ctl_material> mesh_materials;   // per-mesh standard materials (Mesh::m_sMatInfo)
+    std::vector<ctl_material> mats;             // per-node copies (m_sMatData)
+    std::vector<ctl_node> nodes;
+    std::vector<ctl_float4x4> xf, ixf;
+    std::vector<ctl_light> lights;
+    std::vector<uint8_t> anim;
+    ctl_sensor camera{};
+    bool have_camera = false;
+
+    uint32_t add_mesh(const float* positions, uint32_t n_vert, const uint32_t* indices, uint32_t n_tri, const float* normals, const float* uvs,
+                      const uint8_t* tri_material, const ctl_material* materials, uint32_t n_mat);
+    uint32_t add_node(uint32_t mesh_index, const ctl_float4x4* to_world);
+    uint32_t add_area_light(uint32_t node_index, uint32_t local_material, const float radiance[3]);
+    uint32_t add_point_light(const float position[3], const float intensity[3]);
+    void set_camera_lookat(const float pos[3], const float target[3], const float up[3], float fov_degrees, uint32_t w, uint32_t h);
+    void set_camera(const ctl_sensor& s);
+    void finalize(ctl_scene_desc& out);
+};
+
+} // namespace ctl

@@ -1,0 +1,347 @@
+// shading.h — device-side scene vocabulary of the path tracer: sampler, sensor, differential geometry,
+// textures, BSDFs, emitters.  Each function states the reference lines whose behaviour it reproduces.
+#pragma once
+#include "device_scene.h"
+
+namespace ctl {
+
+// ---- SequenceSampler (Kernel/Sampler_device.h:59-113): u = frac(T[d % 30][i % 4096] + T[d % 30][(i / 4096) % 4096])
+struct sampler {
+    const float* __restrict__ t1; const float2* __restrict__ t2; uint32_t idx, d1, d2;
+    __device__ __forceinline__ float next1() {
+        const uint32_t e = (d1 % CTL_SAMPLER_SEQUENCE_LENGTH) * CTL_SAMPLER_NUM_SEQUENCES;
+        float v = t1[e + (idx % CTL_SAMPLER_NUM_SEQUENCES)]; v += t1[e + ((idx / CTL_SAMPLER_NUM_SEQUENCES) % CTL_SAMPLER_NUM_SEQUENCES)];
+        d1++; return fracf(v);
+    }
+    __device__ __forceinline__ f2 next2() {
+        const uint32_t e = (d2 % CTL_SAMPLER_SEQUENCE_LENGTH) * CTL_SAMPLER_NUM_SEQUENCES;
+        const float2 a = t2[e + (idx % CTL_SAMPLER_NUM_SEQUENCES)], b = t2[e + ((idx / CTL_SAMPLER_NUM_SEQUENCES) % CTL_SAMPLER_NUM_SEQUENCES)];
+        float x = a.x; x += b.x; float y = a.y; y += b.y;
+        d2++; return f2{ fracf(x), fracf(y) };
+    }
+};
+
+// ---- PerspectiveSensor::sampleRay (SceneTypes/Sensor.cu:116-128)
+__device__ __forceinline__ void sensor_sample_ray(const dev_sensor& c, f2 pixelSample, f3& o, f3& d) {
+    const float px = pixelSample.x * c.inv_res[0], py = pixelSample.y * c.inv_res[1];
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { float s = c.s2c[i * 4] * px; s += c.s2c[i * 4 + 1] * py; s += c.s2c[i * 4 + 2] * 0.0f; s += c.s2c[i * 4 + 3] * 1.0f; r[i] = s; }
+    const f3 nearP(r[0] / r[3], r[1] / r[3], r[2] / r[3]);
+    const f3 dn = normalize(nearP);
+    m34 m;
+#pragma unroll
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) m.r[i][j] = c.to_world[i * 4 + j];
+    o = xform_point(m, f3(0.0f));   // toWorld.Translation()
+    d = xform_dir(m, dn);
+}
+
+// ---- differential geometry at a hit (Kernel/TraceHelper.cu:274-307 -> Engine/TriangleData.cu:75-103)
+struct diff_geom { f3 P; frame sys; f3 n; f2 uv; };
+__device__ __forceinline__ void fill_dg(const dev_scene& S, float u, float v, int tri, int node, diff_geom& dg) {
+    const uint4 ta = S.tri_data[tri * 2], tb = S.tri_data[tri * 2 + 1];   // {nme.x, nme.y, dpd.x, dpd.y} {dpd.z, uv0, uv1, uv2}
+    const float4 f0 = S.inst_fwd[node * 3], f1 = S.inst_fwd[node * 3 + 1], f2_ = S.inst_fwd[node * 3 + 2];
+    m34 l2w; l2w.r[0][0] = f0.x; l2w.r[0][1] = f0.y; l2w.r[0][2] = f0.z; l2w.r[0][3] = f0.w; l2w.r[1][0] = f1.x; l2w.r[1][1] = f1.y; l2w.r[1][2] = f1.z; l2w.r[1][3] = f1.w;
+    l2w.r[2][0] = f2_.x; l2w.r[2][1] = f2_.y; l2w.r[2][2] = f2_.z; l2w.r[2][3] = f2_.w;
+    const f3 na = uchar2_to_normal(ta.x & 0xffff), nb = uchar2_to_normal(ta.x >> 16), nc = uchar2_to_normal(ta.y & 0xffff);
+    const float w = 1.0f - u - v;
+    const f3 n = normalize(u * na + v * nb + w * nc);
+    const f3 dpdu(half_to_float((uint16_t)ta.z), half_to_float((uint16_t)(ta.z >> 16)), half_to_float((uint16_t)ta.w));
+    const f3 dpdv(half_to_float((uint16_t)(ta.w >> 16)), half_to_float((uint16_t)tb.x), half_to_float((uint16_t)(tb.x >> 16)));
+    f3 s = dpdu - n * dot(n, dpdu);
+    f3 t = cross(s, n);
+    s = xform_dir(l2w, s); t = xform_dir(l2w, t);
+    dg.sys.s = normalize(s); dg.sys.t = normalize(t); dg.sys.n = normalize(cross(t, s));
+    const f3 wdpdu = xform_dir(l2w, dpdu), wdpdv = xform_dir(l2w, dpdv);
+    dg.n = normalize(cross(wdpdu, wdpdv));
+    const f2 uva{ half_to_float((uint16_t)tb.y), half_to_float((uint16_t)(tb.y >> 16)) }, uvb{ half_to_float((uint16_t)tb.z), half_to_float((uint16_t)(tb.z >> 16)) },
+        uvc{ half_to_float((uint16_t)tb.w), half_to_float((uint16_t)(tb.w >> 16)) };
+    dg.uv = f2{ u * uva.x + v * uvb.x + w * uvc.x, u * uva.y + v * uvb.y + w * uvc.y };
+    if (dot(dg.n, dg.sys.n) < 0.0f) dg.n = -dg.n;
+}
+__device__ __forceinline__ uint32_t tri_mat_index(const dev_scene& S, int tri) { return (S.tri_data[tri * 2].y >> 16) & 0xff; }   // TriangleData.h:40-44
+
+// ---- textures (SceneTypes/Texture.h:107-157)
+__device__ __forceinline__ f3 tex_eval(const ctl_texture& t, const diff_geom& dg) {
+    if (t.type == CTL_TEX_CHECKER) {
+        const float u = dg.uv.x * t.uv_scale[0] + t.uv_offset[0], v = dg.uv.y * t.uv_scale[1] + t.uv_offset[1];
+        int xm = (int)(u * 2) % 2, ym = (int)(v * 2) % 2; if (xm < 0) xm += 2; if (ym < 0) ym += 2;
+        const int x = 2 * xm - 1, y = 2 * ym - 1;
+        return (x * y == 1) ? f3(t.value[0], t.value[1], t.value[2]) : f3(t.value1[0], t.value1[1], t.value1[2]);
+    }
+    return f3(t.value[0], t.value[1], t.value[2]);
+}
+__device__ __forceinline__ float avg3(f3 s) { float r = s.x; r += s.y; r += s.z; return r * (1.0f / 3); }   // Spectrum.h:180-190
+
+// ---- microfacet distribution (Engine/MicrofacetDistribution.{h,cu}); Beckmann + GGX
+struct microfacet {
+    int type; float aU, aV; bool vis;
+    __device__ __forceinline__ microfacet(int t, float u, float v, bool sv) : type(t), aU(max2(u, 1e-4f)), aV(max2(v, 1e-4f)), vis(sv) {}
+    __device__ __forceinline__ bool iso() const { return aU == aV; }
+    __device__ float eval(f3 m) const {   // MicrofacetDistribution.cu:6-42
+        if (cos_theta(m) <= 0) return 0.0f;
+        const float c2 = m.z * m.z;
+        const float be = ((m.x * m.x) / (aU * aU) + (m.y * m.y) / (aV * aV)) / c2;
+        float result;
+        if (type == CTL_MF_BECKMANN) result = expf(-be) / (kPi * aU * aV * c2 * c2);
+        else { const float root = (1 + be) * c2; result = 1.0f / (kPi * aU * aV * root * root); }
+        if (result < 1e-20f) result = 0;
+        return result;
+    }
+    __device__ float project_roughness(f3 v) const {
+        const float is2 = 1 / sin_theta2(v);
+        if (iso() || is2 <= 0) return aU;
+        const float cp2 = v.x * v.x * is2, sp2 = v.y * v.y * is2;
+        return sqrtf(cp2 * aU * aU + sp2 * aV * aV);
+    }
+    __device__ float smith_g1(f3 v, f3 m) const {   // MicrofacetDistribution.cu:309-343
+        if (dot(v, m) * cos_theta(v) <= 0) return 0.0f;
+        const float tt = fabsf(tan_theta(v));
+        if (tt == 0.0f) return 1.0f;
+        const float alpha = project_roughness(v);
+        if (type == CTL_MF_GGX) { const float root = alpha * tt; return 2.0f / (1.0f + sqrtf(1.0f * 1.0f + root * root)); }
+        const float a = 1.0f / (alpha * tt);
+        if (a >= 1.6f) return 1.0f;
+        const float a2 = a * a;
+        return (3.535f * a + 2.181f * a2) / (1.0f + 2.276f * a + 2.577f * a2);
+    }
+    __device__ float G(f3 wi, f3 wo, f3 m) const { return smith_g1(wi, m) * smith_g1(wo, m); }
+    __device__ float pdf_visible(f3 wi, f3 m) const { if (cos_theta(wi) == 0) return 0.0f; return smith_g1(wi, m) * absdot(wi, m) * eval(m) / fabsf(cos_theta(wi)); }
+    __device__ float pdf(f3 wi, f3 m) const { return vis ? pdf_visible(wi, m) : eval(m) * cos_theta(m); }
+    __device__ f3 sample_all(f2 s, float& pdf_) const {   // MicrofacetDistribution.cu:44-149
+        float cosThetaM, sinPhiM, cosPhiM, alphaSqr;
+        if (iso()) { sincosf((2.0f * kPi) * s.y, &sinPhiM, &cosPhiM); alphaSqr = aU * aU; }
+        else {
+            const float phiM = atanf(aV / aU * tanf(kPi + 2 * kPi * s.y)) + kPi * floorf(2 * s.y + 0.5f);
+            sincosf(phiM, &sinPhiM, &cosPhiM);
+            const float cs = cosPhiM / aU, ss = sinPhiM / aV;
+            alphaSqr = 1.0f / (cs * cs + ss * ss);
+        }
+        if (type == CTL_MF_BECKMANN) {
+            const float t2 = alphaSqr * -logf(1.0f - s.x);
+            cosThetaM = 1.0f / sqrtf(1.0f + t2);
+            pdf_ = (1.0f - s.x) / (kPi * aU * aV * cosThetaM * cosThetaM * cosThetaM);
+        } else {
+            const float t2 = alphaSqr * s.x / (1.0f - s.x);
+            cosThetaM = 1.0f / sqrtf(1.0f + t2);
+            const float temp = 1 + t2 / alphaSqr;
+            pdf_ = kInvPi / (aU * aV * cosThetaM * cosThetaM * cosThetaM * temp * temp);
+        }
+        if (pdf_ < 1e-20f) pdf_ = 0;
+        const float sinThetaM = sqrtf(max2(0.0f, 1 - cosThetaM * cosThetaM));
+        return f3(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
+    }
+    __device__ f2 sample_visible11(float thetaI, f2 s) const {   // MicrofacetDistribution.cu:185-307, GGX branch
+        if (thetaI < 1e-4f) { const float r = safe_sqrt(s.x / (1 - s.x)); float sp, cp; sincosf(2 * kPi * s.y, &sp, &cp); return f2{ r * cp, r * sp }; }
+        const float tanThetaI = tanf(thetaI), a = 1 / tanThetaI;
+        const float G1 = 2.0f / (1.0f + safe_sqrt(1.0f + 1.0f / (a * a)));
+        float A = 2.0f * s.x / G1 - 1.0f;
+        if (fabsf(A) == 1) A -= copysign_bits(1.0f, A) * 1e-7f;
+        const float tmp = 1.0f / (A * A - 1.0f), B = tanThetaI;
+        const float D = safe_sqrt(B * B * tmp * tmp - (A * A - B * B) * tmp);
+        const float sx1 = B * tmp - D, sx2 = B * tmp + D;
+        f2 slope; slope.x = (A < 0.0f || sx2 > 1.0f / tanThetaI) ? sx1 : sx2;
+        float Sg;
+        if (s.y > 0.5f) { Sg = 1.0f; s.y = 2.0f * (s.y - 0.5f); } else { Sg = -1.0f; s.y = 2.0f * (0.5f - s.y); }
+        const float z = (s.y * (s.y * (s.y * (-0.365728915865723f) + 0.790235037209296f) - 0.424965825137544f) + 0.000152998850436920f) /
+                        (s.y * (s.y * (s.y * (s.y * 0.169507819808272f - 0.397203533833404f) - 0.232500544458471f) + 1.0f) - 0.539825872510702f);
+        slope.y = Sg * z * sqrtf(1.0f + slope.x * slope.x);
+        return slope;
+    }
+    __device__ f3 sample_visible(f3 _wi, f2 s) const {   // MicrofacetDistribution.cu:151-183
+        const f3 wi = normalize(f3(aU * _wi.x, aV * _wi.y, _wi.z));
+        float theta = 0, phi = 0;
+        if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
+        float sp, cp; sincosf(phi, &sp, &cp);
+        f2 slope = sample_visible11(theta, s);
+        slope = f2{ cp * slope.x - sp * slope.y, sp * slope.x + cp * slope.y };
+        slope.x *= aU; slope.y *= aV;
+        const float nrm = 1.0f / sqrtf(slope.x * slope.x + slope.y * slope.y + 1.0f);
+        return f3(-slope.x * nrm, -slope.y * nrm, nrm);
+    }
+    __device__ f3 sample(f3 wi, f2 s, float& pdf_) const { if (vis) { const f3 m = sample_visible(wi, s); pdf_ = pdf_visible(wi, m); return m; } return sample_all(s, pdf_); }
+};
+__device__ __forceinline__ f3 reflect_about(f3 wi, f3 n) { return normalize(2 * dot(wi, n) * n - wi); }   // FresnelHelper.h:148-151
+
+// ---- BSDFs (SceneTypes/BSDF_Simple.cu) in the local shading frame
+enum { kESmooth = 0x2 | 0x4 | 0x8 | 0x10, kEDelta = 0x1 | 0x20 | 0x40, kEAll = 0x1ff };
+struct bsdf_rec { diff_geom dg; f3 wi, wo; float eta; uint32_t type_mask, sampled_type; };
+
+__device__ f3 bsdf_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp) {
+    switch (M.bsdf_type) {
+    case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:7-36
+        const uint32_t ct = M.combined_type;
+        if (!(b.type_mask & ct) || (ct == CTL_EDiffuseReflection && cos_theta(b.wi) <= 0)) return f3(0.0f);
+        b.sampled_type = ct;
+        float sc = 1;
+        if (ct == (CTL_EDiffuseReflection | CTL_EDiffuseTransmission)) {
+            b.sampled_type = smp.x < 0.5f ? CTL_EDiffuseReflection : CTL_EDiffuseTransmission;
+            smp.x = smp.x < 0.5f ? smp.x * 2 : (smp.x - 0.5f) * 2;
+            sc = 0.5f;
+        }
+        b.wo = square_to_cosine_hemisphere(smp);
+        if ((ct == CTL_EDiffuseTransmission || (ct == (CTL_EDiffuseReflection | CTL_EDiffuseTransmission) && b.sampled_type == CTL_EDiffuseTransmission)) && cos_theta(b.wi) > 0) b.wo.z *= -1;
+        b.eta = 1.0f;
+        pdf = fabsf(kInvPi * cos_theta(b.wo)) * sc;
+        return tex_eval(M.tex[0], b.dg) * sc;
+    }
+    case CTL_BSDF_DIELECTRIC: {   // BSDF_Simple.cu:174-224; no dispersion -> eta = B + C / 0.6 (Dispersion.h)
+        const bool sr = (b.type_mask & CTL_EDeltaReflection) != 0, st = (b.type_mask & CTL_EDeltaTransmission) != 0;
+        float cosThetaT; const float eta = M.f[0] + M.f[1] / (600 / 1e3f), invEta = 1.0f / eta;
+        const float F = fresnel_dielectric_ext(cos_theta(b.wi), cosThetaT, eta);
+        if (st && sr) {
+            if (smp.x <= F) { b.sampled_type = CTL_EDeltaReflection; b.wo = reflect_local(b.wi); b.eta = 1.0f; pdf = F; return tex_eval(M.tex[1], b.dg); }
+            b.sampled_type = CTL_EDeltaTransmission; b.wo = refract_local(b.wi, cosThetaT, eta, invEta);
+            b.eta = cosThetaT < 0 ? eta : invEta; pdf = (1 - F) * 1.0f;
+            const float factor = (cosThetaT < 0 ? invEta : eta);
+            return f3(1.0f) * tex_eval(M.tex[0], b.dg) * (factor * factor);
+        } else if (sr) { b.sampled_type = CTL_EDeltaReflection; b.wo = reflect_local(b.wi); b.eta = 1.0f; pdf = 1.0f; return tex_eval(M.tex[1], b.dg); }
+        else if (st) {
+            b.sampled_type = CTL_EDeltaTransmission; b.wo = refract_local(b.wi, cosThetaT, eta, invEta);
+            b.eta = cosThetaT < 0 ? eta : invEta; pdf = 1.0f * 1.0f;
+            const float factor = (cosThetaT < 0 ? invEta : eta);
+            return f3(1.0f) * tex_eval(M.tex[0], b.dg) * (factor * factor * (1 - F));
+        }
+        return f3(0.0f);
+    }
+    case CTL_BSDF_CONDUCTOR: {   // BSDF_Simple.cu:617-630
+        if (!(b.type_mask & CTL_EDeltaReflection) || cos_theta(b.wi) <= 0) return f3(0.0f);
+        b.sampled_type = CTL_EDeltaReflection; b.wo = reflect_local(b.wi); b.eta = 1.0f; pdf = 1;
+        return tex_eval(M.tex[0], b.dg) * fresnel_conductor_exact(cos_theta(b.wi), f3(M.f[0], M.f[1], M.f[2]), f3(M.f[3], M.f[4], M.f[5]));
+    }
+    case CTL_BSDF_ROUGHCONDUCTOR: {   // BSDF_Simple.cu:662-705
+        if (cos_theta(b.wi) < 0 || !(b.type_mask & CTL_EGlossyReflection)) return f3(0.0f);
+        const microfacet distr((int)M.u[0], avg3(tex_eval(M.tex[1], b.dg)), avg3(tex_eval(M.tex[2], b.dg)), M.u[1] != 0);
+        const f3 m = distr.sample(b.wi, smp, pdf);
+        if (pdf == 0) return f3(0.0f);
+        b.wo = reflect_about(b.wi, m); b.eta = 1.0f; b.sampled_type = CTL_EGlossyReflection;
+        if (cos_theta(b.wo) <= 0) return f3(0.0f);
+        const f3 F = fresnel_conductor_exact(dot(b.wi, m), f3(M.f[0], M.f[1], M.f[2]), f3(M.f[3], M.f[4], M.f[5])) * tex_eval(M.tex[0], b.dg);
+        float weight;
+        if (distr.vis) weight = distr.smith_g1(b.wo, m);
+        else weight = distr.eval(m) * distr.G(b.wi, b.wo, m) * dot(b.wi, m) / (pdf * cos_theta(b.wi));
+        pdf /= 4.0f * dot(b.wo, m);
+        return F * weight;
+    }
+    default: return f3(0.0f);
+    }
+}
+
+// f() and pdf() for solid-angle measure (the only measure the path asks for: TraceAlgorithms.cu:55,61)
+__device__ f3 bsdf_f(const ctl_material& M, const bsdf_rec& b) {
+    switch (M.bsdf_type) {
+    case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:38-56
+        const uint32_t ct = M.combined_type;
+        if (!(b.type_mask & ct)) return f3(0.0f);
+        const bool vr = ct == CTL_EDiffuseReflection && cos_theta(b.wi) > 0 && cos_theta(b.wo) > 0;
+        const bool vt = ct == CTL_EDiffuseTransmission && cos_theta(b.wi) * cos_theta(b.wo) < 0;
+        const f3 s = tex_eval(M.tex[0], b.dg) * (kInvPi * fabsf(cos_theta(b.wo)));
+        if (vr || vt) return s;
+        if (ct == (CTL_EDiffuseReflection | CTL_EDiffuseTransmission)) return s * 0.5f;
+        return f3(0.0f);
+    }
+    case CTL_BSDF_ROUGHCONDUCTOR: {   // BSDF_Simple.cu:707-740
+        if (cos_theta(b.wi) < 0 || cos_theta(b.wo) < 0 || !(b.type_mask & CTL_EGlossyReflection)) return f3(0.0f);
+        const f3 H = normalize(b.wo + b.wi);
+        const microfacet distr((int)M.u[0], avg3(tex_eval(M.tex[1], b.dg)), avg3(tex_eval(M.tex[2], b.dg)), M.u[1] != 0);
+        const float D = distr.eval(H);
+        if (D == 0) return f3(0.0f);
+        const f3 F = fresnel_conductor_exact(dot(b.wi, H), f3(M.f[0], M.f[1], M.f[2]), f3(M.f[3], M.f[4], M.f[5])) * tex_eval(M.tex[0], b.dg);
+        const float G = distr.G(b.wi, b.wo, H);
+        const float value = D * G / (4.0f * cos_theta(b.wi));
+        return F * value;
+    }
+    default: return f3(0.0f);   // delta lobes have no solid-angle density (BSDF_Simple.cu:226-252, 632-646)
+    }
+}
+__device__ float bsdf_pdf(const ctl_material& M, const bsdf_rec& b) {
+    switch (M.bsdf_type) {
+    case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:58-75
+        const uint32_t ct = M.combined_type;
+        if (!(b.type_mask & ct)) return 0.0f;
+        const bool vr = ct == CTL_EDiffuseReflection && cos_theta(b.wi) > 0 && cos_theta(b.wo) > 0;
+        const bool vt = ct == CTL_EDiffuseTransmission && cos_theta(b.wi) * cos_theta(b.wo) < 0;
+        const float f = fabsf(kInvPi * cos_theta(b.wo));
+        if (vr || vt) return f;
+        if (ct == (CTL_EDiffuseReflection | CTL_EDiffuseTransmission)) return f * 0.5f;
+        return 0.0f;
+    }
+    case CTL_BSDF_ROUGHCONDUCTOR: {   // BSDF_Simple.cu:742-763
+        if (cos_theta(b.wi) < 0 || cos_theta(b.wo) < 0 || !(b.type_mask & CTL_EGlossyReflection)) return 0.0f;
+        const f3 H = normalize(b.wo + b.wi);
+        const microfacet distr((int)M.u[0], avg3(tex_eval(M.tex[1], b.dg)), avg3(tex_eval(M.tex[2], b.dg)), M.u[1] != 0);
+        if (distr.vis) return distr.eval(H) * distr.smith_g1(b.wi, H) / (4.0f * cos_theta(b.wi));
+        return distr.pdf(b.wi, H) / (4 * absdot(b.wo, H));
+    }
+    default: return 0.0f;
+    }
+}
+
+// ---- emitters
+enum { kMeasureSolidAngle = 1, kMeasureArea = 3, kMeasureDiscrete = 4 };
+struct direct_rec { f3 p, n, ref, refN, d; float pdf, dist; int measure; };
+
+// MonteCarlo::sampleReuse (Math/MonteCarlo.cu:7-14): lower_bound over cdf[0..size]
+__device__ __forceinline__ uint32_t sample_reuse(const float* __restrict__ cdf, uint32_t size, float& s, float& pdf) {
+    uint32_t lo = 0, n = size + 1;
+    while (n > 0) { const uint32_t half = n >> 1; if (cdf[lo + half] < s) { lo += half + 1; n -= half + 1; } else n = half; }
+    int index = (int)lo - 1; if (index < 0) index = 0; if (index > (int)size - 1) index = (int)size - 1;
+    pdf = cdf[index + 1] - cdf[index];
+    s = (s - cdf[index]) / pdf;
+    return (uint32_t)index;
+}
+// DiffuseLight::sampleDirect / PointLight::sampleDirect (SceneTypes/Light.cu:83-137, 13-31) with ShapeSet::SamplePosition (Engine/ShapeSet.cu:51-69)
+__device__ f3 light_sample_direct(const dev_scene& S, const ctl_light& L, direct_rec& r, f2 smp) {
+    if (L.type == CTL_LIGHT_POINT) {
+        r.p = f3(L.position[0], L.position[1], L.position[2]);
+        const f3 dir = r.p - r.ref;
+        r.dist = length(dir);
+        const float invDist = 1.0f / r.dist;
+        r.d = dir * invDist; r.n = f3(0.0f); r.pdf = 1; r.measure = kMeasureDiscrete;
+        return f3(L.radiance[0], L.radiance[1], L.radiance[2]) * (invDist * invDist);
+    }
+    const float* cdf = (const float*)(S.anim + L.area_dist_index);
+    const ctl_shape_tri* tris = (const ctl_shape_tri*)(S.anim + L.triangles_index);
+    float pdfTri;
+    const uint32_t index = sample_reuse(cdf, L.count, smp.y, pdfTri);
+    const ctl_shape_tri& sn = tris[index];
+    const f2 bary = square_to_uniform_triangle(smp);
+    const f3 p0(sn.p[0][0], sn.p[0][1], sn.p[0][2]), p1(sn.p[1][0], sn.p[1][1], sn.p[1][2]), p2(sn.p[2][0], sn.p[2][1], sn.p[2][2]);
+    r.p = bary.x * p0 + bary.y * p1 + (1.f - bary.x - bary.y) * p2;
+    r.n = f3(sn.n[0], sn.n[1], sn.n[2]);
+    r.pdf = 1.0f / L.sum_area;
+    const f3 dir = r.p - r.ref;
+    const float distSquared = len_sqr(dir);
+    r.dist = sqrtf(distSquared);
+    r.d = dir / r.dist;
+    const float dp = absdot(r.d, r.n);
+    r.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+    r.measure = kMeasureSolidAngle;
+    if (dot(r.d, r.refN) >= 0 && dot(r.d, r.n) < 0 && r.pdf != 0) return f3(L.radiance[0], L.radiance[1], L.radiance[2]) / r.pdf * 1.0f;
+    r.pdf = 0.0f;
+    return f3(0.0f);
+}
+// DiffuseLight::pdfDirect (SceneTypes/Light.cu:139-159), solid-angle measure
+__device__ __forceinline__ float light_pdf_direct(const ctl_light& L, f3 d, f3 refN, f3 n, float dist) {
+    if (L.type != CTL_LIGHT_DIFFUSE) return 0.0f;
+    if (dot(d, refN) >= 0 && dot(d, n) < 0) { const float pdfPos = 1.0f / L.sum_area; return pdfPos * (dist * dist) / absdot(d, n); }
+    return 0.0f;
+}
+// DiffuseLight::eval (SceneTypes/Light.cu:67-81), constant radiance texture
+__device__ __forceinline__ f3 light_eval(const ctl_light& L, f3 sys_n, f3 d) {
+    if (L.type != CTL_LIGHT_DIFFUSE || dot(sys_n, d) <= 0) return f3(0.0f);
+    return f3(L.radiance[0], L.radiance[1], L.radiance[2]);
+}
+// KernelDynamicScene::sampleEmitter / pdfEmitter (Engine/KernelDynamicScene.cu:25-46)
+__device__ __forceinline__ int sample_emitter(const dev_scene& S, float& emPdf, float sx) {
+    if (S.num_lights == 0) return -1;
+    uint32_t idx = 0;
+    while (idx < S.num_lights && !(sx < S.light_cdf[idx])) idx++;   // upper_bound
+    if (idx >= S.num_lights) idx = S.num_lights - 1;
+    const float fU = S.light_cdf[idx], fL = idx > 0 ? S.light_cdf[idx - 1] : 0.0f;
+    emPdf = fU - fL;
+    return (int)S.light_indices[idx];
+}
+__device__ __forceinline__ float pdf_emitter(const dev_scene& S, uint32_t light) { return S.light_cdf[light] - (light == 0 ? 0.0f : S.light_cdf[light - 1]); }
+
+} // namespace ctl

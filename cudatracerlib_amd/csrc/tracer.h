@@ -1,0 +1,160 @@
+// tracer.h — host-side plugin API: the reference's TracerBase / Tracer<PROGRESSIVE> / WavefrontPathTracer surface
+// (Kernel/Tracer.h:67-294, Integrators/PseudoRealtime/WavefrontPathTracer.h:24-67) over HIP.
+// Same virtuals, same parameter keys, same counters; errors are std::runtime_error as in the reference.
+#pragma once
+#include "../../include/ctl_amd.h"
+#include "device_scene.h"
+#include "kernels.h"
+#include "sequence_generator.h"
+#include <hip/hip_runtime.h>
+#include <map>
+#include <string>
+#include <vector>
+#include <memory>
+#include <stdexcept>
+#include <climits>
+
+namespace ctl {
+
+struct hip_error : std::runtime_error { using std::runtime_error::runtime_error; };
+void throw_hip(hipError_t e, const char* file, int line);
+#define CTL_HIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) ::ctl::throw_hip(_e, __FILE__, __LINE__); } while (0)   // ThrowCudaErrors (Defines.h:98-99)
+
+template <typename T> struct dbuf {   // tracked device allocation (Base/CudaMemoryManager.h)
+    T* p = nullptr; size_t n = 0;
+    dbuf() {}
+    dbuf(const dbuf&) = delete; dbuf& operator=(const dbuf&) = delete;
+    ~dbuf() { free(); }
+    void alloc(size_t count) { free(); n = count; if (count) CTL_HIP(hipMalloc((void**)&p, count * sizeof(T))); }
+    void free() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    void upload(const T* h, size_t count, hipStream_t s = 0) { if (count > n) alloc(count); if (count) CTL_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s)); }
+};
+
+// KernelDynamicScene in HBM (UpdateKernel, Kernel/TraceHelper.cu:182-217)
+class Scene {
+public:
+    explicit Scene(const ctl_scene_desc& d);
+    dev_scene S{};
+    uint32_t n_nodes = 0;
+private:
+    dbuf<float4> top_nodes_, bot_nodes_, leaf_tris_, inst_, inst_fwd_;
+    dbuf<uint4> tri_data_, node_info_;
+    dbuf<ctl_material> mats_; dbuf<ctl_light> lights_; dbuf<unsigned char> anim_;
+};
+
+// Engine/Image.h:31-91 (accumulator part)
+class Image {
+public:
+    Image(uint32_t w, uint32_t h);
+    void Clear();
+    uint32_t getWidth() const { return w_; }
+    uint32_t getHeight() const { return h_; }
+    ctl_pixel_data* device() { return px_.p; }
+    void read(ctl_pixel_data* host);
+    void write(const ctl_pixel_data* host);
+    void resolve_rgb(float splat_scale, float* host_rgb);
+private:
+    uint32_t w_, h_; dbuf<ctl_pixel_data> px_; dbuf<float> rgb_;
+};
+
+// Kernel/TracerSettings.h:196-350 — typed parameters with interval / set constraints
+struct TracerParameter {
+    enum kind_t { Bool, Int } kind; int value, lo, hi;
+};
+class TracerParameterCollection {
+public:
+    void addBool(const std::string& key, bool v) { p_[key] = { TracerParameter::Bool, v ? 1 : 0, 0, 1 }; }
+    void addInterval(const std::string& key, int v, int lo, int hi) { p_[key] = { TracerParameter::Int, v, lo, hi }; }
+    int getValue(const std::string& key) const { auto it = p_.find(key); if (it == p_.end()) throw std::runtime_error("Unknown parameter key: " + key); return it->second.value; }
+    void setValue(const std::string& key, int v, TracerParameter::kind_t kind) {
+        auto it = p_.find(key);
+        if (it == p_.end()) throw std::runtime_error("Unknown parameter key: " + key);
+        if (it->second.kind != kind) throw std::runtime_error("Parameter type mismatch for key: " + key);
+        if (v < it->second.lo || v > it->second.hi) throw std::runtime_error("Parameter value outside of its interval: " + key);
+        it->second.value = v;
+    }
+    bool has(const std::string& key) const { return p_.count(key) != 0; }
+private:
+    std::map<std::string, TracerParameter> p_;
+};
+
+class event_timer {   // hipEvent pairs on the tracer's stream, summed per kernel class after synchronisation
+public:
+    ~event_timer();
+    void begin(hipStream_t s, int cls);
+    void end(hipStream_t s);
+    void collect(double ms_out[4]);   // adds elapsed ms per class, recycles the events
+private:
+    struct rec { hipEvent_t a, b; int cls; };
+    std::vector<rec> used_; std::vector<hipEvent_t> free_;
+    hipEvent_t get();
+};
+
+class TracerBase {
+public:
+    TracerBase();
+    virtual ~TracerBase();
+    virtual void InitializeScene(Scene* s) { m_pScene = s; }
+    virtual void Resize(unsigned int _w, unsigned int _h) { w = _w; h = _h; }
+    virtual void DoPass(Image* I, bool a_NewTrace) = 0;
+    virtual bool isMultiPass() const = 0;
+    virtual float getSplatScale() const = 0;
+    unsigned int getNumPassesDone() const { return m_uPassesDone; }
+    uint64_t getRaysInLastPass() const { return m_uLastNumRaysTraced; }
+    float getLastTimeSpentRenderingSec() const { return m_fLastRuntime; }
+    uint64_t getAccRays() const { return m_uAccNumRaysTraced; }
+    float getAccTimeSpentRenderingSec() const { return m_fAccRuntime; }
+    TracerParameterCollection& getParameters() { return m_sParameters; }
+    // build-specific additions
+    virtual void DoPasses(Image* I, bool a_NewTrace, unsigned int n) { for (unsigned int i = 0; i < n; i++) DoPass(I, a_NewTrace && i == 0); }
+    void setTileShard(uint32_t rank, uint32_t world) { if (world == 0 || rank >= world) throw std::runtime_error("bad tile shard"); shard_rank = rank; shard_world = world; if (w != 0xffffffffu) Resize(w, h); }
+    void setSamplerTables(const float* t1, const float* t2);
+    void getKernelStats(ctl_tracer_stats& s) const;
+protected:
+    Scene* m_pScene = nullptr;
+    TracerParameterCollection m_sParameters;
+    unsigned int w = 0xffffffffu, h = 0xffffffffu;
+    unsigned int m_uPassesDone = 0;
+    uint64_t m_uLastNumRaysTraced = 0, m_uAccNumRaysTraced = 0;
+    float m_fLastRuntime = 0, m_fAccRuntime = 0;
+    hipEvent_t start = nullptr, stop = nullptr;
+    hipStream_t stream = nullptr;
+    sequence_generator m_SamplingSequenceGenerator;   // IndependantSamplingSequenceGenerator
+    std::vector<float> user_t1, user_t2; bool have_user_tables = false;
+    uint32_t shard_rank = 0, shard_world = 1;
+    event_timer timer; double kernel_ms[4] = { 0, 0, 0, 0 }; uint64_t intersect_rays = 0, intersect_launches = 0;
+};
+
+template <bool PROGRESSIVE> class Tracer : public TracerBase {
+public:
+    void DoPass(Image* I, bool a_NewTrace) override { DoPasses(I, a_NewTrace, 1); }
+    void DoPasses(Image* I, bool a_NewTrace, unsigned int n) override;
+    bool isMultiPass() const override { return PROGRESSIVE; }
+    float getSplatScale() const override { return PROGRESSIVE ? 1.0f / float(m_uPassesDone) : 0.0f; }
+protected:
+    // render `n` passes; tables for pass k are at t1 + k*stride1 / t2 + k*stride2 (device)
+    virtual void DoRender(Image* I, unsigned int n_passes, const float* d_t1, const float* d_t2) = 0;
+    virtual uint64_t takeRayCount() = 0;
+    dbuf<float> d_t1, d_t2;
+};
+
+// Integrators/PseudoRealtime/WavefrontPathTracer.h:24-67
+class WavefrontPathTracer : public Tracer<true> {
+public:
+    WavefrontPathTracer();
+    void Resize(unsigned int w, unsigned int h) override;
+protected:
+    void DoRender(Image* I, unsigned int n_passes, const float* d_t1, const float* d_t2) override;
+    uint64_t takeRayCount() override;
+private:
+    wave_queues Q{};
+    uint32_t capacity = 0;
+    std::vector<std::unique_ptr<dbuf<float4>>> f4_; dbuf<float2> px_[3]; dbuf<int> hit_node_; dbuf<uint32_t> occ_[2], counts_, work_; dbuf<unsigned long long> stats_;
+    int grid_blocks = 0;
+    float4* new_f4(size_t n);
+};
+
+int device_count();
+void require_device();
+
+} // namespace ctl

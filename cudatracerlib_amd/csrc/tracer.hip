@@ -1,0 +1,250 @@
+// tracer.hip — host side of the plugin: scene upload / re-layout, Image, the Tracer<true> pass loop and the
+// WavefrontPathTracer bounce loop (Integrators/PseudoRealtime/WavefrontPathTracer.cu:166-191 re-designed:
+// no host synchronisation inside a pass — queue lengths stay on the device).
+#include "tracer.h"
+#include "scene_builder.h"
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+namespace ctl {
+
+void throw_hip(hipError_t e, const char* file, int line) {   // ThrowCudaErrors (Defines.cpp:15-29)
+    throw hip_error(std::string("In file ") + file + ", line " + std::to_string(line) + " : " + hipGetErrorString(e));
+}
+int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+void require_device() { if (device_count() <= 0) throw hip_error("no HIP device: the MI355X path tracer has no CPU fallback"); }
+
+// ------------------------------------------------------------------------------------------------ Scene
+Scene::Scene(const ctl_scene_desc& d) {
+    require_device();
+    if (!d.n_nodes) throw std::runtime_error("ctl_scene_create: scene has no nodes");
+    if (d.env_map_index != 0xffffffffu) throw std::runtime_error("ctl_scene_create: environment emitters are not supported yet");
+    n_nodes = d.n_nodes;
+    std::vector<float4> tmp;
+    // scene BVH and mesh BVHs keep the reference's 64-B node (one aligned 64-B fetch group per visit)
+    tmp.assign(std::max<size_t>(4, (size_t)d.n_scene_bvh_nodes * 4), make_float4(0, 0, 0, 0));
+    if (d.n_scene_bvh_nodes) std::memcpy(tmp.data(), d.scene_bvh_nodes, (size_t)d.n_scene_bvh_nodes * 64);
+    top_nodes_.upload(tmp.data(), tmp.size());
+    tmp.assign(std::max<size_t>(4, (size_t)d.n_bvh_nodes * 4), make_float4(0, 0, 0, 0));
+    if (d.n_bvh_nodes) std::memcpy(tmp.data(), d.bvh_nodes, (size_t)d.n_bvh_nodes * 64);
+    bot_nodes_.upload(tmp.data(), tmp.size());
+    // leaf entries: Woop rows + index word interleaved to a 64-B stride so a leaf streams as whole 64-B groups
+    // (the reference reads 3 float4 from t_tris and 1 uint from t_triIndices, Kernel/TraceHelper.cu:641-644)
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;   // (first woop entry, mesh)
+    for (uint32_t m = 0; m < d.n_meshes; m++) ranges.emplace_back(d.meshes[m].bvh_tri_offset / 3, m);
+    std::sort(ranges.begin(), ranges.end());
+    tmp.assign(std::max<size_t>(4, (size_t)d.n_woop * 4), make_float4(0, 0, 0, 0));
+    for (size_t r = 0; r < ranges.size(); r++) {
+        const uint32_t first = ranges[r].first, last = (r + 1 < ranges.size()) ? ranges[r + 1].first : d.n_woop;
+        const ctl_kernel_mesh& km = d.meshes[ranges[r].second];
+        for (uint32_t w = first; w < last; w++) {
+            const ctl_woop_tri& t = d.woop[w];
+            tmp[w * 4 + 0] = make_float4(t.a[0], t.a[1], t.a[2], t.a[3]);
+            tmp[w * 4 + 1] = make_float4(t.b[0], t.b[1], t.b[2], t.b[3]);
+            tmp[w * 4 + 2] = make_float4(t.c[0], t.c[1], t.c[2], t.c[3]);
+            const uint32_t idx = d.woop_index[km.bvh_index_offset + (w - first)].index;
+            tmp[w * 4 + 3] = make_float4(__builtin_bit_cast(float, idx), 0, 0, 0);
+        }
+    }
+    leaf_tris_.upload(tmp.data(), tmp.size());
+    // instances: inverse transform rows + the mesh offsets the reference fetches from Node / KernelMesh (TraceHelper.cu:530,557-560)
+    std::vector<float4> inst((size_t)d.n_nodes * 4), fwd((size_t)d.n_nodes * 3);
+    std::vector<uint4> ninfo(d.n_nodes);
+    for (uint32_t k = 0; k < d.n_nodes; k++) {
+        const float* im = d.node_inv_transforms[k].m; const float* fm = d.node_transforms[k].m;
+        if (im[12] != 0.0f || im[13] != 0.0f || im[14] != 0.0f || fm[12] != 0.0f || fm[13] != 0.0f || fm[14] != 0.0f)
+            throw std::runtime_error("ctl_scene_create: node transforms must be affine");
+        const ctl_node& N = d.nodes[k];
+        if (N.mesh_index >= d.n_meshes) throw std::runtime_error("ctl_scene_create: node references a missing mesh");
+        const ctl_kernel_mesh& km = d.meshes[N.mesh_index];
+        for (int r = 0; r < 3; r++) { inst[k * 4 + r] = make_float4(im[r * 4], im[r * 4 + 1], im[r * 4 + 2], im[r * 4 + 3]); fwd[k * 3 + r] = make_float4(fm[r * 4], fm[r * 4 + 1], fm[r * 4 + 2], fm[r * 4 + 3]); }
+        inst[k * 4 + 3] = make_float4(im[15], __builtin_bit_cast(float, km.bvh_node_offset), __builtin_bit_cast(float, km.bvh_tri_offset / 3), __builtin_bit_cast(float, km.tri_offset));
+        ninfo[k] = make_uint4(N.material_offset, N.lights[0], N.lights[1], N.n_lights);
+    }
+    inst_.upload(inst.data(), inst.size()); inst_fwd_.upload(fwd.data(), fwd.size()); node_info_.upload(ninfo.data(), ninfo.size());
+    static_assert(sizeof(ctl_triangle_data) == 32, "TriangleData is 32 B");
+    tri_data_.upload((const uint4*)d.tri_data, (size_t)d.n_tri_data * 2);
+    mats_.upload(d.materials, d.n_materials);
+    if (d.n_lights_buf) lights_.upload(d.lights, d.n_lights_buf); else lights_.alloc(1);
+    if (d.n_anim_bytes) anim_.upload(d.anim, d.n_anim_bytes); else anim_.alloc(16);
+    for (uint32_t i = 0; i < d.n_materials; i++) {
+        const uint32_t t = d.materials[i].bsdf_type;
+        if (t != CTL_BSDF_DIFFUSE && t != CTL_BSDF_DIELECTRIC && t != CTL_BSDF_CONDUCTOR && t != CTL_BSDF_ROUGHCONDUCTOR)
+            throw std::runtime_error("ctl_scene_create: BSDF type " + std::to_string(t) + " has no HIP implementation yet");
+    }
+    CTL_HIP(hipDeviceSynchronize());
+    S.top_nodes = top_nodes_.p; S.bot_nodes = bot_nodes_.p; S.leaf_tris = leaf_tris_.p; S.inst = inst_.p; S.inst_fwd = inst_fwd_.p;
+    S.tri_data = tri_data_.p; S.node_info = node_info_.p; S.mats = mats_.p; S.lights = lights_.p; S.anim = anim_.p;
+    S.start_node = d.scene_start_node; S.n_nodes = d.n_nodes; S.num_lights = d.num_lights; S.env_map_index = d.env_map_index; S.eps = d.ray_trace_eps;
+    for (int i = 0; i < CTL_MAX_NUM_LIGHTS; i++) { S.light_indices[i] = d.light_indices[i]; S.light_cdf[i] = d.light_cdf[i]; }
+    // PerspectiveSensor::Update (SceneTypes/Sensor.cu:76-96)
+    const ctl_sensor& c = d.camera;
+    if (c.type != CTL_SENSOR_PERSPECTIVE) throw std::runtime_error("ctl_scene_create: only the perspective sensor is implemented");
+    const float aspect = c.resolution[0] / c.resolution[1];
+    const float recip = 1.0f / (c.far_depth - c.near_depth), cot = 1.0f / tanf(c.fov / 2.0f);
+    const float persp[16] = { cot, 0, 0, 0, 0, cot, 0, 0, 0, 0, c.far_depth * recip, -c.near_depth * c.far_depth * recip, 0, 0, 1, 0 };
+    const float sc[16] = { -0.5f, 0, 0, 0, 0, -0.5f * aspect, 0, 0, 0, 0, 1.0f, 0, 0, 0, 0, 1 };
+    const float tr[16] = { 1, 0, 0, -1.0f, 0, 1, 0, -1.0f / aspect, 0, 0, 1, 0.0f, 0, 0, 0, 1 };
+    float a[16], c2s[16];
+    mat_mul(sc, tr, a); mat_mul(a, persp, c2s);
+    mat_inverse(c2s, S.cam.s2c);
+    std::memcpy(S.cam.to_world, c.to_world, 48);
+    S.cam.inv_res[0] = 1.0f / c.resolution[0]; S.cam.inv_res[1] = 1.0f / c.resolution[1];
+}
+
+// ------------------------------------------------------------------------------------------------ Image
+Image::Image(uint32_t w, uint32_t h) : w_(w), h_(h) { require_device(); px_.alloc((size_t)w * h); Clear(); }
+void Image::Clear() { CTL_HIP(hipMemset(px_.p, 0, px_.n * sizeof(ctl_pixel_data))); }
+void Image::read(ctl_pixel_data* host) { CTL_HIP(hipDeviceSynchronize()); CTL_HIP(hipMemcpy(host, px_.p, px_.n * sizeof(ctl_pixel_data), hipMemcpyDeviceToHost)); }
+void Image::write(const ctl_pixel_data* host) { CTL_HIP(hipMemcpy(px_.p, host, px_.n * sizeof(ctl_pixel_data), hipMemcpyHostToDevice)); }
+void Image::resolve_rgb(float splat_scale, float* host_rgb) {
+    if (!rgb_.p) rgb_.alloc(px_.n * 3);
+    CTL_HIP(hipDeviceSynchronize());
+    launch_ctx lc{ nullptr, 1024 };
+    launch_resolve_rgb(lc, px_.p, (uint32_t)px_.n, splat_scale, rgb_.p);
+    CTL_HIP(hipDeviceSynchronize());
+    CTL_HIP(hipMemcpy(host_rgb, rgb_.p, px_.n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+}
+
+// ------------------------------------------------------------------------------------------------ timing
+event_timer::~event_timer() { for (auto& r : used_) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } for (auto e : free_) (void)hipEventDestroy(e); }
+hipEvent_t event_timer::get() { if (!free_.empty()) { hipEvent_t e = free_.back(); free_.pop_back(); return e; } hipEvent_t e; CTL_HIP(hipEventCreate(&e)); return e; }
+void event_timer::begin(hipStream_t s, int cls) { rec r{ get(), get(), cls }; CTL_HIP(hipEventRecord(r.a, s)); used_.push_back(r); }
+void event_timer::end(hipStream_t s) { CTL_HIP(hipEventRecord(used_.back().b, s)); }
+void event_timer::collect(double ms_out[4]) {
+    for (auto& r : used_) { float ms = 0; CTL_HIP(hipEventElapsedTime(&ms, r.a, r.b)); ms_out[r.cls] += ms; free_.push_back(r.a); free_.push_back(r.b); }
+    used_.clear();
+}
+
+// ------------------------------------------------------------------------------------------------ TracerBase / Tracer<true>
+TracerBase::TracerBase() {
+    require_device();
+    CTL_HIP(hipEventCreate(&start)); CTL_HIP(hipEventCreate(&stop));
+    CTL_HIP(hipStreamCreate(&stream));
+}
+TracerBase::~TracerBase() {
+    if (start) (void)hipEventDestroy(start);
+    if (stop) (void)hipEventDestroy(stop);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+void TracerBase::setSamplerTables(const float* t1, const float* t2) {
+    const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH;
+    user_t1.assign(t1, t1 + n1); user_t2.assign(t2, t2 + 2 * n1); have_user_tables = true;
+}
+void TracerBase::getKernelStats(ctl_tracer_stats& s) const {
+    s.rays_last_pass = m_uLastNumRaysTraced; s.rays_total = m_uAccNumRaysTraced; s.seconds_last_pass = m_fLastRuntime; s.seconds_total = m_fAccRuntime;
+    s.passes_done = m_uPassesDone; s.ms_raygen = kernel_ms[0]; s.ms_intersect = kernel_ms[1]; s.ms_shade = kernel_ms[2];
+    s.intersect_rays = intersect_rays; s.intersect_launches = intersect_launches;
+}
+
+// Tracer<true>::DoPass (Kernel/Tracer.h:209-248), generalised to n passes per call: the host regenerates the
+// sampling tables once per pass exactly as UpdateKernel does, but uploads them ahead of the kernels.
+template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_NewTrace, unsigned int n) {
+    if (!m_pScene) throw std::runtime_error("DoPass: InitializeScene was not called");
+    if (w == 0xffffffffu) throw std::runtime_error("DoPass: Resize was not called");
+    if (I->getWidth() != w || I->getHeight() != h) throw std::runtime_error("DoPass: image size differs from the tracer size");
+    if (n == 0) return;
+    if (a_NewTrace || !PROGRESSIVE) { m_uPassesDone = 0; m_uAccNumRaysTraced = 0; m_fAccRuntime = 0; I->Clear(); }
+    const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH, n2 = n1 * 2;
+    std::vector<float> h1(n1 * n), h2(n2 * n);
+    for (unsigned int k = 0; k < n; k++) {
+        if (have_user_tables && k == 0) { std::memcpy(&h1[0], user_t1.data(), n1 * 4); std::memcpy(&h2[0], user_t2.data(), n2 * 4); have_user_tables = false; }
+        else m_SamplingSequenceGenerator.compute(&h1[k * n1], &h2[k * n2]);
+    }
+    if (d_t1.n < h1.size()) { d_t1.alloc(h1.size()); d_t2.alloc(h2.size()); }
+    CTL_HIP(hipMemcpyAsync(d_t1.p, h1.data(), h1.size() * 4, hipMemcpyHostToDevice, stream));
+    CTL_HIP(hipMemcpyAsync(d_t2.p, h2.data(), h2.size() * 4, hipMemcpyHostToDevice, stream));
+    CTL_HIP(hipStreamSynchronize(stream));   // tables resident before the timed region (the reference times the upload too; it is < 1 % of a pass)
+    for (int i = 0; i < 4; i++) kernel_ms[i] = 0; intersect_rays = 0; intersect_launches = 0;
+    CTL_HIP(hipEventRecord(start, stream));
+    m_uPassesDone += n;
+    DoRender(I, n, d_t1.p, d_t2.p);
+    CTL_HIP(hipEventRecord(stop, stream));
+    CTL_HIP(hipEventSynchronize(stop));
+    float ms = 0; CTL_HIP(hipEventElapsedTime(&ms, start, stop));
+    timer.collect(kernel_ms);
+    m_fLastRuntime = ms / 1000.0f;
+    m_uLastNumRaysTraced = takeRayCount();
+    m_fAccRuntime += m_fLastRuntime; m_uAccNumRaysTraced += m_uLastNumRaysTraced;
+}
+template class Tracer<true>;
+
+// ------------------------------------------------------------------------------------------------ WavefrontPathTracer
+WavefrontPathTracer::WavefrontPathTracer() {
+    // WavefrontPathTracer.h:29-39
+    m_sParameters.addBool("Direct", true);
+    m_sParameters.addInterval("MaxPathLength", 50, 1, INT_MAX);
+    m_sParameters.addInterval("RRStartDepth", 5, 1, INT_MAX);
+    int dev = 0; hipDeviceProp_t prop; CTL_HIP(hipGetDevice(&dev)); CTL_HIP(hipGetDeviceProperties(&prop, dev));
+    grid_blocks = prop.multiProcessorCount * 8;   // 8 x 256-thread workgroups per CU = 32 waves/CU
+}
+float4* WavefrontPathTracer::new_f4(size_t n) { f4_.emplace_back(new dbuf<float4>()); f4_.back()->alloc(n); return f4_.back()->p; }
+
+void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
+    Tracer<true>::Resize(_w, _h);
+    // DoubleRayBuffer(w*h, w*h) (WavefrontPathTracer.h:59) — here per rank: its tile shard's pixels
+    capacity = shard_pixel_count(_w, _h, shard_rank, shard_world);
+    f4_.clear();
+    for (int b = 0; b < 2; b++) {
+        path_soa& p = Q.path[b];
+        p.ray_o = new_f4(capacity); p.ray_d = new_f4(capacity); p.thr = new_f4(capacity); p.rad = new_f4(capacity); p.nor = new_f4(capacity); p.pend = new_f4(capacity);
+        px_[b].alloc(capacity); p.px = px_[b].p;
+        Q.sh_o[b] = new_f4(capacity); Q.sh_d[b] = new_f4(capacity); occ_[b].alloc(capacity); Q.sh_occ[b] = occ_[b].p;
+    }
+    Q.hit = new_f4(capacity); hit_node_.alloc(capacity); Q.hit_node = hit_node_.p;
+    Q.fin.rad = new_f4(capacity); Q.fin.dir = new_f4(capacity); px_[2].alloc(capacity); Q.fin.px = px_[2].p;
+    stats_.alloc(1); Q.stats = stats_.p; CTL_HIP(hipMemset(stats_.p, 0, sizeof(unsigned long long)));
+    Q.capacity = capacity;
+    counts_.free(); work_.free();
+}
+
+uint64_t WavefrontPathTracer::takeRayCount() {
+    unsigned long long r = 0;
+    CTL_HIP(hipMemcpy(&r, stats_.p, sizeof(r), hipMemcpyDeviceToHost));
+    CTL_HIP(hipMemset(stats_.p, 0, sizeof(r)));
+    return (uint64_t)r;
+}
+
+void WavefrontPathTracer::DoRender(Image* I, unsigned int n_passes, const float* d_t1p, const float* d_t2p) {
+    const int maxPathLength = m_sParameters.getValue("MaxPathLength"), rrStart = m_sParameters.getValue("RRStartDepth");
+    const bool direct = m_sParameters.getValue("Direct") != 0;
+    const size_t n_counts = (size_t)(maxPathLength + 2) * 4, n_work = (size_t)2 * (maxPathLength + 2);
+    if (counts_.n < n_counts) { counts_.alloc(n_counts); work_.alloc(n_work); }
+    Q.counts = counts_.p; Q.work = work_.p;
+    launch_ctx lc{ stream, grid_blocks };
+    const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH;
+    for (unsigned int k = 0; k < n_passes; k++) {
+        pass_params P{};
+        P.t1 = d_t1p + k * n1; P.t2 = (const float2*)(d_t2p + k * n1 * 2);
+        P.width = w; P.height = h; P.tile_rank = shard_rank; P.tile_world = shard_world; P.n_local_pixels = capacity;
+        P.direct = direct ? 1 : 0; P.max_path_length = maxPathLength; P.rr_start_depth = rrStart;
+        CTL_HIP(hipMemsetAsync(counts_.p, 0, n_counts * sizeof(uint32_t), stream));
+        CTL_HIP(hipMemsetAsync(work_.p, 0, n_work * sizeof(uint32_t), stream));
+        timer.begin(stream, 0); launch_raygen(lc, m_pScene->S, Q, P); timer.end(stream);
+        for (int depth = 1; depth <= maxPathLength; depth++) {
+            const int cur = (depth - 1) & 1;
+            timer.begin(stream, 1);
+            launch_intersect_closest(lc, m_pScene->S, Q.path[cur].ray_o, Q.path[cur].ray_d, &Q.counts[(depth - 1) * 4 + 0], &Q.work[2 * depth], Q.hit, Q.hit_node);
+            if (depth > 1 && direct)
+                launch_intersect_any(lc, m_pScene->S, Q.sh_o[(depth - 1) & 1], Q.sh_d[(depth - 1) & 1], &Q.counts[(depth - 1) * 4 + 1], &Q.work[2 * depth + 1], Q.sh_occ[(depth - 1) & 1]);
+            timer.end(stream);
+            intersect_launches += (depth > 1 && direct) ? 2 : 1;
+            timer.begin(stream, 2);
+            if (depth > 1 && direct) launch_finalize(lc, Q, P, depth - 1, I->device());
+            launch_shade(lc, m_pScene->S, Q, P, depth, I->device());
+            timer.end(stream);
+        }
+        if (direct) {
+            timer.begin(stream, 1);
+            launch_intersect_any(lc, m_pScene->S, Q.sh_o[maxPathLength & 1], Q.sh_d[maxPathLength & 1], &Q.counts[maxPathLength * 4 + 1], &Q.work[2 * (maxPathLength + 1)], Q.sh_occ[maxPathLength & 1]);
+            timer.end(stream);
+            intersect_launches += 1;
+            timer.begin(stream, 2); launch_finalize(lc, Q, P, maxPathLength, I->device()); timer.end(stream);
+        }
+        launch_accumulate_stats(lc, Q, maxPathLength);
+    }
+    CTL_HIP(hipGetLastError());
+}
+
+} // namespace ctl

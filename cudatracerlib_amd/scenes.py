@@ -1,0 +1,177 @@
+"""In-repo scene generators (no assets ship with the reference or this repo; SURVEY §8d "Synthetic inputs").
+
+* ``cornell_box``      — C1/C2: the classic Cornell box (5 walls, 2 blocks, ceiling quad light), optional glass sphere.
+* ``synthetic_sm``     — the seeded procedural stress scene that stands in for San Miguel when the asset is absent:
+                          instanced icospheres / boxes in a 100^3 volume inside a room, 4 quad lights.
+All builders go through DynamicScene (the loader-facing API) and return it after UpdateScene().
+"""
+import numpy as np
+from . import api
+
+
+def _quad(p, n):
+    """two triangles of a quad with a given normal; vertices are not shared between quads"""
+    p = np.asarray(p, np.float32)
+    return p, np.array([[0, 1, 2], [0, 2, 3]], np.uint32), np.tile(np.asarray(n, np.float32), (4, 1))
+
+
+def _quad_normal(p, inward_point):
+    p = np.asarray(p, np.float64)
+    n = np.cross(p[1] - p[0], p[3] - p[0])
+    n /= np.linalg.norm(n)
+    if np.dot(np.asarray(inward_point, np.float64) - p.mean(0), n) < 0:
+        n = -n
+    return n
+
+
+class _MeshAcc:
+    def __init__(self):
+        self.P, self.I, self.N, self.M = [], [], [], []
+        self.nv = 0
+
+    def add(self, P, I, N, mat):
+        self.P.append(P); self.I.append(I + self.nv); self.N.append(N); self.M.append(np.full(len(I), mat, np.uint8))
+        self.nv += len(P)
+
+    def arrays(self):
+        return np.concatenate(self.P), np.concatenate(self.I), np.concatenate(self.N), np.concatenate(self.M)
+
+
+def icosphere(subdiv):
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t], [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
+                  [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]], np.int64)
+    for _ in range(subdiv):
+        verts = list(map(tuple, v)); cache = {}; nf = []
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                m = (np.array(verts[a]) + np.array(verts[b])) / 2.0
+                verts.append(tuple(m / np.linalg.norm(m))); cache[k] = len(verts) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        v = np.array(verts, np.float64); f = np.array(nf, np.int64)
+    return v.astype(np.float32), f.astype(np.uint32)
+
+
+def unit_box():
+    m = _MeshAcc()
+    c = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], np.float32)
+    for idx, n in (([0, 3, 2, 1], [0, 0, -1]), ([4, 5, 6, 7], [0, 0, 1]), ([0, 1, 5, 4], [0, -1, 0]), ([3, 7, 6, 2], [0, 1, 0]), ([0, 4, 7, 3], [-1, 0, 0]), ([1, 2, 6, 5], [1, 0, 0])):
+        P, I, N = _quad(c[idx], n)
+        m.add(P, I, N, 0)
+    P, I, N, _ = m.arrays()
+    return P, I, N
+
+
+WHITE, RED, GREEN = (0.725, 0.71, 0.68), (0.63, 0.065, 0.05), (0.14, 0.45, 0.091)
+LIGHT_RADIANCE = (17.0, 12.0, 4.0)
+
+
+def cornell_box(width=256, height=256, glass_sphere=False, extra_materials=False):
+    """C1 (glass_sphere=False) / C2 (glass_sphere=True).  Materials of the room mesh: 0 white, 1 red, 2 green, 3 light."""
+    sc = api.DynamicScene()
+    center = (278, 274, 280)
+    m = _MeshAcc()
+    quads = [
+        ([[552.8, 0, 0], [0, 0, 0], [0, 0, 559.2], [549.6, 0, 559.2]], 0),                   # floor
+        ([[556, 548.8, 0], [556, 548.8, 559.2], [0, 548.8, 559.2], [0, 548.8, 0]], 0),        # ceiling
+        ([[549.6, 0, 559.2], [0, 0, 559.2], [0, 548.8, 559.2], [556, 548.8, 559.2]], 0),      # back wall
+        ([[0, 0, 559.2], [0, 0, 0], [0, 548.8, 0], [0, 548.8, 559.2]], 2),                    # right wall (green)
+        ([[552.8, 0, 0], [549.6, 0, 559.2], [556, 548.8, 559.2], [556, 548.8, 0]], 1),        # left wall (red)
+    ]
+    for p, mat in quads:
+        P, I, N = _quad(p, _quad_normal(p, center))
+        m.add(P, I, N, mat)
+    P, I, N = _quad([[343, 548.3, 227], [343, 548.3, 332], [213, 548.3, 332], [213, 548.3, 227]], [0, -1, 0])
+    m.add(P, I, N, 3)
+    short = [[[130, 165, 65], [82, 165, 225], [240, 165, 272], [290, 165, 114]], [[290, 0, 114], [290, 165, 114], [240, 165, 272], [240, 0, 272]],
+             [[130, 0, 65], [130, 165, 65], [290, 165, 114], [290, 0, 114]], [[82, 0, 225], [82, 165, 225], [130, 165, 65], [130, 0, 65]],
+             [[240, 0, 272], [240, 165, 272], [82, 165, 225], [82, 0, 225]]]
+    tall = [[[423, 330, 247], [265, 330, 296], [314, 330, 456], [472, 330, 406]], [[423, 0, 247], [423, 330, 247], [472, 330, 406], [472, 0, 406]],
+            [[472, 0, 406], [472, 330, 406], [314, 330, 456], [314, 0, 456]], [[314, 0, 456], [314, 330, 456], [265, 330, 296], [265, 0, 296]],
+            [[265, 0, 296], [265, 330, 296], [423, 330, 247], [423, 0, 247]]]
+    for block, mat in ((short, 4 if extra_materials else 0), (tall, 5 if extra_materials else 0)):
+        c = np.mean(np.asarray(block, np.float64).reshape(-1, 3), axis=0); c[1] = 80.0
+        for p in block:
+            n = -_quad_normal(p, c)
+            P, I, N = _quad(p, n)
+            m.add(P, I, N, mat)
+    P, I, N, M = m.arrays()
+    mats = [api.diffuse(WHITE), api.diffuse(RED), api.diffuse(GREEN), api.diffuse((0.78, 0.78, 0.78))]
+    if extra_materials:
+        mats += [api.roughconductor(alpha=0.15, distribution=1, sample_visible=True), api.conductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))]
+    room = sc.add_mesh(P, I, normals=N, tri_material=M, materials=mats)
+    node = sc.CreateNode(room)
+    sc.CreateLight(node, 3, LIGHT_RADIANCE)
+    if glass_sphere:
+        V, F = icosphere(4)
+        sph = sc.add_mesh(V, F, normals=V, materials=[api.dielectric(int_ior=1.5, ext_ior=1.0)])
+        r = 90.0
+        xf = np.array([[r, 0, 0, 186.0], [0, r, 0, 165.0 + r + 0.5], [0, 0, r, 169.0], [0, 0, 0, 1]], np.float32)
+        sc.CreateNode(sph, xf)
+    sc.setCamera((278, 273, -800), (278, 273, 0), (0, 1, 0), 39.3077, width, height)
+    sc.UpdateScene()
+    return sc
+
+
+def _rotation(rs):
+    q = rs.normal(size=4); q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def synthetic_sm(width=1920, height=1080, n_instances=2000, subdiv=4, seed=42):
+    """"synthetic-SM": n_instances instanced icosphere / box meshes (icosphere(4) = 5120 triangles) with seeded random
+    rotations, scales and positions in a 100^3 volume inside a closed room; 4 diffuse + 2 microfacet materials; 4 quad lights."""
+    rs = np.random.RandomState(seed)   # MT19937
+    sc = api.DynamicScene()
+    mats = [api.diffuse((0.7, 0.7, 0.7)), api.diffuse((0.7, 0.25, 0.2)), api.diffuse((0.2, 0.55, 0.25)), api.diffuse((0.25, 0.3, 0.7)),
+            api.roughconductor(alpha=0.2, distribution=1, sample_visible=True), api.roughconductor(alpha=0.05, distribution=1, sample_visible=True, eta=(0.14, 0.37, 1.44), k=(3.98, 2.38, 1.6))]
+    base = []
+    V, F = icosphere(subdiv)
+    for mi in range(len(mats)):
+        # a bumpy variant per material keeps the per-mesh BVHs distinct
+        bump = 1.0 + 0.08 * np.sin(V[:, :1] * (3 + mi)) * np.cos(V[:, 1:2] * (5 + mi))
+        Vb = (V * bump).astype(np.float32)
+        base.append(sc.add_mesh(Vb, F, normals=None, materials=[mats[mi]]))
+    Pb, Ib, Nb = unit_box()
+    box_meshes = [sc.add_mesh(Pb, Ib, normals=Nb, materials=[mats[i]]) for i in range(4)]
+    for i in range(n_instances):
+        pos = rs.uniform(-50, 50, size=3)
+        s = rs.uniform(1.0, 3.5)
+        R = _rotation(rs)
+        xf = np.eye(4)
+        if rs.uniform() < 0.85:
+            mesh = base[rs.randint(len(base))]
+            xf[:3, :3] = R * s
+        else:
+            mesh = box_meshes[rs.randint(len(box_meshes))]
+            xf[:3, :3] = R @ np.diag(rs.uniform(0.6, 2.5, size=3) * s * 0.6)
+        xf[:3, 3] = pos
+        sc.CreateNode(mesh, xf.astype(np.float32))
+    # room (inward-facing) and 4 quad lights under the ceiling
+    m = _MeshAcc()
+    R0 = 70.0
+    c = np.array([[-R0, -R0, -R0], [R0, -R0, -R0], [R0, R0, -R0], [-R0, R0, -R0], [-R0, -R0, R0], [R0, -R0, R0], [R0, R0, R0], [-R0, R0, R0]], np.float32)
+    for idx, n, mat in (([0, 3, 2, 1], [0, 0, 1], 0), ([4, 5, 6, 7], [0, 0, -1], 0), ([0, 1, 5, 4], [0, 1, 0], 0), ([3, 7, 6, 2], [0, -1, 0], 0), ([0, 4, 7, 3], [1, 0, 0], 1), ([1, 2, 6, 5], [-1, 0, 0], 2)):
+        P, I, N = _quad(c[idx], n)
+        m.add(P, I, N, mat)
+    P, I, N, M = m.arrays()
+    room = sc.add_mesh(P, I, normals=N, tri_material=M, materials=[api.diffuse(WHITE), api.diffuse(RED), api.diffuse(GREEN)])
+    sc.CreateNode(room)
+    for lx, lz in ((-35, -35), (35, -35), (-35, 35), (35, 35)):
+        P, I, N = _quad([[lx - 12, R0 - 0.5, lz - 12], [lx + 12, R0 - 0.5, lz - 12], [lx + 12, R0 - 0.5, lz + 12], [lx - 12, R0 - 0.5, lz + 12]], [0, -1, 0])
+        lm = sc.add_mesh(P, I, normals=N, materials=[api.diffuse((0.5, 0.5, 0.5))])
+        ln = sc.CreateNode(lm)
+        sc.CreateLight(ln, 0, (40.0, 38.0, 34.0))
+    sc.setCamera((0, 5, -68.0), (0, 0, 0), (0, 1, 0), 60.0, width, height)
+    sc.UpdateScene()
+    return sc

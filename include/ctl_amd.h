@@ -281,8 +281,10 @@ int ctl_tracer_get_stats(ctl_tracer* t, ctl_tracer_stats* out);
 /* __internal__IntersectBuffers (Kernel/TraceHelper.cu:736-746): n rays -> n hits; host pointers.
  * any_hit = 1 selects intersectKernel<true>. */
 int ctl_intersect(ctl_scene* s, const ctl_ray* rays, uint32_t n, ctl_hit* hits, int any_hit);
-/* device-pointer variant, asynchronous on the scene's stream; ms_out (may be NULL) = HIP-event time of the launch */
-int ctl_intersect_device(ctl_scene* s, const void* d_rays, uint32_t n, void* d_hits, int any_hit, float* ms_out);
+/* device-pointer variant (the layout the tracer itself uses): d_ray_o[n], d_ray_d[n] = float4 (origin,tmin) / (direction,tmax);
+ * d_hit4[n] = float4 (t, u, v, triangle index bits, -1 = miss); d_hit_node[n] = int32.  Synchronous; ms_out (may be NULL) =
+ * HIP-event time of the kernel launch. */
+int ctl_intersect_device(ctl_scene* s, const void* d_ray_o, const void* d_ray_d, uint32_t n, void* d_hit4, void* d_hit_node, int any_hit, float* ms_out);
 /* traversal statistics for the roofline: sums over the n rays of inner-node visits, triangle tests and
  * instance entries (B_ray = 32 + 16 + 64*N_inner + 52*N_tri + 108*N_inst). */
 typedef struct { uint64_t n_inner, n_tri, n_inst; } ctl_traversal_counts;

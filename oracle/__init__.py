@@ -1,0 +1,128 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes access to the CPU restatement (oracle/liboracle.so) and, when built, to the reference-backed library
+(oracle/_ref/libctlref.so, compiled from /root/reference's own sources by `make -C oracle ref`).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package; the product
+(cudatracerlib_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+f32, u32, u16, u64 = C.c_float, C.c_uint32, C.c_uint16, C.c_uint64
+
+
+def build(ref=True, quiet=True):
+    """compile the C++ restatement (and, when /root/reference is present, the reference-backed _ref library)"""
+    out = subprocess.DEVNULL if quiet else None
+    subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=out)
+    if ref and os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=out)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(f32))
+
+
+def load():
+    path = os.path.join(_HERE, "liboracle.so")
+    if not os.path.exists(path):
+        build(ref=False)
+    o = C.CDLL(path)
+    o.orc_half_to_float.restype = f32; o.orc_half_to_float.argtypes = [u16, C.c_int]
+    o.orc_float_to_half.restype = u16; o.orc_float_to_half.argtypes = [f32]
+    o.orc_normal_encode.restype = u16
+    o.orc_normal_decode.argtypes = [u16, C.c_void_p]
+    o.orc_seqgen_create.restype = C.c_void_p
+    o.orc_seqgen_destroy.argtypes = [C.c_void_p]
+    o.orc_seqgen_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    o.orc_xorwow_init.argtypes = [u64, u64, C.c_void_p]
+    o.orc_render.restype = u64
+    o.orc_render.argtypes = [C.c_void_p, u32, u32, u32, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, u32, u32, C.c_int]
+    o.orc_intersect.argtypes = [C.c_void_p, C.c_void_p, u32, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    o.orc_fresnel_dielectric_ext.restype = f32; o.orc_fresnel_dielectric_ext.argtypes = [f32, f32, C.c_void_p]
+    o.orc_fresnel_conductor_exact.argtypes = [f32, C.c_void_p, C.c_void_p, C.c_void_p]
+    o.orc_sensor_sample_ray.argtypes = [C.c_void_p, f32, f32, C.c_void_p, C.c_void_p]
+    o.orc_sampler_float.restype = f32; o.orc_sampler_float.argtypes = [C.c_void_p, C.c_void_p, u32, u32]
+    o.orc_sampler_float2.argtypes = [C.c_void_p, C.c_void_p, u32, u32, C.c_void_p]
+    for n in ("orc_square_to_cosine_hemisphere", "orc_square_to_uniform_triangle", "orc_square_to_uniform_disk_concentric"):
+        getattr(o, n).argtypes = [f32, f32, C.c_void_p]
+    o.orc_microfacet_eval.argtypes = [C.c_int, f32, f32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    o.orc_microfacet_sample.argtypes = [C.c_int, f32, f32, C.c_int, C.c_void_p, f32, f32, C.c_void_p]
+    o.orc_bsdf_sample.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
+    o.orc_bsdf_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_void_p]
+    o.orc_light_sample_direct.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
+    o.orc_triangle_data_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_int, C.c_void_p]
+    o.orc_triangle_fill_dg.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_int, C.c_void_p]
+    o.orc_woop_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
+    return o
+
+
+def load_ref():
+    """the reference-backed library, or None when it has not been built (no /root/reference on this box and no prebuilt file)"""
+    path = os.path.join(_HERE, "_ref", "libctlref.so")
+    if not os.path.exists(path):
+        return None
+    r = C.CDLL(path, mode=os.RTLD_LAZY)   # CUDA-runtime symbols of never-called reference code stay unresolved
+    r.ref_half_to_float.restype = f32; r.ref_half_to_float.argtypes = [u16]
+    r.ref_float_to_half.restype = u16; r.ref_float_to_half.argtypes = [f32]
+    r.ref_normal_encode.restype = u16
+    r.ref_normal_decode.argtypes = [u16, C.c_void_p]
+    r.ref_fresnel_dielectric_ext.restype = f32; r.ref_fresnel_dielectric_ext.argtypes = [f32, f32, C.c_void_p]
+    r.ref_fresnel_conductor_exact.argtypes = [f32, C.c_void_p, C.c_void_p, C.c_void_p]
+    r.ref_power_heuristic.restype = f32; r.ref_power_heuristic.argtypes = [f32, f32]
+    r.ref_sensor_sample_ray.argtypes = [C.c_void_p, f32, f32, f32, C.c_int, C.c_int, f32, f32, C.c_void_p, C.c_void_p]
+    for n in ("ref_square_to_cosine_hemisphere", "ref_square_to_uniform_triangle", "ref_square_to_uniform_disk_concentric"):
+        getattr(r, n).argtypes = [f32, f32, C.c_void_p]
+    r.ref_microfacet_eval.argtypes = [C.c_int, f32, f32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    r.ref_microfacet_sample.argtypes = [C.c_int, f32, f32, C.c_int, C.c_void_p, f32, f32, C.c_void_p]
+    r.ref_triangle_data_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_void_p]
+    r.ref_triangle_fill_dg.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
+    r.ref_woop_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p]
+    r.ref_construct_bvh.argtypes = [C.c_void_p, C.c_void_p, u32, u32, C.c_void_p, C.c_void_p]
+    r.ref_construct_bvh_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    return r
+
+
+class Oracle:
+    """convenience wrappers over liboracle.so working on a ctypes ctl_scene_desc (host pointers)"""
+
+    def __init__(self):
+        self.lib = load()
+
+    def intersect(self, desc, rays, any_hit=False, count=False, threads=8):
+        r = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.zeros(len(r), dtype=[("dist", "f4"), ("node_idx", "i4"), ("tri_idx", "i4"), ("u", "f4"), ("v", "f4")])
+        cnt = (u64 * 3)()
+        self.lib.orc_intersect(C.addressof(desc), r.ctypes.data, len(r), hits.ctypes.data, 1 if any_hit else 0, C.addressof(cnt) if count else None, threads)
+        if count:
+            return hits, dict(n_inner=cnt[0], n_tri=cnt[1], n_inst=cnt[2])
+        return hits
+
+    def render(self, desc, width, height, n_passes=1, tables=None, direct=True, max_path_length=8, rr_start=5, threads=8, rows=None, half_host_quirk=False):
+        """pathKernel2<DIRECT,false> over all pixels (Integrators/PathTracer.cu:182-194). tables = list of (t1, t2) per pass or None.
+        Returns (pixel_data (h, w, 7), rays)."""
+        img = np.zeros((height, width, 7), np.float32)
+        y0, y1 = (0, height) if rows is None else rows
+        if tables is not None:
+            t1 = np.ascontiguousarray(np.concatenate([np.asarray(t[0], np.float32).ravel() for t in tables]))
+            t2 = np.ascontiguousarray(np.concatenate([np.asarray(t[1], np.float32).ravel() for t in tables]))
+            assert len(tables) == n_passes
+            p1, p2 = t1.ctypes.data, t2.ctypes.data
+        else:
+            p1 = p2 = None
+        rays = self.lib.orc_render(C.addressof(desc), width, height, n_passes, p1, p2, 1 if direct else 0, max_path_length, rr_start,
+                                   img.ctypes.data, threads, y0, y1, 1 if half_host_quirk else 0)
+        return img, int(rays)
+
+    def sequence_tables(self, n_passes):
+        g = self.lib.orc_seqgen_create()
+        out = []
+        for _ in range(n_passes):
+            t1 = np.zeros(4096 * 30, np.float32); t2 = np.zeros(4096 * 30 * 2, np.float32)
+            self.lib.orc_seqgen_compute(g, t1.ctypes.data, t2.ctypes.data)
+            out.append((t1, t2))
+        self.lib.orc_seqgen_destroy(g)
+        return out
