@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X wavefront path tracer.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+metric   : Mrays/s (primary + continuation + shadow rays / wall time of the render loop; scene load, BVH build and
+           image read-back excluded), SURVEY §8d, on the 1920x1080 depth-8 workload.
+step     : one pass (1 sample per pixel of the 1920x1080 frame) through ray-gen -> {intersect, shade} x depth 8.
+workload : "synthetic-SM" — the seeded procedural stand-in for San Miguel (BASELINE.json configs[2]; the asset is not
+           in the reference tree, this repo or the GPU box), 2000 instanced meshes / 8.7 M instanced triangles.
+N > 1    : image tiles (64x64) are sharded round-robin over the ranks (weak in nothing: total work fixed => "strong");
+           every rank holds a full scene replica; ONE RCCL reduce of the PixelData framebuffer to rank 0 closes the timed
+           region (tiles are disjoint up to film-edge jitter, so the sum is the gather).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_scene(args):
+    from cudatracerlib_amd import scenes
+    if args.workload == "synthetic-sm":
+        return scenes.synthetic_sm(args.width, args.height, n_instances=args.instances, subdiv=args.subdiv)
+    if args.workload == "cornell-glass":
+        return scenes.cornell_box(args.width, args.height, glass_sphere=True)
+    raise SystemExit("unknown workload " + args.workload)
+
+
+def b_ray(counts, rays):
+    """algorithmic bytes: 32 (ray) + 16 (result) + 64 N_inner + 52 N_tri + 108 N_inst per ray"""
+    return 48.0 * rays + 64.0 * counts.n_inner + 52.0 * counts.n_tri + 108.0 * counts.n_inst
+
+
+def cpu_baseline(desc, args):
+    """oracle (CPU restatement of PathTrace<DIRECT>) on a bounded sample of the same workload: 1 pass over a band of
+    rows in the middle of the frame, all host cores, grown until >= ~8 s of CPU work or the whole frame is done."""
+    import oracle
+    orc = oracle.Oracle()
+    cores = os.cpu_count() or 1
+    rows, y0 = 8, args.height // 2
+    total_rays, total_t, done_rows = 0, 0.0, 0
+    while total_t < 8.0 and done_rows < args.height // 2:
+        a, b = y0 + done_rows, min(args.height, y0 + done_rows + rows)
+        t = time.time()
+        _, rays = orc.render(desc, args.width, args.height, n_passes=1, direct=True, max_path_length=args.depth, rr_start=5, threads=cores, rows=(a, b))
+        total_t += time.time() - t
+        total_rays += rays
+        done_rows += b - a
+        rows = min(rows * 2, 128)
+    return {"value": round(total_rays / total_t / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "1 pass over %d rows (y=%d..%d) of the %dx%d frame, depth %d, %d threads, %.1f s" % (done_rows, y0, y0 + done_rows, args.width, args.height, args.depth, cores, total_t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="synthetic-sm")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--instances", type=int, default=2000)
+    ap.add_argument("--subdiv", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    import cudatracerlib_amd as ctl
+    if ctl.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    ctl.api._check(ctl.lib.ctl_set_device(local_rank))
+
+    sc = build_scene(args)
+    desc = sc.desc
+    scene = ctl.Scene(desc)
+    tr = ctl.WavefrontPathTracer()
+    p = tr.getParameters()
+    p.setValue("Direct", True); p.setValue("MaxPathLength", args.depth); p.setValue("RRStartDepth", 5)
+    tr.setTileShard(rank, world)
+    tr.Resize(args.width, args.height)
+    tr.InitializeScene(scene)
+    img = ctl.Image(args.width, args.height)
+
+    fb = None
+    if world > 1:
+        import torch
+        fb = torch.zeros(args.width * args.height * 7, dtype=torch.float32, device="cuda")
+
+    def sync():
+        ctl.api._check(ctl.lib.ctl_device_synchronize())
+        if world > 1:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    if args.warmup > 0:
+        tr.DoPasses(img, args.warmup, new_trace=True)
+    sync()
+    t0 = time.perf_counter()
+    tr.DoPasses(img, args.steps, new_trace=(args.warmup == 0))
+    if world > 1:
+        # the single framebuffer exchange of the render: PixelData sums -> rank 0 over RCCL/xGMI
+        ctl.api._check(ctl.lib.ctl_memcpy_d2d(fb.data_ptr(), img.device_ptr(), args.width * args.height * 28))
+        dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+    sync()
+    elapsed = time.perf_counter() - t0
+    st = tr.stats()
+    rays = float(st.rays_last_pass)
+    k_ms_closest, k_ms_any = st.ms_intersect, st.ms_intersect_any
+    n_closest, n_any = int(st.intersect_rays), int(st.shadow_rays)
+    launches_closest = int(st.intersect_launches)
+    if world > 1:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        r = torch.tensor([rays], dtype=torch.float64, device="cuda"); dist.all_reduce(r, op=dist.ReduceOp.SUM); rays = float(r.item())
+
+    out = None
+    if rank == 0:
+        # traversal statistics of the SAME rays (one extra, untimed pass in counting mode) -> algorithmic bytes
+        tr.setCounting(True)
+        tr.DoPasses(img, 1, new_trace=False)
+        cs = tr.stats()
+        tr.setCounting(False)
+        per_ray_closest = b_ray(cs.closest_counts, cs.intersect_rays) / max(1, cs.intersect_rays)
+        per_ray_any = b_ray(cs.any_counts, cs.shadow_rays) / max(1, cs.shadow_rays)
+        # dominant kernel = closest-hit intersect: bytes per launch / average launch duration (HIP events on the tracer's stream)
+        avg_launch_ms = k_ms_closest / max(1, launches_closest)
+        bytes_per_launch = per_ray_closest * n_closest / max(1, launches_closest)
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_intersect_closest_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s at 1920x1080 depth-8 (per pass = 1 spp); achieved HBM GB/s vs peak",
+            "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic-SM %dx%d, 1 spp/step, depth %d, NEE on, %d instances x icosphere(%d)/boxes, %d instanced triangles"
+                       % (args.width, args.height, args.depth, args.instances, args.subdiv, int(_instanced_tris(desc))) if args.workload == "synthetic-sm" else args.workload,
+                       "parallelism": "image tiles 64x64 round-robin over %d GPU(s), 1 RCCL reduce of the framebuffer" % world,
+                       "rays_per_step": int(rays / args.steps)},
+            "roofline": {"bound": "hbm", "kernel": "k_intersect<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "bytes_per_ray": round(per_ray_closest, 1), "rays_per_launch": int(n_closest / max(1, launches_closest)),
+                         "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches_closest,
+                         "shadow_kernel": {"bytes_per_ray": round(per_ray_any, 1), "rays": n_any, "ms": round(k_ms_any, 3),
+                                           "achieved": round(per_ray_any * n_any / (k_ms_any * 1e-3) / 1e9, 2) if k_ms_any > 0 else 0.0},
+                         "ms_intersect": round(k_ms_closest, 3), "ms_shade": round(st.ms_shade, 3), "ms_raygen": round(st.ms_raygen, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def _instanced_tris(desc):
+    nodes = desc.view("nodes", np.uint32, desc.n_nodes, 6)
+    meshes = desc.view("meshes", np.uint32, desc.n_meshes, 5)
+    # triangles per mesh = difference of consecutive tri offsets (meshes are appended in order)
+    offs = np.append(meshes[:, 0], desc.n_tri_data)
+    per_mesh = np.diff(offs)
+    return per_mesh[nodes[:, 0]].sum()
+
+
+if __name__ == "__main__":
+    main()

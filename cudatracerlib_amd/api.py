@@ -71,7 +71,9 @@ class ctl_traversal_counts(C.Structure):
 
 class ctl_tracer_stats(C.Structure):
     _fields_ = [("rays_last_pass", u64), ("rays_total", u64), ("seconds_last_pass", C.c_double), ("seconds_total", C.c_double), ("passes_done", u32),
-                ("ms_intersect", C.c_double), ("ms_shade", C.c_double), ("ms_raygen", C.c_double), ("intersect_rays", u64), ("intersect_launches", u64)]
+                ("ms_intersect", C.c_double), ("ms_shade", C.c_double), ("ms_raygen", C.c_double), ("ms_intersect_any", C.c_double),
+                ("intersect_rays", u64), ("intersect_launches", u64), ("shadow_rays", u64), ("shadow_launches", u64),
+                ("closest_counts", ctl_traversal_counts), ("any_counts", ctl_traversal_counts)]
 
 
 class ctl_scene_desc(C.Structure):
@@ -105,6 +107,7 @@ lib.ctl_device_malloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
 lib.ctl_device_free.argtypes = [C.c_void_p]
 lib.ctl_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.ctl_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+lib.ctl_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.ctl_intersect_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(f32)]
 lib.ctl_image_resolve_rgb.argtypes = [C.c_void_p, f32, C.c_void_p]
 lib.ctl_builder_set_camera_lookat.argtypes = [C.c_void_p, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), f32, u32, u32]
@@ -376,6 +379,10 @@ class WavefrontPathTracer:
 
     def DoPasses(self, image, n, new_trace=False):
         _check(lib.ctl_tracer_do_passes(self._h, image._h, 1 if new_trace else 0, u32(n)))
+
+    def setCounting(self, on):
+        """count N_inner / N_tri / N_inst in the intersect kernels (measurement mode)"""
+        _check(lib.ctl_tracer_set_counting(self._h, 1 if on else 0))
 
     def stats(self):
         s = ctl_tracer_stats()

@@ -102,6 +102,7 @@ int ctl_tracer_set_sampler_tables(ctl_tracer* t, const float* tables_1d, const f
 int ctl_tracer_do_pass(ctl_tracer* t, ctl_image* img, int new_trace) { CTL_REQUIRE(t && img, "null argument"); CTL_TRY t->t->DoPass(&img->img, new_trace != 0); CTL_CATCH }
 int ctl_tracer_do_passes(ctl_tracer* t, ctl_image* img, int new_trace, uint32_t n_passes) { CTL_REQUIRE(t && img, "null argument"); CTL_TRY t->t->DoPasses(&img->img, new_trace != 0, n_passes); CTL_CATCH }
 int ctl_tracer_get_stats(ctl_tracer* t, ctl_tracer_stats* out) { CTL_REQUIRE(t && out, "null argument"); CTL_TRY t->t->getKernelStats(*out); CTL_CATCH }
+int ctl_tracer_set_counting(ctl_tracer* t, int on) { CTL_REQUIRE(t, "null tracer"); CTL_TRY t->t->setCounting(on != 0); CTL_CATCH }
 
 // ---- intersect (row a7 on its own)
 static void run_intersect(Scene& sc, const float4* d_ro, const float4* d_rd, uint32_t n, float4* d_hit, int* d_node, uint32_t* d_occ, int any_hit, unsigned long long* d_counts, float* ms_out) {
@@ -112,7 +113,7 @@ static void run_intersect(Scene& sc, const float4* d_ro, const float4* d_rd, uin
     launch_ctx lc{ nullptr, prop.multiProcessorCount * 8 };
     hipEvent_t a, b; CTL_HIP(hipEventCreate(&a)); CTL_HIP(hipEventCreate(&b));
     CTL_HIP(hipEventRecord(a, nullptr));
-    if (d_counts) launch_intersect_count(lc, sc.S, d_ro, d_rd, ctl.p, ctl.p + 1, d_hit, d_node, any_hit, d_counts);
+    if (d_counts) launch_intersect_count(lc, sc.S, d_ro, d_rd, ctl.p, ctl.p + 1, d_hit, d_node, nullptr, any_hit, d_counts);
     else if (any_hit) launch_intersect_any(lc, sc.S, d_ro, d_rd, ctl.p, ctl.p + 1, d_occ, d_hit, d_node);
     else launch_intersect_closest(lc, sc.S, d_ro, d_rd, ctl.p, ctl.p + 1, d_hit, d_node);
     CTL_HIP(hipEventRecord(b, nullptr));
@@ -156,6 +157,7 @@ int ctl_device_malloc(size_t bytes, void** out) { CTL_REQUIRE(out, "null out"); 
 int ctl_device_free(void* p) { CTL_TRY CTL_HIP(hipFree(p)); CTL_CATCH }
 int ctl_memcpy_h2d(void* dst, const void* src, size_t bytes) { CTL_TRY CTL_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); CTL_CATCH }
 int ctl_memcpy_d2h(void* dst, const void* src, size_t bytes) { CTL_TRY CTL_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); CTL_CATCH }
+int ctl_memcpy_d2d(void* dst, const void* src, size_t bytes) { CTL_TRY CTL_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice)); CTL_CATCH }
 int ctl_device_synchronize(void) { CTL_TRY require_device(); CTL_HIP(hipDeviceSynchronize()); CTL_CATCH }
 int ctl_set_device(int ordinal) { CTL_TRY require_device(); CTL_HIP(hipSetDevice(ordinal)); CTL_CATCH }
 

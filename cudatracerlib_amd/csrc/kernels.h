@@ -11,7 +11,7 @@ struct path_soa {
     float4* ray_d;    // direction.xyz, tmax                               (traversalRay::b)
     float4* thr;      // throughput cf.rgb, last bsdf pdf                  (WavefrontPTRayData::throughput, bsdf_pdf)
     float4* rad;      // accumulated radiance cl.rgb, pixel index (bits)   (WavefrontPTRayData::L, x/y)
-    float4* nor;      // normal of the previous vertex xyz, packed {d1:8, d2:8, depth:8, flags:8}
+    float4* nor;      // normal of the previous vertex xyz, packed {d1:8, d2:8, pass-in-batch:8, flags:8}
     float4* pend;     // pending NEE contribution directF.rgb, shadow-ray index (bits)   (directF, dIdx)
     float2* px;       // film sample position pX
 };
@@ -37,7 +37,8 @@ struct wave_queues {
 };
 
 struct pass_params {
-    const float* t1; const float2* t2;   // this pass's sampler tables
+    const float* t1; const float2* t2;   // sampler tables of the first pass of this batch; pass b of the batch at + b * 4096*30
+    uint32_t batch;                      // passes rendered together in this wavefront (paths carry their pass id)
     uint32_t width, height;              // full film
     uint32_t tile_rank, tile_world;      // image-tile shard: tiles t with t % world == rank
     uint32_t n_local_pixels;             // pixels rendered by this rank
@@ -51,7 +52,7 @@ void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& 
 void launch_intersect_closest(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node);
 void launch_intersect_any(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, uint32_t* occ, float4* hit = nullptr, int* hit_node = nullptr);
 void launch_intersect_count(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node,
-                            int any_hit, unsigned long long* counts3);
+                            uint32_t* occ, int any_hit, unsigned long long* counts3);
 void launch_shade(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_finalize(const launch_ctx& lc, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_accumulate_stats(const launch_ctx& lc, const wave_queues& Q, int max_depth);

@@ -29,14 +29,17 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool take) {
 // indexing (sampler index = film pixel index, Integrators/PathTracer.cu:185-190).
 __global__ __launch_bounds__(kBlock) void k_raygen(dev_scene S, wave_queues Q, pass_params P) {
     const uint32_t tiles_x = (P.width + 63) / 64;
-    for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < P.n_local_pixels; li += gridDim.x * kBlock) {
+    const uint32_t n_total = P.n_local_pixels * P.batch;   // n_local_pixels is a multiple of 4096: waves never straddle passes
+    const uint32_t n1 = CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH;
+    for (uint32_t gi = blockIdx.x * kBlock + threadIdx.x; gi < n_total; gi += gridDim.x * kBlock) {
+        const uint32_t pass_b = gi / P.n_local_pixels, li = gi - pass_b * P.n_local_pixels;
         const uint32_t tile = P.tile_rank + (li >> 12) * P.tile_world, p = li & 4095u, micro = p >> 6, lane = p & 63u;
         const uint32_t x = (tile % tiles_x) * 64 + (micro & 7u) * 8 + (lane & 7u), y = (tile / tiles_x) * 64 + (micro >> 3) * 8 + (lane >> 3);
         const bool valid = x < P.width && y < P.height;
         const uint32_t slot = wave_append(&Q.counts[0], valid);
         if (!valid) continue;
         const uint32_t pixel = y * P.width + x;
-        sampler rng{ P.t1, P.t2, pixel, 0, 0 };
+        sampler rng{ P.t1 + pass_b * n1, P.t2 + pass_b * n1, pixel, 0, 0 };
         const f2 j = rng.next2();
         const f2 pX{ (float)x + j.x, (float)y + j.y };
         (void)rng.next2();   // aperture sample, unused by the perspective sensor but drawn (PathTracer.cu:190)
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(dev_scene S, wave_queues Q, p
         A.ray_d[slot] = make_float4(d.x, d.y, d.z, 3.402823466e+38f);
         A.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         A.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(pixel));
-        A.nor[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng.d1 | (rng.d2 << 8) | (0u << 16) | (0u << 24)));
+        A.nor[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng.d1 | (rng.d2 << 8) | (pass_b << 16) | (0u << 24)));
         A.pend[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kNoShadow));
         A.px[slot] = make_float2(pX.x, pX.y);
     }
@@ -110,14 +113,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(dev_scene S, wave_queues Q, pa
         const bool active = i < n;
         bool alive = false, want_shadow = false, terminated = false;
         f3 cl(0.0f), cf(0.0f), directF(0.0f), new_o(0.0f), new_d(0.0f), last_nor(0.0f), sh_org(0.0f), sh_dir(0.0f);
-        float bsdf_pdf_out = 0.0f, sh_tmax = 0.0f; uint32_t pixel = 0, d1 = 0, d2 = 0; bool specular = false; float2 px = make_float2(0.f, 0.f);
+        float bsdf_pdf_out = 0.0f, sh_tmax = 0.0f; uint32_t pixel = 0, d1 = 0, d2 = 0, pass_b = 0; bool specular = false; float2 px = make_float2(0.f, 0.f);
         if (active) {
             const float4 ro = A.ray_o[i], rd = A.ray_d[i], thr = A.thr[i], rad = A.rad[i], nor = A.nor[i], pend = A.pend[i];
             const float4 hit = Q.hit[i]; const int hnode = Q.hit_node[i];
             px = A.px[i];
             pixel = __float_as_uint(rad.w);
             const uint32_t packed = __float_as_uint(nor.w);
-            sampler rng{ P.t1, P.t2, pixel, packed & 0xffu, (packed >> 8) & 0xffu };
+            pass_b = (packed >> 16) & 0xffu;
+            const uint32_t n1 = CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH;
+            sampler rng{ P.t1 + pass_b * n1, P.t2 + pass_b * n1, pixel, packed & 0xffu, (packed >> 8) & 0xffu };
             bool specularBounce = ((packed >> 24) & kFlagSpecular) != 0;
             cl = f3(rad.x, rad.y, rad.z); cf = f3(thr.x, thr.y, thr.z);
             float brdf_scattering_pdf = thr.w;
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(dev_scene S, wave_queues Q, pa
             B.ray_d[nslot] = make_float4(new_d.x, new_d.y, new_d.z, 3.402823466e+38f);
             B.thr[nslot] = make_float4(cf.x, cf.y, cf.z, bsdf_pdf_out);
             B.rad[nslot] = make_float4(cl.x, cl.y, cl.z, __uint_as_float(pixel));
-            B.nor[nslot] = make_float4(last_nor.x, last_nor.y, last_nor.z, __uint_as_float((d1 & 0xffu) | ((d2 & 0xffu) << 8) | ((uint32_t)depth << 16) | ((specular ? kFlagSpecular : 0u) << 24)));
+            B.nor[nslot] = make_float4(last_nor.x, last_nor.y, last_nor.z, __uint_as_float((d1 % CTL_SAMPLER_SEQUENCE_LENGTH) | ((d2 % CTL_SAMPLER_SEQUENCE_LENGTH) << 8) | (pass_b << 16)   /* only d mod 30 matters (Sampler_device.h:98,104) */ | ((specular ? kFlagSpecular : 0u) << 24)));
             B.pend[nslot] = make_float4(directF.x, directF.y, directF.z, __uint_as_float(want_shadow ? sslot : kNoShadow));
             B.px[nslot] = px;
         } else if (want_shadow) {
@@ -235,9 +240,9 @@ __global__ __launch_bounds__(kBlock) void k_finalize(wave_queues Q, pass_params 
 // rays of a pass = sum over bounces of (path rays + shadow rays)  (Kernel/TraceHelper.cu:176,745)
 __global__ void k_accumulate_stats(wave_queues Q, int max_depth) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        unsigned long long r = 0;
-        for (int d = 0; d <= max_depth; d++) r += (unsigned long long)Q.counts[d * 4 + 0] + (unsigned long long)Q.counts[d * 4 + 1];
-        Q.stats[0] += r;
+        unsigned long long r = 0, s = 0;
+        for (int d = 0; d <= max_depth; d++) { r += (unsigned long long)Q.counts[d * 4 + 0]; s += (unsigned long long)Q.counts[d * 4 + 1]; }
+        Q.stats[0] += r; Q.stats[1] += s;
     }
 }
 
@@ -263,8 +268,8 @@ void launch_intersect_any(const launch_ctx& lc, const dev_scene& S, const float4
     hipLaunchKernelGGL((k_intersect<true, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, occ, (unsigned long long*)nullptr);
 }
 void launch_intersect_count(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node,
-                            int any_hit, unsigned long long* counts3) {
-    if (any_hit) hipLaunchKernelGGL((k_intersect<true, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, (uint32_t*)nullptr, counts3);
+                            uint32_t* occ, int any_hit, unsigned long long* counts3) {
+    if (any_hit) hipLaunchKernelGGL((k_intersect<true, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, occ, counts3);
     else hipLaunchKernelGGL((k_intersect<false, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, (uint32_t*)nullptr, counts3);
 }
 void launch_shade(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image) {

@@ -122,7 +122,11 @@ protected:
     sequence_generator m_SamplingSequenceGenerator;   // IndependantSamplingSequenceGenerator
     std::vector<float> user_t1, user_t2; bool have_user_tables = false;
     uint32_t shard_rank = 0, shard_world = 1;
-    event_timer timer; double kernel_ms[4] = { 0, 0, 0, 0 }; uint64_t intersect_rays = 0, intersect_launches = 0;
+    event_timer timer; double kernel_ms[4] = { 0, 0, 0, 0 };   // 0 raygen, 1 closest-hit intersect, 2 shade/finalize, 3 any-hit intersect
+    uint64_t intersect_rays = 0, intersect_launches = 0, shadow_rays = 0, shadow_launches = 0;
+    bool counting = false; ctl_traversal_counts closest_counts{}, any_counts{};
+public:
+    void setCounting(bool on) { counting = on; }
 };
 
 template <bool PROGRESSIVE> class Tracer : public TracerBase {
@@ -132,10 +136,15 @@ public:
     bool isMultiPass() const override { return PROGRESSIVE; }
     float getSplatScale() const override { return PROGRESSIVE ? 1.0f / float(m_uPassesDone) : 0.0f; }
 protected:
-    // render `n` passes; tables for pass k are at t1 + k*stride1 / t2 + k*stride2 (device)
-    virtual void DoRender(Image* I, unsigned int n_passes, const float* d_t1, const float* d_t2) = 0;
-    virtual uint64_t takeRayCount() = 0;
-    dbuf<float> d_t1, d_t2;
+    // render `n_batch` passes together; their sampler tables are consecutive at (d_t1, d_t2) (device); asynchronous on `stream`
+    virtual void DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) = 0;
+    virtual void takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) = 0;
+    dbuf<float> d_t1, d_t2;                       // ring of sampler-table sets in HBM
+    float *h_t1 = nullptr, *h_t2 = nullptr; size_t h_cap = 0;   // their pinned host staging
+    std::vector<hipEvent_t> slot_done;
+    virtual unsigned int passBatch() const { return 1; }
+public:
+    ~Tracer() override { if (h_t1) (void)hipHostFree(h_t1); if (h_t2) (void)hipHostFree(h_t2); for (auto e : slot_done) (void)hipEventDestroy(e); }
 };
 
 // Integrators/PseudoRealtime/WavefrontPathTracer.h:24-67
@@ -144,11 +153,12 @@ public:
     WavefrontPathTracer();
     void Resize(unsigned int w, unsigned int h) override;
 protected:
-    void DoRender(Image* I, unsigned int n_passes, const float* d_t1, const float* d_t2) override;
-    uint64_t takeRayCount() override;
+    void DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) override;
+    void takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) override;
+    unsigned int passBatch() const override;
 private:
     wave_queues Q{};
-    uint32_t capacity = 0;
+    uint32_t capacity = 0, n_local_pixels = 0;
     std::vector<std::unique_ptr<dbuf<float4>>> f4_; dbuf<float2> px_[3]; dbuf<int> hit_node_; dbuf<uint32_t> occ_[2], counts_, work_; dbuf<unsigned long long> stats_;
     int grid_blocks = 0;
     float4* new_f4(size_t n);

@@ -133,13 +133,16 @@ void TracerBase::setSamplerTables(const float* t1, const float* t2) {
     user_t1.assign(t1, t1 + n1); user_t2.assign(t2, t2 + 2 * n1); have_user_tables = true;
 }
 void TracerBase::getKernelStats(ctl_tracer_stats& s) const {
+    std::memset(&s, 0, sizeof(s));
     s.rays_last_pass = m_uLastNumRaysTraced; s.rays_total = m_uAccNumRaysTraced; s.seconds_last_pass = m_fLastRuntime; s.seconds_total = m_fAccRuntime;
-    s.passes_done = m_uPassesDone; s.ms_raygen = kernel_ms[0]; s.ms_intersect = kernel_ms[1]; s.ms_shade = kernel_ms[2];
-    s.intersect_rays = intersect_rays; s.intersect_launches = intersect_launches;
+    s.passes_done = m_uPassesDone; s.ms_raygen = kernel_ms[0]; s.ms_intersect = kernel_ms[1]; s.ms_shade = kernel_ms[2]; s.ms_intersect_any = kernel_ms[3];
+    s.intersect_rays = intersect_rays; s.intersect_launches = intersect_launches; s.shadow_rays = shadow_rays; s.shadow_launches = shadow_launches;
+    s.closest_counts = closest_counts; s.any_counts = any_counts;
 }
 
-// Tracer<true>::DoPass (Kernel/Tracer.h:209-248), generalised to n passes per call: the host regenerates the
-// sampling tables once per pass exactly as UpdateKernel does, but uploads them ahead of the kernels.
+// Tracer<true>::DoPass (Kernel/Tracer.h:209-248), generalised to n passes per call.  As in the reference the host
+// regenerates the sampling tables once per pass (UpdateKernel -> SamplingSequenceGeneratorHost::Compute); here the
+// generation of pass k+1 overlaps the GPU work of pass k because nothing in a pass synchronises with the host.
 template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_NewTrace, unsigned int n) {
     if (!m_pScene) throw std::runtime_error("DoPass: InitializeScene was not called");
     if (w == 0xffffffffu) throw std::runtime_error("DoPass: Resize was not called");
@@ -147,25 +150,44 @@ template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_
     if (n == 0) return;
     if (a_NewTrace || !PROGRESSIVE) { m_uPassesDone = 0; m_uAccNumRaysTraced = 0; m_fAccRuntime = 0; I->Clear(); }
     const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH, n2 = n1 * 2;
-    std::vector<float> h1(n1 * n), h2(n2 * n);
-    for (unsigned int k = 0; k < n; k++) {
-        if (have_user_tables && k == 0) { std::memcpy(&h1[0], user_t1.data(), n1 * 4); std::memcpy(&h2[0], user_t2.data(), n2 * 4); have_user_tables = false; }
-        else m_SamplingSequenceGenerator.compute(&h1[k * n1], &h2[k * n2]);
+    // passes are rendered in batches of `B` (one wavefront carries the paths of B passes; each path uses its own pass's
+    // tables), B chosen so that a launch holds enough paths to fill 256 CUs even when a rank owns 1/8 of the tiles
+    const unsigned int B = passBatch();
+    const unsigned int ring = 2;   // batches in flight; slot reuse is guarded by an event per slot
+    if (d_t1.n < n1 * ring * B) { d_t1.alloc(n1 * ring * B); d_t2.alloc(n2 * ring * B); }
+    if (h_cap < n1 * ring * B) {   // pinned staging so that the uploads really are asynchronous
+        if (h_t1) { (void)hipHostFree(h_t1); (void)hipHostFree(h_t2); h_t1 = h_t2 = nullptr; }
+        CTL_HIP(hipHostMalloc((void**)&h_t1, n1 * ring * B * sizeof(float))); CTL_HIP(hipHostMalloc((void**)&h_t2, n2 * ring * B * sizeof(float)));
+        h_cap = n1 * ring * B;
     }
-    if (d_t1.n < h1.size()) { d_t1.alloc(h1.size()); d_t2.alloc(h2.size()); }
-    CTL_HIP(hipMemcpyAsync(d_t1.p, h1.data(), h1.size() * 4, hipMemcpyHostToDevice, stream));
-    CTL_HIP(hipMemcpyAsync(d_t2.p, h2.data(), h2.size() * 4, hipMemcpyHostToDevice, stream));
-    CTL_HIP(hipStreamSynchronize(stream));   // tables resident before the timed region (the reference times the upload too; it is < 1 % of a pass)
-    for (int i = 0; i < 4; i++) kernel_ms[i] = 0; intersect_rays = 0; intersect_launches = 0;
+    if (slot_done.empty()) { slot_done.resize(ring); for (auto& e : slot_done) CTL_HIP(hipEventCreate(&e)); }
+    for (int i = 0; i < 4; i++) kernel_ms[i] = 0;
+    intersect_rays = intersect_launches = shadow_rays = shadow_launches = 0;
     CTL_HIP(hipEventRecord(start, stream));
-    m_uPassesDone += n;
-    DoRender(I, n, d_t1.p, d_t2.p);
+    unsigned int batch_idx = 0;
+    for (unsigned int k = 0; k < n; batch_idx++) {
+        const unsigned int nb = std::min(B, n - k), slot = batch_idx % ring;
+        if (batch_idx >= ring) CTL_HIP(hipEventSynchronize(slot_done[slot]));   // the batch that last used this slot has finished
+        float* a = h_t1 + (size_t)slot * B * n1; float* b = h_t2 + (size_t)slot * B * n2;
+        for (unsigned int j = 0; j < nb; j++) {
+            if (have_user_tables) { std::memcpy(a + j * n1, user_t1.data(), n1 * 4); std::memcpy(b + j * n2, user_t2.data(), n2 * 4); have_user_tables = false; }
+            else m_SamplingSequenceGenerator.compute(a + j * n1, b + j * n2);
+        }
+        CTL_HIP(hipMemcpyAsync(d_t1.p + (size_t)slot * B * n1, a, (size_t)nb * n1 * 4, hipMemcpyHostToDevice, stream));
+        CTL_HIP(hipMemcpyAsync(d_t2.p + (size_t)slot * B * n2, b, (size_t)nb * n2 * 4, hipMemcpyHostToDevice, stream));
+        m_uPassesDone += nb;
+        DoRender(I, d_t1.p + (size_t)slot * B * n1, d_t2.p + (size_t)slot * B * n2, nb);
+        CTL_HIP(hipEventRecord(slot_done[slot], stream));
+        k += nb;
+    }
     CTL_HIP(hipEventRecord(stop, stream));
     CTL_HIP(hipEventSynchronize(stop));
+    CTL_HIP(hipGetLastError());
     float ms = 0; CTL_HIP(hipEventElapsedTime(&ms, start, stop));
     timer.collect(kernel_ms);
     m_fLastRuntime = ms / 1000.0f;
-    m_uLastNumRaysTraced = takeRayCount();
+    takeRayCounts(intersect_rays, shadow_rays);
+    m_uLastNumRaysTraced = intersect_rays + shadow_rays;
     m_fAccRuntime += m_fLastRuntime; m_uAccNumRaysTraced += m_uLastNumRaysTraced;
 }
 template class Tracer<true>;
@@ -176,6 +198,8 @@ WavefrontPathTracer::WavefrontPathTracer() {
     m_sParameters.addBool("Direct", true);
     m_sParameters.addInterval("MaxPathLength", 50, 1, INT_MAX);
     m_sParameters.addInterval("RRStartDepth", 5, 1, INT_MAX);
+    // build-specific: passes rendered together in one wavefront; 0 = choose so that a launch carries >= ~4 M paths
+    m_sParameters.addInterval("PassBatch", 0, 0, 64);
     int dev = 0; hipDeviceProp_t prop; CTL_HIP(hipGetDevice(&dev)); CTL_HIP(hipGetDeviceProperties(&prop, dev));
     grid_blocks = prop.multiProcessorCount * 8;   // 8 x 256-thread workgroups per CU = 32 waves/CU
 }
@@ -184,7 +208,8 @@ float4* WavefrontPathTracer::new_f4(size_t n) { f4_.emplace_back(new dbuf<float4
 void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
     Tracer<true>::Resize(_w, _h);
     // DoubleRayBuffer(w*h, w*h) (WavefrontPathTracer.h:59) — here per rank: its tile shard's pixels
-    capacity = shard_pixel_count(_w, _h, shard_rank, shard_world);
+    n_local_pixels = shard_pixel_count(_w, _h, shard_rank, shard_world);
+    capacity = n_local_pixels * passBatch();
     f4_.clear();
     for (int b = 0; b < 2; b++) {
         path_soa& p = Q.path[b];
@@ -194,57 +219,75 @@ void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
     }
     Q.hit = new_f4(capacity); hit_node_.alloc(capacity); Q.hit_node = hit_node_.p;
     Q.fin.rad = new_f4(capacity); Q.fin.dir = new_f4(capacity); px_[2].alloc(capacity); Q.fin.px = px_[2].p;
-    stats_.alloc(1); Q.stats = stats_.p; CTL_HIP(hipMemset(stats_.p, 0, sizeof(unsigned long long)));
+    stats_.alloc(8); Q.stats = stats_.p; CTL_HIP(hipMemset(stats_.p, 0, 8 * sizeof(unsigned long long)));
     Q.capacity = capacity;
     counts_.free(); work_.free();
 }
 
-uint64_t WavefrontPathTracer::takeRayCount() {
-    unsigned long long r = 0;
-    CTL_HIP(hipMemcpy(&r, stats_.p, sizeof(r), hipMemcpyDeviceToHost));
+// stats: [0] path rays, [1] shadow rays, [2..4] closest-hit N_inner/N_tri/N_inst, [5..7] any-hit N_inner/N_tri/N_inst
+void WavefrontPathTracer::takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) {
+    unsigned long long r[8];
+    CTL_HIP(hipMemcpy(r, stats_.p, sizeof(r), hipMemcpyDeviceToHost));
     CTL_HIP(hipMemset(stats_.p, 0, sizeof(r)));
-    return (uint64_t)r;
+    path_rays = r[0]; shadow_rays_ = r[1];
+    closest_counts.n_inner = r[2]; closest_counts.n_tri = r[3]; closest_counts.n_inst = r[4];
+    any_counts.n_inner = r[5]; any_counts.n_tri = r[6]; any_counts.n_inst = r[7];
 }
 
-void WavefrontPathTracer::DoRender(Image* I, unsigned int n_passes, const float* d_t1p, const float* d_t2p) {
+// WavefrontPathTracer::DoRender (Integrators/PseudoRealtime/WavefrontPathTracer.cu:166-191): ray generation, then per
+// bounce {intersect path rays, intersect the previous bounce's shadow rays, shade}.  Queue lengths stay in HBM, so
+// the whole pass is enqueued without any host round trip (the reference synchronises 3x per bounce).
+unsigned int WavefrontPathTracer::passBatch() const {
+    const int v = m_sParameters.getValue("PassBatch");
+    if (v > 0) return (unsigned int)v;
+    if (w == 0xffffffffu) return 1;
+    const uint64_t per_pass = shard_pixel_count(w, h, shard_rank, shard_world);
+    const uint64_t target = 4u << 20;
+    return (unsigned int)std::min<uint64_t>(64, std::max<uint64_t>(1, (target + per_pass - 1) / per_pass));
+}
+
+void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_t2p, unsigned int n_batch) {
+    if ((uint64_t)n_local_pixels * n_batch > capacity) Resize(w, h);   // PassBatch was raised after Resize
     const int maxPathLength = m_sParameters.getValue("MaxPathLength"), rrStart = m_sParameters.getValue("RRStartDepth");
     const bool direct = m_sParameters.getValue("Direct") != 0;
     const size_t n_counts = (size_t)(maxPathLength + 2) * 4, n_work = (size_t)2 * (maxPathLength + 2);
     if (counts_.n < n_counts) { counts_.alloc(n_counts); work_.alloc(n_work); }
     Q.counts = counts_.p; Q.work = work_.p;
-    launch_ctx lc{ stream, grid_blocks };
-    const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH;
-    for (unsigned int k = 0; k < n_passes; k++) {
-        pass_params P{};
-        P.t1 = d_t1p + k * n1; P.t2 = (const float2*)(d_t2p + k * n1 * 2);
-        P.width = w; P.height = h; P.tile_rank = shard_rank; P.tile_world = shard_world; P.n_local_pixels = capacity;
-        P.direct = direct ? 1 : 0; P.max_path_length = maxPathLength; P.rr_start_depth = rrStart;
-        CTL_HIP(hipMemsetAsync(counts_.p, 0, n_counts * sizeof(uint32_t), stream));
-        CTL_HIP(hipMemsetAsync(work_.p, 0, n_work * sizeof(uint32_t), stream));
-        timer.begin(stream, 0); launch_raygen(lc, m_pScene->S, Q, P); timer.end(stream);
-        for (int depth = 1; depth <= maxPathLength; depth++) {
-            const int cur = (depth - 1) & 1;
-            timer.begin(stream, 1);
-            launch_intersect_closest(lc, m_pScene->S, Q.path[cur].ray_o, Q.path[cur].ray_d, &Q.counts[(depth - 1) * 4 + 0], &Q.work[2 * depth], Q.hit, Q.hit_node);
-            if (depth > 1 && direct)
-                launch_intersect_any(lc, m_pScene->S, Q.sh_o[(depth - 1) & 1], Q.sh_d[(depth - 1) & 1], &Q.counts[(depth - 1) * 4 + 1], &Q.work[2 * depth + 1], Q.sh_occ[(depth - 1) & 1]);
-            timer.end(stream);
-            intersect_launches += (depth > 1 && direct) ? 2 : 1;
-            timer.begin(stream, 2);
-            if (depth > 1 && direct) launch_finalize(lc, Q, P, depth - 1, I->device());
-            launch_shade(lc, m_pScene->S, Q, P, depth, I->device());
-            timer.end(stream);
-        }
-        if (direct) {
-            timer.begin(stream, 1);
-            launch_intersect_any(lc, m_pScene->S, Q.sh_o[maxPathLength & 1], Q.sh_d[maxPathLength & 1], &Q.counts[maxPathLength * 4 + 1], &Q.work[2 * (maxPathLength + 1)], Q.sh_occ[maxPathLength & 1]);
-            timer.end(stream);
-            intersect_launches += 1;
-            timer.begin(stream, 2); launch_finalize(lc, Q, P, maxPathLength, I->device()); timer.end(stream);
-        }
-        launch_accumulate_stats(lc, Q, maxPathLength);
+    const launch_ctx lc{ stream, grid_blocks };
+    const dev_scene& S = m_pScene->S;
+    pass_params P{};
+    P.t1 = d_t1p; P.t2 = (const float2*)d_t2p;
+    P.batch = n_batch;
+    P.width = w; P.height = h; P.tile_rank = shard_rank; P.tile_world = shard_world; P.n_local_pixels = n_local_pixels;
+    P.direct = direct ? 1 : 0; P.max_path_length = maxPathLength; P.rr_start_depth = rrStart;
+    CTL_HIP(hipMemsetAsync(counts_.p, 0, n_counts * sizeof(uint32_t), stream));
+    CTL_HIP(hipMemsetAsync(work_.p, 0, n_work * sizeof(uint32_t), stream));
+    timer.begin(stream, 0); launch_raygen(lc, S, Q, P); timer.end(stream);
+    auto shadow_pass = [&](int d) {   // any-hit intersection of the shadow rays emitted at depth d
+        timer.begin(stream, 3);
+        if (counting) launch_intersect_count(lc, S, Q.sh_o[d & 1], Q.sh_d[d & 1], &Q.counts[d * 4 + 1], &Q.work[2 * d + 3], nullptr, nullptr, Q.sh_occ[d & 1], 1, Q.stats + 5);
+        else launch_intersect_any(lc, S, Q.sh_o[d & 1], Q.sh_d[d & 1], &Q.counts[d * 4 + 1], &Q.work[2 * d + 3], Q.sh_occ[d & 1]);
+        timer.end(stream);
+        shadow_launches++;
+    };
+    for (int depth = 1; depth <= maxPathLength; depth++) {
+        const int cur = (depth - 1) & 1;
+        timer.begin(stream, 1);
+        if (counting) launch_intersect_count(lc, S, Q.path[cur].ray_o, Q.path[cur].ray_d, &Q.counts[(depth - 1) * 4 + 0], &Q.work[2 * depth], Q.hit, Q.hit_node, nullptr, 0, Q.stats + 2);
+        else launch_intersect_closest(lc, S, Q.path[cur].ray_o, Q.path[cur].ray_d, &Q.counts[(depth - 1) * 4 + 0], &Q.work[2 * depth], Q.hit, Q.hit_node);
+        timer.end(stream);
+        intersect_launches++;
+        if (depth > 1 && direct) shadow_pass(depth - 1);
+        timer.begin(stream, 2);
+        if (depth > 1 && direct) launch_finalize(lc, Q, P, depth - 1, I->device());
+        launch_shade(lc, S, Q, P, depth, I->device());
+        timer.end(stream);
     }
-    CTL_HIP(hipGetLastError());
+    if (direct) {
+        shadow_pass(maxPathLength);
+        timer.begin(stream, 2); launch_finalize(lc, Q, P, maxPathLength, I->device()); timer.end(stream);
+    }
+    launch_accumulate_stats(lc, Q, maxPathLength);
 }
 
 } // namespace ctl

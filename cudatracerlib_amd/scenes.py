@@ -56,7 +56,9 @@ def icosphere(subdiv):
             ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
             nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
         v = np.array(verts, np.float64); f = np.array(nf, np.int64)
-    return v.astype(np.float32), f.astype(np.uint32)
+    # clockwise-outward winding: the reference's importers reverse the index order of OBJ / .serialized faces
+    # (ObjParser.cpp:861-866, ObjectParser.cpp:187-188) and Mesh::ComputeVertexNormals (Mesh.cpp:151-190) expects it
+    return v.astype(np.float32), np.ascontiguousarray(f[:, ::-1]).astype(np.uint32)
 
 
 def unit_box():

@@ -264,18 +264,29 @@ int ctl_tracer_set_sampler_tables(ctl_tracer* t, const float* tables_1d, const f
 int ctl_tracer_do_pass(ctl_tracer* t, ctl_image* img, int new_trace);
 /* n passes back-to-back without host synchronisation in between (throughput mode). */
 int ctl_tracer_do_passes(ctl_tracer* t, ctl_image* img, int new_trace, uint32_t n_passes);
+/* traversal statistics for the roofline: sums over rays of inner-node visits, triangle tests and instance entries
+ * (B_ray = 32 + 16 + 64*N_inner + 52*N_tri + 108*N_inst). */
+typedef struct { uint64_t n_inner, n_tri, n_inst; } ctl_traversal_counts;
 typedef struct {
     uint64_t rays_last_pass;       /* getRaysInLastPass (64-bit; the reference wraps at 2^32)            */
     uint64_t rays_total;           /* getAccRays                                                         */
     double seconds_last_pass;      /* getLastTimeSpentRenderingSec                                       */
     double seconds_total;          /* getAccTimeSpentRenderingSec                                        */
     uint32_t passes_done;          /* getNumPassesDone                                                   */
-    /* per-kernel HIP-event timing of the last do_pass/do_passes call, milliseconds */
-    double ms_intersect, ms_shade, ms_raygen;
-    uint64_t intersect_rays;       /* rays through the intersect kernels in that call                    */
+    /* per-kernel HIP-event timing of the last do_pass/do_passes call, milliseconds (events on the tracer's stream) */
+    double ms_intersect;           /* closest-hit intersect kernel (path rays)                           */
+    double ms_shade, ms_raygen;
+    double ms_intersect_any;       /* any-hit intersect kernel (NEE shadow rays)                         */
+    uint64_t intersect_rays;       /* path rays through the closest-hit kernel in that call              */
     uint64_t intersect_launches;
+    uint64_t shadow_rays;          /* shadow rays through the any-hit kernel in that call                */
+    uint64_t shadow_launches;
+    /* traversal statistics, filled only while ctl_tracer_set_counting(t, 1): sums over all rays of the call */
+    ctl_traversal_counts closest_counts, any_counts;
 } ctl_tracer_stats;
 int ctl_tracer_get_stats(ctl_tracer* t, ctl_tracer_stats* out);
+/* run the intersect kernels in counting mode (N_inner / N_tri / N_inst of SURVEY §8d); slower, for measurement only */
+int ctl_tracer_set_counting(ctl_tracer* t, int on);
 
 /* ---------------------------------------------------- intersect (row a7 alone) */
 /* __internal__IntersectBuffers (Kernel/TraceHelper.cu:736-746): n rays -> n hits; host pointers.
@@ -287,7 +298,6 @@ int ctl_intersect(ctl_scene* s, const ctl_ray* rays, uint32_t n, ctl_hit* hits, 
 int ctl_intersect_device(ctl_scene* s, const void* d_ray_o, const void* d_ray_d, uint32_t n, void* d_hit4, void* d_hit_node, int any_hit, float* ms_out);
 /* traversal statistics for the roofline: sums over the n rays of inner-node visits, triangle tests and
  * instance entries (B_ray = 32 + 16 + 64*N_inner + 52*N_tri + 108*N_inst). */
-typedef struct { uint64_t n_inner, n_tri, n_inst; } ctl_traversal_counts;
 int ctl_intersect_count(ctl_scene* s, const ctl_ray* rays, uint32_t n, int any_hit, ctl_traversal_counts* out);
 
 /* device memory helpers so that Python callers need no HIP binding */
@@ -295,6 +305,7 @@ int ctl_device_malloc(size_t bytes, void** out);
 int ctl_device_free(void* p);
 int ctl_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int ctl_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int ctl_memcpy_d2d(void* dst, const void* src, size_t bytes);
 int ctl_device_synchronize(void);
 int ctl_set_device(int ordinal);
 
