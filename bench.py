@@ -120,7 +120,8 @@ def main():
     if world > 1:
         # the single framebuffer exchange of the render: PixelData sums -> rank 0 over RCCL/xGMI
         ctl.api._check(ctl.lib.ctl_memcpy_d2d(fb.data_ptr(), img.device_ptr(), args.width * args.height * 28))
-        dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+        from cudatracerlib_amd.parallel import reduce_framebuffer
+        reduce_framebuffer(fb, dst=0)
     sync()
     elapsed = time.perf_counter() - t0
     st = tr.stats()

@@ -99,7 +99,13 @@ struct microfacet {
         const float tt = fabsf(tan_theta(v));
         if (tt == 0.0f) return 1.0f;
         const float alpha = project_roughness(v);
-        if (type == CTL_MF_GGX) { const float root = alpha * tt; return 2.0f / (1.0f + sqrtf(1.0f * 1.0f + root * root)); }
+        if (type == CTL_MF_GGX) {   // 2 / (1 + hypot2(1, alpha tan)) with math::hypot2's scaling (Math/MathFunc.h:326-341)
+            const float root = alpha * tt; float hyp;
+            if (1.0f > fabsf(root)) { const float r = root / 1.0f; hyp = 1.0f * sqrtf(1.0f + r * r); }
+            else if (root != 0.0f) { const float r = 1.0f / root; hyp = fabsf(root) * sqrtf(1.0f + r * r); }
+            else hyp = 0.0f;
+            return 2.0f / (1.0f + hyp);
+        }
         const float a = 1.0f / (alpha * tt);
         if (a >= 1.6f) return 1.0f;
         const float a2 = a * a;

@@ -72,7 +72,7 @@ typedef struct { float dist; int32_t node_idx; int32_t tri_idx; float u, v; } ct
 /* Engine/Image.h:10-29 — 28 B accumulator */
 typedef struct { float rgb[3]; float rgb_splat[3]; float weight_sum; } ctl_pixel_data;
 /* Engine/ShapeSet.h:19-30 — area-light triangle, 64 B, lives in the anim blob */
-typedef struct { float p[3][3]; float n[3]; float area; uint32_t i_dat; uint32_t t_dat; } ctl_shape_tri;
+typedef struct { float p[3][3]; float n[3]; float area; uint32_t i_dat; uint32_t t_dat; uint32_t pad; } ctl_shape_tri;   /* CUDA_ALIGN(16): 64 B */
 
 /* --------------------------------------------- compact scene-type descriptors */
 /* The reference stores BSDFs / lights / sensors as tagged C++ unions (Material 3344 B,

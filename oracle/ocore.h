@@ -373,6 +373,13 @@ inline float pdfEmitter(const Scene& S, const ctl_light* L) {
 }
 
 // --------------------------------------------------------------------------- microfacet (Engine/MicrofacetDistribution.{h,cu})
+inline float hypot2(float a, float b) {   // Math/MathFunc.h:326-341
+    float r;
+    if (fabsf(a) > fabsf(b)) { r = b / a; r = fabsf(a) * std::sqrt(1.0f + r * r); }
+    else if (b != 0.0f) { r = a / b; r = fabsf(b) * std::sqrt(1.0f + r * r); }
+    else r = 0.0f;
+    return r;
+}
 struct Microfacet {
     int type; float alphaU, alphaV; bool sampleVis; float expU = 0, expV = 0;
     Microfacet(int t, float aU, float aV, bool sv) : type(t), alphaU(fmax2(aU, 1e-4f)), alphaV(fmax2(aV, 1e-4f)), sampleVis(sv) {
@@ -407,7 +414,7 @@ struct Microfacet {
         const float tanTheta = fabsf(Frame::tanTheta(v));
         if (tanTheta == 0.0f) return 1.0f;
         float alpha = projectRoughness(v);
-        if (type == CTL_MF_GGX) { const float root = alpha * tanTheta; return 2.0f / (1.0f + std::sqrt(1.0f * 1.0f + root * root)); }
+        if (type == CTL_MF_GGX) { const float root = alpha * tanTheta; return 2.0f / (1.0f + hypot2(1.0f, root)); }
         float a = 1.0f / (alpha * tanTheta);
         if (a >= 1.6f) return 1.0f;
         float aSqr = a * a;

@@ -24,6 +24,11 @@ uint16_t orc_float_to_half(float f) { return floatToHalf(f); }
 float orc_half_to_float(uint16_t h, int host_quirk) { return halfToFloat(h, host_quirk != 0); }
 uint16_t orc_normal_encode(const float* n) { return normalToUchar2(V3(n[0], n[1], n[2])); }
 void orc_normal_decode(uint16_t v, float* n) { V3 r = uchar2ToNormal(v); n[0] = r.x; n[1] = r.y; n[2] = r.z; }
+// batch variants (the exhaustive codec tests)
+void orc_half_to_float_n(const uint16_t* h, uint32_t n, int host_quirk, float* out) { for (uint32_t i = 0; i < n; i++) out[i] = halfToFloat(h[i], host_quirk != 0); }
+void orc_float_to_half_n(const float* f, uint32_t n, uint16_t* out) { for (uint32_t i = 0; i < n; i++) out[i] = floatToHalf(f[i]); }
+void orc_normal_decode_n(const uint16_t* v, uint32_t n, float* out) { for (uint32_t i = 0; i < n; i++) { V3 r = uchar2ToNormal(v[i]); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; } }
+void orc_normal_encode_n(const float* nrm, uint32_t n, uint16_t* out) { for (uint32_t i = 0; i < n; i++) out[i] = normalToUchar2(V3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2])); }
 void orc_matrix_inverse(const float* m, float* out) { M44 a; std::memcpy(a.d, m, 64); M44 r = inverse(a); std::memcpy(out, r.d, 64); }
 
 // TriangleData(P, matIndex, T, N) (Engine/TriangleData.cu:11-16)

@@ -73,8 +73,9 @@ void ref_square_to_uniform_triangle(float x, float y, float* out) { auto r = War
 void ref_square_to_uniform_disk_concentric(float x, float y, float* out) { auto r = Warp::squareToUniformDiskConcentric(Vec2f(x, y)); out[0] = r.x; out[1] = r.y; }
 float ref_fresnel_dielectric_ext(float cosThetaI, float eta, float* cosThetaT) { return FresnelHelper::fresnelDielectricExt(cosThetaI, *cosThetaT, eta); }
 void ref_fresnel_conductor_exact(float cosThetaI, const float* eta, const float* k, float* out) {
-    Spectrum r = FresnelHelper::fresnelConductorExact(cosThetaI, Spectrum(eta[0], eta[1], eta[2]), Spectrum(k[0], k[1], k[2]));
-    out[0] = r[0]; out[1] = r[1]; out[2] = r[2];
+    // the scalar overload (FresnelHelper.h:92-117): the Spectrum overload (:119-146) is the same expression per channel, but
+    // Spectrum's RGB constructor lives in Math/Spectrum.cu, which only nvcc can compile (cudaMemcpyToSymbol of a struct, :729)
+    for (int c = 0; c < 3; c++) out[c] = FresnelHelper::fresnelConductorExact(cosThetaI, eta[c], k[c]);
 }
 void ref_coordinate_system(const float* a, float* s, float* t) {
     NormalizedT<Vec3f> S, T; coordinateSystem(NormalizedT<Vec3f>(Vec3f(a[0], a[1], a[2])), S, T);

@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE'S OWN code (oracle/_ref/libctlref.so, compiled from /root/reference
+by `make -C oracle ref`).  Run in the build container only; the fixtures are data (inputs + the reference's outputs),
+committed so that the oracle stays pinned on boxes where /root/reference does not exist.
+
+    python tests/golden/generate.py
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle  # noqa: E402
+
+f32 = C.c_float
+
+
+def main():
+    r = oracle.load_ref()
+    if r is None:
+        raise SystemExit("oracle/_ref/libctlref.so missing: run `make -C oracle ref` (needs /root/reference)")
+    rs = np.random.RandomState(20260929)
+
+    # ---- Woop triangles: setData rows, getData round trip, Intersect (Engine/TriIntersectorData.cu)
+    n = 256
+    tris = (rs.normal(size=(n, 3, 3)) * rs.uniform(0.05, 50, size=(n, 1, 1))).astype(np.float32)
+    rows = np.zeros((n, 12), np.float32); back = np.zeros((n, 3, 3), np.float32)
+    rays_o = np.zeros((n, 3), np.float32); rays_d = np.zeros((n, 3), np.float32); hits = np.zeros((n, 4), np.float32)
+    for i in range(n):
+        r.ref_woop_set_data(tris[i, 0].ctypes.data_as(C.c_void_p), tris[i, 1].ctypes.data_as(C.c_void_p), tris[i, 2].ctypes.data_as(C.c_void_p), rows[i].ctypes.data_as(C.c_void_p))
+        r.ref_woop_get_data(rows[i].ctypes.data_as(C.c_void_p), back[i, 0].ctypes.data_as(C.c_void_p), back[i, 1].ctypes.data_as(C.c_void_p), back[i, 2].ctypes.data_as(C.c_void_p))
+        b = rs.dirichlet([1, 1, 1]) if i % 3 else rs.uniform(-0.5, 1.5, size=3)
+        target = (b[0] * tris[i, 0] + b[1] * tris[i, 1] + (1 - b[0] - b[1]) * tris[i, 2]).astype(np.float32)
+        o = (target + rs.normal(size=3) * 5).astype(np.float32)
+        d = target - o; d = (d / np.linalg.norm(d)).astype(np.float32)
+        rays_o[i], rays_d[i] = o, d
+        tuv = np.zeros(3, np.float32)
+        h = r.ref_woop_intersect(rows[i].ctypes.data, o.ctypes.data, d.ctypes.data, f32(1e30), tuv.ctypes.data)
+        hits[i] = [h, tuv[0], tuv[1], tuv[2]]
+    np.savez_compressed(os.path.join(HERE, "woop.npz"), tris=tris, rows=rows, back=back, rays_o=rays_o, rays_d=rays_d, hits=hits)
+
+    # ---- codecs: half (host branch), spherical normals (Math/half.h, Math/Compression.h)
+    h2f = np.array([r.ref_half_to_float(h) for h in range(65536)], np.float32)
+    xs = np.concatenate([rs.normal(size=4096).astype(np.float32) * np.float32(10.0) ** rs.randint(-8, 6, 4096).astype(np.float32),
+                         np.array([0, -0.0, 1e-8, 6e-5, 65504, 65520, 1e6, np.inf, -np.inf], np.float32)]).astype(np.float32)
+    f2h = np.array([r.ref_float_to_half(float(x)) for x in xs], np.uint16)
+    dec = np.zeros((65536, 3), np.float32)
+    for v in range(65536):
+        r.ref_normal_decode(v, dec[v].ctypes.data)
+    nrm = rs.normal(size=(4096, 3)).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm[:6] = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+    enc = np.array([r.ref_normal_encode(nrm[i].ctypes.data_as(C.c_void_p)) for i in range(len(nrm))], np.uint16)
+    np.savez_compressed(os.path.join(HERE, "codecs.npz"), half_to_float_host=h2f, f2h_in=xs, f2h_out=f2h, normal_decode=dec, normal_in=nrm, normal_encode=enc)
+
+    # ---- TriangleData pack + fillDG (Engine/TriangleData.cu)
+    n = 128
+    P = (rs.normal(size=(n, 9)) * 3).astype(np.float32)
+    N = rs.normal(size=(n, 3, 3)).astype(np.float32); N /= np.linalg.norm(N, axis=2, keepdims=True); N = N.reshape(n, 9).copy()
+    T = rs.uniform(-2, 2, size=(n, 6)).astype(np.float32); T[: n // 4] = 0
+    packed = np.zeros((n, 8), np.uint32); dg = np.zeros((n, 21), np.float32)
+    M = np.zeros((n, 16), np.float32); uv = rs.dirichlet([1, 1, 1], size=n).astype(np.float32)
+    for i in range(n):
+        r.ref_triangle_data_pack(P[i].ctypes.data, N[i].ctypes.data, T[i].ctypes.data, i % 7, packed[i].ctypes.data)
+        m = np.eye(4, dtype=np.float32)
+        if i % 2:
+            q = rs.normal(size=(3, 3)); q, _ = np.linalg.qr(q); m[:3, :3] = q * rs.uniform(0.5, 3); m[:3, 3] = rs.normal(size=3) * 10
+        M[i] = m.reshape(16)
+        r.ref_triangle_fill_dg(packed[i].ctypes.data, M[i].ctypes.data, f32(uv[i, 0]), f32(uv[i, 1]), dg[i].ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "triangle_data.npz"), P=P, N=N, T=T, packed=packed, M=M, uv=uv[:, :2].copy(), dg=dg)
+
+    # ---- warps / Fresnel / frames (Math/Warp.h, FresnelHelper.h, Frame.h, float4x4.h)
+    s = rs.uniform(0, 1, size=(1024, 2)).astype(np.float32); s[0] = [0.5, 0.5]; s[1] = [0, 0]; s[2] = [0.999999, 0.5]
+    cosh = np.zeros((len(s), 3), np.float32); tri = np.zeros((len(s), 2), np.float32); disk = np.zeros((len(s), 2), np.float32)
+    for i in range(len(s)):
+        r.ref_square_to_cosine_hemisphere(f32(s[i, 0]), f32(s[i, 1]), cosh[i].ctypes.data)
+        r.ref_square_to_uniform_triangle(f32(s[i, 0]), f32(s[i, 1]), tri[i].ctypes.data)
+        r.ref_square_to_uniform_disk_concentric(f32(s[i, 0]), f32(s[i, 1]), disk[i].ctypes.data)
+    ci = rs.uniform(-1, 1, size=512).astype(np.float32); eta = rs.choice(np.array([1.0, 1.5, 1.5046 / 1.000277, 1 / 1.5, 2.4], np.float32), size=512)
+    fd = np.zeros((512, 2), np.float32)
+    for i in range(512):
+        ct = f32()
+        fd[i, 0] = r.ref_fresnel_dielectric_ext(f32(ci[i]), f32(eta[i]), C.byref(ct)); fd[i, 1] = ct.value
+    ce = rs.uniform(0, 1, size=256).astype(np.float32); ek = rs.uniform(0.05, 5, size=(256, 6)).astype(np.float32); fc = np.zeros((256, 3), np.float32)
+    for i in range(256):
+        r.ref_fresnel_conductor_exact(f32(ce[i]), ek[i, :3].ctypes.data, ek[i, 3:].ctypes.data, fc[i].ctypes.data)
+    cs_in = nrm[:512].copy(); cs_s = np.zeros((512, 3), np.float32); cs_t = np.zeros((512, 3), np.float32)
+    for i in range(512):
+        r.ref_coordinate_system(cs_in[i].ctypes.data_as(C.c_void_p), cs_s[i].ctypes.data_as(C.c_void_p), cs_t[i].ctypes.data_as(C.c_void_p))
+    mats = rs.normal(size=(128, 16)).astype(np.float32); mats[::2, 12:] = [0, 0, 0, 1]; inv = np.zeros((128, 16), np.float32)
+    for i in range(128):
+        r.ref_matrix_inverse(mats[i].ctypes.data_as(C.c_void_p), inv[i].ctypes.data_as(C.c_void_p))
+    np.savez_compressed(os.path.join(HERE, "math.npz"), s=s, cosine_hemisphere=cosh, uniform_triangle=tri, disk_concentric=disk,
+                        fd_cos=ci, fd_eta=eta, fd_out=fd, fc_cos=ce, fc_eta_k=ek, fc_out=fc, cs_in=cs_in, cs_s=cs_s, cs_t=cs_t, mat_in=mats, mat_inv=inv)
+
+    # ---- microfacet distribution (Engine/MicrofacetDistribution.cu): Beckmann/GGX eval, G1, pdf, sample
+    n = 512
+    wi = rs.normal(size=(n, 3)).astype(np.float32); wi[:, 2] = np.abs(wi[:, 2]) + 0.05; wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    m = rs.normal(size=(n, 3)).astype(np.float32); m[:, 2] = np.abs(m[:, 2]) + 0.2; m /= np.linalg.norm(m, axis=1, keepdims=True)
+    cfg = np.stack([rs.randint(0, 2, n), rs.randint(0, 2, n)], axis=1).astype(np.int32)   # type, sampleVisible
+    alpha = rs.uniform(0.02, 0.6, size=(n, 2)).astype(np.float32); alpha[::2, 1] = alpha[::2, 0]
+    cfg[(cfg[:, 0] == 0), 1] = 0   # Beckmann visible sampling needs erfinv: not on this path's configs, excluded
+    ev = np.zeros((n, 3), np.float32); sm = np.zeros((n, 4), np.float32); su = rs.uniform(0.01, 0.99, size=(n, 2)).astype(np.float32)
+    for i in range(n):
+        r.ref_microfacet_eval(int(cfg[i, 0]), f32(alpha[i, 0]), f32(alpha[i, 1]), int(cfg[i, 1]), wi[i].ctypes.data, m[i].ctypes.data, ev[i].ctypes.data)
+        r.ref_microfacet_sample(int(cfg[i, 0]), f32(alpha[i, 0]), f32(alpha[i, 1]), int(cfg[i, 1]), wi[i].ctypes.data, f32(su[i, 0]), f32(su[i, 1]), sm[i].ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "microfacet.npz"), wi=wi, m=m, cfg=cfg, alpha=alpha, eval=ev, su=su, sample=sm)
+
+    # ---- PerspectiveSensor::sampleRay (SceneTypes/Sensor.cu:76-128)
+    n = 256
+    cams = []
+    px = rs.uniform(0, 1, size=(n, 2)).astype(np.float32); out = np.zeros((n, 6), np.float32); par = np.zeros((n, 5), np.float32); tw = np.zeros((n, 16), np.float32)
+    for i in range(n):
+        w, h = int(rs.choice([64, 256, 1920])), int(rs.choice([64, 256, 1080]))
+        fov = np.float32(np.radians(rs.uniform(20, 100)))
+        q, _ = np.linalg.qr(rs.normal(size=(3, 3)))
+        m = np.eye(4, dtype=np.float32); m[:3, :3] = q; m[:3, 3] = rs.normal(size=3) * 20
+        tw[i] = m.reshape(16); par[i] = [fov, 1e-2, 1e4, w, h]
+        p = (px[i] * [w, h]).astype(np.float32); px[i] = p
+        r.ref_sensor_sample_ray(tw[i].ctypes.data, f32(fov), f32(1e-2), f32(1e4), w, h, f32(p[0]), f32(p[1]), out[i, :3].ctypes.data, out[i, 3:].ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "sensor.npz"), to_world=tw, params=par, pixel=px, ray=out)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

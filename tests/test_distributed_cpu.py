@@ -1,0 +1,65 @@
+"""N > 1 path on CPU: two processes over gloo run the host logic bench.py uses for multi-GPU — tile ownership, a
+per-rank full-size PixelData frame, ONE sum-reduce to rank 0 (cudatracerlib_amd/parallel.py).  The per-rank radiance
+comes from the oracle (the GPUs are not here); what is tested is that the shards partition the film and that the single
+collective reproduces the one-rank frame exactly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, w, h, out_path):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from cudatracerlib_amd import scenes, parallel
+    sc = scenes.cornell_box(w, h)
+    orc = oracle.Oracle()
+    tables = orc.sequence_tables(1)
+    full, _ = orc.render(sc.desc, w, h, n_passes=1, tables=tables, max_path_length=4, threads=2)
+    mine = full * parallel.tile_mask(w, h, rank, world)[..., None]          # this rank's tiles, zeros elsewhere
+    fb = torch.from_numpy(np.ascontiguousarray(mine.reshape(-1)))
+    parallel.reduce_framebuffer(fb, dst=0)                                     # the one exchange step
+    if rank == 0:
+        np.save(out_path, np.stack([fb.numpy().reshape(h, w, 7), full]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_ownership_partitions_the_film():
+    from cudatracerlib_amd import parallel
+    for (w, h, world) in ((192, 128, 2), (1920, 1080, 8), (100, 70, 3)):
+        own = parallel.tile_owner(w, h, world)
+        assert own.shape == (h, w) and own.min() == 0 and own.max() == min(world, ((w + 63) // 64) * ((h + 63) // 64)) - 1
+        masks = [parallel.tile_mask(w, h, r, world) for r in range(world)]
+        assert np.array_equal(sum(m.astype(int) for m in masks), np.ones((h, w), int))
+        # per-rank path capacity (incl. clipped border lanes) covers the owned pixels
+        for r in range(world):
+            assert parallel.local_pixel_count(w, h, r, world) >= masks[r].sum()
+    # load balance at the benchmark size: 510 tiles over 8 ranks
+    counts = [parallel.tile_mask(1920, 1080, r, 8).sum() for r in range(8)]
+    assert max(counts) / min(counts) < 1.1
+
+
+def test_two_rank_gloo_reduce_reproduces_single_rank_frame(tmp_path):
+    import torch.multiprocessing as mp
+    w, h = 192, 128   # 3 x 2 tiles
+    out = str(tmp_path / "fb.npy")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, w, h, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got, full = np.load(out)
+    assert np.array_equal(got, full)   # x + 0 == x: bit-identical to the one-rank frame
+    assert full[..., 6].sum() == w * h   # one sample per pixel per pass (a jittered sample may land in the neighbouring pixel)
