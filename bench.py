@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--instances", type=int, default=2000)
     ap.add_argument("--subdiv", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flatten", type=int, default=1, help="traverse one world-space BVH over all instanced triangles (64 B of HBM per triangle)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,7 +92,7 @@ def main():
 
     sc = build_scene(args)
     desc = sc.desc
-    scene = ctl.Scene(desc)
+    scene = ctl.Scene(desc, flatten=bool(args.flatten))
     tr = ctl.WavefrontPathTracer()
     p = tr.getParameters()
     p.setValue("Direct", True); p.setValue("MaxPathLength", args.depth); p.setValue("RRStartDepth", 5)
@@ -161,11 +162,13 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic-SM %dx%d, 1 spp/step, depth %d, NEE on, %d instances x icosphere(%d)/boxes, %d instanced triangles"
                        % (args.width, args.height, args.depth, args.instances, args.subdiv, int(_instanced_tris(desc))) if args.workload == "synthetic-sm" else args.workload,
+                       "bvh": "flattened world-space BVH2 (64 B nodes, 64 B leaf entries)" if args.flatten else "two-level (scene BVH + instanced mesh BVHs)",
                        "parallelism": "image tiles 64x64 round-robin over %d GPU(s), 1 RCCL reduce of the framebuffer" % world,
                        "rays_per_step": int(rays / args.steps)},
             "roofline": {"bound": "hbm", "kernel": "k_intersect<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_ray": round(per_ray_closest, 1), "rays_per_launch": int(n_closest / max(1, launches_closest)),
+                         "bytes_per_ray": round(per_ray_closest, 1), "per_ray": {"n_inner": round(cs.closest_counts.n_inner / max(1, cs.intersect_rays), 2), "n_tri": round(cs.closest_counts.n_tri / max(1, cs.intersect_rays), 2), "n_inst": round(cs.closest_counts.n_inst / max(1, cs.intersect_rays), 2)},
+                         "lane_utilisation": {"inner": round(cs.closest_counts.n_inner / max(1, 64 * cs.closest_counts.wave_inner_iters), 3), "tri": round(cs.closest_counts.n_tri / max(1, 64 * cs.closest_counts.wave_tri_iters), 3)}, "rays_per_launch": int(n_closest / max(1, launches_closest)),
                          "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches_closest,
                          "shadow_kernel": {"bytes_per_ray": round(per_ray_any, 1), "rays": n_any, "ms": round(k_ms_any, 3),
                                            "achieved": round(per_ray_any * n_any / (k_ms_any * 1e-3) / 1e9, 2) if k_ms_any > 0 else 0.0},

@@ -66,7 +66,7 @@ class ctl_pixel_data(C.Structure):
 
 
 class ctl_traversal_counts(C.Structure):
-    _fields_ = [("n_inner", u64), ("n_tri", u64), ("n_inst", u64)]
+    _fields_ = [("n_inner", u64), ("n_tri", u64), ("n_inst", u64), ("wave_inner_iters", u64), ("wave_tri_iters", u64)]
 
 
 class ctl_tracer_stats(C.Structure):
@@ -259,10 +259,10 @@ class DynamicScene:
 class Scene:
     """The scene resident in HBM (UpdateKernel, Kernel/TraceHelper.cu:182-217)."""
 
-    def __init__(self, desc):
+    def __init__(self, desc, flatten=False):
         self._h = C.c_void_p()
         self._keepalive = desc
-        _check(lib.ctl_scene_create(C.byref(desc), C.byref(self._h)))
+        _check(lib.ctl_scene_create_ex(C.byref(desc), u32(1 if flatten else 0), C.byref(self._h)))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -288,7 +288,7 @@ def intersect_count(scene, rays, any_hit=False):
     r, rp = _rays_struct(rays)
     c = ctl_traversal_counts()
     _check(lib.ctl_intersect_count(scene._h, rp, u32(len(r)), 1 if any_hit else 0, C.byref(c)))
-    return dict(n_inner=c.n_inner, n_tri=c.n_tri, n_inst=c.n_inst)
+    return dict(n_inner=c.n_inner, n_tri=c.n_tri, n_inst=c.n_inst, wave_inner_iters=c.wave_inner_iters, wave_tri_iters=c.wave_tri_iters)
 
 
 class Image:

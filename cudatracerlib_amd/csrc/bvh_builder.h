@@ -33,3 +33,10 @@ struct bvh_result {
 void build_bvh(const std::vector<aabb>& prim_boxes, int max_leaf, bool wrap_single_leaf, int max_depth_limit, bvh_result& out);
 
 } // namespace ctl
+
+namespace ctl {
+// 4-wide node obtained by collapsing the BVH2 (greedy: repeatedly open the inner child with the largest surface area).
+// child >= 0: index into the wide-node array; child < 0: ~firstLeafEntry (same leaf entries as the BVH2); n = children used.
+struct wide4_node { aabb box; aabb cbox[4]; int child[4]; int n; };
+void collapse_bvh4(const bvh_result& R, std::vector<wide4_node>& out, int& max_depth);
+} // namespace ctl

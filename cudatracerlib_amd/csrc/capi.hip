@@ -11,7 +11,7 @@
 using namespace ctl;
 
 struct ctl_builder { scene_builder b; };
-struct ctl_scene { Scene s; explicit ctl_scene(const ctl_scene_desc& d) : s(d) {} };
+struct ctl_scene { Scene s; ctl_scene(const ctl_scene_desc& d, bool flatten) : s(d, flatten) {} };
 struct ctl_image { Image img; ctl_image(uint32_t w, uint32_t h) : img(w, h) {} };
 struct ctl_tracer { std::unique_ptr<TracerBase> t; };
 struct ctl_sequence_generator { sequence_generator g; };
@@ -63,7 +63,8 @@ int ctl_builder_set_camera(ctl_builder* b, const ctl_sensor* sensor) { CTL_REQUI
 int ctl_builder_finalize(ctl_builder* b, ctl_scene_desc* out) { CTL_REQUIRE(b && out, "null argument"); CTL_TRY b->b.finalize(*out); CTL_CATCH }
 
 // ---- scene
-int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc); CTL_CATCH }
+int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc, false); CTL_CATCH }
+int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc, (flags & CTL_SCENE_FLATTEN) != 0); CTL_CATCH }
 void ctl_scene_destroy(ctl_scene* s) { delete s; }
 int ctl_parse_mitsuba_scene(ctl_builder* b, const char* xml_path, int32_t* width_inout, int32_t* height_inout) {
     CTL_REQUIRE(b && xml_path, "null argument");
@@ -128,7 +129,7 @@ static void intersect_host(Scene& sc, const ctl_ray* rays, uint32_t n, ctl_hit* 
     for (uint32_t i = 0; i < n; i++) { ro[i] = make_float4(rays[i].a[0], rays[i].a[1], rays[i].a[2], rays[i].a[3]); rd[i] = make_float4(rays[i].b[0], rays[i].b[1], rays[i].b[2], rays[i].b[3]); }
     dbuf<float4> d_ro, d_rd, d_hit; dbuf<int> d_node; dbuf<unsigned long long> d_cnt;
     d_ro.upload(ro.data(), n); d_rd.upload(rd.data(), n); d_hit.alloc(n); d_node.alloc(n);
-    if (counts) { d_cnt.alloc(3); CTL_HIP(hipMemset(d_cnt.p, 0, 24)); }
+    if (counts) { d_cnt.alloc(5); CTL_HIP(hipMemset(d_cnt.p, 0, 40)); }
     CTL_HIP(hipDeviceSynchronize());
     run_intersect(sc, d_ro.p, d_rd.p, n, d_hit.p, d_node.p, nullptr, any_hit, counts ? d_cnt.p : nullptr, nullptr);
     if (hits) {
@@ -136,7 +137,7 @@ static void intersect_host(Scene& sc, const ctl_ray* rays, uint32_t n, ctl_hit* 
         CTL_HIP(hipMemcpy(hh.data(), d_hit.p, (size_t)n * 16, hipMemcpyDeviceToHost)); CTL_HIP(hipMemcpy(hn.data(), d_node.p, (size_t)n * 4, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < n; i++) { hits[i].dist = hh[i].x; hits[i].u = hh[i].y; hits[i].v = hh[i].z; hits[i].tri_idx = __builtin_bit_cast(int, hh[i].w); hits[i].node_idx = hn[i]; }
     }
-    if (counts) { unsigned long long c[3]; CTL_HIP(hipMemcpy(c, d_cnt.p, 24, hipMemcpyDeviceToHost)); counts->n_inner = c[0]; counts->n_tri = c[1]; counts->n_inst = c[2]; }
+    if (counts) { unsigned long long c[5]; CTL_HIP(hipMemcpy(c, d_cnt.p, 40, hipMemcpyDeviceToHost)); *counts = ctl_traversal_counts{ c[0], c[1], c[2], c[3], c[4] }; }
 }
 int ctl_intersect(ctl_scene* s, const ctl_ray* rays, uint32_t n, ctl_hit* hits, int any_hit) {
     CTL_REQUIRE(s && (rays || !n) && (hits || !n), "null argument");

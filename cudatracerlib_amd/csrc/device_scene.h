@@ -7,7 +7,7 @@
 namespace ctl {
 
 constexpr int kExitMarker = 0x76543211;   // traversal-stack marker: leave the current instance (> kSentinel as unsigned)
-constexpr int kStackSize = 64;            // top depth + bottom depth + markers, checked by the builder
+constexpr int kStackSize = 96;            // two-level: top depth + bottom depth + markers; 4-wide flat tree: 3 * depth + 1 — both checked at upload
 
 // precomputed PerspectiveSensor state (SceneTypes/Sensor.cu:76-96)
 struct dev_sensor {
@@ -21,6 +21,9 @@ struct dev_scene {
     const float4* bot_nodes;     // all mesh BVHs, same encoding; a mesh's root is at its node offset
     const float4* leaf_tris;     // 4 x float4 per leaf entry: Woop rows a,b,c + {index bits, 0, 0, 0}  (64 B, one fetch group)
     const float4* inst;          // 4 x float4 per node: inverse-transform rows 0..2 + {w33, nodeOff4, leafOff, triOff} (bits)
+    const float4* flat_nodes;    // optional single-level world-space BVH over all instanced triangles (flatten.cpp), else nullptr
+    const float4* flat_leaves;   // 4 x float4 per leaf entry: world-space Woop rows + {globalTri << 1 | last, node, 0, 0}
+    int flat_root;
     const float4* inst_fwd;      // 3 x float4 per node: forward-transform rows 0..2 (fillDG)
     const uint4* tri_data;       // 2 x uint4 per triangle (TriangleData, 32 B)
     const uint4* node_info;      // per node {material_offset, light0, light1, n_lights}

@@ -47,6 +47,8 @@ struct pass_params {
 
 struct launch_ctx { hipStream_t stream; int grid_blocks; };
 
+// measurement knobs (environment: CTL_REFILL_IDLE), applied once per process
+void apply_tuning_from_env();
 void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P);
 // intersect `n = counts[count_slot]` rays (device-side count) from (ro, rd) into (hit, hit_node) or into occ (any-hit)
 void launch_intersect_closest(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node);

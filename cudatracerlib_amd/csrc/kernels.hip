@@ -5,6 +5,7 @@
 #include "kernels.h"
 #include "traverse.h"
 #include "shading.h"
+#include <cstdlib>
 
 namespace ctl {
 
@@ -56,31 +57,20 @@ __global__ __launch_bounds__(kBlock) void k_raygen(dev_scene S, wave_queues Q, p
 }
 
 // ------------------------------------------------------------------------------------------------ intersection
-// One ray per lane; a wave draws 64 consecutive rays at a time from a global cursor (persistent waves, as the
-// reference's g_warpCounter pool, Kernel/TraceHelper.cu:386-399, re-derived for 64-wide waves).
-template <bool ANY_HIT, bool COUNT>
+// Persistent waves with lane refill and an LDS traversal stack — see traverse.h (the reference's g_warpCounter pool,
+// Kernel/TraceHelper.cu:386-399, re-derived for 64-wide waves).
+template <bool ANY_HIT, bool COUNT, bool FLAT>
 __global__ __launch_bounds__(kBlock) void k_intersect(dev_scene S, const float4* __restrict__ ro, const float4* __restrict__ rd, const uint32_t* __restrict__ n_ptr,
                                                        uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ,
                                                        unsigned long long* __restrict__ counts3) {
+    __shared__ int lds_stack[(FLAT ? kLdsStackFlat : kLdsStack) * kBlock];
     const uint32_t n = *n_ptr;
-    const int lane = threadIdx.x & 63;
-    int stack[kStackSize];
-    trav_counts tc{ 0, 0, 0 };
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(work, 64u);
-        base = __shfl(base, 0, 64);
-        if (base >= n) break;
-        const uint32_t i = base + lane;
-        if (i < n) {
-            const float4 o = ro[i], d = rd[i];
-            const ray_hit h = traverse<ANY_HIT, COUNT>(S, make_float3(o.x, o.y, o.z), o.w, make_float3(d.x, d.y, d.z), d.w, stack, tc);
-            if (ANY_HIT && occ) occ[i] = h.tri >= 0 ? 1u : 0u;
-            if (hit) { hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.tri)); hit_node[i] = h.node; }
-        }
-    }
+    trav_counts tc{ 0, 0, 0, 0, 0 };
+    if (FLAT) intersect_flat<ANY_HIT, COUNT>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
+    else intersect_persistent<ANY_HIT, COUNT>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
     if (COUNT) {
         atomicAdd(&counts3[0], (unsigned long long)tc.n_inner); atomicAdd(&counts3[1], (unsigned long long)tc.n_tri); atomicAdd(&counts3[2], (unsigned long long)tc.n_inst);
+        atomicAdd(&counts3[3], (unsigned long long)tc.w_inner); atomicAdd(&counts3[4], (unsigned long long)tc.w_tri);
     }
 }
 
@@ -257,20 +247,33 @@ __global__ __launch_bounds__(kBlock) void k_resolve_rgb(const ctl_pixel_data* __
     }
 }
 
+void apply_tuning_from_env() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (const char* e = getenv("CTL_REFILL_IDLE")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refill_idle), &v, sizeof(v)); }
+    if (const char* e = getenv("CTL_TRI_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tri_batch), &v, sizeof(v)); }
+}
+
 // ------------------------------------------------------------------------------------------------ launch wrappers
 void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P) {
     hipLaunchKernelGGL(k_raygen, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, Q, P);
 }
+#define CTL_LAUNCH_INTERSECT(ANY, CNT, ...)                                                                                          \
+    do {                                                                                                                             \
+        if (S.flat_nodes) hipLaunchKernelGGL((k_intersect<ANY, CNT, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((k_intersect<ANY, CNT, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__);            \
+    } while (0)
 void launch_intersect_closest(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node) {
-    hipLaunchKernelGGL((k_intersect<false, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, (uint32_t*)nullptr, (unsigned long long*)nullptr);
+    CTL_LAUNCH_INTERSECT(false, false, S, ro, rd, n_ptr, work, hit, hit_node, (uint32_t*)nullptr, (unsigned long long*)nullptr);
 }
 void launch_intersect_any(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, uint32_t* occ, float4* hit, int* hit_node) {
-    hipLaunchKernelGGL((k_intersect<true, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, occ, (unsigned long long*)nullptr);
+    CTL_LAUNCH_INTERSECT(true, false, S, ro, rd, n_ptr, work, hit, hit_node, occ, (unsigned long long*)nullptr);
 }
 void launch_intersect_count(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node,
                             uint32_t* occ, int any_hit, unsigned long long* counts3) {
-    if (any_hit) hipLaunchKernelGGL((k_intersect<true, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, occ, counts3);
-    else hipLaunchKernelGGL((k_intersect<false, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, (uint32_t*)nullptr, counts3);
+    if (any_hit) CTL_LAUNCH_INTERSECT(true, true, S, ro, rd, n_ptr, work, hit, hit_node, occ, counts3);
+    else CTL_LAUNCH_INTERSECT(false, true, S, ro, rd, n_ptr, work, hit, hit_node, (uint32_t*)nullptr, counts3);
 }
 void launch_shade(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image) {
     hipLaunchKernelGGL(k_shade, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, Q, P, depth, image);

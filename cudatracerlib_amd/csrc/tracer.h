@@ -33,11 +33,13 @@ template <typename T> struct dbuf {   // tracked device allocation (Base/CudaMem
 // KernelDynamicScene in HBM (UpdateKernel, Kernel/TraceHelper.cu:182-217)
 class Scene {
 public:
-    explicit Scene(const ctl_scene_desc& d);
+    // flatten: also build the single-level world-space BVH (flatten.cpp) and make the intersect kernels use it
+    explicit Scene(const ctl_scene_desc& d, bool flatten = false);
+    bool flattened() const { return S.flat_nodes != nullptr; }
     dev_scene S{};
     uint32_t n_nodes = 0;
 private:
-    dbuf<float4> top_nodes_, bot_nodes_, leaf_tris_, inst_, inst_fwd_;
+    dbuf<float4> top_nodes_, bot_nodes_, leaf_tris_, inst_, inst_fwd_, flat_nodes_, flat_leaves_;
     dbuf<uint4> tri_data_, node_info_;
     dbuf<ctl_material> mats_; dbuf<ctl_light> lights_; dbuf<unsigned char> anim_;
 };

@@ -3,6 +3,7 @@
 // no host synchronisation inside a pass — queue lengths stay on the device).
 #include "tracer.h"
 #include "scene_builder.h"
+#include "flatten.h"
 #include <algorithm>
 #include <cstring>
 #include <string>
@@ -13,10 +14,10 @@ void throw_hip(hipError_t e, const char* file, int line) {   // ThrowCudaErrors 
     throw hip_error(std::string("In file ") + file + ", line " + std::to_string(line) + " : " + hipGetErrorString(e));
 }
 int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
-void require_device() { if (device_count() <= 0) throw hip_error("no HIP device: the MI355X path tracer has no CPU fallback"); }
+void require_device() { if (device_count() <= 0) throw hip_error("no HIP device: the MI355X path tracer has no CPU fallback"); apply_tuning_from_env(); }
 
 // ------------------------------------------------------------------------------------------------ Scene
-Scene::Scene(const ctl_scene_desc& d) {
+Scene::Scene(const ctl_scene_desc& d, bool flatten) {
     require_device();
     if (!d.n_nodes) throw std::runtime_error("ctl_scene_create: scene has no nodes");
     if (d.env_map_index != 0xffffffffu) throw std::runtime_error("ctl_scene_create: environment emitters are not supported yet");
@@ -72,6 +73,17 @@ Scene::Scene(const ctl_scene_desc& d) {
         const uint32_t t = d.materials[i].bsdf_type;
         if (t != CTL_BSDF_DIFFUSE && t != CTL_BSDF_DIELECTRIC && t != CTL_BSDF_CONDUCTOR && t != CTL_BSDF_ROUGHCONDUCTOR)
             throw std::runtime_error("ctl_scene_create: BSDF type " + std::to_string(t) + " has no HIP implementation yet");
+    }
+    S.flat_nodes = nullptr; S.flat_leaves = nullptr; S.flat_root = 0;
+    if (flatten) {
+        flat_scene F;
+        if (flatten_scene(d, F, (size_t)1 << 30)) {   // up to 2^30 instanced triangles (64 GiB of leaf entries)
+            if (3 * F.max_depth + 4 > kStackSize) throw std::runtime_error("ctl_scene_create: flattened BVH too deep for the traversal stack");
+            flat_nodes_.upload((const float4*)F.nodes.data(), F.nodes.size() * 4);
+            flat_leaves_.upload((const float4*)F.leaves.data(), F.leaves.size() * 4);
+            CTL_HIP(hipDeviceSynchronize());
+            S.flat_nodes = flat_nodes_.p; S.flat_leaves = flat_leaves_.p; S.flat_root = 0;
+        }
     }
     CTL_HIP(hipDeviceSynchronize());
     S.top_nodes = top_nodes_.p; S.bot_nodes = bot_nodes_.p; S.leaf_tris = leaf_tris_.p; S.inst = inst_.p; S.inst_fwd = inst_fwd_.p;
@@ -219,19 +231,19 @@ void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
     }
     Q.hit = new_f4(capacity); hit_node_.alloc(capacity); Q.hit_node = hit_node_.p;
     Q.fin.rad = new_f4(capacity); Q.fin.dir = new_f4(capacity); px_[2].alloc(capacity); Q.fin.px = px_[2].p;
-    stats_.alloc(8); Q.stats = stats_.p; CTL_HIP(hipMemset(stats_.p, 0, 8 * sizeof(unsigned long long)));
+    stats_.alloc(12); Q.stats = stats_.p; CTL_HIP(hipMemset(stats_.p, 0, 12 * sizeof(unsigned long long)));
     Q.capacity = capacity;
     counts_.free(); work_.free();
 }
 
-// stats: [0] path rays, [1] shadow rays, [2..4] closest-hit N_inner/N_tri/N_inst, [5..7] any-hit N_inner/N_tri/N_inst
+// stats: [0] path rays, [1] shadow rays, [2..6] closest-hit traversal counts, [7..11] any-hit traversal counts
 void WavefrontPathTracer::takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) {
-    unsigned long long r[8];
+    unsigned long long r[12];
     CTL_HIP(hipMemcpy(r, stats_.p, sizeof(r), hipMemcpyDeviceToHost));
     CTL_HIP(hipMemset(stats_.p, 0, sizeof(r)));
     path_rays = r[0]; shadow_rays_ = r[1];
-    closest_counts.n_inner = r[2]; closest_counts.n_tri = r[3]; closest_counts.n_inst = r[4];
-    any_counts.n_inner = r[5]; any_counts.n_tri = r[6]; any_counts.n_inst = r[7];
+    closest_counts = ctl_traversal_counts{ r[2], r[3], r[4], r[5], r[6] };
+    any_counts = ctl_traversal_counts{ r[7], r[8], r[9], r[10], r[11] };
 }
 
 // WavefrontPathTracer::DoRender (Integrators/PseudoRealtime/WavefrontPathTracer.cu:166-191): ray generation, then per
@@ -265,7 +277,7 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     timer.begin(stream, 0); launch_raygen(lc, S, Q, P); timer.end(stream);
     auto shadow_pass = [&](int d) {   // any-hit intersection of the shadow rays emitted at depth d
         timer.begin(stream, 3);
-        if (counting) launch_intersect_count(lc, S, Q.sh_o[d & 1], Q.sh_d[d & 1], &Q.counts[d * 4 + 1], &Q.work[2 * d + 3], nullptr, nullptr, Q.sh_occ[d & 1], 1, Q.stats + 5);
+        if (counting) launch_intersect_count(lc, S, Q.sh_o[d & 1], Q.sh_d[d & 1], &Q.counts[d * 4 + 1], &Q.work[2 * d + 3], nullptr, nullptr, Q.sh_occ[d & 1], 1, Q.stats + 7);
         else launch_intersect_any(lc, S, Q.sh_o[d & 1], Q.sh_d[d & 1], &Q.counts[d * 4 + 1], &Q.work[2 * d + 3], Q.sh_occ[d & 1]);
         timer.end(stream);
         shadow_launches++;

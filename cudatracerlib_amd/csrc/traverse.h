@@ -1,16 +1,31 @@
-// traverse.h — two-level BVH traversal + Woop triangle test for one ray per lane (gfx950, wave64).
-// Behaviour = intersectKernel<ANY_HIT> (Kernel/TraceHelper.cu:326-734): scene BVH -> instance transform ->
-// mesh BVH -> Woop triangles, closest (or first) hit with t in (tmin, tmax).  The arithmetic that decides the
-// reported hit (ray transform, t, u, v) is evaluated in the reference's expression order without FMA contraction,
-// so (t, u, v, triangle) are bit-identical to the reference's host path; the slab tests only cull.
+// traverse.h — two-level BVH traversal + Woop triangle test, persistent wave64 formulation for gfx950.
+//
+// Behaviour = intersectKernel<ANY_HIT> (Kernel/TraceHelper.cu:326-734): scene BVH -> instance transform -> mesh BVH ->
+// Woop triangles, closest (or first) hit with t in (tmin, tmax).  The arithmetic that decides the reported hit (ray
+// transform, t, u, v) is evaluated in the reference's expression order without FMA contraction, so (t, u, v, triangle)
+// are bit-identical to the reference's host path; the slab tests only cull.
+//
+// Execution model (re-derived for 64-wide waves, not the reference's 32-lane ballot code, TraceHelper.cu:386-399):
+//  * a wave owns 64 ray slots and keeps running; a lane whose ray is finished writes its hit and, once enough lanes are
+//    idle, the idle lanes are refilled together with fresh rays (ballot + mbcnt prefix into a per-wave chunk that is
+//    claimed from the global cursor with one atomic per 512 rays) — incoherent rays finish at very different times,
+//    and without refill most lanes of a wave idle behind its slowest ray;
+//  * the traversal stack lives in LDS ([entry][thread] layout: a lane always hits its own bank), only entries beyond
+//    kLdsStack spill to scratch.
 #pragma once
 #include "device_scene.h"
 
 namespace ctl {
 
-struct trav_counts { uint32_t n_inner, n_tri, n_inst; };
+struct trav_counts { uint32_t n_inner, n_tri, n_inst, w_inner, w_tri; };
 
-struct ray_hit { float t, u, v; int tri, node; };
+constexpr int kLdsStack = 24;        // stack entries per lane kept in LDS, two-level kernel (24 x 256 x 4 B = 24 KiB per workgroup)
+constexpr int kLdsStackFlat = 20;    // flat kernel: 20 KiB per workgroup -> 8 workgroups = 32 waves per CU
+__device__ int g_tri_batch = 1;      // flat kernel: leaf entries are tested once this many lanes wait at a leaf.  Measured on MI355X
+                                     // (gpurun_out/tune_tri.log): batching leaves LOSES (973 -> 835 Mrays/s from 1 to 40) — the kernel is
+                                     // memory-latency bound and every waiting lane is a load not in flight; kept as a knob (CTL_TRI_BATCH)
+__device__ int g_refill_idle = 20;   // refill as soon as this many lanes of the wave are idle (CTL_REFILL_IDLE overrides)
+constexpr uint32_t kChunk = 512;     // rays claimed from the global cursor per atomic
 
 __device__ __forceinline__ float rcp_guarded(float d) {   // TraceHelper.cu:417-420: 1/(|d| > 2^-80 ? d : copysign(2^-80, d))
     const float ooeps = 8.271806125530277e-25f;   // exp2(-80)
@@ -33,90 +48,277 @@ __device__ __forceinline__ void slab2(const float4 n0, const float4 n1, const fl
     c1max = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), tmax));
 }
 
-template <bool ANY_HIT, bool COUNT>
-__device__ __forceinline__ ray_hit traverse(const dev_scene& S, float3 org, float tmin, float3 dir, float tmax, int* __restrict__ stack, trav_counts& cnt) {
-    ray_hit h; h.t = tmax; h.tri = -1; h.node = -1; h.u = h.v = 0.0f;
-    if (S.n_nodes == 0) return h;
-    // current-space ray (world at the top level, object space inside an instance)
-    float ox = org.x, oy = org.y, oz = org.z, dx = dir.x, dy = dir.y, dz = dir.z;
-    float idx = rcp_guarded(dx), idy = rcp_guarded(dy), idz = rcp_guarded(dz);
-    float oox = ox * idx, ooy = oy * idy, ooz = oz * idz;
-    // world-space copies restored when an instance is left
-    const float widx = idx, widy = idy, widz = idz, woox = oox, wooy = ooy, wooz = ooz;
-    const float4* __restrict__ nodes = S.top_nodes;
-    int sp = 0; stack[0] = kSentinel;
-    int node = S.start_node;
-    bool bottom = false; int sp_enter = 0, cur_inst = -1; uint32_t leaf_base = 0, tri_base = 0;
+// per-lane traversal stack: entries [0, kLdsStack) in LDS, the rest in scratch
+template <int N> struct lane_stack_t {
+    int* lds;                                   // this lane's column, stride = blockDim.x
+    int ovf[kStackSize - N];
+    __device__ __forceinline__ int get(int i) const { return i < N ? lds[i * 256] : ovf[i - N]; }
+    __device__ __forceinline__ void set(int i, int v) { if (i < N) lds[i * 256] = v; else ovf[i - N] = v; }
+};
+typedef lane_stack_t<kLdsStack> lane_stack;
 
-    while (node != kSentinel) {
-        // ---- inner nodes
-        while ((unsigned)node < (unsigned)kSentinel) {
-            const float4 n0 = nodes[node], n1 = nodes[node + 1], nz = nodes[node + 2], cn = nodes[node + 3];
-            if (COUNT) cnt.n_inner++;
-            float c0min, c0max, c1min, c1max;
-            slab2(n0, n1, nz, idx, idy, idz, oox, ooy, ooz, tmin, h.t, c0min, c0max, c1min, c1max);
-            int c0 = __float_as_int(cn.x), c1 = __float_as_int(cn.y);
-            const bool t0 = (c0max >= c0min), t1 = (c1max >= c1min);
-            if (!t0 && !t1) { node = stack[sp]; sp--; }
-            else {
-                node = t0 ? c0 : c1;
-                if (t0 && t1) { if (c1min < c0min) { int t = node; node = c1; c1 = t; } sp++; stack[sp] = c1; }
+// The whole intersect kernel body: `n` rays (ro, rd) -> hit / hit_node (closest) and/or occ (any-hit flag).
+template <bool ANY_HIT, bool COUNT>
+__device__ __forceinline__ void intersect_persistent(const dev_scene& S, const float4* __restrict__ ro, const float4* __restrict__ rd, uint32_t n, uint32_t* __restrict__ work,
+                                                     float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack, trav_counts& cnt) {
+    const int lane = threadIdx.x & 63;
+    const int refill_idle = g_refill_idle;
+    lane_stack st; st.lds = lds_stack + threadIdx.x;
+    // ---- per-lane ray state
+    bool has_ray = false;
+    uint32_t ray_id = 0;
+    float orgx = 0, orgy = 0, orgz = 0, dirx = 0, diry = 0, dirz = 0, tmin = 0;     // world-space ray
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;                            // current-space ray
+    float idx = 0, idy = 0, idz = 0, oox = 0, ooy = 0, ooz = 0;
+    float widx = 0, widy = 0, widz = 0, woox = 0, wooy = 0, wooz = 0;                // world-space slab terms, restored at instance exit
+    float ht = 0, hu = 0, hv = 0; int htri = -1, hnode = -1;
+    const float4* __restrict__ nodes = S.top_nodes;
+    int sp = 0, node = kSentinel, sp_enter = 0, cur_inst = -1; uint32_t leaf_base = 0, tri_base = 0; bool bottom = false;
+    // ---- per-wave ray chunk (uniform)
+    uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = (n == 0) || S.n_nodes == 0;
+    if (S.n_nodes == 0) {   // empty scene: every ray misses (TraceHelper.cu:442-443)
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            if (ANY_HIT && occ) occ[i] = 0u;
+            if (hit) { hit[i] = make_float4(rd[i].w, 0.f, 0.f, __int_as_float(-1)); hit_node[i] = -1; }
+        }
+        return;
+    }
+
+    for (;;) {
+        // ---- refill idle lanes
+        const unsigned long long idle = __ballot(!has_ray);
+        if (idle != 0ull && !exhausted && (__popcll(idle) >= refill_idle || idle == ~0ull)) {
+            if (chunk_next >= chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work, kChunk);
+                base = __shfl(base, 0, 64);
+                chunk_next = base; chunk_end = base + kChunk < n ? base + kChunk : n;
+                if (base >= n) { exhausted = true; chunk_next = chunk_end = n; }
+            }
+            if (!exhausted) {
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
+                const uint32_t avail = chunk_end - chunk_next, want = (uint32_t)__popcll(idle);
+                const uint32_t my = chunk_next + prefix;
+                if (!has_ray && prefix < avail) {
+                    const float4 o = ro[my], d = rd[my];
+                    ray_id = my; has_ray = true;
+                    orgx = o.x; orgy = o.y; orgz = o.z; tmin = o.w; dirx = d.x; diry = d.y; dirz = d.z;
+                    ox = orgx; oy = orgy; oz = orgz; dx = dirx; dy = diry; dz = dirz;
+                    idx = rcp_guarded(dx); idy = rcp_guarded(dy); idz = rcp_guarded(dz);
+                    oox = ox * idx; ooy = oy * idy; ooz = oz * idz;
+                    widx = idx; widy = idy; widz = idz; woox = oox; wooy = ooy; wooz = ooz;
+                    ht = d.w; hu = hv = 0.0f; htri = -1; hnode = -1;
+                    nodes = S.top_nodes; bottom = false; sp = 0; st.set(0, kSentinel); node = S.start_node;
+                }
+                chunk_next += want < avail ? want : avail;
             }
         }
-        if (node < 0) {
-            if (!bottom) {
-                // ---- enter instance ~node (TraceHelper.cu:526-560)
-                cur_inst = ~node;
-                if (COUNT) cnt.n_inst++;
-                const float4 r0 = S.inst[cur_inst * 4], r1 = S.inst[cur_inst * 4 + 1], r2 = S.inst[cur_inst * 4 + 2], r3 = S.inst[cur_inst * 4 + 3];
-                m34 m; m.r[0][0] = r0.x; m.r[0][1] = r0.y; m.r[0][2] = r0.z; m.r[0][3] = r0.w; m.r[1][0] = r1.x; m.r[1][1] = r1.y; m.r[1][2] = r1.z; m.r[1][3] = r1.w;
-                m.r[2][0] = r2.x; m.r[2][1] = r2.y; m.r[2][2] = r2.z; m.r[2][3] = r2.w;
-                const f3 d = xform_dir(m, f3(dir.x, dir.y, dir.z)), o = xform_point_w(m, f3(org.x, org.y, org.z), r3.x);
-                ox = o.x; oy = o.y; oz = o.z; dx = d.x; dy = d.y; dz = d.z;
-                idx = rcp_guarded(dx); idy = rcp_guarded(dy); idz = rcp_guarded(dz);
-                oox = ox * idx; ooy = oy * idy; ooz = oz * idz;
-                nodes = S.bot_nodes + __float_as_uint(r3.y);
-                leaf_base = __float_as_uint(r3.z); tri_base = __float_as_uint(r3.w);
-                sp++; stack[sp] = kExitMarker; sp_enter = sp;
-                bottom = true; node = 0;
-            } else {
-                // ---- leaf: Woop triangles (TraceHelper.cu:636-694)
-                for (uint32_t addr = leaf_base + (uint32_t)(~node);; addr++) {
-                    const float4 v00 = S.leaf_tris[addr * 4], v11 = S.leaf_tris[addr * 4 + 1], v22 = S.leaf_tris[addr * 4 + 2];
-                    const uint32_t index = __float_as_uint(S.leaf_tris[addr * 4 + 3].x);
-                    if (COUNT) cnt.n_tri++;
-                    const float Oz = v00.w - ox * v00.x - oy * v00.y - oz * v00.z;
-                    const float invDz = 1.0f / (dx * v00.x + dy * v00.y + dz * v00.z);
-                    const float t = Oz * invDz;
-                    if (t > tmin && t < h.t) {
-                        const float Ox = v11.w + ox * v11.x + oy * v11.y + oz * v11.z;
-                        const float Dx = dx * v11.x + dy * v11.y + dz * v11.z;
-                        const float u = Ox + t * Dx;
-                        if (u >= 0.0f) {
-                            const float Oy = v22.w + ox * v22.x + oy * v22.y + oz * v22.z;
-                            const float Dy = dx * v22.x + dy * v22.y + dz * v22.z;
-                            const float v = Oy + t * Dy;
-                            if (v >= 0.0f && u + v <= 1.0f) {
-                                h.t = t; h.u = u; h.v = v; h.tri = (int)((index >> 1) + tri_base); h.node = cur_inst;
-                                if (ANY_HIT) return h;
+        if (__ballot(has_ray) == 0ull) { if (exhausted) break; continue; }
+
+        if (has_ray) {
+            // ---- inner nodes: the wave stays here while any lane still has one
+            while ((unsigned)node < (unsigned)kSentinel) {
+                const float4 n0 = nodes[node], n1 = nodes[node + 1], nz = nodes[node + 2], cn = nodes[node + 3];
+                if (COUNT) { cnt.n_inner++; if (lane == (int)__builtin_ctzll(__ballot(1))) cnt.w_inner++; }
+                float c0min, c0max, c1min, c1max;
+                slab2(n0, n1, nz, idx, idy, idz, oox, ooy, ooz, tmin, ht, c0min, c0max, c1min, c1max);
+                int c0 = __float_as_int(cn.x), c1 = __float_as_int(cn.y);
+                const bool t0 = (c0max >= c0min), t1 = (c1max >= c1min);
+                if (!t0 && !t1) { node = st.get(sp); sp--; }
+                else {
+                    node = t0 ? c0 : c1;
+                    if (t0 && t1) { if (c1min < c0min) { const int t = node; node = c1; c1 = t; } sp++; st.set(sp, c1); }
+                }
+            }
+            bool finished = false;
+            if (node < 0) {
+                if (!bottom) {
+                    // ---- enter instance ~node (TraceHelper.cu:526-560)
+                    cur_inst = ~node;
+                    if (COUNT) cnt.n_inst++;
+                    const float4 r0 = S.inst[cur_inst * 4], r1 = S.inst[cur_inst * 4 + 1], r2 = S.inst[cur_inst * 4 + 2], r3 = S.inst[cur_inst * 4 + 3];
+                    m34 m; m.r[0][0] = r0.x; m.r[0][1] = r0.y; m.r[0][2] = r0.z; m.r[0][3] = r0.w; m.r[1][0] = r1.x; m.r[1][1] = r1.y; m.r[1][2] = r1.z; m.r[1][3] = r1.w;
+                    m.r[2][0] = r2.x; m.r[2][1] = r2.y; m.r[2][2] = r2.z; m.r[2][3] = r2.w;
+                    const f3 d = xform_dir(m, f3(dirx, diry, dirz)), o = xform_point_w(m, f3(orgx, orgy, orgz), r3.x);
+                    ox = o.x; oy = o.y; oz = o.z; dx = d.x; dy = d.y; dz = d.z;
+                    idx = rcp_guarded(dx); idy = rcp_guarded(dy); idz = rcp_guarded(dz);
+                    oox = ox * idx; ooy = oy * idy; ooz = oz * idz;
+                    nodes = S.bot_nodes + __float_as_uint(r3.y);
+                    leaf_base = __float_as_uint(r3.z); tri_base = __float_as_uint(r3.w);
+                    sp++; st.set(sp, kExitMarker); sp_enter = sp;
+                    bottom = true; node = 0;
+                } else {
+                    // ---- leaf: Woop triangles (TraceHelper.cu:636-694)
+                    for (uint32_t addr = leaf_base + (uint32_t)(~node);; addr++) {
+                        const float4 v00 = S.leaf_tris[addr * 4], v11 = S.leaf_tris[addr * 4 + 1], v22 = S.leaf_tris[addr * 4 + 2];
+                        const uint32_t index = __float_as_uint(S.leaf_tris[addr * 4 + 3].x);
+                        if (COUNT) { cnt.n_tri++; if (lane == (int)__builtin_ctzll(__ballot(1))) cnt.w_tri++; }
+                        const float Oz = v00.w - ox * v00.x - oy * v00.y - oz * v00.z;
+                        const float invDz = 1.0f / (dx * v00.x + dy * v00.y + dz * v00.z);
+                        const float t = Oz * invDz;
+                        if (t > tmin && t < ht) {
+                            const float Ox = v11.w + ox * v11.x + oy * v11.y + oz * v11.z;
+                            const float Dx = dx * v11.x + dy * v11.y + dz * v11.z;
+                            const float u = Ox + t * Dx;
+                            if (u >= 0.0f) {
+                                const float Oy = v22.w + ox * v22.x + oy * v22.y + oz * v22.z;
+                                const float Dy = dx * v22.x + dy * v22.y + dz * v22.z;
+                                const float v = Oy + t * Dy;
+                                if (v >= 0.0f && u + v <= 1.0f) {
+                                    ht = t; hu = u; hv = v; htri = (int)((index >> 1) + tri_base); hnode = cur_inst;
+                                    if (ANY_HIT) { finished = true; break; }
+                                }
                             }
                         }
+                        if (index & 1) break;
                     }
-                    if (index & 1) break;
+                    node = st.get(sp); sp--;
                 }
-                node = stack[sp]; sp--;
+            }
+            if (!finished) {
+                // a mesh BVH that ends in the sentinel (one-leaf meshes carry 0x76543210 as second child) only ends that mesh
+                if (bottom && node == kSentinel) { sp = sp_enter - 1; node = kExitMarker; }
+                if (node == kExitMarker) {
+                    ox = orgx; oy = orgy; oz = orgz; dx = dirx; dy = diry; dz = dirz;
+                    idx = widx; idy = widy; idz = widz; oox = woox; ooy = wooy; ooz = wooz;
+                    nodes = S.top_nodes; bottom = false;
+                    node = st.get(sp); sp--;
+                }
+                finished = (node == kSentinel);
+            }
+            if (finished) {
+                if (ANY_HIT && occ) occ[ray_id] = htri >= 0 ? 1u : 0u;
+                if (hit) { hit[ray_id] = make_float4(ht, hu, hv, __int_as_float(htri)); hit_node[ray_id] = hnode; }
+                has_ray = false; node = kSentinel;
             }
         }
-        // a mesh BVH that ends in the sentinel (one-leaf meshes carry 0x76543210 as second child) only ends that mesh
-        if (bottom && node == kSentinel) { sp = sp_enter - 1; node = kExitMarker; }
-        if (node == kExitMarker) {
-            ox = org.x; oy = org.y; oz = org.z; dx = dir.x; dy = dir.y; dz = dir.z;
-            idx = widx; idy = widy; idz = widz; oox = woox; ooy = wooy; ooz = wooz;
-            nodes = S.top_nodes; bottom = false;
-            node = stack[sp]; sp--;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Single-level variant over the flattened world-space BVH (flatten.cpp).  One loop iteration = one 64-B fetch group per
+// lane — an inner node OR one leaf entry — so every lane that holds a ray does useful work in every iteration; only the
+// math after the (shared) fetch diverges between the two kinds.
+template <bool ANY_HIT, bool COUNT>
+__device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4* __restrict__ ro, const float4* __restrict__ rd, uint32_t n, uint32_t* __restrict__ work,
+                                               float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack, trav_counts& cnt) {
+    const int lane = threadIdx.x & 63;
+    const int refill_idle = g_refill_idle, tri_batch = g_tri_batch;
+    lane_stack_t<kLdsStackFlat> st; st.lds = lds_stack + threadIdx.x;
+    bool has_ray = false;
+    uint32_t ray_id = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, tmin = 0, idx = 0, idy = 0, idz = 0, oox = 0, ooy = 0, ooz = 0;
+    float ht = 0, hu = 0, hv = 0; int htri = -1, hnode = -1;
+    int sp = 0, node = kSentinel;
+    const float4* __restrict__ nodes = S.flat_nodes;
+    const float4* __restrict__ leaves = S.flat_leaves;
+    uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = (n == 0);
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!has_ray);
+        if (idle != 0ull && !exhausted && (__popcll(idle) >= refill_idle || idle == ~0ull)) {
+            if (chunk_next >= chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work, kChunk);
+                base = __shfl(base, 0, 64);
+                chunk_next = base; chunk_end = base + kChunk < n ? base + kChunk : n;
+                if (base >= n) { exhausted = true; chunk_next = chunk_end = n; }
+            }
+            if (!exhausted) {
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
+                const uint32_t avail = chunk_end - chunk_next, want = (uint32_t)__popcll(idle);
+                const uint32_t my = chunk_next + prefix;
+                if (!has_ray && prefix < avail) {
+                    const float4 o = ro[my], d = rd[my];
+                    ray_id = my; has_ray = true;
+                    ox = o.x; oy = o.y; oz = o.z; tmin = o.w; dx = d.x; dy = d.y; dz = d.z;
+                    idx = rcp_guarded(dx); idy = rcp_guarded(dy); idz = rcp_guarded(dz);
+                    oox = ox * idx; ooy = oy * idy; ooz = oz * idz;
+                    ht = d.w; hu = hv = 0.0f; htri = -1; hnode = -1;
+                    sp = 0; st.set(0, kSentinel); node = S.flat_root;
+                }
+                chunk_next += want < avail ? want : avail;
+            }
+        }
+        if (__ballot(has_ray) == 0ull) { if (exhausted) break; continue; }
+
+        // leaf entries are tested in batches: lanes that reached a leaf sit out until enough of them wait (or nobody has an
+        // inner node left), so the Woop code runs with many lanes instead of a handful in every iteration
+        const bool is_leaf = has_ray && node < 0;
+        const unsigned long long at_leaf = __ballot(is_leaf);
+        const bool do_leaf = __popcll(at_leaf) >= tri_batch || at_leaf == __ballot(has_ray);
+        if (has_ray && (!is_leaf || do_leaf)) {
+            const float4* __restrict__ p = is_leaf ? leaves + (size_t)(~node) * 4 : nodes + node;
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            bool finished = false;
+            if (!is_leaf) {
+                if (COUNT) { cnt.n_inner++; if (lane == (int)__builtin_ctzll(__ballot(1))) cnt.w_inner++; }
+                // 4-wide node (flatten.h): q0 = origin.xyz + {ex,ey,ez,mask}; q1 = qlo_x,qhi_x,qlo_y,qhi_y; q2 = qlo_z,qhi_z,child0,child1; q3 = child2,child3
+                const uint32_t meta = __float_as_uint(q0.w);
+                const float ax = __uint_as_float((meta & 0xffu) << 23) * idx, ay = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy, az = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
+                const float bx = __builtin_fmaf(q0.x, idx, -oox), by = __builtin_fmaf(q0.y, idy, -ooy), bz = __builtin_fmaf(q0.z, idz, -ooz);
+                const uint32_t lx = __float_as_uint(q1.x), hx = __float_as_uint(q1.y), ly = __float_as_uint(q1.z), hy = __float_as_uint(q1.w), lz = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
+                uint32_t key[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float tlx = __builtin_fmaf((float)((lx >> (8 * c)) & 0xffu), ax, bx), thx = __builtin_fmaf((float)((hx >> (8 * c)) & 0xffu), ax, bx);
+                    const float tly = __builtin_fmaf((float)((ly >> (8 * c)) & 0xffu), ay, by), thy = __builtin_fmaf((float)((hy >> (8 * c)) & 0xffu), ay, by);
+                    const float tlz = __builtin_fmaf((float)((lz >> (8 * c)) & 0xffu), az, bz), thz = __builtin_fmaf((float)((hz >> (8 * c)) & 0xffu), az, bz);
+                    const float cmin = fmaxf(fmaxf(fminf(tlx, thx), fminf(tly, thy)), fmaxf(fminf(tlz, thz), tmin));
+                    const float cmax = fminf(fminf(fmaxf(tlx, thx), fmaxf(tly, thy)), fminf(fmaxf(tlz, thz), ht));
+                    const bool h = (cmax >= cmin) && ((meta >> (24 + c)) & 1u);
+                    // sort key: entry distance (>= 0, so its bit pattern orders like the float) with the child slot in the two low bits
+                    key[c] = h ? ((__float_as_uint(cmin) & ~3u) | (uint32_t)c) : 0xffffffffu;
+                }
+                if (!ANY_HIT) {   // front-to-back: 5-comparator network on the keys
+#define CTL_CSWAP(a, b) { const uint32_t lo_ = key[a] < key[b] ? key[a] : key[b], hi_ = key[a] < key[b] ? key[b] : key[a]; key[a] = lo_; key[b] = hi_; }
+                    CTL_CSWAP(0, 1) CTL_CSWAP(2, 3) CTL_CSWAP(0, 2) CTL_CSWAP(1, 3) CTL_CSWAP(1, 2)
+#undef CTL_CSWAP
+                }
+                const int ch0 = __float_as_int(q2.z), ch1 = __float_as_int(q2.w), ch2 = __float_as_int(q3.x), ch3 = __float_as_int(q3.y);
+                auto child_of = [&](uint32_t k) { const uint32_t s = k & 3u; return s == 0 ? ch0 : (s == 1 ? ch1 : (s == 2 ? ch2 : ch3)); };
+                if (ANY_HIT) {   // order is irrelevant for occlusion: visit every hit child
+                    int first = kSentinel; bool have = false;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) if (key[c] != 0xffffffffu) { const int cc = child_of(key[c]); if (!have) { first = cc; have = true; } else { sp++; st.set(sp, cc); } }
+                    if (have) node = first; else { node = st.get(sp); sp--; }
+                } else {
+                    // farthest first onto the stack, nearest continues
+                    if (key[3] != 0xffffffffu) { sp++; st.set(sp, child_of(key[3])); }
+                    if (key[2] != 0xffffffffu) { sp++; st.set(sp, child_of(key[2])); }
+                    if (key[1] != 0xffffffffu) { sp++; st.set(sp, child_of(key[1])); }
+                    if (key[0] != 0xffffffffu) node = child_of(key[0]); else { node = st.get(sp); sp--; }
+                }
+            } else {
+                if (COUNT) { cnt.n_tri++; if (lane == (int)__builtin_ctzll(__ballot(1))) cnt.w_tri++; }
+                const uint32_t index = __float_as_uint(q3.x);
+                const float Oz = q0.w - ox * q0.x - oy * q0.y - oz * q0.z;
+                const float invDz = 1.0f / (dx * q0.x + dy * q0.y + dz * q0.z);
+                const float t = Oz * invDz;
+                if (t > tmin && t < ht) {
+                    const float Ox = q1.w + ox * q1.x + oy * q1.y + oz * q1.z;
+                    const float Dx = dx * q1.x + dy * q1.y + dz * q1.z;
+                    const float u = Ox + t * Dx;
+                    if (u >= 0.0f) {
+                        const float Oy = q2.w + ox * q2.x + oy * q2.y + oz * q2.z;
+                        const float Dy = dx * q2.x + dy * q2.y + dz * q2.z;
+                        const float v = Oy + t * Dy;
+                        if (v >= 0.0f && u + v <= 1.0f) {
+                            ht = t; hu = u; hv = v; htri = (int)(index >> 1); hnode = (int)__float_as_uint(q3.y);
+                            if (ANY_HIT) finished = true;
+                        }
+                    }
+                }
+                if (index & 1) { node = st.get(sp); sp--; } else node = node - 1;   // ~(entry + 1) == node - 1
+            }
+            if (!finished) finished = (node == kSentinel);
+            if (finished) {
+                if (ANY_HIT && occ) occ[ray_id] = htri >= 0 ? 1u : 0u;
+                if (hit) { hit[ray_id] = make_float4(ht, hu, hv, __int_as_float(htri)); hit_node[ray_id] = hnode; }
+                has_ray = false; node = kSentinel;
+            }
         }
     }
-    return h;
 }
 
 } // namespace ctl

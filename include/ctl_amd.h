@@ -217,6 +217,11 @@ int ctl_builder_finalize(ctl_builder* b, ctl_scene_desc* out);
 typedef struct ctl_scene ctl_scene;
 /* UpdateKernel(scene) (Kernel/TraceHelper.cu:182-217): uploads + re-lays-out the arrays in HBM. */
 int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out);
+/* flags: CTL_SCENE_FLATTEN = additionally bake every node's transform into its triangles and traverse ONE world-space BVH
+ * (64 B of HBM per instanced triangle).  Same triangle/node/material per hit; t,u,v agree with the two-level traversal to
+ * fp32 round-off instead of bit-for-bit. */
+enum { CTL_SCENE_FLATTEN = 1 };
+int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out);
 void ctl_scene_destroy(ctl_scene* s);
 /* ParseMitsubaScene (Engine/SceneLoader/Mitsuba/MitsubaLoader.h:13): fills a builder from a Mitsuba-0.5 XML file. */
 int ctl_parse_mitsuba_scene(ctl_builder* b, const char* xml_path, int32_t* width_inout, int32_t* height_inout);
@@ -266,7 +271,9 @@ int ctl_tracer_do_pass(ctl_tracer* t, ctl_image* img, int new_trace);
 int ctl_tracer_do_passes(ctl_tracer* t, ctl_image* img, int new_trace, uint32_t n_passes);
 /* traversal statistics for the roofline: sums over rays of inner-node visits, triangle tests and instance entries
  * (B_ray = 32 + 16 + 64*N_inner + 52*N_tri + 108*N_inst). */
-typedef struct { uint64_t n_inner, n_tri, n_inst; } ctl_traversal_counts;
+typedef struct { uint64_t n_inner, n_tri, n_inst;
+                 uint64_t wave_inner_iters, wave_tri_iters;   /* wave-level loop iterations: n_inner / (64 * wave_inner_iters) = lane utilisation */
+} ctl_traversal_counts;
 typedef struct {
     uint64_t rays_last_pass;       /* getRaysInLastPass (64-bit; the reference wraps at 2^32)            */
     uint64_t rays_total;           /* getAccRays                                                         */

@@ -95,7 +95,7 @@ class Oracle:
     def intersect(self, desc, rays, any_hit=False, count=False, threads=8):
         r = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         hits = np.zeros(len(r), dtype=[("dist", "f4"), ("node_idx", "i4"), ("tri_idx", "i4"), ("u", "f4"), ("v", "f4")])
-        cnt = (u64 * 3)()
+        cnt = (u64 * 5)()
         self.lib.orc_intersect(C.addressof(desc), r.ctypes.data, len(r), hits.ctypes.data, 1 if any_hit else 0, C.addressof(cnt) if count else None, threads)
         if count:
             return hits, dict(n_inner=cnt[0], n_tri=cnt[1], n_inst=cnt[2])

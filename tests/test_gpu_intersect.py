@@ -71,3 +71,25 @@ def test_traversal_counts_match_oracle(gpu, orc):
     _, o = orc.intersect(sc.desc, rays, count=True)
     for k in ("n_inner", "n_tri", "n_inst"):
         assert abs(g[k] - o[k]) <= 0.15 * o[k], (k, g[k], o[k])
+
+
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_flattened_world_space_bvh(gpu, orc, any_hit):
+    """CTL_SCENE_FLATTEN: one world-space BVH over all instanced triangles.  Same triangle and node per ray as the
+    two-level traversal; t,u,v to fp32 round-off (the world-space Woop rows are recomputed in double), not bit-for-bit."""
+    sc = scenes.synthetic_sm(64, 64, n_instances=300, subdiv=2)
+    rays = camera_and_random_rays(sc.desc, 30000, 7, any_tmax=any_hit)
+    scene = gpu.Scene(sc.desc, flatten=True)
+    got = gpu.intersect(scene, rays, any_hit=any_hit)
+    want = orc.intersect(sc.desc, rays, any_hit=any_hit)
+    if any_hit:
+        assert (np.array_equal(got["tri_idx"] >= 0, want["tri_idx"] >= 0)) or ((got["tri_idx"] >= 0) != (want["tri_idx"] >= 0)).mean() < 2e-4
+        return
+    same = got["tri_idx"] == want["tri_idx"]
+    assert same.mean() > 0.9995          # grazing edges / equal-t ties may pick a neighbour
+    assert np.array_equal(got["node_idx"][same], want["node_idx"][same])
+    h = same & (want["tri_idx"] >= 0)
+    # world-space vertices are recovered from the fp32 Woop rows (relative error ~1e-6 of the coordinate magnitude)
+    diag = float(np.linalg.norm(np.array(sc.desc.box_max[:]) - np.array(sc.desc.box_min[:])))
+    assert np.allclose(got["dist"][h], want["dist"][h], rtol=2e-5, atol=5e-6 * diag)
+    assert np.allclose(got["u"][h], want["u"][h], atol=2e-3) and np.allclose(got["v"][h], want["v"][h], atol=2e-3)
