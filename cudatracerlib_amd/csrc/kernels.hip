@@ -25,19 +25,46 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool take) {
     return base + prefix;
 }
 
+// Append to up to three global queues from a whole workgroup with ONE atomic per queue per workgroup: ballot/mbcnt inside
+// each wave, wave totals through LDS, thread k < 3 reserves the block's range.  A single queue cursor saturates at
+// ~88 returning atomics/us on MI355X (MI355X_MICROARCH.md "dequeue"), which a per-wave append hits at once: 160 k waves per
+// pass step on three cursors were the whole cost of the first shade kernel.  Must be called by every thread of the block.
+constexpr int kWideBlock = 1024;
+struct block_slots { uint32_t s[3]; };
+__device__ __forceinline__ block_slots block_append3(uint32_t* c0, bool t0, uint32_t* c1, bool t1, uint32_t* c2, bool t2, uint32_t (*s_cnt)[kWideBlock / 64], uint32_t* s_base) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const unsigned long long m0 = __ballot(t0), m1 = __ballot(t1), m2 = __ballot(t2);
+    if (lane == 0) { s_cnt[0][wave] = (uint32_t)__popcll(m0); s_cnt[1][wave] = (uint32_t)__popcll(m1); s_cnt[2][wave] = (uint32_t)__popcll(m2); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t* ctr = threadIdx.x == 0 ? c0 : (threadIdx.x == 1 ? c1 : c2);
+        uint32_t tot = 0;
+        for (int w = 0; w < n_waves; w++) { const uint32_t c = s_cnt[threadIdx.x][w]; s_cnt[threadIdx.x][w] = tot; tot += c; }   // exclusive prefix over waves
+        s_base[threadIdx.x] = (tot && ctr) ? atomicAdd(ctr, tot) : 0u;
+    }
+    __syncthreads();
+    block_slots r;
+    r.s[0] = s_base[0] + s_cnt[0][wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0));
+    r.s[1] = s_base[1] + s_cnt[1][wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0));
+    r.s[2] = s_base[2] + s_cnt[2][wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0));
+    __syncthreads();   // s_cnt / s_base are reused by the next iteration
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------ ray generation
 // pathCreateKernelWPT (Integrators/PseudoRealtime/WavefrontPathTracer.cu:17-49) with the megakernel's sampler
 // indexing (sampler index = film pixel index, Integrators/PathTracer.cu:185-190).
-__global__ __launch_bounds__(kBlock) void k_raygen(dev_scene S, wave_queues Q, pass_params P) {
+__global__ __launch_bounds__(kWideBlock) void k_raygen(dev_scene S, wave_queues Q, pass_params P) {
+    __shared__ uint32_t s_cnt[3][kWideBlock / 64]; __shared__ uint32_t s_base[3];
     const uint32_t tiles_x = (P.width + 63) / 64;
     const uint32_t n_total = P.n_local_pixels * P.batch;   // n_local_pixels is a multiple of 4096: waves never straddle passes
     const uint32_t n1 = CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH;
-    for (uint32_t gi = blockIdx.x * kBlock + threadIdx.x; gi < n_total; gi += gridDim.x * kBlock) {
+    for (uint32_t gi = blockIdx.x * kWideBlock + threadIdx.x; gi < n_total; gi += gridDim.x * kWideBlock) {   // n_total is a multiple of 4096
         const uint32_t pass_b = gi / P.n_local_pixels, li = gi - pass_b * P.n_local_pixels;
         const uint32_t tile = P.tile_rank + (li >> 12) * P.tile_world, p = li & 4095u, micro = p >> 6, lane = p & 63u;
         const uint32_t x = (tile % tiles_x) * 64 + (micro & 7u) * 8 + (lane & 7u), y = (tile / tiles_x) * 64 + (micro >> 3) * 8 + (lane >> 3);
         const bool valid = x < P.width && y < P.height;
-        const uint32_t slot = wave_append(&Q.counts[0], valid);
+        const uint32_t slot = block_append3(&Q.counts[0], valid, nullptr, false, nullptr, false, s_cnt, s_base).s[0];
         if (!valid) continue;
         const uint32_t pixel = y * P.width + x;
         sampler rng{ P.t1 + pass_b * n1, P.t2 + pass_b * n1, pixel, 0, 0 };
@@ -87,7 +114,8 @@ __device__ __forceinline__ void add_sample(ctl_pixel_data* img, uint32_t W, uint
 
 // ------------------------------------------------------------------------------------------------ shading
 // One lane = one queued path vertex.  `depth` is the megakernel's 1-based depth of this vertex.
-__global__ __launch_bounds__(kBlock) void k_shade(dev_scene S, wave_queues Q, pass_params P, int depth, ctl_pixel_data* __restrict__ image) {
+__global__ __launch_bounds__(kWideBlock) void k_shade(dev_scene S, wave_queues Q, pass_params P, int depth, ctl_pixel_data* __restrict__ image) {
+    __shared__ uint32_t s_cnt[3][kWideBlock / 64]; __shared__ uint32_t s_base[3];
     const int cur = (depth - 1) & 1, nxt = depth & 1;
     const path_soa& A = Q.path[cur];
     const path_soa& B = Q.path[nxt];
@@ -98,8 +126,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(dev_scene S, wave_queues Q, pa
     const uint32_t* occ_prev = Q.sh_occ[(depth - 1) & 1];
     float4* sh_o = Q.sh_o[depth & 1]; float4* sh_d = Q.sh_d[depth & 1];
 
-    const uint32_t n_round = (n + 63u) & ~63u;   // whole waves stay converged for the ballots
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
+    const uint32_t n_round = (n + (kWideBlock - 1u)) & ~(kWideBlock - 1u);   // whole workgroups iterate together (barriers in block_append3)
+    for (uint32_t i = blockIdx.x * kWideBlock + threadIdx.x; i < n_round; i += gridDim.x * kWideBlock) {
         const bool active = i < n;
         bool alive = false, want_shadow = false, terminated = false;
         f3 cl(0.0f), cf(0.0f), directF(0.0f), new_o(0.0f), new_d(0.0f), last_nor(0.0f), sh_org(0.0f), sh_dir(0.0f);
@@ -192,9 +220,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(dev_scene S, wave_queues Q, pa
             specular = specularBounce; bsdf_pdf_out = brdf_scattering_pdf; d1 = rng.d1; d2 = rng.d2;
         }
         // ---- stream compaction: survivors, shadow rays and waiting terminations are appended densely, one atomic per wave
-        const uint32_t sslot = wave_append(n_shadow, want_shadow);
-        const uint32_t nslot = wave_append(n_next, alive);
-        const uint32_t fslot = wave_append(n_final, terminated && want_shadow);
+        const block_slots bs = block_append3(n_shadow, want_shadow, n_next, alive, n_final, terminated && want_shadow, s_cnt, s_base);
+        const uint32_t sslot = bs.s[0], nslot = bs.s[1], fslot = bs.s[2];
         if (!active) continue;
         if (want_shadow) { sh_o[sslot] = make_float4(sh_org.x, sh_org.y, sh_org.z, S.eps); sh_d[sslot] = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, sh_tmax); }
         if (alive) {
@@ -252,12 +279,13 @@ void apply_tuning_from_env() {
     if (done) return;
     done = true;
     if (const char* e = getenv("CTL_REFILL_IDLE")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refill_idle), &v, sizeof(v)); }
+    if (const char* e = getenv("CTL_ANY_SORTED")) { int v = atoi(e) != 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_any_sorted), &v, sizeof(v)); }
     if (const char* e = getenv("CTL_TRI_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tri_batch), &v, sizeof(v)); }
 }
 
 // ------------------------------------------------------------------------------------------------ launch wrappers
 void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P) {
-    hipLaunchKernelGGL(k_raygen, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, Q, P);
+    hipLaunchKernelGGL(k_raygen, dim3(lc.grid_blocks / 4), dim3(kWideBlock), 0, lc.stream, S, Q, P);
 }
 #define CTL_LAUNCH_INTERSECT(ANY, CNT, ...)                                                                                          \
     do {                                                                                                                             \
@@ -276,7 +304,7 @@ void launch_intersect_count(const launch_ctx& lc, const dev_scene& S, const floa
     else CTL_LAUNCH_INTERSECT(false, true, S, ro, rd, n_ptr, work, hit, hit_node, (uint32_t*)nullptr, counts3);
 }
 void launch_shade(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image) {
-    hipLaunchKernelGGL(k_shade, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, Q, P, depth, image);
+    hipLaunchKernelGGL(k_shade, dim3(lc.grid_blocks / 8), dim3(kWideBlock), 0, lc.stream, S, Q, P, depth, image);   // one 16-wave workgroup per CU (122 VGPRs)
 }
 void launch_finalize(const launch_ctx& lc, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image) {
     hipLaunchKernelGGL(k_finalize, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, Q, P, depth, image);

@@ -24,7 +24,8 @@ constexpr int kLdsStackFlat = 20;    // flat kernel: 20 KiB per workgroup -> 8 w
 __device__ int g_tri_batch = 1;      // flat kernel: leaf entries are tested once this many lanes wait at a leaf.  Measured on MI355X
                                      // (gpurun_out/tune_tri.log): batching leaves LOSES (973 -> 835 Mrays/s from 1 to 40) — the kernel is
                                      // memory-latency bound and every waiting lane is a load not in flight; kept as a knob (CTL_TRI_BATCH)
-__device__ int g_refill_idle = 20;   // refill as soon as this many lanes of the wave are idle (CTL_REFILL_IDLE overrides)
+__device__ int g_any_sorted = 0;     // flat kernel, any-hit: visit hit children nearest-first instead of in slot order (CTL_ANY_SORTED)
+__device__ int g_refill_idle = 12;   // refill as soon as this many lanes of the wave are idle (CTL_REFILL_IDLE overrides)
 constexpr uint32_t kChunk = 512;     // rays claimed from the global cursor per atomic
 
 __device__ __forceinline__ float rcp_guarded(float d) {   // TraceHelper.cu:417-420: 1/(|d| > 2^-80 ? d : copysign(2^-80, d))
@@ -270,7 +271,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
                     // sort key: entry distance (>= 0, so its bit pattern orders like the float) with the child slot in the two low bits
                     key[c] = h ? ((__float_as_uint(cmin) & ~3u) | (uint32_t)c) : 0xffffffffu;
                 }
-                if (!ANY_HIT) {   // front-to-back: 5-comparator network on the keys
+                if (!ANY_HIT || g_any_sorted) {   // front-to-back: 5-comparator network on the keys
 #define CTL_CSWAP(a, b) { const uint32_t lo_ = key[a] < key[b] ? key[a] : key[b], hi_ = key[a] < key[b] ? key[b] : key[a]; key[a] = lo_; key[b] = hi_; }
                     CTL_CSWAP(0, 1) CTL_CSWAP(2, 3) CTL_CSWAP(0, 2) CTL_CSWAP(1, 3) CTL_CSWAP(1, 2)
 #undef CTL_CSWAP
