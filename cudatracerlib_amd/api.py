@@ -190,6 +190,64 @@ def roughconductor(alpha=0.1, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), distrib
     return m
 
 
+def thindielectric(int_ior=1.5046, ext_ior=1.000277, specular_transmittance=1.0, specular_reflectance=1.0):
+    """thindielectric(eta) — BSDF_Simple.h:96-125."""
+    m = _material(4, E["DeltaReflection"] | E["Null"])
+    m.tex[0], m.tex[1] = _const_tex(specular_transmittance), _const_tex(specular_reflectance)
+    m.f[0] = np.float32(np.float32(int_ior) / np.float32(ext_ior))
+    return m
+
+
+def roughdielectric(alpha=0.1, int_ior=1.5046, ext_ior=1.000277, distribution=1, sample_visible=True, specular_transmittance=1.0, specular_reflectance=1.0, alpha_v=None):
+    """roughdielectric(type, eta, alphaU, alphaV) — BSDF_Simple.h:127-163 (distribution: 0 Beckmann, 1 GGX)."""
+    m = _material(5, E["GlossyReflection"] | E["GlossyTransmission"])
+    m.tex[0], m.tex[1] = _const_tex(specular_transmittance), _const_tex(specular_reflectance)
+    m.tex[2], m.tex[3] = _const_tex(alpha), _const_tex(alpha if alpha_v is None else alpha_v)
+    eta = np.float32(np.float32(int_ior) / np.float32(ext_ior))
+    m.f[0], m.f[1] = eta, np.float32(1.0) / eta
+    m.u[0], m.u[1] = distribution, 1 if sample_visible else 0
+    return m
+
+
+def fresnel_diffuse_reflectance(eta):
+    """FresnelHelper::fresnelDiffuseReflectance(eta, false) (Math/FresnelHelper.cu:13-60): integral of F(sqrt(xi), eta) over [0,1].
+    The reference integrates adaptively to 1e-5; this is the same integral evaluated in double precision."""
+    if eta == 1:
+        return 0.0
+    # substitute xi = c^2 (d xi = 2 c dc) so the integrand is smooth at grazing incidence
+    c = np.linspace(0.0, 1.0, 400001)
+    ct2 = 1.0 - (1.0 - c * c) / (eta * eta)
+    ct = np.sqrt(np.maximum(ct2, 0.0))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rs = (c - eta * ct) / (c + eta * ct)
+        rp = (eta * c - ct) / (eta * c + ct)
+        F = np.where(ct2 <= 0, 1.0, 0.5 * (rs * rs + rp * rp))
+    y = F * 2.0 * c
+    return float(np.sum((y[1:] + y[:-1]) * 0.5 * np.diff(c)))
+
+
+def plastic(diffuse_reflectance=(0.5, 0.5, 0.5), int_ior=1.49, ext_ior=1.000277, specular_reflectance=1.0, nonlinear=False):
+    """plastic(eta, diffuse, specular) — BSDF_Simple.h:234-270 incl. Update(): fdrInt/fdrExt, invEta2, specularSamplingWeight."""
+    m = _material(8, E["DeltaReflection"] | E["DiffuseReflection"])
+    m.tex[0], m.tex[1] = _const_tex(diffuse_reflectance), _const_tex(specular_reflectance)
+    eta = float(np.float32(np.float32(int_ior) / np.float32(ext_ior)))
+    lum = lambda t: t.value[0] * 0.212671 + t.value[1] * 0.715160 + t.value[2] * 0.072169   # Spectrum::getLuminance (Spectrum.cu:174-177)
+    d_avg, s_avg = lum(m.tex[0]), lum(m.tex[1])
+    m.f[0], m.f[1], m.f[2], m.f[3], m.f[4] = fresnel_diffuse_reflectance(1 / eta), fresnel_diffuse_reflectance(eta), eta, 1.0 / (eta * eta), s_avg / (d_avg + s_avg)
+    m.u[0] = 1 if nonlinear else 0
+    return m
+
+
+def phong(diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(0.2, 0.2, 0.2), exponent=30.0):
+    """phong(diffuse, specular, exponent) — BSDF_Simple.h:313-340; specularSamplingWeight = sAvg / (dAvg + sAvg)."""
+    m = _material(10, E["GlossyReflection"] | E["DiffuseReflection"])
+    m.tex[0], m.tex[1], m.tex[2] = _const_tex(diffuse_reflectance), _const_tex(specular_reflectance), _const_tex(exponent)
+    lum = lambda t: t.value[0] * 0.212671 + t.value[1] * 0.715160 + t.value[2] * 0.072169
+    d_avg, s_avg = lum(m.tex[0]), lum(m.tex[1])
+    m.f[0] = s_avg / (d_avg + s_avg)
+    return m
+
+
 # ---------------------------------------------------------------- DynamicScene (Engine/DynamicScene.h:70-187, loader-facing subset)
 class DynamicScene:
     def __init__(self):

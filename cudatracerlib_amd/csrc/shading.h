@@ -173,6 +173,10 @@ __device__ __forceinline__ f3 reflect_about(f3 wi, f3 n) { return normalize(2 * 
 enum { kESmooth = 0x2 | 0x4 | 0x8 | 0x10, kEDelta = 0x1 | 0x20 | 0x40, kEAll = 0x1ff };
 struct bsdf_rec { diff_geom dg; f3 wi, wo; float eta; uint32_t type_mask, sampled_type; };
 
+} // namespace ctl
+#include "bsdf_more.h"
+namespace ctl {
+
 __device__ f3 bsdf_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp) {
     switch (M.bsdf_type) {
     case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:7-36
@@ -229,7 +233,7 @@ __device__ f3 bsdf_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp
         pdf /= 4.0f * dot(b.wo, m);
         return F * weight;
     }
-    default: return f3(0.0f);
+    default: return bsdf_more_sample(M, b, pdf, smp);
     }
 }
 
@@ -257,7 +261,8 @@ __device__ f3 bsdf_f(const ctl_material& M, const bsdf_rec& b) {
         const float value = D * G / (4.0f * cos_theta(b.wi));
         return F * value;
     }
-    default: return f3(0.0f);   // delta lobes have no solid-angle density (BSDF_Simple.cu:226-252, 632-646)
+    case CTL_BSDF_DIELECTRIC: case CTL_BSDF_CONDUCTOR: case CTL_BSDF_THINDIELECTRIC: return f3(0.0f);   // delta lobes have no solid-angle density (BSDF_Simple.cu:226-252, 632-646)
+    default: return bsdf_more_f(M, b);
     }
 }
 __device__ float bsdf_pdf(const ctl_material& M, const bsdf_rec& b) {
@@ -279,7 +284,8 @@ __device__ float bsdf_pdf(const ctl_material& M, const bsdf_rec& b) {
         if (distr.vis) return distr.eval(H) * distr.smith_g1(b.wi, H) / (4.0f * cos_theta(b.wi));
         return distr.pdf(b.wi, H) / (4 * absdot(b.wo, H));
     }
-    default: return 0.0f;
+    case CTL_BSDF_DIELECTRIC: case CTL_BSDF_CONDUCTOR: case CTL_BSDF_THINDIELECTRIC: return 0.0f;
+    default: return bsdf_more_pdf(M, b);
     }
 }
 

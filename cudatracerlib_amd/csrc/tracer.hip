@@ -71,7 +71,9 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
     if (d.n_anim_bytes) anim_.upload(d.anim, d.n_anim_bytes); else anim_.alloc(16);
     for (uint32_t i = 0; i < d.n_materials; i++) {
         const uint32_t t = d.materials[i].bsdf_type;
-        if (t != CTL_BSDF_DIFFUSE && t != CTL_BSDF_DIELECTRIC && t != CTL_BSDF_CONDUCTOR && t != CTL_BSDF_ROUGHCONDUCTOR)
+        const bool ok = t == CTL_BSDF_DIFFUSE || t == CTL_BSDF_DIELECTRIC || t == CTL_BSDF_THINDIELECTRIC || t == CTL_BSDF_ROUGHDIELECTRIC || t == CTL_BSDF_CONDUCTOR ||
+                        t == CTL_BSDF_ROUGHCONDUCTOR || t == CTL_BSDF_PLASTIC || t == CTL_BSDF_PHONG;
+        if (!ok)
             throw std::runtime_error("ctl_scene_create: BSDF type " + std::to_string(t) + " has no HIP implementation yet");
     }
     S.flat_nodes = nullptr; S.flat_leaves = nullptr; S.flat_root = 0;

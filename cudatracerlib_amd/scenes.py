@@ -106,7 +106,13 @@ def cornell_box(width=256, height=256, glass_sphere=False, extra_materials=False
             m.add(P, I, N, mat)
     P, I, N, M = m.arrays()
     mats = [api.diffuse(WHITE), api.diffuse(RED), api.diffuse(GREEN), api.diffuse((0.78, 0.78, 0.78))]
-    if extra_materials:
+    if extra_materials == 2:      # short block plastic, tall block rough glass (GGX, visible normals)
+        mats += [api.plastic(diffuse_reflectance=(0.2, 0.3, 0.7), int_ior=1.49), api.roughdielectric(alpha=0.1, int_ior=1.5, ext_ior=1.0, distribution=1, sample_visible=True)]
+    elif extra_materials == 3:    # short block phong, tall block thin glass
+        mats += [api.phong(diffuse_reflectance=(0.5, 0.3, 0.1), specular_reflectance=(0.3, 0.3, 0.3), exponent=40.0), api.thindielectric(int_ior=1.5, ext_ior=1.0)]
+    elif extra_materials == 4:    # short block nonlinear plastic, tall block Beckmann rough glass sampled from the full distribution
+        mats += [api.plastic(diffuse_reflectance=(0.6, 0.2, 0.2), int_ior=1.9, nonlinear=True), api.roughdielectric(alpha=0.25, alpha_v=0.1, int_ior=1.33, ext_ior=1.0, distribution=0, sample_visible=False)]
+    elif extra_materials:
         mats += [api.roughconductor(alpha=0.15, distribution=1, sample_visible=True), api.conductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))]
     room = sc.add_mesh(P, I, normals=N, tri_material=M, materials=mats)
     node = sc.CreateNode(room)

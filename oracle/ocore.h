@@ -490,6 +490,10 @@ struct Microfacet {
 inline V3 reflectAbout(V3 wi, V3 n) { return normalize(2 * dot(wi, n) * n - wi); }   // FresnelHelper.h:148-151
 inline float avg3(Spec s) { float r = 0.0f; r += s.x; r += s.y; r += s.z; return r * (1.0f / 3); }   // Spectrum.h:180-190
 
+} // namespace orc
+#include "obsdf2.h"
+namespace orc {
+
 // --------------------------------------------------------------------------- BSDFs (SceneTypes/BSDF_Simple.cu)
 inline bool bsdfHasComponent(const ctl_material& M, unsigned type) { return (type & M.combined_type) != 0; }
 
@@ -559,7 +563,7 @@ inline Spec bsdfSample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sample
         pdf /= 4.0f * dot(bRec.wo, m);
         return F * weight;
     }
-    default: throw std::runtime_error("oracle: bsdf type not restated");
+    default: return bsdf2Sample(M, bRec, pdf, _sample);
     }
 }
 
@@ -588,7 +592,7 @@ inline Spec bsdfF(const ctl_material& M, const BRec& bRec, int measure = ESolidA
         float value = D * G / (4.0f * Frame::cosTheta(bRec.wi));
         return F * value;
     }
-    default: throw std::runtime_error("oracle: bsdf type not restated");
+    default: return bsdf2F(M, bRec, measure);
     }
 }
 
@@ -612,7 +616,7 @@ inline float bsdfPdf(const ctl_material& M, const BRec& bRec, int measure = ESol
         if (distr.sampleVis) return distr.eval(H) * distr.smithG1(bRec.wi, H) / (4.0f * Frame::cosTheta(bRec.wi));
         return distr.pdf(bRec.wi, H) / (4 * absdot(bRec.wo, H));
     }
-    default: throw std::runtime_error("oracle: bsdf type not restated");
+    default: return bsdf2Pdf(M, bRec, measure);
     }
 }
 

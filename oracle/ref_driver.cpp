@@ -39,7 +39,7 @@ void ref_woop_get_data(const float* w12, float* v0, float* v1, float* v2) {
 // TriIntersectorData::Intersect uses the fixed tmin 1e-4 (TriIntersectorData.cu:40)
 int ref_woop_intersect(const float* w12, const float* o, const float* d, float tmax, float* tuv) {
     TriIntersectorData t; std::memcpy(&t, w12, 48);
-    float dist = tmax; Vec2f bary;
+    float dist = tmax; Vec2f bary(0.0f);   // left untouched on a miss
     bool h = t.Intersect(Ray(Vec3f(o[0], o[1], o[2]), Vec3f(d[0], d[1], d[2])), &dist, &bary);
     tuv[0] = dist; tuv[1] = bary.x; tuv[2] = bary.y;
     return h ? 1 : 0;
@@ -82,6 +82,7 @@ void ref_coordinate_system(const float* a, float* s, float* t) {
     s[0] = S.x; s[1] = S.y; s[2] = S.z; t[0] = T.x; t[1] = T.y; t[2] = T.z;
 }
 float ref_power_heuristic(float a, float b) { return MonteCarlo::PowerHeuristic(1, a, 1, b); }
+float ref_fresnel_diffuse_reflectance(float eta, int fast) { return FresnelHelper::fresnelDiffuseReflectance(eta, fast != 0); }
 
 void ref_microfacet_eval(int type, float aU, float aV, int sampleVisible, const float* wi, const float* m, float* out) {
     MicrofacetDistribution d((MicrofacetDistribution::EType)type, aU, aV, sampleVisible != 0);

@@ -92,7 +92,11 @@ def main():
     mats = rs.normal(size=(128, 16)).astype(np.float32); mats[::2, 12:] = [0, 0, 0, 1]; inv = np.zeros((128, 16), np.float32)
     for i in range(128):
         r.ref_matrix_inverse(mats[i].ctypes.data_as(C.c_void_p), inv[i].ctypes.data_as(C.c_void_p))
-    np.savez_compressed(os.path.join(HERE, "math.npz"), s=s, cosine_hemisphere=cosh, uniform_triangle=tri, disk_concentric=disk,
+    # FresnelHelper::fresnelDiffuseReflectance(eta, fast=false) (Math/FresnelHelper.cu:13-60), used by plastic::Update()
+    r.ref_fresnel_diffuse_reflectance.restype = C.c_float; r.ref_fresnel_diffuse_reflectance.argtypes = [C.c_float, C.c_int]
+    fdr_eta = np.array([1.49 / 1.000277, 1.000277 / 1.49, 1.5, 1 / 1.5, 1.33, 1 / 1.33, 1.9, 1 / 1.9, 2.4, 1.05], np.float32)
+    fdr_val = np.array([r.ref_fresnel_diffuse_reflectance(float(e), 0) for e in fdr_eta], np.float32)
+    np.savez_compressed(os.path.join(HERE, "math.npz"), s=s, cosine_hemisphere=cosh, uniform_triangle=tri, disk_concentric=disk, fdr_eta=fdr_eta, fdr_value=fdr_val,
                         fd_cos=ci, fd_eta=eta, fd_out=fd, fc_cos=ce, fc_eta_k=ek, fc_out=fc, cs_in=cs_in, cs_s=cs_s, cs_t=cs_t, mat_in=mats, mat_inv=inv)
 
     # ---- microfacet distribution (Engine/MicrofacetDistribution.cu): Beckmann/GGX eval, G1, pdf, sample

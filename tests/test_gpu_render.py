@@ -59,6 +59,14 @@ def test_cornell_microfacet_and_conductor(gpu, orc):
     assert_close(got, want)
 
 
+@pytest.mark.parametrize("variant", [2, 3, 4])
+def test_cornell_plastic_roughdielectric_phong_thindielectric(gpu, orc, variant):
+    """2: plastic + GGX rough glass, 3: phong + thin glass, 4: nonlinear plastic + anisotropic Beckmann rough glass"""
+    sc = scenes.cornell_box(64, 64, extra_materials=variant)
+    got, want, tr, rays = render_pair(gpu, orc, sc, 64, 64, 3)
+    assert_close(got, want)
+
+
 def test_no_direct_and_short_paths(gpu, orc):
     sc = scenes.cornell_box(48, 48)
     got, want, _, _ = render_pair(gpu, orc, sc, 48, 48, 2, max_len=3, rr=1, direct=False)
