@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/<tag>/ (written by tools/profile_round.sh on the MI355X box) into profiles/<tag>_*:
+
+  <tag>_bench.json          the bench.py JSON line of that run
+  <tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats per-kernel summary (verbatim)
+  <tag>_pmc_summary.csv     per kernel: launches, FETCH_SIZE / WRITE_SIZE (KB, as rocprofv3 reports them), TCC hit rate
+  roofline_traffic.json     HBM bytes per launch of the dominant kernel (read by bench.py -> roofline.traffic)
+
+FETCH_SIZE/WRITE_SIZE are reported by rocprofv3 in KB.  MI355X_MICROARCH.md ("HBM"): on gfx950 FETCH_SIZE counts
+128-B requests as 64 B for wide coalesced streams (x2 correction); other access shapes are uncalibrated.  The traversal
+kernel issues 16 B/lane loads of scattered 64-B groups, so both the raw figure and the x2 figure are kept; bench.py's
+`traffic` uses the x2 (upper) figure for reads and the raw figure for writes.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    return name.split("(")[0].replace("ctl::", "").replace("void ", "")
+
+
+def read_counters(d):
+    acc = defaultdict(lambda: defaultdict(float)); n = defaultdict(lambda: defaultdict(int))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
+    return acc, n
+
+
+def main():
+    tag = sys.argv[1]
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))
+    for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(dst, tag + "_kernel_stats.csv"))
+    rows = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC"):
+        acc, n = read_counters(os.path.join(src, "pmc_" + c))
+        for k in acc:
+            rows.setdefault(k, {})
+            for name, v in acc[k].items():
+                rows[k][name] = v; rows[k]["launches"] = n[k][name]
+    out = os.path.join(dst, tag + "_pmc_summary.csv")
+    with open(out, "w") as fh:
+        fh.write("kernel,launches,FETCH_SIZE_KB_total,WRITE_SIZE_KB_total,fetch_bytes_per_launch_raw,fetch_bytes_per_launch_x2,write_bytes_per_launch,TCC_hit_rate\n")
+        for k, r in sorted(rows.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0)):
+            L = max(1, r.get("launches", 1)); fe, wr = r.get("FETCH_SIZE", 0.0), r.get("WRITE_SIZE", 0.0)
+            hit, miss = r.get("TCC_HIT_sum", 0.0), r.get("TCC_MISS_sum", 0.0)
+            fh.write("%s,%d,%.1f,%.1f,%.0f,%.0f,%.0f,%s\n" % (k, L, fe, wr, fe * 1024 / L, 2 * fe * 1024 / L, wr * 1024 / L, ("%.3f" % (hit / (hit + miss))) if hit + miss > 0 else ""))
+    # dominant kernel = closest-hit intersect without counters: k_intersect<false, false, FLAT>
+    dom = [k for k in rows if k.startswith("k_intersect<false, false")]
+    if dom:
+        k = max(dom, key=lambda k: rows[k].get("FETCH_SIZE", 0)); r = rows[k]; L = max(1, r.get("launches", 1))
+        json.dump({"tag": tag, "kernel": k, "launches_profiled": L,
+                   "fetch_bytes_per_launch_raw": r.get("FETCH_SIZE", 0) * 1024 / L, "write_bytes_per_launch": r.get("WRITE_SIZE", 0) * 1024 / L,
+                   "k_intersect_closest_bytes_per_launch": (2 * r.get("FETCH_SIZE", 0) + r.get("WRITE_SIZE", 0)) * 1024 / L,
+                   "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes) per launch; launches in the profiled run trace 2 passes each (PassBatch auto), same as bench.py"},
+                  open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    main()
