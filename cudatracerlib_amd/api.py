@@ -41,7 +41,12 @@ class ctl_light(C.Structure):
     _fields_ = [("type", u32), ("radiance", f32 * 3), ("area_dist_index", u32), ("triangles_index", u32), ("sum_area", f32), ("count", u32),
                 ("orthogonal", u32), ("node_idx", u32), ("position", f32 * 3), ("direction", f32 * 3),
                 ("cutoff_angle", f32), ("beam_width", f32), ("cos_cutoff_angle", f32), ("cos_beam_width", f32), ("inv_transition_width", f32),
-                ("to_world", f32 * 16), ("env_image", u32), ("env_scale", f32 * 3), ("bsphere_center", f32 * 3), ("bsphere_radius", f32)]
+                ("to_world", f32 * 16), ("env_image", u32), ("env_scale", f32 * 3), ("bsphere_center", f32 * 3), ("bsphere_radius", f32),
+                ("cdf_rows_index", u32), ("cdf_cols_index", u32), ("row_weights_index", u32), ("normalization", f32)]
+
+
+class ctl_mipmap(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("width", u32), ("height", u32), ("texel_type", u32), ("wrap_mode", u32), ("filter_mode", u32)]
 
 
 class ctl_sensor(C.Structure):
@@ -83,7 +88,8 @@ class ctl_scene_desc(C.Structure):
                 ("anim", C.c_void_p), ("n_anim_bytes", u32), ("scene_start_node", i32), ("scene_bvh_nodes", C.c_void_p), ("n_scene_bvh_nodes", u32),
                 ("node_transforms", C.c_void_p), ("node_inv_transforms", C.c_void_p), ("env_map_index", u32),
                 ("box_min", f32 * 3), ("box_max", f32 * 3), ("camera", ctl_sensor), ("num_lights", u32),
-                ("light_indices", u32 * MAX_NUM_LIGHTS), ("light_cdf", f32 * MAX_NUM_LIGHTS), ("ray_trace_eps", f32)]
+                ("light_indices", u32 * MAX_NUM_LIGHTS), ("light_cdf", f32 * MAX_NUM_LIGHTS), ("ray_trace_eps", f32),
+                ("images", C.POINTER(ctl_mipmap)), ("n_images", u32)]
 
     # numpy views of the reference-layout arrays (host memory owned by the builder)
     def view(self, name, dtype, count, width):
@@ -110,6 +116,10 @@ lib.ctl_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.ctl_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.ctl_intersect_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(f32)]
 lib.ctl_image_resolve_rgb.argtypes = [C.c_void_p, f32, C.c_void_p]
+lib.ctl_builder_add_spot_light.argtypes = [C.c_void_p, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), f32, f32]
+lib.ctl_builder_add_distant_light.argtypes = [C.c_void_p, C.POINTER(f32), C.POINTER(f32), f32]
+lib.ctl_builder_add_image.argtypes = [C.c_void_p, C.c_void_p, u32, u32, u32, u32, u32, C.POINTER(u32)]
+lib.ctl_builder_set_environment_map.argtypes = [C.c_void_p, u32, C.POINTER(f32), C.c_void_p]
 lib.ctl_builder_set_camera_lookat.argtypes = [C.c_void_p, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), f32, u32, u32]
 
 
@@ -135,6 +145,9 @@ def _f32(a, shape=None):
 
 # ---------------------------------------------------------------- material helpers (Mitsuba plugin defaults, ObjectParser.h:754-966)
 E = dict(Null=0x1, DiffuseReflection=0x2, DiffuseTransmission=0x4, GlossyReflection=0x8, GlossyTransmission=0x10, DeltaReflection=0x20, DeltaTransmission=0x40)
+TEXEL_RGBE, TEXEL_RGBCOL = 0, 1
+WRAP_REPEAT, WRAP_CLAMP, WRAP_MIRROR, WRAP_BLACK = 0, 1, 2, 3
+FILTER_POINT, FILTER_BILINEAR, FILTER_ANISOTROPIC, FILTER_TRILINEAR = 0, 1, 2, 3
 TEX_CONSTANT, BSDF_DIFFUSE, BSDF_DIELECTRIC, BSDF_CONDUCTOR, BSDF_ROUGHCONDUCTOR = 2, 1, 3, 6, 7
 
 
@@ -145,6 +158,50 @@ def _const_tex(rgb):
     t.value[:] = [float(x) for x in rgb]
     t.uv_scale[:] = [1.0, 1.0]
     return t
+
+
+def image_texture(image, scale=1.0, uv_scale=(1.0, 1.0), uv_offset=(0.0, 0.0)):
+    """ImageTexture(mapping, file, scale) (SceneTypes/Texture.h:159-183) over a registered image."""
+    t = _const_tex(scale)
+    t.type = 4
+    t.uv_scale[:] = [float(x) for x in uv_scale]; t.uv_offset[:] = [float(x) for x in uv_offset]
+    t.image = image
+    return t
+
+
+def checker_texture(color0, color1, uv_scale=(1.0, 1.0), uv_offset=(0.0, 0.0)):
+    """CheckerboardTexture (SceneTypes/Texture.h:127-157)."""
+    t = _const_tex(color0)
+    t.type = 3
+    c1 = (color1, color1, color1) if np.isscalar(color1) else color1
+    t.value1[:] = [float(x) for x in c1]
+    t.uv_scale[:] = [float(x) for x in uv_scale]; t.uv_offset[:] = [float(x) for x in uv_offset]
+    return t
+
+
+def _as_tex(v):
+    return v if isinstance(v, ctl_texture) else _const_tex(v)
+
+
+def float3_to_rgbe(rgb):
+    """SpectrumConverter::Float3ToRGBE (Math/Spectrum.h:534-555) over an (h, w, 3) float array -> (h, w) uint32 texels."""
+    c = np.asarray(rgb, np.float32)
+    mx = c.max(axis=-1)
+    m, e = np.frexp(mx.astype(np.float64))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        k = (m.astype(np.float32) * np.float32(256.0) / mx).astype(np.float32)
+    out = np.zeros(c.shape[:-1], np.uint32)
+    ok = mx >= 1e-32
+    q = np.zeros(c.shape, np.uint32)
+    q[ok] = (c[ok] * k[ok][:, None]).astype(np.uint8)   # (unsigned char)(c * max_)
+    out[ok] = q[ok][:, 0] | (q[ok][:, 1] << 8) | (q[ok][:, 2] << 16) | (((e[ok] + 128).astype(np.uint32) & 0xff) << 24)
+    return out
+
+
+def float3_to_rgbcol(rgb):
+    """SpectrumConverter::Float3ToCOLORREF (Math/Spectrum.h:521-526)."""
+    c = (np.clip(np.asarray(rgb, np.float32), 0.0, 1.0) * np.float32(255.0)).astype(np.uint8).astype(np.uint32)
+    return c[..., 0] | (c[..., 1] << 8) | (c[..., 2] << 16) | np.uint32(255 << 24)
 
 
 def _material(bsdf_type, combined, two_sided=False):
@@ -158,7 +215,7 @@ def _material(bsdf_type, combined, two_sided=False):
 def diffuse(reflectance=(0.5, 0.5, 0.5), two_sided=False):
     """diffuse(reflectance) — BSDF_Simple.h:6-24."""
     m = _material(BSDF_DIFFUSE, E["DiffuseReflection"], two_sided)
-    m.tex[0] = _const_tex(reflectance)
+    m.tex[0] = _as_tex(reflectance)
     return m
 
 
@@ -297,6 +354,28 @@ class DynamicScene:
     def setCamera(self, pos, target, up, fov_degrees, width, height):
         _check(lib.ctl_builder_set_camera_lookat(self._h, (f32 * 3)(*map(float, pos)), (f32 * 3)(*map(float, target)), (f32 * 3)(*map(float, up)),
                                                  f32(fov_degrees), u32(width), u32(height)))
+
+    def CreateSpotLight(self, position, target, intensity, cutoff_angle=20.0, beam_width=None):
+        """SpotLight(p, t, L, cutoffAngle, beamWidth) in degrees; Mitsuba default beamWidth = 3/4 cutoffAngle (ObjectParser.h spot)."""
+        bw = cutoff_angle * 0.75 if beam_width is None else beam_width
+        _check(lib.ctl_builder_add_spot_light(self._h, (f32 * 3)(*position), (f32 * 3)(*target), (f32 * 3)(*intensity), f32(cutoff_angle), f32(bw)))
+
+    def CreateDistantLight(self, direction, irradiance, scene_radius=1.0):
+        _check(lib.ctl_builder_add_distant_light(self._h, (f32 * 3)(*direction), (f32 * 3)(*irradiance), f32(scene_radius)))
+
+    def add_image(self, texels, texel_type=TEXEL_RGBCOL, wrap=WRAP_REPEAT, filter=FILTER_BILINEAR):
+        """Register level 0 of a KernelMIPMap: texels (h, w) uint32, byte 0 = r ... byte 3 = e / alpha.  Returns the image index."""
+        t = np.ascontiguousarray(texels, dtype=np.uint32)
+        idx = u32()
+        _check(lib.ctl_builder_add_image(self._h, t.ctypes.data_as(C.c_void_p), u32(t.shape[1]), u32(t.shape[0]), u32(texel_type), u32(wrap), u32(filter), C.byref(idx)))
+        return idx.value
+
+    def setEnvironementMap(self, image, scale=(1.0, 1.0, 1.0), to_world=None):
+        """DynamicScene::setEnvironementMap (DynamicScene.cpp:846-859) for an already decoded lat-long image."""
+        m = None
+        if to_world is not None:
+            m = ctl_float4x4(); m.m[:] = [float(x) for x in np.asarray(to_world, np.float32).reshape(16)]
+        _check(lib.ctl_builder_set_environment_map(self._h, u32(image), (f32 * 3)(*scale), C.byref(m) if m is not None else None))
 
     def ParseMitsubaScene(self, path, width=-1, height=-1):
         """ParseMitsubaScene (Engine/SceneLoader/Mitsuba/MitsubaLoader.h:13)."""

@@ -55,6 +55,22 @@ int ctl_builder_add_point_light(ctl_builder* b, const float position[3], const f
     CTL_REQUIRE(b && position && intensity, "null argument");
     CTL_TRY b->b.add_point_light(position, intensity); CTL_CATCH
 }
+int ctl_builder_add_spot_light(ctl_builder* b, const float position[3], const float target[3], const float intensity[3], float cutoff_angle_degrees, float beam_width_degrees) {
+    CTL_REQUIRE(b && position && target && intensity, "null argument");
+    CTL_TRY b->b.add_spot_light(position, target, intensity, cutoff_angle_degrees, beam_width_degrees); CTL_CATCH
+}
+int ctl_builder_add_distant_light(ctl_builder* b, const float direction[3], const float irradiance[3], float scene_radius) {
+    CTL_REQUIRE(b && direction && irradiance, "null argument");
+    CTL_TRY b->b.add_distant_light(direction, irradiance, scene_radius); CTL_CATCH
+}
+int ctl_builder_add_image(ctl_builder* b, const uint32_t* texels, uint32_t width, uint32_t height, uint32_t texel_type, uint32_t wrap_mode, uint32_t filter_mode, uint32_t* image_index_out) {
+    CTL_REQUIRE(b && texels, "null argument");
+    CTL_TRY uint32_t i = b->b.add_image(texels, width, height, texel_type, wrap_mode, filter_mode); if (image_index_out) *image_index_out = i; CTL_CATCH
+}
+int ctl_builder_set_environment_map(ctl_builder* b, uint32_t image_index, const float scale[3], const ctl_float4x4* to_world) {
+    CTL_REQUIRE(b && scale, "null argument");
+    CTL_TRY b->b.set_environment_map(image_index, scale, to_world); CTL_CATCH
+}
 int ctl_builder_set_camera_lookat(ctl_builder* b, const float pos[3], const float target[3], const float up[3], float fov_degrees, uint32_t width, uint32_t height) {
     CTL_REQUIRE(b && pos && target && up && width && height, "bad argument");
     CTL_TRY b->b.set_camera_lookat(pos, target, up, fov_degrees, width, height); CTL_CATCH

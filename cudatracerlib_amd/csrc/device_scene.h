@@ -30,6 +30,7 @@ struct dev_scene {
     const ctl_material* mats;
     const ctl_light* lights;
     const unsigned char* anim;
+    const ctl_mipmap* images;    // level-0 KernelMIPMap descriptors with device texel pointers
     int start_node;
     uint32_t n_nodes;
     uint32_t num_lights;

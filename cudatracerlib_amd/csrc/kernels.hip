@@ -215,7 +215,16 @@ __global__ __launch_bounds__(kWideBlock) void k_shade(dev_scene S, wave_queues Q
                     if (rng.next1() >= q) alive = false; else cf = cf / q;
                 }
             }
-            // miss: EvalEnvironment == 0 without an environment emitter (KernelDynamicScene.cu:48-55)
+            else if (S.env_map_index != 0xffffffffu) {
+                // miss with an environment emitter (PathTracer.cu:99-111), MIS-weighted against NEE of the previous vertex
+                const ctl_light& light = S.lights[S.env_map_index];
+                float misWeight = 1.0f;
+                if (!(!P.direct || depth == 1 || specularBounce)) {
+                    const float direct_pdf = env_pdf_direct(S, light, r_d) * pdf_emitter(S, S.env_map_index);
+                    misWeight = power_heuristic(brdf_scattering_pdf, direct_pdf);
+                }
+                cl = cl + misWeight * cf * env_eval(S, light, r_d);
+            }
             terminated = !alive;
             specular = specularBounce; bsdf_pdf_out = brdf_scattering_pdf; d1 = rng.d1; d2 = rng.d2;
         }

@@ -234,6 +234,108 @@ uint32_t scene_builder::add_point_light(const float position[3], const float int
     return (uint32_t)lights.size() - 1;
 }
 
+// Frame(n) (Math/Frame.h:31-35) -> rows s, t, n of ctl_light::to_world
+static void store_frame(ctl_light& L, f3 n) {
+    f3 s, t; coordinate_system(n, s, t);
+    std::memset(L.to_world, 0, sizeof(L.to_world));
+    L.to_world[0] = s.x; L.to_world[1] = s.y; L.to_world[2] = s.z;
+    L.to_world[4] = t.x; L.to_world[5] = t.y; L.to_world[6] = t.z;
+    L.to_world[8] = n.x; L.to_world[9] = n.y; L.to_world[10] = n.z;
+}
+
+// SpotLight::SpotLight (SceneTypes/Light.cu:268-277): width = cutoff angle, fall = beam width, both in degrees
+uint32_t scene_builder::add_spot_light(const float position[3], const float target[3], const float intensity[3], float cutoff_deg, float beam_deg) {
+    ctl_light L{};
+    L.type = CTL_LIGHT_SPOT;
+    for (int i = 0; i < 3; i++) { L.position[i] = position[i]; L.direction[i] = target[i]; L.radiance[i] = intensity[i]; }
+    L.cutoff_angle = cutoff_deg * (kPi / 180.0f); L.beam_width = beam_deg * (kPi / 180.0f);
+    L.cos_beam_width = cosf(L.beam_width); L.cos_cutoff_angle = cosf(L.cutoff_angle);
+    L.inv_transition_width = 1.0f / (L.cutoff_angle - L.beam_width);
+    store_frame(L, normalize(f3(target[0], target[1], target[2]) - f3(position[0], position[1], position[2])));
+    lights.push_back(L);
+    return (uint32_t)lights.size() - 1;
+}
+
+// DistantLight(L, d, r) (SceneTypes/Light.h:155-163): radius = r * 1.1 (the Mitsuba loader passes r = 1, ObjectParser.h:530)
+uint32_t scene_builder::add_distant_light(const float direction[3], const float irradiance[3], float scene_radius) {
+    ctl_light L{};
+    L.type = CTL_LIGHT_DISTANT;
+    for (int i = 0; i < 3; i++) { L.direction[i] = direction[i]; L.radiance[i] = irradiance[i]; }
+    store_frame(L, normalize(f3(direction[0], direction[1], direction[2])));
+    L.bsphere_radius = scene_radius * 1.1f;
+    lights.push_back(L);
+    return (uint32_t)lights.size() - 1;
+}
+
+uint32_t scene_builder::add_image(const uint32_t* texels, uint32_t w, uint32_t h, uint32_t texel_type, uint32_t wrap, uint32_t filter) {
+    if (!texels || w == 0 || h == 0) throw std::runtime_error("ctl_builder_add_image: empty image");
+    if (texel_type > CTL_TEXEL_RGBCOL || wrap > CTL_WRAP_BLACK || filter > CTL_FILTER_TRILINEAR) throw std::runtime_error("ctl_builder_add_image: bad texel type / wrap / filter mode");
+    image_texels.emplace_back(texels, texels + (size_t)w * h);
+    ctl_mipmap m{}; m.width = w; m.height = h; m.texel_type = texel_type; m.wrap_mode = wrap; m.filter_mode = filter;
+    images.push_back(m);
+    return (uint32_t)images.size() - 1;
+}
+
+static f3 texel_decode(uint32_t v, uint32_t type) {   // SpectrumConverter::RGBEToFloat3 / COLORREFToFloat3 (Math/Spectrum.h:528-565)
+    unsigned x = v & 0xff, y = (v >> 8) & 0xff, z = (v >> 16) & 0xff, w = v >> 24;
+    if (type == CTL_TEXEL_RGBE) {
+        if (!w) return f3(0.0f);
+        float e = ldexpf(1.0f, int(w) - (128 + 8));
+        return f3(x * e, y * e, z * e);
+    }
+    return f3(float(x) / 255.0f, float(y) / 255.0f, float(z) / 255.0f);
+}
+
+// DynamicScene::setEnvironementMap (Engine/DynamicScene.cpp:846-859) + InfiniteLight::InfiniteLight (SceneTypes/Light.cpp:10-61)
+uint32_t scene_builder::set_environment_map(uint32_t image, const float scale[3], const ctl_float4x4* to_world) {
+    if (env_light != 0xffffffffu) throw std::runtime_error("Can't set environment map when it is already set!");
+    if (image >= images.size()) throw std::runtime_error("ctl_builder_set_environment_map: bad image index");
+    const ctl_mipmap& M = images[image]; const std::vector<uint32_t>& tx = image_texels[image];
+    const uint32_t W = M.width, H = M.height;
+    auto align_to = [&](size_t a) { while (anim.size() % a) anim.push_back(0); };
+    align_to(16); uint32_t cols_off = (uint32_t)anim.size(); anim.resize(anim.size() + (size_t)(W + 1) * H * sizeof(float));
+    align_to(16); uint32_t rows_off = (uint32_t)anim.size(); anim.resize(anim.size() + (size_t)(H + 1) * sizeof(float));
+    align_to(16); uint32_t wts_off = (uint32_t)anim.size(); anim.resize(anim.size() + (size_t)H * sizeof(float));
+    std::vector<float> cdfCols((size_t)(W + 1) * H), cdfRows(H + 1), rowWeights(H);
+    const float sizeX = (float)W, sizeY = (float)H;
+    size_t colPos = 0, rowPos = 0;
+    float rowSum = 0.0f;
+    cdfRows[rowPos++] = 0;
+    for (uint32_t y = 0; y < H; ++y) {
+        float colSum = 0;
+        cdfCols[colPos++] = 0;
+        for (uint32_t x = 0; x < W; ++x) {
+            f3 v = texel_decode(tx[(size_t)y * W + x], M.texel_type);
+            colSum += v.x * 0.212671f + v.y * 0.715160f + v.z * 0.072169f;   // Spectrum::getLuminance
+            cdfCols[colPos++] = colSum;
+        }
+        float normalization = 1.0f / colSum;
+        for (uint32_t x = 1; x < W; ++x) cdfCols[colPos - x - 1] *= normalization;
+        cdfCols[colPos - 1] = 1.0f;
+        float weight = sinf((y + 0.5f) * kPi / sizeY);
+        rowWeights[y] = weight;
+        rowSum += colSum * weight;
+        cdfRows[rowPos++] = rowSum;
+    }
+    float normalization = 1.0f / rowSum;
+    for (uint32_t y = 1; y < H; ++y) cdfRows[rowPos - y - 1] *= normalization;
+    cdfRows[rowPos - 1] = 1.0f;
+    std::memcpy(anim.data() + cols_off, cdfCols.data(), cdfCols.size() * sizeof(float));
+    std::memcpy(anim.data() + rows_off, cdfRows.data(), cdfRows.size() * sizeof(float));
+    std::memcpy(anim.data() + wts_off, rowWeights.data(), rowWeights.size() * sizeof(float));
+    ctl_light L{};
+    L.type = CTL_LIGHT_INFINITE;
+    L.env_image = image;
+    for (int i = 0; i < 3; i++) L.env_scale[i] = scale[i];
+    L.cdf_cols_index = cols_off; L.cdf_rows_index = rows_off; L.row_weights_index = wts_off;
+    L.normalization = 1.0f / (rowSum * (2 * kPi / sizeX) * (kPi / sizeY));
+    static const float ident[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+    std::memcpy(L.to_world, to_world ? to_world->m : ident, 64);
+    lights.push_back(L);
+    env_light = (uint32_t)lights.size() - 1;
+    return env_light;
+}
+
 // Sensor::SetToWorld(pos, tar, up) (SceneTypes/Sensor.cu:691-699) with the loader's frame reconstruction
 // (ObjectParser.h:292-297, Sensor.cu:682-689): r = f x up, u = r x f, columns (r, u, f), translation pos.
 void scene_builder::set_camera_lookat(const float pos[3], const float target[3], const float up_in[3], float fov_degrees, uint32_t w, uint32_t h) {
@@ -294,8 +396,18 @@ void scene_builder::finalize(ctl_scene_desc& out) {
     out.scene_start_node = start;
     out.scene_bvh_nodes = scene_bvh.data(); out.n_scene_bvh_nodes = (uint32_t)scene_bvh.size();
     out.node_transforms = xf.data(); out.node_inv_transforms = ixf.data();
-    out.env_map_index = 0xffffffffu;
+    out.env_map_index = env_light;
     for (int i = 0; i < 3; i++) { out.box_min[i] = scene.lo[i]; out.box_max[i] = scene.hi[i]; }
+    for (size_t i = 0; i < images.size(); i++) images[i].texels = image_texels[i].data();
+    out.images = images.data(); out.n_images = (uint32_t)images.size();
+    {   // the light that depends on the scene box: InfiniteLight::Update (SceneTypes/Light.h:318-325)
+        f3 lo(scene.lo[0], scene.lo[1], scene.lo[2]), hi(scene.hi[0], scene.hi[1], scene.hi[2]);
+        f3 center = (lo + hi) * 0.5f;   // AABB::Center (Math/AABB.h)
+        f3 size = hi - lo;
+        for (auto& L : lights) {
+            if (L.type == CTL_LIGHT_INFINITE) { L.bsphere_center[0] = center.x; L.bsphere_center[1] = center.y; L.bsphere_center[2] = center.z; L.bsphere_radius = length(size) / 1.5f; }
+        }
+    }
     out.camera = camera;
     // LightStream::fillDeviceData (Engine/DynamicScene.cpp:172-196): uniform weights, first MAX_NUM_LIGHTS lights
     out.num_lights = std::min<uint32_t>(CTL_MAX_NUM_LIGHTS, (uint32_t)lights.size());

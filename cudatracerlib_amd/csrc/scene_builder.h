@@ -27,6 +27,9 @@ struct scene_builder {
     std::vector<ctl_float4x4> xf, ixf;
     std::vector<ctl_light> lights;
     std::vector<uint8_t> anim;
+    std::vector<std::vector<uint32_t>> image_texels;   // level-0 texels of every registered KernelMIPMap
+    std::vector<ctl_mipmap> images;
+    uint32_t env_light = 0xffffffffu;
     ctl_sensor camera{};
     bool have_camera = false;
 
@@ -35,6 +38,10 @@ struct scene_builder {
     uint32_t add_node(uint32_t mesh_index, const ctl_float4x4* to_world);
     uint32_t add_area_light(uint32_t node_index, uint32_t local_material, const float radiance[3]);
     uint32_t add_point_light(const float position[3], const float intensity[3]);
+    uint32_t add_spot_light(const float position[3], const float target[3], const float intensity[3], float cutoff_deg, float beam_deg);
+    uint32_t add_distant_light(const float direction[3], const float irradiance[3], float scene_radius);
+    uint32_t add_image(const uint32_t* texels, uint32_t w, uint32_t h, uint32_t texel_type, uint32_t wrap, uint32_t filter);
+    uint32_t set_environment_map(uint32_t image, const float scale[3], const ctl_float4x4* to_world);
     void set_camera_lookat(const float pos[3], const float target[3], const float up[3], float fov_degrees, uint32_t w, uint32_t h);
     void set_camera(const ctl_sensor& s);
     void finalize(ctl_scene_desc& out);

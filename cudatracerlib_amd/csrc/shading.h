@@ -37,9 +37,10 @@ __device__ __forceinline__ void sensor_sample_ray(const dev_sensor& c, f2 pixelS
 }
 
 // ---- differential geometry at a hit (Kernel/TraceHelper.cu:274-307 -> Engine/TriangleData.cu:75-103)
-struct diff_geom { f3 P; frame sys; f3 n; f2 uv; };
+struct diff_geom { f3 P; frame sys; f3 n; f2 uv; const ctl_mipmap* images; };   // images: g_SceneData.m_sTexData (uniform)
 __device__ __forceinline__ void fill_dg(const dev_scene& S, float u, float v, int tri, int node, diff_geom& dg) {
     const uint4 ta = S.tri_data[tri * 2], tb = S.tri_data[tri * 2 + 1];   // {nme.x, nme.y, dpd.x, dpd.y} {dpd.z, uv0, uv1, uv2}
+    dg.images = S.images;
     const float4 f0 = S.inst_fwd[node * 3], f1 = S.inst_fwd[node * 3 + 1], f2_ = S.inst_fwd[node * 3 + 2];
     m34 l2w; l2w.r[0][0] = f0.x; l2w.r[0][1] = f0.y; l2w.r[0][2] = f0.z; l2w.r[0][3] = f0.w; l2w.r[1][0] = f1.x; l2w.r[1][1] = f1.y; l2w.r[1][2] = f1.z; l2w.r[1][3] = f1.w;
     l2w.r[2][0] = f2_.x; l2w.r[2][1] = f2_.y; l2w.r[2][2] = f2_.z; l2w.r[2][3] = f2_.w;
@@ -61,13 +62,61 @@ __device__ __forceinline__ void fill_dg(const dev_scene& S, float u, float v, in
 }
 __device__ __forceinline__ uint32_t tri_mat_index(const dev_scene& S, int tri) { return (S.tri_data[tri * 2].y >> 16) & 0xff; }   // TriangleData.h:40-44
 
-// ---- textures (SceneTypes/Texture.h:107-157)
+// ---- KernelMIPMap level 0 (Engine/MIPMap.cu:21-57,116-121,155-172; MIPMap_device.h:34-55)
+__device__ __forceinline__ f3 texel_decode(uint32_t v, uint32_t type) {
+    const uint32_t x = v & 0xff, y = (v >> 8) & 0xff, z = (v >> 16) & 0xff, w = v >> 24;
+    if (type == CTL_TEXEL_RGBE) {   // SpectrumConverter::RGBEToFloat3 (Math/Spectrum.h:557-565)
+        if (!w) return f3(0.0f);
+        const float e = ldexpf(1.0f, (int)w - (128 + 8));
+        return f3(x * e, y * e, z * e);
+    }
+    return f3(float(x) / 255.0f, float(y) / 255.0f, float(z) / 255.0f);   // COLORREFToFloat3 (:528-532)
+}
+__device__ __forceinline__ float fracf_(float f) { return f - floorf(f); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ bool wrap_coordinates(f2 uv, f2 dim, uint32_t w, f2& loc) {
+    switch (w) {
+    case CTL_WRAP_REPEAT: loc = f2{ fracf_(uv.x) * dim.x, fracf_(1.0f - uv.y) * dim.y }; return true;
+    case CTL_WRAP_CLAMP: loc = f2{ clampf(uv.x, 0.0f, 1.0f) * dim.x, clampf(1.0f - uv.y, 0.0f, 1.0f) * dim.y }; return true;
+    case CTL_WRAP_MIRROR: {   // the reference tests the parity of uv.x for both axes
+        const float lx = (int)uv.x % 2 == 0 ? fracf_(uv.x) : 1.0f - fracf_(uv.x), ly = (int)uv.x % 2 == 0 ? fracf_(uv.y) : 1.0f - fracf_(uv.y);
+        loc = f2{ lx * dim.x, ly * dim.y }; return true; }
+    case CTL_WRAP_BLACK:
+        if (uv.x < 0 || uv.x >= 1 || uv.y < 0 || uv.y >= 1) return false;
+        loc = f2{ uv.x * dim.x, uv.y * dim.y }; return true;
+    }
+    return false;
+}
+__device__ __forceinline__ f3 mip_texel(const ctl_mipmap& M, f2 uv) {
+    f2 l;
+    if (!wrap_coordinates(uv, f2{ (float)M.width, (float)M.height }, M.wrap_mode, l)) return f3(0.0f);
+    const int x = clampi((int)l.x, 0, (int)M.width - 1), y = clampi((int)l.y, 0, (int)M.height - 1);
+    return texel_decode(M.texels[(size_t)y * M.width + x], M.texel_type);
+}
+__device__ __forceinline__ f3 mip_triangle(const ctl_mipmap& M, f2 uv) {
+    const f2 sz{ (float)M.width, (float)M.height }, is{ 1.0f / sz.x, 1.0f / sz.y };
+    const float ds = fracf_(uv.x * sz.x), dt = fracf_(uv.y * sz.y);
+    return ((1.f - ds) * (1.f - dt)) * mip_texel(M, uv) + ((1.f - ds) * dt) * mip_texel(M, f2{ uv.x + 0, uv.y + is.y }) +
+           (ds * (1.f - dt)) * mip_texel(M, f2{ uv.x + is.x, uv.y + 0 }) + (ds * dt) * mip_texel(M, f2{ uv.x + is.x, uv.y + is.y });
+}
+__device__ __forceinline__ f3 mip_fetch(const ctl_mipmap& M, int x, int y) {
+    x = clampi(x, 0, (int)M.width - 1); y = clampi(y, 0, (int)M.height - 1);
+    return texel_decode(M.texels[(size_t)y * M.width + x], M.texel_type);
+}
+
+// ---- textures (SceneTypes/Texture.h:107-183, Texture.cu:6-29)
 __device__ __forceinline__ f3 tex_eval(const ctl_texture& t, const diff_geom& dg) {
     if (t.type == CTL_TEX_CHECKER) {
         const float u = dg.uv.x * t.uv_scale[0] + t.uv_offset[0], v = dg.uv.y * t.uv_scale[1] + t.uv_offset[1];
         int xm = (int)(u * 2) % 2, ym = (int)(v * 2) % 2; if (xm < 0) xm += 2; if (ym < 0) ym += 2;
         const int x = 2 * xm - 1, y = 2 * ym - 1;
         return (x * y == 1) ? f3(t.value[0], t.value[1], t.value[2]) : f3(t.value1[0], t.value1[1], t.value1[2]);
+    }
+    if (t.type == CTL_TEX_IMAGE) {
+        if (t.image == 0xffffffffu) return f3(0.0f);
+        const f2 uv{ t.uv_scale[0] * dg.uv.x + 0 * dg.uv.y + t.uv_offset[0], 0 * dg.uv.x + t.uv_scale[1] * dg.uv.y + t.uv_offset[1] };
+        const ctl_mipmap& M = dg.images[t.image];
+        return (M.filter_mode == CTL_FILTER_POINT ? mip_texel(M, uv) : mip_triangle(M, uv)) * f3(t.value[0], t.value[1], t.value[2]);
     }
     return f3(t.value[0], t.value[1], t.value[2]);
 }
@@ -302,7 +351,73 @@ __device__ __forceinline__ uint32_t sample_reuse(const float* __restrict__ cdf, 
     s = (s - cdf[index]) / pdf;
     return (uint32_t)index;
 }
-// DiffuseLight::sampleDirect / PointLight::sampleDirect (SceneTypes/Light.cu:83-137, 13-31) with ShapeSet::SamplePosition (Engine/ShapeSet.cu:51-69)
+__device__ __forceinline__ frame light_frame(const ctl_light& L) {
+    frame f; f.s = f3(L.to_world[0], L.to_world[1], L.to_world[2]); f.t = f3(L.to_world[4], L.to_world[5], L.to_world[6]); f.n = f3(L.to_world[8], L.to_world[9], L.to_world[10]);
+    return f;
+}
+// SpotLight::falloffCurve (SceneTypes/Light.cu:327-336)
+__device__ __forceinline__ f3 spot_falloff(const ctl_light& L, f3 d) {
+    const float cosTheta = d.z;
+    if (cosTheta <= L.cos_cutoff_angle) return f3(0.0f);
+    if (cosTheta >= L.cos_beam_width) return f3(1.0f);
+    return f3((L.cutoff_angle - acosf(cosTheta)) * L.inv_transition_width);
+}
+__device__ __forceinline__ float luminance(f3 s) { return s.x * 0.212671f + s.y * 0.715160f + s.z * 0.072169f; }   // Spectrum.cu:174-177
+__device__ __forceinline__ float interval_to_tent(float sample) {   // Math/Warp.h:13-27
+    float sign;
+    if (sample < 0.5f) { sign = 1; sample *= 2; } else { sign = -1; sample = 2 * (sample - 0.5f); }
+    return sign * (1 - sqrtf(sample));
+}
+// InfiniteLight::internalSampleDirection (SceneTypes/Light.cu:420-463)
+__device__ void env_sample_direction(const dev_scene& S, const ctl_light& L, f2 sample, f3& d, f3& value, float& pdf) {
+    const ctl_mipmap& map = S.images[L.env_image];
+    const float* cdfRows = (const float*)(S.anim + L.cdf_rows_index), *cdfCols = (const float*)(S.anim + L.cdf_cols_index), *rowWeights = (const float*)(S.anim + L.row_weights_index);
+    const float sizeX = (float)map.width, sizeY = (float)map.height;
+    float qpdf;
+    const uint32_t row = sample_reuse(cdfRows, (uint32_t)sizeY, sample.y, qpdf);
+    const uint32_t col = sample_reuse(cdfCols + row * (uint32_t)(sizeX + 1), (uint32_t)sizeX, sample.x, qpdf);
+    const f2 pos{ (float)col + interval_to_tent(sample.x), (float)row + interval_to_tent(sample.y) };
+    const int xPos = clampi((int)floorf(pos.x), 0, (int)(sizeX - 1)), yPos = clampi((int)floorf(pos.y), 0, (int)(sizeY - 1));
+    const float dx1 = pos.x - xPos, dx2 = 1.0f - dx1, dy1 = pos.y - yPos, dy2 = 1.0f - dy1;
+    const f3 value1 = mip_fetch(map, xPos, yPos) * dx2 * dy2 + mip_fetch(map, xPos + 1, yPos) * dx1 * dy2;
+    const f3 value2 = mip_fetch(map, xPos, yPos + 1) * dx2 * dy1 + mip_fetch(map, xPos + 1, yPos + 1) * dx1 * dy1;
+    value = (value1 + value2) * f3(L.env_scale[0], L.env_scale[1], L.env_scale[2]);
+    pdf = (luminance(value1) * rowWeights[(int)clampf((float)yPos, 0.0f, sizeY - 1.0f)] +
+           luminance(value2) * rowWeights[(int)clampf((float)(yPos + 1), 0.0f, sizeY - 1.0f)]) * L.normalization;
+    const float pixX = 2 * kPi / sizeX, pixY = kPi / sizeY;
+    const float sinPhi = sinf(pixX * (pos.x + 0.5f)), cosPhi = cosf(pixX * (pos.x + 0.5f));
+    const float sinTheta = sinf(pixY * (pos.y + 0.5f)), cosTheta = cosf(pixY * (pos.y + 0.5f));
+    d = f3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
+    pdf /= fmaxf(fabsf(sinTheta), 0.000001f);
+}
+__device__ __forceinline__ f3 xform_dir_transpose(const float* m, f3 d) {   // OrthogonalAffineMap::TransformDirectionTranspose (float4x4.h:424-427)
+    return f3(dot(d, f3(m[0], m[4], m[8])), dot(d, f3(m[1], m[5], m[9])), dot(d, f3(m[2], m[6], m[10])));
+}
+// InfiniteLight::internalPdfDirection (SceneTypes/Light.cu:465-486)
+__device__ float env_pdf_direction(const dev_scene& S, const ctl_light& L, f3 d) {
+    const ctl_mipmap& map = S.images[L.env_image];
+    const float* rowWeights = (const float*)(S.anim + L.row_weights_index);
+    const float sizeX = (float)map.width, sizeY = (float)map.height;
+    const f2 uv{ atan2f(d.x, -d.z) * kInvTwoPi, acosf(fminf(1.0f, fmaxf(-1.0f, d.y))) * kInvPi };
+    const float u = uv.x * sizeX - 0.5f, v = uv.y * sizeY - 0.5f;
+    const int xPos = (int)floorf(u), yPos = (int)floorf(v);
+    const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+    const f3 value1 = mip_fetch(map, xPos, yPos) * dx2 * dy2 + mip_fetch(map, xPos + 1, yPos) * dx1 * dy2;
+    const f3 value2 = mip_fetch(map, xPos, yPos + 1) * dx2 * dy1 + mip_fetch(map, xPos + 1, yPos + 1) * dx1 * dy1;
+    const float sinTheta = sqrtf(fmaxf(0.0f, 1 - d.y * d.y));
+    return (luminance(value1) * rowWeights[clampi(yPos, 0, (int)sizeY - 1)] + luminance(value2) * rowWeights[clampi(yPos + 1, 0, (int)sizeY - 1)])
+        * L.normalization / fmaxf(fabsf(sinTheta), 0.000001f);
+}
+// InfiniteLight::evalEnvironment (SceneTypes/Light.cu:488-501)
+__device__ f3 env_eval(const dev_scene& S, const ctl_light& L, f3 dir) {
+    const f3 v = xform_dir_transpose(L.to_world, dir);
+    const f2 uv{ atan2f(v.x, -v.z) * kInvTwoPi, acosf(fminf(1.0f, fmaxf(-1.0f, v.y))) * kInvPi };
+    return mip_triangle(S.images[L.env_image], uv) * f3(L.env_scale[0], L.env_scale[1], L.env_scale[2]);
+}
+// InfiniteLight::pdfDirect, solid-angle measure (SceneTypes/Light.cu:368-378)
+__device__ __forceinline__ float env_pdf_direct(const dev_scene& S, const ctl_light& L, f3 d) { return env_pdf_direction(S, L, xform_dir_transpose(L.to_world, d)); }
+// DiffuseLight / PointLight / SpotLight / DistantLight / InfiniteLight ::sampleDirect (SceneTypes/Light.cu:83-137, 13-31, 287-301, 224-245, 350-366)
+// with ShapeSet::SamplePosition (Engine/ShapeSet.cu:51-69)
 __device__ f3 light_sample_direct(const dev_scene& S, const ctl_light& L, direct_rec& r, f2 smp) {
     if (L.type == CTL_LIGHT_POINT) {
         r.p = f3(L.position[0], L.position[1], L.position[2]);
@@ -311,6 +426,36 @@ __device__ f3 light_sample_direct(const dev_scene& S, const ctl_light& L, direct
         const float invDist = 1.0f / r.dist;
         r.d = dir * invDist; r.n = f3(0.0f); r.pdf = 1; r.measure = kMeasureDiscrete;
         return f3(L.radiance[0], L.radiance[1], L.radiance[2]) * (invDist * invDist);
+    }
+    if (L.type == CTL_LIGHT_SPOT) {   // Light.cu:287-301
+        r.p = f3(L.position[0], L.position[1], L.position[2]);
+        const f3 dir = r.p - r.ref;
+        r.dist = length(dir);
+        const float invDist = 1.0f / r.dist;
+        r.d = dir * invDist; r.n = f3(0.0f); r.pdf = 1; r.measure = kMeasureDiscrete;
+        return f3(L.radiance[0], L.radiance[1], L.radiance[2]) * spot_falloff(L, light_frame(L).to_local(-r.d)) * (invDist * invDist);
+    }
+    if (L.type == CTL_LIGHT_DISTANT) {   // Light.cu:224-245
+        const f3 d = light_frame(L).to_world(f3(0.0f, 0.0f, 1.0f));
+        const f3 diskCenter = d * L.bsphere_radius;
+        const float distance = dot(r.ref - diskCenter, d);
+        if (distance < 0) { r.pdf = 0.0f; return f3(0.0f); }
+        r.p = r.ref - distance * d; r.d = -d; r.n = d; r.dist = distance; r.pdf = 1.0f; r.measure = kMeasureDiscrete;
+        return f3(L.radiance[0], L.radiance[1], L.radiance[2]);
+    }
+    if (L.type == CTL_LIGHT_INFINITE) {   // Light.cu:350-366
+        f3 value, d; float pdf;
+        env_sample_direction(S, L, smp, d, value, pdf);
+        d = f3(L.to_world[0] * d.x + L.to_world[1] * d.y + L.to_world[2] * d.z + L.to_world[3] * 0.0f,
+               L.to_world[4] * d.x + L.to_world[5] * d.y + L.to_world[6] * d.z + L.to_world[7] * 0.0f,
+               L.to_world[8] * d.x + L.to_world[9] * d.y + L.to_world[10] * d.z + L.to_world[11] * 0.0f);
+        r.pdf = pdf;
+        r.p = f3(L.bsphere_center[0], L.bsphere_center[1], L.bsphere_center[2]) + d * L.bsphere_radius;
+        r.n = -normalize(d);
+        r.dist = L.bsphere_radius;
+        r.d = normalize(d);
+        r.measure = kMeasureSolidAngle;
+        return value / pdf;
     }
     const float* cdf = (const float*)(S.anim + L.area_dist_index);
     const ctl_shape_tri* tris = (const ctl_shape_tri*)(S.anim + L.triangles_index);

@@ -20,7 +20,8 @@ void require_device() { if (device_count() <= 0) throw hip_error("no HIP device:
 Scene::Scene(const ctl_scene_desc& d, bool flatten) {
     require_device();
     if (!d.n_nodes) throw std::runtime_error("ctl_scene_create: scene has no nodes");
-    if (d.env_map_index != 0xffffffffu) throw std::runtime_error("ctl_scene_create: environment emitters are not supported yet");
+    if (d.env_map_index != 0xffffffffu && (d.env_map_index >= d.n_lights_buf || d.lights[d.env_map_index].type != CTL_LIGHT_INFINITE))
+        throw std::runtime_error("ctl_scene_create: env_map_index does not name an InfiniteLight");
     n_nodes = d.n_nodes;
     std::vector<float4> tmp;
     // scene BVH and mesh BVHs keep the reference's 64-B node (one aligned 64-B fetch group per visit)
@@ -69,7 +70,35 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
     mats_.upload(d.materials, d.n_materials);
     if (d.n_lights_buf) lights_.upload(d.lights, d.n_lights_buf); else lights_.alloc(1);
     if (d.n_anim_bytes) anim_.upload(d.anim, d.n_anim_bytes); else anim_.alloc(16);
+    // KernelMIPMap level 0 of every image: one texel pool + a table of descriptors with device pointers
+    {
+        size_t total = 0;
+        for (uint32_t i = 0; i < d.n_images; i++) total += (size_t)d.images[i].width * d.images[i].height;
+        std::vector<uint32_t> pool; pool.reserve(total);
+        std::vector<size_t> off(d.n_images);
+        for (uint32_t i = 0; i < d.n_images; i++) {
+            const ctl_mipmap& m = d.images[i];
+            if (!m.texels || !m.width || !m.height) throw std::runtime_error("ctl_scene_create: empty image");
+            off[i] = pool.size(); pool.insert(pool.end(), m.texels, m.texels + (size_t)m.width * m.height);
+        }
+        if (total) texels_.upload(pool.data(), pool.size()); else texels_.alloc(4);
+        std::vector<ctl_mipmap> tab(d.n_images);
+        for (uint32_t i = 0; i < d.n_images; i++) { tab[i] = d.images[i]; tab[i].texels = texels_.p + off[i]; }
+        if (d.n_images) images_.upload(tab.data(), tab.size()); else images_.alloc(1);
+        S.images = images_.p;
+    }
+    for (uint32_t i = 0; i < d.n_lights_buf; i++) {
+        const ctl_light& L = d.lights[i];
+        if (L.type < CTL_LIGHT_POINT || L.type > CTL_LIGHT_INFINITE) throw std::runtime_error("ctl_scene_create: unknown light type " + std::to_string(L.type));
+        if (L.type == CTL_LIGHT_DIFFUSE && L.orthogonal) throw std::runtime_error("ctl_scene_create: orthogonal area lights have no HIP implementation yet");
+        if (L.type == CTL_LIGHT_INFINITE && L.env_image >= d.n_images) throw std::runtime_error("ctl_scene_create: InfiniteLight references a missing image");
+    }
     for (uint32_t i = 0; i < d.n_materials; i++) {
+        for (int k = 0; k < 4; k++) {
+            const ctl_texture& t = d.materials[i].tex[k];
+            if (t.type == CTL_TEX_IMAGE && t.image != 0xffffffffu && t.image >= d.n_images) throw std::runtime_error("ctl_scene_create: texture references a missing image");
+            if (t.type != CTL_TEX_CONSTANT && t.type != CTL_TEX_CHECKER && t.type != CTL_TEX_IMAGE && t.type != 0) throw std::runtime_error("ctl_scene_create: texture type " + std::to_string(t.type) + " has no HIP implementation yet");
+        }
         const uint32_t t = d.materials[i].bsdf_type;
         const bool ok = t == CTL_BSDF_DIFFUSE || t == CTL_BSDF_DIELECTRIC || t == CTL_BSDF_THINDIELECTRIC || t == CTL_BSDF_ROUGHDIELECTRIC || t == CTL_BSDF_CONDUCTOR ||
                         t == CTL_BSDF_ROUGHCONDUCTOR || t == CTL_BSDF_PLASTIC || t == CTL_BSDF_PHONG;

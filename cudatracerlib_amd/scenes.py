@@ -183,3 +183,61 @@ def synthetic_sm(width=1920, height=1080, n_instances=2000, subdiv=4, seed=42):
     sc.setCamera((0, 5, -68.0), (0, 0, 0), (0, 1, 0), 60.0, width, height)
     sc.UpdateScene()
     return sc
+
+
+def procedural_envmap(w=64, h=32):
+    """lat-long HDR environment: sky gradient, a bright sun lobe and a dim ground, as RGBE texels (h, w) uint32"""
+    y, x = np.meshgrid((np.arange(h) + 0.5) / h, (np.arange(w) + 0.5) / w, indexing="ij")
+    theta, phi = y * np.pi, x * 2 * np.pi
+    d = np.stack([np.sin(phi) * np.sin(theta), np.cos(theta), -np.cos(phi) * np.sin(theta)], -1)
+    sky = np.where(d[..., 1:2] > 0, np.array([0.35, 0.55, 0.9]) * (0.3 + 0.7 * d[..., 1:2]) , np.array([0.12, 0.1, 0.08]))
+    sun_dir = np.array([0.4, 0.75, -0.53]); sun_dir /= np.linalg.norm(sun_dir)
+    c = np.clip((d * sun_dir).sum(-1, keepdims=True), 0, 1)
+    rgb = sky + np.array([40.0, 34.0, 25.0]) * c ** 60
+    return api.float3_to_rgbe(rgb.astype(np.float32))
+
+
+def checker_image(n=16, a=(0.8, 0.8, 0.75), b=(0.15, 0.2, 0.5)):
+    """n x n RGBCOL bitmap with a 4x4 checker and a per-texel gradient (so that bilinear filtering matters)"""
+    y, x = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    m = (((x * 4) // n + (y * 4) // n) % 2)[..., None]
+    g = (0.6 + 0.4 * (x + y)[..., None] / (2 * n - 2))
+    rgb = np.where(m == 0, np.asarray(a), np.asarray(b)) * g
+    return api.float3_to_rgbcol(rgb.astype(np.float32))
+
+
+def env_scene(width=96, height=64, rotate_env=False, point_filter=False, extra_lights=False):
+    """C5-style shading stress in miniature: ground quad with a bitmap texture, glass / rough-glass / metal / plastic spheres
+    and a box, lit by a lat-long environment map (+ optionally a spot, a distant and a point light)."""
+    sc = api.DynamicScene()
+    img = sc.add_image(checker_image(), api.TEXEL_RGBCOL, api.WRAP_REPEAT, api.FILTER_POINT if point_filter else api.FILTER_BILINEAR)
+    P, I, N = _quad([[-12, 0, -12], [-12, 0, 12], [12, 0, 12], [12, 0, -12]], [0, 1, 0])
+    uv = np.array([[0, 0], [0, 3], [3, 3], [3, 0]], np.float32)
+    ground = sc.add_mesh(P, I, normals=N, uvs=uv, materials=[api.diffuse(api.image_texture(img, scale=(0.9, 0.9, 0.9)))])
+    sc.CreateNode(ground)
+    V, F = icosphere(3)
+    mats = [api.dielectric(int_ior=1.5, ext_ior=1.0), api.roughdielectric(alpha=0.12, int_ior=1.5, ext_ior=1.0),
+            api.roughconductor(alpha=0.1), api.plastic(diffuse_reflectance=(0.7, 0.15, 0.1)), api.diffuse((0.6, 0.6, 0.6))]
+    for k, m in enumerate(mats):
+        mesh = sc.add_mesh(V, F, normals=V, materials=[m])
+        r = 1.0 + 0.15 * k
+        xf = np.array([[r, 0, 0, -6.0 + 3.0 * k], [0, r, 0, r + 0.01], [0, 0, r, 0.5 * (k % 2)], [0, 0, 0, 1]], np.float32)
+        sc.CreateNode(mesh, xf)
+    Pb, Ib, Nb = unit_box()
+    box = sc.add_mesh(Pb, Ib, normals=Nb, materials=[api.phong((0.2, 0.5, 0.3), (0.3, 0.3, 0.3), 50.0)])
+    sc.CreateNode(box, np.array([[1.2, 0, 0.5, 1.5], [0, 0.8, 0, 0.8], [-0.5, 0, 1.2, 4.0], [0, 0, 0, 1]], np.float32))
+    env = sc.add_image(procedural_envmap(), api.TEXEL_RGBE, api.WRAP_REPEAT, api.FILTER_BILINEAR)
+    T = None
+    if rotate_env:
+        a = 0.7; c, s = np.cos(a), np.sin(a)
+        T = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], np.float32)
+    sc.setEnvironementMap(env, (1.0, 1.0, 1.0), T)
+    if extra_lights:
+        sc.CreateSpotLight((0, 8, 6), (0, 0, 0), (300, 280, 250), cutoff_angle=25.0, beam_width=15.0)
+        # r = 1 as the Mitsuba loader passes it (ObjectParser.h:530): the reference puts the emitter disk at +1.1 d, so only
+        # points with dot(P, d) > 1.1 receive light (DistantLight::sampleDirect, Light.cu:224-245)
+        sc.CreateDistantLight((-0.3, 0.8, 0.5), (1.5, 1.4, 1.2), scene_radius=1.0)
+        sc.CreatePointLight((5, 3, -4), (40, 50, 60))
+    sc.setCamera((0, 5, 14), (0, 1, 0), (0, 1, 0), 45.0, width, height)
+    sc.UpdateScene()
+    return sc

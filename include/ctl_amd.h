@@ -89,6 +89,21 @@ typedef struct {
     uint32_t image;      /* index into the scene's image table (CTL_TEX_IMAGE)  */
 } ctl_texture;           /* 48 B */
 
+/* CTL_TEX_IMAGE (ImageTexture, SceneTypes/Texture.h:159-183, Texture.cu:6-13): value = m_scale, uv_scale/uv_offset = the
+ * diagonal TextureMapping2D (m11, m22, m13, m23), image = index into ctl_scene_desc::images. */
+
+/* Engine/MIPMap_device.h:11-32,57-69 — level 0 of a KernelMIPMap.  The path samples level 0 only: ImageTexture::Evaluate
+ * without uv partials -> Sample(uv) = Texel(0,uv) / triangle(0,uv) (MIPMap.cu:116-121), InfiniteLight -> Sample(uv, 0) =
+ * triangle(0,uv) and Sample(0,x,y) (MIPMap.cu:139-165). */
+enum { CTL_WRAP_REPEAT = 0, CTL_WRAP_CLAMP = 1, CTL_WRAP_MIRROR = 2, CTL_WRAP_BLACK = 3 };
+enum { CTL_FILTER_POINT = 0, CTL_FILTER_BILINEAR = 1, CTL_FILTER_ANISOTROPIC = 2, CTL_FILTER_TRILINEAR = 3 };
+enum { CTL_TEXEL_RGBE = 0, CTL_TEXEL_RGBCOL = 1 };   /* Texture_DataType; both are uchar4 (Math/Spectrum.h:323-324,528-565) */
+typedef struct {
+    const uint32_t* texels;    /* width*height level-0 texels, row-major, byte 0 = r (x), 1 = g, 2 = b, 3 = e / alpha */
+    uint32_t width, height;
+    uint32_t texel_type, wrap_mode, filter_mode;
+} ctl_mipmap;
+
 /* ids = the reference's TYPE_FUNC ids (BSDF_Simple.h:6-401, BSDF_Complex.h:9-182) */
 enum { CTL_BSDF_DIFFUSE = 1, CTL_BSDF_ROUGHDIFFUSE = 2, CTL_BSDF_DIELECTRIC = 3, CTL_BSDF_THINDIELECTRIC = 4,
        CTL_BSDF_ROUGHDIELECTRIC = 5, CTL_BSDF_CONDUCTOR = 6, CTL_BSDF_ROUGHCONDUCTOR = 7, CTL_BSDF_PLASTIC = 8,
@@ -140,11 +155,16 @@ typedef struct {
     float position[3];
     float direction[3];
     float cutoff_angle, beam_width, cos_cutoff_angle, cos_beam_width, inv_transition_width;
-    float to_world[16];            /* spot / envmap frame                                      */
-    /* InfiniteLight (round 2: image + row/col CDFs live in the image table) */
-    uint32_t env_image;
-    float env_scale[3];
-    float bsphere_center[3], bsphere_radius;
+    float to_world[16];            /* Spot / Distant: Frame ToWorld as rows s = [0..2], t = [4..6], n = [8..10];
+                                      Infinite: m_worldTransform, row-major 4x4                */
+    /* InfiniteLight (SceneTypes/Light.h:293-311, Light.cpp:10-61); the three tables are byte offsets into the anim blob */
+    uint32_t env_image;            /* radianceMap: index into ctl_scene_desc::images           */
+    float env_scale[3];            /* m_scale                                                  */
+    float bsphere_center[3], bsphere_radius;   /* m_SceneCenter, m_SceneRadius; DistantLight::radius */
+    uint32_t cdf_rows_index;       /* float[height + 1]                                        */
+    uint32_t cdf_cols_index;       /* float[height * (width + 1)]                              */
+    uint32_t row_weights_index;    /* float[height]                                            */
+    float normalization;           /* m_normalization                                          */
 } ctl_light;
 
 /* ids = TYPE_FUNC ids of SceneTypes/Sensor.h:107,191,272,364,445 */
@@ -183,6 +203,7 @@ typedef struct {
     uint32_t light_indices[CTL_MAX_NUM_LIGHTS];
     float light_cdf[CTL_MAX_NUM_LIGHTS];
     float ray_trace_eps;                      /* m_rayTraceEps = 1e-4 * |box diagonal| (DynamicScene.cpp:587) */
+    const ctl_mipmap* images;            uint32_t n_images;       /* m_sTexData (level 0) */
 } ctl_scene_desc;
 
 /* ------------------------------------------------------------- scene builder */
@@ -205,6 +226,19 @@ int ctl_builder_add_node(ctl_builder* b, uint32_t mesh_index, const ctl_float4x4
 int ctl_builder_add_area_light(ctl_builder* b, uint32_t node_index, uint32_t local_material, const float radiance[3]);
 /* DynamicScene::CreateLight(Light) for point lights (SceneTypes/Light.h:31-94) */
 int ctl_builder_add_point_light(ctl_builder* b, const float position[3], const float intensity[3]);
+/* SpotLight(p, t, L, width, fall) (SceneTypes/Light.cu:268-277): cutoff/beam angles in degrees as the loader passes them
+ * (cutoffAngle, beamWidth). */
+int ctl_builder_add_spot_light(ctl_builder* b, const float position[3], const float target[3], const float intensity[3],
+                               float cutoff_angle_degrees, float beam_width_degrees);
+/* DistantLight(L, d, r) (SceneTypes/Light.h:155-163): d = ToWorld.n (sampleDirect returns dRec.d = -d); r = radius of the
+ * scene's bounding sphere as the caller sees it (the light stores 1.1 r; the Mitsuba loader passes r = 1, ObjectParser.h:530). */
+int ctl_builder_add_distant_light(ctl_builder* b, const float direction[3], const float irradiance[3], float scene_radius);
+/* MIPMap level 0 handed over decoded (the reference decodes files with FreeImage, Engine/MIPMap.cpp): returns the image index */
+int ctl_builder_add_image(ctl_builder* b, const uint32_t* texels, uint32_t width, uint32_t height, uint32_t texel_type,
+                          uint32_t wrap_mode, uint32_t filter_mode, uint32_t* image_index_out);
+/* DynamicScene::setEnvironementMap(scale, file) (Engine/DynamicScene.cpp:846-859) + InfiniteLight ctor (Light.cpp:10-61):
+ * builds the row / column CDFs; to_world (row-major 4x4, orthogonal) may be NULL = identity. */
+int ctl_builder_set_environment_map(ctl_builder* b, uint32_t image_index, const float scale[3], const ctl_float4x4* to_world);
 /* DynamicScene::setCamera — perspective sensor as built by the Mitsuba loader (ObjectParser.h:292-297): */
 int ctl_builder_set_camera_lookat(ctl_builder* b, const float pos[3], const float target[3], const float up[3],
                                   float fov_degrees, uint32_t width, uint32_t height);

@@ -54,6 +54,10 @@ def load():
     o.orc_bsdf_sample.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
     o.orc_bsdf_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_void_p]
     o.orc_light_sample_direct.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
+    o.orc_light_pdf_direct.restype = f32
+    o.orc_light_pdf_direct.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p]
+    o.orc_env_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    o.orc_texture_eval.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
     o.orc_triangle_data_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_int, C.c_void_p]
     o.orc_triangle_fill_dg.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_int, C.c_void_p]
     o.orc_woop_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]

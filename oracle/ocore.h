@@ -173,6 +173,7 @@ inline bool occluded(const Scene& S, V3 o, V3 d, float tmin, float tmax) {
 // --------------------------------------------------------------------------- TriangleData / fillDG
 struct DG {   // Engine/DifferentialGeometry.h:11-47
     V3 P; Frame sys; V3 n; V3 dpdu, dpdv; V2 uv; V2 bary; uint8_t extraData;
+    const ctl_mipmap* images = nullptr;   // g_SceneData.m_sTexData (ImageTexture::getTexture, Texture.cu:39-42)
 };
 // Engine/TriangleData.cu:22-32 + 34-65
 inline void triDataSetUV(ctl_triangle_data& T, V2 a, V2 b, V2 c) {
@@ -227,16 +228,72 @@ inline void triDataFillDG(const ctl_triangle_data& T, const M44& localToWorld, D
 inline void fillDG(const Scene& S, V2 bary, uint32_t triIdx, uint32_t nodeIdx, DG& dg) {
     M44 l2w; std::memcpy(l2w.d, S.d.node_transforms[nodeIdx].m, 64);
     dg.bary = bary;
+    dg.images = S.d.images;
     triDataFillDG(S.d.tri_data[triIdx], l2w, dg, S.half_host_quirk);
 }
 
-// --------------------------------------------------------------------------- textures (SceneTypes/Texture.h, constant only + checker)
+// --------------------------------------------------------------------------- KernelMIPMap, level 0 (Engine/MIPMap.cu, MIPMap_device.h)
+inline Spec texelDecode(uint32_t v, uint32_t type) {
+    unsigned x = v & 0xff, y = (v >> 8) & 0xff, z = (v >> 16) & 0xff, w = v >> 24;
+    if (type == CTL_TEXEL_RGBE) {   // SpectrumConverter::RGBEToFloat3 (Math/Spectrum.h:557-565)
+        if (w) { float e = ldexpf(1.0f, int(w) - (128 + 8)); return Spec(x * e, y * e, z * e); }
+        return Spec(0.0f);
+    }
+    return Spec(float(x) / 255.0f, float(y) / 255.0f, float(z) / 255.0f);   // COLORREFToFloat3 (:528-532)
+}
+// MIPMap_device.h:34-55 (the MIRROR branch tests the parity of uv.x for both axes, as the reference does)
+inline bool wrapCoordinates(V2 uv, V2 dim, uint32_t w, V2& loc) {
+    switch (w) {
+    case CTL_WRAP_REPEAT: loc = V2{ fracf(uv.x) * dim.x, fracf(1.0f - uv.y) * dim.y }; return true;
+    case CTL_WRAP_CLAMP: loc = V2{ clampf(uv.x, 0.0f, 1.0f) * dim.x, clampf(1.0f - uv.y, 0.0f, 1.0f) * dim.y }; return true;
+    case CTL_WRAP_MIRROR:
+        loc.x = (int)uv.x % 2 == 0 ? fracf(uv.x) : 1.0f - fracf(uv.x);
+        loc.y = (int)uv.x % 2 == 0 ? fracf(uv.y) : 1.0f - fracf(uv.y);
+        loc = V2{ loc.x * dim.x, loc.y * dim.y }; return true;
+    case CTL_WRAP_BLACK:
+        if (uv.x < 0 || uv.x >= 1 || uv.y < 0 || uv.y >= 1) return false;
+        loc = V2{ uv.x * dim.x, uv.y * dim.y }; return true;
+    }
+    return false;
+}
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// KernelMIPMap::Texel(0, uv) (MIPMap.cu:21-44)
+inline Spec mipTexel(const ctl_mipmap& M, V2 uv) {
+    V2 l;
+    if (!wrapCoordinates(uv, V2{ (float)M.width, (float)M.height }, M.wrap_mode, l)) return Spec(0.0f);
+    int x = clampi((int)l.x, 0, (int)M.width - 1), y = clampi((int)l.y, 0, (int)M.height - 1);
+    return texelDecode(M.texels[(size_t)y * M.width + x], M.texel_type);
+}
+// KernelMIPMap::triangle(0, uv) (MIPMap.cu:46-57)
+inline Spec mipTriangle(const ctl_mipmap& M, V2 uv) {
+    V2 s{ (float)M.width, (float)M.height }, is{ 1.0f / s.x, 1.0f / s.y };
+    V2 l{ uv.x * s.x, uv.y * s.y };
+    float ds = fracf(l.x), dt = fracf(l.y);
+    return ((1.f - ds) * (1.f - dt)) * mipTexel(M, uv) +
+           ((1.f - ds) * dt) * mipTexel(M, V2{ uv.x + 0, uv.y + is.y }) +
+           (ds * (1.f - dt)) * mipTexel(M, V2{ uv.x + is.x, uv.y + 0 }) +
+           (ds * dt) * mipTexel(M, V2{ uv.x + is.x, uv.y + is.y });
+}
+// KernelMIPMap::Sample(uv) (MIPMap.cu:116-121)
+inline Spec mipSample(const ctl_mipmap& M, V2 uv) { return M.filter_mode == CTL_FILTER_POINT ? mipTexel(M, uv) : mipTriangle(M, uv); }
+// KernelMIPMap::Sample(0.0f, x, y) (MIPMap.cu:155-172): width 0 -> level 0, clamped direct fetch
+inline Spec mipFetch(const ctl_mipmap& M, int x, int y) {
+    x = clampi(x, 0, (int)M.width - 1); y = clampi(y, 0, (int)M.height - 1);
+    return texelDecode(M.texels[(size_t)y * M.width + x], M.texel_type);
+}
+
+// --------------------------------------------------------------------------- textures (SceneTypes/Texture.h: constant, checkerboard, image)
 inline Spec texEval(const ctl_texture& t, const DG& dg) {
     if (t.type == CTL_TEX_CHECKER) {
         float u = dg.uv.x * t.uv_scale[0] + t.uv_offset[0], v = dg.uv.y * t.uv_scale[1] + t.uv_offset[1];
         auto modulo = [](int a, int b) { int r = a % b; return (r < 0) ? r + b : r; };   // MathFunc.h:120-124
         int x = 2 * modulo((int)(u * 2), 2) - 1, y = 2 * modulo((int)(v * 2), 2) - 1;      // Texture.h:136-146
         return (x * y == 1) ? Spec(t.value[0], t.value[1], t.value[2]) : Spec(t.value1[0], t.value1[1], t.value1[2]);
+    }
+    if (t.type == CTL_TEX_IMAGE) {   // ImageTexture::Evaluate(dg) without uv partials -> Evaluate(uv) (Texture.cu:6-29)
+        if (t.image == 0xffffffffu || dg.images == nullptr) return Spec(0.0f);
+        V2 uv{ t.uv_scale[0] * dg.uv.x + 0 * dg.uv.y + t.uv_offset[0], 0 * dg.uv.x + t.uv_scale[1] * dg.uv.y + t.uv_offset[1] };   // TextureMapping2D::TransformPoint (Texture.h:34-41)
+        return mipSample(dg.images[t.image], uv) * Spec(t.value[0], t.value[1], t.value[2]);
     }
     return Spec(t.value[0], t.value[1], t.value[2]);
 }
@@ -316,7 +373,70 @@ inline void shapeSamplePosition(const Scene& S, const ctl_light& L, DirectRec& p
     pRec.measure = EArea;
     pRec.uv = bary;
 }
-// SceneTypes/Light.cu:83-137 (m_bOrthogonal == false branch) and :13-31 (point)
+inline Frame lightFrame(const ctl_light& L) {   // Spot / Distant `Frame ToWorld`
+    return Frame(V3(L.to_world[0], L.to_world[1], L.to_world[2]), V3(L.to_world[4], L.to_world[5], L.to_world[6]), V3(L.to_world[8], L.to_world[9], L.to_world[10]));
+}
+// SpotLight::falloffCurve (SceneTypes/Light.cu:327-336)
+inline Spec spotFalloff(const ctl_light& L, V3 d) {
+    const float cosTheta = Frame::cosTheta(d);
+    if (cosTheta <= L.cos_cutoff_angle) return Spec(0.0f);
+    if (cosTheta >= L.cos_beam_width) return Spec(1.0f);
+    return Spec((L.cutoff_angle - acosf(cosTheta)) * L.inv_transition_width);
+}
+inline float luminance(Spec s) { return s.x * 0.212671f + s.y * 0.715160f + s.z * 0.072169f; }   // Spectrum.cu:174-177
+inline float intervalToTent(float sample) {   // Math/Warp.h:13-27
+    float sign;
+    if (sample < 0.5f) { sign = 1; sample *= 2; } else { sign = -1; sample = 2 * (sample - 0.5f); }
+    return sign * (1 - std::sqrt(sample));
+}
+inline unsigned sampleReuse(const float* cdf, unsigned size, float& sample, float& pdf);
+// InfiniteLight::internalSampleDirection (SceneTypes/Light.cu:420-463)
+inline void envSampleDirection(const Scene& S, const ctl_light& L, V2 sample, V3& d, Spec& value, float& pdf) {
+    const ctl_mipmap& map = S.d.images[L.env_image];
+    const float* cdfRows = (const float*)(S.d.anim + L.cdf_rows_index), *cdfCols = (const float*)(S.d.anim + L.cdf_cols_index), *rowWeights = (const float*)(S.d.anim + L.row_weights_index);
+    const float sizeX = (float)map.width, sizeY = (float)map.height;
+    float qpdf;
+    unsigned row = sampleReuse(cdfRows, (unsigned)sizeY, sample.y, qpdf),
+             col = sampleReuse(cdfCols + row * (unsigned)(sizeX + 1), (unsigned)sizeX, sample.x, qpdf);
+    V2 pos{ (float)col + intervalToTent(sample.x), (float)row + intervalToTent(sample.y) };
+    int xPos = clampi(floor2int(pos.x), 0, (int)(sizeX - 1)), yPos = clampi(floor2int(pos.y), 0, (int)(sizeY - 1));
+    float dx1 = pos.x - xPos, dx2 = 1.0f - dx1, dy1 = pos.y - yPos, dy2 = 1.0f - dy1;
+    Spec value1 = mipFetch(map, xPos, yPos) * dx2 * dy2 + mipFetch(map, xPos + 1, yPos) * dx1 * dy2;
+    Spec value2 = mipFetch(map, xPos, yPos + 1) * dx2 * dy1 + mipFetch(map, xPos + 1, yPos + 1) * dx1 * dy1;
+    value = (value1 + value2) * Spec(L.env_scale[0], L.env_scale[1], L.env_scale[2]);
+    pdf = (luminance(value1) * rowWeights[(int)clampf((float)yPos, 0.0f, sizeY - 1.0f)] +
+           luminance(value2) * rowWeights[(int)clampf((float)(yPos + 1), 0.0f, sizeY - 1.0f)]) * L.normalization;
+    const float pixX = 2 * PI / sizeX, pixY = PI / sizeY;   // m_pixelSize (Light.cpp:54)
+    float sinPhi = sinf(pixX * (pos.x + 0.5f)), cosPhi = cosf(pixX * (pos.x + 0.5f));
+    float sinTheta = sinf(pixY * (pos.y + 0.5f)), cosTheta = cosf(pixY * (pos.y + 0.5f));
+    d = V3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
+    pdf /= fmax2(fabsf(sinTheta), EPSILON);
+}
+inline V3 transformDirTranspose(const float* m, V3 d) {   // OrthogonalAffineMap::TransformDirectionTranspose (float4x4.h:424-427)
+    return V3(dot(d, V3(m[0], m[4], m[8])), dot(d, V3(m[1], m[5], m[9])), dot(d, V3(m[2], m[6], m[10])));
+}
+// InfiniteLight::internalPdfDirection (SceneTypes/Light.cu:465-486)
+inline float envPdfDirection(const Scene& S, const ctl_light& L, V3 d) {
+    const ctl_mipmap& map = S.d.images[L.env_image];
+    const float* rowWeights = (const float*)(S.d.anim + L.row_weights_index);
+    const float sizeX = (float)map.width, sizeY = (float)map.height;
+    V2 uv{ atan2f(d.x, -d.z) * INV_TWOPI, safe_acos(d.y) * INV_PI };
+    float u = uv.x * sizeX - 0.5f, v = uv.y * sizeY - 0.5f;
+    int xPos = floor2int(u), yPos = floor2int(v);
+    float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+    Spec value1 = mipFetch(map, xPos, yPos) * dx2 * dy2 + mipFetch(map, xPos + 1, yPos) * dx1 * dy2;
+    Spec value2 = mipFetch(map, xPos, yPos + 1) * dx2 * dy1 + mipFetch(map, xPos + 1, yPos + 1) * dx1 * dy1;
+    float sinTheta = safe_sqrt(1 - d.y * d.y);
+    return (luminance(value1) * rowWeights[clampi(yPos, 0, (int)sizeY - 1)] + luminance(value2) * rowWeights[clampi(yPos + 1, 0, (int)sizeY - 1)])
+        * L.normalization / fmax2(fabsf(sinTheta), EPSILON);
+}
+// InfiniteLight::evalEnvironment(ray) (SceneTypes/Light.cu:488-501): Sample(uv, 0) = triangle(0, uv)
+inline Spec envEval(const Scene& S, const ctl_light& L, V3 dir) {
+    V3 v = transformDirTranspose(L.to_world, dir);
+    V2 uv{ atan2f(v.x, -v.z) * INV_TWOPI, safe_acos(v.y) * INV_PI };
+    return mipTriangle(S.d.images[L.env_image], uv) * Spec(L.env_scale[0], L.env_scale[1], L.env_scale[2]);
+}
+// SceneTypes/Light.cu:83-137 (m_bOrthogonal == false branch), :13-31 (point), :287-301 (spot), :224-245 (distant), :350-366 (infinite)
 inline Spec lightSampleDirect(const Scene& S, const ctl_light& L, DirectRec& dRec, V2 sample) {
     if (L.type == CTL_LIGHT_POINT) {
         dRec.p = V3(L.position[0], L.position[1], L.position[2]);
@@ -325,6 +445,36 @@ inline Spec lightSampleDirect(const Scene& S, const ctl_light& L, DirectRec& dRe
         float invDist = 1.0f / dRec.dist;
         dRec.d = dir * invDist; dRec.n = V3(0.0f); dRec.pdf = 1; dRec.measure = EDiscrete; dRec.uv = V2{ 0.5f, 0.5f };
         return Spec(L.radiance[0], L.radiance[1], L.radiance[2]) * (invDist * invDist);
+    }
+    if (L.type == CTL_LIGHT_SPOT) {   // SceneTypes/Light.cu:287-301
+        dRec.p = V3(L.position[0], L.position[1], L.position[2]);
+        V3 dir = dRec.p - dRec.ref;
+        dRec.dist = length(dir);
+        float invDist = 1.0f / dRec.dist;
+        dRec.d = dir * invDist; dRec.n = V3(0.0f); dRec.pdf = 1; dRec.measure = EDiscrete; dRec.uv = V2{ 0.5f, 0.5f };
+        return Spec(L.radiance[0], L.radiance[1], L.radiance[2]) * spotFalloff(L, lightFrame(L).toLocal(-dRec.d)) * (invDist * invDist);
+    }
+    if (L.type == CTL_LIGHT_DISTANT) {   // SceneTypes/Light.cu:224-245
+        V3 d = lightFrame(L).toWorld(V3(0.0f, 0.0f, 1.0f));
+        V3 diskCenter = d * L.bsphere_radius;
+        float distance = dot(dRec.ref - diskCenter, d);
+        if (distance < 0) return Spec(0.0f);
+        dRec.p = dRec.ref - distance * d; dRec.d = -d; dRec.n = d; dRec.dist = distance;
+        dRec.pdf = 1.0f; dRec.measure = EDiscrete;
+        return Spec(L.radiance[0], L.radiance[1], L.radiance[2]);
+    }
+    if (L.type == CTL_LIGHT_INFINITE) {   // SceneTypes/Light.cu:350-366
+        Spec value; V3 d; float pdf;
+        envSampleDirection(S, L, sample, d, value, pdf);
+        M44 wt; std::memcpy(wt.d, L.to_world, 64);
+        d = transformDir(wt, d);
+        dRec.pdf = pdf;
+        dRec.p = V3(L.bsphere_center[0], L.bsphere_center[1], L.bsphere_center[2]) + d * L.bsphere_radius;
+        dRec.n = -normalize(d);
+        dRec.dist = L.bsphere_radius;
+        dRec.d = normalize(d);
+        dRec.measure = ESolidAngle;
+        return value / pdf;
     }
     shapeSamplePosition(S, L, dRec, sample);
     V3 dir = dRec.p - dRec.ref;
@@ -340,8 +490,14 @@ inline Spec lightSampleDirect(const Scene& S, const ctl_light& L, DirectRec& dRe
     return Spec(0.0f);
 }
 // SceneTypes/Light.cu:139-159
-inline float lightPdfDirect(const ctl_light& L, const DirectRec& dRec) {
-    if (L.type == CTL_LIGHT_POINT) return dRec.measure == EDiscrete ? 1.0f : 0.0f;
+inline float lightPdfDirect(const Scene& S, const ctl_light& L, const DirectRec& dRec) {
+    if (L.type == CTL_LIGHT_POINT || L.type == CTL_LIGHT_SPOT || L.type == CTL_LIGHT_DISTANT) return dRec.measure == EDiscrete ? 1.0f : 0.0f;
+    if (L.type == CTL_LIGHT_INFINITE) {   // SceneTypes/Light.cu:368-378
+        float pdfSA = envPdfDirection(S, L, transformDirTranspose(L.to_world, dRec.d));
+        if (dRec.measure == ESolidAngle) return pdfSA;
+        else if (dRec.measure == EArea) return pdfSA * absdot(dRec.d, dRec.n) / (dRec.dist * dRec.dist);
+        else return 0.0f;
+    }
     if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
         float pdfPos = 1.0f / L.sum_area;
         if (dRec.measure == ESolidAngle) return pdfPos * (dRec.dist * dRec.dist) / absdot(dRec.d, dRec.n);
@@ -693,7 +849,7 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
                     DirectRec dRec(ro, last_nor);   // DirectSamplingRecFromRay (TraceAlgorithms.cu:33-42)
                     dRec.p = bRec.dg.P; dRec.n = bRec.dg.n; dRec.d = rd; dRec.dist = r2.dist; dRec.measure = ESolidAngle;
                     const ctl_light* light = S.d.lights + li;
-                    float direct_pdf = lightPdfDirect(*light, dRec) * pdfEmitter(S, light);
+                    float direct_pdf = lightPdfDirect(S, *light, dRec) * pdfEmitter(S, light);
                     misWeight = powerHeuristic(1, brdf_scattering_pdf, 1, direct_pdf);
                 }
                 cl = cl + misWeight * cf * lightEval(S.d.lights[li], bRec.dg.sys, -rd);
@@ -711,7 +867,18 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
             cf = cf / vmax(cf);
         }
     }
-    // miss: no environment map support in this round's descriptor set -> EvalEnvironment == 0 (KernelDynamicScene.cu:48-55)
+    if (!r2.hasHit() && S.d.env_map_index != 0xffffffffu) {   // PathTracer.cu:99-111; EvalEnvironment == 0 without an environment map
+        const ctl_light* light = S.d.lights + S.d.env_map_index;
+        float misWeight = 1.0f;
+        if (!DIRECT || depth == 1 || specularBounce) misWeight = 1.0f;
+        else {
+            DirectRec dRec(ro, last_nor);   // DirectSamplingRecFromRay(r, dist, last_nor, Vec3f(), NormalizedT<Vec3f>()), measure ESolidAngle
+            dRec.p = V3(0.0f); dRec.n = V3(0.0f); dRec.d = rd; dRec.dist = r2.dist; dRec.measure = ESolidAngle;
+            float direct_pdf = lightPdfDirect(S, *light, dRec) * pdfEmitter(S, light);
+            misWeight = powerHeuristic(1, brdf_scattering_pdf, 1, direct_pdf);
+        }
+        cl = cl + misWeight * cf * envEval(S, *light, rd);
+    }
     return cl;
 }
 

@@ -131,6 +131,26 @@ void orc_light_sample_direct(const ctl_scene_desc* desc, uint32_t light, const f
     out[8] = d.p.x; out[9] = d.p.y; out[10] = d.p.z; out[11] = d.n.x; out[12] = d.n.y; out[13] = d.n.z;
 }
 
+// Light::pdfDirect for a direction d seen from ref (solid-angle measure); p / n / dist describe the emitter point (area lights)
+float orc_light_pdf_direct(const ctl_scene_desc* desc, uint32_t light, const float* ref, const float* refN, const float* d, float dist, const float* n) {
+    Scene S; S.d = *desc;
+    DirectRec r(V3(ref[0], ref[1], ref[2]), V3(refN[0], refN[1], refN[2]));
+    r.d = V3(d[0], d[1], d[2]); r.dist = dist; r.n = V3(n[0], n[1], n[2]); r.measure = ESolidAngle;
+    return lightPdfDirect(S, desc->lights[light], r);
+}
+// InfiniteLight::evalEnvironment for a world direction
+void orc_env_eval(const ctl_scene_desc* desc, const float* dir, float* out) {
+    Scene S; S.d = *desc;
+    Spec v(0.0f);
+    if (desc->env_map_index != 0xffffffffu) v = envEval(S, desc->lights[desc->env_map_index], V3(dir[0], dir[1], dir[2]));
+    out[0] = v.x; out[1] = v.y; out[2] = v.z;
+}
+// ImageTexture / checkerboard / constant evaluation at a uv (Texture::Evaluate(dg))
+void orc_texture_eval(const ctl_scene_desc* desc, const ctl_texture* t, float u, float v, float* out) {
+    DG dg; dg.uv = V2{ u, v }; dg.images = desc ? desc->images : nullptr;
+    Spec s = texEval(*t, dg); out[0] = s.x; out[1] = s.y; out[2] = s.z;
+}
+
 // ---- full render: pathKernel2<DIRECT,false> looped over all pixels (Integrators/PathTracer.cu:182-194) ---------
 // tables: n_passes consecutive (t1[30*4096], t2[30*4096*2]) pairs, or NULL -> own SequenceGenerator
 // (one Compute() per pass, as Tracer<true>::DoPass -> UpdateKernel does, Kernel/Tracer.h:229).

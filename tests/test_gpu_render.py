@@ -67,6 +67,21 @@ def test_cornell_plastic_roughdielectric_phong_thindielectric(gpu, orc, variant)
     assert_close(got, want)
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(rotate_env=True, point_filter=True), dict(extra_lights=True)])
+def test_environment_map_bitmap_texture_and_delta_lights(gpu, orc, kw):
+    """InfiniteLight NEE + miss MIS, ImageTexture (bilinear / point), spot + distant + point lights, 6 BSDF types in one frame"""
+    sc = scenes.env_scene(96, 64, **kw)
+    got, want, tr, rays = render_pair(gpu, orc, sc, 96, 64, 3)
+    assert_close(got, want)
+    assert want[..., :3].mean() > 0.1
+
+
+def test_environment_map_without_nee(gpu, orc):
+    sc = scenes.env_scene(64, 48)
+    got, want, _, _ = render_pair(gpu, orc, sc, 64, 48, 2, max_len=4, rr=2, direct=False)
+    assert_close(got, want)
+
+
 def test_no_direct_and_short_paths(gpu, orc):
     sc = scenes.cornell_box(48, 48)
     got, want, _, _ = render_pair(gpu, orc, sc, 48, 48, 2, max_len=3, rr=1, direct=False)
