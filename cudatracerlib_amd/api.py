@@ -49,6 +49,11 @@ class ctl_mipmap(C.Structure):
     _fields_ = [("texels", C.c_void_p), ("width", u32), ("height", u32), ("texel_type", u32), ("wrap_mode", u32), ("filter_mode", u32)]
 
 
+class ctl_rough_transmittance(C.Structure):
+    _fields_ = [("trans", C.c_void_p), ("diff_trans", C.c_void_p), ("eta_samples", u32), ("alpha_samples", u32), ("theta_samples", u32),
+                ("eta_min", f32), ("eta_max", f32), ("alpha_min", f32), ("alpha_max", f32)]
+
+
 class ctl_sensor(C.Structure):
     _fields_ = [("type", u32), ("to_world", f32 * 16), ("fov", f32), ("near_depth", f32), ("far_depth", f32), ("resolution", f32 * 2),
                 ("aperture_radius", f32), ("focus_distance", f32)]
@@ -89,7 +94,7 @@ class ctl_scene_desc(C.Structure):
                 ("node_transforms", C.c_void_p), ("node_inv_transforms", C.c_void_p), ("env_map_index", u32),
                 ("box_min", f32 * 3), ("box_max", f32 * 3), ("camera", ctl_sensor), ("num_lights", u32),
                 ("light_indices", u32 * MAX_NUM_LIGHTS), ("light_cdf", f32 * MAX_NUM_LIGHTS), ("ray_trace_eps", f32),
-                ("images", C.POINTER(ctl_mipmap)), ("n_images", u32)]
+                ("images", C.POINTER(ctl_mipmap)), ("n_images", u32), ("rough_transmittance", C.POINTER(ctl_rough_transmittance))]
 
     # numpy views of the reference-layout arrays (host memory owned by the builder)
     def view(self, name, dtype, count, width):
@@ -305,6 +310,39 @@ def phong(diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(0.2, 0.2, 0
     return m
 
 
+def _lum(t):
+    return t.value[0] * 0.212671 + t.value[1] * 0.715160 + t.value[2] * 0.072169   # Spectrum::getLuminance of a constant texture's Average()
+
+
+def roughdiffuse(reflectance=(0.5, 0.5, 0.5), alpha=0.2, use_fast_approx=False):
+    """roughdiffuse(reflectance, alpha) — BSDF_Simple.h:26-60 (Oren-Nayar)."""
+    m = _material(2, E["DiffuseReflection"])
+    m.tex[0], m.tex[1] = _as_tex(reflectance), _as_tex(alpha)
+    m.u[0] = 1 if use_fast_approx else 0
+    return m
+
+
+def ward(diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(0.2, 0.2, 0.2), alpha_u=0.1, alpha_v=0.1, variant=2):
+    """ward(variant, diffuse, specular, alphaU, alphaV) — BSDF_Simple.h:342-381; variant 0 Ward, 1 Ward-Duer, 2 balanced."""
+    m = _material(11, E["GlossyReflection"] | E["DiffuseReflection"])
+    m.tex[0], m.tex[1], m.tex[2], m.tex[3] = _as_tex(diffuse_reflectance), _as_tex(specular_reflectance), _as_tex(alpha_u), _as_tex(alpha_v)
+    d_avg, s_avg = _lum(m.tex[0]), _lum(m.tex[1])
+    m.f[0] = s_avg / (d_avg + s_avg)
+    m.u[0] = variant
+    return m
+
+
+def roughplastic(diffuse_reflectance=(0.5, 0.5, 0.5), alpha=0.1, int_ior=1.49, ext_ior=1.000277, distribution=0, specular_reflectance=1.0, nonlinear=False, sample_visible=True):
+    """roughplastic(type, eta, alpha, diffuse, specular) — BSDF_Simple.h:272-312; needs the rough-transmittance table of slot `distribution`."""
+    m = _material(9, E["GlossyReflection"] | E["DiffuseReflection"])
+    m.tex[0], m.tex[1], m.tex[2] = _as_tex(diffuse_reflectance), _as_tex(specular_reflectance), _as_tex(alpha)
+    eta = float(np.float32(np.float32(int_ior) / np.float32(ext_ior)))
+    d_avg, s_avg = _lum(m.tex[0]), _lum(m.tex[1])
+    m.f[0], m.f[1], m.f[2] = eta, 1.0 / (eta * eta), s_avg / (d_avg + s_avg)
+    m.u[0], m.u[1], m.u[2] = 1 if nonlinear else 0, 0 if distribution == 2 else (1 if sample_visible else 0), distribution   # getSampleVisible(type, true)
+    return m
+
+
 # ---------------------------------------------------------------- DynamicScene (Engine/DynamicScene.h:70-187, loader-facing subset)
 class DynamicScene:
     def __init__(self):
@@ -369,6 +407,19 @@ class DynamicScene:
         idx = u32()
         _check(lib.ctl_builder_add_image(self._h, t.ctypes.data_as(C.c_void_p), u32(t.shape[1]), u32(t.shape[0]), u32(texel_type), u32(wrap), u32(filter), C.byref(idx)))
         return idx.value
+
+    def setRoughTransmittance(self, slot, trans, diff_trans, eta_range, alpha_range):
+        """RoughTransmittanceManager slot (0 beckmann.dat, 1 phong.dat, 2 ggx.dat — indexed by the distribution TYPE at run time,
+        RoughTransmittance.cu:124-157).  trans: (2*eta, alpha, theta) float32, diff_trans: (2*eta, alpha)."""
+        t = np.ascontiguousarray(trans, np.float32); dt = np.ascontiguousarray(diff_trans, np.float32)
+        r = ctl_rough_transmittance()
+        r.trans, r.diff_trans = t.ctypes.data, dt.ctypes.data
+        r.eta_samples, r.alpha_samples, r.theta_samples = t.shape[0] // 2, t.shape[1], t.shape[2]
+        r.eta_min, r.eta_max, r.alpha_min, r.alpha_max = eta_range[0], eta_range[1], alpha_range[0], alpha_range[1]
+        _check(lib.ctl_builder_set_rough_transmittance(self._h, u32(slot), C.byref(r)))
+
+    def loadRoughTransmittance(self, slot, path):
+        _check(lib.ctl_builder_load_rough_transmittance(self._h, u32(slot), path.encode()))
 
     def setEnvironementMap(self, image, scale=(1.0, 1.0, 1.0), to_world=None):
         """DynamicScene::setEnvironementMap (DynamicScene.cpp:846-859) for an already decoded lat-long image."""

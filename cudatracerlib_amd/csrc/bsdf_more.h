@@ -1,6 +1,7 @@
 // bsdf_more.h — thindielectric, roughdielectric, plastic, phong for the shade kernel (included by shading.h).
 // Behaviour per function: SceneTypes/BSDF_Simple.cu lines cited at each case.
 #pragma once
+#include "bsdf_rough.h"
 
 namespace ctl {
 
@@ -128,7 +129,7 @@ __device__ f3 bsdf_more_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f
         if (pdf == 0) return f3(0.0f);
         return phong_f(M, b) / pdf;
     }
-    default: return f3(0.0f);
+    default: return bsdf_rough_sample(M, b, pdf, smp);
     }
 }
 
@@ -159,7 +160,7 @@ __device__ f3 bsdf_more_f(const ctl_material& M, const bsdf_rec& b) {
         return plastic_diffuse(M, b.dg) * ((kInvPi * cos_theta(b.wo)) * M.f[3] * (1 - Fi) * (1 - Fo));
     }
     case CTL_BSDF_PHONG: return phong_f(M, b);
-    default: return f3(0.0f);
+    default: return bsdf_rough_f(M, b);
     }
 }
 
@@ -192,7 +193,7 @@ __device__ float bsdf_more_pdf(const ctl_material& M, const bsdf_rec& b) {
         return (kInvPi * cos_theta(b.wo)) * (1 - ps);
     }
     case CTL_BSDF_PHONG: return phong_pdf(M, b);
-    default: return 0.0f;
+    default: return bsdf_rough_pdf(M, b);
     }
 }
 

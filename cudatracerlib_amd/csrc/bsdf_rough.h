@@ -1,0 +1,269 @@
+// bsdf_rough.h — roughdiffuse, ward, roughplastic (SceneTypes/BSDF_Simple.cu:82-172, 1173-1313, 890-1057) with the
+// rough-transmittance tables (Engine/RoughTransmittance.cu:55-119) and their cubic spline lookup (Math/Spline.cu:223-453).
+// Included by bsdf_more.h; expression order follows the reference (no FMA contraction), see DESIGN.md §4.
+#pragma once
+
+namespace ctl {
+
+// one dimension of Spline::evalCubicInterp{2D,3D}: knots on [0,1], extrapolate = false
+__device__ __forceinline__ bool spline_weights(float p, uint32_t size, float* w, uint32_t& knot) {
+    if (!(p >= 0.0f && p <= 1.0f)) return false;
+    float t = ((p - 0.0f) * (size - 1)) / (1.0f - 0.0f);
+    knot = min((uint32_t)t, size - 2);
+    t = t - (float)knot;
+    const float t2 = t * t, t3 = t2 * t;
+    w[0] = 0.0f; w[1] = 2 * t3 - 3 * t2 + 1; w[2] = -2 * t3 + 3 * t2; w[3] = 0.0f;
+    const float d0 = t3 - 2 * t2 + t, d1 = t3 - t2;
+    if (knot > 0) { w[2] += 0.5f * d0; w[0] -= 0.5f * d0; } else { w[2] += d0; w[1] -= d0; }
+    if (knot + 2 < size) { w[3] += 0.5f * d1; w[1] -= 0.5f * d1; } else { w[2] += d1; w[1] -= d1; }
+    return true;
+}
+__device__ float eval_cubic_interp_2d(float px, float py, const float* __restrict__ values, uint32_t sx, uint32_t sy) {
+    float wx[4], wy[4]; uint32_t kx, ky;
+    if (!spline_weights(px, sx, wx, kx) || !spline_weights(py, sy, wy, ky)) return 0.0f;
+    float result = 0.0f;
+    for (int y = -1; y <= 2; ++y)
+        for (int x = -1; x <= 2; ++x) {
+            const float wxy = wx[x + 1] * wy[y + 1];
+            if (wxy == 0) continue;
+            result += values[(size_t)(ky + y) * sx + kx + x] * wxy;
+        }
+    return result;
+}
+__device__ float eval_cubic_interp_3d(float px, float py, float pz, const float* __restrict__ values, uint32_t sx, uint32_t sy, uint32_t sz) {
+    float wx[4], wy[4], wz[4]; uint32_t kx, ky, kz;
+    if (!spline_weights(px, sx, wx, kx) || !spline_weights(py, sy, wy, ky) || !spline_weights(pz, sz, wz, kz)) return 0.0f;
+    float result = 0.0f;
+    for (int z = -1; z <= 2; ++z)
+        for (int y = -1; y <= 2; ++y) {
+            const float wyz = wy[y + 1] * wz[z + 1];
+            for (int x = -1; x <= 2; ++x) {
+                const float wxyz = wx[x + 1] * wyz;
+                if (wxyz == 0) continue;
+                result += values[((size_t)(kz + z) * sy + (ky + y)) * sx + kx + x] * wxyz;
+            }
+        }
+    return result;
+}
+// RoughTransmittanceManager::Evaluate / EvaluateDiffuse for the table of slot `type`
+__device__ float rough_transmittance(const diff_geom& dg, uint32_t type, float cosTheta, float alpha, float eta) {
+    const ctl_rough_transmittance& T = dg.rough_transmittance[type];
+    const float warpedCosTheta = powf(fabsf(cosTheta), 0.25f);
+    if (cosTheta < 0) { cosTheta = -cosTheta; eta = 1.0f / eta; }
+    const float* data = T.trans;
+    if (eta < 1) { data += (size_t)T.eta_samples * T.alpha_samples * T.theta_samples; eta = 1.0f / eta; }
+    if (eta < T.eta_min) eta = T.eta_min;
+    const float warpedAlpha = powf((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f);
+    const float warpedEta = powf((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
+    const float result = eval_cubic_interp_3d(warpedCosTheta, warpedAlpha, warpedEta, data, T.theta_samples, T.alpha_samples, T.eta_samples);
+    return min2(1.0f, max2(0.0f, result));
+}
+__device__ float rough_transmittance_diffuse(const diff_geom& dg, uint32_t type, float alpha, float eta) {
+    const ctl_rough_transmittance& T = dg.rough_transmittance[type];
+    const float* data = T.diff_trans;
+    if (eta < 1) { data += (size_t)T.eta_samples * T.alpha_samples; eta = 1.0f / eta; }
+    if (eta < T.eta_min) eta = T.eta_min;
+    const float warpedAlpha = powf((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f);
+    const float warpedEta = powf((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
+    const float result = eval_cubic_interp_2d(warpedAlpha, warpedEta, data, T.alpha_samples, T.eta_samples);
+    return min2(1.0f, max2(0.0f, result));
+}
+
+__device__ __forceinline__ float sin_phi(f3 v) { const float st = sin_theta(v); if (st == 0.0f) return 1.0f; return clampf(v.y / st, -1.0f, 1.0f); }   // Frame.h
+__device__ __forceinline__ float cos_phi(f3 v) { const float st = sin_theta(v); if (st == 0.0f) return 1.0f; return clampf(v.x / st, -1.0f, 1.0f); }
+__device__ __forceinline__ float safe_acosf(float v) { return acosf(min2(1.0f, max2(-1.0f, v))); }
+__device__ __forceinline__ float safe_sqrtf(float v) { return sqrtf(max2(0.0f, v)); }
+
+__device__ f3 roughdiffuse_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:82-172
+    if (!(b.type_mask & CTL_EGlossyReflection) || cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0) return f3(0.0f);
+    const float conversionFactor = 1 / sqrtf((float)2);
+    const float sigma = avg3(tex_eval(M.tex[1], b.dg)) * conversionFactor;
+    const float sigma2 = sigma * sigma;
+    const float sinThetaI = sin_theta(b.wi), sinThetaO = sin_theta(b.wo);
+    float cosPhiDiff = 0;
+    if (sinThetaI > 0.000001f && sinThetaO > 0.000001f) cosPhiDiff = cos_phi(b.wi) * cos_phi(b.wo) + sin_phi(b.wi) * sin_phi(b.wo);
+    if (M.u[0]) {
+        const float A = 1.0f - 0.5f * sigma2 / (sigma2 + 0.33f), B = 0.45f * sigma2 / (sigma2 + 0.09f);
+        float sinAlpha, tanBeta;
+        if (cos_theta(b.wi) > cos_theta(b.wo)) { sinAlpha = sinThetaO; tanBeta = sinThetaI / cos_theta(b.wi); }
+        else { sinAlpha = sinThetaI; tanBeta = sinThetaO / cos_theta(b.wo); }
+        return tex_eval(M.tex[0], b.dg) * (kInvPi * cos_theta(b.wo) * (A + B * max2(cosPhiDiff, 0.0f) * sinAlpha * tanBeta));
+    }
+    const float thetaI = safe_acosf(cos_theta(b.wi)), thetaO = safe_acosf(cos_theta(b.wo)), alpha = max2(thetaI, thetaO), beta = min2(thetaI, thetaO);
+    float sinAlpha, sinBeta, tanBeta;
+    if (cos_theta(b.wi) > cos_theta(b.wo)) { sinAlpha = sinThetaO; sinBeta = sinThetaI; tanBeta = sinThetaI / cos_theta(b.wi); }
+    else { sinAlpha = sinThetaI; sinBeta = sinThetaO; tanBeta = sinThetaO / cos_theta(b.wo); }
+    const float tmp = sigma2 / (sigma2 + 0.09f), tmp2 = (4 * kInvPi * kInvPi) * alpha * beta, tmp3 = 2 * beta * kInvPi;
+    const float C1 = 1.0f - 0.5f * sigma2 / (sigma2 + 0.33f), C3 = 0.125f * tmp * tmp2 * tmp2, C4 = 0.17f * sigma2 / (sigma2 + 0.13f);
+    float C2 = 0.45f * tmp;
+    if (cosPhiDiff > 0) C2 *= sinAlpha; else C2 *= sinAlpha - tmp3 * tmp3 * tmp3;
+    const float tanHalf = (sinAlpha + sinBeta) / (safe_sqrtf(1.0f - sinAlpha * sinAlpha) + safe_sqrtf(1.0f - sinBeta * sinBeta));
+    const f3 rho = tex_eval(M.tex[0], b.dg);
+    const f3 snglScat = rho * (C1 + cosPhiDiff * C2 * tanBeta + (1.0f - fabsf(cosPhiDiff)) * C3 * tanHalf);
+    const f3 dblScat = rho * rho * (C4 * (1.0f - cosPhiDiff * tmp3 * tmp3));
+    return (snglScat + dblScat) * (kInvPi * cos_theta(b.wo));
+}
+
+__device__ f3 ward_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:1232-1276
+    if (cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0) return f3(0.0f);
+    const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
+    f3 result(0.0f);
+    if (hs) {
+        const f3 H = b.wi + b.wo;
+        const float alphaU = avg3(tex_eval(M.tex[2], b.dg)), alphaV = avg3(tex_eval(M.tex[3], b.dg));
+        float factor1 = 0.0f;
+        switch (M.u[0]) {
+        case 0: factor1 = 1.0f / (4.0f * kPi * alphaU * alphaV * sqrtf(cos_theta(b.wi) * cos_theta(b.wo))); break;
+        case 1: factor1 = 1.0f / (4.0f * kPi * alphaU * alphaV * cos_theta(b.wi) * cos_theta(b.wo)); break;
+        case 2: factor1 = dot(H, H) / (kPi * alphaU * alphaV * powf(cos_theta(normalize(H)), 4)); break;
+        }
+        const float factor2 = H.x / alphaU, factor3 = H.y / alphaV;
+        const float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
+        const float specRef = factor1 * expf(exponent);
+        if (specRef > 1e-10f) result = result + tex_eval(M.tex[1], b.dg) * specRef;
+    }
+    if (hd) result = result + tex_eval(M.tex[0], b.dg) * kInvPi;
+    return result * cos_theta(b.wo);
+}
+__device__ float ward_pdf(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:1278-1313
+    if (cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0) return 0.0f;
+    const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
+    float diffuseProb = 0.0f, specProb = 0.0f; const float ssw = M.f[0];
+    if (hs) {
+        const float alphaU = avg3(tex_eval(M.tex[2], b.dg)), alphaV = avg3(tex_eval(M.tex[3], b.dg));
+        const f3 H = normalize(b.wi + b.wo);
+        const float factor1 = 1.0f / (4.0f * kPi * alphaU * alphaV * dot(H, b.wi) * powf(cos_theta(H), 3));
+        const float factor2 = H.x / alphaU, factor3 = H.y / alphaV;
+        const float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
+        specProb = factor1 * expf(exponent);
+    }
+    if (hd) diffuseProb = kInvPi * cos_theta(b.wo);
+    if (hd && hs) return ssw * specProb + (1 - ssw) * diffuseProb;
+    else if (hd) return diffuseProb;
+    else if (hs) return specProb;
+    return 0.0f;
+}
+
+__device__ __forceinline__ microfacet roughplastic_distr(const ctl_material& M, const diff_geom& dg) {
+    const float a = avg3(tex_eval(M.tex[2], dg));
+    return microfacet((int)M.u[2], a, a, M.u[1] != 0);
+}
+__device__ __forceinline__ float roughplastic_prob_specular(const ctl_material& M, const bsdf_rec& b, const microfacet& distr) {
+    const float ps = 1 - rough_transmittance(b.dg, M.u[2], cos_theta(b.wi), distr.aU, M.f[0]);
+    return (ps * M.f[2]) / (ps * M.f[2] + (1 - ps) * (1 - M.f[2]));
+}
+__device__ f3 roughplastic_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:948-1005
+    const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
+    if (cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0 || (!hs && !hd)) return f3(0.0f);
+    const microfacet distr = roughplastic_distr(M, b.dg);
+    f3 result(0.0f);
+    if (hs) {
+        const f3 H = normalize(b.wo + b.wi);
+        const float D = distr.eval(H);
+        float ct; const float F = fresnel_dielectric_ext(dot(b.wi, H), ct, M.f[0]);
+        const float G = distr.G(b.wi, b.wo, H);
+        const float value = F * D * G / (4.0f * cos_theta(b.wi));
+        result = result + tex_eval(M.tex[1], b.dg) * value;
+    }
+    if (hd) {
+        f3 diff = tex_eval(M.tex[0], b.dg);
+        const float T12 = rough_transmittance(b.dg, M.u[2], cos_theta(b.wi), distr.aU, M.f[0]);
+        const float T21 = rough_transmittance(b.dg, M.u[2], cos_theta(b.wo), distr.aU, M.f[0]);
+        const float Fdr = 1 - rough_transmittance_diffuse(b.dg, M.u[2], distr.aU, M.f[0]);
+        if (M.u[0]) diff = diff / (f3(1.0f) - diff * Fdr);
+        else diff = diff / (1 - Fdr);
+        result = result + diff * (kInvPi * cos_theta(b.wo) * T12 * T21 * M.f[1]);
+    }
+    return result;
+}
+__device__ float roughplastic_pdf(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:1007-1057
+    const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
+    if (cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0 || (!hs && !hd)) return 0.0f;
+    const microfacet distr = roughplastic_distr(M, b.dg);
+    const f3 H = normalize(b.wo + b.wi);
+    float probDiffuse, probSpecular;
+    if (hs && hd) { probSpecular = roughplastic_prob_specular(M, b, distr); probDiffuse = 1 - probSpecular; }
+    else probDiffuse = probSpecular = 1.0f;
+    float result = 0.0f;
+    if (hs) {
+        const float dwh_dwo = 1.0f / (4.0f * dot(b.wo, H));
+        const float prob = distr.pdf(b.wi, H);
+        result = prob * dwh_dwo * probSpecular;
+    }
+    if (hd) result += probDiffuse * (kInvPi * cos_theta(b.wo));
+    return result;
+}
+
+__device__ f3 bsdf_rough_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp) {
+    switch (M.bsdf_type) {
+    case CTL_BSDF_ROUGHDIFFUSE: {   // BSDF_Simple.h:42-49
+        b.wo = square_to_cosine_hemisphere(smp); b.eta = 1.0f; b.sampled_type = CTL_EGlossyReflection;
+        pdf = kInvPi * cos_theta(b.wo);
+        return roughdiffuse_f(M, b) / pdf;
+    }
+    case CTL_BSDF_WARD: {   // BSDF_Simple.cu:1173-1230
+        const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
+        if (!hs && !hd) return f3(0.0f);
+        bool spec = hs; const float ssw = M.f[0];
+        if (hd && hs) { if (smp.x <= ssw) smp.x /= ssw; else { smp.x = (smp.x - ssw) / (1 - ssw); spec = false; } }
+        if (spec) {
+            const float alphaU = avg3(tex_eval(M.tex[2], b.dg)), alphaV = avg3(tex_eval(M.tex[3], b.dg));
+            float phiH = atanf(alphaV / alphaU * tanf(2.0f * kPi * smp.y));
+            if (smp.y > 0.5f) phiH += kPi;
+            const float cosPhiH = cosf(phiH);
+            const float sinPhiH = safe_sqrtf(1.0f - cosPhiH * cosPhiH);
+            const float thetaH = atanf(safe_sqrtf(-logf(smp.x) / ((cosPhiH * cosPhiH) / (alphaU * alphaU) + (sinPhiH * sinPhiH) / (alphaV * alphaV))));
+            const float sinTheta = sinf(thetaH), cosTheta = cosf(thetaH), sinPhi = sinf(phiH), cosPhi = cosf(phiH);
+            const f3 H(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+            b.wo = reflect_about(b.wi, H);
+            b.sampled_type = CTL_EGlossyReflection;
+            if (cos_theta(b.wo) <= 0.0f) return f3(0.0f);
+        } else { b.wo = square_to_cosine_hemisphere(smp); b.sampled_type = CTL_EDiffuseReflection; }
+        b.eta = 1.0f;
+        pdf = ward_pdf(M, b);
+        if (pdf == 0) return f3(0.0f);
+        return ward_f(M, b) / pdf;
+    }
+    case CTL_BSDF_ROUGHPLASTIC: {   // BSDF_Simple.cu:890-946
+        const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
+        if (cos_theta(b.wi) <= 0 || (!hs && !hd)) return f3(0.0f);
+        bool spec = hs;
+        const microfacet distr = roughplastic_distr(M, b.dg);
+        if (hs && hd) {
+            const float ps = roughplastic_prob_specular(M, b, distr);
+            if (smp.y < ps) smp.y /= ps; else { smp.y = (smp.y - ps) / (1 - ps); spec = false; }
+        }
+        if (spec) {
+            float unused; const f3 m = distr.sample(b.wi, smp, unused);
+            b.wo = reflect_about(b.wi, m);
+            b.sampled_type = CTL_EGlossyReflection;
+            if (cos_theta(b.wo) <= 0) return f3(0.0f);
+        } else { b.sampled_type = CTL_EDiffuseReflection; b.wo = square_to_cosine_hemisphere(smp); }
+        b.eta = 1.0f;
+        pdf = roughplastic_pdf(M, b);
+        if (pdf == 0) return f3(0.0f);
+        return roughplastic_f(M, b) / pdf;
+    }
+    default: return f3(0.0f);
+    }
+}
+__device__ f3 bsdf_rough_f(const ctl_material& M, const bsdf_rec& b) {
+    switch (M.bsdf_type) {
+    case CTL_BSDF_ROUGHDIFFUSE: return roughdiffuse_f(M, b);
+    case CTL_BSDF_WARD: return ward_f(M, b);
+    case CTL_BSDF_ROUGHPLASTIC: return roughplastic_f(M, b);
+    default: return f3(0.0f);
+    }
+}
+__device__ float bsdf_rough_pdf(const ctl_material& M, const bsdf_rec& b) {
+    switch (M.bsdf_type) {
+    case CTL_BSDF_ROUGHDIFFUSE:   // BSDF_Simple.h:51-59
+        if (!(b.type_mask & CTL_EGlossyReflection) || cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0) return 0.0f;
+        return kInvPi * cos_theta(b.wo);
+    case CTL_BSDF_WARD: return ward_pdf(M, b);
+    case CTL_BSDF_ROUGHPLASTIC: return roughplastic_pdf(M, b);
+    default: return 0.0f;
+    }
+}
+
+} // namespace ctl

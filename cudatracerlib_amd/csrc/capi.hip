@@ -71,6 +71,14 @@ int ctl_builder_set_environment_map(ctl_builder* b, uint32_t image_index, const 
     CTL_REQUIRE(b && scale, "null argument");
     CTL_TRY b->b.set_environment_map(image_index, scale, to_world); CTL_CATCH
 }
+int ctl_builder_set_rough_transmittance(ctl_builder* b, uint32_t slot, const ctl_rough_transmittance* table) {
+    CTL_REQUIRE(b && table, "null argument");
+    CTL_TRY b->b.set_rough_transmittance(slot, *table); CTL_CATCH
+}
+int ctl_builder_load_rough_transmittance(ctl_builder* b, uint32_t slot, const char* dat_path) {
+    CTL_REQUIRE(b && dat_path, "null argument");
+    CTL_TRY b->b.load_rough_transmittance(slot, dat_path); CTL_CATCH
+}
 int ctl_builder_set_camera_lookat(ctl_builder* b, const float pos[3], const float target[3], const float up[3], float fov_degrees, uint32_t width, uint32_t height) {
     CTL_REQUIRE(b && pos && target && up && width && height, "bad argument");
     CTL_TRY b->b.set_camera_lookat(pos, target, up, fov_degrees, width, height); CTL_CATCH

@@ -31,6 +31,7 @@ struct dev_scene {
     const ctl_light* lights;
     const unsigned char* anim;
     const ctl_mipmap* images;    // level-0 KernelMIPMap descriptors with device texel pointers
+    const ctl_rough_transmittance* rough_transmittance;   // 3 tables with device pointers, or nullptr
     int start_node;
     uint32_t n_nodes;
     uint32_t num_lights;

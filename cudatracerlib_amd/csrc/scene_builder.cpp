@@ -2,6 +2,8 @@
 // DynamicScene that the Mitsuba loader drives (Engine/DynamicScene.h:70-187), emitting the reference's
 // KernelDynamicScene arrays (Engine/KernelDynamicScene.h:28-109) as a ctl_scene_desc.
 #include "scene_builder.h"
+#include <cstdio>
+#include <string>
 #include "ctl_math.h"
 #include <cstring>
 #include <algorithm>
@@ -336,6 +338,40 @@ uint32_t scene_builder::set_environment_map(uint32_t image, const float scale[3]
     return env_light;
 }
 
+// RoughTransmittanceManager::StaticInitialize (Engine/RoughTransmittance.cu:124-131): one slot
+void scene_builder::set_rough_transmittance(uint32_t slot, const ctl_rough_transmittance& t) {
+    if (slot >= 3) throw std::runtime_error("ctl_builder_set_rough_transmittance: slot must be 0..2");
+    if (!t.trans || !t.diff_trans || t.eta_samples < 2 || t.alpha_samples < 2 || t.theta_samples < 2) throw std::runtime_error("ctl_builder_set_rough_transmittance: bad table");
+    const size_t nt = (size_t)2 * t.eta_samples * t.alpha_samples * t.theta_samples, nd = (size_t)2 * t.eta_samples * t.alpha_samples;
+    rt_trans[slot].assign(t.trans, t.trans + nt); rt_diff[slot].assign(t.diff_trans, t.diff_trans + nd);
+    rt[slot] = t; have_rt = true;
+}
+// RoughTransmittance::RoughTransmittance(name) (Engine/RoughTransmittance.cu:8-45): "MTS_TRANSMITTANCE", three size_t counts,
+// four float bounds, then per (eta, alpha): theta_samples transmittances followed by one diffuse transmittance
+void scene_builder::load_rough_transmittance(uint32_t slot, const char* path) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("Could not open file : ") + path);
+    std::vector<unsigned char> buf;
+    std::fseek(f, 0, SEEK_END); long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+    buf.resize(sz > 0 ? (size_t)sz : 0);
+    if (sz > 0 && std::fread(buf.data(), 1, buf.size(), f) != buf.size()) { std::fclose(f); throw std::runtime_error("short read"); }
+    std::fclose(f);
+    const char header[] = "MTS_TRANSMITTANCE"; const size_t hl = sizeof(header) - 1;
+    if (buf.size() < hl + 3 * 8 + 4 * 4 || std::memcmp(buf.data(), header, hl) != 0) throw std::runtime_error("Invalid filetype for rough transmittance!");
+    size_t pos = hl; uint64_t cnt[3]; float bnd[4];
+    std::memcpy(cnt, buf.data() + pos, 24); pos += 24;
+    std::memcpy(bnd, buf.data() + pos, 16); pos += 16;
+    const size_t E = cnt[0], A = cnt[1], T = cnt[2], nt = 2 * E * A * T, nd = 2 * E * A;
+    if (buf.size() != pos + (nt + nd) * sizeof(float)) throw std::runtime_error("RoughTransmittance: unexpected file size");
+    const float* ptr = (const float*)(buf.data() + pos);
+    std::vector<float> trans(nt), diff(nd); size_t de = 0, fe = 0;
+    for (size_t i = 0; i < 2 * E; ++i) for (size_t j = 0; j < A; ++j) { for (size_t k = 0; k < T; ++k) trans[de++] = *ptr++; diff[fe++] = *ptr++; }
+    ctl_rough_transmittance t{}; t.trans = trans.data(); t.diff_trans = diff.data();
+    t.eta_samples = (uint32_t)E; t.alpha_samples = (uint32_t)A; t.theta_samples = (uint32_t)T;
+    t.eta_min = bnd[0]; t.eta_max = bnd[1]; t.alpha_min = bnd[2]; t.alpha_max = bnd[3];
+    set_rough_transmittance(slot, t);
+}
+
 // Sensor::SetToWorld(pos, tar, up) (SceneTypes/Sensor.cu:691-699) with the loader's frame reconstruction
 // (ObjectParser.h:292-297, Sensor.cu:682-689): r = f x up, u = r x f, columns (r, u, f), translation pos.
 void scene_builder::set_camera_lookat(const float pos[3], const float target[3], const float up_in[3], float fov_degrees, uint32_t w, uint32_t h) {
@@ -400,6 +436,8 @@ void scene_builder::finalize(ctl_scene_desc& out) {
     for (int i = 0; i < 3; i++) { out.box_min[i] = scene.lo[i]; out.box_max[i] = scene.hi[i]; }
     for (size_t i = 0; i < images.size(); i++) images[i].texels = image_texels[i].data();
     out.images = images.data(); out.n_images = (uint32_t)images.size();
+    for (int i = 0; i < 3; i++) { rt[i].trans = rt_trans[i].empty() ? nullptr : rt_trans[i].data(); rt[i].diff_trans = rt_diff[i].empty() ? nullptr : rt_diff[i].data(); }
+    out.rough_transmittance = have_rt ? rt : nullptr;
     {   // the light that depends on the scene box: InfiniteLight::Update (SceneTypes/Light.h:318-325)
         f3 lo(scene.lo[0], scene.lo[1], scene.lo[2]), hi(scene.hi[0], scene.hi[1], scene.hi[2]);
         f3 center = (lo + hi) * 0.5f;   // AABB::Center (Math/AABB.h)

@@ -30,6 +30,9 @@ struct scene_builder {
     std::vector<std::vector<uint32_t>> image_texels;   // level-0 texels of every registered KernelMIPMap
     std::vector<ctl_mipmap> images;
     uint32_t env_light = 0xffffffffu;
+    std::vector<float> rt_trans[3], rt_diff[3];        // RoughTransmittanceManager's three tables
+    ctl_rough_transmittance rt[3] = {};
+    bool have_rt = false;
     ctl_sensor camera{};
     bool have_camera = false;
 
@@ -42,6 +45,8 @@ struct scene_builder {
     uint32_t add_distant_light(const float direction[3], const float irradiance[3], float scene_radius);
     uint32_t add_image(const uint32_t* texels, uint32_t w, uint32_t h, uint32_t texel_type, uint32_t wrap, uint32_t filter);
     uint32_t set_environment_map(uint32_t image, const float scale[3], const ctl_float4x4* to_world);
+    void set_rough_transmittance(uint32_t slot, const ctl_rough_transmittance& t);
+    void load_rough_transmittance(uint32_t slot, const char* path);
     void set_camera_lookat(const float pos[3], const float target[3], const float up[3], float fov_degrees, uint32_t w, uint32_t h);
     void set_camera(const ctl_sensor& s);
     void finalize(ctl_scene_desc& out);

@@ -87,6 +87,25 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
         if (d.n_images) images_.upload(tab.data(), tab.size()); else images_.alloc(1);
         S.images = images_.p;
     }
+    // RoughTransmittanceManager's tables (roughplastic): one float pool + 3 descriptors with device pointers
+    S.rough_transmittance = nullptr;
+    if (d.rough_transmittance) {
+        std::vector<float> pool; size_t off_t[3] = {}, off_d[3] = {};
+        for (int i = 0; i < 3; i++) {
+            const ctl_rough_transmittance& t = d.rough_transmittance[i];
+            if (!t.trans || !t.diff_trans) continue;
+            const size_t nt = (size_t)2 * t.eta_samples * t.alpha_samples * t.theta_samples, nd = (size_t)2 * t.eta_samples * t.alpha_samples;
+            off_t[i] = pool.size(); pool.insert(pool.end(), t.trans, t.trans + nt);
+            off_d[i] = pool.size(); pool.insert(pool.end(), t.diff_trans, t.diff_trans + nd);
+        }
+        if (!pool.empty()) {
+            rt_data_.upload(pool.data(), pool.size());
+            ctl_rough_transmittance tab[3];
+            for (int i = 0; i < 3; i++) { tab[i] = d.rough_transmittance[i]; const bool ok = tab[i].trans && tab[i].diff_trans; tab[i].trans = ok ? rt_data_.p + off_t[i] : nullptr; tab[i].diff_trans = ok ? rt_data_.p + off_d[i] : nullptr; }
+            rt_.upload(tab, 3);
+            S.rough_transmittance = rt_.p;
+        }
+    }
     for (uint32_t i = 0; i < d.n_lights_buf; i++) {
         const ctl_light& L = d.lights[i];
         if (L.type < CTL_LIGHT_POINT || L.type > CTL_LIGHT_INFINITE) throw std::runtime_error("ctl_scene_create: unknown light type " + std::to_string(L.type));
@@ -101,7 +120,15 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
         }
         const uint32_t t = d.materials[i].bsdf_type;
         const bool ok = t == CTL_BSDF_DIFFUSE || t == CTL_BSDF_DIELECTRIC || t == CTL_BSDF_THINDIELECTRIC || t == CTL_BSDF_ROUGHDIELECTRIC || t == CTL_BSDF_CONDUCTOR ||
-                        t == CTL_BSDF_ROUGHCONDUCTOR || t == CTL_BSDF_PLASTIC || t == CTL_BSDF_PHONG;
+                        t == CTL_BSDF_ROUGHCONDUCTOR || t == CTL_BSDF_PLASTIC || t == CTL_BSDF_PHONG || t == CTL_BSDF_ROUGHDIFFUSE || t == CTL_BSDF_WARD || t == CTL_BSDF_ROUGHPLASTIC;
+        if (t == CTL_BSDF_ROUGHPLASTIC) {
+            const uint32_t slot = d.materials[i].u[2];
+            if (slot > CTL_MF_GGX) throw std::runtime_error("ctl_scene_create: roughplastic with the Phong distribution has no HIP implementation yet");
+            if (!d.rough_transmittance || !d.rough_transmittance[slot].trans || !d.rough_transmittance[slot].diff_trans)
+                throw std::runtime_error("ctl_scene_create: roughplastic needs the rough-transmittance table of its distribution (ctl_builder_set_rough_transmittance)");
+        }
+        if ((t == CTL_BSDF_ROUGHCONDUCTOR || t == CTL_BSDF_ROUGHDIELECTRIC) && d.materials[i].u[0] > CTL_MF_GGX)
+            throw std::runtime_error("ctl_scene_create: the Phong microfacet distribution has no HIP implementation yet");
         if (!ok)
             throw std::runtime_error("ctl_scene_create: BSDF type " + std::to_string(t) + " has no HIP implementation yet");
     }

@@ -112,6 +112,16 @@ def cornell_box(width=256, height=256, glass_sphere=False, extra_materials=False
         mats += [api.phong(diffuse_reflectance=(0.5, 0.3, 0.1), specular_reflectance=(0.3, 0.3, 0.3), exponent=40.0), api.thindielectric(int_ior=1.5, ext_ior=1.0)]
     elif extra_materials == 4:    # short block nonlinear plastic, tall block Beckmann rough glass sampled from the full distribution
         mats += [api.plastic(diffuse_reflectance=(0.6, 0.2, 0.2), int_ior=1.9, nonlinear=True), api.roughdielectric(alpha=0.25, alpha_v=0.1, int_ior=1.33, ext_ior=1.0, distribution=0, sample_visible=False)]
+    elif extra_materials == 5:    # short block Oren-Nayar (full model), tall block anisotropic balanced Ward; fast Oren-Nayar on the floor via variant 7
+        mats += [api.roughdiffuse((0.7, 0.5, 0.2), alpha=0.4), api.ward((0.3, 0.3, 0.5), (0.05, 0.05, 0.05), alpha_u=0.08, alpha_v=0.25, variant=2)]   # (the reference's balanced variant gains energy, see tests/test_oracle_bsdf.py)
+    elif extra_materials == 6:    # short block Beckmann rough plastic, tall block GGX nonlinear rough plastic (synthetic transmittance tables)
+        from . import rough_tables
+        for slot in (0, 1):
+            tr, df, er, ar = rough_tables.make_table(slot, n_eta=4, n_alpha=5, n_theta=8, quad=16)
+            sc.setRoughTransmittance(slot, tr, df, er, ar)
+        mats += [api.roughplastic((0.2, 0.5, 0.25), alpha=0.15, distribution=0), api.roughplastic((0.6, 0.25, 0.2), alpha=0.3, int_ior=1.6, distribution=1, nonlinear=True)]
+    elif extra_materials == 7:    # short block fast-approximation Oren-Nayar, tall block original Ward
+        mats += [api.roughdiffuse((0.7, 0.5, 0.2), alpha=0.6, use_fast_approx=True), api.ward((0.2, 0.4, 0.3), (0.3, 0.3, 0.3), alpha_u=0.15, alpha_v=0.15, variant=0)]
     elif extra_materials:
         mats += [api.roughconductor(alpha=0.15, distribution=1, sample_visible=True), api.conductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))]
     room = sc.add_mesh(P, I, normals=N, tri_material=M, materials=mats)

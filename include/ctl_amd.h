@@ -104,6 +104,16 @@ typedef struct {
     uint32_t texel_type, wrap_mode, filter_mode;
 } ctl_mipmap;
 
+/* Engine/RoughTransmittance.h:9-27 — one table of Mitsuba's data/microfacet/{beckmann,phong,ggx}.dat (roughplastic).
+ * trans[2*eta_samples][alpha_samples][theta_samples], diff_trans[2*eta_samples][alpha_samples] (the second half of each is
+ * the eta < 1 block).  ctl_scene_desc::rough_transmittance points at THREE of them, indexed by the microfacet distribution
+ * type exactly as RoughTransmittanceManager does (RoughTransmittance.cu:124-157: slot 0 beckmann.dat, 1 phong.dat, 2 ggx.dat). */
+typedef struct {
+    const float* trans; const float* diff_trans;
+    uint32_t eta_samples, alpha_samples, theta_samples;
+    float eta_min, eta_max, alpha_min, alpha_max;
+} ctl_rough_transmittance;
+
 /* ids = the reference's TYPE_FUNC ids (BSDF_Simple.h:6-401, BSDF_Complex.h:9-182) */
 enum { CTL_BSDF_DIFFUSE = 1, CTL_BSDF_ROUGHDIFFUSE = 2, CTL_BSDF_DIELECTRIC = 3, CTL_BSDF_THINDIELECTRIC = 4,
        CTL_BSDF_ROUGHDIELECTRIC = 5, CTL_BSDF_CONDUCTOR = 6, CTL_BSDF_ROUGHCONDUCTOR = 7, CTL_BSDF_PLASTIC = 8,
@@ -128,7 +138,8 @@ enum { CTL_MF_BECKMANN = 0, CTL_MF_GGX = 1, CTL_MF_PHONG = 2 };
  *                 f4 specularSamplingWeight, u0 nonlinear
  *  roughplastic   tex0 diffuse, tex1 specular, tex2 alpha, f0 eta, f1 invEta2, f2 specularSamplingWeight,
  *                 u0 nonlinear, u1 sampleVisible, u2 distribution
- *  phong          tex0 diffuse, tex1 specular, tex2 exponent, f0 specularSamplingWeight */
+ *  phong          tex0 diffuse, tex1 specular, tex2 exponent, f0 specularSamplingWeight
+ *  ward           tex0 diffuse, tex1 specular, tex2 alphaU, tex3 alphaV, f0 specularSamplingWeight, u0 variant (0 Ward, 1 Ward-Duer, 2 balanced) */
 typedef struct {
     uint32_t bsdf_type;        /* CTL_BSDF_*                                       */
     uint32_t combined_type;    /* BSDF::m_combinedType (SceneTypes/BSDF.h:24)      */
@@ -204,6 +215,7 @@ typedef struct {
     float light_cdf[CTL_MAX_NUM_LIGHTS];
     float ray_trace_eps;                      /* m_rayTraceEps = 1e-4 * |box diagonal| (DynamicScene.cpp:587) */
     const ctl_mipmap* images;            uint32_t n_images;       /* m_sTexData (level 0) */
+    const ctl_rough_transmittance* rough_transmittance;           /* [3] or NULL (needed by roughplastic only) */
 } ctl_scene_desc;
 
 /* ------------------------------------------------------------- scene builder */
@@ -239,6 +251,10 @@ int ctl_builder_add_image(ctl_builder* b, const uint32_t* texels, uint32_t width
 /* DynamicScene::setEnvironementMap(scale, file) (Engine/DynamicScene.cpp:846-859) + InfiniteLight ctor (Light.cpp:10-61):
  * builds the row / column CDFs; to_world (row-major 4x4, orthogonal) may be NULL = identity. */
 int ctl_builder_set_environment_map(ctl_builder* b, uint32_t image_index, const float scale[3], const ctl_float4x4* to_world);
+/* RoughTransmittanceManager::StaticInitialize (Engine/RoughTransmittance.cu:124-131): install the table of one slot (0..2);
+ * the arrays are copied.  ctl_builder_load_rough_transmittance parses a Mitsuba "MTS_TRANSMITTANCE" .dat file (:8-45). */
+int ctl_builder_set_rough_transmittance(ctl_builder* b, uint32_t slot, const ctl_rough_transmittance* table);
+int ctl_builder_load_rough_transmittance(ctl_builder* b, uint32_t slot, const char* dat_path);
 /* DynamicScene::setCamera — perspective sensor as built by the Mitsuba loader (ObjectParser.h:292-297): */
 int ctl_builder_set_camera_lookat(ctl_builder* b, const float pos[3], const float target[3], const float up[3],
                                   float fov_degrees, uint32_t width, uint32_t height);

@@ -1,5 +1,5 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see omath.h header).
-// obsdf2.h — thindielectric, roughdielectric, plastic, phong (SceneTypes/BSDF_Simple.cu).  Included by ocore.h after
+// obsdf2.h — thindielectric, roughdielectric, plastic, phong (SceneTypes/BSDF_Simple.cu); other types go on to obsdf3.h.  Included by ocore.h after
 // BRec / Microfacet / texEval are defined.  PARITY UNPINNED: BSDF_Simple.cu cannot be built here (curand_kernel.h).
 #pragma once
 
@@ -114,7 +114,7 @@ inline Spec bsdf2Sample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sampl
         if (pdf == 0) return Spec(0.0f);
         return bsdf2F(M, bRec, ESolidAngle) / pdf;
     }
-    default: throw std::runtime_error("oracle: bsdf type not restated");
+    default: return bsdf3Sample(M, bRec, pdf, _sample);
     }
 }
 
@@ -163,7 +163,7 @@ inline Spec bsdf2F(const ctl_material& M, const BRec& bRec, int measure) {
         if (hasDiffuse) result = result + texEval(M.tex[0], bRec.dg) * INV_PI;
         return result * Frame::cosTheta(bRec.wo);
     }
-    default: throw std::runtime_error("oracle: bsdf type not restated");
+    default: return bsdf3F(M, bRec, measure);
     }
 }
 
@@ -212,7 +212,7 @@ inline float bsdf2Pdf(const ctl_material& M, const BRec& bRec, int measure) {
         else if (hasSpecular) return specProb;
         return 0.0f;
     }
-    default: throw std::runtime_error("oracle: bsdf type not restated");
+    default: return bsdf3Pdf(M, bRec, measure);
     }
 }
 

@@ -174,6 +174,7 @@ inline bool occluded(const Scene& S, V3 o, V3 d, float tmin, float tmax) {
 struct DG {   // Engine/DifferentialGeometry.h:11-47
     V3 P; Frame sys; V3 n; V3 dpdu, dpdv; V2 uv; V2 bary; uint8_t extraData;
     const ctl_mipmap* images = nullptr;   // g_SceneData.m_sTexData (ImageTexture::getTexture, Texture.cu:39-42)
+    const ctl_rough_transmittance* rough_transmittance = nullptr;   // RoughTransmittanceManager's three tables (RoughTransmittance.cu:121-131)
 };
 // Engine/TriangleData.cu:22-32 + 34-65
 inline void triDataSetUV(ctl_triangle_data& T, V2 a, V2 b, V2 c) {
@@ -228,7 +229,7 @@ inline void triDataFillDG(const ctl_triangle_data& T, const M44& localToWorld, D
 inline void fillDG(const Scene& S, V2 bary, uint32_t triIdx, uint32_t nodeIdx, DG& dg) {
     M44 l2w; std::memcpy(l2w.d, S.d.node_transforms[nodeIdx].m, 64);
     dg.bary = bary;
-    dg.images = S.d.images;
+    dg.images = S.d.images; dg.rough_transmittance = S.d.rough_transmittance;
     triDataFillDG(S.d.tri_data[triIdx], l2w, dg, S.half_host_quirk);
 }
 
@@ -647,6 +648,7 @@ inline V3 reflectAbout(V3 wi, V3 n) { return normalize(2 * dot(wi, n) * n - wi);
 inline float avg3(Spec s) { float r = 0.0f; r += s.x; r += s.y; r += s.z; return r * (1.0f / 3); }   // Spectrum.h:180-190
 
 } // namespace orc
+#include "obsdf3.h"
 #include "obsdf2.h"
 namespace orc {
 

@@ -20,7 +20,21 @@ DELTA = 0x1 | 0x20 | 0x40
 
 @pytest.fixture(scope="module")
 def lib():
-    return oracle.load()
+    o = oracle.load()
+    # rough-transmittance tables for the roughplastic probes (synthetic stand-ins for Mitsuba's microfacet/*.dat)
+    from cudatracerlib_amd import rough_tables
+    keep = []
+    tabs = (api.ctl_rough_transmittance * 3)()
+    for slot in (0, 1):
+        tr, df, er, ar = rough_tables.make_table(slot, n_eta=4, n_alpha=5, n_theta=8, quad=16)
+        keep += [tr, df]
+        t = tabs[slot]
+        t.trans, t.diff_trans = tr.ctypes.data, df.ctypes.data
+        t.eta_samples, t.alpha_samples, t.theta_samples = tr.shape[0] // 2, tr.shape[1], tr.shape[2]
+        t.eta_min, t.eta_max, t.alpha_min, t.alpha_max = er[0], er[1], ar[0], ar[1]
+    o.orc_set_probe_rough_transmittance(C.addressof(tabs))
+    o._keep = (keep, tabs)
+    return o
 
 
 def _sample(lib, m, wi, s):
@@ -51,6 +65,12 @@ MODELS = {
     "plastic": lambda: api.plastic(diffuse_reflectance=(1, 1, 1), int_ior=1.49),
     "plastic_nonlinear": lambda: api.plastic(diffuse_reflectance=(0.5, 0.4, 0.3), int_ior=1.9, nonlinear=True),
     "phong": lambda: api.phong(diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(0.5, 0.5, 0.5), exponent=25.0),
+    "roughdiffuse": lambda: api.roughdiffuse((1, 1, 1), alpha=0.5),
+    "roughdiffuse_fast": lambda: api.roughdiffuse((0.8, 0.8, 0.8), alpha=0.3, use_fast_approx=True),
+    "ward": lambda: api.ward((0.4, 0.4, 0.4), (0.5, 0.5, 0.5), 0.15, 0.15, variant=2),
+    "ward_aniso_duer": lambda: api.ward((0.4, 0.4, 0.4), (0.3, 0.3, 0.3), 0.1, 0.3, variant=1),
+    "roughplastic_beckmann": lambda: api.roughplastic((0.5, 0.5, 0.5), alpha=0.2, distribution=0),
+    "roughplastic_ggx_nonlinear": lambda: api.roughplastic((0.6, 0.3, 0.2), alpha=0.35, int_ior=1.7, distribution=1, nonlinear=True),
     "thindielectric": lambda: api.thindielectric(int_ior=1.5, ext_ior=1.0),
     "dielectric": lambda: api.dielectric(int_ior=1.5, ext_ior=1.0),
 }
@@ -88,6 +108,10 @@ def test_sample_eval_pdf_are_consistent(lib, name):
 
 @pytest.mark.parametrize("name", list(MODELS))
 def test_no_energy_gain(lib, name):
+    if name == "ward":
+        # the reference's balanced variant divides by cos^4 of the NORMALISED half vector (BSDF_Simple.cu:1257-1258, marked
+        # "POSSIBLE ERROR" there; Mitsuba uses the unnormalised one), which gains up to |wi+wo|^4 = 16x; restated as is
+        pytest.skip("reference quirk: the balanced Ward variant is not energy conserving")
     m = MODELS[name]()
     rs = np.random.RandomState(11)
     for theta in (0.2, 1.0, 1.45):
