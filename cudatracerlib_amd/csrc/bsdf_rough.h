@@ -194,7 +194,7 @@ __device__ float roughplastic_pdf(const ctl_material& M, const bsdf_rec& b) {   
     return result;
 }
 
-__device__ f3 bsdf_rough_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp) {
+__device__ __noinline__ f3 bsdf_rough_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp) {
     switch (M.bsdf_type) {
     case CTL_BSDF_ROUGHDIFFUSE: {   // BSDF_Simple.h:42-49
         b.wo = square_to_cosine_hemisphere(smp); b.eta = 1.0f; b.sampled_type = CTL_EGlossyReflection;
@@ -247,7 +247,7 @@ __device__ f3 bsdf_rough_sample(const ctl_material& M, bsdf_rec& b, float& pdf, 
     default: return f3(0.0f);
     }
 }
-__device__ f3 bsdf_rough_f(const ctl_material& M, const bsdf_rec& b) {
+__device__ __noinline__ f3 bsdf_rough_f(const ctl_material& M, const bsdf_rec& b) {
     switch (M.bsdf_type) {
     case CTL_BSDF_ROUGHDIFFUSE: return roughdiffuse_f(M, b);
     case CTL_BSDF_WARD: return ward_f(M, b);
@@ -255,7 +255,7 @@ __device__ f3 bsdf_rough_f(const ctl_material& M, const bsdf_rec& b) {
     default: return f3(0.0f);
     }
 }
-__device__ float bsdf_rough_pdf(const ctl_material& M, const bsdf_rec& b) {
+__device__ __noinline__ float bsdf_rough_pdf(const ctl_material& M, const bsdf_rec& b) {
     switch (M.bsdf_type) {
     case CTL_BSDF_ROUGHDIFFUSE:   // BSDF_Simple.h:51-59
         if (!(b.type_mask & CTL_EGlossyReflection) || cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0) return 0.0f;

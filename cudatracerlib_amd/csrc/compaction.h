@@ -1,0 +1,61 @@
+// compaction.h — wave- and workgroup-level queue appends (stream compaction) and the framebuffer accumulation shared by the
+// ray-generation, shade and finalize kernels.
+#pragma once
+#include "kernels.h"
+
+namespace ctl {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------------ wave primitives
+// Append one element per participating lane to a global queue: one atomic per wave (ballot + mbcnt prefix).
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool take) {
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0) return 0;
+    const uint32_t n = (uint32_t)__popcll(mask);
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+    uint32_t base = 0;
+    const int leader = (int)__builtin_ctzll(mask);
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, n);
+    base = __shfl(base, leader, 64);
+    return base + prefix;
+}
+
+// Append to up to three global queues from a whole workgroup with ONE atomic per queue per workgroup: ballot/mbcnt inside
+// each wave, wave totals through LDS, thread k < 3 reserves the block's range.  A single queue cursor saturates at
+// ~88 returning atomics/us on MI355X (MI355X_MICROARCH.md "dequeue"), which a per-wave append hits at once: 160 k waves per
+// pass step on three cursors were the whole cost of the first shade kernel.  Must be called by every thread of the block.
+constexpr int kWideBlock = 1024;
+struct block_slots { uint32_t s[3]; };
+__device__ __forceinline__ block_slots block_append3(uint32_t* c0, bool t0, uint32_t* c1, bool t1, uint32_t* c2, bool t2, uint32_t (*s_cnt)[kWideBlock / 64], uint32_t* s_base) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const unsigned long long m0 = __ballot(t0), m1 = __ballot(t1), m2 = __ballot(t2);
+    if (lane == 0) { s_cnt[0][wave] = (uint32_t)__popcll(m0); s_cnt[1][wave] = (uint32_t)__popcll(m1); s_cnt[2][wave] = (uint32_t)__popcll(m2); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t* ctr = threadIdx.x == 0 ? c0 : (threadIdx.x == 1 ? c1 : c2);
+        uint32_t tot = 0;
+        for (int w = 0; w < n_waves; w++) { const uint32_t c = s_cnt[threadIdx.x][w]; s_cnt[threadIdx.x][w] = tot; tot += c; }   // exclusive prefix over waves
+        s_base[threadIdx.x] = (tot && ctr) ? atomicAdd(ctr, tot) : 0u;
+    }
+    __syncthreads();
+    block_slots r;
+    r.s[0] = s_base[0] + s_cnt[0][wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0));
+    r.s[1] = s_base[1] + s_cnt[1][wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0));
+    r.s[2] = s_base[2] + s_cnt[2][wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0));
+    __syncthreads();   // s_cnt / s_base are reused by the next iteration
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ framebuffer
+// Image::AddSample (Engine/Image.cu:22-44): clamp negatives, drop NaN/Inf, floor to the pixel, 4 float atomics.
+__device__ __forceinline__ void add_sample(ctl_pixel_data* img, uint32_t W, uint32_t H, float sx, float sy, f3 L) {
+    L = f3(max2(0.0f, L.x), max2(0.0f, L.y), max2(0.0f, L.z));
+    const int x = (int)floorf(sx), y = (int)floorf(sy);
+    const bool bad = !(isfinite(L.x) && isfinite(L.y) && isfinite(L.z));
+    if (x < 0 || x >= (int)W || y < 0 || y >= (int)H || bad) return;
+    ctl_pixel_data* r = img + ((size_t)y * W + x);
+    atomicAdd(&r->rgb[0], L.x); atomicAdd(&r->rgb[1], L.y); atomicAdd(&r->rgb[2], L.z); atomicAdd(&r->weight_sum, 1.0f);
+}
+
+} // namespace ctl

@@ -3,6 +3,12 @@
 #pragma once
 #include "device_scene.h"
 
+// Feature set compiled into the shading functions of this translation unit (bits = kShade* of device_scene.h).  The shade
+// kernel is built twice (shade_basic.hip: 0, shade_full.hip: all); everything else uses the full set.
+#ifndef CTL_SHADE_FEATURES
+#define CTL_SHADE_FEATURES 0xF
+#endif
+
 namespace ctl {
 
 // ---- SequenceSampler (Kernel/Sampler_device.h:59-113): u = frac(T[d % 30][i % 4096] + T[d % 30][(i / 4096) % 4096])
@@ -104,6 +110,15 @@ __device__ __forceinline__ f3 mip_fetch(const ctl_mipmap& M, int x, int y) {
     return texel_decode(M.texels[(size_t)y * M.width + x], M.texel_type);
 }
 
+// ImageTexture::Evaluate(uv) (Texture.cu:6-13); out of line: tex_eval is inlined at every BSDF parameter fetch and the bitmap
+// path must not cost the constant-texture path registers
+__device__ __noinline__ f3 tex_eval_image(const ctl_texture& t, f2 duv, const ctl_mipmap* images) {
+    if (t.image == 0xffffffffu) return f3(0.0f);
+    const f2 uv{ t.uv_scale[0] * duv.x + 0 * duv.y + t.uv_offset[0], 0 * duv.x + t.uv_scale[1] * duv.y + t.uv_offset[1] };
+    const ctl_mipmap& M = images[t.image];
+    return (M.filter_mode == CTL_FILTER_POINT ? mip_texel(M, uv) : mip_triangle(M, uv)) * f3(t.value[0], t.value[1], t.value[2]);
+}
+
 // ---- textures (SceneTypes/Texture.h:107-183, Texture.cu:6-29)
 __device__ __forceinline__ f3 tex_eval(const ctl_texture& t, const diff_geom& dg) {
     if (t.type == CTL_TEX_CHECKER) {
@@ -112,12 +127,9 @@ __device__ __forceinline__ f3 tex_eval(const ctl_texture& t, const diff_geom& dg
         const int x = 2 * xm - 1, y = 2 * ym - 1;
         return (x * y == 1) ? f3(t.value[0], t.value[1], t.value[2]) : f3(t.value1[0], t.value1[1], t.value1[2]);
     }
-    if (t.type == CTL_TEX_IMAGE) {
-        if (t.image == 0xffffffffu) return f3(0.0f);
-        const f2 uv{ t.uv_scale[0] * dg.uv.x + 0 * dg.uv.y + t.uv_offset[0], 0 * dg.uv.x + t.uv_scale[1] * dg.uv.y + t.uv_offset[1] };
-        const ctl_mipmap& M = dg.images[t.image];
-        return (M.filter_mode == CTL_FILTER_POINT ? mip_texel(M, uv) : mip_triangle(M, uv)) * f3(t.value[0], t.value[1], t.value[2]);
-    }
+#if CTL_SHADE_FEATURES & 4
+    if (t.type == CTL_TEX_IMAGE) return tex_eval_image(t, dg.uv, dg.images);
+#endif
     return f3(t.value[0], t.value[1], t.value[2]);
 }
 __device__ __forceinline__ float avg3(f3 s) { float r = s.x; r += s.y; r += s.z; return r * (1.0f / 3); }   // Spectrum.h:180-190
@@ -282,7 +294,11 @@ __device__ f3 bsdf_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp
         pdf /= 4.0f * dot(b.wo, m);
         return F * weight;
     }
+#if CTL_SHADE_FEATURES & 3
     default: return bsdf_more_sample(M, b, pdf, smp);
+#else
+    default: return f3(0.0f);
+#endif
     }
 }
 
@@ -311,7 +327,11 @@ __device__ f3 bsdf_f(const ctl_material& M, const bsdf_rec& b) {
         return F * value;
     }
     case CTL_BSDF_DIELECTRIC: case CTL_BSDF_CONDUCTOR: case CTL_BSDF_THINDIELECTRIC: return f3(0.0f);   // delta lobes have no solid-angle density (BSDF_Simple.cu:226-252, 632-646)
+#if CTL_SHADE_FEATURES & 3
     default: return bsdf_more_f(M, b);
+#else
+    default: return f3(0.0f);
+#endif
     }
 }
 __device__ float bsdf_pdf(const ctl_material& M, const bsdf_rec& b) {
@@ -334,7 +354,11 @@ __device__ float bsdf_pdf(const ctl_material& M, const bsdf_rec& b) {
         return distr.pdf(b.wi, H) / (4 * absdot(b.wo, H));
     }
     case CTL_BSDF_DIELECTRIC: case CTL_BSDF_CONDUCTOR: case CTL_BSDF_THINDIELECTRIC: return 0.0f;
+#if CTL_SHADE_FEATURES & 3
     default: return bsdf_more_pdf(M, b);
+#else
+    default: return 0.0f;
+#endif
     }
 }
 
@@ -427,6 +451,7 @@ __device__ f3 light_sample_direct(const dev_scene& S, const ctl_light& L, direct
         r.d = dir * invDist; r.n = f3(0.0f); r.pdf = 1; r.measure = kMeasureDiscrete;
         return f3(L.radiance[0], L.radiance[1], L.radiance[2]) * (invDist * invDist);
     }
+#if CTL_SHADE_FEATURES & 8
     if (L.type == CTL_LIGHT_SPOT) {   // Light.cu:287-301
         r.p = f3(L.position[0], L.position[1], L.position[2]);
         const f3 dir = r.p - r.ref;
@@ -457,6 +482,7 @@ __device__ f3 light_sample_direct(const dev_scene& S, const ctl_light& L, direct
         r.measure = kMeasureSolidAngle;
         return value / pdf;
     }
+#endif
     const float* cdf = (const float*)(S.anim + L.area_dist_index);
     const ctl_shape_tri* tris = (const ctl_shape_tri*)(S.anim + L.triangles_index);
     float pdfTri;

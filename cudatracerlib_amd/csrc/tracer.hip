@@ -106,6 +106,15 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
             S.rough_transmittance = rt_.p;
         }
     }
+    // which shade-kernel build this scene needs (kernels.hip launch_shade)
+    S.shade_features = 0;
+    for (uint32_t i = 0; i < d.n_lights_buf; i++) if (d.lights[i].type != CTL_LIGHT_POINT && d.lights[i].type != CTL_LIGHT_DIFFUSE) S.shade_features |= kShadeMoreLights;
+    for (uint32_t i = 0; i < d.n_materials; i++) {
+        const uint32_t t = d.materials[i].bsdf_type;
+        if (t == CTL_BSDF_THINDIELECTRIC || t == CTL_BSDF_ROUGHDIELECTRIC || t == CTL_BSDF_PLASTIC || t == CTL_BSDF_PHONG) S.shade_features |= kShadeMoreBsdfs;
+        if (t == CTL_BSDF_ROUGHDIFFUSE || t == CTL_BSDF_WARD || t == CTL_BSDF_ROUGHPLASTIC) S.shade_features |= kShadeRoughBsdfs;
+        for (int k = 0; k < 4; k++) if (d.materials[i].tex[k].type == CTL_TEX_IMAGE) S.shade_features |= kShadeImageTextures;
+    }
     for (uint32_t i = 0; i < d.n_lights_buf; i++) {
         const ctl_light& L = d.lights[i];
         if (L.type < CTL_LIGHT_POINT || L.type > CTL_LIGHT_INFINITE) throw std::runtime_error("ctl_scene_create: unknown light type " + std::to_string(L.type));
