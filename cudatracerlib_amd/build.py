@@ -10,7 +10,7 @@ import os, subprocess, sys, glob
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libctl_amd.so")
-SRCS = ["kernels.hip", "shade_basic.hip", "shade_full.hip", "tracer.hip", "capi.hip", "scene_builder.cpp", "bvh_builder.cpp", "flatten.cpp", "mitsuba_loader.cpp"]
+SRCS = ["kernels.hip", "shade_basic.hip", "shade_full.hip", "tracer.hip", "capi.hip", "scene_builder.cpp", "bvh_builder.cpp", "flatten.cpp", "mitsuba_loader.cpp", "image_io.cpp", "mesh_io.cpp"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-pthread"]
 
@@ -40,7 +40,7 @@ def build(force=False, verbose=True):
     bad = [s for s, p in procs if p.wait() != 0]
     if bad:
         raise RuntimeError("hipcc failed for: " + ", ".join(bad))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", OUT] + objs + ["-pthread"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", OUT] + objs + ["-pthread", "-lz"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

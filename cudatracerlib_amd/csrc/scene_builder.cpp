@@ -99,20 +99,24 @@ static f3 tri_data_center_normal(const ctl_triangle_data& T, const m34& l2w) {
 }
 
 // Mesh::ComputeVertexNormals (Engine/Mesh.cpp:151-190), "sphere inscribed polytope" weights
-static void compute_vertex_normals(const float* V, const uint32_t* I, uint32_t nv, uint32_t nt, std::vector<f3>& N) {
+static aabb box_transform(const aabb& b, const float* m);
+
+static void compute_vertex_normals(const float* V, const uint32_t* I, uint32_t nv, uint32_t nt, std::vector<f3>& N, bool flip = false) {
     N.assign(nv, f3(0.0f));
     auto vtx = [&](uint32_t i) { return f3(V[3 * i], V[3 * i + 1], V[3 * i + 2]); };
+    const float flip_coeff = flip ? -1.0f : 1.0f;
     for (uint32_t f = 0; f < nt; f++) {
         uint32_t i1 = I ? I[f * 3] : f * 3, i2 = I ? I[f * 3 + 1] : f * 3 + 1, i3 = I ? I[f * 3 + 2] : f * 3 + 2;
         f3 v1 = vtx(i1), v2 = vtx(i2), v3 = vtx(i3);
-        auto nor = [&](f3 pb, f3 n1, f3 n2) { return 1.0f * cross(n1 - pb, n2 - pb) / (len_sqr(n1 - pb) * len_sqr(n2 - pb)); };
+        auto nor = [&](f3 pb, f3 n1, f3 n2) { return flip_coeff * cross(n1 - pb, n2 - pb) / (len_sqr(n1 - pb) * len_sqr(n2 - pb)); };
         N[i1] = N[i1] + nor(v1, v3, v2); N[i2] = N[i2] + nor(v2, v1, v3); N[i3] = N[i3] + nor(v3, v2, v1);
     }
     for (uint32_t a = 0; a < nv; a++) N[a] = normalize(N[a]);
 }
 
 uint32_t scene_builder::add_mesh(const float* positions, uint32_t n_vert, const uint32_t* indices, uint32_t n_tri, const float* normals,
-                                 const float* uvs, const uint8_t* tri_material, const ctl_material* materials, uint32_t n_mat) {
+                                 const float* uvs, const uint8_t* tri_material, const ctl_material* materials, uint32_t n_mat,
+                                 bool flip_normals, bool face_normals, float max_smooth_angle) {
     if (!positions || n_tri == 0 || n_mat == 0 || !materials) throw std::runtime_error("ctl_builder_add_mesh: empty mesh or no material");
     if (!indices && n_vert != n_tri * 3) throw std::runtime_error("ctl_builder_add_mesh: triangle soup needs n_vert == 3*n_tri");
     mesh_rec mr{};
@@ -120,7 +124,7 @@ uint32_t scene_builder::add_mesh(const float* positions, uint32_t n_vert, const 
     mr.mat_offset = (uint32_t)mesh_materials.size(); mr.n_mat = n_mat;
     mesh_materials.insert(mesh_materials.end(), materials, materials + n_mat);
     std::vector<f3> comp;
-    if (!normals) compute_vertex_normals(positions, indices, n_vert, n_tri, comp);
+    if (!normals || flip_normals) compute_vertex_normals(positions, indices, n_vert, n_tri, comp, flip_normals);   // Mesh.cpp:216-217
     auto vidx = [&](uint32_t ti, int j) { return indices ? indices[ti * 3 + j] : ti * 3 + j; };
     auto vtx = [&](uint32_t i) { return f3(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]); };
     mr.box.reset();
@@ -134,9 +138,16 @@ uint32_t scene_builder::add_mesh(const float* positions, uint32_t n_vert, const 
             if (l >= n_vert) throw std::runtime_error("ctl_builder_add_mesh: vertex index out of range");
             p[j] = vtx(l);
             t[j] = uvs ? f2{ uvs[2 * l], uvs[2 * l + 1] } : f2{ 0.0f, 0.0f };
-            n[j] = normals ? normalize(f3(normals[3 * l], normals[3 * l + 1], normals[3 * l + 2])) : comp[l];
+            n[j] = (normals && !flip_normals) ? normalize(f3(normals[3 * l], normals[3 * l + 1], normals[3 * l + 2])) : comp[l];
             float pp[3] = { p[j].x, p[j].y, p[j].z };
             boxes[ti].grow(pp); mr.box.grow(pp);
+        }
+        if (face_normals || max_smooth_angle != 0) {   // Mesh.cpp:247-267
+            f3 n_face = normalize(cross(p[0] - p[1], p[2] - p[1]));
+            if (flip_normals) n_face = -n_face;
+            bool use_face = face_normals;
+            if (!face_normals) for (int j = 0; j < 3; j++) if (acosf(dot(n_face, n[j])) > max_smooth_angle) use_face = true;
+            if (use_face) n[0] = n[1] = n[2] = n_face;
         }
         uint32_t mi = tri_material ? tri_material[ti] : 0;
         if (mi >= n_mat) throw std::runtime_error("ctl_builder_add_mesh: triangle material index out of range");
@@ -180,6 +191,37 @@ uint32_t scene_builder::add_node(uint32_t mesh_index, const ctl_float4x4* to_wor
         throw std::runtime_error("ctl_builder_add_node: node transform is singular");
     xf.push_back(m); ixf.push_back(inv);
     return (uint32_t)nodes.size() - 1;
+}
+
+// DynamicScene::SetNodeTransform (Engine/DynamicScene.cpp:338-346).  Area lights created from the node BEFORE the call keep the
+// triangles of the old transform (the reference recalculates them; the loader always sets the transform first).
+void scene_builder::set_node_transform(uint32_t node_index, const ctl_float4x4& m) {
+    if (node_index >= nodes.size()) throw std::runtime_error("set_node_transform: bad node index");
+    if (m.m[12] != 0.0f || m.m[13] != 0.0f || m.m[14] != 0.0f || m.m[15] != 1.0f) throw std::runtime_error("set_node_transform: node transform must be affine (last row 0 0 0 1)");
+    ctl_float4x4 inv; mat_inverse(m.m, inv.m);
+    if (inv.m[12] != 0.0f || inv.m[13] != 0.0f || inv.m[14] != 0.0f || !(inv.m[15] > 0.0f)) throw std::runtime_error("set_node_transform: node transform is singular");
+    xf[node_index] = m; ixf[node_index] = inv;
+}
+// `mat->bsdf = ...; mat->bsdf.As()->m_enableTwoSided = ...` of BsdfParser::apply_bsdf (ObjectParser.h:996-1010): replaces the BSDF
+// of one of the node's materials and keeps its NodeLightIndex
+void scene_builder::set_node_bsdf(uint32_t node_index, uint32_t local_material, const ctl_material& m) {
+    if (node_index >= nodes.size()) throw std::runtime_error("set_node_bsdf: bad node index");
+    const ctl_node& N = nodes[node_index];
+    if (local_material >= mesh_info[N.mesh_index].n_mat) throw std::runtime_error("set_node_bsdf: bad material index");
+    ctl_material& dst = mats[N.material_offset + local_material];
+    const uint32_t nli = dst.node_light_index;
+    dst = m; dst.node_light_index = nli;
+}
+const ctl_material& scene_builder::node_material(uint32_t node_index, uint32_t local_material) const {
+    const ctl_node& N = nodes.at(node_index);
+    if (local_material >= mesh_info[N.mesh_index].n_mat) throw std::runtime_error("node_material: bad material index");
+    return mats[N.material_offset + local_material];
+}
+// AABB of all nodes (DynamicScene::getSceneBox)
+aabb scene_builder::scene_box() const {
+    aabb scene; scene.reset();
+    for (size_t i = 0; i < nodes.size(); i++) { const aabb b = box_transform(mesh_info[nodes[i].mesh_index].box, xf[i].m); scene.grow(b); }
+    return scene;
 }
 
 // DynamicScene::CreateLight(node, matName, L) + CreateShape (Engine/DynamicScene.cpp:689-767) + ShapeSet (Engine/ShapeSet.cpp:17-59)

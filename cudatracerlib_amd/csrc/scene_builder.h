@@ -37,8 +37,13 @@ struct scene_builder {
     bool have_camera = false;
 
     uint32_t add_mesh(const float* positions, uint32_t n_vert, const uint32_t* indices, uint32_t n_tri, const float* normals, const float* uvs,
-                      const uint8_t* tri_material, const ctl_material* materials, uint32_t n_mat);
+                      const uint8_t* tri_material, const ctl_material* materials, uint32_t n_mat,
+                      bool flip_normals = false, bool face_normals = false, float max_smooth_angle = 0.0f);   // Mesh::CompileMesh options (Mesh.cpp:199)
     uint32_t add_node(uint32_t mesh_index, const ctl_float4x4* to_world);
+    void set_node_transform(uint32_t node_index, const ctl_float4x4& to_world);
+    void set_node_bsdf(uint32_t node_index, uint32_t local_material, const ctl_material& m);
+    const ctl_material& node_material(uint32_t node_index, uint32_t local_material) const;
+    aabb scene_box() const;
     uint32_t add_area_light(uint32_t node_index, uint32_t local_material, const float radiance[3]);
     uint32_t add_point_light(const float position[3], const float intensity[3]);
     uint32_t add_spot_light(const float position[3], const float target[3], const float intensity[3], float cutoff_deg, float beam_deg);

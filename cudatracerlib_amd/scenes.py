@@ -251,3 +251,61 @@ def env_scene(width=96, height=64, rotate_env=False, point_filter=False, extra_l
     sc.setCamera((0, 5, 14), (0, 1, 0), (0, 1, 0), 45.0, width, height)
     sc.UpdateScene()
     return sc
+
+
+def write_cornell_mitsuba(directory, width=256, height=256, glass_sphere=False):
+    """C1 / C2 as a Mitsuba-0.5 scene (SURVEY §8d "Cornell box authored in-repo as Mitsuba XML"): <directory>/cornell.xml plus
+    one OBJ per surface group under meshes/.  Geometry and materials are those of ``cornell_box``; returns the XML path."""
+    import os
+    os.makedirs(os.path.join(directory, "meshes"), exist_ok=True)
+    center = (278, 274, 280)
+
+    def obj(name, quads, normals_from=None, inward=True):
+        lines, k = [], 0
+        for p in quads:
+            n = _quad_normal(p, center if normals_from is None else normals_from)
+            if not inward:
+                n = -n
+            P = np.asarray(p, np.float64)
+            # counter-clockwise as seen from the side the normal points to (the importer reverses the order)
+            if np.dot(np.cross(P[1] - P[0], P[2] - P[0]), n) < 0:
+                P = P[::-1]
+            lines += ["v %.9g %.9g %.9g" % tuple(v) for v in P] + ["vn %.9g %.9g %.9g" % tuple(n)] * 4
+            lines += ["f %d//%d %d//%d %d//%d %d//%d" % tuple(np.repeat(np.arange(k + 1, k + 5), 2))]
+            k += 4
+        with open(os.path.join(directory, "meshes", name + ".obj"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    white = [[[552.8, 0, 0], [0, 0, 0], [0, 0, 559.2], [549.6, 0, 559.2]], [[556, 548.8, 0], [556, 548.8, 559.2], [0, 548.8, 559.2], [0, 548.8, 0]],
+             [[549.6, 0, 559.2], [0, 0, 559.2], [0, 548.8, 559.2], [556, 548.8, 559.2]]]
+    obj("white", white)
+    obj("green", [[[0, 0, 559.2], [0, 0, 0], [0, 548.8, 0], [0, 548.8, 559.2]]])
+    obj("red", [[[552.8, 0, 0], [549.6, 0, 559.2], [556, 548.8, 559.2], [556, 548.8, 0]]])
+    obj("light", [[[343, 548.3, 227], [343, 548.3, 332], [213, 548.3, 332], [213, 548.3, 227]]])
+    short = [[[130, 165, 65], [82, 165, 225], [240, 165, 272], [290, 165, 114]], [[290, 0, 114], [290, 165, 114], [240, 165, 272], [240, 0, 272]],
+             [[130, 0, 65], [130, 165, 65], [290, 165, 114], [290, 0, 114]], [[82, 0, 225], [82, 165, 225], [130, 165, 65], [130, 0, 65]],
+             [[240, 0, 272], [240, 165, 272], [82, 165, 225], [82, 0, 225]]]
+    tall = [[[423, 330, 247], [265, 330, 296], [314, 330, 456], [472, 330, 406]], [[423, 0, 247], [423, 330, 247], [472, 330, 406], [472, 0, 406]],
+            [[472, 0, 406], [472, 330, 406], [314, 330, 456], [314, 0, 456]], [[314, 0, 456], [314, 330, 456], [265, 330, 296], [265, 0, 296]],
+            [[265, 0, 296], [265, 330, 296], [423, 330, 247], [423, 0, 247]]]
+    for name, block in (("short", short), ("tall", tall)):
+        c = np.mean(np.asarray(block, np.float64).reshape(-1, 3), axis=0); c[1] = 80.0
+        obj(name, block, normals_from=c, inward=False)
+    rgb = lambda c: "%g, %g, %g" % tuple(c)
+    shape = lambda name, bsdf, extra="": '  <shape type="obj"><string name="filename" value="meshes/%s.obj"/><ref id="%s"/>%s</shape>\n' % (name, bsdf, extra)
+    xml = ('<?xml version="1.0" encoding="utf-8"?>\n<scene version="0.5.0">\n'
+           '  <integrator type="path"><integer name="maxDepth" value="8"/></integrator>\n'
+           '  <sensor type="perspective">\n    <float name="fov" value="39.3077"/>\n    <string name="fovAxis" value="x"/>\n'
+           '    <transform name="toWorld"><lookat origin="278, 273, -800" target="278, 273, 0" up="0, 1, 0"/></transform>\n'
+           '    <film type="hdrfilm"><integer name="width" value="%d"/><integer name="height" value="%d"/></film>\n  </sensor>\n' % (width, height))
+    for name, c in (("white", WHITE), ("red", RED), ("green", GREEN), ("lamp", (0.78, 0.78, 0.78))):
+        xml += '  <bsdf type="diffuse" id="%s"><rgb name="reflectance" value="%s"/></bsdf>\n' % (name, rgb(c))
+    xml += shape("white", "white") + shape("red", "red") + shape("green", "green") + shape("short", "white") + shape("tall", "white")
+    xml += shape("light", "lamp", '<emitter type="area"><rgb name="radiance" value="%s"/></emitter>' % rgb(LIGHT_RADIANCE))
+    if glass_sphere:
+        xml += ('  <shape type="sphere"><float name="radius" value="90"/><point name="center" x="186" y="255.5" z="169"/>'
+                '<bsdf type="dielectric"><float name="intIOR" value="1.5"/><float name="extIOR" value="1.0"/></bsdf></shape>\n')
+    xml += "</scene>\n"
+    path = os.path.join(directory, "cornell.xml")
+    with open(path, "w") as f:
+        f.write(xml)
+    return path

@@ -77,6 +77,16 @@ def test_environment_map_bitmap_texture_and_delta_lights(gpu, orc, kw):
     assert want[..., :3].mean() > 0.1
 
 
+def test_mitsuba_xml_scene(gpu, orc, tmp_path):
+    """ParseMitsubaScene -> UpdateScene -> render: Cornell box + glass sphere authored as Mitsuba XML (BASELINE config 2 geometry)"""
+    path = scenes.write_cornell_mitsuba(str(tmp_path), 64, 64, glass_sphere=True)
+    sc = gpu.DynamicScene()
+    assert sc.ParseMitsubaScene(path) == (64, 64)
+    sc.UpdateScene()
+    got, want, tr, rays = render_pair(gpu, orc, sc, 64, 64, 3)
+    assert_close(got, want)
+
+
 def test_environment_map_without_nee(gpu, orc):
     sc = scenes.env_scene(64, 48)
     got, want, _, _ = render_pair(gpu, orc, sc, 64, 48, 2, max_len=4, rr=2, direct=False)
