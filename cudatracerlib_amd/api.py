@@ -508,6 +508,16 @@ class Image:
     def device_ptr(self):
         return lib.ctl_image_device_ptr(self._h)
 
+    def applyImagePipeline(self, splat_scale=0.0):
+        """applyImagePipeline without filter / post-process: (h, w, 4) uint8 sRGB display image."""
+        a = np.zeros((self.height, self.width), np.uint32)
+        _check(lib.ctl_image_apply_pipeline(self._h, f32(splat_scale), a.ctypes.data_as(C.c_void_p)))
+        return a.view(np.uint8).reshape(self.height, self.width, 4)
+
+    def WriteDisplayImage(self, path, splat_scale=0.0):
+        """Image::WriteDisplayImage: .png (display image), .hdr / .pfm (linear)."""
+        _check(lib.ctl_image_write_file(self._h, f32(splat_scale), path.encode()))
+
     def getRGB(self, splat_scale=0.0):
         """copySamplesToOutput (Kernel/ImagePipeline/ImagePipeline.cu:14-30) up to linear RGB."""
         a = np.zeros((self.height, self.width, 3), np.float32)

@@ -92,6 +92,22 @@ __global__ __launch_bounds__(kBlock) void k_resolve_rgb(const ctl_pixel_data* __
     }
 }
 
+// copySamplesToOutput (Kernel/ImagePipeline/ImagePipeline.cu:8-23): PixelData::toSpectrum(splatScale) -> sRGB transfer curve
+// (Spectrum.cu:229-235) -> RGBCOL (Spectrum.h:521-526), the pipeline without filter / post-process
+__global__ __launch_bounds__(kBlock) void k_apply_pipeline(const ctl_pixel_data* __restrict__ image, uint32_t n, float splat_scale, uint32_t* __restrict__ out) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const ctl_pixel_data p = image[i];
+        const float w = p.weight_sum != 0 ? p.weight_sum : 1;
+        uint32_t packed = 255u << 24;
+        for (int c = 0; c < 3; c++) {
+            float v = p.rgb[c] / w + p.rgb_splat[c] * splat_scale;
+            v = v <= 0.0031308f ? 12.92f * v : 1.055f * powf(v, (float)(1.0 / 2.4)) - 0.055f;
+            packed |= (uint32_t)(unsigned char)(clampf(v, 0.0f, 1.0f) * 255.0f) << (8 * c);
+        }
+        out[i] = packed;
+    }
+}
+
 void apply_tuning_from_env() {
     static bool done = false;
     if (done) return;
@@ -132,6 +148,9 @@ void launch_finalize(const launch_ctx& lc, const wave_queues& Q, const pass_para
 }
 void launch_accumulate_stats(const launch_ctx& lc, const wave_queues& Q, int max_depth) {
     hipLaunchKernelGGL(k_accumulate_stats, dim3(1), dim3(64), 0, lc.stream, Q, max_depth);
+}
+void launch_apply_pipeline(const launch_ctx& lc, const ctl_pixel_data* image, uint32_t n, float splat_scale, uint32_t* rgbcol_out) {
+    hipLaunchKernelGGL(k_apply_pipeline, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, image, n, splat_scale, rgbcol_out);
 }
 void launch_resolve_rgb(const launch_ctx& lc, const ctl_pixel_data* image, uint32_t n, float splat_scale, float* rgb_out) {
     hipLaunchKernelGGL(k_resolve_rgb, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, image, n, splat_scale, rgb_out);

@@ -4,7 +4,10 @@
 #include "tracer.h"
 #include "scene_builder.h"
 #include "flatten.h"
+#include "image_io.h"
+#include "mitsuba_loader.h"   // unsupported_error
 #include <algorithm>
+#include <cctype>
 #include <cstring>
 #include <string>
 
@@ -184,6 +187,29 @@ void Image::resolve_rgb(float splat_scale, float* host_rgb) {
     launch_resolve_rgb(lc, px_.p, (uint32_t)px_.n, splat_scale, rgb_.p);
     CTL_HIP(hipDeviceSynchronize());
     CTL_HIP(hipMemcpy(host_rgb, rgb_.p, px_.n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+}
+
+void Image::apply_pipeline(float splat_scale, uint32_t* host_rgbcol) {
+    if (!out_.p) out_.alloc(px_.n);
+    CTL_HIP(hipDeviceSynchronize());
+    launch_ctx lc{ nullptr, 1024 };
+    launch_apply_pipeline(lc, px_.p, (uint32_t)px_.n, splat_scale, out_.p);
+    CTL_HIP(hipDeviceSynchronize());
+    CTL_HIP(hipMemcpy(host_rgbcol, out_.p, px_.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+}
+void Image::write_file(float splat_scale, const char* path) {
+    const std::string p(path); const size_t dot = p.find_last_of('.');
+    std::string ext = dot == std::string::npos ? "" : p.substr(dot + 1);
+    for (auto& c : ext) c = (char)std::tolower((unsigned char)c);
+    if (ext == "hdr" || ext == "pfm") {   // toFreeImage(true): linear float data
+        std::vector<float> rgb(px_.n * 3); resolve_rgb(splat_scale, rgb.data());
+        if (ext == "hdr") write_hdr(p, rgb.data(), w_, h_); else write_pfm(p, rgb.data(), w_, h_);
+    } else if (ext == "png") {            // toFreeImage(false): the processed (gamma-corrected, 8-bit) data
+        std::vector<uint32_t> col(px_.n); apply_pipeline(splat_scale, col.data());
+        std::vector<float> rgb(px_.n * 3);
+        for (size_t i = 0; i < px_.n; i++) for (int c = 0; c < 3; c++) rgb[i * 3 + c] = (float)((col[i] >> (8 * c)) & 0xff) / 255.0f;
+        write_png(p, rgb.data(), w_, h_, false);
+    } else throw unsupported_error("Failed saving Screenshot! (only .png, .hdr and .pfm writers are built in)");
 }
 
 // ------------------------------------------------------------------------------------------------ timing

@@ -298,6 +298,12 @@ int ctl_image_write_pixels(ctl_image* img, const ctl_pixel_data* host_in);
 void* ctl_image_device_ptr(ctl_image* img);                                 /* PixelData* in HBM (RCCL gather) */
 /* copySamplesToOutput (Kernel/ImagePipeline/ImagePipeline.cu:14-30): rgb/weight + splat*scale -> linear RGB float */
 int ctl_image_resolve_rgb(ctl_image* img, float splat_scale, float* host_rgb_out);
+/* applyImagePipeline(tracer, img, filter = 0, process = 0) (Kernel/ImagePipeline/ImagePipeline.cu:54-63): the display image,
+ * sRGB transfer curve + 8-bit RGBCOL per pixel (byte 0 = r, alpha = 255).  splat_scale = TracerBase::getSplatScale() = 1/passes. */
+int ctl_image_apply_pipeline(ctl_image* img, float splat_scale, uint32_t* host_rgbcol_out);
+/* Image::WriteDisplayImage (Engine/Image.cpp:67-75): .png writes the display image, .hdr / .pfm the linear float image.
+ * Other formats (the reference saves through FreeImage) -> CTL_ERR_UNSUPPORTED. */
+int ctl_image_write_file(ctl_image* img, float splat_scale, const char* path);
 
 /* ------------------------------------------------------------------- tracer */
 typedef struct ctl_tracer ctl_tracer;

@@ -87,6 +87,38 @@ def test_mitsuba_xml_scene(gpu, orc, tmp_path):
     assert_close(got, want)
 
 
+def test_image_pipeline_and_output_files(gpu, tmp_path):
+    """applyImagePipeline (no filter / post-process) = toSpectrum(splatScale) -> sRGB curve -> RGBCOL; WriteDisplayImage"""
+    import struct, zlib
+    sc = scenes.cornell_box(40, 32)
+    scene = gpu.Scene(sc.desc)
+    tr = gpu.WavefrontPathTracer(); tr.getParameters().setValue("MaxPathLength", 4)
+    tr.Resize(40, 32); tr.InitializeScene(scene)
+    img = gpu.Image(40, 32)
+    tr.DoPasses(img, 4, new_trace=True)
+    px = img.getPixelData()
+    lin = px[..., :3] / np.where(px[..., 6:7] != 0, px[..., 6:7], 1) + px[..., 3:6] * 0.25
+    assert np.allclose(img.getRGB(0.25), lin, rtol=1e-6, atol=1e-7)
+    srgb = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(np.maximum(lin, 0), 1 / 2.4) - 0.055)
+    want = (np.clip(srgb, 0, 1) * 255).astype(np.uint8)
+    got = img.applyImagePipeline(0.25)
+    assert np.all(got[..., 3] == 255)
+    assert np.abs(got[..., :3].astype(int) - want.astype(int)).max() <= 1        # powf vs numpy at a truncation boundary
+    for ext in ("png", "hdr", "pfm"):
+        img.WriteDisplayImage(str(tmp_path / ("out." + ext)), 0.25)
+    raw = open(tmp_path / "out.png", "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">II", raw[16:24]) == (40, 32)
+    idat = raw[raw.index(b"IDAT") + 4: raw.index(b"IEND") - 8]
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(32, 1 + 40 * 3)
+    assert np.all(rows[:, 0] == 0) and np.array_equal(rows[:, 1:].reshape(32, 40, 3), got[..., :3])
+    pfm = open(tmp_path / "out.pfm", "rb").read()
+    head = b"PF\n40 32\n-1.0\n"
+    assert pfm.startswith(head) and np.allclose(np.frombuffer(pfm[len(head):], "<f4").reshape(32, 40, 3)[::-1], img.getRGB(0.25))
+    assert open(tmp_path / "out.hdr", "rb").read().startswith(b"#?RADIANCE")
+    with pytest.raises(gpu.CtlError):
+        img.WriteDisplayImage(str(tmp_path / "out.jpg"))
+
+
 def test_environment_map_without_nee(gpu, orc):
     sc = scenes.env_scene(64, 48)
     got, want, _, _ = render_pair(gpu, orc, sc, 64, 48, 2, max_len=4, rr=2, direct=False)
