@@ -614,3 +614,10 @@ class SequenceGenerator:
         t2 = np.zeros(2 * SAMPLER_N1, np.float32)
         _check(lib.ctl_sequence_generator_compute(self._h, _fp(t1), _fp(t2)))
         return t1, t2
+
+    def compute_many(self, n, threads=8):
+        """tables of the next n passes, (n, 30*4096) and (n, 2*30*4096), generated in parallel through XORWOW skip-ahead"""
+        t1 = np.zeros((n, SAMPLER_N1), np.float32)
+        t2 = np.zeros((n, 2 * SAMPLER_N1), np.float32)
+        _check(lib.ctl_sequence_generator_compute_many(self._h, u32(n), _fp(t1), _fp(t2), u32(threads)))
+        return t1, t2

@@ -100,6 +100,12 @@ int ctl_sequence_generator_create(ctl_sequence_generator** out) { CTL_REQUIRE(ou
 void ctl_sequence_generator_destroy(ctl_sequence_generator* g) { delete g; }
 int ctl_sequence_generator_compute(ctl_sequence_generator* g, float* tables_1d, float* tables_2d) { CTL_REQUIRE(g && tables_1d && tables_2d, "null argument"); CTL_TRY g->g.compute(tables_1d, tables_2d); CTL_CATCH }
 
+int ctl_sequence_generator_compute_many(ctl_sequence_generator* g, uint32_t n_passes, float* tables_1d, float* tables_2d, uint32_t threads) {
+    CTL_REQUIRE(g && tables_1d && tables_2d, "null argument");
+    const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH;
+    CTL_TRY g->g.compute_many(tables_1d, tables_2d, n_passes, n1, 2 * n1, threads); CTL_CATCH
+}
+
 // ---- image
 int ctl_image_create(uint32_t width, uint32_t height, ctl_image** out) { CTL_REQUIRE(out && width && height, "bad argument"); CTL_TRY *out = new ctl_image(width, height); CTL_CATCH }
 void ctl_image_destroy(ctl_image* img) { delete img; }

@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include <thread>
+#include <algorithm>
 
 namespace ctl {
 
@@ -48,20 +50,81 @@ public:
     }
 };
 
+// 160x160 bit matrices over GF(2) acting on the xorwow v-state (rows = images of the state bits)
+struct xorwow_matrix {
+    std::vector<uint32_t> r;   // 160 rows x 5 words
+    xorwow_matrix() : r(160 * 5, 0) {}
+    static xorwow_matrix one_step() {
+        xorwow_matrix M;
+        for (int i = 0; i < 5; i++) for (int j = 0; j < 32; j++) {
+            xorwow s; s.d = 0; std::memset(s.v, 0, sizeof(s.v)); s.v[i] = 1u << j; s.next();
+            std::memcpy(&M.r[(i * 32 + j) * 5], s.v, 20);
+        }
+        return M;
+    }
+    void apply(const uint32_t* in, uint32_t* out) const {
+        uint32_t o[5] = { 0, 0, 0, 0, 0 };
+        for (int i = 0; i < 5; i++) for (int j = 0; j < 32; j++) if (in[i] & (1u << j)) for (int k = 0; k < 5; k++) o[k] ^= r[(i * 32 + j) * 5 + k];
+        std::memcpy(out, o, 20);
+    }
+    xorwow_matrix then(const xorwow_matrix& B) const {   // first *this, then B
+        xorwow_matrix C; for (int row = 0; row < 160; row++) B.apply(&r[row * 5], &C.r[row * 5]); return C;
+    }
+    static xorwow_matrix power(uint64_t n) {   // (one step)^n
+        xorwow_matrix result; for (int i = 0; i < 160; i++) result.r[i * 5 + i / 32] = 1u << (i % 32);   // identity
+        xorwow_matrix sq = one_step();
+        for (; n; n >>= 1) { if (n & 1) result = result.then(sq); if (n >> 1) sq = sq.then(sq); }
+        return result;
+    }
+};
+
 class sequence_generator {
     xorwow rng_;
+    xorwow_matrix pass_jump_; bool have_jump_ = false;
+    static constexpr unsigned N = 4096, L = 30;
+    static constexpr uint64_t kDrawsPerPass = (uint64_t)N * L * 3;   // L 1-D values + L 2-D values per sequence
+    static void fill(xorwow& rng, float* t1, float* t2) {
+        // the draws come in sequence-major order (Sampler.h:76-84) while the tables are element-major: go through a 16-sequence
+        // tile so that the table is written one whole cache line at a time
+        constexpr unsigned TS = 16;
+        float a[TS][L], b[TS][2 * L];
+        for (unsigned s0 = 0; s0 < N; s0 += TS) {
+            for (unsigned s = 0; s < TS; s++) {
+                for (unsigned i = 0; i < L; i++) a[s][i] = rng.uniform();
+                // Vec2f(rng.randomFloat(), rng.randomFloat()) (Sampler.h:83): the reference's host compilers evaluate
+                // constructor arguments right to left, so the first draw is .y
+                for (unsigned i = 0; i < L; i++) { const float y = rng.uniform(), x = rng.uniform(); b[s][2 * i] = x; b[s][2 * i + 1] = y; }
+            }
+            for (unsigned i = 0; i < L; i++) for (unsigned s = 0; s < TS; s++) {
+                t1[i * N + s0 + s] = a[s][i];
+                t2[2 * (i * N + s0 + s)] = b[s][2 * i]; t2[2 * (i * N + s0 + s) + 1] = b[s][2 * i + 1];
+            }
+        }
+    }
 public:
     sequence_generator() { rng_.init(1234, 7539414); }
     // tables for the next pass: t1[e*4096 + s], t2[2*(e*4096 + s) + {0,1}]
-    void compute(float* t1, float* t2) {
-        const unsigned N = 4096, L = 30;
-        for (unsigned s = 0; s < N; s++) {
-            for (unsigned i = 0; i < L; i++) t1[i * N + s] = rng_.uniform();
-            // Vec2f(rng.randomFloat(), rng.randomFloat()) (Sampler.h:83): the reference's host compilers evaluate
-            // constructor arguments right to left, so the first draw is .y
-            for (unsigned i = 0; i < L; i++) { const float y = rng_.uniform(), x = rng_.uniform(); t2[2 * (i * N + s)] = x; t2[2 * (i * N + s) + 1] = y; }
-        }
-    }
+    void compute(float* t1, float* t2) { fill(rng_, t1, t2); }
+    // tables of the next n passes, generated by up to `threads` host threads.  The stream is the same single XORWOW stream the
+    // reference draws from: pass k starts kDrawsPerPass * k draws further on, reached with the GF(2) jump matrix of one pass
+    // (the Weyl counter d advances linearly).
+    void compute_many(float* t1, float* t2, unsigned n, size_t stride1, size_t stride2, unsigned threads);
 };
+
+inline void sequence_generator::compute_many(float* t1, float* t2, unsigned n, size_t stride1, size_t stride2, unsigned threads) {
+    if (n == 0) return;
+    if (n == 1 || threads <= 1) { for (unsigned k = 0; k < n; k++) compute(t1 + k * stride1, t2 + k * stride2); return; }
+    if (!have_jump_) { pass_jump_ = xorwow_matrix::power(kDrawsPerPass); have_jump_ = true; }
+    std::vector<xorwow> start(n + 1);
+    start[0] = rng_;
+    for (unsigned k = 0; k < n; k++) { start[k + 1] = start[k]; pass_jump_.apply(start[k].v, start[k + 1].v); start[k + 1].d = start[k].d + (uint32_t)(362437u * (uint32_t)kDrawsPerPass); }
+    const unsigned T = std::min(threads, n);
+    std::vector<std::thread> pool;
+    auto work = [&](unsigned tid) { for (unsigned k = tid; k < n; k += T) { xorwow r = start[k]; fill(r, t1 + k * stride1, t2 + k * stride2); } };
+    for (unsigned t = 1; t < T; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    rng_ = start[n];
+}
 
 } // namespace ctl

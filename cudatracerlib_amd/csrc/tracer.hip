@@ -7,6 +7,7 @@
 #include "image_io.h"
 #include "mitsuba_loader.h"   // unsupported_error
 #include <algorithm>
+#include <thread>
 #include <cctype>
 #include <cstring>
 #include <string>
@@ -274,10 +275,11 @@ template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_
         const unsigned int nb = std::min(B, n - k), slot = batch_idx % ring;
         if (batch_idx >= ring) CTL_HIP(hipEventSynchronize(slot_done[slot]));   // the batch that last used this slot has finished
         float* a = h_t1 + (size_t)slot * B * n1; float* b = h_t2 + (size_t)slot * B * n2;
-        for (unsigned int j = 0; j < nb; j++) {
-            if (have_user_tables) { std::memcpy(a + j * n1, user_t1.data(), n1 * 4); std::memcpy(b + j * n2, user_t2.data(), n2 * 4); have_user_tables = false; }
-            else m_SamplingSequenceGenerator.compute(a + j * n1, b + j * n2);
-        }
+        unsigned int j0 = 0;
+        if (have_user_tables) { std::memcpy(a, user_t1.data(), n1 * 4); std::memcpy(b, user_t2.data(), n2 * 4); have_user_tables = false; j0 = 1; }
+        // one XORWOW stream as in the reference (Kernel/Sampler.h:57-85), generated by several host threads through skip-ahead:
+        // a rank that owns 1/8 of the frame renders 16 passes per launch and must not wait 16 ms for its tables
+        m_SamplingSequenceGenerator.compute_many(a + j0 * n1, b + j0 * n2, nb - j0, n1, n2, std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
         CTL_HIP(hipMemcpyAsync(d_t1.p + (size_t)slot * B * n1, a, (size_t)nb * n1 * 4, hipMemcpyHostToDevice, stream));
         CTL_HIP(hipMemcpyAsync(d_t2.p + (size_t)slot * B * n2, b, (size_t)nb * n2 * 4, hipMemcpyHostToDevice, stream));
         m_uPassesDone += nb;

@@ -287,6 +287,9 @@ int ctl_sequence_generator_create(ctl_sequence_generator** out);
 void ctl_sequence_generator_destroy(ctl_sequence_generator* g);
 /* SamplingSequenceGeneratorHost::Compute (Kernel/Sampler.h:36-55): next pass's tables into host buffers. */
 int ctl_sequence_generator_compute(ctl_sequence_generator* g, float* tables_1d, float* tables_2d);
+/* the tables of the next n_passes passes (consecutive [30*4096] / [30*4096*2] blocks), generated by up to `threads` host
+ * threads; same values as n_passes calls of ctl_sequence_generator_compute (XORWOW skip-ahead) */
+int ctl_sequence_generator_compute_many(ctl_sequence_generator* g, uint32_t n_passes, float* tables_1d, float* tables_2d, uint32_t threads);
 
 /* -------------------------------------------------------------------- image */
 typedef struct ctl_image ctl_image;

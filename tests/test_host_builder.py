@@ -173,6 +173,19 @@ def test_sequence_generator_matches_oracle(ctl, orc):
         assert np.array_equal(bits(t1), bits(want[k][0])) and np.array_equal(bits(t2), bits(want[k][1]))
 
 
+def test_parallel_table_generation_is_the_same_stream(ctl):
+    """compute_many = skip-ahead by one pass's 368 640 draws per table set: identical bits to sequential generation, and the
+    generator continues from the right state afterwards"""
+    a, b = ctl.SequenceGenerator(), ctl.SequenceGenerator()
+    seq = [a.compute() for _ in range(5)]
+    m1, m2 = b.compute_many(3, threads=3)
+    for k in range(3):
+        assert np.array_equal(m1[k].view(np.uint32), seq[k][0].view(np.uint32)) and np.array_equal(m2[k].view(np.uint32), seq[k][1].view(np.uint32))
+    n1, n2 = b.compute_many(2, threads=8)
+    for k in range(2):
+        assert np.array_equal(n1[k].view(np.uint32), seq[3 + k][0].view(np.uint32)) and np.array_equal(n2[k].view(np.uint32), seq[3 + k][1].view(np.uint32))
+
+
 def test_builder_errors(ctl):
     sc = ctl.DynamicScene()
     with pytest.raises(ctl.CtlError):
