@@ -26,6 +26,7 @@ struct dev_scene {
     const float4* flat_nodes;    // optional single-level world-space BVH over all instanced triangles (flatten.cpp), else nullptr
     const float4* flat_leaves;   // 4 x float4 per leaf entry: world-space Woop rows + {globalTri << 1 | last, node, 0, 0}
     int flat_root;
+    int flat_width;              // 4: flat4_node (64 B), 8: flat8_node (128 B)
     const float4* inst_fwd;      // 3 x float4 per node: forward-transform rows 0..2 (fillDG)
     const uint4* tri_data;       // 2 x uint4 per triangle (TriangleData, 32 B)
     const uint4* node_info;      // per node {material_offset, light0, light1, n_lights}

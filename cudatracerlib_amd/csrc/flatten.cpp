@@ -66,8 +66,8 @@ float round_up(double x) { float f = (float)x; return ((double)f < x) ? std::nex
 
 }  // namespace
 
-bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangles) {
-    out.nodes.clear(); out.leaves.clear();
+bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangles, int width) {
+    out.nodes.clear(); out.nodes8.clear(); out.leaves.clear(); out.width = width == 8 ? 8 : 4;
     // leaf-entry range of every mesh (the woop stream is shared; a mesh ends where the next one starts)
     std::vector<std::pair<uint32_t, uint32_t>> starts;
     for (uint32_t m = 0; m < d.n_meshes; m++) starts.emplace_back(d.meshes[m].bvh_tri_offset / 3, m);
@@ -108,34 +108,88 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     }
     bvh_result R;
     build_bvh(boxes, 4, true, 60, R);
-    // collapse to 4-wide nodes and quantise the child boxes conservatively
-    std::vector<wide4_node> W; int wdepth = 0;
-    collapse_bvh4(R, W, wdepth);
-    out.nodes.resize(W.size());
-    for (size_t i = 0; i < W.size(); i++) {
-        const wide4_node& w = W[i]; flat4_node& f = out.nodes[i];
-        std::memset(&f, 0, sizeof(f));
-        uint32_t* q[3][2] = { { &f.qlo_x, &f.qhi_x }, { &f.qlo_y, &f.qhi_y }, { &f.qlo_z, &f.qhi_z } };
+    // quantise a child box conservatively against the node's own box (one exponent per axis)
+    auto quantise = [&](const aabb& nbox, const aabb* cbox, int n, float origin[3], uint8_t e_out[3], uint8_t qlo[3][8], uint8_t qhi[3][8]) {
         for (int k = 0; k < 3; k++) {
-            f.origin[k] = w.box.lo[k];
-            const double ext = (double)w.box.hi[k] - (double)w.box.lo[k];
+            origin[k] = nbox.lo[k];
+            const double ext = (double)nbox.hi[k] - (double)nbox.lo[k];
             int e = 1;   // smallest normal exponent
             if (ext > 0) { int ex; std::frexp(ext / 255.0, &ex); e = ex + 127; /* 2^ex >= ext/255 */ if (e < 1) e = 1; if (e > 254) e = 254; }
-            f.e[k] = (uint8_t)e;
+            e_out[k] = (uint8_t)e;
             const double step = std::ldexp(1.0, e - 127);
-            for (int c = 0; c < w.n; c++) {
-                long lo = (long)std::floor(((double)w.cbox[c].lo[k] - (double)f.origin[k]) / step);
-                long hi = (long)std::ceil(((double)w.cbox[c].hi[k] - (double)f.origin[k]) / step);
+            for (int c = 0; c < n; c++) {
+                long lo = (long)std::floor(((double)cbox[c].lo[k] - (double)origin[k]) / step);
+                long hi = (long)std::ceil(((double)cbox[c].hi[k] - (double)origin[k]) / step);
                 // the device evaluates origin + step * q in fp32 (one rounding): keep the box conservative under that rounding too
-                while (lo > 0 && (float)((double)f.origin[k] + step * (double)lo) > w.cbox[c].lo[k]) lo--;
-                while (hi < 255 && (float)((double)f.origin[k] + step * (double)hi) < w.cbox[c].hi[k]) hi++;
-                lo = std::min(255L, std::max(0L, lo)); hi = std::min(255L, std::max(0L, hi));
-                *q[k][0] |= (uint32_t)lo << (8 * c); *q[k][1] |= (uint32_t)hi << (8 * c);
+                while (lo > 0 && (float)((double)origin[k] + step * (double)lo) > cbox[c].lo[k]) lo--;
+                while (hi < 255 && (float)((double)origin[k] + step * (double)hi) < cbox[c].hi[k]) hi++;
+                qlo[k][c] = (uint8_t)std::min(255L, std::max(0L, lo)); qhi[k][c] = (uint8_t)std::min(255L, std::max(0L, hi));
             }
         }
-        for (int c = 0; c < 4; c++) {
-            if (c < w.n) { f.mask |= (uint8_t)(1u << c); f.child[c] = w.child[c] >= 0 ? w.child[c] * 4 : w.child[c]; }
-            else f.child[c] = 0x76543210;
+    };
+    int wdepth = 0;
+    if (out.width == 8) {
+        std::vector<wide8_node> W;
+        collapse_bvh8(R, W, wdepth);
+        out.nodes8.resize(W.size());
+        for (size_t i = 0; i < W.size(); i++) {
+            const wide8_node& w = W[i]; flat8_node& f = out.nodes8[i];
+            std::memset(&f, 0, sizeof(f));
+            uint8_t qlo[3][8] = {}, qhi[3][8] = {};
+            quantise(w.box, w.cbox, w.n, f.origin, f.e, qlo, qhi);
+            uint32_t* ql[3] = { f.qlo_x, f.qlo_y, f.qlo_z }; uint32_t* qh[3] = { f.qhi_x, f.qhi_y, f.qhi_z };
+            for (int k = 0; k < 3; k++) for (int c = 0; c < w.n; c++) { ql[k][c / 4] |= (uint32_t)qlo[k][c] << (8 * (c % 4)); qh[k][c / 4] |= (uint32_t)qhi[k][c] << (8 * (c % 4)); }
+            for (int c = 0; c < 8; c++) {
+                if (c < w.n) { f.mask |= (uint8_t)(1u << c); f.child[c] = w.child[c] >= 0 ? w.child[c] * 8 : w.child[c]; }
+                else f.child[c] = 0x76543210;
+            }
+        }
+    } else {
+        // collapse to 4-wide nodes and quantise the child boxes conservatively
+        std::vector<wide4_node> W;
+        collapse_bvh4(R, W, wdepth);
+        {   // memory order: the inner children of a node sit next to each other (<= 256 B = two 128-B L2 lines), subtrees stay
+            // clustered.  Traversal is bound by the rate of random line fetches (tools/gather_probe.hip), and a ray that enters a node
+            // usually enters one or two of its children next: siblings sharing a line turn some of those fetches into L2 hits.
+            std::vector<int> new_id(W.size(), -1), order; order.reserve(W.size());
+            std::vector<int> stack; new_id[0] = 0; order.push_back(0); stack.push_back(0);
+            while (!stack.empty()) {
+                const int me = stack.back(); stack.pop_back();
+                int kids[4], nk = 0;
+                for (int c = 0; c < W[me].n; c++) if (W[me].child[c] >= 0) kids[nk++] = W[me].child[c];
+                for (int c = 0; c < nk; c++) { new_id[kids[c]] = (int)order.size(); order.push_back(kids[c]); }
+                for (int c = nk - 1; c >= 0; c--) stack.push_back(kids[c]);
+            }
+            std::vector<wide4_node> W2(W.size());
+            for (size_t i = 0; i < order.size(); i++) { W2[i] = W[order[i]]; for (int c = 0; c < W2[i].n; c++) if (W2[i].child[c] >= 0) W2[i].child[c] = new_id[W2[i].child[c]]; }
+            W.swap(W2);
+        }
+        out.nodes.resize(W.size());
+        for (size_t i = 0; i < W.size(); i++) {
+            const wide4_node& w = W[i]; flat4_node& f = out.nodes[i];
+            std::memset(&f, 0, sizeof(f));
+            uint32_t* q[3][2] = { { &f.qlo_x, &f.qhi_x }, { &f.qlo_y, &f.qhi_y }, { &f.qlo_z, &f.qhi_z } };
+            for (int k = 0; k < 3; k++) {
+                f.origin[k] = w.box.lo[k];
+                const double ext = (double)w.box.hi[k] - (double)w.box.lo[k];
+                int e = 1;   // smallest normal exponent
+                if (ext > 0) { int ex; std::frexp(ext / 255.0, &ex); e = ex + 127; /* 2^ex >= ext/255 */ if (e < 1) e = 1; if (e > 254) e = 254; }
+                f.e[k] = (uint8_t)e;
+                const double step = std::ldexp(1.0, e - 127);
+                for (int c = 0; c < w.n; c++) {
+                    long lo = (long)std::floor(((double)w.cbox[c].lo[k] - (double)f.origin[k]) / step);
+                    long hi = (long)std::ceil(((double)w.cbox[c].hi[k] - (double)f.origin[k]) / step);
+                    // the device evaluates origin + step * q in fp32 (one rounding): keep the box conservative under that rounding too
+                    while (lo > 0 && (float)((double)f.origin[k] + step * (double)lo) > w.cbox[c].lo[k]) lo--;
+                    while (hi < 255 && (float)((double)f.origin[k] + step * (double)hi) < w.cbox[c].hi[k]) hi++;
+                    lo = std::min(255L, std::max(0L, lo)); hi = std::min(255L, std::max(0L, hi));
+                    *q[k][0] |= (uint32_t)lo << (8 * c); *q[k][1] |= (uint32_t)hi << (8 * c);
+                }
+            }
+            for (int c = 0; c < 4; c++) {
+                if (c < w.n) { f.mask |= (uint8_t)(1u << c); f.child[c] = w.child[c] >= 0 ? w.child[c] * 4 : w.child[c]; }
+                else f.child[c] = 0x76543210;
+            }
         }
     }
     out.leaves.resize(R.leaf_prims.size());

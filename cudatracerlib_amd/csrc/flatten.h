@@ -22,13 +22,31 @@ struct flat4_node {
 };
 static_assert(sizeof(flat4_node) == 64, "wide node is one 64-B fetch group");
 
+// 8-wide node, 128 B = ONE L2 line per visit.  tools/gather_probe.hip: an MI355X gathers ~56-60 G random records/s from HBM
+// (95-127 G/s from L2) whether a record is 16, 64 or 128 bytes — traversal time is the NUMBER of records fetched, so a node
+// should fill the line it costs.  Eight children per visit need ~20 node fetches per ray where the 4-wide node needs ~34.
+// Child c, axis k: lo = origin[k] + 2^(e[k]-127) * qlo[k][c] (conservative, as flat4_node).  96 B are used; the device loads 6 float4.
+struct flat8_node {
+    float origin[3];
+    uint8_t e[3];
+    uint8_t mask;                  // bit c set <=> child c exists
+    uint32_t qlo_x[2], qhi_x[2];   // byte c of the 8-byte group = child c
+    uint32_t qlo_y[2], qhi_y[2];
+    uint32_t qlo_z[2], qhi_z[2];
+    int32_t child[8];              // >= 0: node index * 8 (float4 units); < 0: ~firstLeafEntry
+    uint32_t pad[8];
+};
+static_assert(sizeof(flat8_node) == 128, "8-wide node is one 128-B line");
+
 struct flat_scene {
+    int width = 4;                     // 4: nodes, 8: nodes8
+    std::vector<flat8_node> nodes8;
     std::vector<flat4_node> nodes;     // node 0 is the root
     std::vector<flat_leaf> leaves;
     int max_depth = 0;                 // of the 4-wide tree
 };
 
 // false when the scene has no triangles or more than `max_triangles` instanced triangles
-bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangles);
+bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangles, int width = 8);
 
 }  // namespace ctl

@@ -10,6 +10,7 @@
 #include <thread>
 #include <cctype>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 
 namespace ctl {
@@ -145,15 +146,24 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
         if (!ok)
             throw std::runtime_error("ctl_scene_create: BSDF type " + std::to_string(t) + " has no HIP implementation yet");
     }
-    S.flat_nodes = nullptr; S.flat_leaves = nullptr; S.flat_root = 0;
+    S.flat_nodes = nullptr; S.flat_leaves = nullptr; S.flat_root = 0; S.flat_width = 0;
     if (flatten) {
+        // node width: 4 (64-byte nodes).  CTL_FLAT_WIDTH=8 selects the 128-byte 8-wide layout (traverse8.h) — measured on MI355X it
+        // needs 24 instead of 34 node visits per ray on synthetic-SM but runs 1.85x slower (the kernel is bound by VALU issue, and an
+        // 8-wide node costs more than twice the instructions of a 4-wide one); kept as an experiment, see DESIGN.md §3.
+        int width = 4;
+        if (const char* e = getenv("CTL_FLAT_WIDTH")) { if (atoi(e) == 8) width = 8; }
         flat_scene F;
-        if (flatten_scene(d, F, (size_t)1 << 30)) {   // up to 2^30 instanced triangles (64 GiB of leaf entries)
-            if (3 * F.max_depth + 4 > kStackSize) throw std::runtime_error("ctl_scene_create: flattened BVH too deep for the traversal stack");
-            flat_nodes_.upload((const float4*)F.nodes.data(), F.nodes.size() * 4);
+        bool ok = flatten_scene(d, F, (size_t)1 << 30, width);   // up to 2^30 instanced triangles (64 GiB of leaf entries)
+        if (ok && width == 8 && 7 * F.max_depth + 4 > kStackSize) { width = 4; ok = flatten_scene(d, F, (size_t)1 << 30, 4); }
+        if (ok) {
+            if (width == 4 && 3 * F.max_depth + 4 > kStackSize) throw std::runtime_error("ctl_scene_create: flattened BVH too deep for the traversal stack");
+            if (width == 8) flat_nodes_.upload((const float4*)F.nodes8.data(), F.nodes8.size() * 8);
+            else flat_nodes_.upload((const float4*)F.nodes.data(), F.nodes.size() * 4);
+            F.leaves.emplace_back(); std::memset(&F.leaves.back(), 0, sizeof(flat_leaf));   // one spare entry behind the last leaf
             flat_leaves_.upload((const float4*)F.leaves.data(), F.leaves.size() * 4);
             CTL_HIP(hipDeviceSynchronize());
-            S.flat_nodes = flat_nodes_.p; S.flat_leaves = flat_leaves_.p; S.flat_root = 0;
+            S.flat_nodes = flat_nodes_.p; S.flat_leaves = flat_leaves_.p; S.flat_root = 0; S.flat_width = width;
         }
     }
     CTL_HIP(hipDeviceSynchronize());

@@ -20,7 +20,7 @@ namespace ctl {
 struct trav_counts { uint32_t n_inner, n_tri, n_inst, w_inner, w_tri; };
 
 constexpr int kLdsStack = 24;        // stack entries per lane kept in LDS, two-level kernel (24 x 256 x 4 B = 24 KiB per workgroup)
-constexpr int kLdsStackFlat = 20;    // flat kernel: 20 KiB per workgroup -> 8 workgroups = 32 waves per CU
+constexpr int kLdsStackFlat = 19;    // flat kernel: 19 rows + 1 spare row (absorbs unused push slots) = 20 KiB per workgroup -> 8 workgroups = 32 waves per CU
 __device__ int g_tri_batch = 1;      // flat kernel: leaf entries are tested once this many lanes wait at a leaf.  Measured on MI355X
                                      // (gpurun_out/tune_tri.log): batching leaves LOSES (973 -> 835 Mrays/s from 1 to 40) — the kernel is
                                      // memory-latency bound and every waiting lane is a load not in flight; kept as a knob (CTL_TRI_BATCH)
@@ -259,42 +259,51 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
                 const float ax = __uint_as_float((meta & 0xffu) << 23) * idx, ay = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy, az = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
                 const float bx = __builtin_fmaf(q0.x, idx, -oox), by = __builtin_fmaf(q0.y, idy, -ooy), bz = __builtin_fmaf(q0.z, idz, -ooz);
                 const uint32_t lx = __float_as_uint(q1.x), hx = __float_as_uint(q1.y), ly = __float_as_uint(q1.z), hy = __float_as_uint(q1.w), lz = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
+                // near / far plane words picked by the sign of the ray direction (ax.. carry the sign of 1/d): the entry distance is
+                // the max of three near planes and the exit distance the min of three far planes, no per-plane min/max
+                const bool px = idx >= 0.0f, py = idy >= 0.0f, pz = idz >= 0.0f;
+                const uint32_t nx = px ? lx : hx, fx = px ? hx : lx, ny = py ? ly : hy, fy = py ? hy : ly, nz = pz ? lz : hz, fz = pz ? hz : lz;
                 uint32_t key[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const float tlx = __builtin_fmaf((float)((lx >> (8 * c)) & 0xffu), ax, bx), thx = __builtin_fmaf((float)((hx >> (8 * c)) & 0xffu), ax, bx);
-                    const float tly = __builtin_fmaf((float)((ly >> (8 * c)) & 0xffu), ay, by), thy = __builtin_fmaf((float)((hy >> (8 * c)) & 0xffu), ay, by);
-                    const float tlz = __builtin_fmaf((float)((lz >> (8 * c)) & 0xffu), az, bz), thz = __builtin_fmaf((float)((hz >> (8 * c)) & 0xffu), az, bz);
-                    const float cmin = fmaxf(fmaxf(fminf(tlx, thx), fminf(tly, thy)), fmaxf(fminf(tlz, thz), tmin));
-                    const float cmax = fminf(fminf(fmaxf(tlx, thx), fmaxf(tly, thy)), fminf(fmaxf(tlz, thz), ht));
+                    const float tnx = __builtin_fmaf((float)((nx >> (8 * c)) & 0xffu), ax, bx), tfx = __builtin_fmaf((float)((fx >> (8 * c)) & 0xffu), ax, bx);
+                    const float tny = __builtin_fmaf((float)((ny >> (8 * c)) & 0xffu), ay, by), tfy = __builtin_fmaf((float)((fy >> (8 * c)) & 0xffu), ay, by);
+                    const float tnz = __builtin_fmaf((float)((nz >> (8 * c)) & 0xffu), az, bz), tfz = __builtin_fmaf((float)((fz >> (8 * c)) & 0xffu), az, bz);
+                    const float cmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+                    const float cmax = fminf(fminf(tfx, tfy), fminf(tfz, ht));
                     const bool h = (cmax >= cmin) && ((meta >> (24 + c)) & 1u);
                     // sort key: entry distance (>= 0, so its bit pattern orders like the float) with the child slot in the two low bits
                     key[c] = h ? ((__float_as_uint(cmin) & ~3u) | (uint32_t)c) : 0xffffffffu;
                 }
-                if (!ANY_HIT || g_any_sorted) {   // front-to-back: 5-comparator network on the keys
+                // front-to-back: 5-comparator network on the keys; misses (0xffffffff) end up last, so the hits are a prefix
 #define CTL_CSWAP(a, b) { const uint32_t lo_ = key[a] < key[b] ? key[a] : key[b], hi_ = key[a] < key[b] ? key[b] : key[a]; key[a] = lo_; key[b] = hi_; }
-                    CTL_CSWAP(0, 1) CTL_CSWAP(2, 3) CTL_CSWAP(0, 2) CTL_CSWAP(1, 3) CTL_CSWAP(1, 2)
+                CTL_CSWAP(0, 1) CTL_CSWAP(2, 3) CTL_CSWAP(0, 2) CTL_CSWAP(1, 3) CTL_CSWAP(1, 2)
 #undef CTL_CSWAP
-                }
                 const int ch0 = __float_as_int(q2.z), ch1 = __float_as_int(q2.w), ch2 = __float_as_int(q3.x), ch3 = __float_as_int(q3.y);
                 auto child_of = [&](uint32_t k) { const uint32_t s = k & 3u; return s == 0 ? ch0 : (s == 1 ? ch1 : (s == 2 ? ch2 : ch3)); };
-                if (ANY_HIT) {   // order is irrelevant for occlusion: visit every hit child
-                    int first = kSentinel; bool have = false;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) if (key[c] != 0xffffffffu) { const int cc = child_of(key[c]); if (!have) { first = cc; have = true; } else { sp++; st.set(sp, cc); } }
-                    if (have) node = first; else { node = st.get(sp); sp--; }
-                } else {
-                    // farthest first onto the stack, nearest continues
-                    if (key[3] != 0xffffffffu) { sp++; st.set(sp, child_of(key[3])); }
-                    if (key[2] != 0xffffffffu) { sp++; st.set(sp, child_of(key[2])); }
-                    if (key[1] != 0xffffffffu) { sp++; st.set(sp, child_of(key[1])); }
-                    if (key[0] != 0xffffffffu) node = child_of(key[0]); else { node = st.get(sp); sp--; }
+                const int n_hit = (key[0] != 0xffffffffu) + (key[1] != 0xffffffffu) + (key[2] != 0xffffffffu) + (key[3] != 0xffffffffu);
+                if (n_hit == 0) { node = st.get(sp); sp--; }
+                else {
+                    node = child_of(key[0]);   // nearest continues, the others go onto the stack farthest first
+                    if (n_hit > 1) {
+                        const int top = sp + n_hit - 1;
+                        if (top < kLdsStackFlat) {   // common case: three unconditional LDS stores, unused ones into the spare row
+                            st.lds[top * 256] = child_of(key[1]);
+                            st.lds[(n_hit >= 3 ? top - 1 : kLdsStackFlat) * 256] = child_of(key[2]);
+                            st.lds[(n_hit >= 4 ? top - 2 : kLdsStackFlat) * 256] = child_of(key[3]);
+                            sp = top;
+                        } else {
+                            if (n_hit >= 4) { sp++; st.set(sp, child_of(key[3])); }
+                            if (n_hit >= 3) { sp++; st.set(sp, child_of(key[2])); }
+                            sp++; st.set(sp, child_of(key[1]));
+                        }
+                    }
                 }
             } else {
                 if (COUNT) { cnt.n_tri++; if (lane == (int)__builtin_ctzll(__ballot(1))) cnt.w_tri++; }
                 const uint32_t index = __float_as_uint(q3.x);
                 const float Oz = q0.w - ox * q0.x - oy * q0.y - oz * q0.z;
-                const float invDz = 1.0f / (dx * q0.x + dy * q0.y + dz * q0.z);
+                const float invDz = __builtin_amdgcn_rcpf(dx * q0.x + dy * q0.y + dz * q0.z);   // 1 ulp; the flattened layout promises fp32 round-off, not bit equality
                 const float t = Oz * invDz;
                 if (t > tmin && t < ht) {
                     const float Ox = q1.w + ox * q1.x + oy * q1.y + oz * q1.z;
