@@ -343,6 +343,39 @@ def roughplastic(diffuse_reflectance=(0.5, 0.5, 0.5), alpha=0.1, int_ior=1.49, e
     return m
 
 
+def _coating_ssw(sigma_a, thickness):
+    a = np.mean([np.exp(v * (-2.0 * thickness)) for v in sigma_a.value[:]])
+    return 1.0 / (a + 1.0)
+
+
+def coating(nested_index, nested, int_ior=1.5046, ext_ior=1.000277, thickness=1.0, sigma_a=0.0, specular_reflectance=1.0):
+    """coating(nested, eta, thickness, sigmaA, specular) — BSDF_Complex.h:9-75.  `nested_index` = DynamicScene.add_material(nested)."""
+    m = _material(13, E["DeltaReflection"] | nested.combined_type)
+    m.tex[0], m.tex[1] = _as_tex(sigma_a), _as_tex(specular_reflectance)
+    eta = float(np.float32(np.float32(int_ior) / np.float32(ext_ior)))
+    m.f[0], m.f[1], m.f[2], m.f[3] = eta, 1.0 / eta, thickness, _coating_ssw(m.tex[0], thickness)
+    m.u[2] = nested_index
+    return m
+
+
+def roughcoating(nested_index, nested, alpha=0.1, int_ior=1.5046, ext_ior=1.000277, thickness=1.0, sigma_a=0.0, distribution=0, specular_reflectance=1.0):
+    """roughcoating(type, nested, eta, thickness, sigmaA, alpha, specular) — BSDF_Complex.h:77-147; needs the rough-transmittance table."""
+    m = _material(14, E["GlossyReflection"] | nested.combined_type)
+    m.tex[0], m.tex[1], m.tex[2] = _as_tex(sigma_a), _as_tex(specular_reflectance), _as_tex(alpha)
+    eta = float(np.float32(np.float32(int_ior) / np.float32(ext_ior)))
+    m.f[0], m.f[1], m.f[2], m.f[3] = eta, 1.0 / eta, thickness, _coating_ssw(m.tex[0], thickness)
+    m.u[0], m.u[1], m.u[2] = distribution, 0 if distribution == 2 else 1, nested_index
+    return m
+
+
+def blend(index0, nested0, index1, nested1, weight=0.5):
+    """blend(nested1, nested2, weight) — BSDF_Complex.h:149-181 (blendbsdf / mixturebsdf of the loader)."""
+    m = _material(15, nested0.combined_type | nested1.combined_type)
+    m.tex[0] = _as_tex(weight)
+    m.u[2], m.u[3] = index0, index1
+    return m
+
+
 # ---------------------------------------------------------------- DynamicScene (Engine/DynamicScene.h:70-187, loader-facing subset)
 class DynamicScene:
     def __init__(self):
@@ -406,6 +439,12 @@ class DynamicScene:
         t = np.ascontiguousarray(texels, dtype=np.uint32)
         idx = u32()
         _check(lib.ctl_builder_add_image(self._h, t.ctypes.data_as(C.c_void_p), u32(t.shape[1]), u32(t.shape[0]), u32(texel_type), u32(wrap), u32(filter), C.byref(idx)))
+        return idx.value
+
+    def add_material(self, material):
+        """register the nested BSDF of a coating / roughcoating / blend; returns its absolute material index"""
+        idx = u32()
+        _check(lib.ctl_builder_add_material(self._h, C.byref(material), C.byref(idx)))
         return idx.value
 
     def setRoughTransmittance(self, slot, trans, diff_trans, eta_range, alpha_range):

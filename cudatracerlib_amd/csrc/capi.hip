@@ -71,6 +71,10 @@ int ctl_builder_set_environment_map(ctl_builder* b, uint32_t image_index, const 
     CTL_REQUIRE(b && scale, "null argument");
     CTL_TRY b->b.set_environment_map(image_index, scale, to_world); CTL_CATCH
 }
+int ctl_builder_add_material(ctl_builder* b, const ctl_material* material, uint32_t* index_out) {
+    CTL_REQUIRE(b && material, "null argument");
+    CTL_TRY uint32_t i = b->b.add_aux_material(*material); if (index_out) *index_out = i; CTL_CATCH
+}
 int ctl_builder_set_rough_transmittance(ctl_builder* b, uint32_t slot, const ctl_rough_transmittance* table) {
     CTL_REQUIRE(b && table, "null argument");
     CTL_TRY b->b.set_rough_transmittance(slot, *table); CTL_CATCH

@@ -102,4 +102,24 @@ inline ctl_material make_ward(uint32_t variant, const ctl_texture& diff, const c
     return m;
 }
 
+// coating / roughcoating: m_specularSamplingWeight = 1 / (avg(exp(-2 thickness sigmaA)) + 1) (BSDF_Complex.h:27-29,44-47)
+inline float coating_ssw(const ctl_texture& sigmaA, float thickness) {
+    const float a = (expf(sigmaA.value[0] * (-2 * thickness)) + expf(sigmaA.value[1] * (-2 * thickness)) + expf(sigmaA.value[2] * (-2 * thickness))) * (1.0f / 3);
+    return 1.0f / (a + 1.0f);
+}
+inline ctl_material make_coating(uint32_t nested_index, uint32_t nested_type, float eta, float thickness, const ctl_texture& sigmaA, const ctl_texture& spec) {
+    ctl_material m = mat_base(CTL_BSDF_COATING, CTL_EDeltaReflection | nested_type); m.tex[0] = sigmaA; m.tex[1] = spec;
+    m.f[0] = eta; m.f[1] = 1.0f / eta; m.f[2] = thickness; m.f[3] = coating_ssw(sigmaA, thickness); m.u[2] = nested_index;
+    return m;
+}
+inline ctl_material make_roughcoating(uint32_t dist, uint32_t nested_index, uint32_t nested_type, float eta, float thickness, const ctl_texture& sigmaA, const ctl_texture& alpha, const ctl_texture& spec) {
+    ctl_material m = mat_base(CTL_BSDF_ROUGHCOATING, CTL_EGlossyReflection | nested_type); m.tex[0] = sigmaA; m.tex[1] = spec; m.tex[2] = alpha;
+    m.f[0] = eta; m.f[1] = 1.0f / eta; m.f[2] = thickness; m.f[3] = coating_ssw(sigmaA, thickness); m.u[0] = dist; m.u[1] = dist == CTL_MF_PHONG ? 0 : 1; m.u[2] = nested_index;
+    return m;
+}
+inline ctl_material make_blend(uint32_t n0, uint32_t type0, uint32_t n1, uint32_t type1, const ctl_texture& weight) {
+    ctl_material m = mat_base(CTL_BSDF_BLEND, type0 | type1); m.tex[0] = weight; m.u[2] = n0; m.u[3] = n1;
+    return m;
+}
+
 } // namespace ctl

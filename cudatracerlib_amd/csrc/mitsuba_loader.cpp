@@ -274,13 +274,27 @@ struct loader {
         else if (T == "mask") { auto nested = all_nested(n, depth - 1); if (nested.size() != 1) bad("expected 1 nested bsdf in mask!"); unsupported("bsdf type mask (opacity maps)"); d = nested[0]; d.has_alphamap = true; }
         else if (T == "coating" || T == "roughcoating") {
             auto nested = all_nested(n, depth); if (nested.size() != 1) bad("expected 1 nested bsdf in coating!");
-            if (depth != 1) unsupported("bsdf type " + T);   // at nesting depth 1 the reference itself returns the nested BSDF (:873-874)
-            d = nested[0];
+            if (depth == 1 || nested[0].mat.bsdf_type >= CTL_BSDF_HK) d = nested[0];   // is_max_depth(): the reference returns the nested BSDF (:873-874); BSDFFirst cannot hold a nesting model
+            else {
+                generic_ior(n, refl, trans, ior);
+                const float thickness = prop_f(n, "thickness", 1.0f); const ctl_texture sigmaA = try_tex(n, "sigmaA", rgb(0.0f));
+                const uint32_t ni = B.add_aux_material(nested[0].mat);
+                if (T == "coating") d = make(make_coating(ni, nested[0].mat.combined_type, ior, thickness, sigmaA, refl), &nested);
+                else { generic_rough(n, aU, aV, dist); d = make(make_roughcoating(dist, ni, nested[0].mat.combined_type, ior, thickness, sigmaA, aU, refl), &nested); }
+            }
         }
         else if (T == "mixturebsdf" || T == "blendbsdf") {
             auto nested = all_nested(n, depth); if (nested.size() != 2) bad("expected 2 nested bsdf in " + T + "!");
-            if (depth != 1) unsupported("bsdf type " + T);
-            d = nested[0];
+            if (depth == 1 || nested[0].mat.bsdf_type >= CTL_BSDF_HK || nested[1].mat.bsdf_type >= CTL_BSDF_HK) d = nested[0];
+            else {
+                ctl_texture weight;
+                if (T == "mixturebsdf") {
+                    auto w = split_array(prop_s(n, "weights")); if (w.size() != 2) bad("not able to get 2 weights from weights property");
+                    const float w1 = std::stof(w[0]), w2 = std::stof(w[1]); weight = tex_const(w1 / (w1 + w2));
+                } else weight = try_tex(n, "weight", rgb(0.5f));
+                const uint32_t n0 = B.add_aux_material(nested[0].mat), n1 = B.add_aux_material(nested[1].mat);
+                d = make(make_blend(n0, nested[0].mat.combined_type, n1, nested[1].mat.combined_type, weight), &nested);
+            }
         }
         else bad("invalid BsdfData type : " + T);
         if (n.has_attr("id")) ref_bsdf[n.attr("id")] = d;

@@ -212,6 +212,11 @@ void scene_builder::set_node_bsdf(uint32_t node_index, uint32_t local_material, 
     const uint32_t nli = dst.node_light_index;
     dst = m; dst.node_light_index = nli;
 }
+uint32_t scene_builder::add_aux_material(const ctl_material& m) {
+    if (m.bsdf_type >= CTL_BSDF_HK) throw std::runtime_error("add_aux_material: a nested BSDF must be one of the simple models (BSDFFirst, SceneTypes/BSDF.h:102)");
+    mats.push_back(m); mats.back().node_light_index = 0xffffffffu;
+    return (uint32_t)mats.size() - 1;
+}
 const ctl_material& scene_builder::node_material(uint32_t node_index, uint32_t local_material) const {
     const ctl_node& N = nodes.at(node_index);
     if (local_material >= mesh_info[N.mesh_index].n_mat) throw std::runtime_error("node_material: bad material index");

@@ -42,6 +42,7 @@ struct scene_builder {
     uint32_t add_node(uint32_t mesh_index, const ctl_float4x4* to_world);
     void set_node_transform(uint32_t node_index, const ctl_float4x4& to_world);
     void set_node_bsdf(uint32_t node_index, uint32_t local_material, const ctl_material& m);
+    uint32_t add_aux_material(const ctl_material& m);   // a material no triangle refers to: the nested BSDF of a coating / roughcoating / blend; returns its absolute index
     const ctl_material& node_material(uint32_t node_index, uint32_t local_material) const;
     aabb scene_box() const;
     uint32_t add_area_light(uint32_t node_index, uint32_t local_material, const float radiance[3]);

@@ -6,7 +6,7 @@
 // Feature set compiled into the shading functions of this translation unit (bits = kShade* of device_scene.h).  The shade
 // kernel is built twice (shade_basic.hip: 0, shade_full.hip: all); everything else uses the full set.
 #ifndef CTL_SHADE_FEATURES
-#define CTL_SHADE_FEATURES 0xF
+#define CTL_SHADE_FEATURES 0x1F
 #endif
 
 namespace ctl {
@@ -43,10 +43,10 @@ __device__ __forceinline__ void sensor_sample_ray(const dev_sensor& c, f2 pixelS
 }
 
 // ---- differential geometry at a hit (Kernel/TraceHelper.cu:274-307 -> Engine/TriangleData.cu:75-103)
-struct diff_geom { f3 P; frame sys; f3 n; f2 uv; const ctl_mipmap* images; const ctl_rough_transmittance* rough_transmittance; };   // images: g_SceneData.m_sTexData; tables of RoughTransmittanceManager (both uniform)
+struct diff_geom { f3 P; frame sys; f3 n; f2 uv; const ctl_mipmap* images; const ctl_rough_transmittance* rough_transmittance; const ctl_material* mats; };   // images: g_SceneData.m_sTexData; tables of RoughTransmittanceManager (both uniform)
 __device__ __forceinline__ void fill_dg(const dev_scene& S, float u, float v, int tri, int node, diff_geom& dg) {
     const uint4 ta = S.tri_data[tri * 2], tb = S.tri_data[tri * 2 + 1];   // {nme.x, nme.y, dpd.x, dpd.y} {dpd.z, uv0, uv1, uv2}
-    dg.images = S.images; dg.rough_transmittance = S.rough_transmittance;
+    dg.images = S.images; dg.rough_transmittance = S.rough_transmittance; dg.mats = S.mats;
     const float4 f0 = S.inst_fwd[node * 3], f1 = S.inst_fwd[node * 3 + 1], f2_ = S.inst_fwd[node * 3 + 2];
     m34 l2w; l2w.r[0][0] = f0.x; l2w.r[0][1] = f0.y; l2w.r[0][2] = f0.z; l2w.r[0][3] = f0.w; l2w.r[1][0] = f1.x; l2w.r[1][1] = f1.y; l2w.r[1][2] = f1.z; l2w.r[1][3] = f1.w;
     l2w.r[2][0] = f2_.x; l2w.r[2][1] = f2_.y; l2w.r[2][2] = f2_.z; l2w.r[2][3] = f2_.w;
@@ -360,6 +360,31 @@ __device__ float bsdf_pdf(const ctl_material& M, const bsdf_rec& b) {
     default: return 0.0f;
 #endif
     }
+}
+
+} // namespace ctl
+#if CTL_SHADE_FEATURES & 16
+#include "bsdf_complex.h"
+#endif
+namespace ctl {
+// BSDFALL::sample / f / pdf (SceneTypes/BSDF.h:141-207): the nesting models on top of the simple ones
+__device__ __forceinline__ f3 bsdf_sample_top(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp) {
+#if CTL_SHADE_FEATURES & 16
+    if (M.bsdf_type >= CTL_BSDF_COATING) return bsdf_complex_sample(M, b, pdf, smp);
+#endif
+    return bsdf_sample(M, b, pdf, smp);
+}
+__device__ __forceinline__ f3 bsdf_f_top(const ctl_material& M, const bsdf_rec& b) {
+#if CTL_SHADE_FEATURES & 16
+    if (M.bsdf_type >= CTL_BSDF_COATING) return bsdf_complex_f(M, b, 1);
+#endif
+    return bsdf_f(M, b);
+}
+__device__ __forceinline__ float bsdf_pdf_top(const ctl_material& M, const bsdf_rec& b) {
+#if CTL_SHADE_FEATURES & 16
+    if (M.bsdf_type >= CTL_BSDF_COATING) return bsdf_complex_pdf(M, b, 1);
+#endif
+    return bsdf_pdf(M, b);
 }
 
 // ---- emitters

@@ -118,6 +118,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
         const uint32_t t = d.materials[i].bsdf_type;
         if (t == CTL_BSDF_THINDIELECTRIC || t == CTL_BSDF_ROUGHDIELECTRIC || t == CTL_BSDF_PLASTIC || t == CTL_BSDF_PHONG) S.shade_features |= kShadeMoreBsdfs;
         if (t == CTL_BSDF_ROUGHDIFFUSE || t == CTL_BSDF_WARD || t == CTL_BSDF_ROUGHPLASTIC) S.shade_features |= kShadeRoughBsdfs;
+        if (t == CTL_BSDF_COATING || t == CTL_BSDF_ROUGHCOATING || t == CTL_BSDF_BLEND) S.shade_features |= kShadeNestingBsdfs | kShadeMoreBsdfs | kShadeRoughBsdfs;
         for (int k = 0; k < 4; k++) if (d.materials[i].tex[k].type == CTL_TEX_IMAGE) S.shade_features |= kShadeImageTextures;
     }
     for (uint32_t i = 0; i < d.n_lights_buf; i++) {
@@ -134,7 +135,18 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
         }
         const uint32_t t = d.materials[i].bsdf_type;
         const bool ok = t == CTL_BSDF_DIFFUSE || t == CTL_BSDF_DIELECTRIC || t == CTL_BSDF_THINDIELECTRIC || t == CTL_BSDF_ROUGHDIELECTRIC || t == CTL_BSDF_CONDUCTOR ||
-                        t == CTL_BSDF_ROUGHCONDUCTOR || t == CTL_BSDF_PLASTIC || t == CTL_BSDF_PHONG || t == CTL_BSDF_ROUGHDIFFUSE || t == CTL_BSDF_WARD || t == CTL_BSDF_ROUGHPLASTIC;
+                        t == CTL_BSDF_ROUGHCONDUCTOR || t == CTL_BSDF_PLASTIC || t == CTL_BSDF_PHONG || t == CTL_BSDF_ROUGHDIFFUSE || t == CTL_BSDF_WARD || t == CTL_BSDF_ROUGHPLASTIC ||
+                        t == CTL_BSDF_COATING || t == CTL_BSDF_ROUGHCOATING || t == CTL_BSDF_BLEND;
+        if (t == CTL_BSDF_COATING || t == CTL_BSDF_ROUGHCOATING || t == CTL_BSDF_BLEND) {
+            for (int k = 0; k < (t == CTL_BSDF_BLEND ? 2 : 1); k++) {
+                const uint32_t ni = d.materials[i].u[2 + k];
+                if (ni >= d.n_materials || d.materials[ni].bsdf_type >= CTL_BSDF_HK) throw std::runtime_error("ctl_scene_create: nested BSDF index out of range or not a simple BSDF (BSDFFirst)");
+            }
+            if (t == CTL_BSDF_ROUGHCOATING) {
+                const uint32_t slot = d.materials[i].u[0];
+                if (slot > CTL_MF_GGX || !d.rough_transmittance || !d.rough_transmittance[slot].trans) throw std::runtime_error("ctl_scene_create: roughcoating needs the rough-transmittance table of its (Beckmann / GGX) distribution");
+            }
+        }
         if (t == CTL_BSDF_ROUGHPLASTIC) {
             const uint32_t slot = d.materials[i].u[2];
             if (slot > CTL_MF_GGX) throw std::runtime_error("ctl_scene_create: roughplastic with the Phong distribution has no HIP implementation yet");

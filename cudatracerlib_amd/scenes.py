@@ -120,6 +120,23 @@ def cornell_box(width=256, height=256, glass_sphere=False, extra_materials=False
             tr, df, er, ar = rough_tables.make_table(slot, n_eta=4, n_alpha=5, n_theta=8, quad=16)
             sc.setRoughTransmittance(slot, tr, df, er, ar)
         mats += [api.roughplastic((0.2, 0.5, 0.25), alpha=0.15, distribution=0), api.roughplastic((0.6, 0.25, 0.2), alpha=0.3, int_ior=1.6, distribution=1, nonlinear=True)]
+    elif extra_materials in (8, 9, 10):   # the nesting models: coating / roughcoating / blend over simple BSDFs registered as auxiliary materials
+        add = lambda m: (sc.add_material(m), m)
+        if extra_materials == 8:      # absorbing smooth coating over diffuse; blend of diffuse and GGX metal
+            i0, n0 = add(api.diffuse((0.7, 0.6, 0.3)))
+            i1, n1 = add(api.diffuse((0.2, 0.3, 0.6))); i2, n2 = add(api.roughconductor(alpha=0.2))
+            mats += [api.coating(i0, n0, int_ior=1.5, ext_ior=1.0, thickness=2.0, sigma_a=(0.1, 0.4, 0.8)), api.blend(i1, n1, i2, n2, weight=0.35)]
+        elif extra_materials == 9:    # rough coating (Beckmann table) over diffuse; blend of a delta mirror and diffuse
+            from . import rough_tables
+            tr, df, er, ar = rough_tables.make_table(0, n_eta=4, n_alpha=5, n_theta=8, quad=16)
+            sc.setRoughTransmittance(0, tr, df, er, ar)
+            i0, n0 = add(api.diffuse((0.6, 0.3, 0.2)))
+            i1, n1 = add(api.conductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))); i2, n2 = add(api.diffuse((0.3, 0.6, 0.3)))
+            mats += [api.roughcoating(i0, n0, alpha=0.2, int_ior=1.5, ext_ior=1.0, distribution=0), api.blend(i1, n1, i2, n2, weight=0.6)]
+        else:                         # coating over a delta conductor; coating over plastic (delta + diffuse nested lobes)
+            i0, n0 = add(api.conductor(eta=(0.14, 0.37, 1.44), k=(3.98, 2.38, 1.6)))
+            i1, n1 = add(api.plastic(diffuse_reflectance=(0.2, 0.5, 0.3), int_ior=1.49))
+            mats += [api.coating(i0, n0, int_ior=1.4, ext_ior=1.0, thickness=1.0, sigma_a=0.0), api.coating(i1, n1, int_ior=1.6, ext_ior=1.0, thickness=0.5, sigma_a=(0.3, 0.1, 0.1))]
     elif extra_materials == 7:    # short block fast-approximation Oren-Nayar, tall block original Ward
         mats += [api.roughdiffuse((0.7, 0.5, 0.2), alpha=0.6, use_fast_approx=True), api.ward((0.2, 0.4, 0.3), (0.3, 0.3, 0.3), alpha_u=0.15, alpha_v=0.15, variant=0)]
     elif extra_materials:

@@ -139,6 +139,11 @@ enum { CTL_MF_BECKMANN = 0, CTL_MF_GGX = 1, CTL_MF_PHONG = 2 };
  *  roughplastic   tex0 diffuse, tex1 specular, tex2 alpha, f0 eta, f1 invEta2, f2 specularSamplingWeight,
  *                 u0 nonlinear, u1 sampleVisible, u2 distribution
  *  phong          tex0 diffuse, tex1 specular, tex2 exponent, f0 specularSamplingWeight
+ *  coating        tex0 sigmaA, tex1 specularReflectance, f0 eta, f1 invEta, f2 thickness, f3 specularSamplingWeight, u2 nested material
+ *  roughcoating   tex0 sigmaA, tex1 specularReflectance, tex2 alpha, f0 eta, f1 invEta, f2 thickness, f3 specularSamplingWeight,
+ *                 u0 distribution, u1 sampleVisible, u2 nested material
+ *  blend          tex0 weight, u2 / u3 nested materials (absolute indices, ctl_builder_add_material); combined_type of the three =
+ *                 own lobes | the nested BSDFs' combined_type
  *  ward           tex0 diffuse, tex1 specular, tex2 alphaU, tex3 alphaV, f0 specularSamplingWeight, u0 variant (0 Ward, 1 Ward-Duer, 2 balanced) */
 typedef struct {
     uint32_t bsdf_type;        /* CTL_BSDF_*                                       */
@@ -251,6 +256,9 @@ int ctl_builder_add_image(ctl_builder* b, const uint32_t* texels, uint32_t width
 /* DynamicScene::setEnvironementMap(scale, file) (Engine/DynamicScene.cpp:846-859) + InfiniteLight ctor (Light.cpp:10-61):
  * builds the row / column CDFs; to_world (row-major 4x4, orthogonal) may be NULL = identity. */
 int ctl_builder_set_environment_map(ctl_builder* b, uint32_t image_index, const float scale[3], const ctl_float4x4* to_world);
+/* Registers a BSDF that no triangle refers to directly: the nested BSDF (BSDFFirst, SceneTypes/BSDF.h:102) of a coating,
+ * roughcoating or blend.  Returns its absolute index in ctl_scene_desc::materials, to be stored in the parent's u[2] (/u[3]). */
+int ctl_builder_add_material(ctl_builder* b, const ctl_material* material, uint32_t* index_out);
 /* RoughTransmittanceManager::StaticInitialize (Engine/RoughTransmittance.cu:124-131): install the table of one slot (0..2);
  * the arrays are copied.  ctl_builder_load_rough_transmittance parses a Mitsuba "MTS_TRANSMITTANCE" .dat file (:8-45). */
 int ctl_builder_set_rough_transmittance(ctl_builder* b, uint32_t slot, const ctl_rough_transmittance* table);

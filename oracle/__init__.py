@@ -57,6 +57,8 @@ def load():
     o.orc_rough_transmittance_eval.restype = f32; o.orc_rough_transmittance_eval.argtypes = [u32, f32, f32, f32]
     o.orc_rough_transmittance_eval_diffuse.restype = f32; o.orc_rough_transmittance_eval_diffuse.argtypes = [u32, f32, f32]
     o.orc_set_probe_rough_transmittance.argtypes = [C.c_void_p]
+    o.orc_set_probe_materials.argtypes = [C.c_void_p]
+    o.orc_bsdf_eval_discrete.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_void_p]
     o.orc_light_pdf_direct.restype = f32
     o.orc_light_pdf_direct.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p]
     o.orc_env_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

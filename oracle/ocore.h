@@ -175,6 +175,7 @@ struct DG {   // Engine/DifferentialGeometry.h:11-47
     V3 P; Frame sys; V3 n; V3 dpdu, dpdv; V2 uv; V2 bary; uint8_t extraData;
     const ctl_mipmap* images = nullptr;   // g_SceneData.m_sTexData (ImageTexture::getTexture, Texture.cu:39-42)
     const ctl_rough_transmittance* rough_transmittance = nullptr;   // RoughTransmittanceManager's three tables (RoughTransmittance.cu:121-131)
+    const ctl_material* materials = nullptr;   // g_SceneData.m_sMatData: nested BSDFs of coating / roughcoating / blend are entries of it
 };
 // Engine/TriangleData.cu:22-32 + 34-65
 inline void triDataSetUV(ctl_triangle_data& T, V2 a, V2 b, V2 c) {
@@ -229,7 +230,7 @@ inline void triDataFillDG(const ctl_triangle_data& T, const M44& localToWorld, D
 inline void fillDG(const Scene& S, V2 bary, uint32_t triIdx, uint32_t nodeIdx, DG& dg) {
     M44 l2w; std::memcpy(l2w.d, S.d.node_transforms[nodeIdx].m, 64);
     dg.bary = bary;
-    dg.images = S.d.images; dg.rough_transmittance = S.d.rough_transmittance;
+    dg.images = S.d.images; dg.rough_transmittance = S.d.rough_transmittance; dg.materials = S.d.materials;
     triDataFillDG(S.d.tri_data[triIdx], l2w, dg, S.half_host_quirk);
 }
 
@@ -650,12 +651,14 @@ inline float avg3(Spec s) { float r = 0.0f; r += s.x; r += s.y; r += s.z; return
 } // namespace orc
 #include "obsdf3.h"
 #include "obsdf2.h"
+#include "obsdf4.h"
 namespace orc {
 
 // --------------------------------------------------------------------------- BSDFs (SceneTypes/BSDF_Simple.cu)
 inline bool bsdfHasComponent(const ctl_material& M, unsigned type) { return (type & M.combined_type) != 0; }
 
 inline Spec bsdfSample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sample) {
+    if (M.bsdf_type >= CTL_BSDF_COATING) return bsdfComplexSample(M, bRec, pdf, _sample);
     switch (M.bsdf_type) {
     case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:7-36
         unsigned ct = M.combined_type;
@@ -726,6 +729,8 @@ inline Spec bsdfSample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sample
 }
 
 inline Spec bsdfF(const ctl_material& M, const BRec& bRec, int measure = ESolidAngle) {
+    if (M.bsdf_type >= CTL_BSDF_COATING) return bsdfComplexF(M, bRec, measure);
+    if (measure == EDiscrete) return bsdfFDiscrete(M, bRec);   // only nested evaluation asks for the discrete measure
     switch (M.bsdf_type) {
     case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:38-56
         unsigned ct = M.combined_type;
@@ -755,6 +760,8 @@ inline Spec bsdfF(const ctl_material& M, const BRec& bRec, int measure = ESolidA
 }
 
 inline float bsdfPdf(const ctl_material& M, const BRec& bRec, int measure = ESolidAngle) {
+    if (M.bsdf_type >= CTL_BSDF_COATING) return bsdfComplexPdf(M, bRec, measure);
+    if (measure == EDiscrete) return bsdfPdfDiscrete(M, bRec);
     switch (M.bsdf_type) {
     case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:58-75
         unsigned ct = M.combined_type;

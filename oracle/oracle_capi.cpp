@@ -113,19 +113,27 @@ void orc_intersect(const ctl_scene_desc* desc, const ctl_ray* rays, uint32_t n, 
 // tables used by the BSDF probes below (roughplastic); the pointer must stay valid
 static const ctl_rough_transmittance* g_probe_rt = nullptr;
 void orc_set_probe_rough_transmittance(const ctl_rough_transmittance* t3) { g_probe_rt = t3; }
+static const ctl_material* g_probe_mats = nullptr;   // material array the nested indices of coating / roughcoating / blend refer to
+void orc_set_probe_materials(const ctl_material* m) { g_probe_mats = m; }
 float orc_rough_transmittance_eval(uint32_t slot, float cosTheta, float alpha, float eta) { DG dg; dg.rough_transmittance = g_probe_rt; return roughTransmittance(dg, slot, cosTheta, alpha, eta); }
 float orc_rough_transmittance_eval_diffuse(uint32_t slot, float alpha, float eta) { DG dg; dg.rough_transmittance = g_probe_rt; return roughTransmittanceDiffuse(dg, slot, alpha, eta); }
 // local-frame probe: dg is an identity frame at the origin with uv = (u,v).  out = f(3), pdf, wo(3), sampledType, eta
 void orc_bsdf_sample(const ctl_material* M, const float* wi, float sx, float sy, float* out) {
     BRec b; b.dg.P = V3(0.0f); b.dg.sys = Frame(V3(1, 0, 0), V3(0, 1, 0), V3(0, 0, 1)); b.dg.n = V3(0, 0, 1); b.dg.uv = V2{ 0, 0 };
-    b.wi = V3(wi[0], wi[1], wi[2]); b.wo = V3(0.0f); b.eta = 1.0f; b.typeMask = EAll; b.sampledType = 0; b.dg.rough_transmittance = g_probe_rt;
+    b.wi = V3(wi[0], wi[1], wi[2]); b.wo = V3(0.0f); b.eta = 1.0f; b.typeMask = EAll; b.sampledType = 0; b.dg.rough_transmittance = g_probe_rt; b.dg.materials = g_probe_mats;
     float pdf = 0; Spec f = bsdfSample(*M, b, pdf, V2{ sx, sy });
     out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = pdf; out[4] = b.wo.x; out[5] = b.wo.y; out[6] = b.wo.z; out[7] = (float)b.sampledType; out[8] = b.eta;
 }
 void orc_bsdf_eval(const ctl_material* M, const float* wi, const float* wo, uint32_t typeMask, float* out) {
     BRec b; b.dg.P = V3(0.0f); b.dg.sys = Frame(V3(1, 0, 0), V3(0, 1, 0), V3(0, 0, 1)); b.dg.n = V3(0, 0, 1); b.dg.uv = V2{ 0, 0 };
-    b.wi = V3(wi[0], wi[1], wi[2]); b.wo = V3(wo[0], wo[1], wo[2]); b.eta = 1.0f; b.typeMask = typeMask; b.sampledType = 0; b.dg.rough_transmittance = g_probe_rt;
+    b.wi = V3(wi[0], wi[1], wi[2]); b.wo = V3(wo[0], wo[1], wo[2]); b.eta = 1.0f; b.typeMask = typeMask; b.sampledType = 0; b.dg.rough_transmittance = g_probe_rt; b.dg.materials = g_probe_mats;
     Spec f = bsdfF(*M, b); out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = bsdfPdf(*M, b);
+}
+// f / pdf with the discrete measure (delta lobes; what the nesting BSDFs ask their children for)
+void orc_bsdf_eval_discrete(const ctl_material* M, const float* wi, const float* wo, uint32_t typeMask, float* out) {
+    BRec b; b.dg.P = V3(0.0f); b.dg.sys = Frame(V3(1, 0, 0), V3(0, 1, 0), V3(0, 0, 1)); b.dg.n = V3(0, 0, 1); b.dg.uv = V2{ 0, 0 };
+    b.wi = V3(wi[0], wi[1], wi[2]); b.wo = V3(wo[0], wo[1], wo[2]); b.eta = 1.0f; b.typeMask = typeMask; b.sampledType = 0; b.dg.rough_transmittance = g_probe_rt; b.dg.materials = g_probe_mats;
+    Spec f = bsdfF(*M, b, EDiscrete); out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = bsdfPdf(*M, b, EDiscrete);
 }
 // out = value(3), pdf, d(3), dist, p(3), n(3)
 void orc_light_sample_direct(const ctl_scene_desc* desc, uint32_t light, const float* ref, const float* refN, float sx, float sy, float* out) {

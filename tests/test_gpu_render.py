@@ -59,6 +59,14 @@ def test_cornell_microfacet_and_conductor(gpu, orc):
     assert_close(got, want)
 
 
+@pytest.mark.parametrize("variant", [8, 9, 10])
+def test_cornell_coating_roughcoating_blend(gpu, orc, variant):
+    """the nesting BSDFs (BSDF_Complex.cu) over diffuse / metal / plastic children, incl. delta children (discrete-measure f / pdf)"""
+    sc = scenes.cornell_box(64, 64, extra_materials=variant)
+    got, want, tr, rays = render_pair(gpu, orc, sc, 64, 64, 3)
+    assert_close(got, want)
+
+
 @pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7])
 def test_cornell_plastic_roughdielectric_phong_thindielectric(gpu, orc, variant):
     """2: plastic + GGX rough glass, 3: phong + thin glass, 4: nonlinear plastic + anisotropic Beckmann rough glass,

@@ -123,6 +123,72 @@ def test_no_energy_gain(lib, name):
         assert np.all(tot / len(S) <= 1.02), (theta, tot / len(S))
 
 
+def _nesting_models():
+    """(name, material array, index of the parent): children are entries of the same array (absolute indices)"""
+    mats = (api.ctl_material * 16)()
+    children = [api.diffuse((0.8, 0.7, 0.6)), api.roughconductor(alpha=0.2), api.conductor(eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.1)),
+                api.plastic((0.5, 0.5, 0.5), int_ior=1.49), api.dielectric(int_ior=1.5, ext_ior=1.0)]
+    for i, c in enumerate(children):
+        mats[i] = c
+    parents = {
+        "coating_diffuse": api.coating(0, children[0], int_ior=1.5, ext_ior=1.0, thickness=1.0, sigma_a=(0.1, 0.2, 0.4)),
+        "coating_conductor": api.coating(2, children[2], int_ior=1.4, ext_ior=1.0),
+        "coating_plastic": api.coating(3, children[3], int_ior=1.6, ext_ior=1.0, thickness=0.5, sigma_a=0.2),
+        "roughcoating_diffuse": api.roughcoating(0, children[0], alpha=0.2, int_ior=1.5, ext_ior=1.0, distribution=0),
+        "roughcoating_ggx_metal": api.roughcoating(1, children[1], alpha=0.3, int_ior=1.5, ext_ior=1.0, distribution=1, sigma_a=0.1),
+        "blend_diffuse_metal": api.blend(0, children[0], 1, children[1], weight=0.3),
+        "blend_mirror_diffuse": api.blend(2, children[2], 0, children[0], weight=0.6),
+        "blend_glass_diffuse": api.blend(4, children[4], 0, children[0], weight=0.5),
+    }
+    out = {}
+    for k, (name, p) in enumerate(parents.items()):
+        mats[8 + k] = p
+        out[name] = 8 + k
+    return mats, out
+
+
+@pytest.mark.parametrize("name", ["coating_diffuse", "coating_conductor", "coating_plastic", "roughcoating_diffuse", "roughcoating_ggx_metal",
+                                  "blend_diffuse_metal", "blend_mirror_diffuse", "blend_glass_diffuse"])
+def test_nesting_models_are_consistent(lib, name):
+    """coating / roughcoating / blend: sample() == f / pdf in the measure of the sampled lobe (solid angle or discrete), no energy gain"""
+    mats, index = _nesting_models()
+    lib.orc_set_probe_materials(C.addressof(mats))
+    m = mats[index[name]]
+    rs = np.random.RandomState(13)
+    n_checked = 0
+    for theta in (0.15, 0.8, 1.25):
+        wi = _wi(theta)
+        tot = np.zeros(3); S = rs.rand(600, 2)
+        for s in S:
+            r = _sample(lib, m, wi, s)
+            w, pdf, wo, typ = r[:3], r[3], r[4:7], int(r[7])
+            tot += w
+            if pdf == 0 or not np.any(w):
+                continue
+            assert np.all(np.isfinite(r)) and abs(np.linalg.norm(wo) - 1) < 1e-3
+            out = np.zeros(4, np.float32)
+            wi32, wo32 = np.asarray(wi, np.float32), np.asarray(wo, np.float32)
+            if typ & DELTA:
+                lib.orc_bsdf_eval_discrete(C.addressof(m), wi32.ctypes.data, wo32.ctypes.data, EAll, out.ctypes.data)
+            else:
+                lib.orc_bsdf_eval(C.addressof(m), wi32.ctypes.data, wo32.ctypes.data, EAll, out.ctypes.data)
+            if name.startswith("coating") and (typ & DELTA):
+                # a delta child reflects into the same direction as the coat itself; f()/pdf() with the discrete measure answer for
+                # the coat's own lobe first (BSDF_Complex.cu:89-93,135-138), so the pair cannot be told apart afterwards
+                continue
+            if name.startswith("coating"):
+                # coating::sample scales the nested sample instead of calling f()/pdf(): compare the ratio
+                assert out[3] > 0
+                assert out[:3] / out[3] == pytest.approx(w, rel=2e-2, abs=2e-4), (theta, s, typ)
+            else:
+                assert out[3] == pytest.approx(pdf, rel=5e-3, abs=1e-6), (theta, s, typ)
+                assert out[:3] / out[3] == pytest.approx(w, rel=1e-2, abs=1e-4), (theta, s, typ)
+            n_checked += 1
+        assert np.all(tot / len(S) <= 1.03), (theta, tot / len(S))
+    assert n_checked > 200 or name == "coating_conductor"   # (all of its lobes are delta)
+    lib.orc_set_probe_materials(None)
+
+
 def test_plastic_branches(lib):
     """plastic: P(specular) = Fi*w / (Fi*w + (1-Fi)(1-w)) (BSDF_Simple.cu plastic::sample); both branches carry 1/prob."""
     m = api.plastic(diffuse_reflectance=(0.5, 0.5, 0.5), int_ior=1.49)
