@@ -583,9 +583,11 @@ class _Parameters:
 class WavefrontPathTracer:
     """Integrators/PseudoRealtime/WavefrontPathTracer.h:24-67 behind Tracer<true> (Kernel/Tracer.h:193-294)."""
 
+    PLUGIN = b"WavefrontPathTracer"
+
     def __init__(self):
         self._h = C.c_void_p()
-        _check(lib.ctl_tracer_create(b"WavefrontPathTracer", C.byref(self._h)))
+        _check(lib.ctl_tracer_create(self.PLUGIN, C.byref(self._h)))
         self._scene = None
 
     def __del__(self):
@@ -634,6 +636,12 @@ class WavefrontPathTracer:
 
     def getNumPassesDone(self):
         return self.stats().passes_done
+
+
+class PathTracer(WavefrontPathTracer):
+    """Integrators/PathTracer.h:7-31 — the megakernel integrator (one kernel per pass) behind the same plugin API; needs a
+    flattened scene.  For A/B against the wavefront tracer."""
+    PLUGIN = b"PathTracer"
 
 
 class SequenceGenerator:

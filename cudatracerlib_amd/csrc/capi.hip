@@ -125,9 +125,9 @@ int ctl_image_write_file(ctl_image* img, float splat_scale, const char* path) { 
 // ---- tracer
 int ctl_tracer_create(const char* plugin, ctl_tracer** out) {
     CTL_REQUIRE(plugin && out, "null argument");
-    if (std::strcmp(plugin, "WavefrontPathTracer") != 0 && std::strcmp(plugin, "PT_Wave") != 0)   // main.cpp:95-96
-        return fail(CTL_ERR_UNSUPPORTED, std::string("unknown tracer plugin: ") + plugin);
-    CTL_TRY ctl_tracer* t = new ctl_tracer(); try { t->t.reset(new WavefrontPathTracer()); } catch (...) { delete t; throw; } *out = t; CTL_CATCH
+    const bool wave = !std::strcmp(plugin, "WavefrontPathTracer") || !std::strcmp(plugin, "PT_Wave"), mega = !std::strcmp(plugin, "PathTracer") || !std::strcmp(plugin, "PT");   // main.cpp:91-96
+    if (!wave && !mega) return fail(CTL_ERR_UNSUPPORTED, std::string("unknown tracer plugin: ") + plugin);
+    CTL_TRY ctl_tracer* t = new ctl_tracer(); try { if (wave) t->t.reset(new WavefrontPathTracer()); else t->t.reset(new PathTracer()); } catch (...) { delete t; throw; } *out = t; CTL_CATCH
 }
 void ctl_tracer_destroy(ctl_tracer* t) { delete t; }
 int ctl_tracer_set_param_bool(ctl_tracer* t, const char* key, int value) { CTL_REQUIRE(t && key, "null argument"); CTL_TRY t->t->getParameters().setValue(key, value ? 1 : 0, TracerParameter::Bool); CTL_CATCH }

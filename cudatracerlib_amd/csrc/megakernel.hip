@@ -1,0 +1,188 @@
+// megakernel.hip — the "PathTracer" plugin: the reference's megakernel integrator (Integrators/PathTracer.cu: pathKernel2
+// :182-194 looping PathTrace<DIRECT> :10-113) as ONE kernel, one lane = one (pixel, pass) path from the camera to termination.
+// Same device functions as the wavefront tracer (shading.h), same sampler draws in the same order, shadow rays resolved inline.
+// It exists for A/B comparison behind the same plugin API; the wavefront formulation is the fast one.
+#include "kernels.h"
+#include "shading.h"
+#include "compaction.h"
+#include "tracer.h"
+#include "traverse.h"
+#include "mitsuba_loader.h"   // unsupported_error
+#include <climits>
+
+namespace ctl {
+
+// single-ray traversal of the flattened 4-wide BVH (flatten.h): closest hit, or any hit in (tmin, tmax)
+template <bool ANY_HIT>
+__device__ bool trace_single(const dev_scene& S, f3 o, f3 d, float tmin, float tmax, float& ht, float& hu, float& hv, int& htri, int& hnode) {
+    const float4* __restrict__ nodes = S.flat_nodes;
+    const float4* __restrict__ leaves = S.flat_leaves;
+    const float idx = rcp_guarded(d.x), idy = rcp_guarded(d.y), idz = rcp_guarded(d.z);
+    const float oox = o.x * idx, ooy = o.y * idy, ooz = o.z * idz;
+    int stack[kStackSize]; int sp = 0; stack[0] = kSentinel;
+    int node = S.flat_root;
+    ht = tmax; hu = hv = 0.0f; htri = -1; hnode = -1;
+    while (node != kSentinel) {
+        if (node >= 0) {
+            const float4 q0 = nodes[node], q1 = nodes[node + 1], q2 = nodes[node + 2], q3 = nodes[node + 3];
+            const uint32_t meta = __float_as_uint(q0.w);
+            const float ax = __uint_as_float((meta & 0xffu) << 23) * idx, ay = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy, az = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
+            const float bx = __builtin_fmaf(q0.x, idx, -oox), by = __builtin_fmaf(q0.y, idy, -ooy), bz = __builtin_fmaf(q0.z, idz, -ooz);
+            const uint32_t lx = __float_as_uint(q1.x), hx = __float_as_uint(q1.y), ly = __float_as_uint(q1.z), hy = __float_as_uint(q1.w), lz = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
+            const bool px = idx >= 0.0f, py = idy >= 0.0f, pz = idz >= 0.0f;
+            const uint32_t nx = px ? lx : hx, fx = px ? hx : lx, ny = py ? ly : hy, fy = py ? hy : ly, nz = pz ? lz : hz, fz = pz ? hz : lz;
+            const int ch[4] = { __float_as_int(q2.z), __float_as_int(q2.w), __float_as_int(q3.x), __float_as_int(q3.y) };
+            uint32_t key[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float tnx = __builtin_fmaf((float)((nx >> (8 * c)) & 0xffu), ax, bx), tfx = __builtin_fmaf((float)((fx >> (8 * c)) & 0xffu), ax, bx);
+                const float tny = __builtin_fmaf((float)((ny >> (8 * c)) & 0xffu), ay, by), tfy = __builtin_fmaf((float)((fy >> (8 * c)) & 0xffu), ay, by);
+                const float tnz = __builtin_fmaf((float)((nz >> (8 * c)) & 0xffu), az, bz), tfz = __builtin_fmaf((float)((fz >> (8 * c)) & 0xffu), az, bz);
+                const float cmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin)), cmax = fminf(fminf(tfx, tfy), fminf(tfz, ht));
+                key[c] = ((cmax >= cmin) && ((meta >> (24 + c)) & 1u)) ? ((__float_as_uint(cmin) & ~3u) | (uint32_t)c) : 0xffffffffu;
+            }
+#define CTL_CSWAP(a, b) { const uint32_t lo_ = key[a] < key[b] ? key[a] : key[b], hi_ = key[a] < key[b] ? key[b] : key[a]; key[a] = lo_; key[b] = hi_; }
+            CTL_CSWAP(0, 1) CTL_CSWAP(2, 3) CTL_CSWAP(0, 2) CTL_CSWAP(1, 3) CTL_CSWAP(1, 2)
+#undef CTL_CSWAP
+            for (int i = 3; i >= 1; i--) if (key[i] != 0xffffffffu) stack[++sp] = ch[key[i] & 3u];
+            node = key[0] != 0xffffffffu ? ch[key[0] & 3u] : stack[sp--];
+        } else {
+            const float4* p = leaves + (size_t)(~node) * 4;
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            const uint32_t index = __float_as_uint(q3.x);
+            const float Oz = q0.w - o.x * q0.x - o.y * q0.y - o.z * q0.z;
+            const float invDz = __builtin_amdgcn_rcpf(d.x * q0.x + d.y * q0.y + d.z * q0.z);
+            const float t = Oz * invDz;
+            if (t > tmin && t < ht) {
+                const float Ox = q1.w + o.x * q1.x + o.y * q1.y + o.z * q1.z, Dx = d.x * q1.x + d.y * q1.y + d.z * q1.z;
+                const float u = Ox + t * Dx;
+                if (u >= 0.0f) {
+                    const float Oy = q2.w + o.x * q2.x + o.y * q2.y + o.z * q2.z, Dy = d.x * q2.x + d.y * q2.y + d.z * q2.z;
+                    const float v = Oy + t * Dy;
+                    if (v >= 0.0f && u + v <= 1.0f) { ht = t; hu = u; hv = v; htri = (int)(index >> 1); hnode = (int)__float_as_uint(q3.y); if (ANY_HIT) return true; }
+                }
+            }
+            node = (index & 1) ? stack[sp--] : node - 1;
+        }
+    }
+    return htri >= 0;
+}
+
+// pathKernel2<DIRECT> + PathTrace<DIRECT> (Integrators/PathTracer.cu:182-194, 10-113), no participating media
+__global__ __launch_bounds__(256) void k_path_trace(dev_scene S, pass_params P, ctl_pixel_data* __restrict__ image, unsigned long long* __restrict__ ray_count) {
+    const uint32_t tiles_x = (P.width + 63) / 64;
+    const uint32_t n_total = P.n_local_pixels * P.batch;
+    const uint32_t n1 = CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH;
+    unsigned long long rays = 0;
+    for (uint32_t gi = blockIdx.x * 256u + threadIdx.x; gi < n_total; gi += gridDim.x * 256u) {
+        const uint32_t pass_b = gi / P.n_local_pixels, li = gi - pass_b * P.n_local_pixels;
+        const uint32_t tile = P.tile_rank + (li >> 12) * P.tile_world, p = li & 4095u, micro = p >> 6, ln = p & 63u;
+        const uint32_t x = (tile % tiles_x) * 64 + (micro & 7u) * 8 + (ln & 7u), y = (tile / tiles_x) * 64 + (micro >> 3) * 8 + (ln >> 3);
+        if (x >= P.width || y >= P.height) continue;
+        sampler rng{ P.t1 + pass_b * n1, P.t2 + pass_b * n1, y * P.width + x, 0, 0 };
+        const f2 j = rng.next2();
+        const f2 pX{ (float)x + j.x, (float)y + j.y };
+        (void)rng.next2();   // aperture sample
+        f3 r_o, r_d; sensor_sample_ray(S.cam, pX, r_o, r_d);
+        f3 cl(0.0f), cf(1.0f), last_nor(0.0f);
+        int depth = 0; bool specularBounce = false, had_hit = false;
+        float brdf_scattering_pdf = 0;
+        while (depth++ < P.max_path_length) {
+            float t, u, v; int tri, node;
+            had_hit = trace_single<false>(S, r_o, r_d, S.eps, 3.402823466e+38f, t, u, v, tri, node);
+            rays++;
+            if (!had_hit) break;
+            bsdf_rec b; b.eta = 1.0f; b.sampled_type = 0; b.type_mask = kEAll;
+            b.dg.P = r_o + t * r_d;
+            fill_dg(S, u, v, tri, node, b.dg);
+            b.wi = b.dg.sys.to_local(-r_d);
+            const uint4 ninfo = S.node_info[node];
+            const ctl_material& mat = S.mats[ninfo.x + tri_mat_index(S, tri)];
+            if (mat.two_sided && b.wi.z < 0) { b.dg.n = -b.dg.n; b.dg.sys.n = -b.dg.sys.n; b.wi.z *= -1.0f; }
+            const uint32_t nli = mat.node_light_index;
+            if (nli != 0xffffffffu) {
+                const uint32_t li2 = nli == 0 ? ninfo.y : ninfo.z;
+                const ctl_light& light = S.lights[li2];
+                float misWeight = 1.0f;
+                if (!(!P.direct || depth == 1 || specularBounce)) misWeight = power_heuristic(brdf_scattering_pdf, light_pdf_direct(light, r_d, last_nor, b.dg.n, t) * pdf_emitter(S, li2));
+                cl = cl + misWeight * cf * light_eval(light, b.dg.sys.n, -r_d);
+            }
+            const f3 f = bsdf_sample_top(mat, b, brdf_scattering_pdf, rng.next2());
+            last_nor = b.dg.sys.n;
+            if (P.direct && (mat.combined_type & kESmooth) && S.num_lights) {   // UniformSampleOneLight + EstimateDirect (TraceAlgorithms.cu:44-101)
+                const f2 sl = rng.next2();
+                float lpdf; const int li2 = sample_emitter(S, lpdf, sl.x);
+                if (li2 >= 0) {
+                    direct_rec dr; dr.ref = b.dg.P; dr.refN = b.dg.sys.n;
+                    const f3 value = light_sample_direct(S, S.lights[li2], dr, rng.next2());
+                    if (!is_zero(value)) {
+                        bsdf_rec b2 = b; b2.wo = b.dg.sys.to_local(dr.d); b2.type_mask = kEAll & ~kEDelta;
+                        const f3 bsdfVal = bsdf_f_top(mat, b2);
+                        if (!is_zero(bsdfVal)) {
+                            float st, su, sv; int stri, snode;
+                            rays++;
+                            if (!trace_single<true>(S, dr.ref, dr.d, S.eps, dr.dist - S.eps, st, su, sv, stri, snode)) {   // Occluded(r, 0, dist)
+                                float weight = 1.0f;
+                                if (dr.measure != kMeasureDiscrete) weight = power_heuristic((dr.measure == kMeasureArea ? dr.pdf * dr.dist / fabsf(dot(dr.n, dr.d)) : dr.pdf) * lpdf, bsdf_pdf_top(mat, b2));
+                                cl = cl + cf * ((value * bsdfVal * weight) / lpdf);
+                            }
+                        }
+                    }
+                }
+            }
+            specularBounce = (b.sampled_type & kEDelta) != 0;
+            cf = cf * f;
+            r_o = b.dg.P; r_d = b.dg.sys.to_world(b.wo);
+            if (is_zero(cf)) break;   // cannot contribute any more (the wavefront tracer makes the same cut)
+            if (depth > P.rr_start_depth && !specularBounce) {
+                const float q = max3c(cf);
+                if (rng.next1() >= q) break;
+                cf = cf / q;
+            }
+        }
+        if (!had_hit && S.env_map_index != 0xffffffffu) {   // PathTracer.cu:99-111
+            const ctl_light& light = S.lights[S.env_map_index];
+            float misWeight = 1.0f;
+            if (!(!P.direct || depth == 1 || specularBounce)) misWeight = power_heuristic(brdf_scattering_pdf, env_pdf_direct(S, light, r_d) * pdf_emitter(S, S.env_map_index));
+            cl = cl + misWeight * cf * env_eval(S, light, r_d);
+        }
+        add_sample(image, P.width, P.height, pX.x, pX.y, cl);
+    }
+    // one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(ray_count, rays);
+}
+
+PathTracer::PathTracer() {
+    m_sParameters.addBool("Direct", true);                        // Integrators/PathTracer.h:10-19
+    m_sParameters.addBool("Regularization", false);               // accepted; regularised roughness is not implemented and must stay off
+    m_sParameters.addInterval("MaxPathLength", 50, 1, INT_MAX);
+    m_sParameters.addInterval("RRStartDepth", 5, 1, INT_MAX);
+    int dev = 0; hipDeviceProp_t prop; CTL_HIP(hipGetDevice(&dev)); CTL_HIP(hipGetDeviceProperties(&prop, dev));
+    grid_blocks = prop.multiProcessorCount * 8;
+}
+void PathTracer::InitializeScene(Scene* s) {
+    if (!s->S.flat_nodes || s->S.flat_width != 4) throw unsupported_error("PathTracer (megakernel): the scene must be created with CTL_SCENE_FLATTEN (4-wide nodes)");
+    Tracer<true>::InitializeScene(s);
+}
+void PathTracer::Resize(unsigned int _w, unsigned int _h) {
+    Tracer<true>::Resize(_w, _h);
+    n_local_pixels = shard_pixel_count(_w, _h, shard_rank, shard_world);
+    if (!count_.p) count_.alloc(1);
+}
+void PathTracer::DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) {
+    if (m_sParameters.getValue("Regularization")) throw unsupported_error("PathTracer: Regularization is not implemented");
+    pass_params P{};
+    P.t1 = d_t1; P.t2 = (const float2*)d_t2; P.batch = n_batch; P.width = w; P.height = h; P.tile_rank = shard_rank; P.tile_world = shard_world; P.n_local_pixels = n_local_pixels;
+    P.direct = m_sParameters.getValue("Direct"); P.max_path_length = m_sParameters.getValue("MaxPathLength"); P.rr_start_depth = m_sParameters.getValue("RRStartDepth");
+    CTL_HIP(hipMemsetAsync(count_.p, 0, sizeof(unsigned long long), stream));
+    timer.begin(stream, 2);
+    hipLaunchKernelGGL(k_path_trace, dim3(grid_blocks), dim3(256), 0, stream, m_pScene->S, P, I->device(), count_.p);
+    timer.end(stream);
+    CTL_HIP(hipMemcpyAsync(&host_count_, count_.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    CTL_HIP(hipStreamSynchronize(stream));
+    total_rays_ += host_count_;
+}
+void PathTracer::takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) { path_rays = total_rays_; shadow_rays_ = 0; total_rays_ = 0; }
+
+} // namespace ctl

@@ -168,6 +168,20 @@ private:
     float4* new_f4(size_t n);
 };
 
+// Integrators/PathTracer.h:7-31 — the megakernel integrator behind the same plugin API (megakernel.hip)
+class PathTracer : public Tracer<true> {
+public:
+    PathTracer();
+    void Resize(unsigned int w, unsigned int h) override;
+    void InitializeScene(Scene* s) override;
+protected:
+    void DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) override;
+    void takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) override;
+private:
+    dbuf<unsigned long long> count_; unsigned long long host_count_ = 0; uint64_t total_rays_ = 0;
+    uint32_t n_local_pixels = 0; int grid_blocks = 0;
+};
+
 int device_count();
 void require_device();
 

@@ -95,6 +95,35 @@ def test_mitsuba_xml_scene(gpu, orc, tmp_path):
     assert_close(got, want)
 
 
+@pytest.mark.parametrize("scene_kw", [dict(glass_sphere=True), dict(extra_materials=6), dict(extra_materials=8)])
+def test_megakernel_path_tracer_plugin(gpu, orc, scene_kw):
+    """ctl_tracer_create("PathTracer"): PathTrace<DIRECT> as one kernel — same image as the oracle (and as the wavefront tracer),
+    same ray count as the wavefront tracer"""
+    sc = scenes.cornell_box(64, 64, **scene_kw)
+    d = sc.desc
+    tables = orc.sequence_tables(3)
+    want, _ = orc.render(d, 64, 64, n_passes=3, tables=tables, max_path_length=8)
+    scene = gpu.Scene(d, flatten=True)
+    out = {}
+    for cls in (gpu.PathTracer, gpu.WavefrontPathTracer):
+        tr = cls(); tr.getParameters().setValue("MaxPathLength", 8)
+        tr.Resize(64, 64); tr.InitializeScene(scene)
+        img = gpu.Image(64, 64)
+        for k in range(3):
+            tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
+        out[cls.__name__] = (img.getPixelData(), tr.stats().rays_total)
+    got, rays_mega = out["PathTracer"]
+    g, w = got[..., :3], want[..., :3]
+    assert np.array_equal(got[..., 6], want[..., 6])
+    assert (np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2).mean() >= 0.99        # flattened layout: t,u,v to fp32 round-off
+    assert abs(g.mean() - w.mean()) <= 5e-3 * w.mean()
+    wave, rays_wave = out["WavefrontPathTracer"]
+    assert np.isclose(got[..., :3], wave[..., :3], rtol=1e-3, atol=1e-3).all(axis=2).mean() >= 0.995
+    assert abs(int(rays_mega) - int(rays_wave)) <= 1e-3 * rays_wave
+    with pytest.raises(gpu.CtlError):
+        tr = gpu.PathTracer(); tr.Resize(64, 64); tr.InitializeScene(gpu.Scene(d))        # needs the flattened layout
+
+
 def test_image_pipeline_and_output_files(gpu, tmp_path):
     """applyImagePipeline (no filter / post-process) = toSpectrum(splatScale) -> sRGB curve -> RGBCOL; WriteDisplayImage"""
     import struct, zlib
