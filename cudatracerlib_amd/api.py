@@ -34,7 +34,9 @@ class ctl_texture(C.Structure):
 
 class ctl_material(C.Structure):
     _fields_ = [("bsdf_type", u32), ("combined_type", u32), ("two_sided", u32), ("node_light_index", u32),
-                ("tex", ctl_texture * 4), ("f", f32 * 8), ("u", u32 * 4)]
+                ("tex", ctl_texture * 4), ("f", f32 * 8), ("u", u32 * 4),
+                ("map_kind", u32), ("alpha_state", u32), ("alpha_test_scalar", f32), ("alpha_test_color", f32 * 3), ("reserved_", u32 * 2),
+                ("map_tex", ctl_texture), ("alpha_tex", ctl_texture)]
 
 
 class ctl_light(C.Structure):
@@ -105,7 +107,7 @@ class ctl_scene_desc(C.Structure):
         return np.frombuffer(buf, dtype=dtype).reshape(count, width)
 
 
-assert C.sizeof(ctl_texture) == 48 and C.sizeof(ctl_material) == 256 and C.sizeof(ctl_pixel_data) == 28 and C.sizeof(ctl_hit) == 20
+assert C.sizeof(ctl_texture) == 48 and C.sizeof(ctl_material) == 384 and C.sizeof(ctl_pixel_data) == 28 and C.sizeof(ctl_hit) == 20
 
 lib.ctl_last_error.restype = C.c_char_p
 lib.ctl_version.restype = C.c_char_p
@@ -366,6 +368,34 @@ def roughcoating(nested_index, nested, alpha=0.1, int_ior=1.5046, ext_ior=1.0002
     m.f[0], m.f[1], m.f[2], m.f[3] = eta, 1.0 / eta, thickness, _coating_ssw(m.tex[0], thickness)
     m.u[0], m.u[1], m.u[2] = distribution, 0 if distribution == 2 else 1, nested_index
     return m
+
+
+MAP_NONE, MAP_NORMAL, MAP_HEIGHT = 0, 1, 2
+ALPHA_DISABLED, ALPHA_MAP_LUMINANCE, ALPHA_MAP_ALPHA, ALPHA_MAP_COLOR = 0, 1, 2, 3
+ALPHA_REFLECTANCE_LUMINANCE, ALPHA_REFLECTANCE_ALPHA, ALPHA_REFLECTANCE_COLOR = 5, 6, 7
+
+
+def set_normal_map(material, texture):
+    """Material::SetNormalMap (Engine/Material.h:93-99); excludes a height map."""
+    if material.map_kind == MAP_HEIGHT:
+        raise CtlError(-1, "Cannot set both height and normal map!")
+    material.map_kind = MAP_NORMAL; material.map_tex = _as_tex(texture)
+    return material
+
+
+def set_height_map(material, texture):
+    """Material::SetHeightMap (Engine/Material.h:100-106); only image textures perturb the frame (Material.cu:109)."""
+    if material.map_kind == MAP_NORMAL:
+        raise CtlError(-1, "Cannot set both height and normal map!")
+    material.map_kind = MAP_HEIGHT; material.map_tex = _as_tex(texture)
+    return material
+
+
+def set_alpha_map(material, texture, state=ALPHA_MAP_LUMINANCE, test_scalar=1.0, test_color=(0.0, 0.0, 0.0)):
+    """Material::SetAlphaMap + AlphaBlendData::test_val_* (Engine/Material.h:24-36,107-111)."""
+    material.alpha_state = state; material.alpha_tex = _as_tex(texture)
+    material.alpha_test_scalar = float(test_scalar); material.alpha_test_color[:] = [float(x) for x in test_color]
+    return material
 
 
 def blend(index0, nested0, index1, nested1, weight=0.5):

@@ -8,7 +8,7 @@ namespace ctl {
 
 constexpr int kExitMarker = 0x76543211;   // traversal-stack marker: leave the current instance (> kSentinel as unsigned)
 // feature bits of the shade kernel builds (CTL_SHADE_FEATURES in shading.h)
-enum { kShadeMoreBsdfs = 1, kShadeRoughBsdfs = 2, kShadeImageTextures = 4, kShadeMoreLights = 8, kShadeNestingBsdfs = 16 };
+enum { kShadeMoreBsdfs = 1, kShadeRoughBsdfs = 2, kShadeImageTextures = 4, kShadeMoreLights = 8, kShadeNestingBsdfs = 16, kShadeSurfaceMaps = 32 };
 constexpr int kStackSize = 96;            // two-level: top depth + bottom depth + markers; 4-wide flat tree: 3 * depth + 1 — both checked at upload
 
 // precomputed PerspectiveSensor state (SceneTypes/Sensor.cu:76-96)
@@ -39,6 +39,7 @@ struct dev_scene {
     uint32_t n_nodes;
     uint32_t num_lights;
     uint32_t env_map_index;
+    uint32_t alpha_maps;         // KernelDynamicScene::doAlphaMapping: some material carries an alpha map
     uint32_t shade_features;     // kShade* bits the scene needs (selects the shade-kernel build, kernels.hip launch_shade)
     float eps;                   // m_rayTraceEps
     uint32_t light_indices[CTL_MAX_NUM_LIGHTS];

@@ -45,7 +45,7 @@ struct pass_params {
     int direct, max_path_length, rr_start_depth;
 };
 
-struct launch_ctx { hipStream_t stream; int grid_blocks; };
+struct launch_ctx { hipStream_t stream; int grid_blocks; bool alpha_test = false; };   // alpha_test: intersect kernels run Material::AlphaTest on candidate hits
 
 // measurement knobs (environment: CTL_REFILL_IDLE), applied once per process
 void apply_tuning_from_env();

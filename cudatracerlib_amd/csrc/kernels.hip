@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kWideBlock) void k_raygen(dev_scene S, wave_queues 
 // ------------------------------------------------------------------------------------------------ intersection
 // Persistent waves with lane refill and an LDS traversal stack — see traverse.h (the reference's g_warpCounter pool,
 // Kernel/TraceHelper.cu:386-399, re-derived for 64-wide waves).
-template <bool ANY_HIT, bool COUNT, int FLAT>   // FLAT: 0 two-level, 4 / 8 flattened BVH with 4- / 8-wide nodes
+template <bool ANY_HIT, bool COUNT, int FLAT, bool ALPHA>   // FLAT: 0 two-level, 4 / 8 flattened BVH with 4- / 8-wide nodes; ALPHA: alpha-test candidate hits
 __global__ __launch_bounds__(kBlock) void k_intersect(dev_scene S, const float4* __restrict__ ro, const float4* __restrict__ rd, const uint32_t* __restrict__ n_ptr,
                                                        uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ,
                                                        unsigned long long* __restrict__ counts3) {
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(kBlock) void k_intersect(dev_scene S, const float4*
     const uint32_t n = *n_ptr;
     trav_counts tc{ 0, 0, 0, 0, 0 };
     if (FLAT == 8) intersect_flat8<ANY_HIT, COUNT>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
-    else if (FLAT == 4) intersect_flat<ANY_HIT, COUNT>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
-    else intersect_persistent<ANY_HIT, COUNT>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
+    else if (FLAT == 4) intersect_flat<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
+    else intersect_persistent<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
     if (COUNT) {
         atomicAdd(&counts3[0], (unsigned long long)tc.n_inner); atomicAdd(&counts3[1], (unsigned long long)tc.n_tri); atomicAdd(&counts3[2], (unsigned long long)tc.n_inst);
         atomicAdd(&counts3[3], (unsigned long long)tc.w_inner); atomicAdd(&counts3[4], (unsigned long long)tc.w_tri);
@@ -125,9 +125,11 @@ void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& 
 }
 #define CTL_LAUNCH_INTERSECT(ANY, CNT, ...)                                                                                          \
     do {                                                                                                                             \
-        if (S.flat_nodes && S.flat_width == 8) hipLaunchKernelGGL((k_intersect<ANY, CNT, 8>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
-        else if (S.flat_nodes) hipLaunchKernelGGL((k_intersect<ANY, CNT, 4>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((k_intersect<ANY, CNT, 0>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__);            \
+        if (S.flat_nodes && S.flat_width == 8) hipLaunchKernelGGL((k_intersect<ANY, CNT, 8, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
+        else if (S.flat_nodes && lc.alpha_test) hipLaunchKernelGGL((k_intersect<ANY, CNT, 4, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
+        else if (S.flat_nodes) hipLaunchKernelGGL((k_intersect<ANY, CNT, 4, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
+        else if (lc.alpha_test) hipLaunchKernelGGL((k_intersect<ANY, CNT, 0, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((k_intersect<ANY, CNT, 0, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__);     \
     } while (0)
 void launch_intersect_closest(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node) {
     CTL_LAUNCH_INTERSECT(false, false, S, ro, rd, n_ptr, work, hit, hit_node, (uint32_t*)nullptr, (unsigned long long*)nullptr);

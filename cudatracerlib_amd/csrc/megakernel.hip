@@ -59,7 +59,10 @@ __device__ bool trace_single(const dev_scene& S, f3 o, f3 d, float tmin, float t
                 if (u >= 0.0f) {
                     const float Oy = q2.w + o.x * q2.x + o.y * q2.y + o.z * q2.z, Dy = d.x * q2.x + d.y * q2.y + d.z * q2.z;
                     const float v = Oy + t * Dy;
-                    if (v >= 0.0f && u + v <= 1.0f) { ht = t; hu = u; hv = v; htri = (int)(index >> 1); hnode = (int)__float_as_uint(q3.y); if (ANY_HIT) return true; }
+                    // USE_ALPHA of __traceRay_internal__ (TraceHelper.cu:135-153): scenes with alpha maps test every candidate hit
+                    if (v >= 0.0f && u + v <= 1.0f && (!S.alpha_maps || alpha_survives(S.tri_data, S.node_info, S.mats, S.images, (int)(index >> 1), (int)__float_as_uint(q3.y), u, v))) {
+                        ht = t; hu = u; hv = v; htri = (int)(index >> 1); hnode = (int)__float_as_uint(q3.y); if (ANY_HIT) return true;
+                    }
                 }
             }
             node = (index & 1) ? stack[sp--] : node - 1;
@@ -98,6 +101,7 @@ __global__ __launch_bounds__(256) void k_path_trace(dev_scene S, pass_params P, 
             b.wi = b.dg.sys.to_local(-r_d);
             const uint4 ninfo = S.node_info[node];
             const ctl_material& mat = S.mats[ninfo.x + tri_mat_index(S, tri)];
+            if (mat.map_kind != CTL_MAP_NONE) sample_normal_map(mat, b.dg);
             if (mat.two_sided && b.wi.z < 0) { b.dg.n = -b.dg.n; b.dg.sys.n = -b.dg.sys.n; b.wi.z *= -1.0f; }
             const uint32_t nli = mat.node_light_index;
             if (nli != 0xffffffffu) {

@@ -1,0 +1,119 @@
+// mipmap.h — KernelMIPMap level 0 on the device, and the material alpha test that single-ray traversal runs on candidate hits
+// (Material::AlphaTest, Engine/Material.cu:141-190, called from TraceHelper.cu:135-153).  Shared by the shade kernels and the
+// traversal kernels.
+#pragma once
+#include "device_scene.h"
+
+namespace ctl {
+
+__device__ __forceinline__ float luminance(f3 s) { return s.x * 0.212671f + s.y * 0.715160f + s.z * 0.072169f; }   // Spectrum.cu:174-177
+
+// ---- KernelMIPMap level 0 (Engine/MIPMap.cu:21-57,116-121,155-172; MIPMap_device.h:34-55)
+__device__ __forceinline__ f3 texel_decode(uint32_t v, uint32_t type) {
+    const uint32_t x = v & 0xff, y = (v >> 8) & 0xff, z = (v >> 16) & 0xff, w = v >> 24;
+    if (type == CTL_TEXEL_RGBE) {   // SpectrumConverter::RGBEToFloat3 (Math/Spectrum.h:557-565)
+        if (!w) return f3(0.0f);
+        const float e = ldexpf(1.0f, (int)w - (128 + 8));
+        return f3(x * e, y * e, z * e);
+    }
+    return f3(float(x) / 255.0f, float(y) / 255.0f, float(z) / 255.0f);   // COLORREFToFloat3 (:528-532)
+}
+__device__ __forceinline__ float fracf_(float f) { return f - floorf(f); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ bool wrap_coordinates(f2 uv, f2 dim, uint32_t w, f2& loc) {
+    switch (w) {
+    case CTL_WRAP_REPEAT: loc = f2{ fracf_(uv.x) * dim.x, fracf_(1.0f - uv.y) * dim.y }; return true;
+    case CTL_WRAP_CLAMP: loc = f2{ clampf(uv.x, 0.0f, 1.0f) * dim.x, clampf(1.0f - uv.y, 0.0f, 1.0f) * dim.y }; return true;
+    case CTL_WRAP_MIRROR: {   // the reference tests the parity of uv.x for both axes
+        const float lx = (int)uv.x % 2 == 0 ? fracf_(uv.x) : 1.0f - fracf_(uv.x), ly = (int)uv.x % 2 == 0 ? fracf_(uv.y) : 1.0f - fracf_(uv.y);
+        loc = f2{ lx * dim.x, ly * dim.y }; return true; }
+    case CTL_WRAP_BLACK:
+        if (uv.x < 0 || uv.x >= 1 || uv.y < 0 || uv.y >= 1) return false;
+        loc = f2{ uv.x * dim.x, uv.y * dim.y }; return true;
+    }
+    return false;
+}
+__device__ __forceinline__ f3 mip_texel(const ctl_mipmap& M, f2 uv) {
+    f2 l;
+    if (!wrap_coordinates(uv, f2{ (float)M.width, (float)M.height }, M.wrap_mode, l)) return f3(0.0f);
+    const int x = clampi((int)l.x, 0, (int)M.width - 1), y = clampi((int)l.y, 0, (int)M.height - 1);
+    return texel_decode(M.texels[(size_t)y * M.width + x], M.texel_type);
+}
+__device__ __forceinline__ f3 mip_triangle(const ctl_mipmap& M, f2 uv) {
+    const f2 sz{ (float)M.width, (float)M.height }, is{ 1.0f / sz.x, 1.0f / sz.y };
+    const float ds = fracf_(uv.x * sz.x), dt = fracf_(uv.y * sz.y);
+    return ((1.f - ds) * (1.f - dt)) * mip_texel(M, uv) + ((1.f - ds) * dt) * mip_texel(M, f2{ uv.x + 0, uv.y + is.y }) +
+           (ds * (1.f - dt)) * mip_texel(M, f2{ uv.x + is.x, uv.y + 0 }) + (ds * dt) * mip_texel(M, f2{ uv.x + is.x, uv.y + is.y });
+}
+__device__ __forceinline__ f3 mip_fetch(const ctl_mipmap& M, int x, int y) {
+    x = clampi(x, 0, (int)M.width - 1); y = clampi(y, 0, (int)M.height - 1);
+    return texel_decode(M.texels[(size_t)y * M.width + x], M.texel_type);
+}
+
+// KernelMIPMap::SampleAlpha (MIPMap.cu:123-138); the texel index is clamped here, the reference does not
+__device__ __forceinline__ float mip_sample_alpha(const ctl_mipmap& M, f2 uv) {
+    f2 l;
+    if (!wrap_coordinates(uv, f2{ (float)M.width, (float)M.height }, M.wrap_mode, l)) return 0.0f;
+    if (M.texel_type == CTL_TEXEL_RGBE) return 1.0f;
+    const int x = clampi((int)l.x, 0, (int)M.width - 1), y = clampi((int)l.y, 0, (int)M.height - 1);
+    return float(M.texels[(size_t)y * M.width + x] >> 24) / 255.0f;
+}
+// KernelMIPMap::evalGradient (MIPMap.cu:174-191)
+__device__ __forceinline__ void mip_eval_gradient(const ctl_mipmap& M, f2 uv, f3& g0, f3& g1) {
+    const f2 dim{ (float)M.width, (float)M.height };
+    const float u = uv.x * dim.x - 0.5f, v = uv.y * dim.y - 0.5f;
+    const int xPos = (int)u, yPos = (int)v;
+    const float dx = u - xPos, dy = v - yPos;
+    const f3 p00 = mip_texel(M, f2{ (float)xPos / dim.x, (float)yPos / dim.y });
+    const f3 p10 = mip_texel(M, f2{ ((float)xPos + 1) / dim.x, (float)yPos / dim.y });
+    const f3 p01 = mip_texel(M, f2{ (float)xPos / dim.x, ((float)yPos + 1) / dim.y });
+    const f3 p11 = mip_texel(M, f2{ ((float)xPos + 1) / dim.x, ((float)yPos + 1) / dim.y });
+    const f3 tmp = p01 + p10 - p11;
+    g0 = (p10 + p00 * (dy - 1) - tmp * dy) * dim.x;
+    g1 = (p01 + p00 * (dx - 1) - tmp * dx) * dim.y;
+}
+__device__ __forceinline__ f2 tex_map_point(const ctl_texture& t, f2 uv) { return f2{ t.uv_scale[0] * uv.x + 0 * uv.y + t.uv_offset[0], 0 * uv.x + t.uv_scale[1] * uv.y + t.uv_offset[1] }; }   // TextureMapping2D::TransformPoint
+
+// sample_fast (Material.cu:141-158): constant / checkerboard / image texture at an interpolated uv
+__device__ __forceinline__ f3 tex_eval_uv(const ctl_texture& t, f2 duv, const ctl_mipmap* images) {
+    if (t.type == CTL_TEX_CHECKER) {
+        const f2 p = tex_map_point(t, duv);
+        int xm = (int)(p.x * 2) % 2, ym = (int)(p.y * 2) % 2; if (xm < 0) xm += 2; if (ym < 0) ym += 2;
+        return ((2 * xm - 1) * (2 * ym - 1) == 1) ? f3(t.value[0], t.value[1], t.value[2]) : f3(t.value1[0], t.value1[1], t.value1[2]);
+    }
+    if (t.type == CTL_TEX_IMAGE) {
+        if (t.image == 0xffffffffu) return f3(0.0f);
+        const ctl_mipmap& M = images[t.image];
+        const f2 uv = tex_map_point(t, duv);
+        return (M.filter_mode == CTL_FILTER_POINT ? mip_texel(M, uv) : mip_triangle(M, uv)) * f3(t.value[0], t.value[1], t.value[2]);
+    }
+    return f3(t.value[0], t.value[1], t.value[2]);
+}
+
+// Material::AlphaTest for the triangle a ray is about to accept.  Out of line and fed with plain pointers: it sits in the
+// traversal loops, where only scenes with alpha maps may pay for it.
+__device__ __noinline__ bool alpha_survives(const uint4* __restrict__ tri_data, const uint4* __restrict__ node_info, const ctl_material* __restrict__ mats,
+                                            const ctl_mipmap* __restrict__ images, int tri, int node, float u, float v) {
+    const uint4 ta = tri_data[tri * 2], tb = tri_data[tri * 2 + 1];
+    const ctl_material& mat = mats[node_info[node].x + ((ta.y >> 16) & 0xff)];
+    const uint32_t st = mat.alpha_state;
+    if (st == CTL_ALPHA_DISABLED) return true;
+    const f2 a{ half_to_float((uint16_t)tb.y), half_to_float((uint16_t)(tb.y >> 16)) }, b{ half_to_float((uint16_t)tb.z), half_to_float((uint16_t)(tb.z >> 16)) },
+        c{ half_to_float((uint16_t)tb.w), half_to_float((uint16_t)(tb.w >> 16)) };
+    const float w = 1 - u - v;
+    const f2 uv{ u * a.x + v * b.x + w * c.x, u * a.y + v * b.y + w * c.y };
+    const ctl_texture& refl = mat.tex[0];
+    if ((st == CTL_ALPHA_MAP_ALPHA && mat.alpha_tex.type == CTL_TEX_IMAGE) || (st == CTL_ALPHA_REFLECTANCE_ALPHA && refl.type == CTL_TEX_IMAGE)) {
+        const ctl_texture& t = st == CTL_ALPHA_MAP_ALPHA ? mat.alpha_tex : refl;
+        return mip_sample_alpha(images[t.image], tex_map_point(t, uv)) >= mat.alpha_test_scalar;
+    }
+    const f3 val = tex_eval_uv((st & 4) ? refl : mat.alpha_tex, uv, images);
+    if ((st & 3) == 1) return luminance(val) >= mat.alpha_test_scalar;
+    if ((st & 3) == 3) {
+        const f3 d = val - f3(mat.alpha_test_color[0], mat.alpha_test_color[1], mat.alpha_test_color[2]);
+        return max2(max2(fabsf(d.x), fabsf(d.y)), fabsf(d.z)) <= mat.alpha_test_scalar;
+    }
+    return true;
+}
+
+} // namespace ctl

@@ -46,7 +46,8 @@ f3 forward(const mat4& m) { return xf_dir(m, f3(0, 0, 1)); }
 
 struct rgb { float r, g, b; rgb(float v = 0) : r(v), g(v), b(v) {} rgb(float R, float G, float B) : r(R), g(G), b(B) {} };
 
-struct bsdf_data { ctl_material mat; bool two_sided = false; bool has_heightmap = false, has_alphamap = false; };
+// BsdfData (ObjectParser.h:600-610); the height / alpha map travel inside ctl_material (map_tex, alpha_tex)
+struct bsdf_data { ctl_material mat; bool two_sided = false; };
 struct shape_result;
 struct group_data { std::vector<std::pair<mat4, uint32_t>> nodes; int instanciations = 0; };
 struct shape_result { int type = 3; uint32_t node = 0; group_data group; };   // 1 node, 2 group, 3 nothing (ObjectParser.h:1147-1166)
@@ -242,7 +243,14 @@ struct loader {
     }
     static bsdf_data make(const ctl_material& m, const std::vector<bsdf_data>* others = nullptr) {   // BsdfParser::create (:605-626)
         bsdf_data d; d.mat = m;
-        if (others) for (auto& c : *others) { d.two_sided |= c.two_sided; d.has_heightmap |= c.has_heightmap; d.has_alphamap |= c.has_alphamap; }
+        if (others) for (auto& c : *others) {   // the first nested BSDF that has a map hands it up (:621-624)
+            d.two_sided |= c.two_sided;
+            if (d.mat.map_kind == CTL_MAP_NONE && c.mat.map_kind != CTL_MAP_NONE) { d.mat.map_kind = c.mat.map_kind; d.mat.map_tex = c.mat.map_tex; }
+            if (d.mat.alpha_state == CTL_ALPHA_DISABLED && c.mat.alpha_state != CTL_ALPHA_DISABLED) {
+                d.mat.alpha_state = c.mat.alpha_state; d.mat.alpha_tex = c.mat.alpha_tex; d.mat.alpha_test_scalar = c.mat.alpha_test_scalar;
+                std::memcpy(d.mat.alpha_test_color, c.mat.alpha_test_color, sizeof(d.mat.alpha_test_color));
+            }
+        }
         return d;
     }
     bsdf_data parse_bsdf(const xml_node& n, int depth) {   // BsdfParser::parse (:968-992)
@@ -270,8 +278,17 @@ struct loader {
         }
         else if (T == "difftrans") { ctl_material m = make_diffuse(try_tex(n, "reflectance", rgb(0.5f))); m.combined_type = CTL_EDiffuseTransmission; d = make(m); }
         else if (T == "twosided") { auto nested = all_nested(n, depth - 1); if (nested.size() != 1) bad("expected 1 nested bsdf in twosided!"); d = nested[0]; d.two_sided = true; }
-        else if (T == "bumpmap") { auto nested = all_nested(n, depth - 1); if (nested.size() != 1) bad("expected 1 nested bsdf in bumpmap!"); unsupported("bsdf type bumpmap (height maps)"); d = nested[0]; d.has_heightmap = true; }
-        else if (T == "mask") { auto nested = all_nested(n, depth - 1); if (nested.size() != 1) bad("expected 1 nested bsdf in mask!"); unsupported("bsdf type mask (opacity maps)"); d = nested[0]; d.has_alphamap = true; }
+        else if (T == "bumpmap") { auto nested = all_nested(n, depth - 1); if (nested.size() != 1) bad("expected 1 nested bsdf in bumpmap!"); d = nested[0]; d.mat.map_kind = CTL_MAP_HEIGHT; d.mat.map_tex = try_tex(n, "texture", rgb(0.0f)); }   // :867-877
+        else if (T == "mask") { auto nested = all_nested(n, depth - 1); if (nested.size() != 1) bad("expected 1 nested bsdf in mask!");   // :930-947
+            const ctl_texture opacity = try_tex(n, "opacity", rgb(0.0f));
+            if (nested[0].mat.bsdf_type == CTL_BSDF_DIFFUSE) {   // the reference turns a masked diffuse into a diffuse TRANSMITTER coloured by the opacity (:940-944)
+                ctl_material m = make_diffuse(opacity); m.combined_type = CTL_EDiffuseTransmission; d = make(m, &nested);
+            } else {
+                // SetAlphaMap(opacity, AlphaMap_Luminance) (:1006-1007).  The reference leaves AlphaBlendData::test_val_scalar uninitialised on this
+                // path; the build uses 1.0, the value the reference's OBJ loader sets for its alpha maps (ObjParser.cpp:849)
+                d = nested[0]; d.mat.alpha_state = CTL_ALPHA_MAP_LUMINANCE; d.mat.alpha_tex = opacity; d.mat.alpha_test_scalar = 1.0f;
+            }
+        }
         else if (T == "coating" || T == "roughcoating") {
             auto nested = all_nested(n, depth); if (nested.size() != 1) bad("expected 1 nested bsdf in coating!");
             if (depth == 1 || nested[0].mat.bsdf_type >= CTL_BSDF_HK) d = nested[0];   // is_max_depth(): the reference returns the nested BSDF (:873-874); BSDFFirst cannot hold a nesting model

@@ -2,11 +2,12 @@
 // textures, BSDFs, emitters.  Each function states the reference lines whose behaviour it reproduces.
 #pragma once
 #include "device_scene.h"
+#include "mipmap.h"
 
 // Feature set compiled into the shading functions of this translation unit (bits = kShade* of device_scene.h).  The shade
 // kernel is built twice (shade_basic.hip: 0, shade_full.hip: all); everything else uses the full set.
 #ifndef CTL_SHADE_FEATURES
-#define CTL_SHADE_FEATURES 0x1F
+#define CTL_SHADE_FEATURES 0x3F
 #endif
 
 namespace ctl {
@@ -43,7 +44,12 @@ __device__ __forceinline__ void sensor_sample_ray(const dev_sensor& c, f2 pixelS
 }
 
 // ---- differential geometry at a hit (Kernel/TraceHelper.cu:274-307 -> Engine/TriangleData.cu:75-103)
-struct diff_geom { f3 P; frame sys; f3 n; f2 uv; const ctl_mipmap* images; const ctl_rough_transmittance* rough_transmittance; const ctl_material* mats; };   // images: g_SceneData.m_sTexData; tables of RoughTransmittanceManager (both uniform)
+struct diff_geom {
+    f3 P; frame sys; f3 n; f2 uv; const ctl_mipmap* images; const ctl_rough_transmittance* rough_transmittance; const ctl_material* mats;
+#if CTL_SHADE_FEATURES & 32
+    f3 dpdu, dpdv;   // world space, for height maps only
+#endif
+};   // images: g_SceneData.m_sTexData; tables of RoughTransmittanceManager (both uniform)
 __device__ __forceinline__ void fill_dg(const dev_scene& S, float u, float v, int tri, int node, diff_geom& dg) {
     const uint4 ta = S.tri_data[tri * 2], tb = S.tri_data[tri * 2 + 1];   // {nme.x, nme.y, dpd.x, dpd.y} {dpd.z, uv0, uv1, uv2}
     dg.images = S.images; dg.rough_transmittance = S.rough_transmittance; dg.mats = S.mats;
@@ -61,54 +67,15 @@ __device__ __forceinline__ void fill_dg(const dev_scene& S, float u, float v, in
     dg.sys.s = normalize(s); dg.sys.t = normalize(t); dg.sys.n = normalize(cross(t, s));
     const f3 wdpdu = xform_dir(l2w, dpdu), wdpdv = xform_dir(l2w, dpdv);
     dg.n = normalize(cross(wdpdu, wdpdv));
+#if CTL_SHADE_FEATURES & 32
+    dg.dpdu = wdpdu; dg.dpdv = wdpdv;
+#endif
     const f2 uva{ half_to_float((uint16_t)tb.y), half_to_float((uint16_t)(tb.y >> 16)) }, uvb{ half_to_float((uint16_t)tb.z), half_to_float((uint16_t)(tb.z >> 16)) },
         uvc{ half_to_float((uint16_t)tb.w), half_to_float((uint16_t)(tb.w >> 16)) };
     dg.uv = f2{ u * uva.x + v * uvb.x + w * uvc.x, u * uva.y + v * uvb.y + w * uvc.y };
     if (dot(dg.n, dg.sys.n) < 0.0f) dg.n = -dg.n;
 }
 __device__ __forceinline__ uint32_t tri_mat_index(const dev_scene& S, int tri) { return (S.tri_data[tri * 2].y >> 16) & 0xff; }   // TriangleData.h:40-44
-
-// ---- KernelMIPMap level 0 (Engine/MIPMap.cu:21-57,116-121,155-172; MIPMap_device.h:34-55)
-__device__ __forceinline__ f3 texel_decode(uint32_t v, uint32_t type) {
-    const uint32_t x = v & 0xff, y = (v >> 8) & 0xff, z = (v >> 16) & 0xff, w = v >> 24;
-    if (type == CTL_TEXEL_RGBE) {   // SpectrumConverter::RGBEToFloat3 (Math/Spectrum.h:557-565)
-        if (!w) return f3(0.0f);
-        const float e = ldexpf(1.0f, (int)w - (128 + 8));
-        return f3(x * e, y * e, z * e);
-    }
-    return f3(float(x) / 255.0f, float(y) / 255.0f, float(z) / 255.0f);   // COLORREFToFloat3 (:528-532)
-}
-__device__ __forceinline__ float fracf_(float f) { return f - floorf(f); }
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ bool wrap_coordinates(f2 uv, f2 dim, uint32_t w, f2& loc) {
-    switch (w) {
-    case CTL_WRAP_REPEAT: loc = f2{ fracf_(uv.x) * dim.x, fracf_(1.0f - uv.y) * dim.y }; return true;
-    case CTL_WRAP_CLAMP: loc = f2{ clampf(uv.x, 0.0f, 1.0f) * dim.x, clampf(1.0f - uv.y, 0.0f, 1.0f) * dim.y }; return true;
-    case CTL_WRAP_MIRROR: {   // the reference tests the parity of uv.x for both axes
-        const float lx = (int)uv.x % 2 == 0 ? fracf_(uv.x) : 1.0f - fracf_(uv.x), ly = (int)uv.x % 2 == 0 ? fracf_(uv.y) : 1.0f - fracf_(uv.y);
-        loc = f2{ lx * dim.x, ly * dim.y }; return true; }
-    case CTL_WRAP_BLACK:
-        if (uv.x < 0 || uv.x >= 1 || uv.y < 0 || uv.y >= 1) return false;
-        loc = f2{ uv.x * dim.x, uv.y * dim.y }; return true;
-    }
-    return false;
-}
-__device__ __forceinline__ f3 mip_texel(const ctl_mipmap& M, f2 uv) {
-    f2 l;
-    if (!wrap_coordinates(uv, f2{ (float)M.width, (float)M.height }, M.wrap_mode, l)) return f3(0.0f);
-    const int x = clampi((int)l.x, 0, (int)M.width - 1), y = clampi((int)l.y, 0, (int)M.height - 1);
-    return texel_decode(M.texels[(size_t)y * M.width + x], M.texel_type);
-}
-__device__ __forceinline__ f3 mip_triangle(const ctl_mipmap& M, f2 uv) {
-    const f2 sz{ (float)M.width, (float)M.height }, is{ 1.0f / sz.x, 1.0f / sz.y };
-    const float ds = fracf_(uv.x * sz.x), dt = fracf_(uv.y * sz.y);
-    return ((1.f - ds) * (1.f - dt)) * mip_texel(M, uv) + ((1.f - ds) * dt) * mip_texel(M, f2{ uv.x + 0, uv.y + is.y }) +
-           (ds * (1.f - dt)) * mip_texel(M, f2{ uv.x + is.x, uv.y + 0 }) + (ds * dt) * mip_texel(M, f2{ uv.x + is.x, uv.y + is.y });
-}
-__device__ __forceinline__ f3 mip_fetch(const ctl_mipmap& M, int x, int y) {
-    x = clampi(x, 0, (int)M.width - 1); y = clampi(y, 0, (int)M.height - 1);
-    return texel_decode(M.texels[(size_t)y * M.width + x], M.texel_type);
-}
 
 // ImageTexture::Evaluate(uv) (Texture.cu:6-13); out of line: tex_eval is inlined at every BSDF parameter fetch and the bitmap
 // path must not cost the constant-texture path registers
@@ -132,6 +99,28 @@ __device__ __forceinline__ f3 tex_eval(const ctl_texture& t, const diff_geom& dg
 #endif
     return f3(t.value[0], t.value[1], t.value[2]);
 }
+#if CTL_SHADE_FEATURES & 32
+// Material::SampleNormalMap (Engine/Material.cu:96-138; parallax occlusion is never enabled by the reference)
+__device__ __forceinline__ void sample_normal_map(const ctl_material& mat, diff_geom& dg) {
+    if (mat.map_kind == CTL_MAP_NORMAL) {
+        const f3 c = tex_eval(mat.map_tex, dg);
+        const f3 nWorld = normalize(dg.sys.to_world(c - f3(0.5f)));
+        dg.sys.n = nWorld;
+        dg.sys.t = normalize(cross(nWorld, dg.sys.s));
+        dg.sys.s = normalize(cross(nWorld, dg.sys.t));
+    } else if (mat.map_kind == CTL_MAP_HEIGHT && mat.map_tex.type == CTL_TEX_IMAGE && mat.map_tex.image != 0xffffffffu) {
+        f3 g0, g1;
+        mip_eval_gradient(dg.images[mat.map_tex.image], tex_map_point(mat.map_tex, dg.uv), g0, g1);
+        const float dDispDu = luminance(g0), dDispDv = luminance(g1);
+        const f3 dpdu = dg.dpdu + dg.sys.n * (dDispDu - dot(dg.sys.n, dg.dpdu));
+        const f3 dpdv = dg.dpdv + dg.sys.n * (dDispDv - dot(dg.sys.n, dg.dpdv));
+        dg.sys.n = normalize(cross(dpdu, dpdv));
+        dg.sys.s = normalize(dpdu - dg.sys.n * dot(dg.sys.n, dpdu));
+        dg.sys.t = normalize(cross(dg.sys.n, dg.sys.s));
+        if (dot(dg.sys.n, dg.n) < 0) dg.sys.n = -dg.sys.n;
+    }
+}
+#endif
 __device__ __forceinline__ float avg3(f3 s) { float r = s.x; r += s.y; r += s.z; return r * (1.0f / 3); }   // Spectrum.h:180-190
 
 // ---- microfacet distribution (Engine/MicrofacetDistribution.{h,cu}); Beckmann + GGX
@@ -411,7 +400,6 @@ __device__ __forceinline__ f3 spot_falloff(const ctl_light& L, f3 d) {
     if (cosTheta >= L.cos_beam_width) return f3(1.0f);
     return f3((L.cutoff_angle - acosf(cosTheta)) * L.inv_transition_width);
 }
-__device__ __forceinline__ float luminance(f3 s) { return s.x * 0.212671f + s.y * 0.715160f + s.z * 0.072169f; }   // Spectrum.cu:174-177
 __device__ __forceinline__ float interval_to_tent(float sample) {   // Math/Warp.h:13-27
     float sign;
     if (sample < 0.5f) { sign = 1; sample *= 2; } else { sign = -1; sample = 2 * (sample - 0.5f); }

@@ -71,6 +71,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
     }
     inst_.upload(inst.data(), inst.size()); inst_fwd_.upload(fwd.data(), fwd.size()); node_info_.upload(ninfo.data(), ninfo.size());
     static_assert(sizeof(ctl_triangle_data) == 32, "TriangleData is 32 B");
+    static_assert(sizeof(ctl_material) == 384 && sizeof(ctl_texture) == 48, "material descriptor layout (include/ctl_amd.h)");
     tri_data_.upload((const uint4*)d.tri_data, (size_t)d.n_tri_data * 2);
     mats_.upload(d.materials, d.n_materials);
     if (d.n_lights_buf) lights_.upload(d.lights, d.n_lights_buf); else lights_.alloc(1);
@@ -112,7 +113,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
         }
     }
     // which shade-kernel build this scene needs (kernels.hip launch_shade)
-    S.shade_features = 0;
+    S.shade_features = 0; S.alpha_maps = 0;
     for (uint32_t i = 0; i < d.n_lights_buf; i++) if (d.lights[i].type != CTL_LIGHT_POINT && d.lights[i].type != CTL_LIGHT_DIFFUSE) S.shade_features |= kShadeMoreLights;
     for (uint32_t i = 0; i < d.n_materials; i++) {
         const uint32_t t = d.materials[i].bsdf_type;
@@ -120,6 +121,8 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
         if (t == CTL_BSDF_ROUGHDIFFUSE || t == CTL_BSDF_WARD || t == CTL_BSDF_ROUGHPLASTIC) S.shade_features |= kShadeRoughBsdfs;
         if (t == CTL_BSDF_COATING || t == CTL_BSDF_ROUGHCOATING || t == CTL_BSDF_BLEND) S.shade_features |= kShadeNestingBsdfs | kShadeMoreBsdfs | kShadeRoughBsdfs;
         for (int k = 0; k < 4; k++) if (d.materials[i].tex[k].type == CTL_TEX_IMAGE) S.shade_features |= kShadeImageTextures;
+        if (d.materials[i].map_kind != CTL_MAP_NONE) S.shade_features |= kShadeSurfaceMaps | kShadeImageTextures;
+        if (d.materials[i].alpha_state != CTL_ALPHA_DISABLED) S.alpha_maps = 1;
     }
     for (uint32_t i = 0; i < d.n_lights_buf; i++) {
         const ctl_light& L = d.lights[i];
@@ -128,8 +131,13 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
         if (L.type == CTL_LIGHT_INFINITE && L.env_image >= d.n_images) throw std::runtime_error("ctl_scene_create: InfiniteLight references a missing image");
     }
     for (uint32_t i = 0; i < d.n_materials; i++) {
-        for (int k = 0; k < 4; k++) {
-            const ctl_texture& t = d.materials[i].tex[k];
+        const ctl_material& mi = d.materials[i];
+        if (mi.map_kind > CTL_MAP_HEIGHT) throw std::runtime_error("ctl_scene_create: unknown surface map kind");
+        if (mi.alpha_state > CTL_ALPHA_REFLECTANCE_COLOR || mi.alpha_state == 4) throw std::runtime_error("ctl_scene_create: unknown alpha blend state");
+        for (int k = 0; k < 6; k++) {
+            if (k == 4 && mi.map_kind == CTL_MAP_NONE) continue;
+            if (k == 5 && mi.alpha_state == CTL_ALPHA_DISABLED) continue;
+            const ctl_texture& t = k < 4 ? mi.tex[k] : (k == 4 ? mi.map_tex : mi.alpha_tex);
             if (t.type == CTL_TEX_IMAGE && t.image != 0xffffffffu && t.image >= d.n_images) throw std::runtime_error("ctl_scene_create: texture references a missing image");
             if (t.type != CTL_TEX_CONSTANT && t.type != CTL_TEX_CHECKER && t.type != CTL_TEX_IMAGE && t.type != 0) throw std::runtime_error("ctl_scene_create: texture type " + std::to_string(t.type) + " has no HIP implementation yet");
         }
@@ -329,6 +337,9 @@ WavefrontPathTracer::WavefrontPathTracer() {
     m_sParameters.addInterval("RRStartDepth", 5, 1, INT_MAX);
     // build-specific: passes rendered together in one wavefront; 0 = choose so that a launch carries >= ~4 M paths
     m_sParameters.addInterval("PassBatch", 0, 0, 64);
+    // build-specific: run Material::AlphaTest on candidate hits.  Off = the reference's wavefront tracer (its intersectKernel has no
+    // alpha test, only the single-ray traceRay of the megakernel integrators does, TraceHelper.cu:135-153)
+    m_sParameters.addBool("AlphaTest", false);
     int dev = 0; hipDeviceProp_t prop; CTL_HIP(hipGetDevice(&dev)); CTL_HIP(hipGetDeviceProperties(&prop, dev));
     grid_blocks = prop.multiProcessorCount * 8;   // 8 x 256-thread workgroups per CU = 32 waves/CU
 }
@@ -382,8 +393,9 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     const size_t n_counts = (size_t)(maxPathLength + 2) * 4, n_work = (size_t)2 * (maxPathLength + 2);
     if (counts_.n < n_counts) { counts_.alloc(n_counts); work_.alloc(n_work); }
     Q.counts = counts_.p; Q.work = work_.p;
-    const launch_ctx lc{ stream, grid_blocks };
     const dev_scene& S = m_pScene->S;
+    const launch_ctx lc{ stream, grid_blocks, m_sParameters.getValue("AlphaTest") != 0 && S.alpha_maps != 0 };
+    if (lc.alpha_test && S.flat_nodes && S.flat_width == 8) throw std::runtime_error("AlphaTest is not available with the 8-wide flattened BVH");
     pass_params P{};
     P.t1 = d_t1p; P.t2 = (const float2*)d_t2p;
     P.batch = n_batch;

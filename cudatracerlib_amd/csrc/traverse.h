@@ -14,6 +14,7 @@
 //    kLdsStack spill to scratch.
 #pragma once
 #include "device_scene.h"
+#include "mipmap.h"
 
 namespace ctl {
 
@@ -59,7 +60,8 @@ template <int N> struct lane_stack_t {
 typedef lane_stack_t<kLdsStack> lane_stack;
 
 // The whole intersect kernel body: `n` rays (ro, rd) -> hit / hit_node (closest) and/or occ (any-hit flag).
-template <bool ANY_HIT, bool COUNT>
+// ALPHA: candidate hits pass Material::AlphaTest first (the reference does this in its single-ray traceRay only, TraceHelper.cu:135-153)
+template <bool ANY_HIT, bool COUNT, bool ALPHA = false>
 __device__ __forceinline__ void intersect_persistent(const dev_scene& S, const float4* __restrict__ ro, const float4* __restrict__ rd, uint32_t n, uint32_t* __restrict__ work,
                                                      float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack, trav_counts& cnt) {
     const int lane = threadIdx.x & 63;
@@ -165,7 +167,7 @@ __device__ __forceinline__ void intersect_persistent(const dev_scene& S, const f
                                 const float Oy = v22.w + ox * v22.x + oy * v22.y + oz * v22.z;
                                 const float Dy = dx * v22.x + dy * v22.y + dz * v22.z;
                                 const float v = Oy + t * Dy;
-                                if (v >= 0.0f && u + v <= 1.0f) {
+                                if (v >= 0.0f && u + v <= 1.0f && (!ALPHA || alpha_survives(S.tri_data, S.node_info, S.mats, S.images, (int)((index >> 1) + tri_base), cur_inst, u, v))) {
                                     ht = t; hu = u; hv = v; htri = (int)((index >> 1) + tri_base); hnode = cur_inst;
                                     if (ANY_HIT) { finished = true; break; }
                                 }
@@ -200,7 +202,7 @@ __device__ __forceinline__ void intersect_persistent(const dev_scene& S, const f
 // Single-level variant over the flattened world-space BVH (flatten.cpp).  One loop iteration = one 64-B fetch group per
 // lane — an inner node OR one leaf entry — so every lane that holds a ray does useful work in every iteration; only the
 // math after the (shared) fetch diverges between the two kinds.
-template <bool ANY_HIT, bool COUNT>
+template <bool ANY_HIT, bool COUNT, bool ALPHA = false>
 __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4* __restrict__ ro, const float4* __restrict__ rd, uint32_t n, uint32_t* __restrict__ work,
                                                float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack, trav_counts& cnt) {
     const int lane = threadIdx.x & 63;
@@ -313,7 +315,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
                         const float Oy = q2.w + ox * q2.x + oy * q2.y + oz * q2.z;
                         const float Dy = dx * q2.x + dy * q2.y + dz * q2.z;
                         const float v = Oy + t * Dy;
-                        if (v >= 0.0f && u + v <= 1.0f) {
+                        if (v >= 0.0f && u + v <= 1.0f && (!ALPHA || alpha_survives(S.tri_data, S.node_info, S.mats, S.images, (int)(index >> 1), (int)__float_as_uint(q3.y), u, v))) {
                             ht = t; hu = u; hv = v; htri = (int)(index >> 1); hnode = (int)__float_as_uint(q3.y);
                             if (ANY_HIT) finished = true;
                         }

@@ -270,6 +270,64 @@ def env_scene(width=96, height=64, rotate_env=False, point_filter=False, extra_l
     return sc
 
 
+def bump_image(n=64, seed=3):
+    """Smooth procedural height field, (n, n, 3) floats in [0, 1] (also the source of the tangent-space normal map below)."""
+    y, x = np.mgrid[0:n, 0:n].astype(np.float32) / n
+    h = 0.5 + 0.25 * np.sin(6.2831853 * 3 * x) * np.cos(6.2831853 * 2 * y) + 0.2 * np.sin(6.2831853 * (x + 2 * y))
+    return np.repeat(np.clip(h, 0, 1)[..., None], 3, axis=2).astype(np.float32)
+
+
+def normal_image(n=64, strength=0.08):
+    """Tangent-space normal map (rgb = n * 0.5 + 0.5) of ``bump_image``."""
+    h = bump_image(n)[..., 0]
+    gx = (np.roll(h, -1, axis=1) - np.roll(h, 1, axis=1)) * 0.5 * n * strength
+    gy = (np.roll(h, -1, axis=0) - np.roll(h, 1, axis=0)) * 0.5 * n * strength
+    nrm = np.stack([-gx, -gy, np.ones_like(h)], axis=2)
+    nrm /= np.linalg.norm(nrm, axis=2, keepdims=True)
+    return (nrm * 0.5 + 0.5).astype(np.float32)
+
+
+def maps_scene(width=96, height=64, surface_map="normal", alpha="luminance"):
+    """Material maps in miniature: a ground quad with a normal map (``surface_map`` = "normal"), a height map ("height") or neither
+    (None) under a glossy BSDF, and an upright card whose material carries an alpha map (``alpha`` = "luminance": checkerboard
+    texture tested by luminance; "alpha": the alpha channel of an RGBA bitmap; "color": colour key; None: no alpha map) in front
+    of a red wall, lit by an area light and a point light."""
+    sc = api.DynamicScene()
+    P, I, N = _quad([[-6, 0, -6], [-6, 0, 6], [6, 0, 6], [6, 0, -6]], [0, 1, 0])
+    uv = np.array([[0, 0], [0, 2], [2, 2], [2, 0]], np.float32)
+    ground_mat = api.roughconductor(alpha=0.25, distribution=1, sample_visible=True)
+    if surface_map == "normal":
+        img = sc.add_image(api.float3_to_rgbcol(normal_image()), api.TEXEL_RGBCOL, api.WRAP_REPEAT, api.FILTER_BILINEAR)
+        api.set_normal_map(ground_mat, api.image_texture(img))
+    elif surface_map == "height":
+        img = sc.add_image(api.float3_to_rgbcol(bump_image()), api.TEXEL_RGBCOL, api.WRAP_REPEAT, api.FILTER_BILINEAR)
+        api.set_height_map(ground_mat, api.image_texture(img, scale=(0.3, 0.3, 0.3)))
+    sc.CreateNode(sc.add_mesh(P, I, normals=N, uvs=uv, materials=[ground_mat]))
+    # back wall (red) and the card in front of it
+    P, I, N = _quad([[-6, 0, -4], [6, 0, -4], [6, 6, -4], [-6, 6, -4]], [0, 0, 1])
+    sc.CreateNode(sc.add_mesh(P, I, normals=N, materials=[api.diffuse((0.7, 0.1, 0.1))]))
+    card_mat = api.diffuse((0.2, 0.6, 0.8), two_sided=True)
+    if alpha == "luminance":
+        api.set_alpha_map(card_mat, api.checker_texture(1.0, 0.0, uv_scale=(4.0, 3.0)), api.ALPHA_MAP_LUMINANCE, 0.5)
+    elif alpha == "alpha":
+        yy, xx = np.mgrid[0:32, 0:32]
+        rgba = np.zeros((32, 32), np.uint32) | 0x00808080
+        rgba |= np.where(((xx - 16) ** 2 + (yy - 16) ** 2) < 144, np.uint32(0xff000000), np.uint32(0x20000000))
+        aimg = sc.add_image(rgba.astype(np.uint32), api.TEXEL_RGBCOL, api.WRAP_REPEAT, api.FILTER_POINT)
+        api.set_alpha_map(card_mat, api.image_texture(aimg, uv_scale=(2.0, 2.0)), api.ALPHA_MAP_ALPHA, 0.5)
+    elif alpha == "color":
+        api.set_alpha_map(card_mat, api.checker_texture((0.9, 0.1, 0.1), (0.1, 0.1, 0.9), uv_scale=(3.0, 3.0)), api.ALPHA_MAP_COLOR, 0.25, (1.0, 0.0, 0.0))
+    P, I, N = _quad([[-3, 0.2, -1], [3, 0.2, -1], [3, 4.2, -1], [-3, 4.2, -1]], [0, 0, 1])
+    sc.CreateNode(sc.add_mesh(P, I, normals=N, uvs=np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32), materials=[card_mat]))
+    P, I, N = _quad([[-2, 7.5, 0], [2, 7.5, 0], [2, 7.5, 3], [-2, 7.5, 3]], [0, -1, 0])
+    lm = sc.add_mesh(P, I, normals=N, materials=[api.diffuse((0.5, 0.5, 0.5))])
+    sc.CreateLight(sc.CreateNode(lm), 0, (25.0, 24.0, 22.0))
+    sc.CreatePointLight((0, 3, 6), (30, 30, 30))
+    sc.setCamera((0, 3.5, 11), (0, 2, 0), (0, 1, 0), 45.0, width, height)
+    sc.UpdateScene()
+    return sc
+
+
 def write_cornell_mitsuba(directory, width=256, height=256, glass_sphere=False):
     """C1 / C2 as a Mitsuba-0.5 scene (SURVEY §8d "Cornell box authored in-repo as Mitsuba XML"): <directory>/cornell.xml plus
     one OBJ per surface group under meshes/.  Geometry and materials are those of ``cornell_box``; returns the XML path."""

@@ -153,7 +153,24 @@ typedef struct {
     ctl_texture tex[4];
     float f[8];
     uint32_t u[4];
-} ctl_material;                /* 256 B */
+    /* Material::NormalMap / HeightMap (Engine/Material.h:58-59,93-106: at most one of them) and Material::AlphaMap
+     * (Material.h:13-36,60,107-111).  The normal / height map perturbs the shading frame in TraceResult::getBsdfSample
+     * (Material::SampleNormalMap, Material.cu:96-138; parallax occlusion is never enabled by the reference and is not carried).
+     * The alpha test runs inside single-ray traversal (TraceHelper.cu:135-153) — i.e. for the megakernel PathTracer; the
+     * reference's wavefront intersectKernel has no alpha test, see the AlphaTest tracer parameter. */
+    uint32_t map_kind;         /* CTL_MAP_NONE / CTL_MAP_NORMAL / CTL_MAP_HEIGHT                 */
+    uint32_t alpha_state;      /* AlphaBlendState, CTL_ALPHA_*                                   */
+    float alpha_test_scalar;   /* AlphaBlendData::test_val_scalar                                */
+    float alpha_test_color[3]; /* AlphaBlendData::test_val_color                                 */
+    uint32_t reserved_[2];
+    ctl_texture map_tex;       /* the normal or height map                                      */
+    ctl_texture alpha_tex;     /* AlphaBlendData::tex                                            */
+} ctl_material;                /* 384 B */
+enum { CTL_MAP_NONE = 0, CTL_MAP_NORMAL = 1, CTL_MAP_HEIGHT = 2 };
+/* Material.h:13-22: low two bits = test (1 luminance >= scalar, 2 alpha channel >= scalar, 3 |colour - test colour| <= scalar),
+ * bit 2 = take the BSDF's first texture instead of alpha_tex */
+enum { CTL_ALPHA_DISABLED = 0, CTL_ALPHA_MAP_LUMINANCE = 1, CTL_ALPHA_MAP_ALPHA = 2, CTL_ALPHA_MAP_COLOR = 3,
+       CTL_ALPHA_REFLECTANCE_LUMINANCE = 5, CTL_ALPHA_REFLECTANCE_ALPHA = 6, CTL_ALPHA_REFLECTANCE_COLOR = 7 };
 
 /* ids = TYPE_FUNC ids of SceneTypes/Light.h:36,98,147,228,296 */
 enum { CTL_LIGHT_POINT = 1, CTL_LIGHT_DIFFUSE = 2, CTL_LIGHT_DISTANT = 3, CTL_LIGHT_SPOT = 4, CTL_LIGHT_INFINITE = 5 };

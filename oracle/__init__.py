@@ -63,6 +63,8 @@ def load():
     o.orc_light_pdf_direct.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p]
     o.orc_env_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     o.orc_texture_eval.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
+    o.orc_sample_normal_map.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p, C.c_void_p]
+    o.orc_alpha_test.argtypes = [C.c_void_p, C.c_void_p, f32, f32]
     o.orc_triangle_data_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_int, C.c_void_p]
     o.orc_triangle_fill_dg.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_int, C.c_void_p]
     o.orc_woop_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
@@ -101,17 +103,19 @@ class Oracle:
     def __init__(self):
         self.lib = load()
 
-    def intersect(self, desc, rays, any_hit=False, count=False, threads=8):
+    def intersect(self, desc, rays, any_hit=False, count=False, threads=8, alpha_test=False):
         r = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         hits = np.zeros(len(r), dtype=[("dist", "f4"), ("node_idx", "i4"), ("tri_idx", "i4"), ("u", "f4"), ("v", "f4")])
         cnt = (u64 * 5)()
-        self.lib.orc_intersect(C.addressof(desc), r.ctypes.data, len(r), hits.ctypes.data, 1 if any_hit else 0, C.addressof(cnt) if count else None, threads)
+        self.lib.orc_intersect(C.addressof(desc), r.ctypes.data, len(r), hits.ctypes.data, (1 if any_hit else 0) | (2 if alpha_test else 0), C.addressof(cnt) if count else None, threads)
         if count:
             return hits, dict(n_inner=cnt[0], n_tri=cnt[1], n_inst=cnt[2])
         return hits
 
-    def render(self, desc, width, height, n_passes=1, tables=None, direct=True, max_path_length=8, rr_start=5, threads=8, rows=None, half_host_quirk=False):
+    def render(self, desc, width, height, n_passes=1, tables=None, direct=True, max_path_length=8, rr_start=5, threads=8, rows=None, half_host_quirk=False, alpha_test=False):
         """pathKernel2<DIRECT,false> over all pixels (Integrators/PathTracer.cu:182-194). tables = list of (t1, t2) per pass or None.
+        alpha_test: traceRay<USE_ALPHA> when the scene has alpha maps (what the reference's single-ray path does; its wavefront
+        intersectKernel has no alpha test).
         Returns (pixel_data (h, w, 7), rays)."""
         img = np.zeros((height, width, 7), np.float32)
         y0, y1 = (0, height) if rows is None else rows
@@ -123,7 +127,7 @@ class Oracle:
         else:
             p1 = p2 = None
         rays = self.lib.orc_render(C.addressof(desc), width, height, n_passes, p1, p2, 1 if direct else 0, max_path_length, rr_start,
-                                   img.ctypes.data, threads, y0, y1, 1 if half_host_quirk else 0)
+                                   img.ctypes.data, threads, y0, y1, (1 if half_host_quirk else 0) | (2 if alpha_test else 0))
         return img, int(rays)
 
     def sequence_tables(self, n_passes):

@@ -121,7 +121,13 @@ inline bool tracerayTemplate(V3 ori, V3 dir, float& rayT, float node_tmin, const
 struct Scene {
     ctl_scene_desc d;
     bool half_host_quirk = false;   // reproduce half::ToFloat's host branch (Math/half.h:76-83)
+    bool alpha_test = false;        // KernelDynamicScene::doAlphaMapping (DynamicScene.cpp:586): traceRay<USE_ALPHA = true>
 };
+inline bool sceneHasAlphaMaps(const ctl_scene_desc& d) {   // MaterialBuffer::hasAlphaMappings
+    for (uint32_t i = 0; i < d.n_materials; i++) if (d.materials[i].alpha_state != CTL_ALPHA_DISABLED) return true;
+    return false;
+}
+inline bool alphaSurvive(const Scene& S, uint32_t tri, uint32_t nodeIdx, float u, float v);   // TraceHelper.cu:135-153, defined with the textures
 
 // Kernel/TraceHelper.cu:88-180 (__traceRay_internal__<false> + traceRay).  any_hit/tmax generalise it to the
 // wavefront kernel's interface (TraceHelper.cu:326-734): a ctl_ray carries tmin in a.w and tmax in b.w.
@@ -145,7 +151,7 @@ inline bool traceRay(const Scene& S, V3 ori, V3 dir, float tmin_tri, float tmax,
                 uint32_t index = g.woop_index[mesh.bvh_index_offset + triAddr].index;
                 if (cnt) cnt->n_tri++;
                 float t, u, v;
-                if (woopIntersect(w, o, d, tmin_tri, res.dist, t, u, v)) {
+                if (woopIntersect(w, o, d, tmin_tri, res.dist, t, u, v) && (!S.alpha_test || alphaSurvive(S, (index >> 1) + mesh.tri_offset, nodeIdx, u, v))) {
                     res.node = nodeIdx; res.tri = (index >> 1) + mesh.tri_offset; res.u = u; res.v = v; res.dist = t;
                     found = true;
                     if (any_hit) { stop = true; break; }
@@ -300,6 +306,88 @@ inline Spec texEval(const ctl_texture& t, const DG& dg) {
     return Spec(t.value[0], t.value[1], t.value[2]);
 }
 
+inline float luminance(Spec s) { return s.x * 0.212671f + s.y * 0.715160f + s.z * 0.072169f; }   // Spectrum.cu:174-177
+// KernelMIPMap::SampleAlpha (MIPMap.cu:123-138); the reference indexes the texel without clamping, the restatement clamps
+inline float mipSampleAlpha(const ctl_mipmap& M, V2 uv) {
+    V2 l;
+    if (!wrapCoordinates(uv, V2{ (float)M.width, (float)M.height }, M.wrap_mode, l)) return 0.0f;
+    if (M.texel_type == CTL_TEXEL_RGBE) return 1.0f;
+    int x = clampi((int)l.x, 0, (int)M.width - 1), y = clampi((int)l.y, 0, (int)M.height - 1);
+    return float(M.texels[(size_t)y * M.width + x] >> 24) / 255.0f;
+}
+// KernelMIPMap::evalGradient (MIPMap.cu:174-191)
+inline void mipEvalGradient(const ctl_mipmap& M, V2 uv, Spec grad[2]) {
+    const V2 dim{ (float)M.width, (float)M.height };
+    float u = uv.x * dim.x - 0.5f, v = uv.y * dim.y - 0.5f;
+    int xPos = (int)u, yPos = (int)v;   // math::Float2Int
+    float dx = u - xPos, dy = v - yPos;
+    const Spec p00 = mipTexel(M, V2{ (float)xPos / dim.x, (float)yPos / dim.y });
+    const Spec p10 = mipTexel(M, V2{ ((float)xPos + 1) / dim.x, (float)yPos / dim.y });
+    const Spec p01 = mipTexel(M, V2{ (float)xPos / dim.x, ((float)yPos + 1) / dim.y });
+    const Spec p11 = mipTexel(M, V2{ ((float)xPos + 1) / dim.x, ((float)yPos + 1) / dim.y });
+    Spec tmp = p01 + p10 - p11;
+    grad[0] = (p10 + p00 * (dy - 1) - tmp * dy) * dim.x;
+    grad[1] = (p01 + p00 * (dx - 1) - tmp * dx) * dim.y;
+}
+inline V2 texMapPoint(const ctl_texture& t, V2 uv) { return V2{ t.uv_scale[0] * uv.x + 0 * uv.y + t.uv_offset[0], 0 * uv.x + t.uv_scale[1] * uv.y + t.uv_offset[1] }; }   // TextureMapping2D::TransformPoint
+
+// Material::SampleNormalMap (Engine/Material.cu:96-138; enableParallaxOcclusion is never set by the reference)
+inline bool sampleNormalMap(const ctl_material& mat, DG& dg) {
+    if (mat.map_kind == CTL_MAP_NORMAL) {
+        Spec c = texEval(mat.map_tex, dg);
+        V3 n = c;   // toLinearRGB of an RGB spectrum
+        V3 nWorld = normalize(dg.sys.toWorld(n - V3(0.5f)));
+        dg.sys.n = nWorld;
+        dg.sys.t = normalize(cross(nWorld, dg.sys.s));
+        dg.sys.s = normalize(cross(nWorld, dg.sys.t));
+        return true;
+    }
+    if (mat.map_kind == CTL_MAP_HEIGHT && mat.map_tex.type == CTL_TEX_IMAGE && mat.map_tex.image != 0xffffffffu && dg.images) {
+        V2 uv = texMapPoint(mat.map_tex, dg.uv);
+        Spec grad[2];
+        mipEvalGradient(dg.images[mat.map_tex.image], uv, grad);
+        float dDispDu = luminance(grad[0]), dDispDv = luminance(grad[1]);
+        V3 dpdu = dg.dpdu + dg.sys.n * (dDispDu - dot(dg.sys.n, dg.dpdu));
+        V3 dpdv = dg.dpdv + dg.sys.n * (dDispDv - dot(dg.sys.n, dg.dpdv));
+        dg.sys.n = normalize(cross(dpdu, dpdv));
+        dg.sys.s = normalize(dpdu - dg.sys.n * dot(dg.sys.n, dpdu));
+        dg.sys.t = normalize(cross(dg.sys.n, dg.sys.s));
+        if (dot(dg.sys.n, dg.n) < 0) dg.sys.n = -dg.sys.n;
+        return true;
+    }
+    return false;
+}
+
+// Material::AlphaTest (Engine/Material.cu:160-190); sample_fast (:141-158) = texEval at the interpolated uv
+inline bool materialAlphaTest(const ctl_material& mat, V2 uv, const ctl_mipmap* images) {
+    const uint32_t st = mat.alpha_state;
+    if (st == CTL_ALPHA_DISABLED) return true;
+    const ctl_texture& refl = mat.tex[0];   // bsdf.getTexture(0)
+    const bool refl_img = refl.type == CTL_TEX_IMAGE, alpha_img = mat.alpha_tex.type == CTL_TEX_IMAGE;
+    if ((st == CTL_ALPHA_MAP_ALPHA && alpha_img) || (st == CTL_ALPHA_REFLECTANCE_ALPHA && refl_img)) {
+        const ctl_texture& t = st == CTL_ALPHA_MAP_ALPHA ? mat.alpha_tex : refl;
+        float alpha = mipSampleAlpha(images[t.image], texMapPoint(t, uv));
+        return alpha >= mat.alpha_test_scalar;
+    }
+    DG dg; dg.uv = uv; dg.images = images;
+    Spec val = texEval((st & 4) ? refl : mat.alpha_tex, dg);
+    if ((st & 3) == 1) return luminance(val) >= mat.alpha_test_scalar;
+    if ((st & 3) == 3) {
+        Spec d = val - Spec(mat.alpha_test_color[0], mat.alpha_test_color[1], mat.alpha_test_color[2]);
+        return fmax2(fmax2(fabsf(d.x), fabsf(d.y)), fabsf(d.z)) <= mat.alpha_test_scalar;
+    }
+    return true;
+}
+inline bool alphaSurvive(const Scene& S, uint32_t tri, uint32_t nodeIdx, float u, float v) {
+    const ctl_triangle_data& T = S.d.tri_data[tri];
+    const ctl_material& mat = S.d.materials[triMatIndex(T, S.d.nodes[nodeIdx].material_offset)];
+    if (mat.alpha_state == CTL_ALPHA_DISABLED) return true;
+    auto h = [&](uint32_t bits) { return halfToFloat((uint16_t)bits, S.half_host_quirk); };
+    V2 a{ h(T.uv[0]), h(T.uv[0] >> 16) }, b{ h(T.uv[1]), h(T.uv[1] >> 16) }, c{ h(T.uv[2]), h(T.uv[2] >> 16) };   // getUVSetData(0, a, b, c)
+    V2 uv{ u * a.x + v * b.x + (1 - u - v) * c.x, u * a.y + v * b.y + (1 - u - v) * c.y };
+    return materialAlphaTest(mat, uv, S.d.images);
+}
+
 // --------------------------------------------------------------------------- sampler (Kernel/Sampler_device.h:59-113)
 struct Sampler {
     const float* t1; const float* t2; unsigned idx; unsigned d1 = 0, d2 = 0;
@@ -385,7 +473,6 @@ inline Spec spotFalloff(const ctl_light& L, V3 d) {
     if (cosTheta >= L.cos_beam_width) return Spec(1.0f);
     return Spec((L.cutoff_angle - acosf(cosTheta)) * L.inv_transition_width);
 }
-inline float luminance(Spec s) { return s.x * 0.212671f + s.y * 0.715160f + s.z * 0.072169f; }   // Spectrum.cu:174-177
 inline float intervalToTent(float sample) {   // Math/Warp.h:13-27
     float sign;
     if (sample < 0.5f) { sign = 1; sample *= 2; } else { sign = -1; sample = 2 * (sample - 0.5f); }
@@ -794,12 +881,13 @@ inline uint32_t hitLightIndex(const Scene& S, const Hit& h) {        // TraceRes
     if (nli == UINT32_MAX) return UINT32_MAX;
     return S.d.nodes[h.node].lights[nli];
 }
-// TraceResult.cu:11-43 (no normal map in the descriptor set of this round)
+// TraceResult.cu:11-43.  wi is taken in the frame BEFORE the normal / height map perturbs it, as the reference does (:30-34)
 inline void getBsdfSample(const Scene& S, const Hit& h, V3 rayO, V3 rayD, BRec& bRec) {
     bRec.eta = 1.0f; bRec.sampledType = 0; bRec.typeMask = EAll;
     bRec.dg.P = rayO + rayD * h.dist;   // Ray::operator()(t) (Math/Ray.h)
     fillDG(S, V2{ h.u, h.v }, h.tri, h.node, bRec.dg);
     bRec.wi = bRec.dg.sys.toLocal(-rayD);
+    sampleNormalMap(hitMat(S, h), bRec.dg);
     if (hitMat(S, h).two_sided && bRec.wi.z < 0) {
         bRec.dg.n = -bRec.dg.n; bRec.dg.sys.n = -bRec.dg.sys.n; bRec.wi.z *= -1.0f;
     }

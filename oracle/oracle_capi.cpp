@@ -90,8 +90,9 @@ void orc_sensor_sample_ray(const ctl_sensor* s, float px, float py, float* o, fl
 
 // ---- intersect ------------------------------------------------------------------------------------------------
 // intersectKernel semantics (TraceHelper.cu:326-734): tmin = ray.a.w at node and triangle level, tmax = ray.b.w.
+// any_hit: bit 0 = first hit ends the ray, bit 1 = alpha-test candidate hits (traceRay<USE_ALPHA>, TraceHelper.cu:135-153)
 void orc_intersect(const ctl_scene_desc* desc, const ctl_ray* rays, uint32_t n, ctl_hit* hits, int any_hit, ctl_traversal_counts* counts, int n_threads) {
-    Scene S; S.d = *desc;
+    Scene S; S.d = *desc; S.alpha_test = (any_hit & 2) != 0; any_hit &= 1;
     if (n_threads < 1) n_threads = 1;
     std::vector<TravCounts> tc(n_threads);
     auto work = [&](int tid) {
@@ -164,13 +165,27 @@ void orc_texture_eval(const ctl_scene_desc* desc, const ctl_texture* t, float u,
     Spec s = texEval(*t, dg); out[0] = s.x; out[1] = s.y; out[2] = s.z;
 }
 
+// Material::SampleNormalMap on a hand-made shading point: frame_io = s,t,n (9 floats, replaced by the perturbed frame),
+// geo = geometric normal, dpdu, dpdv (9 floats).  Returns whether a map was applied.
+int orc_sample_normal_map(const ctl_scene_desc* desc, const ctl_material* mat, float u, float v, float* frame_io, const float* geo) {
+    DG dg; dg.uv = V2{ u, v }; dg.images = desc ? desc->images : nullptr;
+    dg.sys = Frame(V3(frame_io[0], frame_io[1], frame_io[2]), V3(frame_io[3], frame_io[4], frame_io[5]), V3(frame_io[6], frame_io[7], frame_io[8]));
+    dg.n = V3(geo[0], geo[1], geo[2]); dg.dpdu = V3(geo[3], geo[4], geo[5]); dg.dpdv = V3(geo[6], geo[7], geo[8]);
+    const bool r = sampleNormalMap(*mat, dg);
+    const V3 f[3] = { dg.sys.s, dg.sys.t, dg.sys.n };
+    for (int i = 0; i < 3; i++) { frame_io[3 * i] = f[i].x; frame_io[3 * i + 1] = f[i].y; frame_io[3 * i + 2] = f[i].z; }
+    return r ? 1 : 0;
+}
+int orc_alpha_test(const ctl_scene_desc* desc, const ctl_material* mat, float u, float v) { return materialAlphaTest(*mat, V2{ u, v }, desc ? desc->images : nullptr) ? 1 : 0; }
+
 // ---- full render: pathKernel2<DIRECT,false> looped over all pixels (Integrators/PathTracer.cu:182-194) ---------
 // tables: n_passes consecutive (t1[30*4096], t2[30*4096*2]) pairs, or NULL -> own SequenceGenerator
 // (one Compute() per pass, as Tracer<true>::DoPass -> UpdateKernel does, Kernel/Tracer.h:229).
 // Renders rows [y0,y1) only (bounded CPU-baseline samples).  Returns the number of rays traced.
 uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t n_passes, const float* tables1, const float* tables2,
                     int direct, int maxPathLength, int rrStart, ctl_pixel_data* img, int n_threads, uint32_t y0, uint32_t y1, int half_host_quirk) {
-    Scene S; S.d = *desc; S.half_host_quirk = half_host_quirk != 0;
+    // half_host_quirk: bit 0 = half::ToFloat host branch, bit 1 = alpha test on (doAlphaMapping: every traceRay, incl. Occluded)
+    Scene S; S.d = *desc; S.half_host_quirk = (half_host_quirk & 1) != 0; S.alpha_test = (half_host_quirk & 2) != 0 && sceneHasAlphaMaps(*desc);
     PerspectiveSensor sensor; sensor.update(desc->camera);
     if (n_threads < 1) n_threads = 1;
     if (y1 > H) y1 = H;

@@ -124,6 +124,44 @@ def test_megakernel_path_tracer_plugin(gpu, orc, scene_kw):
         tr = gpu.PathTracer(); tr.Resize(64, 64); tr.InitializeScene(gpu.Scene(d))        # needs the flattened layout
 
 
+def _render(gpu, cls, scene, tables, w, h, max_len=5, **params):
+    tr = cls()
+    p = tr.getParameters(); p.setValue("MaxPathLength", max_len)
+    for k, v in params.items():
+        p.setValue(k, v)
+    tr.Resize(w, h); tr.InitializeScene(scene)
+    img = gpu.Image(w, h)
+    for k in range(len(tables)):
+        tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
+    return img.getPixelData()
+
+
+@pytest.mark.parametrize("surface_map,alpha", [("normal", "luminance"), ("height", "alpha"), (None, "color")])
+def test_material_maps(gpu, orc, surface_map, alpha):
+    """Normal / height maps in the shading stage (Material::SampleNormalMap) and the alpha test in traversal (Material::AlphaTest):
+    the wavefront tracer ignores alpha maps by default as the reference's intersectKernel does, tests them with AlphaTest=true, and
+    the megakernel PathTracer always tests them (TraceHelper.cu:135-153, 179)."""
+    w, h = 96, 64
+    sc = scenes.maps_scene(w, h, surface_map, alpha)
+    d = sc.desc
+    tables = orc.sequence_tables(2)
+    want_off, _ = orc.render(d, w, h, n_passes=2, tables=tables, max_path_length=5, alpha_test=False)
+    want_on, _ = orc.render(d, w, h, n_passes=2, tables=tables, max_path_length=5, alpha_test=True)
+    assert not np.array_equal(want_off, want_on)
+    two_level, flat = gpu.Scene(d), gpu.Scene(d, flatten=True)
+    assert_close(_render(gpu, gpu.WavefrontPathTracer, two_level, tables, w, h), want_off)
+    assert_close(_render(gpu, gpu.WavefrontPathTracer, two_level, tables, w, h, AlphaTest=True), want_on)
+
+    def close_flat(got, want):                                       # flattened layout: t, u, v to fp32 round-off
+        g, wv = got[..., :3], want[..., :3]
+        assert np.array_equal(got[..., 6], want[..., 6])
+        assert (np.abs(g - wv) <= 2e-3 * (1 + np.abs(wv))).all(axis=2).mean() >= 0.985
+        assert abs(g.mean() - wv.mean()) <= 5e-3 * wv.mean()
+    close_flat(_render(gpu, gpu.WavefrontPathTracer, flat, tables, w, h, AlphaTest=True), want_on)
+    close_flat(_render(gpu, gpu.WavefrontPathTracer, flat, tables, w, h), want_off)
+    close_flat(_render(gpu, gpu.PathTracer, flat, tables, w, h), want_on)
+
+
 def test_image_pipeline_and_output_files(gpu, tmp_path):
     """applyImagePipeline (no filter / post-process) = toSpectrum(splatScale) -> sRGB curve -> RGBCOL; WriteDisplayImage"""
     import struct, zlib
