@@ -33,13 +33,32 @@ static std::string ext_of(const std::string& path) {
 // Semantics of Engine/MeshLoader/ObjParser.cpp: vertices are unique (p, t, n) index triples; vt is stored as (u, 1 - v) (:627);
 // polygons are fanned (0, i-1, i) (:699-700); faces before any known `usemtl` go to a default sub-mesh with diffuse 0.75
 // (:235,242); every triangle is emitted with reversed index order (:861-866); normals are used only if the file has `vn`.
-struct mtl_rec { std::string name; float kd[3] = { 0.75f, 0.75f, 0.75f }, ks[3] = { 0, 0, 0 }, ke[3] = { 0, 0, 0 }, tf[3] = { 0, 0, 0 }; float ns = 0, ni = 1; int illum = 2; int submesh = -1; };
-static ctl_material mtl_to_material(const mtl_rec& M) {   // ObjParser.cpp:808-840 (texture maps of the .mtl are not followed)
-    if (M.illum == 5) { const float e[3] = { 0, 0, 0 }, k[3] = { 1, 1, 1 }; return make_conductor(e, k, tex_const(1.0f)); }
-    if (M.illum == 7) return make_dielectric(M.ni, tex_const(M.ks[0], M.ks[1], M.ks[2]), tex_const(M.tf[0], M.tf[1], M.tf[2]));
-    if (M.illum == 9) return make_dielectric(M.ni, tex_const(0.0f), tex_const(M.tf[0], M.tf[1], M.tf[2]));
-    if (M.illum == 2 && (M.ks[0] != 0 || M.ks[1] != 0 || M.ks[2] != 0)) return make_phong(tex_const(M.kd[0], M.kd[1], M.kd[2]), tex_const(M.ks[0], M.ks[1], M.ks[2]), tex_const(M.ns));
-    return make_diffuse(tex_const(M.kd[0], M.kd[1], M.kd[2]));
+struct mtl_rec {
+    std::string name; float kd[3] = { 0.75f, 0.75f, 0.75f }, ks[3] = { 0, 0, 0 }, ke[3] = { 0, 0, 0 }, tf[3] = { 0, 0, 0 }; float ns = 0, ni = 1; int illum = 2; int submesh = -1;
+    std::string map_kd, map_ks, map_alpha, map_disp;   // ObjMaterial::textures[TextureType_Diffuse / Specular / Alpha / Displacement]
+};
+// CreateTexture(path, colour) (ObjParser.cpp:583-588): a bitmap when the .mtl names one, else the constant
+static ctl_texture mtl_texture(const std::string& file, const float* col, std::vector<std::string>& files) {
+    if (file.empty()) return tex_const(col[0], col[1], col[2]);
+    ctl_texture t = tex_const(1.0f); t.type = CTL_TEX_IMAGE;   // ImageTexture(TextureMapping2D(), file, Spectrum(1))
+    size_t i = 0; while (i < files.size() && files[i] != file) i++;
+    if (i == files.size()) files.push_back(file);
+    t.image = (uint32_t)i;
+    return t;
+}
+static ctl_material mtl_to_material(const mtl_rec& M, std::vector<std::string>& files) {   // ObjParser.cpp:808-850
+    const float zero[3] = { 0, 0, 0 };
+    ctl_material m;
+    if (M.illum == 5) { const float e[3] = { 0, 0, 0 }, k[3] = { 1, 1, 1 }; m = make_conductor(e, k, tex_const(1.0f)); }
+    else if (M.illum == 7) m = make_dielectric(M.ni, tex_const(M.ks[0], M.ks[1], M.ks[2]), tex_const(M.tf[0], M.tf[1], M.tf[2]));
+    else if (M.illum == 9) m = make_dielectric(M.ni, tex_const(0.0f), tex_const(M.tf[0], M.tf[1], M.tf[2]));
+    else if (M.illum == 2 && (M.ks[0] != 0 || M.ks[1] != 0 || M.ks[2] != 0 || !M.map_ks.empty()))
+        m = make_phong(mtl_texture(M.map_kd, M.kd, files), mtl_texture(M.map_ks, M.ks, files), tex_const(M.ns));
+    else if (M.illum == 2) m = make_diffuse(mtl_texture(M.map_kd, M.kd, files));
+    else m = make_diffuse(tex_const(M.kd[0], M.kd[1], M.kd[2]));   // other models leave the Material's default BSDF; the build shades them diffuse
+    if (!M.map_disp.empty()) { m.map_kind = CTL_MAP_HEIGHT; m.map_tex = mtl_texture(M.map_disp, zero, files); }                      // SetHeightMap (:842-845)
+    if (!M.map_alpha.empty()) { m.alpha_state = CTL_ALPHA_MAP_LUMINANCE; m.alpha_tex = mtl_texture(M.map_alpha, zero, files); m.alpha_test_scalar = 1.0f; }   // :846-850
+    return m;
 }
 static void load_mtl(const std::string& path, std::vector<mtl_rec>& out) {
     FILE* f = std::fopen(path.c_str(), "rb");
@@ -53,7 +72,15 @@ static void load_mtl(const std::string& path, std::vector<mtl_rec>& out) {
         else if (key == "Ks") ss >> cur->ks[0] >> cur->ks[1] >> cur->ks[2];
         else if (key == "Ke") ss >> cur->ke[0] >> cur->ke[1] >> cur->ke[2];
         else if (key == "Tf") ss >> cur->tf[0] >> cur->tf[1] >> cur->tf[2];
-        else if (key == "Ns") ss >> cur->ns;
+        else if (key == "Ns") { ss >> cur->ns; if (cur->ns <= 0.0f) { cur->ns = 1.0f; cur->ks[0] = cur->ks[1] = cur->ks[2] = 0.0f; } }   // :487-491
+        else if (key == "map_Kd" || key == "map_Ks" || key == "map_d" || key == "map_D" || key == "map_opacity" || key == "disp" || key == "bump" || key == "map_bump" || key == "map_Bump") {
+            // the file name is the last token (options such as "-bm 0.5" precede it); resolved against the .mtl's directory when it exists there (get_texture_path, :366-371)
+            std::string tok, file; while (ss >> tok) file = tok;
+            if (file.empty()) continue;
+            const std::string local = dir_of(path) + "/" + file;
+            if (FILE* t = std::fopen(local.c_str(), "rb")) { std::fclose(t); file = local; }
+            (key == "map_Kd" ? cur->map_kd : key == "map_Ks" ? cur->map_ks : (key == "map_d" || key == "map_D" || key == "map_opacity") ? cur->map_alpha : cur->map_disp) = file;
+        }
         else if (key == "Ni") ss >> cur->ni;
         else if (key == "illum") ss >> cur->illum;
     }
@@ -118,7 +145,7 @@ mesh_data load_obj(const std::string& path) {
         if (subs[si].tris.empty() && subs.size() > 1) continue;
         if (M.materials.size() >= 255) throw unsupported_error("OBJ with more than 255 materials : " + path);
         const uint8_t mi = (uint8_t)M.materials.size();
-        M.materials.push_back(mtl_to_material(subs[si].mat));
+        M.materials.push_back(mtl_to_material(subs[si].mat, M.image_files));
         for (int k = 0; k < 3; k++) M.emission.push_back(subs[si].mat.ke[k]);
         for (auto& t : subs[si].tris) { M.indices.push_back(t[2]); M.indices.push_back(t[1]); M.indices.push_back(t[0]); M.tri_material.push_back(mi); }
     }

@@ -16,6 +16,7 @@ struct mesh_data {
     std::vector<uint8_t> tri_material;     // per triangle
     std::vector<ctl_material> materials;   // >= 1
     std::vector<float> emission;           // 3 per material (OBJ "Ke"), zero = none
+    std::vector<std::string> image_files;  // bitmaps named by the .mtl: CTL_TEX_IMAGE textures of `materials` carry an index into this list
     // Mesh::CompileMesh options of the .serialized path
     bool flip_normals = false, face_normals = false; float max_smooth_angle = 0.0f;
     uint32_t n_vertices() const { return (uint32_t)(positions.size() / 3); }

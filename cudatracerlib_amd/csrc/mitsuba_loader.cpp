@@ -330,8 +330,15 @@ struct loader {
         if (it != mesh_cache.end()) mesh = it->second;
         else {
             const mesh_data& M = *data;
+            std::vector<ctl_material> mats = M.materials;
+            if (!M.image_files.empty()) {   // bitmaps of an OBJ's .mtl: load (MIPMap defaults: repeat wrap, trilinear filter) and point the textures at the scene's image table
+                std::vector<uint32_t> idx(M.image_files.size());
+                for (size_t i = 0; i < idx.size(); i++) idx[i] = load_image(M.image_files[i], CTL_WRAP_REPEAT, CTL_FILTER_TRILINEAR);
+                auto fix = [&](ctl_texture& t) { if (t.type == CTL_TEX_IMAGE && t.image < idx.size()) t.image = idx[t.image]; };
+                for (auto& m : mats) { for (auto& t : m.tex) fix(t); if (m.map_kind != CTL_MAP_NONE) fix(m.map_tex); if (m.alpha_state != CTL_ALPHA_DISABLED) fix(m.alpha_tex); }
+            }
             mesh = B.add_mesh(M.positions.data(), M.n_vertices(), M.indices.data(), M.n_triangles(), M.normals.empty() ? nullptr : M.normals.data(), M.uvs.empty() ? nullptr : M.uvs.data(),
-                              M.tri_material.data(), M.materials.data(), (uint32_t)M.materials.size(), M.flip_normals, M.face_normals, M.max_smooth_angle);
+                              M.tri_material.data(), mats.data(), (uint32_t)mats.size(), M.flip_normals, M.face_normals, M.max_smooth_angle);
             mesh_cache[key] = mesh; mesh_emission[mesh] = M.emission;
         }
         const uint32_t node = B.add_node(mesh, nullptr);
