@@ -139,6 +139,18 @@ def device_count():
     return int(lib.ctl_device_count())
 
 
+def set_cache_dir(directory):
+    """Directory of the compiled-geometry cache (the reference's .xmsh role); None disables.  Default: $CTL_CACHE_DIR."""
+    _check(lib.ctl_set_cache_dir(None if directory is None else str(directory).encode()))
+
+
+def flatten_probe(desc, width=4):
+    """Host half of Scene(desc, flatten=True): dict(nodes, leaves, depth, hash) of the flattened BVH (built or loaded from the cache)."""
+    out = (u64 * 4)()
+    _check(lib.ctl_flatten_probe(C.byref(desc), u32(width), out))
+    return dict(nodes=out[0], leaves=out[1], depth=out[2], hash=out[3])
+
+
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(f32))
 

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <atomic>
 #include <future>
+#include <thread>
 #include <cmath>
 #include <cstring>
 
@@ -17,7 +18,7 @@ struct tmp_node { aabb box; int left, right; uint32_t begin, end; };   // leaf: 
 struct builder {
     const std::vector<aabb>& boxes;
     std::vector<float> cx, cy, cz;
-    std::vector<uint32_t> idx;
+    std::vector<uint32_t> idx, scratch;
     std::vector<tmp_node> pool;
     std::atomic<int> pool_used{ 0 };
     int max_leaf, depth_limit;
@@ -25,7 +26,7 @@ struct builder {
 
     explicit builder(const std::vector<aabb>& b, int ml, int dl) : boxes(b), max_leaf(ml), depth_limit(dl) {
         size_t n = b.size();
-        cx.resize(n); cy.resize(n); cz.resize(n); idx.resize(n);
+        cx.resize(n); cy.resize(n); cz.resize(n); idx.resize(n); scratch.resize(n >= (1u << 18) ? n : 0);
         for (size_t i = 0; i < n; i++) {
             cx[i] = 0.5f * (b[i].lo[0] + b[i].hi[0]); cy[i] = 0.5f * (b[i].lo[1] + b[i].hi[1]); cz[i] = 0.5f * (b[i].lo[2] + b[i].hi[2]);
             idx[i] = (uint32_t)i;
@@ -34,16 +35,35 @@ struct builder {
     }
     const float* cen(int axis) const { return axis == 0 ? cx.data() : (axis == 1 ? cy.data() : cz.data()); }
 
+    // run f(chunk_begin, chunk_end, chunk) over [begin, end) on `threads` host threads
+    template <typename F> static void chunks(uint32_t begin, uint32_t end, int threads, const F& f) {
+        if (threads <= 1) { f(begin, end, 0); return; }
+        std::vector<std::thread> th; const uint64_t n = end - begin;
+        for (int t = 0; t < threads; t++) th.emplace_back([&, t]() { f(begin + (uint32_t)(n * t / threads), begin + (uint32_t)(n * (t + 1) / threads), t); });
+        for (auto& x : th) x.join();
+    }
+    struct bins3 { aabb bb[3][kBins]; uint32_t cnt[3][kBins]; void reset() { for (int a = 0; a < 3; a++) for (int b = 0; b < kBins; b++) { bb[a][b].reset(); cnt[a][b] = 0; } } };
+
+    // a subtree with par_budget b may use 2^b host threads: large nodes split their passes over them, then the two children share them
     int build(uint32_t begin, uint32_t end, int depth, int par_budget) {
         int me = pool_used.fetch_add(1);
         tmp_node& nd = pool[me];
         nd.begin = begin; nd.end = end; nd.left = nd.right = -1;
-        nd.box.reset();
-        aabb cb; cb.reset();
-        for (uint32_t i = begin; i < end; i++) { uint32_t p = idx[i]; nd.box.grow(boxes[p]); float c[3] = { cx[p], cy[p], cz[p] }; cb.grow(c); }
+        const uint32_t n = end - begin;
+        const int threads = (int)std::min<uint32_t>(1u << std::max(par_budget, 0), std::max<uint32_t>(1, n >> 17));
+        aabb cb;
+        {   // node box and centroid box
+            std::vector<aabb> nb(threads), cbs(threads);
+            chunks(begin, end, threads, [&](uint32_t b0, uint32_t b1, int t) {
+                aabb x, c; x.reset(); c.reset();
+                for (uint32_t i = b0; i < b1; i++) { const uint32_t p = idx[i]; x.grow(boxes[p]); const float cc[3] = { cx[p], cy[p], cz[p] }; c.grow(cc); }
+                nb[t] = x; cbs[t] = c;
+            });
+            nd.box = nb[0]; cb = cbs[0];
+            for (int t = 1; t < threads; t++) { nd.box.grow(nb[t]); cb.grow(cbs[t]); }
+        }
         int d = max_depth.load();
         while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
-        uint32_t n = end - begin;
         if (n <= 1) return me;
         // how many levels are left vs. how many a balanced tree still needs
         int remaining = depth_limit - depth;
@@ -52,18 +72,25 @@ struct builder {
 
         int best_axis = -1, best_bin = -1; float best_cost = 3.402823466e+38f;
         if (!force_median) {
-            for (int axis = 0; axis < 3; axis++) {
-                float lo = cb.lo[axis], hi = cb.hi[axis];
-                if (!(hi > lo)) continue;
-                const float* c = cen(axis);
-                float scale = kBins / (hi - lo);
-                aabb bb[kBins]; uint32_t cnt[kBins];
-                for (int b = 0; b < kBins; b++) { bb[b].reset(); cnt[b] = 0; }
-                for (uint32_t i = begin; i < end; i++) {
-                    uint32_t p = idx[i];
-                    int b = std::min(kBins - 1, std::max(0, (int)((c[p] - lo) * scale)));
-                    bb[b].grow(boxes[p]); cnt[b]++;
+            float lo[3], scale[3]; bool use[3];
+            for (int a = 0; a < 3; a++) { lo[a] = cb.lo[a]; use[a] = cb.hi[a] > cb.lo[a]; scale[a] = use[a] ? kBins / (cb.hi[a] - cb.lo[a]) : 0.0f; }
+            // one pass bins the primitives along all three axes
+            std::vector<bins3> tb(threads);
+            chunks(begin, end, threads, [&](uint32_t b0, uint32_t b1, int t) {
+                bins3& B = tb[t]; B.reset();
+                for (uint32_t i = b0; i < b1; i++) {
+                    const uint32_t p = idx[i]; const aabb& bx = boxes[p]; const float c[3] = { cx[p], cy[p], cz[p] };
+                    for (int a = 0; a < 3; a++) {
+                        if (!use[a]) continue;
+                        const int b = std::min(kBins - 1, std::max(0, (int)((c[a] - lo[a]) * scale[a])));
+                        B.bb[a][b].grow(bx); B.cnt[a][b]++;
+                    }
                 }
+            });
+            for (int t = 1; t < threads; t++) for (int a = 0; a < 3; a++) for (int b = 0; b < kBins; b++) if (tb[t].cnt[a][b]) { tb[0].bb[a][b].grow(tb[t].bb[a][b]); tb[0].cnt[a][b] += tb[t].cnt[a][b]; }
+            for (int axis = 0; axis < 3; axis++) {
+                if (!use[axis]) continue;
+                const aabb* bb = tb[0].bb[axis]; const uint32_t* cnt = tb[0].cnt[axis];
                 float rarea[kBins]; uint32_t rcnt[kBins];
                 aabb acc; acc.reset(); uint32_t ac = 0;
                 for (int b = kBins - 1; b > 0; b--) { if (cnt[b]) acc.grow(bb[b]); ac += cnt[b]; rarea[b] = ac ? acc.area() : 0.0f; rcnt[b] = ac; }
@@ -83,9 +110,22 @@ struct builder {
         if (best_axis >= 0 && !force_median) {
             const float* c = cen(best_axis);
             float lo = cb.lo[best_axis], scale = kBins / (cb.hi[best_axis] - lo);
-            auto it = std::partition(idx.begin() + begin, idx.begin() + end, [&](uint32_t p) {
-                int b = std::min(kBins - 1, std::max(0, (int)((c[p] - lo) * scale))); return b <= best_bin; });
-            mid = (uint32_t)(it - idx.begin());
+            auto left = [&](uint32_t p) { int b = std::min(kBins - 1, std::max(0, (int)((c[p] - lo) * scale))); return b <= best_bin; };
+            if (threads > 1) {   // count per chunk, then scatter both sides in order into the scratch array and copy back
+                std::vector<uint32_t> nl(threads + 1, 0), first(threads + 1, begin);
+                chunks(begin, end, threads, [&](uint32_t b0, uint32_t b1, int t) { uint32_t k = 0; for (uint32_t i = b0; i < b1; i++) k += left(idx[i]) ? 1u : 0u; nl[t + 1] = k; first[t] = b0; });
+                first[threads] = end;
+                for (int t = 0; t < threads; t++) nl[t + 1] += nl[t];
+                mid = begin + nl[threads];
+                chunks(begin, end, threads, [&](uint32_t b0, uint32_t b1, int t) {
+                    uint32_t l = begin + nl[t], r = mid + (b0 - begin) - nl[t];
+                    for (uint32_t i = b0; i < b1; i++) { const uint32_t p = idx[i]; if (left(p)) scratch[l++] = p; else scratch[r++] = p; }
+                });
+                chunks(begin, end, threads, [&](uint32_t b0, uint32_t b1, int) { std::memcpy(&idx[b0], &scratch[b0], (size_t)(b1 - b0) * 4); });
+            } else {
+                auto it = std::stable_partition(idx.begin() + begin, idx.begin() + end, left);   // stable like the threaded path: the tree does not depend on the thread count
+                mid = (uint32_t)(it - idx.begin());
+            }
         } else mid = begin;
         if (mid == begin || mid == end) {   // median split on the widest centroid axis (or by index when all centroids coincide)
             int axis = 0; float w = -1;
@@ -93,7 +133,7 @@ struct builder {
             mid = begin + n / 2;
             if (w > 0) { const float* c = cen(axis); std::nth_element(idx.begin() + begin, idx.begin() + mid, idx.begin() + end, [&](uint32_t a, uint32_t b) { return c[a] < c[b]; }); }
         }
-        if (par_budget > 0 && n > 32768) {
+        if (par_budget > 0 && n > 32768) {   // the children split this subtree's threads
             auto fut = std::async(std::launch::async, [&, mid, end, depth, par_budget]() { return build(mid, end, depth + 1, par_budget - 1); });
             int l = build(begin, mid, depth + 1, par_budget - 1);
             int r = fut.get();
@@ -139,7 +179,8 @@ void build_bvh(const std::vector<aabb>& prim_boxes, int max_leaf, bool wrap_sing
     out.nodes.clear(); out.leaf_prims.clear(); out.leaf_last.clear(); out.root = 0; out.max_depth = 0;
     if (prim_boxes.empty()) { out.root = kEmptyChild; return; }
     builder B(prim_boxes, max_leaf, max_depth_limit);
-    int root = B.build(0, (uint32_t)prim_boxes.size(), 0, 3);
+    int budget = 0; while ((1u << (budget + 1)) <= std::max(1u, std::thread::hardware_concurrency()) && budget < 6) budget++;   // <= 64 threads
+    int root = B.build(0, (uint32_t)prim_boxes.size(), 0, std::max(budget, 3));
     out.max_depth = B.max_depth.load();
     emitter E{ B, out };
     out.leaf_prims.reserve(prim_boxes.size()); out.leaf_last.reserve(prim_boxes.size());

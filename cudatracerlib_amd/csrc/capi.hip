@@ -4,6 +4,9 @@
 #include "tracer.h"
 #include "scene_builder.h"
 #include "mitsuba_loader.h"
+#include "flatten.h"
+#include "scene_cache.h"
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <new>
@@ -94,6 +97,17 @@ int ctl_builder_finalize(ctl_builder* b, ctl_scene_desc* out) { CTL_REQUIRE(b &&
 int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc, false); CTL_CATCH }
 int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc, (flags & CTL_SCENE_FLATTEN) != 0); CTL_CATCH }
 void ctl_scene_destroy(ctl_scene* s) { delete s; }
+int ctl_set_cache_dir(const char* dir) { CTL_TRY set_cache_dir(dir); CTL_CATCH }
+int ctl_flatten_probe(const ctl_scene_desc* desc, uint32_t width, uint64_t* out4) {
+    CTL_REQUIRE(desc && out4 && (width == 4 || width == 8), "null argument or bad width");
+    CTL_TRY
+        flat_scene F;
+        if (!flatten_scene(*desc, F, (size_t)1 << 30, (int)width)) throw std::runtime_error("ctl_flatten_probe: nothing to flatten");
+        content_hash H; H.add_vector(F.nodes); H.add_vector(F.nodes8); H.add_vector(F.leaves);
+        out4[0] = F.width == 8 ? F.nodes8.size() : F.nodes.size(); out4[1] = F.leaves.size(); out4[2] = (uint64_t)F.max_depth;
+        out4[3] = std::strtoull(H.hex().substr(16).c_str(), nullptr, 16);
+    CTL_CATCH
+}
 int ctl_parse_mitsuba_scene(ctl_builder* b, const char* xml_path, int32_t* width_inout, int32_t* height_inout) {
     CTL_REQUIRE(b && xml_path, "null argument");
     CTL_TRY parse_mitsuba_scene(b->b, xml_path, width_inout, height_inout); CTL_CATCH

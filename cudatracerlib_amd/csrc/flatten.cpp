@@ -6,10 +6,15 @@
 // (the Woop rows are recomputed in double precision from the world-space vertices) instead of bit-for-bit.
 #include "flatten.h"
 #include "bvh_builder.h"
+#include "scene_cache.h"
 #include <cmath>
 #include <cstring>
 #include <algorithm>
 #include <stdexcept>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 
 namespace ctl {
 
@@ -61,6 +66,19 @@ bool woop_rows(const double v[3][3], float a[4], float b[4], float c[4]) {
     for (int j = 0; j < 4; j++) { b[j] = (float)inv[j]; c[j] = (float)inv[4 + j]; }
     return true;
 }
+// phase timing on stderr when CTL_VERBOSE is set
+struct phase_timer {
+    const bool on = std::getenv("CTL_VERBOSE") != nullptr; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) { if (!on) return; const auto n = std::chrono::steady_clock::now(); std::fprintf(stderr, "[ctl flatten] %-18s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count()); t = n; }
+};
+// static split of [0, n) over the host threads
+template <typename F> void parallel_for(size_t n, const F& f, size_t min_chunk = 4096) {
+    const size_t nt = std::min<size_t>(std::min(64u, std::max(1u, std::thread::hardware_concurrency())), std::max<size_t>(1, n / min_chunk));
+    if (nt <= 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; t++) th.emplace_back([&, t]() { f(n * t / nt, n * (t + 1) / nt); });
+    for (auto& x : th) x.join();
+}
 float round_down(double x) { float f = (float)x; return ((double)f > x) ? std::nextafterf(f, -INFINITY) : f; }
 float round_up(double x) { float f = (float)x; return ((double)f < x) ? std::nextafterf(f, INFINITY) : f; }
 
@@ -68,6 +86,7 @@ float round_up(double x) { float f = (float)x; return ((double)f < x) ? std::nex
 
 bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangles, int width) {
     out.nodes.clear(); out.nodes8.clear(); out.leaves.clear(); out.width = width == 8 ? 8 : 4;
+    phase_timer pt;
     // leaf-entry range of every mesh (the woop stream is shared; a mesh ends where the next one starts)
     std::vector<std::pair<uint32_t, uint32_t>> starts;
     for (uint32_t m = 0; m < d.n_meshes; m++) starts.emplace_back(d.meshes[m].bvh_tri_offset / 3, m);
@@ -88,26 +107,56 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
         total += mesh_tris[m].size();
     }
     if (total == 0 || total > max_triangles) return false;
-    struct wtri { double v[3][3]; uint32_t tri, node; };
-    std::vector<wtri> tris; tris.reserve(total);
-    std::vector<aabb> boxes; boxes.reserve(total);
-    for (uint32_t k = 0; k < d.n_nodes; k++) {
-        const ctl_node& N = d.nodes[k]; const ctl_kernel_mesh& km = d.meshes[N.mesh_index];
-        const float* M = d.node_transforms[k].m;
-        for (auto& e : mesh_tris[N.mesh_index]) {
-            double lv[3][3];
-            if (!woop_vertices(d.woop[e.second], lv)) continue;   // degenerate triangle: can never be hit
-            wtri t; t.tri = km.tri_offset + e.first; t.node = k;
-            aabb b; b.reset();
-            for (int j = 0; j < 3; j++) {
-                for (int r = 0; r < 3; r++) t.v[j][r] = (double)M[r * 4] * lv[j][0] + (double)M[r * 4 + 1] * lv[j][1] + (double)M[r * 4 + 2] * lv[j][2] + (double)M[r * 4 + 3];
-                for (int r = 0; r < 3; r++) { const float lo = round_down(t.v[j][r]), hi = round_up(t.v[j][r]); if (lo < b.lo[r]) b.lo[r] = lo; if (hi > b.hi[r]) b.hi[r] = hi; }
-            }
-            tris.push_back(t); boxes.push_back(b);
+    // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node width only
+    std::string key;
+    if (!cache_dir().empty()) {
+        content_hash H; const uint32_t version = 1;
+        H.add_value(version); H.add_value(out.width); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
+        H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
+        H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
+        for (uint32_t k = 0; k < d.n_nodes; k++) { H.add_value(d.nodes[k].mesh_index); H.add(d.node_transforms[k].m, 64); }
+        key = H.hex();
+        cache_reader rd("flat", key);
+        int c_width = 0, c_depth = 0;
+        if (rd.found() && rd.value(c_width) && rd.value(c_depth) && rd.vector(out.nodes) && rd.vector(out.nodes8) && rd.vector(out.leaves) && c_width == out.width &&
+            !out.leaves.empty() && (out.width == 8 ? !out.nodes8.empty() : !out.nodes.empty())) {
+            out.max_depth = c_depth; pt.lap("cache hit");
+            return true;
         }
+        out.nodes.clear(); out.nodes8.clear(); out.leaves.clear();
     }
+    struct wtri { double v[3][3]; uint32_t tri, node; };
+    // object-space vertices of every mesh's triangles once (degenerate ones can never be hit and are dropped), then per node in parallel
+    struct ltri { double v[3][3]; uint32_t tri; };
+    std::vector<std::vector<ltri>> mesh_local(d.n_meshes);
+    for (uint32_t m = 0; m < d.n_meshes; m++) {
+        mesh_local[m].reserve(mesh_tris[m].size());
+        for (auto& e : mesh_tris[m]) { ltri l; l.tri = e.first; if (woop_vertices(d.woop[e.second], l.v)) mesh_local[m].push_back(l); }
+    }
+    std::vector<size_t> node_first(d.n_nodes + 1, 0);
+    for (uint32_t k = 0; k < d.n_nodes; k++) node_first[k + 1] = node_first[k] + mesh_local[d.nodes[k].mesh_index].size();
+    std::vector<wtri> tris(node_first[d.n_nodes]);
+    std::vector<aabb> boxes(node_first[d.n_nodes]);
+    if (tris.empty()) return false;
+    parallel_for(d.n_nodes, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; k++) {
+            const ctl_node& N = d.nodes[k]; const ctl_kernel_mesh& km = d.meshes[N.mesh_index];
+            const float* M = d.node_transforms[k].m;
+            size_t o = node_first[k];
+            for (const ltri& l : mesh_local[N.mesh_index]) {
+                wtri& t = tris[o]; t.tri = km.tri_offset + l.tri; t.node = (uint32_t)k;
+                aabb& b = boxes[o]; b.reset(); o++;
+                for (int j = 0; j < 3; j++) {
+                    for (int r = 0; r < 3; r++) t.v[j][r] = (double)M[r * 4] * l.v[j][0] + (double)M[r * 4 + 1] * l.v[j][1] + (double)M[r * 4 + 2] * l.v[j][2] + (double)M[r * 4 + 3];
+                    for (int r = 0; r < 3; r++) { const float lo = round_down(t.v[j][r]), hi = round_up(t.v[j][r]); if (lo < b.lo[r]) b.lo[r] = lo; if (hi > b.hi[r]) b.hi[r] = hi; }
+                }
+            }
+        }
+    }, 1);
+    pt.lap("world triangles");
     bvh_result R;
     build_bvh(boxes, 4, true, 60, R);
+    pt.lap("build BVH2");
     // quantise a child box conservatively against the node's own box (one exponent per axis)
     auto quantise = [&](const aabb& nbox, const aabb* cbox, int n, float origin[3], uint8_t e_out[3], uint8_t qlo[3][8], uint8_t qhi[3][8]) {
         for (int k = 0; k < 3; k++) {
@@ -165,7 +214,8 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
             W.swap(W2);
         }
         out.nodes.resize(W.size());
-        for (size_t i = 0; i < W.size(); i++) {
+        parallel_for(W.size(), [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
             const wide4_node& w = W[i]; flat4_node& f = out.nodes[i];
             std::memset(&f, 0, sizeof(f));
             uint32_t* q[3][2] = { { &f.qlo_x, &f.qhi_x }, { &f.qlo_y, &f.qhi_y }, { &f.qlo_z, &f.qhi_z } };
@@ -191,16 +241,25 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
                 else f.child[c] = 0x76543210;
             }
         }
+        });
     }
+    pt.lap("collapse+quantise");
     out.leaves.resize(R.leaf_prims.size());
-    for (size_t i = 0; i < R.leaf_prims.size(); i++) {
-        const wtri& t = tris[R.leaf_prims[i]];
-        flat_leaf& L = out.leaves[i];
-        std::memset(&L, 0, sizeof(L));
-        if (!woop_rows(t.v, L.a, L.b, L.c)) { L.a[3] = 0; }   // all-zero rows: t = 0/0 = NaN, never accepted
-        L.index = (t.tri << 1) | (R.leaf_last[i] ? 1u : 0u); L.node = t.node;
-    }
+    parallel_for(R.leaf_prims.size(), [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            const wtri& t = tris[R.leaf_prims[i]];
+            flat_leaf& L = out.leaves[i];
+            std::memset(&L, 0, sizeof(L));
+            if (!woop_rows(t.v, L.a, L.b, L.c)) { L.a[3] = 0; }   // all-zero rows: t = 0/0 = NaN, never accepted
+            L.index = (t.tri << 1) | (R.leaf_last[i] ? 1u : 0u); L.node = t.node;
+        }
+    });
+    pt.lap("leaf entries");
     out.max_depth = wdepth;
+    if (!key.empty()) {
+        cache_writer wr("flat", key);
+        if (wr.active()) { wr.value(out.width); wr.value(out.max_depth); wr.vector(out.nodes); wr.vector(out.nodes8); wr.vector(out.leaves); wr.commit(); pt.lap("cache write"); }
+    }
     return true;
 }
 

@@ -2,6 +2,7 @@
 // DynamicScene that the Mitsuba loader drives (Engine/DynamicScene.h:70-187), emitting the reference's
 // KernelDynamicScene arrays (Engine/KernelDynamicScene.h:28-109) as a ctl_scene_desc.
 #include "scene_builder.h"
+#include "scene_cache.h"
 #include <cstdio>
 #include <string>
 #include "ctl_math.h"
@@ -123,6 +124,28 @@ uint32_t scene_builder::add_mesh(const float* positions, uint32_t n_vert, const 
     mr.tri_offset = (uint32_t)tri.size(); mr.n_tris = n_tri;
     mr.mat_offset = (uint32_t)mesh_materials.size(); mr.n_mat = n_mat;
     mesh_materials.insert(mesh_materials.end(), materials, materials + n_mat);
+    // compiled-mesh cache (scene_cache.h; the reference's .xmsh, Engine/Mesh.cpp:46-98): keyed by every input of the compile step
+    std::string key;
+    if (!cache_dir().empty()) {
+        content_hash H; const uint32_t version = 1, flags = (flip_normals ? 1u : 0u) | (face_normals ? 2u : 0u) | (indices ? 4u : 0u) | (normals ? 8u : 0u) | (uvs ? 16u : 0u) | (tri_material ? 32u : 0u);
+        H.add_value(version); H.add_value(flags); H.add_value(n_vert); H.add_value(n_tri); H.add_value(n_mat); H.add_value(max_smooth_angle);
+        H.add(positions, (size_t)n_vert * 12);
+        if (indices) H.add(indices, (size_t)n_tri * 12);
+        if (normals) H.add(normals, (size_t)n_vert * 12);
+        if (uvs) H.add(uvs, (size_t)n_vert * 8);
+        if (tri_material) H.add(tri_material, n_tri);
+        key = H.hex();
+        cache_reader rd("mesh", key);
+        std::vector<ctl_triangle_data> c_tri; std::vector<ctl_bvh_node> c_nodes; std::vector<ctl_woop_tri> c_woop; std::vector<ctl_woop_index> c_widx; aabb c_box; int c_depth = 0;
+        if (rd.found() && rd.vector(c_tri) && rd.vector(c_nodes) && rd.vector(c_woop) && rd.vector(c_widx) && rd.value(c_box) && rd.value(c_depth) &&
+            c_tri.size() == n_tri && c_woop.size() == c_widx.size() && c_woop.size() >= n_tri) {
+            tri.insert(tri.end(), c_tri.begin(), c_tri.end());
+            mr.box = c_box; mr.max_depth = c_depth;
+            mr.node_offset = (uint32_t)bvh.size(); mr.n_nodes = (uint32_t)c_nodes.size(); bvh.insert(bvh.end(), c_nodes.begin(), c_nodes.end());
+            mr.woop_offset = (uint32_t)woop.size(); mr.n_woop = (uint32_t)c_woop.size(); woop.insert(woop.end(), c_woop.begin(), c_woop.end()); widx.insert(widx.end(), c_widx.begin(), c_widx.end());
+            return finish_mesh(mr);
+        }
+    }
     std::vector<f3> comp;
     if (!normals || flip_normals) compute_vertex_normals(positions, indices, n_vert, n_tri, comp, flip_normals);   // Mesh.cpp:216-217
     auto vidx = [&](uint32_t ti, int j) { return indices ? indices[ti * 3 + j] : ti * 3 + j; };
@@ -166,6 +189,18 @@ uint32_t scene_builder::add_mesh(const float* positions, uint32_t n_vert, const 
         widx[mr.woop_offset + i].index = (t << 1) | (R.leaf_last[i] ? 1u : 0u);
     }
     mr.max_depth = R.max_depth;
+    if (!key.empty()) {
+        cache_writer wr("mesh", key);
+        if (wr.active()) {
+            wr.section(tri.data() + mr.tri_offset, (size_t)n_tri * sizeof(ctl_triangle_data)); wr.vector(R.nodes);
+            wr.section(woop.data() + mr.woop_offset, (size_t)mr.n_woop * sizeof(ctl_woop_tri)); wr.section(widx.data() + mr.woop_offset, (size_t)mr.n_woop * sizeof(ctl_woop_index));
+            wr.value(mr.box); wr.value(mr.max_depth); wr.commit();
+        }
+    }
+    return finish_mesh(mr);
+}
+
+uint32_t scene_builder::finish_mesh(const mesh_rec& mr) {
     mesh_info.push_back(mr);
     ctl_kernel_mesh km;   // Mesh::getKernelData (Engine/Mesh.cpp:100-109)
     km.tri_offset = mr.tri_offset; km.bvh_node_offset = mr.node_offset * 4; km.bvh_tri_offset = mr.woop_offset * 3;

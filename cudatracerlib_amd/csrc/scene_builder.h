@@ -36,6 +36,7 @@ struct scene_builder {
     ctl_sensor camera{};
     bool have_camera = false;
 
+    uint32_t finish_mesh(const mesh_rec& mr);   // registers a compiled (or cache-loaded) mesh, returns its index
     uint32_t add_mesh(const float* positions, uint32_t n_vert, const uint32_t* indices, uint32_t n_tri, const float* normals, const float* uvs,
                       const uint8_t* tri_material, const ctl_material* materials, uint32_t n_mat,
                       bool flip_normals = false, bool face_normals = false, float max_smooth_angle = 0.0f);   // Mesh::CompileMesh options (Mesh.cpp:199)

@@ -298,6 +298,14 @@ int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out);
 enum { CTL_SCENE_FLATTEN = 1 };
 int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out);
 void ctl_scene_destroy(ctl_scene* s);
+/* On-disk cache of compiled geometry — the role of the reference's .xmsh files (Engine/Mesh.cpp:46-98,199-290; DynamicScene::CreateNode
+ * compiles a mesh only when its .xmsh is missing).  With a directory set, ctl_builder_add_mesh stores / reloads a compiled mesh
+ * (TriangleData, BVH nodes, Woop rows) and CTL_SCENE_FLATTEN stores / reloads the flattened BVH, both keyed by a hash of their
+ * inputs.  NULL or "" disables; the default comes from the environment variable CTL_CACHE_DIR.  Host only. */
+int ctl_set_cache_dir(const char* dir);
+/* The host half of CTL_SCENE_FLATTEN without a device (tests, cache warming): builds (or loads) the flattened BVH of `desc` with
+ * `width` = 4 or 8 and reports out4 = { inner nodes, leaf entries, depth of the wide tree, low 64 bits of a hash of the arrays }. */
+int ctl_flatten_probe(const ctl_scene_desc* desc, uint32_t width, uint64_t* out4);
 /* ParseMitsubaScene (Engine/SceneLoader/Mitsuba/MitsubaLoader.h:13): fills a builder from a Mitsuba-0.5 XML file. */
 int ctl_parse_mitsuba_scene(ctl_builder* b, const char* xml_path, int32_t* width_inout, int32_t* height_inout);
 
