@@ -139,6 +139,44 @@ def device_count():
     return int(lib.ctl_device_count())
 
 
+class ctl_reconstruction_filter(C.Structure):
+    _fields_ = [("type", u32), ("x_width", f32), ("y_width", f32), ("p0", f32), ("p1", f32)]
+
+
+class ctl_tonemap(C.Structure):
+    _fields_ = [("key", f32), ("burn", f32)]
+
+
+def box_filter(xw=1.0, yw=1.0):
+    """BoxFilter (SceneTypes/Filter.h:21-37)"""
+    return ctl_reconstruction_filter(1, xw, yw, 0.0, 0.0)
+
+
+def gaussian_filter(xw=2.0, yw=2.0, alpha=-2.0):
+    """GaussianFilter (SceneTypes/Filter.h:39-69); the default alpha = -2 is the reference's"""
+    return ctl_reconstruction_filter(2, xw, yw, alpha, 0.0)
+
+
+def mitchell_filter(B=1.0 / 3.0, Cc=1.0 / 3.0, xw=2.0, yw=2.0):
+    """MitchellFilter (SceneTypes/Filter.h:71-100)"""
+    return ctl_reconstruction_filter(3, xw, yw, B, Cc)
+
+
+def lanczos_filter(xw=6.0, yw=6.0, tau=3.0):
+    """LanczosSincFilter (SceneTypes/Filter.h:102-131)"""
+    return ctl_reconstruction_filter(4, xw, yw, tau, 0.0)
+
+
+def triangle_filter(xw=2.0, yw=2.0):
+    """TriangleFilter (SceneTypes/Filter.h:133-150)"""
+    return ctl_reconstruction_filter(5, xw, yw, 0.0, 0.0)
+
+
+def tonemap(key=0.18, burn=0.0):
+    """ToneMapPostProcess (Kernel/ImagePipeline/PostProcess/ToneMapPostProcess.h:8-24)"""
+    return ctl_tonemap(key, burn)
+
+
 def set_cache_dir(directory):
     """Directory of the compiled-geometry cache (the reference's .xmsh role); None disables.  Default: $CTL_CACHE_DIR."""
     _check(lib.ctl_set_cache_dir(None if directory is None else str(directory).encode()))
@@ -589,10 +627,15 @@ class Image:
     def device_ptr(self):
         return lib.ctl_image_device_ptr(self._h)
 
-    def applyImagePipeline(self, splat_scale=0.0):
-        """applyImagePipeline without filter / post-process: (h, w, 4) uint8 sRGB display image."""
+    def applyImagePipeline(self, splat_scale=0.0, filter=None, process=None):
+        """applyImagePipeline(tracer, img, filter, process) (Kernel/ImagePipeline/ImagePipeline.cu:54-84): (h, w, 4) uint8 display image.
+        filter = ctl_reconstruction_filter (see box_filter ... triangle_filter) or None; process = ctl_tonemap (see tonemap) or None."""
         a = np.zeros((self.height, self.width), np.uint32)
-        _check(lib.ctl_image_apply_pipeline(self._h, f32(splat_scale), a.ctypes.data_as(C.c_void_p)))
+        if filter is None and process is None:
+            _check(lib.ctl_image_apply_pipeline(self._h, f32(splat_scale), a.ctypes.data_as(C.c_void_p)))
+        else:
+            _check(lib.ctl_image_apply_pipeline_ex(self._h, f32(splat_scale), None if filter is None else C.byref(filter),
+                                                   None if process is None else C.byref(process), a.ctypes.data_as(C.c_void_p)))
         return a.view(np.uint8).reshape(self.height, self.width, 4)
 
     def WriteDisplayImage(self, path, splat_scale=0.0):

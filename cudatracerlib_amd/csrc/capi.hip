@@ -133,6 +133,9 @@ int ctl_image_write_pixels(ctl_image* img, const ctl_pixel_data* host_in) { CTL_
 void* ctl_image_device_ptr(ctl_image* img) { return img ? (void*)img->img.device() : nullptr; }
 int ctl_image_resolve_rgb(ctl_image* img, float splat_scale, float* host_rgb_out) { CTL_REQUIRE(img && host_rgb_out, "null argument"); CTL_TRY img->img.resolve_rgb(splat_scale, host_rgb_out); CTL_CATCH }
 
+int ctl_image_apply_pipeline_ex(ctl_image* img, float splat_scale, const ctl_reconstruction_filter* filter, const ctl_tonemap* process, uint32_t* host_rgbcol_out) {
+    CTL_REQUIRE(img && host_rgbcol_out, "null argument"); CTL_TRY img->img.apply_pipeline_ex(splat_scale, filter, process, host_rgbcol_out); CTL_CATCH
+}
 int ctl_image_apply_pipeline(ctl_image* img, float splat_scale, uint32_t* host_rgbcol_out) { CTL_REQUIRE(img && host_rgbcol_out, "null argument"); CTL_TRY img->img.apply_pipeline(splat_scale, host_rgbcol_out); CTL_CATCH }
 int ctl_image_write_file(ctl_image* img, float splat_scale, const char* path) { CTL_REQUIRE(img && path, "null argument"); CTL_TRY img->img.write_file(splat_scale, path); CTL_CATCH }
 

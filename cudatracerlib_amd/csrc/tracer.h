@@ -56,9 +56,10 @@ public:
     void write(const ctl_pixel_data* host);
     void resolve_rgb(float splat_scale, float* host_rgb);
     void apply_pipeline(float splat_scale, uint32_t* host_rgbcol);                 // applyImagePipeline without filter / post-process
+    void apply_pipeline_ex(float splat_scale, const ctl_reconstruction_filter* filter, const ctl_tonemap* process, uint32_t* host_rgbcol);   // image_pipeline.hip
     void write_file(float splat_scale, const char* path);                          // Image::WriteDisplayImage (Engine/Image.cpp:67-75)
 private:
-    uint32_t w_, h_; dbuf<ctl_pixel_data> px_; dbuf<float> rgb_; dbuf<uint32_t> out_;
+    uint32_t w_, h_; dbuf<ctl_pixel_data> px_; dbuf<float> rgb_; dbuf<uint32_t> out_, filtered_; dbuf<int> lum_;   // filtered_: m_filteredColorsDevice (RGBE)
 };
 
 // Kernel/TracerSettings.h:196-350 — typed parameters with interval / set constraints

@@ -337,6 +337,17 @@ int ctl_image_resolve_rgb(ctl_image* img, float splat_scale, float* host_rgb_out
 /* applyImagePipeline(tracer, img, filter = 0, process = 0) (Kernel/ImagePipeline/ImagePipeline.cu:54-63): the display image,
  * sRGB transfer curve + 8-bit RGBCOL per pixel (byte 0 = r, alpha = 255).  splat_scale = TracerBase::getSplatScale() = 1/passes. */
 int ctl_image_apply_pipeline(ctl_image* img, float splat_scale, uint32_t* host_rgbcol_out);
+/* The other three branches of applyImagePipeline (ImagePipeline.cu:64-81): an ImageSamplesFilter and / or a PostProcess.
+ * filter  = CanonicalFilter over a reconstruction Filter (Kernel/ImagePipeline/Filter/CanonicalFilter.cu:6-44, SceneTypes/Filter.h:
+ *           ids = TYPE_FUNC ids; p0 / p1 = Gaussian alpha | Mitchell B, C | Lanczos tau); the filtered image is kept as RGBE.
+ * process = ToneMapPostProcess, Reinhard et al. (PostProcess/ToneMapPostProcess.cu:6-42) driven by Image::ComputeLuminanceInfo
+ *           (Engine/Image.cu:88-168) of the RGBE image; the result is quantised to RGBCOL and then gamma-corrected, as there.
+ * Either may be NULL (both NULL = ctl_image_apply_pipeline).  The NonLocalMeans filter is not part of this build. */
+enum { CTL_RFILTER_BOX = 1, CTL_RFILTER_GAUSSIAN = 2, CTL_RFILTER_MITCHELL = 3, CTL_RFILTER_LANCZOS = 4, CTL_RFILTER_TRIANGLE = 5 };
+typedef struct { uint32_t type; float x_width, y_width, p0, p1; } ctl_reconstruction_filter;
+typedef struct { float key, burn; } ctl_tonemap;           /* defaults of the reference: key 0.18, burn 0 */
+int ctl_image_apply_pipeline_ex(ctl_image* img, float splat_scale, const ctl_reconstruction_filter* filter, const ctl_tonemap* process,
+                                uint32_t* host_rgbcol_out);
 /* Image::WriteDisplayImage (Engine/Image.cpp:67-75): .png writes the display image, .hdr / .pfm the linear float image.
  * Other formats (the reference saves through FreeImage) -> CTL_ERR_UNSUPPORTED. */
 int ctl_image_write_file(ctl_image* img, float splat_scale, const char* path);

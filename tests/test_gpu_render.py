@@ -162,6 +162,32 @@ def test_material_maps(gpu, orc, surface_map, alpha):
     close_flat(_render(gpu, gpu.PathTracer, flat, tables, w, h), want_on)
 
 
+def test_image_pipeline_filters_and_tonemap(gpu):
+    """applyImagePipeline with a CanonicalFilter and / or the Reinhard tone mapper against the numpy oracle (oracle/pipeline.py).
+    8-bit outputs may differ by one step where expf / powf / the atomic log-average differ in the last ulp."""
+    from oracle import pipeline as P
+    sc = scenes.cornell_box(48, 40, glass_sphere=True)
+    scene = gpu.Scene(sc.desc)
+    tr = gpu.WavefrontPathTracer(); tr.getParameters().setValue("MaxPathLength", 4)
+    tr.Resize(48, 40); tr.InitializeScene(scene)
+    img = gpu.Image(48, 40)
+    tr.DoPasses(img, 4, new_trace=True)
+    px = img.getPixelData()
+    api = gpu.api
+    cases = [(api.box_filter(1.0, 2.0), None), (api.gaussian_filter(2.0, 2.0, 2.0), None), (api.mitchell_filter(), None), (api.lanczos_filter(3.0, 3.0, 3.0), None),
+             (api.triangle_filter(2.0, 1.5), None), (None, api.tonemap()), (api.triangle_filter(), api.tonemap(0.3, 0.2)), (api.gaussian_filter(1.5, 1.5, 1.0), api.tonemap(0.18, 0.0))]
+    for flt, proc in cases:
+        got = img.applyImagePipeline(0.25, flt, proc)
+        f = None if flt is None else dict(type=flt.type, xw=flt.x_width, yw=flt.y_width, p0=flt.p0, p1=flt.p1)
+        p = None if proc is None else dict(key=proc.key, burn=proc.burn)
+        want = P.apply_image_pipeline(px, 0.25, f, p)
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 2 and (d > 0).mean() <= 0.03, (None if flt is None else flt.type, proc is not None, d.max(), (d > 0).mean())
+    assert np.array_equal(img.applyImagePipeline(0.25), P.apply_image_pipeline(px, 0.25)) or np.abs(img.applyImagePipeline(0.25).astype(int) - P.apply_image_pipeline(px, 0.25).astype(int)).max() <= 1
+    with pytest.raises(gpu.CtlError):
+        img.applyImagePipeline(0.0, api.ctl_reconstruction_filter(9, 1.0, 1.0, 0.0, 0.0), None)
+
+
 def test_image_pipeline_and_output_files(gpu, tmp_path):
     """applyImagePipeline (no filter / post-process) = toSpectrum(splatScale) -> sRGB curve -> RGBCOL; WriteDisplayImage"""
     import struct, zlib
