@@ -521,6 +521,10 @@ class DynamicScene:
         _check(lib.ctl_builder_add_image(self._h, t.ctypes.data_as(C.c_void_p), u32(t.shape[1]), u32(t.shape[0]), u32(texel_type), u32(wrap), u32(filter), C.byref(idx)))
         return idx.value
 
+    def set_bvh_mode(self, mode):
+        """mesh BVH builder for the following add_mesh calls: "auto" (default), "sbvh" (the reference's SplitBVHBuilder restated) or "binned"."""
+        _check(lib.ctl_builder_set_bvh_mode(self._h, u32({"auto": 0, "sbvh": 1, "binned": 2}[mode])))
+
     def add_material(self, material):
         """register the nested BSDF of a coating / roughcoating / blend; returns its absolute material index"""
         idx = u32()

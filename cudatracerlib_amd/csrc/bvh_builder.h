@@ -32,6 +32,10 @@ struct bvh_result {
 // one-leaf mesh (SplitBVHBuilder.cpp:176-189).  max_depth_limit bounds the traversal stack.
 void build_bvh(const std::vector<aabb>& prim_boxes, int max_leaf, bool wrap_single_leaf, int max_depth_limit, bvh_result& out);
 
+// The reference's mesh build restated (sbvh_builder.cpp): SplitBVHBuilder with spatial splits over the triangles
+// (positions[3 * n_vert], indices[3 * n_tri] or nullptr for a soup).  leaf_prims may name a triangle more than once.
+void build_sbvh(const float* positions, const uint32_t* indices, uint32_t n_tri, int max_leaf, bvh_result& out);
+
 } // namespace ctl
 
 namespace ctl {

@@ -46,6 +46,7 @@ int ctl_builder_add_mesh(ctl_builder* b, const float* positions, uint32_t n_vert
     CTL_REQUIRE(b, "null builder");
     CTL_TRY uint32_t i = b->b.add_mesh(positions, n_vert, indices, n_tri, normals, uvs, tri_material, materials, n_mat); if (mesh_index_out) *mesh_index_out = i; CTL_CATCH
 }
+int ctl_builder_set_bvh_mode(ctl_builder* b, uint32_t mode) { CTL_REQUIRE(b && mode <= CTL_BVH_BINNED, "null builder or unknown mode"); b->b.bvh_mode = mode; return CTL_OK; }
 int ctl_builder_add_node(ctl_builder* b, uint32_t mesh_index, const ctl_float4x4* to_world, uint32_t* node_index_out) {
     CTL_REQUIRE(b, "null builder");
     CTL_TRY uint32_t i = b->b.add_node(mesh_index, to_world); if (node_index_out) *node_index_out = i; CTL_CATCH

@@ -4,6 +4,7 @@
 #include "scene_builder.h"
 #include "scene_cache.h"
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include "ctl_math.h"
 #include <cstring>
@@ -125,9 +126,10 @@ uint32_t scene_builder::add_mesh(const float* positions, uint32_t n_vert, const 
     mr.mat_offset = (uint32_t)mesh_materials.size(); mr.n_mat = n_mat;
     mesh_materials.insert(mesh_materials.end(), materials, materials + n_mat);
     // compiled-mesh cache (scene_cache.h; the reference's .xmsh, Engine/Mesh.cpp:46-98): keyed by every input of the compile step
+    const bool use_sbvh = bvh_mode == CTL_BVH_SBVH || (bvh_mode == CTL_BVH_AUTO && n_tri <= kSbvhAutoLimit);
     std::string key;
     if (!cache_dir().empty()) {
-        content_hash H; const uint32_t version = 1, flags = (flip_normals ? 1u : 0u) | (face_normals ? 2u : 0u) | (indices ? 4u : 0u) | (normals ? 8u : 0u) | (uvs ? 16u : 0u) | (tri_material ? 32u : 0u);
+        content_hash H; const uint32_t version = 2, flags = (use_sbvh ? 64u : 0u) |(flip_normals ? 1u : 0u) | (face_normals ? 2u : 0u) | (indices ? 4u : 0u) | (normals ? 8u : 0u) | (uvs ? 16u : 0u) | (tri_material ? 32u : 0u);
         H.add_value(version); H.add_value(flags); H.add_value(n_vert); H.add_value(n_tri); H.add_value(n_mat); H.add_value(max_smooth_angle);
         H.add(positions, (size_t)n_vert * 12);
         if (indices) H.add(indices, (size_t)n_tri * 12);
@@ -178,7 +180,8 @@ uint32_t scene_builder::add_mesh(const float* positions, uint32_t n_vert, const 
     }
     // ConstructBVH (Engine/MeshLoader/BVHBuilderHelper.cpp:116-147): max leaf size 8
     bvh_result R;
-    build_bvh(boxes, 8, true, 44, R);
+    if (use_sbvh) build_sbvh(positions, indices, n_tri, 8, R);   // the reference's own tree: SplitBVHBuilder with spatial splits
+    else build_bvh(boxes, 8, true, 44, R);                        // binned SAH, object splits only, threaded: for meshes the sweep builder takes minutes on
     mr.node_offset = (uint32_t)bvh.size(); mr.n_nodes = (uint32_t)R.nodes.size();
     bvh.insert(bvh.end(), R.nodes.begin(), R.nodes.end());
     mr.woop_offset = (uint32_t)woop.size(); mr.n_woop = (uint32_t)R.leaf_prims.size();
@@ -198,6 +201,13 @@ uint32_t scene_builder::add_mesh(const float* positions, uint32_t n_vert, const 
         }
     }
     return finish_mesh(mr);
+}
+
+uint32_t scene_builder::default_bvh_mode() {
+    const char* e = std::getenv("CTL_BVH_MODE");
+    if (!e) return CTL_BVH_AUTO;
+    const std::string s(e);
+    return s == "sbvh" ? CTL_BVH_SBVH : (s == "binned" ? CTL_BVH_BINNED : CTL_BVH_AUTO);
 }
 
 uint32_t scene_builder::finish_mesh(const mesh_rec& mr) {

@@ -36,6 +36,12 @@ struct scene_builder {
     ctl_sensor camera{};
     bool have_camera = false;
 
+    // mesh BVH builder: CTL_BVH_SBVH = the reference's SplitBVHBuilder restated (sbvh_builder.cpp, identical arrays), CTL_BVH_BINNED = binned
+    // SAH without spatial splits (bvh_builder.cpp, threaded), CTL_BVH_AUTO = SBVH up to kSbvhAutoLimit = 65536 triangles (its sweep sorts the
+    // references three times per node: the reference quotes minutes for San Miguel), binned above.  Default from $CTL_BVH_MODE.
+    static constexpr uint32_t kSbvhAutoLimit = 1u << 16;
+    uint32_t bvh_mode = default_bvh_mode();
+    static uint32_t default_bvh_mode();
     uint32_t finish_mesh(const mesh_rec& mr);   // registers a compiled (or cache-loaded) mesh, returns its index
     uint32_t add_mesh(const float* positions, uint32_t n_vert, const uint32_t* indices, uint32_t n_tri, const float* normals, const float* uvs,
                       const uint8_t* tri_material, const ctl_material* materials, uint32_t n_mat,

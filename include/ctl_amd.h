@@ -253,6 +253,12 @@ void ctl_builder_destroy(ctl_builder* b);
 int ctl_builder_add_mesh(ctl_builder* b, const float* positions, uint32_t n_vert, const uint32_t* indices, uint32_t n_tri,
                          const float* normals, const float* uvs, const uint8_t* tri_material,
                          const ctl_material* materials, uint32_t n_mat, uint32_t* mesh_index_out);
+/* Which builder ctl_builder_add_mesh uses from now on.  CTL_BVH_SBVH: the reference's SplitBVHBuilder restated
+ * (Engine/SpatialStructures/BVH/SplitBVHBuilder.cpp:219-640 through ConstructBVH) — the same node / Woop / index arrays element for
+ * element.  CTL_BVH_BINNED: binned SAH, object splits only, threaded.  CTL_BVH_AUTO (default; or $CTL_BVH_MODE = sbvh | binned):
+ * SBVH for meshes of up to 65536 triangles, binned above. */
+enum { CTL_BVH_AUTO = 0, CTL_BVH_SBVH = 1, CTL_BVH_BINNED = 2 };
+int ctl_builder_set_bvh_mode(ctl_builder* b, uint32_t mode);
 /* DynamicScene::CreateNode + SetNodeTransform (DynamicScene.cpp:269-346): one instance of a mesh. */
 int ctl_builder_add_node(ctl_builder* b, uint32_t mesh_index, const ctl_float4x4* to_world, uint32_t* node_index_out);
 /* DynamicScene::CreateLight(node, matName, L) (DynamicScene.cpp:689-711): all triangles of the node whose local

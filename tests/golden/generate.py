@@ -125,6 +125,22 @@ def main():
         p = (px[i] * [w, h]).astype(np.float32); px[i] = p
         r.ref_sensor_sample_ray(tw[i].ctypes.data, f32(fov), f32(1e-2), f32(1e4), w, h, f32(p[0]), f32(p[1]), out[i, :3].ctypes.data, out[i, 3:].ctypes.data)
     np.savez_compressed(os.path.join(HERE, "sensor.npz"), to_world=tw, params=par, pixel=px, ray=out)
+    # ---- ConstructBVH = SplitBVHBuilder with spatial splits (Engine/MeshLoader/BVHBuilderHelper.cpp:116-127): the reference's node,
+    #      Woop and index arrays for a few small meshes (inputs are regenerated by tests/test_sbvh.py::sbvh_cases from the same seeds)
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    from test_sbvh import sbvh_cases
+    out = {}
+    for name, (V, F) in sbvh_cases().items():
+        V = np.ascontiguousarray(V, np.float32); F = np.ascontiguousarray(F, np.uint32)
+        nn, nt = C.c_uint32(), C.c_uint32()
+        r.ref_construct_bvh(V.ctypes.data, F.ctypes.data, len(V), F.size, C.byref(nn), C.byref(nt))
+        nodes = np.zeros((nn.value, 16), np.uint32); tris = np.zeros((nt.value, 12), np.uint32); idx = np.zeros(nt.value, np.uint32)
+        r.ref_construct_bvh_fetch(nodes.ctypes.data, tris.ctypes.data, idx.ctypes.data)
+        n_entries = nt.value - 2                                  # the callback allocates two spare entries (BVHBuilderHelper.cpp:34-39)
+        n_nodes = max(1, nn.value - 2) if n_entries else 0        # a one-leaf mesh uses one of the spare nodes for its (leaf, none) root
+        out[name + "_V"] = V; out[name + "_F"] = F
+        out[name + "_nodes"] = nodes[:n_nodes]; out[name + "_woop"] = tris[:n_entries]; out[name + "_index"] = idx[:n_entries]
+    np.savez_compressed(os.path.join(HERE, "sbvh.npz"), **out)
     print("golden fixtures written to", HERE)
 
 
