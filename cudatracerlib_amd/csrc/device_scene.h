@@ -8,7 +8,7 @@ namespace ctl {
 
 constexpr int kExitMarker = 0x76543211;   // traversal-stack marker: leave the current instance (> kSentinel as unsigned)
 // feature bits of the shade kernel builds (CTL_SHADE_FEATURES in shading.h)
-enum { kShadeMoreBsdfs = 1, kShadeRoughBsdfs = 2, kShadeImageTextures = 4, kShadeMoreLights = 8, kShadeNestingBsdfs = 16, kShadeSurfaceMaps = 32 };
+enum { kShadeMoreBsdfs = 1, kShadeRoughBsdfs = 2, kShadeImageTextures = 4, kShadeMoreLights = 8, kShadeNestingBsdfs = 16, kShadeSurfaceMaps = 32, kShadeMoreMicrofacet = 64 };
 constexpr int kStackSize = 96;            // two-level: top depth + bottom depth + markers; 4-wide flat tree: 3 * depth + 1 — both checked at upload
 
 // precomputed PerspectiveSensor state (SceneTypes/Sensor.cu:76-96)

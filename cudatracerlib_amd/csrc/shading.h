@@ -7,7 +7,7 @@
 // Feature set compiled into the shading functions of this translation unit (bits = kShade* of device_scene.h).  The shade
 // kernel is built twice (shade_basic.hip: 0, shade_full.hip: all); everything else uses the full set.
 #ifndef CTL_SHADE_FEATURES
-#define CTL_SHADE_FEATURES 0x3F
+#define CTL_SHADE_FEATURES 0x7F
 #endif
 
 namespace ctl {
@@ -123,10 +123,53 @@ __device__ __forceinline__ void sample_normal_map(const ctl_material& mat, diff_
 #endif
 __device__ __forceinline__ float avg3(f3 s) { float r = s.x; r += s.y; r += s.z; return r * (1.0f / 3); }   // Spectrum.h:180-190
 
-// ---- microfacet distribution (Engine/MicrofacetDistribution.{h,cu}); Beckmann + GGX
+#if CTL_SHADE_FEATURES & 64
+// math::erfinv / math::erf (Math/MathFunc.h:343-393)
+__device__ __forceinline__ float erfinv_ref(float x) {
+    float w = -logf((1.0f - x) * (1.0f + x)), p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f; p = 3.43273939e-07f + p * w; p = -3.5233877e-06f + p * w; p = -4.39150654e-06f + p * w; p = 0.00021858087f + p * w;
+        p = -0.00125372503f + p * w; p = -0.00417768164f + p * w; p = 0.246640727f + p * w; p = 1.50140941f + p * w;
+    } else {
+        w = sqrtf(w) - 3;
+        p = -0.000200214257f; p = 0.000100950558f + p * w; p = 0.00134934322f + p * w; p = -0.00367342844f + p * w; p = 0.00573950773f + p * w;
+        p = -0.0076224613f + p * w; p = 0.00943887047f + p * w; p = 1.00167406f + p * w; p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+__device__ __forceinline__ float erf_ref(float x) {
+    const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+    const float sign = copysign_bits(1.0f, x);
+    x = fabsf(x);
+    const float t = 1.0f / (1.0f + p * x);
+    return sign * (1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * expf(-x * x));
+}
+#endif
+
+// ---- microfacet distribution (Engine/MicrofacetDistribution.{h,cu}).  Beckmann (full-distribution sampling) and GGX are always built;
+// visible-normal sampling of Beckmann and the Phong distribution come with feature bit 64 (kShadeMoreMicrofacet)
 struct microfacet {
     int type; float aU, aV; bool vis;
+#if CTL_SHADE_FEATURES & 64
+    float eU = 0, eV = 0;   // computePhongExponent (MicrofacetDistribution.h)
+    __device__ __forceinline__ microfacet(int t, float u, float v, bool sv) : type(t), aU(max2(u, 1e-4f)), aV(max2(v, 1e-4f)), vis(sv) {
+        if (t == CTL_MF_PHONG) { eU = max2(2.0f / (aU * aU) - 2.0f, 0.0f); eV = max2(2.0f / (aV * aV) - 2.0f, 0.0f); }
+    }
+    __device__ float interp_phong_exp(f3 v) const {
+        const float s2 = sin_theta2(v);
+        if (iso() || s2 <= 2.93873587705571876e-39f) return eU;
+        const float is2 = 1 / s2;
+        return eU * (v.x * v.x * is2) + eV * (v.y * v.y * is2);
+    }
+    __device__ void sample_first_quadrant(float u1, float& phi, float& exponent) const {   // MicrofacetDistribution.h:161-170
+        phi = atanf(sqrtf((eU + 2.0f) / (eV + 2.0f)) * tanf(kPi * u1 * 0.5f));
+        float sp, cp; sincosf(phi, &sp, &cp);
+        exponent = eU * cp * cp + eV * sp * sp;
+    }
+#else
     __device__ __forceinline__ microfacet(int t, float u, float v, bool sv) : type(t), aU(max2(u, 1e-4f)), aV(max2(v, 1e-4f)), vis(sv) {}
+#endif
     __device__ __forceinline__ bool iso() const { return aU == aV; }
     __device__ float eval(f3 m) const {   // MicrofacetDistribution.cu:6-42
         if (cos_theta(m) <= 0) return 0.0f;
@@ -134,6 +177,9 @@ struct microfacet {
         const float be = ((m.x * m.x) / (aU * aU) + (m.y * m.y) / (aV * aV)) / c2;
         float result;
         if (type == CTL_MF_BECKMANN) result = expf(-be) / (kPi * aU * aV * c2 * c2);
+#if CTL_SHADE_FEATURES & 64
+        else if (type == CTL_MF_PHONG) result = sqrtf((eU + 2) * (eV + 2)) * kInvTwoPi * powf(cos_theta(m), interp_phong_exp(m));
+#endif
         else { const float root = (1 + be) * c2; result = 1.0f / (kPi * aU * aV * root * root); }
         if (result < 1e-20f) result = 0;
         return result;
@@ -166,6 +212,22 @@ struct microfacet {
     __device__ float pdf(f3 wi, f3 m) const { return vis ? pdf_visible(wi, m) : eval(m) * cos_theta(m); }
     __device__ f3 sample_all(f2 s, float& pdf_) const {   // MicrofacetDistribution.cu:44-149
         float cosThetaM, sinPhiM, cosPhiM, alphaSqr;
+#if CTL_SHADE_FEATURES & 64
+        if (type == CTL_MF_PHONG) {   // :108-137
+            float phiM, exponent;
+            if (iso()) { phiM = (2.0f * kPi) * s.y; exponent = eU; }
+            else if (s.y < 0.25f) sample_first_quadrant(4 * s.y, phiM, exponent);
+            else if (s.y < 0.5f) { sample_first_quadrant(4 * (0.5f - s.y), phiM, exponent); phiM = kPi - phiM; }
+            else if (s.y < 0.75f) { sample_first_quadrant(4 * (s.y - 0.5f), phiM, exponent); phiM += kPi; }
+            else { sample_first_quadrant(4 * (1 - s.y), phiM, exponent); phiM = 2 * kPi - phiM; }
+            sincosf(phiM, &sinPhiM, &cosPhiM);
+            cosThetaM = powf(s.x, 1.0f / (exponent + 2.0f));
+            pdf_ = sqrtf((eU + 2.0f) * (eV + 2.0f)) * kInvTwoPi * powf(cosThetaM, exponent + 1.0f);
+            if (pdf_ < 1e-20f) pdf_ = 0;
+            const float sinThetaP = sqrtf(max2(0.0f, 1 - cosThetaM * cosThetaM));
+            return f3(sinThetaP * cosPhiM, sinThetaP * sinPhiM, cosThetaM);
+        }
+#endif
         if (iso()) { sincosf((2.0f * kPi) * s.y, &sinPhiM, &cosPhiM); alphaSqr = aU * aU; }
         else {
             const float phiM = atanf(aV / aU * tanf(kPi + 2 * kPi * s.y)) + kPi * floorf(2 * s.y + 0.5f);
@@ -187,7 +249,30 @@ struct microfacet {
         const float sinThetaM = sqrtf(max2(0.0f, 1 - cosThetaM * cosThetaM));
         return f3(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
     }
-    __device__ f2 sample_visible11(float thetaI, f2 s) const {   // MicrofacetDistribution.cu:185-307, GGX branch
+    __device__ f2 sample_visible11(float thetaI, f2 s) const {   // MicrofacetDistribution.cu:185-307
+#if CTL_SHADE_FEATURES & 64
+        if (type == CTL_MF_BECKMANN) {   // :191-256: Newton / bisection on the CDF in the erf domain
+            const float SQRT_PI_INV = 1 / sqrtf(kPi);
+            if (thetaI < 1e-4f) { const float r = sqrtf(-logf(1.0f - s.x)); float sp, cp; sincosf(2 * kPi * s.y, &sp, &cp); return f2{ r * cp, r * sp }; }
+            const float tanThetaI = tanf(thetaI), cotThetaI = 1 / tanThetaI;
+            float a = -1, c = erf_ref(cotThetaI);
+            const float sample_x = max2(s.x, 1e-6f);
+            const float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+            float b = c - (1 + c) * powf(1 - sample_x, fit);
+            const float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+            int it = 0;
+            while (++it < 10) {
+                if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+                const float invErf = erfinv_ref(b);
+                const float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * expf(-invErf * invErf)) - sample_x;
+                const float derivative = normalization * (1 - invErf * tanThetaI);
+                if (fabsf(value) < 1e-5f) break;
+                if (value > 0) c = b; else a = b;
+                b -= value / derivative;
+            }
+            return f2{ erfinv_ref(b), erfinv_ref(2.0f * max2(s.y, 1e-6f) - 1.0f) };
+        }
+#endif
         if (thetaI < 1e-4f) { const float r = safe_sqrt(s.x / (1 - s.x)); float sp, cp; sincosf(2 * kPi * s.y, &sp, &cp); return f2{ r * cp, r * sp }; }
         const float tanThetaI = tanf(thetaI), a = 1 / tanThetaI;
         const float G1 = 2.0f / (1.0f + safe_sqrt(1.0f + 1.0f / (a * a)));

@@ -123,6 +123,11 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
         for (int k = 0; k < 4; k++) if (d.materials[i].tex[k].type == CTL_TEX_IMAGE) S.shade_features |= kShadeImageTextures;
         if (d.materials[i].map_kind != CTL_MAP_NONE) S.shade_features |= kShadeSurfaceMaps | kShadeImageTextures;
         if (d.materials[i].alpha_state != CTL_ALPHA_DISABLED) S.alpha_maps = 1;
+        // visible-normal sampling of the Beckmann distribution (erf / erfinv iteration) and the Phong distribution live in the full build only
+        if (t == CTL_BSDF_ROUGHCONDUCTOR || t == CTL_BSDF_ROUGHDIELECTRIC || t == CTL_BSDF_ROUGHPLASTIC || t == CTL_BSDF_ROUGHCOATING) {
+            const uint32_t dist = t == CTL_BSDF_ROUGHPLASTIC ? d.materials[i].u[2] : d.materials[i].u[0], vis = d.materials[i].u[1];
+            if (dist == CTL_MF_PHONG || (dist == CTL_MF_BECKMANN && vis)) S.shade_features |= kShadeMoreMicrofacet;
+        }
     }
     for (uint32_t i = 0; i < d.n_lights_buf; i++) {
         const ctl_light& L = d.lights[i];
@@ -152,17 +157,17 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
             }
             if (t == CTL_BSDF_ROUGHCOATING) {
                 const uint32_t slot = d.materials[i].u[0];
-                if (slot > CTL_MF_GGX || !d.rough_transmittance || !d.rough_transmittance[slot].trans) throw std::runtime_error("ctl_scene_create: roughcoating needs the rough-transmittance table of its (Beckmann / GGX) distribution");
+                if (slot > CTL_MF_PHONG || !d.rough_transmittance || !d.rough_transmittance[slot].trans) throw std::runtime_error("ctl_scene_create: roughcoating needs the rough-transmittance table of its distribution");
             }
         }
         if (t == CTL_BSDF_ROUGHPLASTIC) {
             const uint32_t slot = d.materials[i].u[2];
-            if (slot > CTL_MF_GGX) throw std::runtime_error("ctl_scene_create: roughplastic with the Phong distribution has no HIP implementation yet");
+            if (slot > CTL_MF_PHONG) throw std::runtime_error("ctl_scene_create: unknown microfacet distribution");
             if (!d.rough_transmittance || !d.rough_transmittance[slot].trans || !d.rough_transmittance[slot].diff_trans)
                 throw std::runtime_error("ctl_scene_create: roughplastic needs the rough-transmittance table of its distribution (ctl_builder_set_rough_transmittance)");
         }
-        if ((t == CTL_BSDF_ROUGHCONDUCTOR || t == CTL_BSDF_ROUGHDIELECTRIC) && d.materials[i].u[0] > CTL_MF_GGX)
-            throw std::runtime_error("ctl_scene_create: the Phong microfacet distribution has no HIP implementation yet");
+        if ((t == CTL_BSDF_ROUGHCONDUCTOR || t == CTL_BSDF_ROUGHDIELECTRIC) && d.materials[i].u[0] > CTL_MF_PHONG)
+            throw std::runtime_error("ctl_scene_create: unknown microfacet distribution");
         if (!ok)
             throw std::runtime_error("ctl_scene_create: BSDF type " + std::to_string(t) + " has no HIP implementation yet");
     }

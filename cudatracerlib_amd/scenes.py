@@ -137,6 +137,10 @@ def cornell_box(width=256, height=256, glass_sphere=False, extra_materials=False
             i0, n0 = add(api.conductor(eta=(0.14, 0.37, 1.44), k=(3.98, 2.38, 1.6)))
             i1, n1 = add(api.plastic(diffuse_reflectance=(0.2, 0.5, 0.3), int_ior=1.49))
             mats += [api.coating(i0, n0, int_ior=1.4, ext_ior=1.0, thickness=1.0, sigma_a=0.0), api.coating(i1, n1, int_ior=1.6, ext_ior=1.0, thickness=0.5, sigma_a=(0.3, 0.1, 0.1))]
+    elif extra_materials == 11:   # short block anisotropic Beckmann metal sampled from the visible normals, tall block rough glass with the Phong distribution
+        mats += [api.roughconductor(alpha=0.25, alpha_v=0.1, distribution=0, sample_visible=True), api.roughdielectric(alpha=0.2, int_ior=1.5, ext_ior=1.0, distribution=2, sample_visible=False)]
+    elif extra_materials == 12:   # short block Beckmann rough glass from the visible normals, tall block Phong-distribution metal
+        mats += [api.roughdielectric(alpha=0.15, int_ior=1.5, ext_ior=1.0, distribution=0, sample_visible=True), api.roughconductor(alpha=0.2, alpha_v=0.35, distribution=2, sample_visible=False)]
     elif extra_materials == 7:    # short block fast-approximation Oren-Nayar, tall block original Ward
         mats += [api.roughdiffuse((0.7, 0.5, 0.2), alpha=0.6, use_fast_approx=True), api.ward((0.2, 0.4, 0.3), (0.3, 0.3, 0.3), alpha_u=0.15, alpha_v=0.15, variant=0)]
     elif extra_materials:

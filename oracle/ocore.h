@@ -625,6 +625,28 @@ inline float hypot2(float a, float b) {   // Math/MathFunc.h:326-341
     else r = 0.0f;
     return r;
 }
+// math::erfinv / math::erf (Math/MathFunc.h:343-393): Giles' single-precision polynomial, A&S 7.1.26
+inline float erfinvRef(float x) {
+    float w = -logf((1.0f - x) * (1.0f + x)), p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f; p = 3.43273939e-07f + p * w; p = -3.5233877e-06f + p * w; p = -4.39150654e-06f + p * w; p = 0.00021858087f + p * w;
+        p = -0.00125372503f + p * w; p = -0.00417768164f + p * w; p = 0.246640727f + p * w; p = 1.50140941f + p * w;
+    } else {
+        w = std::sqrt(w) - 3;
+        p = -0.000200214257f; p = 0.000100950558f + p * w; p = 0.00134934322f + p * w; p = -0.00367342844f + p * w; p = 0.00573950773f + p * w;
+        p = -0.0076224613f + p * w; p = 0.00943887047f + p * w; p = 1.00167406f + p * w; p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+inline float erfRef(float x) {
+    const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+    const float sign = copysignf(1.0f, x);
+    x = fabsf(x);
+    const float t = 1.0f / (1.0f + p * x);
+    const float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * expf(-x * x);
+    return sign * y;
+}
 struct Microfacet {
     int type; float alphaU, alphaV; bool sampleVis; float expU = 0, expV = 0;
     Microfacet(int t, float aU, float aV, bool sv) : type(t), alphaU(fmax2(aU, 1e-4f)), alphaV(fmax2(aV, 1e-4f)), sampleVis(sv) {
@@ -669,8 +691,27 @@ struct Microfacet {
     float pdfVisible(V3 wi, V3 m) const { if (Frame::cosTheta(wi) == 0) return 0.0f; return smithG1(wi, m) * absdot(wi, m) * eval(m) / fabsf(Frame::cosTheta(wi)); }
     float pdfAll(V3 m) const { return eval(m) * Frame::cosTheta(m); }
     float pdf(V3 wi, V3 m) const { return sampleVis ? pdfVisible(wi, m) : pdfAll(m); }
-    V3 sampleAll(V2 sample, float& pdf) const {   // MicrofacetDistribution.cu:44-149 (Beckmann / GGX)
+    void sampleFirstQuadrant(float u1, float& phi, float& exponent) const {   // MicrofacetDistribution.h:161-170
+        phi = atanf(std::sqrt((expU + 2.0f) / (expV + 2.0f)) * tanf(PI * u1 * 0.5f));
+        const float sinPhi = sinf(phi), cosPhi = cosf(phi);
+        exponent = expU * cosPhi * cosPhi + expV * sinPhi * sinPhi;
+    }
+    V3 sampleAll(V2 sample, float& pdf) const {   // MicrofacetDistribution.cu:44-149
         float cosThetaM = 0.0f, sinPhiM, cosPhiM, alphaSqr;
+        if (type == CTL_MF_PHONG) {   // :108-137
+            float phiM, exponent;
+            if (isIso()) { phiM = (2.0f * PI) * sample.y; exponent = expU; }
+            else if (sample.y < 0.25f) sampleFirstQuadrant(4 * sample.y, phiM, exponent);
+            else if (sample.y < 0.5f) { sampleFirstQuadrant(4 * (0.5f - sample.y), phiM, exponent); phiM = PI - phiM; }
+            else if (sample.y < 0.75f) { sampleFirstQuadrant(4 * (sample.y - 0.5f), phiM, exponent); phiM += PI; }
+            else { sampleFirstQuadrant(4 * (1 - sample.y), phiM, exponent); phiM = 2 * PI - phiM; }
+            sinPhiM = sinf(phiM); cosPhiM = cosf(phiM);
+            cosThetaM = powf(sample.x, 1.0f / (exponent + 2.0f));
+            pdf = std::sqrt((expU + 2.0f) * (expV + 2.0f)) * INV_TWOPI * powf(cosThetaM, exponent + 1.0f);
+            if (pdf < 1e-20f) pdf = 0;
+            float sinThetaP = std::sqrt(fmax2(0.0f, 1 - cosThetaM * cosThetaM));
+            return V3(sinThetaP * cosPhiM, sinThetaP * sinPhiM, cosThetaM);
+        }
         if (isIso()) { float a = (2.0f * PI) * sample.y; sinPhiM = sinf(a); cosPhiM = cosf(a); alphaSqr = alphaU * alphaU; }
         else {
             float phiM = atanf(alphaV / alphaU * tanf(PI + 2 * PI * sample.y)) + PI * floorf(2 * sample.y + 0.5f);
@@ -692,8 +733,31 @@ struct Microfacet {
         float sinThetaM = std::sqrt(fmax2(0.0f, 1 - cosThetaM * cosThetaM));
         return V3(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
     }
-    V2 sampleVisible11(float thetaI, V2 sample) const {   // MicrofacetDistribution.cu:185-307 (GGX branch)
+    V2 sampleVisible11(float thetaI, V2 sample) const {   // MicrofacetDistribution.cu:185-307
         V2 slope;
+        if (type == CTL_MF_BECKMANN) {   // :191-256: Newton / bisection on the CDF in the erf domain
+            const float SQRT_PI_INV = 1 / std::sqrt(PI);
+            if (thetaI < 1e-4f) { float r = std::sqrt(-logf(1.0f - sample.x)); float a = 2 * PI * sample.y; return V2{ r * cosf(a), r * sinf(a) }; }
+            float tanThetaI = tanf(thetaI), cotThetaI = 1 / tanThetaI;
+            float a = -1, c = erfRef(cotThetaI);
+            float sample_x = sample.x > 1e-6f ? sample.x : 1e-6f;
+            float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+            float b = c - (1 + c) * powf(1 - sample_x, fit);
+            float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+            int it = 0;
+            while (++it < 10) {
+                if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+                float invErf = erfinvRef(b);
+                float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * expf(-invErf * invErf)) - sample_x;
+                float derivative = normalization * (1 - invErf * tanThetaI);
+                if (fabsf(value) < 1e-5f) break;
+                if (value > 0) c = b; else a = b;
+                b -= value / derivative;
+            }
+            slope.x = erfinvRef(b);
+            slope.y = erfinvRef(2.0f * (sample.y > 1e-6f ? sample.y : 1e-6f) - 1.0f);
+            return slope;
+        }
         if (thetaI < 1e-4f) {
             float r = safe_sqrt(sample.x / (1 - sample.x)); float a = 2 * PI * sample.y;
             return V2{ r * cosf(a), r * sinf(a) };

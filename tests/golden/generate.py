@@ -103,9 +103,9 @@ def main():
     n = 512
     wi = rs.normal(size=(n, 3)).astype(np.float32); wi[:, 2] = np.abs(wi[:, 2]) + 0.05; wi /= np.linalg.norm(wi, axis=1, keepdims=True)
     m = rs.normal(size=(n, 3)).astype(np.float32); m[:, 2] = np.abs(m[:, 2]) + 0.2; m /= np.linalg.norm(m, axis=1, keepdims=True)
-    cfg = np.stack([rs.randint(0, 2, n), rs.randint(0, 2, n)], axis=1).astype(np.int32)   # type, sampleVisible
+    cfg = np.stack([rs.randint(0, 3, n), rs.randint(0, 2, n)], axis=1).astype(np.int32)   # type (Beckmann, GGX, Phong), sampleVisible
     alpha = rs.uniform(0.02, 0.6, size=(n, 2)).astype(np.float32); alpha[::2, 1] = alpha[::2, 0]
-    cfg[(cfg[:, 0] == 0), 1] = 0   # Beckmann visible sampling needs erfinv: not on this path's configs, excluded
+    cfg[(cfg[:, 0] == 2), 1] = 0   # MicrofacetDistribution::getSampleVisible: Phong never samples visible normals (MicrofacetDistribution.h:45-48)
     ev = np.zeros((n, 3), np.float32); sm = np.zeros((n, 4), np.float32); su = rs.uniform(0.01, 0.99, size=(n, 2)).astype(np.float32)
     for i in range(n):
         r.ref_microfacet_eval(int(cfg[i, 0]), f32(alpha[i, 0]), f32(alpha[i, 1]), int(cfg[i, 1]), wi[i].ctypes.data, m[i].ctypes.data, ev[i].ctypes.data)

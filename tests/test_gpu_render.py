@@ -67,10 +67,11 @@ def test_cornell_coating_roughcoating_blend(gpu, orc, variant):
     assert_close(got, want)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 11, 12])
 def test_cornell_plastic_roughdielectric_phong_thindielectric(gpu, orc, variant):
     """2: plastic + GGX rough glass, 3: phong + thin glass, 4: nonlinear plastic + anisotropic Beckmann rough glass,
-    5: Oren-Nayar + balanced Ward, 6: Beckmann / GGX rough plastic (rough-transmittance tables), 7: fast Oren-Nayar + Ward"""
+    5: Oren-Nayar + balanced Ward, 6: Beckmann / GGX rough plastic (rough-transmittance tables), 7: fast Oren-Nayar + Ward,
+    11 / 12: Beckmann sampled from the visible normals (erf / erfinv iteration) and the Phong microfacet distribution"""
     sc = scenes.cornell_box(64, 64, extra_materials=variant)
     got, want, tr, rays = render_pair(gpu, orc, sc, 64, 64, 3)
     assert_close(got, want)

@@ -59,6 +59,9 @@ MODELS = {
     "diffuse": lambda: api.diffuse((1, 1, 1)),
     "roughconductor_ggx_vis": lambda: api.roughconductor(alpha=0.2, distribution=1, sample_visible=True),
     "roughconductor_beck": lambda: api.roughconductor(alpha=0.3, distribution=0, sample_visible=False),
+    "roughconductor_beck_vis_aniso": lambda: api.roughconductor(alpha=0.25, alpha_v=0.1, distribution=0, sample_visible=True),   # what <string name="distribution" value="beckmann"/> loads as
+    "roughconductor_phong": lambda: api.roughconductor(alpha=0.2, alpha_v=0.35, distribution=2, sample_visible=False),
+    "roughdielectric_beck_vis": lambda: api.roughdielectric(alpha=0.2, int_ior=1.5, ext_ior=1.0, distribution=0, sample_visible=True),
     "roughdielectric_ggx_vis": lambda: api.roughdielectric(alpha=0.15, int_ior=1.5, ext_ior=1.0, distribution=1, sample_visible=True),
     "roughdielectric_beck": lambda: api.roughdielectric(alpha=0.3, int_ior=1.33, ext_ior=1.0, distribution=0, sample_visible=False),
     "roughdielectric_aniso": lambda: api.roughdielectric(alpha=0.3, alpha_v=0.1, int_ior=1.5, ext_ior=1.0, distribution=1, sample_visible=True),
