@@ -16,7 +16,7 @@ __device__ __forceinline__ f3 plastic_diffuse(const ctl_material& M, const diff_
 }
 __device__ __forceinline__ microfacet rough_dielectric_distr(const ctl_material& M, const diff_geom& dg, float cos_wi, bool scaled) {
     microfacet d((int)M.u[0], avg3(tex_eval(M.tex[2], dg)), avg3(tex_eval(M.tex[3], dg)), M.u[1] != 0);
-    if (scaled && !d.vis) { const float sc = 1.2f - 0.2f * sqrtf(fabsf(cos_wi)); d.aU *= sc; d.aV *= sc; }   // scaleAlpha (MicrofacetDistribution.h:60-66)
+    if (scaled && !d.vis) { const float sc = 1.2f - 0.2f * sqrtf(fabsf(cos_wi)); d.scale_alpha(sc); }   // scaleAlpha (MicrofacetDistribution.h:60-66)
     return d;
 }
 

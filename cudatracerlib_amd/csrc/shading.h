@@ -170,6 +170,12 @@ struct microfacet {
 #else
     __device__ __forceinline__ microfacet(int t, float u, float v, bool sv) : type(t), aU(max2(u, 1e-4f)), aV(max2(v, 1e-4f)), vis(sv) {}
 #endif
+    __device__ __forceinline__ void scale_alpha(float v) {   // MicrofacetDistribution.h:61-67
+        aU *= v; aV *= v;
+#if CTL_SHADE_FEATURES & 64
+        if (type == CTL_MF_PHONG) { eU = max2(2.0f / (aU * aU) - 2.0f, 0.0f); eV = max2(2.0f / (aV * aV) - 2.0f, 0.0f); }
+#endif
+    }
     __device__ __forceinline__ bool iso() const { return aU == aV; }
     __device__ float eval(f3 m) const {   // MicrofacetDistribution.cu:6-42
         if (cos_theta(m) <= 0) return 0.0f;

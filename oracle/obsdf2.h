@@ -39,7 +39,7 @@ inline Spec bsdf2Sample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sampl
         const float m_eta = M.f[0], m_invEta = M.f[1]; const bool vis = M.u[1] != 0;
         Microfacet distr((int)M.u[0], avg3(texEval(M.tex[2], bRec.dg)), avg3(texEval(M.tex[3], bRec.dg)), vis);
         Microfacet sampleDistr = distr;
-        if (!vis) { float sc = 1.2f - 0.2f * std::sqrt(fabsf(Frame::cosTheta(bRec.wi))); sampleDistr.alphaU *= sc; sampleDistr.alphaV *= sc; }   // scaleAlpha (MicrofacetDistribution.h:60-66)
+        if (!vis) { float sc = 1.2f - 0.2f * std::sqrt(fabsf(Frame::cosTheta(bRec.wi))); sampleDistr.scaleAlpha(sc); }
         float microfacetPDF;
         float sign = signum(Frame::cosTheta(bRec.wi));
         const V3 m = sampleDistr.sample(sign < 0 ? -bRec.wi : bRec.wi, sample, microfacetPDF);
@@ -186,7 +186,7 @@ inline float bsdf2Pdf(const ctl_material& M, const BRec& bRec, int measure) {
         }
         H = H * signum(Frame::cosTheta(H));
         Microfacet sampleDistr((int)M.u[0], avg3(texEval(M.tex[2], bRec.dg)), avg3(texEval(M.tex[3], bRec.dg)), vis);
-        if (!vis) { float sc = 1.2f - 0.2f * std::sqrt(fabsf(Frame::cosTheta(bRec.wi))); sampleDistr.alphaU *= sc; sampleDistr.alphaV *= sc; }
+        if (!vis) { float sc = 1.2f - 0.2f * std::sqrt(fabsf(Frame::cosTheta(bRec.wi))); sampleDistr.scaleAlpha(sc); }
         float sign = signum(Frame::cosTheta(bRec.wi));
         float prob = sampleDistr.pdf(sign < 0 ? -bRec.wi : bRec.wi, H);
         if (hasTransmission && hasReflection) { float F = fresnelDielectricExt(dot(bRec.wi, H), m_eta); prob *= reflect ? F : (1 - F); }

@@ -652,6 +652,10 @@ struct Microfacet {
     Microfacet(int t, float aU, float aV, bool sv) : type(t), alphaU(fmax2(aU, 1e-4f)), alphaV(fmax2(aV, 1e-4f)), sampleVis(sv) {
         if (type == CTL_MF_PHONG) { expU = fmax2(2.0f / (alphaU * alphaU) - 2.0f, 0.0f); expV = fmax2(2.0f / (alphaV * alphaV) - 2.0f, 0.0f); }
     }
+    void scaleAlpha(float value) {   // MicrofacetDistribution.h:61-67: the Phong exponents follow the scaled roughness
+        alphaU *= value; alphaV *= value;
+        if (type == CTL_MF_PHONG) { expU = fmax2(2.0f / (alphaU * alphaU) - 2.0f, 0.0f); expV = fmax2(2.0f / (alphaV * alphaV) - 2.0f, 0.0f); }
+    }
     bool isIso() const { return alphaU == alphaV; }
     float interpPhongExp(V3 v) const {   // MicrofacetDistribution.h interpolatePhongExponent
         const float sinTheta2 = Frame::sinTheta2(v);
