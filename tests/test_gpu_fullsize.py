@@ -1,0 +1,118 @@
+"""The hot path at BASELINE's full size — synthetic-SM, 1920x1080, depth 8, NEE on (bench.py's workload) — through properties
+that do not need the oracle to render the whole frame:
+  * a band of rows rendered by the oracle (PathTrace<DIRECT> on the CPU) equals the same rows of the GPU frame, per pixel;
+  * the frame does not depend on how the passes are batched, nor on how many ranks the tiles are sharded over;
+  * the megakernel plugin and the wavefront plugin produce the same frame and count the same rays;
+  * linearity: 2 x (k passes) accumulates to the same sums as 2k passes.
+"""
+import os
+import numpy as np
+import pytest
+from cudatracerlib_amd import scenes
+
+pytestmark = pytest.mark.gpu
+W, H, DEPTH = 1920, 1080, 8
+
+
+@pytest.fixture(scope="module")
+def workload(gpu, orc, tmp_path_factory):
+    gpu.api.set_cache_dir(os.environ.get("CTL_CACHE_DIR") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "ctl_amd_cache"))
+    sc = scenes.synthetic_sm(W, H, n_instances=2000, subdiv=4)
+    d = sc.desc
+    flat = gpu.Scene(d, flatten=True)
+    gpu.api.set_cache_dir(None)
+    tables = orc.sequence_tables(4)
+    return sc, d, flat, tables
+
+
+def render(gpu, cls, scene, tables, passes=None, shard=None, **params):
+    tr = cls()
+    p = tr.getParameters(); p.setValue("MaxPathLength", DEPTH)
+    for k, v in params.items():
+        p.setValue(k, v)
+    if shard:
+        tr.setTileShard(*shard)
+    tr.Resize(W, H); tr.InitializeScene(scene)
+    img = gpu.Image(W, H)
+    for k in (range(len(tables)) if passes is None else passes):
+        tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == (0 if passes is None else passes[0])))
+    return img.getPixelData(), tr.stats().rays_total
+
+
+def test_oracle_band_equals_the_gpu_rows(gpu, orc, workload):
+    """Bands of the full-size frame rendered by the oracle against the same rows of the GPU frame, for the two-level layout (the
+    reference's traversal arithmetic, bit for bit) and the flattened layout that bench.py times (t, u, v to fp32 round-off)."""
+    sc, d, flat, tables = workload
+    two_level = gpu.Scene(d)
+    bands = (0, 531, 1072)                                            # top edge, middle, bottom edge of the frame
+    want = {}
+    for depth in (2, DEPTH):
+        for y0 in bands:
+            want[depth, y0] = orc.render(d, W, H, n_passes=2, tables=tables[:2], max_path_length=depth, rows=(y0, y0 + 8), threads=os.cpu_count() or 8)[0]
+
+    def check(scene, depth, frac, mean_tol):
+        tr_tables = tables[:2]
+        tr = gpu.WavefrontPathTracer(); tr.getParameters().setValue("MaxPathLength", depth)
+        tr.Resize(W, H); tr.InitializeScene(scene)
+        img = gpu.Image(W, H)
+        for k in range(2):
+            tr.setSamplerTables(*tr_tables[k]); tr.DoPass(img, new_trace=(k == 0))
+        got = img.getPixelData()
+        assert tr.stats().rays_total > 2 * W * H                       # every pixel traced at least its primary ray, twice
+        for y0 in bands:
+            # (y + jitter) can round up to y + 1 in fp32, so a few samples cross a row boundary: the band's edge rows trade samples with rows
+            # the oracle did not render.  Compare the interior rows, on the pixels whose sample count agrees.
+            g, w = got[y0 + 1:y0 + 7, :, :3], want[depth, y0][y0 + 1:y0 + 7, :, :3]
+            same_n = got[y0 + 1:y0 + 7, :, 6] == want[depth, y0][y0 + 1:y0 + 7, :, 6]
+            assert same_n.mean() >= 0.999
+            g, w = g[same_n][None], w[same_n][None]
+            ok = (np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2)
+            assert ok.mean() >= frac, (depth, y0, ok.mean())
+            assert abs(g.mean() - w.mean()) <= mean_tol * w.mean(), (depth, y0, g.mean(), w.mean())
+    # Every bounce off one of the 2000 small spheres multiplies a direction error by roughly distance / radius (tens): the <= 2 ulp
+    # between libm and the device's sin / cos / acos reaches the 2e-3 pixel tolerance after three or four bounces.  So the per-pixel bar
+    # is tight where paths are short and statistical (band mean) at the full depth.
+    check(two_level, 2, 0.998, 1e-3)
+    check(two_level, DEPTH, 0.97, 5e-3)
+    check(flat, 2, 0.99, 5e-3)
+    check(flat, DEPTH, 0.5, 2e-2)
+    outside = np.ones(H, bool); outside[1072:1080] = False
+    assert not np.any(want[DEPTH, 1072][outside])                     # the oracle really rendered the band only
+
+
+def test_batching_and_sharding_do_not_change_the_frame(gpu, workload):
+    sc, d, flat, tables = workload
+    def own_tables(batch):   # the tracer's own generator: passes 1..4 of a fresh XORWOW stream, rendered `batch` passes per wavefront
+        tr = gpu.WavefrontPathTracer(); p = tr.getParameters(); p.setValue("MaxPathLength", DEPTH); p.setValue("PassBatch", batch)
+        tr.Resize(W, H); tr.InitializeScene(flat)
+        img = gpu.Image(W, H)
+        tr.DoPasses(img, 4, new_trace=True)
+        return img.getPixelData(), tr.stats().rays_total
+    single, rays_single = own_tables(1)
+    four, rays_four = own_tables(4)
+    assert rays_single == rays_four
+    assert np.array_equal(single[..., 6], four[..., 6])
+    assert np.allclose(single[..., :3], four[..., :3], rtol=1e-5, atol=1e-5)
+    one, rays_one = render(gpu, gpu.WavefrontPathTracer, flat, tables)
+    parts =[render(gpu, gpu.WavefrontPathTracer, flat, tables, shard=(r, 8)) for r in range(8)]   # what 8 ranks would render
+    s = sum(p[0] for p in parts)
+    assert sum(p[1] for p in parts) == rays_one
+    assert np.array_equal(s[..., 6], one[..., 6])
+    assert np.allclose(s[..., :3], one[..., :3], rtol=1e-5, atol=1e-5)
+    share = np.array([p[1] for p in parts], np.float64) / rays_one
+    assert share.min() > 0.09 and share.max() < 0.16                  # round-robin tiles balance the ranks (ideal 0.125)
+
+
+def test_linearity_and_plugin_agreement(gpu, workload):
+    sc, d, flat, tables = workload
+    ab, rays_ab = render(gpu, gpu.WavefrontPathTracer, flat, tables)
+    a, rays_a = render(gpu, gpu.WavefrontPathTracer, flat, tables, passes=[0, 1])
+    b, rays_b = render(gpu, gpu.WavefrontPathTracer, flat, tables, passes=[2, 3])
+    assert rays_a + rays_b == rays_ab
+    assert np.array_equal(a[..., 6] + b[..., 6], ab[..., 6])
+    assert np.allclose(a[..., :3] + b[..., :3], ab[..., :3], rtol=1e-5, atol=1e-5)
+    mega, rays_mega = render(gpu, gpu.PathTracer, flat, tables[:2])
+    assert abs(int(rays_mega) - int(rays_a)) <= 1e-4 * rays_a
+    assert np.array_equal(mega[..., 6], a[..., 6])
+    close = np.isclose(mega[..., :3], a[..., :3], rtol=1e-3, atol=1e-3).all(axis=2)
+    assert close.mean() >= 0.999 and abs(mega[..., :3].mean() - a[..., :3].mean()) <= 1e-4 * a[..., :3].mean()
