@@ -31,8 +31,10 @@ def build_scene(args):
     from cudatracerlib_amd import scenes
     if args.workload == "synthetic-sm":
         return scenes.synthetic_sm(args.width, args.height, n_instances=args.instances, subdiv=args.subdiv)
-    if args.workload == "cornell-glass":
+    if args.workload == "cornell-glass":      # BASELINE configs[1] (quote it with --width 1024 --height 1024)
         return scenes.cornell_box(args.width, args.height, glass_sphere=True)
+    if args.workload == "synthetic-bathroom":  # stand-in for BASELINE configs[4]: rough BSDFs + environment emitter, the shading stress
+        return scenes.synthetic_bathroom(args.width, args.height)
     raise SystemExit("unknown workload " + args.workload)
 
 
@@ -72,7 +74,7 @@ def cpu_baseline(desc, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=64, help="passes = samples per pixel (BASELINE: 64 spp)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="synthetic-sm")
     ap.add_argument("--width", type=int, default=1920)
@@ -81,6 +83,7 @@ def main():
     ap.add_argument("--instances", type=int, default=2000)
     ap.add_argument("--subdiv", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tracer-param", action="append", default=[], metavar="KEY=VALUE")
     ap.add_argument("--no-cache", action="store_true", help="do not use the compiled-geometry cache ($CTL_CACHE_DIR, default $TMPDIR/ctl_amd_cache)")
     ap.add_argument("--flatten", type=int, default=1, help="traverse one world-space BVH over all instanced triangles (64 B of HBM per triangle)")
     args = ap.parse_args()
@@ -115,6 +118,9 @@ def main():
     tr = ctl.WavefrontPathTracer()
     p = tr.getParameters()
     p.setValue("Direct", True); p.setValue("MaxPathLength", args.depth); p.setValue("RRStartDepth", 5)
+    for kv in args.tracer_param:                 # build-specific knobs for A/B runs, e.g. --tracer-param SortMaterials=false
+        k, v = kv.split("=", 1)
+        p.setValue(k, v.lower() == "true" if v.lower() in ("true", "false") else int(v))
     tr.setTileShard(rank, world)
     tr.Resize(args.width, args.height)
     tr.InitializeScene(scene)
@@ -175,7 +181,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mrays/s at 1920x1080 depth-8 (per pass = 1 spp); achieved HBM GB/s vs peak",
+            "metric": "Mrays/s at %dx%dx%dspp depth-%d; achieved HBM GB/s vs peak" % (args.width, args.height, args.steps, args.depth),
             "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

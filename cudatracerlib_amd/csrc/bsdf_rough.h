@@ -144,12 +144,32 @@ __device__ float ward_pdf(const ctl_material& M, const bsdf_rec& b) {   // BSDF_
     return 0.0f;
 }
 
+__device__ __forceinline__ float rough_transmittance_wi(const bsdf_rec& b, uint32_t type, float cosTheta, float alpha, float eta) {
+#if CTL_SHADE_FEATURES & 2
+    if (b.rt_cos == cosTheta && b.rt_alpha == alpha && b.rt_eta == eta && b.rt_type == type) return b.rt_val;
+    const float v = rough_transmittance(b.dg, type, cosTheta, alpha, eta);
+    b.rt_cos = cosTheta; b.rt_alpha = alpha; b.rt_eta = eta; b.rt_type = type; b.rt_val = v;
+    return v;
+#else
+    return rough_transmittance(b.dg, type, cosTheta, alpha, eta);
+#endif
+}
+__device__ __forceinline__ float rough_transmittance_diffuse_memo(const bsdf_rec& b, uint32_t type, float alpha, float eta) {
+#if CTL_SHADE_FEATURES & 2
+    if (b.rtd_alpha == alpha && b.rtd_eta == eta && b.rtd_type == type) return b.rtd_val;
+    const float v = rough_transmittance_diffuse(b.dg, type, alpha, eta);
+    b.rtd_alpha = alpha; b.rtd_eta = eta; b.rtd_type = type; b.rtd_val = v;
+    return v;
+#else
+    return rough_transmittance_diffuse(b.dg, type, alpha, eta);
+#endif
+}
 __device__ __forceinline__ microfacet roughplastic_distr(const ctl_material& M, const diff_geom& dg) {
     const float a = avg3(tex_eval(M.tex[2], dg));
     return microfacet((int)M.u[2], a, a, M.u[1] != 0);
 }
 __device__ __forceinline__ float roughplastic_prob_specular(const ctl_material& M, const bsdf_rec& b, const microfacet& distr) {
-    const float ps = 1 - rough_transmittance(b.dg, M.u[2], cos_theta(b.wi), distr.aU, M.f[0]);
+    const float ps = 1 - rough_transmittance_wi(b, M.u[2], cos_theta(b.wi), distr.aU, M.f[0]);
     return (ps * M.f[2]) / (ps * M.f[2] + (1 - ps) * (1 - M.f[2]));
 }
 __device__ f3 roughplastic_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:948-1005
@@ -167,9 +187,9 @@ __device__ f3 roughplastic_f(const ctl_material& M, const bsdf_rec& b) {   // BS
     }
     if (hd) {
         f3 diff = tex_eval(M.tex[0], b.dg);
-        const float T12 = rough_transmittance(b.dg, M.u[2], cos_theta(b.wi), distr.aU, M.f[0]);
+        const float T12 = rough_transmittance_wi(b, M.u[2], cos_theta(b.wi), distr.aU, M.f[0]);
         const float T21 = rough_transmittance(b.dg, M.u[2], cos_theta(b.wo), distr.aU, M.f[0]);
-        const float Fdr = 1 - rough_transmittance_diffuse(b.dg, M.u[2], distr.aU, M.f[0]);
+        const float Fdr = 1 - rough_transmittance_diffuse_memo(b, M.u[2], distr.aU, M.f[0]);
         if (M.u[0]) diff = diff / (f3(1.0f) - diff * Fdr);
         else diff = diff / (1 - Fdr);
         result = result + diff * (kInvPi * cos_theta(b.wo) * T12 * T21 * M.f[1]);

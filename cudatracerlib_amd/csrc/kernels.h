@@ -34,6 +34,11 @@ struct wave_queues {
     uint32_t* work;            // dynamic-fetch cursors, one per intersect launch of a pass
     unsigned long long* stats; // [0] rays traced (primary + continuation + shadow)
     uint32_t capacity;
+    // material sort of the shading queue (scenes that need the full shade kernel): path slots grouped by BSDF model, so that the 64 lanes of
+    // a wave run one model's code instead of all of them
+    uint32_t* order;           // [capacity] path slots in shading order
+    unsigned char* mat_key;    // [capacity] BSDF model of the hit (0 = miss)
+    uint32_t* mat_counts;      // [depth * 32 + k]: k < 16 paths per model, 16 + k scatter cursors
 };
 
 struct pass_params {
@@ -43,6 +48,7 @@ struct pass_params {
     uint32_t tile_rank, tile_world;      // image-tile shard: tiles t with t % world == rank
     uint32_t n_local_pixels;             // pixels rendered by this rank
     int direct, max_path_length, rr_start_depth;
+    int sort_materials;                  // shade in wave_queues::order
 };
 
 struct launch_ctx { hipStream_t stream; int grid_blocks; bool alpha_test = false; };   // alpha_test: intersect kernels run Material::AlphaTest on candidate hits

@@ -142,11 +142,55 @@ void launch_intersect_count(const launch_ctx& lc, const dev_scene& S, const floa
     if (any_hit) CTL_LAUNCH_INTERSECT(true, true, S, ro, rd, n_ptr, work, hit, hit_node, occ, counts3);
     else CTL_LAUNCH_INTERSECT(false, true, S, ro, rd, n_ptr, work, hit, hit_node, (uint32_t*)nullptr, counts3);
 }
+// ---- material sort: counting sort of the path slots by the BSDF model they hit (16 buckets), between intersection and shading
+__global__ __launch_bounds__(kBlock) void k_mat_count(dev_scene S, wave_queues Q, int depth) {
+    __shared__ uint32_t h[16];
+    if (threadIdx.x < 16) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n = Q.counts[(depth - 1) * 4 + 0];
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int tri = __float_as_int(Q.hit[i].w);
+        uint32_t key = 0;
+        if (tri >= 0) key = S.mats[S.node_info[Q.hit_node[i]].x + tri_mat_index(S, tri)].bsdf_type & 15u;
+        Q.mat_key[i] = (unsigned char)key;
+        atomicAdd(&h[key], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && h[threadIdx.x]) atomicAdd(&Q.mat_counts[depth * 32 + threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(kBlock) void k_mat_scatter(wave_queues Q, int depth) {
+    __shared__ uint32_t base[16];
+    if (threadIdx.x == 0) { uint32_t s = 0; for (int k = 0; k < 16; k++) { base[k] = s; s += Q.mat_counts[depth * 32 + k]; } }
+    __syncthreads();
+    const uint32_t n = Q.counts[(depth - 1) * 4 + 0];
+    const uint32_t n_round = (n + 63u) & ~63u;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
+        const bool active = i < n;
+        const uint32_t key = active ? Q.mat_key[i] : 0xffu;
+        unsigned long long todo = __ballot(active);
+        while (todo) {   // one atomic per model present in the wave
+            const int leader = (int)__builtin_ctzll(todo);
+            const uint32_t k = (uint32_t)__shfl((int)key, leader, 64);
+            const unsigned long long mine = __ballot(active && key == k);
+            uint32_t first = 0;
+            if (lane == leader) first = atomicAdd(&Q.mat_counts[depth * 32 + 16 + k], (uint32_t)__popcll(mine));
+            first = (uint32_t)__shfl((int)first, leader, 64);
+            if (active && key == k) Q.order[base[k] + first + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = i;
+            todo &= ~mine;
+        }
+    }
+}
+
 // the shade kernel exists in feature-specialised builds (shade_basic.hip / shade_full.hip): a scene that uses only the basic
 // material / light / texture set runs the variant whose code does not carry the registers of the rest (dev_scene::shade_features)
 void launch_shade(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image) {
-    if (S.shade_features == 0) launch_shade_basic(lc, S, Q, P, depth, image);
-    else launch_shade_full(lc, S, Q, P, depth, image);
+    if (S.shade_features == 0) { launch_shade_basic(lc, S, Q, P, depth, image); return; }
+    if (P.sort_materials) {
+        hipLaunchKernelGGL(k_mat_count, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, Q, depth);
+        hipLaunchKernelGGL(k_mat_scatter, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, Q, depth);
+    }
+    launch_shade_full(lc, S, Q, P, depth, image);
 }
 void launch_finalize(const launch_ctx& lc, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image) {
     hipLaunchKernelGGL(k_finalize, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, Q, P, depth, image);

@@ -312,7 +312,15 @@ __device__ __forceinline__ f3 reflect_about(f3 wi, f3 n) { return normalize(2 * 
 
 // ---- BSDFs (SceneTypes/BSDF_Simple.cu) in the local shading frame
 enum { kESmooth = 0x2 | 0x4 | 0x8 | 0x10, kEDelta = 0x1 | 0x20 | 0x40, kEAll = 0x1ff };
-struct bsdf_rec { diff_geom dg; f3 wi, wo; float eta; uint32_t type_mask, sampled_type; };
+struct bsdf_rec {
+    diff_geom dg; f3 wi, wo; float eta; uint32_t type_mask, sampled_type;
+#if CTL_SHADE_FEATURES & 2
+    // RoughTransmittanceManager lookups for the incident direction, memoised per vertex: sample, f and pdf of a rough plastic (and the NEE
+    // evaluation that follows) ask for T(cos wi, alpha, eta) five times and for the diffuse table twice; each is a 64-tap spline lookup.
+    // Keyed by the arguments, so a nested BSDF evaluated with another wi or another table simply misses.
+    mutable float rt_cos = -2.0f, rt_alpha = 0, rt_eta = 0, rt_val = 0, rtd_alpha = -1.0f, rtd_eta = 0, rtd_val = 0; mutable uint32_t rt_type = 0, rtd_type = 0;
+#endif
+};
 
 } // namespace ctl
 #include "bsdf_more.h"

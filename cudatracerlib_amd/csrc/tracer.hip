@@ -345,6 +345,10 @@ WavefrontPathTracer::WavefrontPathTracer() {
     // build-specific: run Material::AlphaTest on candidate hits.  Off = the reference's wavefront tracer (its intersectKernel has no
     // alpha test, only the single-ray traceRay of the megakernel integrators does, TraceHelper.cu:135-153)
     m_sParameters.addBool("AlphaTest", false);
+    // build-specific: group the shading queue by BSDF model before the full shade kernel runs (no effect on scenes served by the basic build).
+    // Off by default: measured on the synthetic-bathroom workload it LOSES (shade 9.1 -> 11.5 ms / pass) — the time goes into the spline
+    // lookups of the rough plastics, not into divergence, and the sorted order turns the path-state reads into gathers
+    m_sParameters.addBool("SortMaterials", false);
     int dev = 0; hipDeviceProp_t prop; CTL_HIP(hipGetDevice(&dev)); CTL_HIP(hipGetDeviceProperties(&prop, dev));
     grid_blocks = prop.multiProcessorCount * 8;   // 8 x 256-thread workgroups per CU = 32 waves/CU
 }
@@ -366,7 +370,8 @@ void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
     Q.fin.rad = new_f4(capacity); Q.fin.dir = new_f4(capacity); px_[2].alloc(capacity); Q.fin.px = px_[2].p;
     stats_.alloc(12); Q.stats = stats_.p; CTL_HIP(hipMemset(stats_.p, 0, 12 * sizeof(unsigned long long)));
     Q.capacity = capacity;
-    counts_.free(); work_.free();
+    order_.alloc(capacity); Q.order = order_.p; mat_key_.alloc(capacity); Q.mat_key = mat_key_.p;
+    counts_.free(); work_.free(); mat_counts_.free();
 }
 
 // stats: [0] path rays, [1] shadow rays, [2..6] closest-hit traversal counts, [7..11] any-hit traversal counts
@@ -396,8 +401,9 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     const int maxPathLength = m_sParameters.getValue("MaxPathLength"), rrStart = m_sParameters.getValue("RRStartDepth");
     const bool direct = m_sParameters.getValue("Direct") != 0;
     const size_t n_counts = (size_t)(maxPathLength + 2) * 4, n_work = (size_t)2 * (maxPathLength + 2);
-    if (counts_.n < n_counts) { counts_.alloc(n_counts); work_.alloc(n_work); }
-    Q.counts = counts_.p; Q.work = work_.p;
+    const size_t n_mat = (size_t)(maxPathLength + 2) * 32;
+    if (counts_.n < n_counts) { counts_.alloc(n_counts); work_.alloc(n_work); mat_counts_.alloc(n_mat); }
+    Q.counts = counts_.p; Q.work = work_.p; Q.mat_counts = mat_counts_.p;
     const dev_scene& S = m_pScene->S;
     const launch_ctx lc{ stream, grid_blocks, m_sParameters.getValue("AlphaTest") != 0 && S.alpha_maps != 0 };
     if (lc.alpha_test && S.flat_nodes && S.flat_width == 8) throw std::runtime_error("AlphaTest is not available with the 8-wide flattened BVH");
@@ -406,6 +412,8 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     P.batch = n_batch;
     P.width = w; P.height = h; P.tile_rank = shard_rank; P.tile_world = shard_world; P.n_local_pixels = n_local_pixels;
     P.direct = direct ? 1 : 0; P.max_path_length = maxPathLength; P.rr_start_depth = rrStart;
+    P.sort_materials = (m_sParameters.getValue("SortMaterials") != 0 && S.shade_features != 0) ? 1 : 0;
+    if (P.sort_materials) CTL_HIP(hipMemsetAsync(mat_counts_.p, 0, n_mat * sizeof(uint32_t), stream));
     CTL_HIP(hipMemsetAsync(counts_.p, 0, n_counts * sizeof(uint32_t), stream));
     CTL_HIP(hipMemsetAsync(work_.p, 0, n_work * sizeof(uint32_t), stream));
     timer.begin(stream, 0); launch_raygen(lc, S, Q, P); timer.end(stream);

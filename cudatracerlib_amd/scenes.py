@@ -274,6 +274,60 @@ def env_scene(width=96, height=64, rotate_env=False, point_filter=False, extra_l
     return sc
 
 
+def synthetic_bathroom(width=1920, height=1080, n_instances=300, subdiv=4, seed=17):
+    """"synthetic-bathroom": the seeded stand-in for BASELINE config 5 (Bitterli bathroom: rough plastic / rough conductor / rough
+    dielectric surfaces under an environment emitter — the shading-divergence stress).  A tiled floor with a bitmap texture and a
+    height map, walls of rough plastic, n_instances spheres / boxes cycling through nine BSDF models (Beckmann and GGX, visible-normal
+    sampling, rough glass, coated metal, Oren-Nayar), lit by a lat-long environment map through a window-less open top plus one area light."""
+    from . import rough_tables
+    rs = np.random.RandomState(seed)
+    sc = api.DynamicScene()
+    for slot in (0, 1):
+        tr, df, er, ar = rough_tables.make_table(slot, n_eta=6, n_alpha=8, n_theta=16, quad=24)
+        sc.setRoughTransmittance(slot, tr, df, er, ar)
+    tiles = sc.add_image(checker_image(), api.TEXEL_RGBCOL, api.WRAP_REPEAT, api.FILTER_BILINEAR)
+    bumps = sc.add_image(api.float3_to_rgbcol(bump_image()), api.TEXEL_RGBCOL, api.WRAP_REPEAT, api.FILTER_BILINEAR)
+    floor_mat = api.roughplastic(api.image_texture(tiles, scale=(0.8, 0.8, 0.8), uv_scale=(12.0, 12.0)), alpha=0.08, distribution=0)
+    api.set_height_map(floor_mat, api.image_texture(bumps, scale=(0.02, 0.02, 0.02), uv_scale=(24.0, 24.0)))
+    P, I, N = _quad([[-30, 0, -30], [-30, 0, 30], [30, 0, 30], [30, 0, -30]], [0, 1, 0])
+    sc.CreateNode(sc.add_mesh(P, I, normals=N, uvs=np.array([[0, 0], [0, 1], [1, 1], [1, 0]], np.float32), materials=[floor_mat]))
+    wall = api.roughplastic((0.75, 0.74, 0.7), alpha=0.2, distribution=1)
+    m = _MeshAcc()
+    for p, n in (([[-30, 0, 30], [-30, 25, 30], [30, 25, 30], [30, 0, 30]], [0, 0, -1]), ([[-30, 0, -30], [-30, 25, -30], [-30, 25, 30], [-30, 0, 30]], [1, 0, 0]),
+                 ([[30, 0, 30], [30, 25, 30], [30, 25, -30], [30, 0, -30]], [-1, 0, 0])):
+        Pq, Iq, Nq = _quad(p, n)
+        m.add(Pq, Iq, Nq, 0)
+    Pw, Iw, Nw, _ = m.arrays()
+    sc.CreateNode(sc.add_mesh(Pw, Iw, normals=Nw, materials=[wall]))
+    i0 = sc.add_material(api.roughconductor(alpha=0.15, distribution=1))
+    n0 = api.roughconductor(alpha=0.15, distribution=1)
+    mats = [api.roughplastic((0.7, 0.2, 0.15), alpha=0.1, distribution=0), api.roughplastic((0.2, 0.3, 0.7), alpha=0.3, int_ior=1.6, distribution=1, nonlinear=True),
+            api.roughconductor(alpha=0.1, distribution=0, sample_visible=True), api.roughconductor(alpha=0.25, alpha_v=0.05, distribution=1, sample_visible=True, eta=(0.14, 0.37, 1.44), k=(3.98, 2.38, 1.6)),
+            api.roughdielectric(alpha=0.08, int_ior=1.5, ext_ior=1.0, distribution=1, sample_visible=True), api.roughdielectric(alpha=0.2, int_ior=1.33, ext_ior=1.0, distribution=0, sample_visible=True),
+            api.dielectric(int_ior=1.5, ext_ior=1.0), api.coating(i0, n0, int_ior=1.5, ext_ior=1.0, thickness=1.0, sigma_a=(0.2, 0.5, 0.9)), api.roughdiffuse((0.6, 0.6, 0.55), alpha=0.4)]
+    V, F = icosphere(subdiv)
+    spheres = [sc.add_mesh(V, F, normals=V, materials=[mm]) for mm in mats]
+    Pb, Ib, Nb = unit_box()
+    boxes = [sc.add_mesh(Pb, Ib, normals=Nb, materials=[mm]) for mm in mats[:4]]
+    for i in range(n_instances):
+        s = rs.uniform(0.6, 2.2)
+        pos = np.array([rs.uniform(-26, 26), 0.0, rs.uniform(-26, 26)])
+        xf = np.eye(4)
+        if rs.uniform() < 0.8:
+            mesh = spheres[i % len(spheres)]; xf[:3, :3] = np.eye(3) * s; pos[1] = s + 0.02 + rs.uniform(0, 6) * (i % 3 == 0)
+        else:
+            mesh = boxes[i % len(boxes)]; xf[:3, :3] = _rotation(rs) @ np.diag(rs.uniform(0.5, 1.5, size=3) * s); pos[1] = 2.5 * s + 0.05
+        xf[:3, 3] = pos
+        sc.CreateNode(mesh, xf.astype(np.float32))
+    env = sc.add_image(procedural_envmap(), api.TEXEL_RGBE, api.WRAP_REPEAT, api.FILTER_BILINEAR)
+    sc.setEnvironementMap(env, (1.0, 1.0, 1.0), None)
+    P, I, N = _quad([[-6, 24.5, -6], [6, 24.5, -6], [6, 24.5, 6], [-6, 24.5, 6]], [0, -1, 0])
+    sc.CreateLight(sc.CreateNode(sc.add_mesh(P, I, normals=N, materials=[api.diffuse((0.5, 0.5, 0.5))])), 0, (30.0, 28.0, 25.0))
+    sc.setCamera((0, 12, -29.0), (0, 3, 0), (0, 1, 0), 65.0, width, height)
+    sc.UpdateScene()
+    return sc
+
+
 def bump_image(n=64, seed=3):
     """Smooth procedural height field, (n, n, 3) floats in [0, 1] (also the source of the tangent-space normal map below)."""
     y, x = np.mgrid[0:n, 0:n].astype(np.float32) / n

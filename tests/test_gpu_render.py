@@ -86,6 +86,15 @@ def test_environment_map_bitmap_texture_and_delta_lights(gpu, orc, kw):
     assert want[..., :3].mean() > 0.1
 
 
+def test_synthetic_bathroom_workload(gpu, orc):
+    """the stand-in for BASELINE config 5 in miniature: nine BSDF models (both distributions, visible normals, coating, rough glass),
+    bitmap texture + height map, environment emitter + area light, instanced meshes — two-level layout, per-pixel bar"""
+    sc = scenes.synthetic_bathroom(96, 54, n_instances=60, subdiv=2)
+    got, want, tr, rays = render_pair(gpu, orc, sc, 96, 54, 3, max_len=6)
+    assert_close(got, want)
+    assert want[..., :3].mean() > 0.1
+
+
 def test_mitsuba_xml_scene(gpu, orc, tmp_path):
     """ParseMitsubaScene -> UpdateScene -> render: Cornell box + glass sphere authored as Mitsuba XML (BASELINE config 2 geometry)"""
     path = scenes.write_cornell_mitsuba(str(tmp_path), 64, 64, glass_sphere=True)
