@@ -47,6 +47,41 @@ __device__ __forceinline__ block_slots block_append3(uint32_t* c0, bool t0, uint
     return r;
 }
 
+// The same append with queues 0 and 1 bucketed by a 3-bit key (the octant of the new ray's direction): inside the block's range the
+// entries come out grouped by key, bucket after bucket, so that the 64 rays a traversal wave picks up next mostly share the octant — they
+// walk the tree in the same order and touch the same node lines.  s_cnt has 17 rows (2 x 8 buckets + the plain queue).
+__device__ __forceinline__ block_slots block_append3_keyed(uint32_t* c0, bool t0, uint32_t k0, uint32_t* c1, bool t1, uint32_t k1, uint32_t* c2, bool t2,
+                                                           uint32_t (*s_cnt)[kWideBlock / 64], uint32_t* s_base) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    uint32_t rank0 = 0, rank1 = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        const unsigned long long a = __ballot(t0 && k0 == k), b = __ballot(t1 && k1 == k);
+        if (lane == 0) { s_cnt[k][wave] = (uint32_t)__popcll(a); s_cnt[8 + k][wave] = (uint32_t)__popcll(b); }
+        if (t0 && k0 == k) rank0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(a >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)a, 0));
+        if (t1 && k1 == k) rank1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+    }
+    const unsigned long long m2 = __ballot(t2);
+    if (lane == 0) s_cnt[16][wave] = (uint32_t)__popcll(m2);
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t* ctr = threadIdx.x == 0 ? c0 : (threadIdx.x == 1 ? c1 : c2);
+        const int row0 = threadIdx.x == 2 ? 16 : (int)threadIdx.x * 8, rows = threadIdx.x == 2 ? 1 : 8;
+        uint32_t tot = 0;
+        for (int r = row0; r < row0 + rows; r++)          // bucket-major exclusive prefix: all waves of bucket 0, then bucket 1, ...
+            for (int w = 0; w < n_waves; w++) { const uint32_t c = s_cnt[r][w]; s_cnt[r][w] = tot; tot += c; }
+        s_base[threadIdx.x] = (tot && ctr) ? atomicAdd(ctr, tot) : 0u;
+    }
+    __syncthreads();
+    block_slots r;
+    r.s[0] = s_base[0] + s_cnt[t0 ? k0 : 0][wave] + rank0;
+    r.s[1] = s_base[1] + s_cnt[8 + (t1 ? k1 : 0)][wave] + rank1;
+    r.s[2] = s_base[2] + s_cnt[16][wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0));
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ uint32_t octant_of(f3 d) { return (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u); }
+
 // ------------------------------------------------------------------------------------------------ framebuffer
 // Image::AddSample (Engine/Image.cu:22-44): clamp negatives, drop NaN/Inf, floor to the pixel, 4 float atomics.
 __device__ __forceinline__ void add_sample(ctl_pixel_data* img, uint32_t W, uint32_t H, float sx, float sy, f3 L) {

@@ -49,6 +49,7 @@ struct pass_params {
     uint32_t n_local_pixels;             // pixels rendered by this rank
     int direct, max_path_length, rr_start_depth;
     int sort_materials;                  // shade in wave_queues::order
+    int sort_octants;                    // append the new rays of a workgroup grouped by direction octant (compaction.h)
 };
 
 struct launch_ctx { hipStream_t stream; int grid_blocks; bool alpha_test = false; };   // alpha_test: intersect kernels run Material::AlphaTest on candidate hits

@@ -349,6 +349,9 @@ WavefrontPathTracer::WavefrontPathTracer() {
     // Off by default: measured on the synthetic-bathroom workload it LOSES (shade 9.1 -> 11.5 ms / pass) — the time goes into the spline
     // lookups of the rough plastics, not into divergence, and the sorted order turns the path-state reads into gathers
     m_sParameters.addBool("SortMaterials", false);
+    // build-specific: the rays a shade workgroup emits are appended grouped by direction octant (compaction.h block_append3_keyed).
+    // Off by default: measured on synthetic-SM the traversal kernels gain 1 % (6.10 -> 6.05 ms / pass) and the shade kernel pays 0.5 ms for it
+    m_sParameters.addBool("SortOctants", false);
     int dev = 0; hipDeviceProp_t prop; CTL_HIP(hipGetDevice(&dev)); CTL_HIP(hipGetDeviceProperties(&prop, dev));
     grid_blocks = prop.multiProcessorCount * 8;   // 8 x 256-thread workgroups per CU = 32 waves/CU
 }
@@ -413,6 +416,7 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     P.width = w; P.height = h; P.tile_rank = shard_rank; P.tile_world = shard_world; P.n_local_pixels = n_local_pixels;
     P.direct = direct ? 1 : 0; P.max_path_length = maxPathLength; P.rr_start_depth = rrStart;
     P.sort_materials = (m_sParameters.getValue("SortMaterials") != 0 && S.shade_features != 0) ? 1 : 0;
+    P.sort_octants = m_sParameters.getValue("SortOctants") != 0 ? 1 : 0;
     if (P.sort_materials) CTL_HIP(hipMemsetAsync(mat_counts_.p, 0, n_mat * sizeof(uint32_t), stream));
     CTL_HIP(hipMemsetAsync(counts_.p, 0, n_counts * sizeof(uint32_t), stream));
     CTL_HIP(hipMemsetAsync(work_.p, 0, n_work * sizeof(uint32_t), stream));
