@@ -201,7 +201,7 @@ static decoded_image decode_hdr(const std::vector<uint8_t>& d, const std::string
 
 decoded_image load_image_file(const std::string& path) {
     const std::string ext = lower_ext(path);
-    if (ext == "jpg" || ext == "jpeg") throw unsupported_error("JPEG decoding is not built in (convert the texture to PNG) : " + path);
+    if (ext == "jpg" || ext == "jpeg" || ext == "jpe") return decode_jpeg(read_file(path), path);
     if (ext == "exr") throw unsupported_error("OpenEXR decoding is not built in (convert to .hdr or .pfm) : " + path);
     const std::vector<uint8_t> d = read_file(path);
     if (ext == "png") return decode_png(d, path);
