@@ -8,6 +8,7 @@
 #include "image_io.h"
 #include "mesh_io.h"
 #include "material_factory.h"
+#include "sequence_generator.h"   // xorwow = CudaRNG
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -503,8 +504,68 @@ struct loader {
             ctl_float4x4 x; std::memcpy(x.m, scale(-rad, -rad, -rad).m, 64); B.set_node_transform(node, x);
             const float k = 4 * 3.14159265358979f * rad * rad; const float r3[3] = { e.r / k, e.g / k, e.b / k };
             B.add_area_light(node, 0, r3);
-        } else if (T == "sunsky" || T == "sun" || T == "sky") unsupported("emitter type " + T);
+        } else if (T == "sunsky" || T == "sun") parse_sun(n);
+        else if (T == "sky") bad("NOT YET IMPLEMENTED");   // LightParser::sky (:554-557)
         else bad("invalid StreamReference<Light> type : " + T);
+    }
+    // LightParser::parseSun (ObjectParser.h:354-493): the sun (and "sunsky": the sky part is dropped there too) becomes EIGHT wide spot lights on a
+    // small disk half a scene diameter up-sun of the scene centre.  The sun position is Mitsuba's (Blanco-Muriel et al., "Computing the Solar
+    // Vector", 2001).  The reference jitters the eight positions with CudaRNG(time(0)), i.e. differently in every run; this loader seeds the
+    // same generator with 0 ($CTL_SUN_SEED overrides), as SURVEY §8d fixes it for the San Miguel configs.
+    void parse_sun(const xml_node& n) {
+        f3 dir;
+        if (const xml_node* sd = n.property("sunDirection")) dir = parse_vector(*sd);
+        else {
+            const int year = prop_i(n, "year", 2010), month = prop_i(n, "month", 7), day = prop_i(n, "day", 10);
+            const float hour = prop_f(n, "hour", 15.0f), minute = prop_f(n, "minute", 0.0f), second = prop_f(n, "second", 0.0f);
+            const float latitude = prop_f(n, "latitude", 35.6894f), longitude = prop_f(n, "longitude", 139.6917f), timezone = (float)prop_i(n, "timezone", 9);
+            const double PI_ = 3.14159265358979323846f;   // the reference's PI is a float constant
+            const double decHours = hour - timezone + (minute + second / 60.0) / 60.0;
+            const int liAux1 = (month - 14) / 12;
+            const int liAux2 = (1461 * (year + 4800 + liAux1)) / 4 + (367 * (month - 2 - 12 * liAux1)) / 12 - (3 * ((year + 4900 + liAux1) / 100)) / 4 + day - 32075;
+            const double elapsedJulianDays = ((double)liAux2 - 0.5 + decHours / 24.0) - 2451545.0;
+            const double omega = 2.1429 - 0.0010394594 * elapsedJulianDays, meanLongitude = 4.8950630 + 0.017202791698 * elapsedJulianDays, anomaly = 6.2400600 + 0.0172019699 * elapsedJulianDays;
+            const double eclipticLongitude = meanLongitude + 0.03341607 * std::sin(anomaly) + 0.00034894 * std::sin(2 * anomaly) - 0.0001134 - 0.0000203 * std::sin(omega);
+            const double eclipticObliquity = 0.4090928 - 6.2140e-9 * elapsedJulianDays + 0.0000396 * std::cos(omega);
+            const double sinEclipticLongitude = std::sin(eclipticLongitude);
+            double dY = std::cos(eclipticObliquity) * sinEclipticLongitude, dX = std::cos(eclipticLongitude);
+            double rightAscension = std::atan2(dY, dX);
+            if (rightAscension < 0.0) rightAscension += 2 * PI_;
+            const double declination = std::asin(std::sin(eclipticObliquity) * sinEclipticLongitude);
+            const double greenwichMeanSiderealTime = 6.6974243242 + 0.0657098283 * elapsedJulianDays + decHours;
+            auto degToRad = [&](double f) { return f * PI_ / 180.0f; };
+            const double localMeanSiderealTime = degToRad(greenwichMeanSiderealTime * 15 + longitude), latitudeInRadians = degToRad(latitude);
+            const double cosLatitude = std::cos(latitudeInRadians), sinLatitude = std::sin(latitudeInRadians);
+            const double hourAngle = localMeanSiderealTime - rightAscension, cosHourAngle = std::cos(hourAngle);
+            double elevation = std::acos(cosLatitude * cosHourAngle * std::cos(declination) + std::sin(declination) * sinLatitude);
+            dY = -std::sin(hourAngle); dX = std::tan(declination) * cosLatitude - sinLatitude * cosHourAngle;
+            double azimuth = std::atan2(dY, dX);
+            if (azimuth < 0.0) azimuth += 2 * PI_;
+            const float EARTH_MEAN_RADIUS = 6371.01f, ASTRONOMICAL_UNIT = 149597890.0f;
+            elevation += (EARTH_MEAN_RADIUS / ASTRONOMICAL_UNIT) * std::sin(elevation);
+            const float sinTheta = sinf((float)elevation), cosTheta = cosf((float)elevation), sinPhi = sinf((float)azimuth), cosPhi = cosf((float)azimuth);
+            dir = f3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
+        }
+        const float scale_ = prop_f(n, "scale", 1.0f), sunRadiusScale = prop_f(n, "sunRadiusScale", 1.0f);
+        if (const xml_node* tw = n.property("toWorld")) dir = xf_dir(parse_matrix(*tw), dir);
+        const aabb box = B.scene_box();   // of what has been loaded so far, as in the reference
+        const f3 size(box.hi[0] - box.lo[0], box.hi[1] - box.lo[1], box.hi[2] - box.lo[2]), center((box.hi[0] + box.lo[0]) * 0.5f, (box.hi[1] + box.lo[1]) * 0.5f, (box.hi[2] + box.lo[2]) * 0.5f);
+        const float scene_rad = length(size);
+        const char* seed_env = std::getenv("CTL_SUN_SEED");
+        xorwow rng; rng.init(1234, seed_env ? (uint64_t)std::strtoull(seed_env, nullptr, 10) : 0);   // CudaRNG(seed) = curand_init(1234, seed, 0)
+        const int N_lights = 8;
+        const float EARTH_MEAN_RADIUS = 6371.01f;
+        const float rel_radius = scene_rad / EARTH_MEAN_RADIUS * sunRadiusScale * 10;
+        const f3 nd = normalize(dir);
+        f3 s, t; coordinate_system(nd, s, t);
+        for (int i = 0; i < N_lights; i++) {
+            f3 p = center - nd * scene_rad / 2;
+            const float jx = 2 * rng.uniform() - 1, jy = 2 * rng.uniform() - 1;
+            p = p + (s * jx + t * jy) * rel_radius;
+            const float e = scale_ * scene_rad * scene_rad / N_lights;
+            const float p3[3] = { p.x, p.y, p.z }, c3[3] = { center.x, center.y, center.z }, i3[3] = { e, e, e };
+            B.add_spot_light(p3, c3, i3, 90.0f, 90.0f);
+        }
     }
 
     void parse_file(const std::string& file);
