@@ -121,6 +121,8 @@ uint32_t scene_builder::add_mesh(const float* positions, uint32_t n_vert, const 
                                  bool flip_normals, bool face_normals, float max_smooth_angle) {
     if (!positions || n_tri == 0 || n_mat == 0 || !materials) throw std::runtime_error("ctl_builder_add_mesh: empty mesh or no material");
     if (!indices && n_vert != n_tri * 3) throw std::runtime_error("ctl_builder_add_mesh: triangle soup needs n_vert == 3*n_tri");
+    if (indices) for (size_t i = 0; i < (size_t)n_tri * 3; i++) if (indices[i] >= n_vert) throw std::runtime_error("ctl_builder_add_mesh: vertex index out of range");   // before anything dereferences them
+    if (tri_material) for (uint32_t i = 0; i < n_tri; i++) if (tri_material[i] >= n_mat) throw std::runtime_error("ctl_builder_add_mesh: triangle material index out of range");
     mesh_rec mr{};
     mr.tri_offset = (uint32_t)tri.size(); mr.n_tris = n_tri;
     mr.mat_offset = (uint32_t)mesh_materials.size(); mr.n_mat = n_mat;

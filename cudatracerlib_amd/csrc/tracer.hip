@@ -171,6 +171,28 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
         if (!ok)
             throw std::runtime_error("ctl_scene_create: BSDF type " + std::to_string(t) + " has no HIP implementation yet");
     }
+    {   // the two-level traversal keeps (scene-BVH depth + exit marker + mesh-BVH depth) entries on its per-lane stack: check it fits
+        auto depth_of = [](const ctl_bvh_node* nodes, size_t n_nodes, int root) {   // child >= 0: float4 index of an inner node
+            int best = 0; std::vector<std::pair<int, int>> st;
+            if (root >= 0 && (size_t)(root / 4) < n_nodes) st.emplace_back(root / 4, 1);
+            while (!st.empty()) {
+                const auto [i, dpt] = st.back(); st.pop_back();
+                best = std::max(best, dpt);
+                if (dpt > 4 * kStackSize) throw std::runtime_error("ctl_scene_create: BVH child links form a cycle");
+                for (int c : { nodes[i].child0, nodes[i].child1 }) if (c >= 0 && c != 0x76543210 && (size_t)(c / 4) < n_nodes) st.emplace_back(c / 4, dpt + 1);
+            }
+            return best;
+        };
+        const int top = d.scene_start_node >= 0 ? depth_of(d.scene_bvh_nodes, d.n_scene_bvh_nodes, d.scene_start_node) : 0;
+        int bottom = 0;
+        for (uint32_t m = 0; m < d.n_meshes; m++) {
+            const uint32_t first = d.meshes[m].bvh_node_offset / 4;
+            if (first < d.n_bvh_nodes) bottom = std::max(bottom, depth_of(d.bvh_nodes + first, d.n_bvh_nodes - first, 0));
+        }
+        if (top + bottom + 3 > kStackSize)
+            throw std::runtime_error("ctl_scene_create: scene BVH depth " + std::to_string(top) + " + mesh BVH depth " + std::to_string(bottom) +
+                                     " does not fit the traversal stack of " + std::to_string(kStackSize) + " entries (rebuild the meshes with CTL_BVH_BINNED, whose depth is bounded)");
+    }
     S.flat_nodes = nullptr; S.flat_leaves = nullptr; S.flat_root = 0; S.flat_width = 0;
     if (flatten) {
         // node width: 4 (64-byte nodes).  CTL_FLAT_WIDTH=8 selects the 128-byte 8-wide layout (traverse8.h) — measured on MI355X it
