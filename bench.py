@@ -95,8 +95,15 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # test hook for a 1-GPU box: CTL_BENCH_SHARE_GPU=1 puts every rank on device 0 and swaps RCCL for gloo, so that the multi-rank flow
+        # (cache staging barrier, tile shards, framebuffer reduce) can be exercised without N GPUs.  Never set by the driver.
+        if os.environ.get("CTL_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     import cudatracerlib_amd as ctl
     if ctl.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")

@@ -32,5 +32,8 @@ def reduce_framebuffer(fb, dst=0):
     """sum the ranks' PixelData frames into rank `dst` (torch tensor, in place). One collective per render."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
+        if dist.get_backend() == "gloo" and fb.is_cuda:   # gloo only all-reduces device tensors (1-GPU test mode of bench.py)
+            dist.all_reduce(fb, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
     return fb
