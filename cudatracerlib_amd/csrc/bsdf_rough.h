@@ -144,6 +144,18 @@ __device__ float ward_pdf(const ctl_material& M, const bsdf_rec& b) {   // BSDF_
     return 0.0f;
 }
 
+// Rough plastic with a constant roughness: the table was reduced to 1-D in cos(theta) at scene upload (tracer.hip), M.reserved_ = {offset + 1, samples}
+__device__ __forceinline__ float rough_transmittance_1d(const float* __restrict__ table, uint32_t size, float cosTheta) {
+    float w[4]; uint32_t knot;
+    if (!spline_weights(powf(fabsf(cosTheta), 0.25f), size, w, knot)) return 0.0f;
+    float result = 0.0f;
+    for (int x = -1; x <= 2; ++x) { if (w[x + 1] == 0) continue; result += table[knot + x] * w[x + 1]; }
+    return min2(1.0f, max2(0.0f, result));
+}
+__device__ __forceinline__ float roughplastic_T(const ctl_material& M, const bsdf_rec& b, float cosTheta, float alpha) {   // cosTheta > 0 on every roughplastic path
+    if (M.reserved_[0]) return rough_transmittance_1d(b.dg.rt_reduced + (M.reserved_[0] - 1), M.reserved_[1], cosTheta);
+    return rough_transmittance(b.dg, M.u[2], cosTheta, alpha, M.f[0]);
+}
 __device__ __forceinline__ float rough_transmittance_wi(const bsdf_rec& b, uint32_t type, float cosTheta, float alpha, float eta) {
 #if CTL_SHADE_FEATURES & 2
     if (b.rt_cos == cosTheta && b.rt_alpha == alpha && b.rt_eta == eta && b.rt_type == type) return b.rt_val;
@@ -169,7 +181,7 @@ __device__ __forceinline__ microfacet roughplastic_distr(const ctl_material& M, 
     return microfacet((int)M.u[2], a, a, M.u[1] != 0);
 }
 __device__ __forceinline__ float roughplastic_prob_specular(const ctl_material& M, const bsdf_rec& b, const microfacet& distr) {
-    const float ps = 1 - rough_transmittance_wi(b, M.u[2], cos_theta(b.wi), distr.aU, M.f[0]);
+    const float ps = 1 - (M.reserved_[0] ? roughplastic_T(M, b, cos_theta(b.wi), distr.aU) : rough_transmittance_wi(b, M.u[2], cos_theta(b.wi), distr.aU, M.f[0]));
     return (ps * M.f[2]) / (ps * M.f[2] + (1 - ps) * (1 - M.f[2]));
 }
 __device__ f3 roughplastic_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:948-1005
@@ -187,9 +199,9 @@ __device__ f3 roughplastic_f(const ctl_material& M, const bsdf_rec& b) {   // BS
     }
     if (hd) {
         f3 diff = tex_eval(M.tex[0], b.dg);
-        const float T12 = rough_transmittance_wi(b, M.u[2], cos_theta(b.wi), distr.aU, M.f[0]);
-        const float T21 = rough_transmittance(b.dg, M.u[2], cos_theta(b.wo), distr.aU, M.f[0]);
-        const float Fdr = 1 - rough_transmittance_diffuse_memo(b, M.u[2], distr.aU, M.f[0]);
+        const float T12 = M.reserved_[0] ? roughplastic_T(M, b, cos_theta(b.wi), distr.aU) : rough_transmittance_wi(b, M.u[2], cos_theta(b.wi), distr.aU, M.f[0]);
+        const float T21 = roughplastic_T(M, b, cos_theta(b.wo), distr.aU);
+        const float Fdr = 1 - (M.reserved_[0] ? b.dg.rt_reduced[M.reserved_[0] - 1 + M.reserved_[1]] : rough_transmittance_diffuse_memo(b, M.u[2], distr.aU, M.f[0]));
         if (M.u[0]) diff = diff / (f3(1.0f) - diff * Fdr);
         else diff = diff / (1 - Fdr);
         result = result + diff * (kInvPi * cos_theta(b.wo) * T12 * T21 * M.f[1]);

@@ -35,6 +35,7 @@ struct dev_scene {
     const unsigned char* anim;
     const ctl_mipmap* images;    // level-0 KernelMIPMap descriptors with device texel pointers
     const ctl_rough_transmittance* rough_transmittance;   // 3 tables with device pointers, or nullptr
+    const float* rt_reduced;     // per rough-plastic material with constant alpha: its transmittance table reduced to 1-D in cos(theta) + the diffuse value (tracer.hip)
     int start_node;
     uint32_t n_nodes;
     uint32_t num_lights;

@@ -46,13 +46,14 @@ __device__ __forceinline__ void sensor_sample_ray(const dev_sensor& c, f2 pixelS
 // ---- differential geometry at a hit (Kernel/TraceHelper.cu:274-307 -> Engine/TriangleData.cu:75-103)
 struct diff_geom {
     f3 P; frame sys; f3 n; f2 uv; const ctl_mipmap* images; const ctl_rough_transmittance* rough_transmittance; const ctl_material* mats;
+    const float* rt_reduced;   // dev_scene::rt_reduced
 #if CTL_SHADE_FEATURES & 32
     f3 dpdu, dpdv;   // world space, for height maps only
 #endif
 };   // images: g_SceneData.m_sTexData; tables of RoughTransmittanceManager (both uniform)
 __device__ __forceinline__ void fill_dg(const dev_scene& S, float u, float v, int tri, int node, diff_geom& dg) {
     const uint4 ta = S.tri_data[tri * 2], tb = S.tri_data[tri * 2 + 1];   // {nme.x, nme.y, dpd.x, dpd.y} {dpd.z, uv0, uv1, uv2}
-    dg.images = S.images; dg.rough_transmittance = S.rough_transmittance; dg.mats = S.mats;
+    dg.images = S.images; dg.rough_transmittance = S.rough_transmittance; dg.mats = S.mats; dg.rt_reduced = S.rt_reduced;
     const float4 f0 = S.inst_fwd[node * 3], f1 = S.inst_fwd[node * 3 + 1], f2_ = S.inst_fwd[node * 3 + 2];
     m34 l2w; l2w.r[0][0] = f0.x; l2w.r[0][1] = f0.y; l2w.r[0][2] = f0.z; l2w.r[0][3] = f0.w; l2w.r[1][0] = f1.x; l2w.r[1][1] = f1.y; l2w.r[1][2] = f1.z; l2w.r[1][3] = f1.w;
     l2w.r[2][0] = f2_.x; l2w.r[2][1] = f2_.y; l2w.r[2][2] = f2_.z; l2w.r[2][3] = f2_.w;

@@ -73,7 +73,8 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
     static_assert(sizeof(ctl_triangle_data) == 32, "TriangleData is 32 B");
     static_assert(sizeof(ctl_material) == 384 && sizeof(ctl_texture) == 48, "material descriptor layout (include/ctl_amd.h)");
     tri_data_.upload((const uint4*)d.tri_data, (size_t)d.n_tri_data * 2);
-    mats_.upload(d.materials, d.n_materials);
+    std::vector<ctl_material> dmats(d.materials, d.materials + d.n_materials);   // uploaded below, once the reduced transmittance tables are attached
+    for (auto& m : dmats) m.reserved_[0] = m.reserved_[1] = 0;
     if (d.n_lights_buf) lights_.upload(d.lights, d.n_lights_buf); else lights_.alloc(1);
     if (d.n_anim_bytes) anim_.upload(d.anim, d.n_anim_bytes); else anim_.alloc(16);
     // KernelMIPMap level 0 of every image: one texel pool + a table of descriptors with device pointers
@@ -112,6 +113,54 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
             S.rough_transmittance = rt_.p;
         }
     }
+    // Rough plastics with a CONSTANT roughness texture look the transmittance table up at fixed (alpha, eta): reduce the 3-D cubic interpolation
+    // (64 taps per lookup, three to five lookups per shaded vertex) to a 1-D table in cos(theta) once, here.  Same spline weights
+    // (Math/Spline.cu:223-453 via RoughTransmittance.cu:55-119), summed alpha / eta first instead of last: equal up to fp32 rounding.
+    S.rt_reduced = nullptr;
+    if (d.rough_transmittance) {
+        auto weights = [](float p, uint32_t size, float* w, uint32_t& knot) {   // = spline_weights (bsdf_rough.h)
+            if (!(p >= 0.0f && p <= 1.0f)) return false;
+            float t = ((p - 0.0f) * (size - 1)) / (1.0f - 0.0f);
+            knot = std::min((uint32_t)t, size - 2); t = t - (float)knot;
+            const float t2 = t * t, t3 = t2 * t;
+            w[0] = 0.0f; w[1] = 2 * t3 - 3 * t2 + 1; w[2] = -2 * t3 + 3 * t2; w[3] = 0.0f;
+            const float d0 = t3 - 2 * t2 + t, d1 = t3 - t2;
+            if (knot > 0) { w[2] += 0.5f * d0; w[0] -= 0.5f * d0; } else { w[2] += d0; w[1] -= d0; }
+            if (knot + 2 < size) { w[3] += 0.5f * d1; w[1] -= 0.5f * d1; } else { w[2] += d1; w[1] -= d1; }
+            return true;
+        };
+        std::vector<float> pool;
+        for (auto& m : dmats) {
+            if (m.bsdf_type != CTL_BSDF_ROUGHPLASTIC || m.tex[2].type != CTL_TEX_CONSTANT || m.u[2] > CTL_MF_PHONG) continue;
+            const ctl_rough_transmittance& T = d.rough_transmittance[m.u[2]];
+            if (!T.trans || !T.diff_trans || T.theta_samples < 2 || T.alpha_samples < 2 || T.eta_samples < 2) continue;
+            float r = m.tex[2].value[0]; r += m.tex[2].value[1]; r += m.tex[2].value[2];
+            const float alpha = std::max(r * (1.0f / 3), 1e-4f);   // avg3 + the MicrofacetDistribution constructor's clamp
+            float eta = m.f[0];
+            const float* data = T.trans; const float* ddata = T.diff_trans;
+            if (eta < 1) { data += (size_t)T.eta_samples * T.alpha_samples * T.theta_samples; ddata += (size_t)T.eta_samples * T.alpha_samples; eta = 1.0f / eta; }
+            if (eta < T.eta_min) eta = T.eta_min;
+            const float wa = std::pow((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f), we = std::pow((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
+            float wy[4], wz[4]; uint32_t ky, kz;
+            const bool ok = weights(wa, T.alpha_samples, wy, ky) && weights(we, T.eta_samples, wz, kz);
+            m.reserved_[0] = (uint32_t)pool.size() + 1; m.reserved_[1] = T.theta_samples;
+            for (uint32_t x = 0; x < T.theta_samples; x++) {
+                float v = 0.0f;
+                if (ok) for (int z = -1; z <= 2; ++z) for (int y = -1; y <= 2; ++y) {
+                    const float wyz = wy[y + 1] * wz[z + 1];
+                    if (wyz == 0) continue;
+                    v += data[((size_t)(kz + z) * T.alpha_samples + (ky + y)) * T.theta_samples + x] * wyz;
+                }
+                pool.push_back(v);
+            }
+            float dv = 0.0f;
+            if (ok) for (int z = -1; z <= 2; ++z) for (int y = -1; y <= 2; ++y) { const float w = wy[y + 1] * wz[z + 1]; if (w == 0) continue; dv += ddata[(size_t)(kz + z) * T.alpha_samples + (ky + y)] * w; }
+            pool.push_back(std::min(1.0f, std::max(0.0f, dv)));   // RoughTransmittanceManager::EvaluateDiffuse clamps
+        }
+        if (!pool.empty()) { rt_reduced_.upload(pool.data(), pool.size()); S.rt_reduced = rt_reduced_.p; }
+        else for (auto& m : dmats) m.reserved_[0] = 0;
+    }
+    mats_.upload(dmats.data(), dmats.size());
     // which shade-kernel build this scene needs (kernels.hip launch_shade)
     S.shade_features = 0; S.alpha_maps = 0;
     for (uint32_t i = 0; i < d.n_lights_buf; i++) if (d.lights[i].type != CTL_LIGHT_POINT && d.lights[i].type != CTL_LIGHT_DIFFUSE) S.shade_features |= kShadeMoreLights;
