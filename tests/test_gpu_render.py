@@ -95,6 +95,28 @@ def test_synthetic_bathroom_workload(gpu, orc):
     assert want[..., :3].mean() > 0.1
 
 
+def test_queue_ordering_options_do_not_change_the_image(gpu, orc):
+    """SortMaterials (shade in BSDF-model order) and SortOctants (append new rays grouped by direction octant) only reorder work:
+    same frame (up to the order of the float atomics) and same ray count as the default order"""
+    sc = scenes.synthetic_bathroom(96, 54, n_instances=60, subdiv=2)
+    scene = gpu.Scene(sc.desc, flatten=True)
+    tables = orc.sequence_tables(3)
+    out = []
+    for params in (dict(), dict(SortMaterials=True), dict(SortOctants=True), dict(SortMaterials=True, SortOctants=True)):
+        tr = gpu.WavefrontPathTracer(); p = tr.getParameters(); p.setValue("MaxPathLength", 6)
+        for k, v in params.items():
+            p.setValue(k, v)
+        tr.Resize(96, 54); tr.InitializeScene(scene)
+        img = gpu.Image(96, 54)
+        for k in range(3):
+            tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
+        out.append((img.getPixelData(), tr.stats().rays_total))
+    for got, rays in out[1:]:
+        assert rays == out[0][1]
+        assert np.array_equal(got[..., 6], out[0][0][..., 6])
+        assert np.allclose(got[..., :3], out[0][0][..., :3], rtol=1e-5, atol=1e-5)
+
+
 def test_mitsuba_xml_scene(gpu, orc, tmp_path):
     """ParseMitsubaScene -> UpdateScene -> render: Cornell box + glass sphere authored as Mitsuba XML (BASELINE config 2 geometry)"""
     path = scenes.write_cornell_mitsuba(str(tmp_path), 64, 64, glass_sphere=True)
