@@ -694,6 +694,17 @@ class WavefrontPathTracer:
         self._scene = scene
         _check(lib.ctl_tracer_initialize_scene(self._h, scene._h))
 
+    def setBlockWeight(self, block_x, block_y, weight):
+        """IUserPreferenceSampler::setWeight of the tracer's block sampler (parameter BlockSamplerType); after Resize"""
+        _check(lib.ctl_tracer_set_block_weight(self._h, u32(block_x), u32(block_y), f32(weight)))
+
+    def getBlockCounts(self, width, height):
+        """samples per 64x64 block of the last rendered pass: (blocks_y, blocks_x) uint8"""
+        by, bx = (height + 63) // 64, (width + 63) // 64
+        a = np.zeros((by, bx), np.uint8)
+        _check(lib.ctl_tracer_get_block_counts(self._h, a.ctypes.data_as(C.c_void_p), u32(bx * by)))
+        return a
+
     def setTileShard(self, rank, world):
         _check(lib.ctl_tracer_set_tile_shard(self._h, u32(rank), u32(world)))
 

@@ -50,6 +50,8 @@ struct pass_params {
     int direct, max_path_length, rr_start_depth;
     int sort_materials;                  // shade in wave_queues::order
     int sort_octants;                    // append the new rays of a workgroup grouped by direction octant (compaction.h)
+    const unsigned char* block_counts;   // samples per 64x64 film block in this pass (a block sampler's decision), nullptr = one everywhere
+    uint32_t max_block_count;            // largest entry of block_counts
 };
 
 struct launch_ctx { hipStream_t stream; int grid_blocks; bool alpha_test = false; };   // alpha_test: intersect kernels run Material::AlphaTest on candidate hits

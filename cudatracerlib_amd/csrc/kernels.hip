@@ -23,11 +23,14 @@ __global__ __launch_bounds__(kWideBlock) void k_raygen(dev_scene S, wave_queues 
         const uint32_t pass_b = gi / P.n_local_pixels, li = gi - pass_b * P.n_local_pixels;
         const uint32_t tile = P.tile_rank + (li >> 12) * P.tile_world, p = li & 4095u, micro = p >> 6, lane = p & 63u;
         const uint32_t x = (tile % tiles_x) * 64 + (micro & 7u) * 8 + (lane & 7u), y = (tile / tiles_x) * 64 + (micro >> 3) * 8 + (lane >> 3);
-        const bool valid = x < P.width && y < P.height;
+        // BlockSamplerBuffer::getNumSamplesPerPixel (WavefrontPathTracer.cu:31-36): 0, 1 or more samples, all drawn from the pixel's one sampler
+        const uint32_t n_smp = P.block_counts ? P.block_counts[tile] : 1u, max_smp = P.block_counts ? P.max_block_count : 1u;
+        for (uint32_t smp = 0; smp < max_smp; smp++) {
+        const bool valid = x < P.width && y < P.height && smp < n_smp;
         const uint32_t slot = block_append3(&Q.counts[0], valid, nullptr, false, nullptr, false, s_cnt, s_base).s[0];
         if (!valid) continue;
         const uint32_t pixel = y * P.width + x;
-        sampler rng{ P.t1 + pass_b * n1, P.t2 + pass_b * n1, pixel, 0, 0 };
+        sampler rng{ P.t1 + pass_b * n1, P.t2 + pass_b * n1, pixel, 0, 2 * smp };
         const f2 j = rng.next2();
         const f2 pX{ (float)x + j.x, (float)y + j.y };
         (void)rng.next2();   // aperture sample, unused by the perspective sensor but drawn (PathTracer.cu:190)
@@ -40,6 +43,7 @@ __global__ __launch_bounds__(kWideBlock) void k_raygen(dev_scene S, wave_queues 
         A.nor[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng.d1 | (rng.d2 << 8) | (pass_b << 16) | (0u << 24)));
         A.pend[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kNoShadow));
         A.px[slot] = make_float2(pX.x, pX.y);
+        }
     }
 }
 

@@ -174,8 +174,11 @@ void PathTracer::Resize(unsigned int _w, unsigned int _h) {
     n_local_pixels = shard_pixel_count(_w, _h, shard_rank, shard_world);
     if (!count_.p) count_.alloc(1);
 }
+
 void PathTracer::DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) {
     if (m_sParameters.getValue("Regularization")) throw unsupported_error("PathTracer: Regularization is not implemented");
+    // the reference's megakernel renders a block once per mention by the sampler, i.e. the SAME sample twice; only the wavefront plugin honours block samplers here
+    if (pass_block_counts_) throw unsupported_error("PathTracer (megakernel): block samplers other than Uniform are served by the WavefrontPathTracer plugin only");
     pass_params P{};
     P.t1 = d_t1; P.t2 = (const float2*)d_t2; P.batch = n_batch; P.width = w; P.height = h; P.tile_rank = shard_rank; P.tile_world = shard_world; P.n_local_pixels = n_local_pixels;
     P.direct = m_sParameters.getValue("Direct"); P.max_path_length = m_sParameters.getValue("MaxPathLength"); P.rr_start_depth = m_sParameters.getValue("RRStartDepth");

@@ -6,6 +6,7 @@
 #include "device_scene.h"
 #include "kernels.h"
 #include "sequence_generator.h"
+#include "block_sampler.h"
 #include <hip/hip_runtime.h>
 #include <map>
 #include <string>
@@ -114,6 +115,10 @@ public:
     virtual void DoPasses(Image* I, bool a_NewTrace, unsigned int n) { for (unsigned int i = 0; i < n; i++) DoPass(I, a_NewTrace && i == 0); }
     void setTileShard(uint32_t rank, uint32_t world) { if (world == 0 || rank >= world) throw std::runtime_error("bad tile shard"); shard_rank = rank; shard_world = world; if (w != 0xffffffffu) Resize(w, h); }
     void setSamplerTables(const float* t1, const float* t2);
+    // IBlockSampler of Tracer<true> (Kernel/Tracer.h:151-152,181-190): chosen by the parameter BlockSamplerType (0 Uniform, 1 Variance,
+    // 2 Difference, 3 Select), re-created by Resize; user weights as IUserPreferenceSampler::setWeight
+    BlockSampler* getBlockSampler();
+    void setBlockWeight(uint32_t block_x, uint32_t block_y, float w) { getBlockSampler()->set_weight(block_x, block_y, w); }
     void getKernelStats(ctl_tracer_stats& s) const;
 protected:
     Scene* m_pScene = nullptr;
@@ -127,6 +132,7 @@ protected:
     sequence_generator m_SamplingSequenceGenerator;   // IndependantSamplingSequenceGenerator
     std::vector<float> user_t1, user_t2; bool have_user_tables = false;
     uint32_t shard_rank = 0, shard_world = 1;
+    std::unique_ptr<BlockSampler> block_sampler_; const unsigned char* pass_block_counts_ = nullptr; uint32_t pass_max_block_count_ = 1; uint64_t pass_paths_ = 0;
     event_timer timer; double kernel_ms[4] = { 0, 0, 0, 0 };   // 0 raygen, 1 closest-hit intersect, 2 shade/finalize, 3 any-hit intersect
     uint64_t intersect_rays = 0, intersect_launches = 0, shadow_rays = 0, shadow_launches = 0;
     bool counting = false; ctl_traversal_counts closest_counts{}, any_counts{};

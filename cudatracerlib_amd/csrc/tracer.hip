@@ -332,6 +332,9 @@ void event_timer::collect(double ms_out[4]) {
 // ------------------------------------------------------------------------------------------------ TracerBase / Tracer<true>
 TracerBase::TracerBase() {
     require_device();
+    m_sParameters.addInterval("BlockSamplerType", 0, 0, 3);          // Tracer.cpp:19 (BlockSamplerTypes::Uniform)
+    m_sParameters.addInterval("FractionDeterministic", 2, 1, INT_MAX);   // IBlockSampler.h:157-163 (the sampler's own parameter collection there)
+    m_sParameters.addInterval("FractionWeighted", 4, 1, INT_MAX);
     CTL_HIP(hipEventCreate(&start)); CTL_HIP(hipEventCreate(&stop));
     CTL_HIP(hipStreamCreate(&stream));
 }
@@ -339,6 +342,14 @@ TracerBase::~TracerBase() {
     if (start) (void)hipEventDestroy(start);
     if (stop) (void)hipEventDestroy(stop);
     if (stream) (void)hipStreamDestroy(stream);
+}
+BlockSampler* TracerBase::getBlockSampler() {   // setCorrectBlockSampler (Tracer.cpp:89-101)
+    if (w == 0xffffffffu) throw std::runtime_error("the block sampler exists once Resize was called");
+    const auto type = (BlockSampler::Type)m_sParameters.getValue("BlockSamplerType");
+    if (!block_sampler_ || block_sampler_->type() != type || block_sampler_->width() != w || block_sampler_->height() != h) block_sampler_.reset(new BlockSampler(type, w, h));
+    block_sampler_->fraction_deterministic = m_sParameters.getValue("FractionDeterministic");
+    block_sampler_->fraction_weighted = m_sParameters.getValue("FractionWeighted");
+    return block_sampler_.get();
 }
 void TracerBase::setSamplerTables(const float* t1, const float* t2) {
     const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH;
@@ -361,10 +372,15 @@ template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_
     if (I->getWidth() != w || I->getHeight() != h) throw std::runtime_error("DoPass: image size differs from the tracer size");
     if (n == 0) return;
     if (a_NewTrace || !PROGRESSIVE) { m_uPassesDone = 0; m_uAccNumRaysTraced = 0; m_fAccRuntime = 0; I->Clear(); }
+    // a block sampler that does not simply take every block once decides pass by pass, from the frame so far (Tracer.h:209-248)
+    BlockSampler* bs = (m_sParameters.getValue("BlockSamplerType") != 0 || block_sampler_) ? getBlockSampler() : nullptr;
+    const bool adaptive = bs && !bs->every_block_once();
+    if (adaptive && shard_world > 1) throw std::runtime_error("block samplers other than Uniform need the whole frame on one rank");
+    if (bs && (a_NewTrace || !PROGRESSIVE)) bs->start_new_rendering(stream);
     const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH, n2 = n1 * 2;
     // passes are rendered in batches of `B` (one wavefront carries the paths of B passes; each path uses its own pass's
     // tables), B chosen so that a launch holds enough paths to fill 256 CUs even when a rank owns 1/8 of the tiles
-    const unsigned int B = passBatch();
+    const unsigned int B = adaptive ? 1u : passBatch();
     const unsigned int ring = 2;   // batches in flight; slot reuse is guarded by an event per slot
     if (d_t1.n < n1 * ring * B) { d_t1.alloc(n1 * ring * B); d_t2.alloc(n2 * ring * B); }
     if (h_cap < n1 * ring * B) {   // pinned staging so that the uploads really are asynchronous
@@ -389,7 +405,16 @@ template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_
         CTL_HIP(hipMemcpyAsync(d_t1.p + (size_t)slot * B * n1, a, (size_t)nb * n1 * 4, hipMemcpyHostToDevice, stream));
         CTL_HIP(hipMemcpyAsync(d_t2.p + (size_t)slot * B * n2, b, (size_t)nb * n2 * 4, hipMemcpyHostToDevice, stream));
         m_uPassesDone += nb;
+        std::vector<unsigned char> block_counts;
+        pass_block_counts_ = nullptr; pass_max_block_count_ = 1;
+        if (adaptive) {
+            bs->counts(block_counts);
+            pass_block_counts_ = bs->upload_counts(block_counts, stream);
+            pass_max_block_count_ = 0; pass_paths_ = 0;
+            for (unsigned char c : block_counts) { pass_max_block_count_ = std::max<uint32_t>(pass_max_block_count_, c); pass_paths_ += (uint64_t)c * 4096u; }
+        }
         DoRender(I, d_t1.p + (size_t)slot * B * n1, d_t2.p + (size_t)slot * B * n2, nb);
+        if (adaptive) bs->add_pass(I->device(), getSplatScale(), block_counts, stream);   // PixelVarianceBuffer::AddPass + IBlockSampler::AddPass; synchronises
         CTL_HIP(hipEventRecord(slot_done[slot], stream));
         k += nb;
     }
@@ -488,6 +513,8 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     P.direct = direct ? 1 : 0; P.max_path_length = maxPathLength; P.rr_start_depth = rrStart;
     P.sort_materials = (m_sParameters.getValue("SortMaterials") != 0 && S.shade_features != 0) ? 1 : 0;
     P.sort_octants = m_sParameters.getValue("SortOctants") != 0 ? 1 : 0;
+    P.block_counts = pass_block_counts_; P.max_block_count = pass_max_block_count_;
+    if (pass_block_counts_ && pass_paths_ > capacity) throw std::runtime_error("ray queue overflow: the block sampler asks for more samples in one pass than the queues hold (DoubleRayBuffer.h:86-89)");
     if (P.sort_materials) CTL_HIP(hipMemsetAsync(mat_counts_.p, 0, n_mat * sizeof(uint32_t), stream));
     CTL_HIP(hipMemsetAsync(counts_.p, 0, n_counts * sizeof(uint32_t), stream));
     CTL_HIP(hipMemsetAsync(work_.p, 0, n_work * sizeof(uint32_t), stream));

@@ -401,6 +401,14 @@ typedef struct {
     ctl_traversal_counts closest_counts, any_counts;
 } ctl_tracer_stats;
 int ctl_tracer_get_stats(ctl_tracer* t, ctl_tracer_stats* out);
+/* Block samplers of Tracer<true> (Kernel/BlockSampler/, Kernel/Tracer.h:209-248; wavefront plugin only).  The int parameter
+ * "BlockSamplerType" selects Uniform (0, default), Variance (1), Difference (2) or Select (3); "FractionDeterministic" (2) and
+ * "FractionWeighted" (4) are the mixed-sampling settings of the Variance / Difference samplers.  Blocks are 64 x 64 pixels, indexed
+ * (block_x, block_y); ctl_tracer_set_block_weight = IUserPreferenceSampler::setWeight (call after ctl_tracer_resize).
+ * ctl_tracer_get_block_counts returns the samples per block (row-major, blocks_x = ceil(width / 64)) of the last rendered pass, all ones
+ * while the sampler takes every block once. */
+int ctl_tracer_set_block_weight(ctl_tracer* t, uint32_t block_x, uint32_t block_y, float weight);
+int ctl_tracer_get_block_counts(ctl_tracer* t, uint8_t* counts_out, uint32_t n_blocks);
 /* run the intersect kernels in counting mode (N_inner / N_tri / N_inst of SURVEY §8d); slower, for measurement only */
 int ctl_tracer_set_counting(ctl_tracer* t, int on);
 

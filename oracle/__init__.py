@@ -63,6 +63,7 @@ def load():
     o.orc_light_pdf_direct.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p]
     o.orc_env_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     o.orc_texture_eval.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
+    o.orc_set_block_counts.argtypes = [C.c_void_p, u32]
     o.orc_sample_normal_map.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p, C.c_void_p]
     o.orc_alpha_test.argtypes = [C.c_void_p, C.c_void_p, f32, f32]
     o.orc_triangle_data_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_int, C.c_void_p]
@@ -112,7 +113,7 @@ class Oracle:
             return hits, dict(n_inner=cnt[0], n_tri=cnt[1], n_inst=cnt[2])
         return hits
 
-    def render(self, desc, width, height, n_passes=1, tables=None, direct=True, max_path_length=8, rr_start=5, threads=8, rows=None, half_host_quirk=False, alpha_test=False):
+    def render(self, desc, width, height, n_passes=1, tables=None, direct=True, max_path_length=8, rr_start=5, threads=8, rows=None, half_host_quirk=False, alpha_test=False, block_counts=None):
         """pathKernel2<DIRECT,false> over all pixels (Integrators/PathTracer.cu:182-194). tables = list of (t1, t2) per pass or None.
         alpha_test: traceRay<USE_ALPHA> when the scene has alpha maps (what the reference's single-ray path does; its wavefront
         intersectKernel has no alpha test).
@@ -126,8 +127,15 @@ class Oracle:
             p1, p2 = t1.ctypes.data, t2.ctypes.data
         else:
             p1 = p2 = None
-        rays = self.lib.orc_render(C.addressof(desc), width, height, n_passes, p1, p2, 1 if direct else 0, max_path_length, rr_start,
-                                   img.ctypes.data, threads, y0, y1, (1 if half_host_quirk else 0) | (2 if alpha_test else 0))
+        if block_counts is not None:   # samples per 64x64 block for these passes (what a block sampler decided), row-major blocks
+            bc = np.ascontiguousarray(block_counts, np.uint8).ravel()
+            self.lib.orc_set_block_counts(bc.ctypes.data, (width + 63) // 64)
+        try:
+            rays = self.lib.orc_render(C.addressof(desc), width, height, n_passes, p1, p2, 1 if direct else 0, max_path_length, rr_start,
+                                       img.ctypes.data, threads, y0, y1, (1 if half_host_quirk else 0) | (2 if alpha_test else 0))
+        finally:
+            if block_counts is not None:
+                self.lib.orc_set_block_counts(None, 0)
         return img, int(rays)
 
     def sequence_tables(self, n_passes):

@@ -179,6 +179,9 @@ int orc_sample_normal_map(const ctl_scene_desc* desc, const ctl_material* mat, f
 int orc_alpha_test(const ctl_scene_desc* desc, const ctl_material* mat, float u, float v) { return materialAlphaTest(*mat, V2{ u, v }, desc ? desc->images : nullptr) ? 1 : 0; }
 
 // ---- full render: pathKernel2<DIRECT,false> looped over all pixels (Integrators/PathTracer.cu:182-194) ---------
+// samples per 64x64 block for the following orc_render calls (a block sampler's decision for one pass); NULL = one sample everywhere
+static const uint8_t* g_block_counts = nullptr; static uint32_t g_blocks_x = 0;
+void orc_set_block_counts(const uint8_t* counts, uint32_t blocks_x) { g_block_counts = counts; g_blocks_x = blocks_x; }
 // tables: n_passes consecutive (t1[30*4096], t2[30*4096*2]) pairs, or NULL -> own SequenceGenerator
 // (one Compute() per pass, as Tracer<true>::DoPass -> UpdateKernel does, Kernel/Tracer.h:229).
 // Renders rows [y0,y1) only (bounded CPU-baseline samples).  Returns the number of rays traced.
@@ -204,8 +207,11 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
             for (;;) {
                 uint32_t y = nextRow.fetch_add(1);
                 if (y >= y1) break;
-                for (uint32_t x = 0; x < W; x++) {
+                for (uint32_t x = 0; x < W; x++)
+                for (uint32_t smp = 0, n_smp = g_block_counts ? g_block_counts[(y / 64) * g_blocks_x + x / 64] : 1u; smp < n_smp; smp++) {
+                    // BlockSamplerBuffer::getNumSamplesPerPixel (WavefrontPathTracer.cu:31-36): the samples of a pixel in one pass continue one sampler
                     Sampler rng(t1, t2, y * W + x);   // TracerBase::getPixelIndex
+                    rng.d2 = 2 * smp;
                     V2 j = rng.randomFloat2();
                     V2 pX{ (float)x + j.x, (float)y + j.y };
                     V2 ap = rng.randomFloat2(); (void)ap;
