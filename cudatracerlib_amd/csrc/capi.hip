@@ -157,6 +157,7 @@ int ctl_tracer_set_tile_shard(ctl_tracer* t, uint32_t rank, uint32_t world) { CT
 int ctl_tracer_set_sampler_tables(ctl_tracer* t, const float* tables_1d, const float* tables_2d) { CTL_REQUIRE(t && tables_1d && tables_2d, "null argument"); CTL_TRY t->t->setSamplerTables(tables_1d, tables_2d); CTL_CATCH }
 int ctl_tracer_do_pass(ctl_tracer* t, ctl_image* img, int new_trace) { CTL_REQUIRE(t && img, "null argument"); CTL_TRY t->t->DoPass(&img->img, new_trace != 0); CTL_CATCH }
 int ctl_tracer_do_passes(ctl_tracer* t, ctl_image* img, int new_trace, uint32_t n_passes) { CTL_REQUIRE(t && img, "null argument"); CTL_TRY t->t->DoPasses(&img->img, new_trace != 0, n_passes); CTL_CATCH }
+int ctl_tracer_reserve_passes(ctl_tracer* t, uint32_t n) { CTL_REQUIRE(t, "null tracer"); CTL_TRY t->t->reservePasses(n); CTL_CATCH }
 int ctl_tracer_set_block_weight(ctl_tracer* t, uint32_t bx, uint32_t by, float w) { CTL_REQUIRE(t, "null tracer"); CTL_TRY t->t->setBlockWeight(bx, by, w); CTL_CATCH }
 int ctl_tracer_get_block_counts(ctl_tracer* t, uint8_t* out, uint32_t n) {
     CTL_REQUIRE(t && out, "null argument");

@@ -113,6 +113,7 @@ public:
     TracerParameterCollection& getParameters() { return m_sParameters; }
     // build-specific additions
     virtual void DoPasses(Image* I, bool a_NewTrace, unsigned int n) { for (unsigned int i = 0; i < n; i++) DoPass(I, a_NewTrace && i == 0); }
+    virtual void reservePasses(unsigned int n) { (void)n; }   // size the queues now for a DoPasses(n) to come (otherwise they grow inside that call)
     void setTileShard(uint32_t rank, uint32_t world) { if (world == 0 || rank >= world) throw std::runtime_error("bad tile shard"); shard_rank = rank; shard_world = world; if (w != 0xffffffffu) Resize(w, h); }
     void setSamplerTables(const float* t1, const float* t2);
     // IBlockSampler of Tracer<true> (Kernel/Tracer.h:151-152,181-190): chosen by the parameter BlockSamplerType (0 Uniform, 1 Variance,
@@ -154,6 +155,8 @@ protected:
     float *h_t1 = nullptr, *h_t2 = nullptr; size_t h_cap = 0;   // their pinned host staging
     std::vector<hipEvent_t> slot_done;
     virtual unsigned int passBatch() const { return 1; }
+    static constexpr unsigned int kTableRing = 2;
+    void ensureTableRing(unsigned int B);   // device + pinned host staging for `kTableRing` batches of B passes
 public:
     ~Tracer() override { if (h_t1) (void)hipHostFree(h_t1); if (h_t2) (void)hipHostFree(h_t2); for (auto e : slot_done) (void)hipEventDestroy(e); }
 };
@@ -163,13 +166,14 @@ class WavefrontPathTracer : public Tracer<true> {
 public:
     WavefrontPathTracer();
     void Resize(unsigned int w, unsigned int h) override;
+    void reservePasses(unsigned int n) override { const unsigned int b = std::min(passBatch(), std::max(1u, n)); if (w != 0xffffffffu && (uint64_t)n_local_pixels * b > capacity) { alloc_batch_ = b; Resize(w, h); } ensureTableRing(b); }
 protected:
     void DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) override;
     void takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) override;
     unsigned int passBatch() const override;
 private:
     wave_queues Q{};
-    uint32_t capacity = 0, n_local_pixels = 0;
+    uint32_t capacity = 0, n_local_pixels = 0, alloc_batch_ = 1;
     std::vector<std::unique_ptr<dbuf<float4>>> f4_; dbuf<float2> px_[3]; dbuf<int> hit_node_; dbuf<uint32_t> occ_[2], counts_, work_, order_, mat_counts_; dbuf<unsigned char> mat_key_; dbuf<unsigned long long> stats_;
     int grid_blocks = 0;
     float4* new_f4(size_t n);

@@ -366,6 +366,17 @@ void TracerBase::getKernelStats(ctl_tracer_stats& s) const {
 // Tracer<true>::DoPass (Kernel/Tracer.h:209-248), generalised to n passes per call.  As in the reference the host
 // regenerates the sampling tables once per pass (UpdateKernel -> SamplingSequenceGeneratorHost::Compute); here the
 // generation of pass k+1 overlaps the GPU work of pass k because nothing in a pass synchronises with the host.
+template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::ensureTableRing(unsigned int B) {
+    const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH, n2 = n1 * 2;
+    const unsigned int ring = kTableRing;
+    if (d_t1.n < n1 * ring * B) { d_t1.alloc(n1 * ring * B); d_t2.alloc(n2 * ring * B); }
+    if (h_cap < n1 * ring * B) {   // pinned staging so that the uploads really are asynchronous
+        if (h_t1) { (void)hipHostFree(h_t1); (void)hipHostFree(h_t2); h_t1 = h_t2 = nullptr; }
+        CTL_HIP(hipHostMalloc((void**)&h_t1, n1 * ring * B * sizeof(float))); CTL_HIP(hipHostMalloc((void**)&h_t2, n2 * ring * B * sizeof(float)));
+        h_cap = n1 * ring * B;
+    }
+    if (slot_done.empty()) { slot_done.resize(ring); for (auto& e : slot_done) CTL_HIP(hipEventCreate(&e)); }
+}
 template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_NewTrace, unsigned int n) {
     if (!m_pScene) throw std::runtime_error("DoPass: InitializeScene was not called");
     if (w == 0xffffffffu) throw std::runtime_error("DoPass: Resize was not called");
@@ -380,15 +391,9 @@ template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_
     const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH, n2 = n1 * 2;
     // passes are rendered in batches of `B` (one wavefront carries the paths of B passes; each path uses its own pass's
     // tables), B chosen so that a launch holds enough paths to fill 256 CUs even when a rank owns 1/8 of the tiles
-    const unsigned int B = adaptive ? 1u : passBatch();
-    const unsigned int ring = 2;   // batches in flight; slot reuse is guarded by an event per slot
-    if (d_t1.n < n1 * ring * B) { d_t1.alloc(n1 * ring * B); d_t2.alloc(n2 * ring * B); }
-    if (h_cap < n1 * ring * B) {   // pinned staging so that the uploads really are asynchronous
-        if (h_t1) { (void)hipHostFree(h_t1); (void)hipHostFree(h_t2); h_t1 = h_t2 = nullptr; }
-        CTL_HIP(hipHostMalloc((void**)&h_t1, n1 * ring * B * sizeof(float))); CTL_HIP(hipHostMalloc((void**)&h_t2, n2 * ring * B * sizeof(float)));
-        h_cap = n1 * ring * B;
-    }
-    if (slot_done.empty()) { slot_done.resize(ring); for (auto& e : slot_done) CTL_HIP(hipEventCreate(&e)); }
+    const unsigned int B = adaptive ? 1u : std::min(passBatch(), n);
+    const unsigned int ring = kTableRing;   // batches in flight; slot reuse is guarded by an event per slot
+    ensureTableRing(B);
     for (int i = 0; i < 4; i++) kernel_ms[i] = 0;
     intersect_rays = intersect_launches = shadow_rays = shadow_launches = 0;
     CTL_HIP(hipEventRecord(start, stream));
@@ -437,7 +442,7 @@ WavefrontPathTracer::WavefrontPathTracer() {
     m_sParameters.addInterval("MaxPathLength", 50, 1, INT_MAX);
     m_sParameters.addInterval("RRStartDepth", 5, 1, INT_MAX);
     // build-specific: passes rendered together in one wavefront; 0 = choose so that a launch carries >= ~4 M paths
-    m_sParameters.addInterval("PassBatch", 0, 0, 64);
+    m_sParameters.addInterval("PassBatch", 0, 0, 128);
     // build-specific: run Material::AlphaTest on candidate hits.  Off = the reference's wavefront tracer (its intersectKernel has no
     // alpha test, only the single-ray traceRay of the megakernel integrators does, TraceHelper.cu:135-153)
     m_sParameters.addBool("AlphaTest", false);
@@ -457,7 +462,7 @@ void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
     Tracer<true>::Resize(_w, _h);
     // DoubleRayBuffer(w*h, w*h) (WavefrontPathTracer.h:59) — here per rank: its tile shard's pixels
     n_local_pixels = shard_pixel_count(_w, _h, shard_rank, shard_world);
-    capacity = n_local_pixels * passBatch();
+    capacity = n_local_pixels * std::max(1u, alloc_batch_);   // grown by DoRender when a larger batch arrives
     f4_.clear();
     for (int b = 0; b < 2; b++) {
         path_soa& p = Q.path[b];
@@ -491,12 +496,15 @@ unsigned int WavefrontPathTracer::passBatch() const {
     if (v > 0) return (unsigned int)v;
     if (w == 0xffffffffu) return 1;
     const uint64_t per_pass = shard_pixel_count(w, h, shard_rank, shard_world);
-    const uint64_t target = 4u << 20;
-    return (unsigned int)std::min<uint64_t>(64, std::max<uint64_t>(1, (target + per_pass - 1) / per_pass));
+    // Paths per launch.  Measured on MI355X (tools/passbatch_probe.py, synthetic-SM 1080p): 2 M paths per launch 1.04 Grays/s, 4 M 1.50, 8 M 1.88,
+    // 33 M 2.33, 67 M 2.45, 134 M 2.51 — the deep bounces of a wavefront hold a small fraction of its paths, and only a large wavefront
+    // keeps 256 CUs x 32 waves busy there.  ~350 B of queue state per path: 64 M paths = 22 GB of the 288 GB.
+    const uint64_t target = 64u << 20;
+    return (unsigned int)std::min<uint64_t>(128, std::max<uint64_t>(1, (target + per_pass - 1) / per_pass));
 }
 
 void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_t2p, unsigned int n_batch) {
-    if ((uint64_t)n_local_pixels * n_batch > capacity) Resize(w, h);   // PassBatch was raised after Resize
+    if ((uint64_t)n_local_pixels * n_batch > capacity) { alloc_batch_ = n_batch; Resize(w, h); }   // the queues grow to the largest batch asked for
     const int maxPathLength = m_sParameters.getValue("MaxPathLength"), rrStart = m_sParameters.getValue("RRStartDepth");
     const bool direct = m_sParameters.getValue("Direct") != 0;
     const size_t n_counts = (size_t)(maxPathLength + 2) * 4, n_work = (size_t)2 * (maxPathLength + 2);

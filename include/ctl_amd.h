@@ -407,6 +407,8 @@ int ctl_tracer_get_stats(ctl_tracer* t, ctl_tracer_stats* out);
  * (block_x, block_y); ctl_tracer_set_block_weight = IUserPreferenceSampler::setWeight (call after ctl_tracer_resize).
  * ctl_tracer_get_block_counts returns the samples per block (row-major, blocks_x = ceil(width / 64)) of the last rendered pass, all ones
  * while the sampler takes every block once. */
+/* Build-specific: allocate the ray queues now for a ctl_tracer_do_passes(n) to come; without it they grow inside that call. */
+int ctl_tracer_reserve_passes(ctl_tracer* t, uint32_t n_passes);
 int ctl_tracer_set_block_weight(ctl_tracer* t, uint32_t block_x, uint32_t block_y, float weight);
 int ctl_tracer_get_block_counts(ctl_tracer* t, uint8_t* counts_out, uint32_t n_blocks);
 /* run the intersect kernels in counting mode (N_inner / N_tri / N_inst of SURVEY §8d); slower, for measurement only */

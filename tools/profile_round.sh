@@ -8,7 +8,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 8 --warmup 2 --no-cpu-baseline"
+ARGS="--no-cpu-baseline"   # bench.py defaults (64 steps, 2 warm-up): the profiled launches are the ones the JSON line is about
 timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o p -- python bench.py $ARGS > "$OUT/stats.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do

@@ -45,3 +45,19 @@ for world in args.world:
         base = dt
     print("world %d: rank-0 share of %d passes in %7.2f ms (%.1f Mrays/s on this rank, x%.2f vs world 1; intersect %.1f shade %.1f ms)"
           % (world, args.steps, dt * 1e3, st.rays_last_pass / dt / 1e6, base / dt, st.ms_intersect + st.ms_intersect_any, st.ms_shade), flush=True)
+
+# load balance: every rank of the largest world in turn (the N-GPU job ends when its slowest rank does)
+world = max(args.world)
+times, rays = [], []
+for rank in range(world):
+    tr = ctl.WavefrontPathTracer()
+    tr.getParameters().setValue("MaxPathLength", 8)
+    tr.setTileShard(rank, world); tr.Resize(1920, 1080); tr.InitializeScene(scene)
+    img = ctl.Image(1920, 1080)
+    tr.DoPasses(img, 2, new_trace=True)
+    t = time.perf_counter()
+    tr.DoPasses(img, args.steps, new_trace=False)
+    times.append((time.perf_counter() - t) * 1e3); rays.append(tr.stats().rays_last_pass)
+print("world %d per-rank ms: %s" % (world, " ".join("%.1f" % x for x in times)))
+print("world %d per-rank Mrays: %s" % (world, " ".join("%.1f" % (x / 1e6) for x in rays)))
+print("slowest / mean = %.3f  -> strong-scaling ceiling from tile imbalance %.1f %%" % (max(times) / np.mean(times), 100 * np.mean(times) / max(times)))

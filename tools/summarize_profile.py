@@ -63,7 +63,7 @@ def main():
         json.dump({"tag": tag, "kernel": k, "launches_profiled": L,
                    "fetch_bytes_per_launch_raw": r.get("FETCH_SIZE", 0) * 1024 / L, "write_bytes_per_launch": r.get("WRITE_SIZE", 0) * 1024 / L,
                    "k_intersect_closest_bytes_per_launch": (2 * r.get("FETCH_SIZE", 0) + r.get("WRITE_SIZE", 0)) * 1024 / L,
-                   "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes) per launch; launches in the profiled run trace 2 passes each (PassBatch auto), same as bench.py"},
+                   "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes) per launch; averaged over every closest-hit launch of the profiled `python bench.py --no-cpu-baseline` run (its warm-up launches carry 2 passes, the timed ones 32)"},
                   open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
     print(open(out).read())
 
