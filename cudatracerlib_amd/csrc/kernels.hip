@@ -120,6 +120,7 @@ void apply_tuning_from_env() {
     done = true;
     if (const char* e = getenv("CTL_REFILL_IDLE")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refill_idle), &v, sizeof(v)); }
     if (const char* e = getenv("CTL_ANY_SORTED")) { int v = atoi(e) != 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_any_sorted), &v, sizeof(v)); }
+    if (const char* e = getenv("CTL_CHUNK_GUIDED")) { int v = atoi(e) != 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chunk_guided), &v, sizeof(v)); }
     if (const char* e = getenv("CTL_TRI_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tri_batch), &v, sizeof(v)); }
 }
 

@@ -27,7 +27,19 @@ __device__ int g_tri_batch = 1;      // flat kernel: leaf entries are tested onc
                                      // memory-latency bound and every waiting lane is a load not in flight; kept as a knob (CTL_TRI_BATCH)
 __device__ int g_any_sorted = 0;     // flat kernel, any-hit: visit hit children nearest-first instead of in slot order (CTL_ANY_SORTED)
 __device__ int g_refill_idle = 12;   // refill as soon as this many lanes of the wave are idle (CTL_REFILL_IDLE overrides)
-constexpr uint32_t kChunk = 512;     // rays claimed from the global cursor per atomic
+constexpr uint32_t kChunk = 512;     // most rays a wave claims from the global cursor per atomic
+__device__ int g_chunk_guided = 1;   // 1: claims shrink with the rays that are left (guided_chunk); 0: always kChunk (CTL_CHUNK_GUIDED=0)
+
+// Rays a wave claims next.  A fixed claim of 512 costs a launch ~0.5 ms whatever its size: at the start every one of the 8192 resident waves
+// claims 512 rays (a launch of 2 M rays keeps half of the waves idle while the others work through eight rounds of rays), and at the end
+// the wave with the last claim runs on alone.  Guided self-scheduling instead: a claim is the share of the REMAINING rays (as this wave last
+// saw the cursor) that would keep every wave supplied for two more claims, between 64 and kChunk, in whole waves of 64.
+__device__ __forceinline__ uint32_t guided_chunk(uint32_t n, uint32_t last_base) {
+    if (!g_chunk_guided) return kChunk;
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6), left = n > last_base ? n - last_base : 0u;
+    const uint32_t c = (left / (2u * waves)) & ~63u;
+    return c < 64u ? 64u : (c > kChunk ? kChunk : c);
+}
 
 __device__ __forceinline__ float rcp_guarded(float d) {   // TraceHelper.cu:417-420: 1/(|d| > 2^-80 ? d : copysign(2^-80, d))
     const float ooeps = 8.271806125530277e-25f;   // exp2(-80)
@@ -92,10 +104,11 @@ __device__ __forceinline__ void intersect_persistent(const dev_scene& S, const f
         const unsigned long long idle = __ballot(!has_ray);
         if (idle != 0ull && !exhausted && (__popcll(idle) >= refill_idle || idle == ~0ull)) {
             if (chunk_next >= chunk_end) {
+                const uint32_t claim = guided_chunk(n, chunk_end);
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work, kChunk);
+                if (lane == 0) base = atomicAdd(work, claim);
                 base = __shfl(base, 0, 64);
-                chunk_next = base; chunk_end = base + kChunk < n ? base + kChunk : n;
+                chunk_next = base; chunk_end = base + claim < n ? base + claim : n;
                 if (base >= n) { exhausted = true; chunk_next = chunk_end = n; }
             }
             if (!exhausted) {
@@ -221,10 +234,11 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
         const unsigned long long idle = __ballot(!has_ray);
         if (idle != 0ull && !exhausted && (__popcll(idle) >= refill_idle || idle == ~0ull)) {
             if (chunk_next >= chunk_end) {
+                const uint32_t claim = guided_chunk(n, chunk_end);
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work, kChunk);
+                if (lane == 0) base = atomicAdd(work, claim);
                 base = __shfl(base, 0, 64);
-                chunk_next = base; chunk_end = base + kChunk < n ? base + kChunk : n;
+                chunk_next = base; chunk_end = base + claim < n ? base + claim : n;
                 if (base >= n) { exhausted = true; chunk_next = chunk_end = n; }
             }
             if (!exhausted) {

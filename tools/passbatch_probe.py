@@ -5,7 +5,9 @@ from cudatracerlib_amd import scenes, api
 api.set_cache_dir('/tmp/ctl_amd_cache')
 sc = scenes.synthetic_sm(1920, 1080, n_instances=2000)
 scene = ctl.Scene(sc.desc, flatten=True)
-for world, pbs in ((1, (8, 16, 32, 64)), (2, (16, 32, 64)), (4, (32, 64))):
+# usage: passbatch_probe.py [world:pb,pb,... ...]   (default: the sweep quoted in DESIGN.md)
+cases = [(int(a.split(':')[0]), tuple(int(x) for x in a.split(':')[1].split(','))) for a in sys.argv[1:]] or [(1, (8, 16, 32, 64)), (2, (16, 32, 64)), (4, (32, 64))]
+for world, pbs in cases:
     for pb in pbs:
         tr = ctl.WavefrontPathTracer(); p = tr.getParameters(); p.setValue("MaxPathLength", 8); p.setValue("PassBatch", pb)
         tr.setTileShard(0, world); tr.Resize(1920, 1080); tr.InitializeScene(scene)
