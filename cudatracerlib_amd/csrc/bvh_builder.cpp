@@ -22,6 +22,7 @@ struct builder {
     std::vector<tmp_node> pool;
     std::atomic<int> pool_used{ 0 };
     int max_leaf, depth_limit;
+    float node_cost = 1.0f;   // SAH cost of visiting a node, in triangle tests
     std::atomic<int> max_depth{ 0 };
 
     explicit builder(const std::vector<aabb>& b, int ml, int dl) : boxes(b), max_leaf(ml), depth_limit(dl) {
@@ -104,7 +105,7 @@ struct builder {
             }
         }
         float area = nd.box.area();
-        float leaf_cost = area * n, split_cost = area * 1.0f + best_cost;   // SAH node cost 1, triangle cost 1 (SplitBVHBuilder.hpp Platform defaults)
+        float leaf_cost = area * n, split_cost = area * node_cost + best_cost;   // SAH node cost 1, triangle cost 1 (SplitBVHBuilder.hpp Platform defaults)
         if (!force_median && (int)n <= max_leaf && (best_axis < 0 || leaf_cost <= split_cost)) return me;   // leaf
         uint32_t mid;
         if (best_axis >= 0 && !force_median) {
@@ -175,10 +176,11 @@ struct emitter {
 
 } // namespace
 
-void build_bvh(const std::vector<aabb>& prim_boxes, int max_leaf, bool wrap_single_leaf, int max_depth_limit, bvh_result& out) {
+void build_bvh(const std::vector<aabb>& prim_boxes, int max_leaf, bool wrap_single_leaf, int max_depth_limit, bvh_result& out, float node_cost) {
     out.nodes.clear(); out.leaf_prims.clear(); out.leaf_last.clear(); out.root = 0; out.max_depth = 0;
     if (prim_boxes.empty()) { out.root = kEmptyChild; return; }
     builder B(prim_boxes, max_leaf, max_depth_limit);
+    B.node_cost = node_cost;
     int budget = 0; while ((1u << (budget + 1)) <= std::max(1u, std::thread::hardware_concurrency()) && budget < 6) budget++;   // <= 64 threads
     int root = B.build(0, (uint32_t)prim_boxes.size(), 0, std::max(budget, 3));
     out.max_depth = B.max_depth.load();

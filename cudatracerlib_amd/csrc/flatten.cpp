@@ -20,6 +20,12 @@ namespace ctl {
 
 namespace {
 
+// builder settings of the world-space BVH; the environment overrides are measurement knobs (tools/flat_build_probe.sh).  SAH node cost 0.5:
+// a 4-wide node covers two levels of the binary tree in one fetch + one loop iteration, a leaf entry costs one of each per triangle.
+// Measured on synthetic-SM: node cost 1 -> 34.0 nodes + 8.45 triangles per ray, 0.5 -> 35.3 + 6.28 and +1 % rays/s; leaf size 2 / 4 / 8: no difference
+int flat_max_leaf() { static const int v = [] { const char* e = getenv("CTL_FLAT_MAX_LEAF"); const int x = e ? atoi(e) : 0; return x >= 1 && x <= 16 ? x : 4; }(); return v; }
+float flat_node_cost() { static const float v = [] { const char* e = getenv("CTL_FLAT_NODE_COST"); const float x = e ? (float)atof(e) : 0.0f; return x > 0.0f ? x : 0.5f; }(); return v; }
+
 // 4x4 inverse in double (cofactor expansion)
 bool inv4(const double m[16], double out[16]) {
     double inv[16];
@@ -110,8 +116,8 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node width only
     std::string key;
     if (!cache_dir().empty()) {
-        content_hash H; const uint32_t version = 1;
-        H.add_value(version); H.add_value(out.width); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
+        content_hash H; const uint32_t version = 2;
+        H.add_value(version); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.width); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
         for (uint32_t k = 0; k < d.n_nodes; k++) { H.add_value(d.nodes[k].mesh_index); H.add(d.node_transforms[k].m, 64); }
@@ -155,7 +161,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     }, 1);
     pt.lap("world triangles");
     bvh_result R;
-    build_bvh(boxes, 4, true, 60, R);
+    build_bvh(boxes, flat_max_leaf(), true, 60, R, flat_node_cost());
     pt.lap("build BVH2");
     // quantise a child box conservatively against the node's own box (one exponent per axis)
     auto quantise = [&](const aabb& nbox, const aabb* cbox, int n, float origin[3], uint8_t e_out[3], uint8_t qlo[3][8], uint8_t qhi[3][8]) {

@@ -60,10 +60,17 @@ def main():
     dom = [k for k in rows if k.startswith("k_intersect<false, false")]
     if dom:
         k = max(dom, key=lambda k: rows[k].get("FETCH_SIZE", 0)); r = rows[k]; L = max(1, r.get("launches", 1))
-        json.dump({"tag": tag, "kernel": k, "launches_profiled": L,
-                   "fetch_bytes_per_launch_raw": r.get("FETCH_SIZE", 0) * 1024 / L, "write_bytes_per_launch": r.get("WRITE_SIZE", 0) * 1024 / L,
-                   "k_intersect_closest_bytes_per_launch": (2 * r.get("FETCH_SIZE", 0) + r.get("WRITE_SIZE", 0)) * 1024 / L,
-                   "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes) per launch; averaged over every closest-hit launch of the profiled `python bench.py --no-cpu-baseline` run (its warm-up launches carry 2 passes, the timed ones 32)"},
+        # The profiled run's launches are not all alike (warm-up launches carry 2 passes, timed ones up to 32): per-launch figures are quoted for
+        # a TIMED launch = bytes per ray of the whole run x the rays of one timed launch (bench.json of the same tag).
+        b = json.load(open(os.path.join(src, "bench.json"))); rf = b["roofline"]
+        rays_run = rf["rays_per_launch"] * rf["launches"] * (b["steps"] + b["warmup"]) / b["steps"]
+        fe_ray, wr_ray = r.get("FETCH_SIZE", 0) * 1024 / rays_run, r.get("WRITE_SIZE", 0) * 1024 / rays_run
+        R = rf["rays_per_launch"]
+        json.dump({"tag": tag, "kernel": k, "launches_profiled": L, "rays_profiled": rays_run, "rays_per_timed_launch": R,
+                   "fetch_bytes_per_ray_raw": fe_ray, "write_bytes_per_ray": wr_ray,
+                   "fetch_bytes_per_launch_raw": fe_ray * R, "write_bytes_per_launch": wr_ray * R,
+                   "k_intersect_closest_bytes_per_launch": (2 * fe_ray + wr_ray) * R,
+                   "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), per ray over every closest-hit launch of the profiled `python bench.py --no-cpu-baseline` run, times the rays of one timed launch"},
                   open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
     print(open(out).read())
 
