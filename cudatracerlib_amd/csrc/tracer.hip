@@ -441,7 +441,7 @@ WavefrontPathTracer::WavefrontPathTracer() {
     m_sParameters.addBool("Direct", true);
     m_sParameters.addInterval("MaxPathLength", 50, 1, INT_MAX);
     m_sParameters.addInterval("RRStartDepth", 5, 1, INT_MAX);
-    // build-specific: passes rendered together in one wavefront; 0 = choose so that a launch carries >= ~4 M paths
+    // build-specific: passes rendered together in one wavefront; 0 = choose so that a launch carries ~64 M paths (passBatch())
     m_sParameters.addInterval("PassBatch", 0, 0, 128);
     // build-specific: run Material::AlphaTest on candidate hits.  Off = the reference's wavefront tracer (its intersectKernel has no
     // alpha test, only the single-ray traceRay of the megakernel integrators does, TraceHelper.cu:135-153)
@@ -497,8 +497,8 @@ unsigned int WavefrontPathTracer::passBatch() const {
     if (w == 0xffffffffu) return 1;
     const uint64_t per_pass = shard_pixel_count(w, h, shard_rank, shard_world);
     // Paths per launch.  Measured on MI355X (tools/passbatch_probe.py, synthetic-SM 1080p): 2 M paths per launch 1.04 Grays/s, 4 M 1.50, 8 M 1.88,
-    // 33 M 2.33, 67 M 2.45, 134 M 2.51 — the deep bounces of a wavefront hold a small fraction of its paths, and only a large wavefront
-    // keeps 256 CUs x 32 waves busy there.  ~350 B of queue state per path: 64 M paths = 22 GB of the 288 GB.
+    // 33 M 2.33, 67 M 2.45, 134 M 2.51 — the persistent traversal kernels keep 524 k rays in flight and every launch pays a ramp and a
+    // tail of a few hundred us, so small launches are mostly ramp and tail.  ~350 B of queue state per path: 64 M paths = 22 GB of the 288 GB.
     const uint64_t target = 64u << 20;
     return (unsigned int)std::min<uint64_t>(128, std::max<uint64_t>(1, (target + per_pass - 1) / per_pass));
 }
