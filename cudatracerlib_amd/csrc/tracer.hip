@@ -405,8 +405,9 @@ template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_
         unsigned int j0 = 0;
         if (have_user_tables) { std::memcpy(a, user_t1.data(), n1 * 4); std::memcpy(b, user_t2.data(), n2 * 4); have_user_tables = false; j0 = 1; }
         // one XORWOW stream as in the reference (Kernel/Sampler.h:57-85), generated by several host threads through skip-ahead:
-        // a rank that owns 1/8 of the frame renders 16 passes per launch and must not wait 16 ms for its tables
-        m_SamplingSequenceGenerator.compute_many(a + j0 * n1, b + j0 * n2, nb - j0, n1, n2, std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+        // the first batch of a call cannot overlap with rendering, and a rank that owns 1/8 of the frame renders 64 passes in 75 ms: one thread
+        // per pass (measured: 16 threads left 4-5 ms of every DoPasses call to table generation)
+        m_SamplingSequenceGenerator.compute_many(a + j0 * n1, b + j0 * n2, nb - j0, n1, n2, std::min(64u, std::max(1u, std::thread::hardware_concurrency())));
         CTL_HIP(hipMemcpyAsync(d_t1.p + (size_t)slot * B * n1, a, (size_t)nb * n1 * 4, hipMemcpyHostToDevice, stream));
         CTL_HIP(hipMemcpyAsync(d_t2.p + (size_t)slot * B * n2, b, (size_t)nb * n2 * 4, hipMemcpyHostToDevice, stream));
         m_uPassesDone += nb;

@@ -26,7 +26,8 @@ __device__ int g_tri_batch = 1;      // flat kernel: leaf entries are tested onc
                                      // (gpurun_out/tune_tri.log): batching leaves LOSES (973 -> 835 Mrays/s from 1 to 40) — the kernel is
                                      // memory-latency bound and every waiting lane is a load not in flight; kept as a knob (CTL_TRI_BATCH)
 __device__ int g_any_sorted = 0;     // flat kernel, any-hit: visit hit children nearest-first instead of in slot order (CTL_ANY_SORTED)
-__device__ int g_refill_idle = 12;   // refill as soon as this many lanes of the wave are idle (CTL_REFILL_IDLE overrides)
+__device__ int g_refill_idle = 20;   // refill as soon as this many lanes of the wave are idle (CTL_REFILL_IDLE overrides; measured 4: 2386, 8: 2433,
+                                     // 12: 2466, 20: 2483, 32: 2473 Mrays/s on synthetic-SM)
 constexpr uint32_t kChunk = 512;     // most rays a wave claims from the global cursor per atomic
 __device__ int g_chunk_guided = 1;   // 1: claims shrink with the rays that are left (guided_chunk); 0: always kChunk (CTL_CHUNK_GUIDED=0)
 
