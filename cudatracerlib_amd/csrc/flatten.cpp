@@ -85,6 +85,17 @@ template <typename F> void parallel_for(size_t n, const F& f, size_t min_chunk =
     for (size_t t = 0; t < nt; t++) th.emplace_back([&, t]() { f(n * t / nt, n * (t + 1) / nt); });
     for (auto& x : th) x.join();
 }
+// child links and leaf ranges of a tree read back from the cache: every link must land inside the arrays before they reach the GPU
+bool flat_links_valid(const flat_scene& F) {
+    const size_t nl = F.leaves.size();
+    auto ok = [&](int32_t c, size_t n_nodes, int unit) {
+        if (c >= 0) return c % unit == 0 && (size_t)(c / unit) < n_nodes;
+        return (size_t)(~c) < nl;
+    };
+    if (F.width == 8) { for (const auto& n : F.nodes8) for (int c = 0; c < 8; c++) if (((n.mask >> c) & 1) && !ok(n.child[c], F.nodes8.size(), 8)) return false; }
+    else for (const auto& n : F.nodes) for (int c = 0; c < 4; c++) if (((n.mask >> c) & 1) && !ok(n.child[c], F.nodes.size(), 4)) return false;
+    return nl > 0 && (F.leaves[nl - 1].index & 1u);   // the last entry closes its leaf
+}
 float round_down(double x) { float f = (float)x; return ((double)f > x) ? std::nextafterf(f, -INFINITY) : f; }
 float round_up(double x) { float f = (float)x; return ((double)f < x) ? std::nextafterf(f, INFINITY) : f; }
 
@@ -124,8 +135,8 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
         key = H.hex();
         cache_reader rd("flat", key);
         int c_width = 0, c_depth = 0;
-        if (rd.found() && rd.value(c_width) && rd.value(c_depth) && rd.vector(out.nodes) && rd.vector(out.nodes8) && rd.vector(out.leaves) && c_width == out.width &&
-            !out.leaves.empty() && (out.width == 8 ? !out.nodes8.empty() : !out.nodes.empty())) {
+        if (rd.found() && rd.value(c_width) && rd.value(c_depth) && rd.vector(out.nodes) && rd.vector(out.nodes8) && rd.vector(out.leaves) && rd.verify() && c_width == out.width &&
+            !out.leaves.empty() && (out.width == 8 ? !out.nodes8.empty() : !out.nodes.empty()) && flat_links_valid(out)) {
             out.max_depth = c_depth; pt.lap("cache hit");
             return true;
         }

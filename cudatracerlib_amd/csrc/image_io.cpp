@@ -39,7 +39,7 @@ static decoded_image decode_png(const std::vector<uint8_t>& d, const std::string
         const uint32_t len = be32(&d[p]); const char* t = (const char*)&d[p + 4];
         if (p + 12 + len > d.size()) throw io_error("truncated PNG : " + path);
         const uint8_t* c = &d[p + 8];
-        if (!std::memcmp(t, "IHDR", 4)) { w = be32(c); h = be32(c + 4); depth = c[8]; ctype = c[9]; interlace = c[12]; }
+        if (!std::memcmp(t, "IHDR", 4)) { if (len != 13) throw io_error("bad PNG IHDR : " + path); w = be32(c); h = be32(c + 4); depth = c[8]; ctype = c[9]; interlace = c[12]; }
         else if (!std::memcmp(t, "PLTE", 4)) plte.assign(c, c + len);
         else if (!std::memcmp(t, "tRNS", 4)) trns.assign(c, c + len);
         else if (!std::memcmp(t, "IDAT", 4)) idat.insert(idat.end(), c, c + len);
@@ -48,7 +48,11 @@ static decoded_image decode_png(const std::vector<uint8_t>& d, const std::string
     }
     if (!w || !h) throw io_error("PNG without IHDR : " + path);
     if (interlace) throw unsupported_error("interlaced PNG is not supported : " + path);
-    if (depth != 8 && depth != 16 && !(ctype == 3 || ctype == 0)) throw unsupported_error("PNG bit depth not supported : " + path);
+    {   // PNG spec table 11.1: grey 1,2,4,8,16; palette 1,2,4,8; every other colour type 8 or 16
+        const bool sub = depth == 1 || depth == 2 || depth == 4;
+        const bool ok = ctype == 0 ? (sub || depth == 8 || depth == 16) : ctype == 3 ? (sub || depth == 8) : (depth == 8 || depth == 16);
+        if (!ok) throw io_error("bad PNG bit depth : " + path);
+    }
     const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!channels) throw io_error("bad PNG colour type : " + path);
     const size_t bpp_bits = (size_t)channels * depth, stride = (w * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
@@ -140,6 +144,7 @@ static decoded_image decode_pnm(const std::vector<uint8_t>& d, const std::string
     if (!pnm_token(d, p, t)) throw io_error("bad PNM header : " + path); const uint32_t w = (uint32_t)std::stoul(t);
     if (!pnm_token(d, p, t)) throw io_error("bad PNM header : " + path); const uint32_t h = (uint32_t)std::stoul(t);
     if (!pnm_token(d, p, t)) throw io_error("bad PNM header : " + path); const double maxv = std::stod(t);
+    if (magic != "PF" && magic != "Pf" && !(maxv >= 1 && maxv <= 65535)) throw io_error("bad PNM maximum value : " + path);
     decoded_image img; img.width = w; img.height = h;
     if (pfm) {
         p++;   // the single whitespace after the scale

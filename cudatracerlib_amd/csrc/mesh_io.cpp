@@ -236,7 +236,7 @@ mesh_data load_serialized(const std::string& path, int shape_index) {
     uint64_t off = 0;
     const size_t tab = d.size() - 4 - osz * n_meshes + osz * (size_t)shape_index;
     if (osz == 8) std::memcpy(&off, &d[tab], 8); else { uint32_t o32; std::memcpy(&o32, &d[tab], 4); off = o32; }
-    if (off + 4 > d.size() || u16(off) != 1052) throw io_error("corrupt sub-mesh header : " + path);
+    if (d.size() < 4 || off > d.size() - 4 || u16(off) != 1052) throw io_error("corrupt sub-mesh header : " + path);
     const uint16_t version = u16(off + 2);
     if (version != 3 && version != 4) throw io_error("invalid version in serialized mesh file");
     z_stream zs; std::memset(&zs, 0, sizeof(zs));

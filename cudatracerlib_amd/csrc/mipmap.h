@@ -105,6 +105,7 @@ __device__ __noinline__ bool alpha_survives(const uint4* __restrict__ tri_data, 
     const ctl_texture& refl = mat.tex[0];
     if ((st == CTL_ALPHA_MAP_ALPHA && mat.alpha_tex.type == CTL_TEX_IMAGE) || (st == CTL_ALPHA_REFLECTANCE_ALPHA && refl.type == CTL_TEX_IMAGE)) {
         const ctl_texture& t = st == CTL_ALPHA_MAP_ALPHA ? mat.alpha_tex : refl;
+        if (t.image == 0xffffffffu) return 0.0f >= mat.alpha_test_scalar;   // an IMAGE texture without an image evaluates to 0 (tex_eval_uv)
         return mip_sample_alpha(images[t.image], tex_map_point(t, uv)) >= mat.alpha_test_scalar;
     }
     const f3 val = tex_eval_uv((st & 4) ? refl : mat.alpha_tex, uv, images);

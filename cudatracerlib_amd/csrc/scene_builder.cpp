@@ -141,7 +141,7 @@ uint32_t scene_builder::add_mesh(const float* positions, uint32_t n_vert, const 
         key = H.hex();
         cache_reader rd("mesh", key);
         std::vector<ctl_triangle_data> c_tri; std::vector<ctl_bvh_node> c_nodes; std::vector<ctl_woop_tri> c_woop; std::vector<ctl_woop_index> c_widx; aabb c_box; int c_depth = 0;
-        if (rd.found() && rd.vector(c_tri) && rd.vector(c_nodes) && rd.vector(c_woop) && rd.vector(c_widx) && rd.value(c_box) && rd.value(c_depth) &&
+        if (rd.found() && rd.vector(c_tri) && rd.vector(c_nodes) && rd.vector(c_woop) && rd.vector(c_widx) && rd.value(c_box) && rd.value(c_depth) && rd.verify() &&
             c_tri.size() == n_tri && c_woop.size() == c_widx.size() && c_woop.size() >= n_tri) {
             tri.insert(tri.end(), c_tri.begin(), c_tri.end());
             mr.box = c_box; mr.max_depth = c_depth;
@@ -224,11 +224,7 @@ uint32_t scene_builder::finish_mesh(const mesh_rec& mr) {
 uint32_t scene_builder::add_node(uint32_t mesh_index, const ctl_float4x4* to_world) {
     if (mesh_index >= meshes.size()) throw std::runtime_error("ctl_builder_add_node: bad mesh index");
     const mesh_rec& mr = mesh_info[mesh_index];
-    ctl_node n{};   // Node::Node (SceneTypes/Node.cpp:10-17): every node owns a copy of the mesh's materials
-    n.mesh_index = mesh_index; n.material_offset = (uint32_t)mats.size(); n.instanciated_material = 0;
-    n.lights[0] = n.lights[1] = 0xffffffffu; n.n_lights = 0;
-    mats.insert(mats.end(), mesh_materials.begin() + mr.mat_offset, mesh_materials.begin() + mr.mat_offset + mr.n_mat);
-    nodes.push_back(n);
+    // validate the transform before anything is appended: a rejected call must leave nodes / mats / xf / ixf untouched
     ctl_float4x4 m;
     if (to_world) m = *to_world; else { std::memset(&m, 0, sizeof(m)); m.m[0] = m.m[5] = m.m[10] = m.m[15] = 1.0f; }
     if (m.m[12] != 0.0f || m.m[13] != 0.0f || m.m[14] != 0.0f || m.m[15] != 1.0f)
@@ -236,6 +232,11 @@ uint32_t scene_builder::add_node(uint32_t mesh_index, const ctl_float4x4* to_wor
     ctl_float4x4 inv; mat_inverse(m.m, inv.m);   // kept as computed: the reference divides by the inverse's own w (float4x4.h:402-406)
     if (inv.m[12] != 0.0f || inv.m[13] != 0.0f || inv.m[14] != 0.0f || !(inv.m[15] > 0.0f))
         throw std::runtime_error("ctl_builder_add_node: node transform is singular");
+    ctl_node n{};   // Node::Node (SceneTypes/Node.cpp:10-17): every node owns a copy of the mesh's materials
+    n.mesh_index = mesh_index; n.material_offset = (uint32_t)mats.size(); n.instanciated_material = 0;
+    n.lights[0] = n.lights[1] = 0xffffffffu; n.n_lights = 0;
+    mats.insert(mats.end(), mesh_materials.begin() + mr.mat_offset, mesh_materials.begin() + mr.mat_offset + mr.n_mat);
+    nodes.push_back(n);
     xf.push_back(m); ixf.push_back(inv);
     return (uint32_t)nodes.size() - 1;
 }
@@ -499,6 +500,7 @@ static aabb box_transform(const aabb& b, const float* m) {
 void scene_builder::finalize(ctl_scene_desc& out) {
     if (nodes.empty()) throw std::runtime_error("ctl_builder_finalize: scene has no nodes");
     if (!have_camera) throw std::runtime_error("ctl_builder_finalize: no camera set");
+    if (nodes.size() != xf.size() || nodes.size() != ixf.size()) throw std::runtime_error("ctl_builder_finalize: node / transform arrays out of step");
     // SceneBVH::Build (Engine/SceneBVH.cpp:11-54): one scene-BVH leaf per node (BVHRebuilder.cpp:380-383)
     std::vector<aabb> nb(nodes.size());
     aabb scene; scene.reset();

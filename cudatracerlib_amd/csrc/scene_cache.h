@@ -6,8 +6,10 @@
 // (vertex data, options, format version), so a stale entry cannot be picked up and no time stamps are compared.  Two kinds:
 //   mesh_<hash>.ctlc   one compiled mesh: TriangleData[], BVHNodeData[], Woop rows, index words, box (scene_builder.cpp add_mesh)
 //   flat_<hash>.ctlc   the flattened world-space BVH of a scene: flat nodes + leaf entries (flatten.cpp)
-// File: "CTLC" u32 version u32 n_sections, then per section u64 byte count + bytes.  Little endian, written to a temporary
-// name and renamed, so a concurrent reader (other ranks of a multi-GPU job share the directory) sees a whole file or none.
+// File: "CTLC" u32 version u32 n_sections, then per section u64 byte count + bytes, then a 16-byte checksum (content_hash of every
+// section's count and bytes).  Little endian, written to a unique temporary (mkstemp) and renamed, so a concurrent reader (other ranks
+// of a multi-GPU job share the directory) sees a whole file or none; a reader must call verify() after its last section and drop
+// what it read when that fails (torn or corrupted entry).
 // Off unless a directory is set (ctl_set_cache_dir / CTL_CACHE_DIR).
 #pragma once
 #include <cstdint>
@@ -28,6 +30,7 @@ public:
     template <typename T> void add_value(const T& v) { add(&v, sizeof(T)); }
     template <typename T> void add_vector(const std::vector<T>& v) { const uint64_t n = v.size(); add_value(n); if (n) add(v.data(), n * sizeof(T)); }
     std::string hex() const;
+    void digest(uint64_t out[2]) const;
 private:
     uint64_t a_ = 0x9E3779B185EBCA87ull, b_ = 0xC2B2AE3D27D4EB4Full, len_ = 0;
     void word(uint64_t w);
@@ -43,7 +46,7 @@ public:
     template <typename T> void value(const T& v) { section(&v, sizeof(T)); }
     void commit();   // rename into place; without it the temporary file is removed
 private:
-    FILE* f_ = nullptr; std::string tmp_, final_; uint32_t n_ = 0; bool ok_ = true;
+    FILE* f_ = nullptr; std::string tmp_, final_; uint32_t n_ = 0; bool ok_ = true; content_hash sum_;
 };
 
 class cache_reader {
@@ -55,12 +58,14 @@ public:
         uint64_t bytes;
         if (!next(bytes) || bytes % sizeof(T)) return false;
         v.resize(bytes / sizeof(T));
-        return bytes == 0 || std::fread(v.data(), 1, bytes, f_) == bytes;
+        return bytes == 0 || body(v.data(), bytes);
     }
-    template <typename T> bool value(T& v) { uint64_t bytes; return next(bytes) && bytes == sizeof(T) && std::fread(&v, 1, sizeof(T), f_) == sizeof(T); }
+    template <typename T> bool value(T& v) { uint64_t bytes; return next(bytes) && bytes == sizeof(T) && body(&v, sizeof(T)); }
+    bool verify();   // every section was read and the trailing checksum matches what was read
 private:
-    FILE* f_ = nullptr; uint32_t left_ = 0;
+    FILE* f_ = nullptr; uint32_t left_ = 0; content_hash sum_; bool ok_ = true;
     bool next(uint64_t& bytes);
+    bool body(void* p, uint64_t bytes);
 };
 
 } // namespace ctl

@@ -497,6 +497,7 @@ unsigned int WavefrontPathTracer::passBatch() const {
     if (v > 0) return (unsigned int)v;
     if (w == 0xffffffffu) return 1;
     const uint64_t per_pass = shard_pixel_count(w, h, shard_rank, shard_world);
+    if (per_pass == 0) return 1;   // more ranks than 64x64 tiles: this rank owns nothing and its passes are empty launches
     // Paths per launch.  Measured on MI355X (tools/passbatch_probe.py, synthetic-SM 1080p): 2 M paths per launch 1.04 Grays/s, 4 M 1.50, 8 M 1.88,
     // 33 M 2.33, 67 M 2.45, 134 M 2.51 — the persistent traversal kernels keep 524 k rays in flight and every launch pays a ramp and a
     // tail of a few hundred us, so small launches are mostly ramp and tail.  ~350 B of queue state per path: 64 M paths = 22 GB of the 288 GB.

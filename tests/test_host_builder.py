@@ -203,3 +203,26 @@ def test_builder_errors(ctl):
         sc.UpdateScene()                                  # no camera
     with pytest.raises(ctl.CtlError):
         sc.CreateNode(m, np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0.5, 1]], np.float32))   # projective
+
+
+def test_rejected_node_leaves_the_builder_intact(ctl, orc):
+    """a CreateNode that fails on its transform must not leave a node behind (nodes / transforms stay in step)"""
+    sc = ctl.DynamicScene()
+    V = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    m = sc.add_mesh(V, np.array([[0, 1, 2]], np.uint32))
+    n0 = sc.CreateNode(m)
+    for bad in (np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0.5, 1]], np.float32),     # projective
+                np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 0], [0, 0, 0, 1]], np.float32)):       # singular
+        with pytest.raises(ctl.CtlError):
+            sc.CreateNode(m, bad)
+    T = np.eye(4, dtype=np.float32); T[0, 3] = 2.0
+    n1 = sc.CreateNode(m, T)
+    assert (n0, n1) == (0, 1)
+    sc.setCamera((0.3, 0.3, 5), (0.3, 0.3, 0), (0, 1, 0), 40.0, 8, 8)
+    d = sc.UpdateScene()
+    assert d.n_nodes == 2
+    xf = d.view("node_transforms", np.float32, 2, 16)
+    assert xf[0, 3] == 0.0 and xf[1, 3] == 2.0          # node 1 carries ITS transform, not the rejected ones'
+    rays = np.array([[2.25, 0.25, 5, 0, 0, 0, -1, 1e30], [0.25, 0.25, 5, 0, 0, 0, -1, 1e30]], np.float32)
+    hits = orc.intersect(d, rays)
+    assert list(hits["node_idx"]) == [1, 0]

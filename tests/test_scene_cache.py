@@ -70,6 +70,15 @@ def test_changed_input_misses_and_damaged_file_is_ignored(cache_dir):
     sc3, d3 = build(1.0)
     for a, b in zip(ref, _arrays(d3)):
         assert np.array_equal(a, b)
+    for f in files:                                                # one flipped payload byte: sizes are right, the checksum is not
+        p = os.path.join(cache_dir, f)
+        data = bytearray(open(p, "rb").read())
+        data[len(data) // 2] ^= 0x40
+        open(p, "wb").write(bytes(data))
+    sc5, d5 = build(1.0)
+    for a, b in zip(ref, _arrays(d5)):
+        assert np.array_equal(a, b)
+    assert not [f for f in os.listdir(cache_dir) if ".tmp" in f]   # writers leave no temporaries behind
     open(os.path.join(cache_dir, files[0]), "wb").write(b"not a cache file")
     sc4, d4 = build(1.0)
     for a, b in zip(ref, _arrays(d4)):
