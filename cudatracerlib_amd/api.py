@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libctl_amd.so")
+# $CTL_AMD_LIB names another build of the same library (tools/build_variant.sh: kernel A/B runs on the GPU box); never a fallback
+_LIB_PATH = os.environ.get("CTL_AMD_LIB") or os.path.join(_HERE, "libctl_amd.so")
 if not os.path.exists(_LIB_PATH):
     raise ImportError(
         "cudatracerlib_amd: %s is missing — build it with `python -m cudatracerlib_amd.build` "
@@ -182,11 +183,43 @@ def set_cache_dir(directory):
     _check(lib.ctl_set_cache_dir(None if directory is None else str(directory).encode()))
 
 
-def flatten_probe(desc, width=4):
+FLAT_Q4, FLAT_F4, FLAT_F2 = 0, 1, 2          # CTL_FLAT_* node formats of the flattened BVH
+FLAT_FORMATS = {"q4": FLAT_Q4, "f4": FLAT_F4, "f2": FLAT_F2}
+
+
+def flatten_probe(desc, format=FLAT_Q4):
     """Host half of Scene(desc, flatten=True): dict(nodes, leaves, depth, hash) of the flattened BVH (built or loaded from the cache)."""
     out = (u64 * 4)()
-    _check(lib.ctl_flatten_probe(C.byref(desc), u32(width), out))
+    _check(lib.ctl_flatten_probe(C.byref(desc), u32(format), out))
     return dict(nodes=out[0], leaves=out[1], depth=out[2], hash=out[3])
+
+
+class FlatBvhDesc(C.Structure):
+    _fields_ = [("format", u32), ("max_depth", u32), ("nodes", C.c_void_p), ("n_nodes", u64), ("node_bytes", u32),
+                ("leaves", C.c_void_p), ("n_leaves", u64)]
+
+
+class FlatBvh:
+    """The flattened BVH as host arrays (ctl_flat_bvh_build): what Scene(desc, flatten=True) uploads.  .desc is a ctl_flat_bvh_desc."""
+
+    def __init__(self, desc, format=FLAT_Q4):
+        self._h = C.c_void_p()
+        self._keepalive = desc
+        _check(lib.ctl_flat_bvh_build(C.byref(desc), u32(format), C.byref(self._h)))
+        self.desc = FlatBvhDesc()
+        _check(lib.ctl_flat_bvh_arrays(self._h, C.byref(self.desc)))
+
+    def nodes(self):
+        n = self.desc.n_nodes * self.desc.node_bytes // 4
+        return np.ctypeslib.as_array(C.cast(self.desc.nodes, C.POINTER(C.c_uint32)), shape=(n,)).reshape(self.desc.n_nodes, -1)
+
+    def leaves(self):
+        return np.ctypeslib.as_array(C.cast(self.desc.leaves, C.POINTER(C.c_uint32)), shape=(self.desc.n_leaves * 32,)).reshape(-1, 32)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.ctl_flat_bvh_destroy(self._h)
+            self._h = None
 
 
 def _fp(a):
@@ -570,10 +603,14 @@ class DynamicScene:
 class Scene:
     """The scene resident in HBM (UpdateKernel, Kernel/TraceHelper.cu:182-217)."""
 
-    def __init__(self, desc, flatten=False):
+    def __init__(self, desc, flatten=False, flat_format=None):
+        """flat_format: None = the library default (Q4, or $CTL_FLAT_FORMAT), else FLAT_Q4 / FLAT_F4 / FLAT_F2 or one of the strings q4 / f4 / f2"""
         self._h = C.c_void_p()
         self._keepalive = desc
-        _check(lib.ctl_scene_create_ex(C.byref(desc), u32(1 if flatten else 0), C.byref(self._h)))
+        flags = 1 if flatten else 0
+        if flat_format is not None:
+            flags |= (FLAT_FORMATS.get(flat_format, flat_format) + 1) << 8
+        _check(lib.ctl_scene_create_ex(C.byref(desc), u32(flags), C.byref(self._h)))
 
     def __del__(self):
         if getattr(self, "_h", None):

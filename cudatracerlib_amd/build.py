@@ -23,16 +23,18 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not stale():
+def build(force=False, verbose=True, out=None, defines=()):
+    """out / defines: a variant build (tools/build_variant.sh) with extra -D flags into its own object directory"""
+    if out is None and not force and not stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    bdir = os.path.join(HERE, "build" if out is None else "build_" + os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(bdir, exist_ok=True)
     procs = []
     for s in SRCS:
-        o = os.path.join(HERE, "build", s + ".o")
-        cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
+        o = os.path.join(bdir, s + ".o")
+        cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))
@@ -40,12 +42,19 @@ def build(force=False, verbose=True):
     bad = [s for s, p in procs if p.wait() != 0]
     if bad:
         raise RuntimeError("hipcc failed for: " + ", ".join(bad))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", OUT] + objs + ["-pthread", "-lz"]
+    target = OUT if out is None else out
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", target] + objs + ["-pthread", "-lz"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+    return target
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    out = None; defines = []
+    while args:
+        a = args.pop(0)
+        if a == "--out": out = os.path.abspath(args.pop(0))
+        elif a.startswith("-D"): defines.append(a[2:])
+    build(force="--force" in sys.argv, out=out, defines=defines, verbose=False)

@@ -246,48 +246,6 @@ struct collapser {
 };
 } // namespace
 
-struct collapser8 {
-    const bvh_result& R; std::vector<wide8_node>& out; int max_depth = 0;
-    int emit(int code2, const aabb& box, int depth) {
-        if (depth > max_depth) max_depth = depth;
-        struct item { int code; aabb box; };
-        item it[8]; int n = 0;
-        const ctl_bvh_node& root = R.nodes[code2 / 4];
-        if (root.child0 != 0x76543210) it[n++] = { root.child0, node_child_box(root, 0) };
-        if (root.child1 != 0x76543210) it[n++] = { root.child1, node_child_box(root, 1) };
-        while (n < 8) {   // open the inner child with the largest surface area until eight children are gathered
-            int best = -1; float ba = -1.0f;
-            for (int i = 0; i < n; i++) if (it[i].code >= 0) { const float a = it[i].box.area(); if (a > ba) { ba = a; best = i; } }
-            if (best < 0) break;
-            const ctl_bvh_node& c = R.nodes[it[best].code / 4];
-            const bool has0 = c.child0 != 0x76543210, has1 = c.child1 != 0x76543210;
-            if (has0 && has1) { it[n++] = { c.child1, node_child_box(c, 1) }; it[best] = { c.child0, node_child_box(c, 0) }; }
-            else if (has0) it[best] = { c.child0, node_child_box(c, 0) };
-            else if (has1) it[best] = { c.child1, node_child_box(c, 1) };
-            else break;
-        }
-        const int me = (int)out.size();
-        out.emplace_back();
-        out[me].box = box; out[me].n = n;
-        for (int i = 0; i < 8; i++) { out[me].child[i] = 0x76543210; out[me].cbox[i].reset(); }
-        for (int i = 0; i < n; i++) {
-            const aabb cb = it[i].box;
-            const int c = it[i].code < 0 ? it[i].code : emit(it[i].code, cb, depth + 1);
-            out[me].child[i] = c; out[me].cbox[i] = cb;
-        }
-        return me;
-    }
-};
-void collapse_bvh8(const bvh_result& R, std::vector<wide8_node>& out, int& max_depth) {
-    out.clear(); max_depth = 0;
-    if (R.nodes.empty()) return;
-    aabb box; box.reset();
-    box.grow(node_child_box(R.nodes[0], 0)); if (R.nodes[0].child1 != 0x76543210) box.grow(node_child_box(R.nodes[0], 1));
-    collapser8 C{ R, out };
-    C.emit(0, box, 0);
-    max_depth = C.max_depth;
-}
-
 void collapse_bvh4(const bvh_result& R, std::vector<wide4_node>& out, int& max_depth) {
     out.clear(); max_depth = 0;
     if (R.nodes.empty()) return;

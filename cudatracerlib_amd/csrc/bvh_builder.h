@@ -43,7 +43,4 @@ namespace ctl {
 // child >= 0: index into the wide-node array; child < 0: ~firstLeafEntry (same leaf entries as the BVH2); n = children used.
 struct wide4_node { aabb box; aabb cbox[4]; int child[4]; int n; };
 void collapse_bvh4(const bvh_result& R, std::vector<wide4_node>& out, int& max_depth);
-// the same collapse to 8 children (one 128-byte node = one L2 line per visit, see flatten.h flat8_node)
-struct wide8_node { aabb box; aabb cbox[8]; int child[8]; int n; };
-void collapse_bvh8(const bvh_result& R, std::vector<wide8_node>& out, int& max_depth);
 } // namespace ctl

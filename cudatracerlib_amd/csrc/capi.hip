@@ -5,6 +5,7 @@
 #include "scene_builder.h"
 #include "mitsuba_loader.h"
 #include "flatten.h"
+#include <memory>
 #include "scene_cache.h"
 #include <cstdlib>
 #include <cstring>
@@ -14,7 +15,8 @@
 using namespace ctl;
 
 struct ctl_builder { scene_builder b; };
-struct ctl_scene { Scene s; ctl_scene(const ctl_scene_desc& d, bool flatten) : s(d, flatten) {} };
+struct ctl_scene { Scene s; ctl_scene(const ctl_scene_desc& d, bool flatten, int fmt = -1) : s(d, flatten, fmt) {} };
+struct ctl_flat_bvh { flat_scene f; };
 struct ctl_image { Image img; ctl_image(uint32_t w, uint32_t h) : img(w, h) {} };
 struct ctl_tracer { std::unique_ptr<TracerBase> t; };
 struct ctl_sequence_generator { sequence_generator g; };
@@ -96,19 +98,41 @@ int ctl_builder_finalize(ctl_builder* b, ctl_scene_desc* out) { CTL_REQUIRE(b &&
 
 // ---- scene
 int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc, false); CTL_CATCH }
-int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc, (flags & CTL_SCENE_FLATTEN) != 0); CTL_CATCH }
+int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY
+    const uint32_t fmt = (flags >> 8) & 3u;   // 0: default, else CTL_FLAT_* + 1
+    *out = new ctl_scene(*desc, (flags & CTL_SCENE_FLATTEN) != 0, (int)fmt - 1);
+CTL_CATCH }
 void ctl_scene_destroy(ctl_scene* s) { delete s; }
 int ctl_set_cache_dir(const char* dir) { CTL_TRY set_cache_dir(dir); CTL_CATCH }
-int ctl_flatten_probe(const ctl_scene_desc* desc, uint32_t width, uint64_t* out4) {
-    CTL_REQUIRE(desc && out4 && (width == 4 || width == 8), "null argument or bad width");
+int ctl_flatten_probe(const ctl_scene_desc* desc, uint32_t format, uint64_t* out4) {
+    CTL_REQUIRE(desc && out4 && format <= CTL_FLAT_F2, "null argument or bad format");
     CTL_TRY
         flat_scene F;
-        if (!flatten_scene(*desc, F, (size_t)1 << 30, (int)width)) throw std::runtime_error("ctl_flatten_probe: nothing to flatten");
-        content_hash H; H.add_vector(F.nodes); H.add_vector(F.nodes8); H.add_vector(F.leaves);
-        out4[0] = F.width == 8 ? F.nodes8.size() : F.nodes.size(); out4[1] = F.leaves.size(); out4[2] = (uint64_t)F.max_depth;
+        if (!flatten_scene(*desc, F, (size_t)1 << 30, (int)format)) throw std::runtime_error("ctl_flatten_probe: nothing to flatten");
+        content_hash H; H.add_vector(F.nodes); H.add_vector(F.nodes_f4); H.add_vector(F.nodes_f2); H.add_vector(F.leaves);
+        out4[0] = F.nodes.size() + F.nodes_f4.size() + F.nodes_f2.size(); out4[1] = F.leaves.size(); out4[2] = (uint64_t)F.max_depth;
         out4[3] = std::strtoull(H.hex().substr(16).c_str(), nullptr, 16);
     CTL_CATCH
 }
+int ctl_flat_bvh_build(const ctl_scene_desc* desc, uint32_t format, ctl_flat_bvh** out) {
+    CTL_REQUIRE(desc && out && format <= CTL_FLAT_F2, "null argument or bad format");
+    CTL_TRY
+        std::unique_ptr<ctl_flat_bvh> h(new ctl_flat_bvh());
+        if (!flatten_scene(*desc, h->f, (size_t)1 << 30, (int)format)) throw std::runtime_error("ctl_flat_bvh_build: nothing to flatten");
+        *out = h.release();
+    CTL_CATCH
+}
+int ctl_flat_bvh_arrays(const ctl_flat_bvh* h, ctl_flat_bvh_desc* out) {
+    CTL_REQUIRE(h && out, "null argument");
+    const flat_scene& F = h->f;
+    out->format = (uint32_t)F.format; out->max_depth = (uint32_t)F.max_depth;
+    if (F.format == kFlatQ4) { out->nodes = F.nodes.data(); out->n_nodes = F.nodes.size(); out->node_bytes = 64; }
+    else if (F.format == kFlatF4) { out->nodes = F.nodes_f4.data(); out->n_nodes = F.nodes_f4.size(); out->node_bytes = 128; }
+    else { out->nodes = F.nodes_f2.data(); out->n_nodes = F.nodes_f2.size(); out->node_bytes = 64; }
+    out->leaves = F.leaves.data(); out->n_leaves = F.leaves.size();
+    return CTL_OK;
+}
+void ctl_flat_bvh_destroy(ctl_flat_bvh* h) { delete h; }
 int ctl_parse_mitsuba_scene(ctl_builder* b, const char* xml_path, int32_t* width_inout, int32_t* height_inout) {
     CTL_REQUIRE(b && xml_path, "null argument");
     CTL_TRY parse_mitsuba_scene(b->b, xml_path, width_inout, height_inout); CTL_CATCH

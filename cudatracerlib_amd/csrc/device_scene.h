@@ -24,9 +24,11 @@ struct dev_scene {
     const float4* leaf_tris;     // 4 x float4 per leaf entry: Woop rows a,b,c + {index bits, 0, 0, 0}  (64 B, one fetch group)
     const float4* inst;          // 4 x float4 per node: inverse-transform rows 0..2 + {w33, nodeOff4, leafOff, triOff} (bits)
     const float4* flat_nodes;    // optional single-level world-space BVH over all instanced triangles (flatten.cpp), else nullptr
-    const float4* flat_leaves;   // 4 x float4 per leaf entry: world-space Woop rows + {globalTri << 1 | last, node, 0, 0}
+    const float4* flat_leaves;   // 4 x float4 per leaf entry: the mesh's object-space Woop rows + {globalTri << 1 | last, node, 0, 0}
     int flat_root;
-    int flat_width;              // 4: flat4_node (64 B), 8: flat8_node (128 B)
+    int flat_compact;            // Q4: the child links are implied by the layout (flat4_node::links), a step loads 48 of the node's 64 B
+    int inst_w_one;              // every node's inverse transform has w33 == 1.0f exactly (x / 1 == x: the traversal skips the division)
+    int flat_format;             // flat_format of flatten.h: 0 Q4 (64-B quantised 4-wide), 1 F4 (128-B fp32 4-wide), 2 F2 (64-B fp32 2-wide)
     const float4* inst_fwd;      // 3 x float4 per node: forward-transform rows 0..2 (fillDG)
     const uint4* tri_data;       // 2 x uint4 per triangle (TriangleData, 32 B)
     const uint4* node_info;      // per node {material_offset, light0, light1, n_lights}

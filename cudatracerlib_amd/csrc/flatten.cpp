@@ -1,9 +1,9 @@
-// flatten.cpp — optional re-layout at scene upload: bake every node's transform into its triangles and build ONE
-// world-space BVH over all instanced triangles ("flattening static instances into one BVH is allowed by the
-// API and likely necessary").  The MI355X has 288 GB of HBM: 64 B per instanced triangle buys a traversal without the
-// per-instance ray transform, without restarting at a mesh root per instance, and with two instead of four kinds of
-// work per wave.  Results: same triangle / node / material as the two-level traversal; t,u,v agree to fp32 round-off
-// (the Woop rows are recomputed in double precision from the world-space vertices) instead of bit-for-bit.
+// flatten.cpp — optional re-layout at scene upload: ONE world-space BVH over all instanced triangles ("flattening
+// static instances into one BVH is allowed by the API and likely necessary").  The MI355X has 288 GB of HBM: 128 B per instanced
+// triangle buys a traversal that never restarts at a mesh root per instance and has two instead of four kinds of work per wave.
+// The tree only culls: a leaf entry keeps the mesh's own object-space Woop rows, its node id and the node's inverse transform, and the
+// kernel evaluates it with the reference's instance-transform + Woop arithmetic, so (t, u, v, triangle, node) equal the two-level traversal bit for bit
+// (flatten.h).  World-space vertices are recovered from the Woop rows in double only to compute the boxes, which are padded.
 #include "flatten.h"
 #include "bvh_builder.h"
 #include "scene_cache.h"
@@ -60,18 +60,6 @@ bool woop_vertices(const ctl_woop_tri& w, double v[3][3]) {
     for (int k = 0; k < 3; k++) { v[2][k] = inv[k * 4 + 3]; v[0][k] = v[2][k] + inv[k * 4 + 0]; v[1][k] = v[2][k] + inv[k * 4 + 1]; }
     return true;
 }
-// Woop rows of a triangle (TriIntersectorData::setData, Engine/TriIntersectorData.cu:5-18) computed in double, rounded once
-bool woop_rows(const double v[3][3], float a[4], float b[4], float c[4]) {
-    double e0[3], e1[3], n[3];
-    for (int k = 0; k < 3; k++) { e0[k] = v[0][k] - v[2][k]; e1[k] = v[1][k] - v[2][k]; }
-    n[0] = e0[1] * e1[2] - e0[2] * e1[1]; n[1] = e0[2] * e1[0] - e0[0] * e1[2]; n[2] = e0[0] * e1[1] - e0[1] * e1[0];
-    const double m[16] = { e0[0], e1[0], n[0], v[2][0], e0[1], e1[1], n[1], v[2][1], e0[2], e1[2], n[2], v[2][2], 0, 0, 0, 1 };
-    double inv[16];
-    if (!inv4(m, inv)) return false;
-    a[0] = (float)inv[8]; a[1] = (float)inv[9]; a[2] = (float)inv[10]; a[3] = (float)-inv[11];
-    for (int j = 0; j < 4; j++) { b[j] = (float)inv[j]; c[j] = (float)inv[4 + j]; }
-    return true;
-}
 // phase timing on stderr when CTL_VERBOSE is set
 struct phase_timer {
     const bool on = std::getenv("CTL_VERBOSE") != nullptr; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -89,11 +77,14 @@ template <typename F> void parallel_for(size_t n, const F& f, size_t min_chunk =
 bool flat_links_valid(const flat_scene& F) {
     const size_t nl = F.leaves.size();
     auto ok = [&](int32_t c, size_t n_nodes, int unit) {
+        if (c == 0x76543210) return true;
         if (c >= 0) return c % unit == 0 && (size_t)(c / unit) < n_nodes;
         return (size_t)(~c) < nl;
     };
-    if (F.width == 8) { for (const auto& n : F.nodes8) for (int c = 0; c < 8; c++) if (((n.mask >> c) & 1) && !ok(n.child[c], F.nodes8.size(), 8)) return false; }
-    else for (const auto& n : F.nodes) for (int c = 0; c < 4; c++) if (((n.mask >> c) & 1) && !ok(n.child[c], F.nodes.size(), 4)) return false;
+    if (F.format == kFlatQ4) { for (const auto& n : F.nodes) for (int c = 0; c < 4; c++) if (((n.mask >> c) & 1) && !ok(n.child[c], F.nodes.size(), 4)) return false; }
+    else if (F.format == kFlatF4) { for (const auto& n : F.nodes_f4) for (int c = 0; c < 4; c++) if (!ok(n.child[c], F.nodes_f4.size(), 8)) return false; }
+    else for (const auto& n : F.nodes_f2) if (!ok(n.child0, F.nodes_f2.size(), 4) || !ok(n.child1, F.nodes_f2.size(), 4)) return false;
+    if (F.node_bytes() == 0) return false;
     return nl > 0 && (F.leaves[nl - 1].index & 1u);   // the last entry closes its leaf
 }
 float round_down(double x) { float f = (float)x; return ((double)f > x) ? std::nextafterf(f, -INFINITY) : f; }
@@ -101,8 +92,19 @@ float round_up(double x) { float f = (float)x; return ((double)f < x) ? std::nex
 
 }  // namespace
 
-bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangles, int width) {
-    out.nodes.clear(); out.nodes8.clear(); out.leaves.clear(); out.width = width == 8 ? 8 : 4;
+int default_flat_format() {
+    static const int v = [] {
+        const char* e = std::getenv("CTL_FLAT_FORMAT");
+        if (e && (!std::strcmp(e, "f4") || !std::strcmp(e, "F4"))) return (int)kFlatF4;
+        if (e && (!std::strcmp(e, "f2") || !std::strcmp(e, "F2"))) return (int)kFlatF2;
+        return (int)kFlatQ4;
+    }();
+    return v;
+}
+
+bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangles, int format) {
+    out.nodes.clear(); out.nodes_f4.clear(); out.nodes_f2.clear(); out.leaves.clear(); out.compact_links = true;
+    out.format = (format == kFlatF4 || format == kFlatF2) ? format : kFlatQ4;
     phase_timer pt;
     // leaf-entry range of every mesh (the woop stream is shared; a mesh ends where the next one starts)
     std::vector<std::pair<uint32_t, uint32_t>> starts;
@@ -124,31 +126,31 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
         total += mesh_tris[m].size();
     }
     if (total == 0 || total > max_triangles) return false;
-    // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node width only
+    // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node format only
     std::string key;
     if (!cache_dir().empty()) {
-        content_hash H; const uint32_t version = 2;
-        H.add_value(version); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.width); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
+        content_hash H; const uint32_t version = 7;
+        H.add_value(version); H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
         for (uint32_t k = 0; k < d.n_nodes; k++) { H.add_value(d.nodes[k].mesh_index); H.add(d.node_transforms[k].m, 64); }
         key = H.hex();
         cache_reader rd("flat", key);
-        int c_width = 0, c_depth = 0;
-        if (rd.found() && rd.value(c_width) && rd.value(c_depth) && rd.vector(out.nodes) && rd.vector(out.nodes8) && rd.vector(out.leaves) && rd.verify() && c_width == out.width &&
-            !out.leaves.empty() && (out.width == 8 ? !out.nodes8.empty() : !out.nodes.empty()) && flat_links_valid(out)) {
-            out.max_depth = c_depth; pt.lap("cache hit");
+        int c_format = -1, c_depth = 0, c_compact = 0;
+        if (rd.found() && rd.value(c_format) && rd.value(c_depth) && rd.value(c_compact) && rd.vector(out.nodes) && rd.vector(out.nodes_f4) && rd.vector(out.nodes_f2) && rd.vector(out.leaves) && rd.verify() &&
+            c_format == out.format && flat_links_valid(out)) {
+            out.max_depth = c_depth; out.compact_links = c_compact != 0; pt.lap("cache hit");
             return true;
         }
-        out.nodes.clear(); out.nodes8.clear(); out.leaves.clear();
+        out.nodes.clear(); out.nodes_f4.clear(); out.nodes_f2.clear(); out.leaves.clear();
     }
-    struct wtri { double v[3][3]; uint32_t tri, node; };
+    struct wtri { uint32_t tri, node, woop; };
     // object-space vertices of every mesh's triangles once (degenerate ones can never be hit and are dropped), then per node in parallel
-    struct ltri { double v[3][3]; uint32_t tri; };
+    struct ltri { double v[3][3]; uint32_t tri, woop; };
     std::vector<std::vector<ltri>> mesh_local(d.n_meshes);
     for (uint32_t m = 0; m < d.n_meshes; m++) {
         mesh_local[m].reserve(mesh_tris[m].size());
-        for (auto& e : mesh_tris[m]) { ltri l; l.tri = e.first; if (woop_vertices(d.woop[e.second], l.v)) mesh_local[m].push_back(l); }
+        for (auto& e : mesh_tris[m]) { ltri l; l.tri = e.first; l.woop = e.second; if (woop_vertices(d.woop[e.second], l.v)) mesh_local[m].push_back(l); }
     }
     std::vector<size_t> node_first(d.n_nodes + 1, 0);
     for (uint32_t k = 0; k < d.n_nodes; k++) node_first[k + 1] = node_first[k] + mesh_local[d.nodes[k].mesh_index].size();
@@ -161,11 +163,20 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
             const float* M = d.node_transforms[k].m;
             size_t o = node_first[k];
             for (const ltri& l : mesh_local[N.mesh_index]) {
-                wtri& t = tris[o]; t.tri = km.tri_offset + l.tri; t.node = (uint32_t)k;
+                wtri& t = tris[o]; t.tri = km.tri_offset + l.tri; t.node = (uint32_t)k; t.woop = l.woop;
                 aabb& b = boxes[o]; b.reset(); o++;
                 for (int j = 0; j < 3; j++) {
-                    for (int r = 0; r < 3; r++) t.v[j][r] = (double)M[r * 4] * l.v[j][0] + (double)M[r * 4 + 1] * l.v[j][1] + (double)M[r * 4 + 2] * l.v[j][2] + (double)M[r * 4 + 3];
-                    for (int r = 0; r < 3; r++) { const float lo = round_down(t.v[j][r]), hi = round_up(t.v[j][r]); if (lo < b.lo[r]) b.lo[r] = lo; if (hi > b.hi[r]) b.hi[r] = hi; }
+                    for (int r = 0; r < 3; r++) {
+                        const double w = (double)M[r * 4] * l.v[j][0] + (double)M[r * 4 + 1] * l.v[j][1] + (double)M[r * 4 + 2] * l.v[j][2] + (double)M[r * 4 + 3];
+                        const float lo = round_down(w), hi = round_up(w); if (lo < b.lo[r]) b.lo[r] = lo; if (hi > b.hi[r]) b.hi[r] = hi;
+                    }
+                }
+                // The kernel decides a hit with the fp32 object-space Woop test, whose accepted region differs from the exact triangle by
+                // round-off: pad the box by a few units in the last place of its largest coordinate (and of its extent).
+                for (int r = 0; r < 3; r++) {
+                    const float mag = std::max(std::max(std::fabs(b.lo[r]), std::fabs(b.hi[r])), b.hi[r] - b.lo[r]);
+                    const float e = mag * 9.5367431640625e-7f + 1e-30f;   // 8 ulp
+                    b.lo[r] -= e; b.hi[r] += e;
                 }
             }
         }
@@ -174,49 +185,40 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     bvh_result R;
     build_bvh(boxes, flat_max_leaf(), true, 60, R, flat_node_cost());
     pt.lap("build BVH2");
-    // quantise a child box conservatively against the node's own box (one exponent per axis)
-    auto quantise = [&](const aabb& nbox, const aabb* cbox, int n, float origin[3], uint8_t e_out[3], uint8_t qlo[3][8], uint8_t qhi[3][8]) {
-        for (int k = 0; k < 3; k++) {
-            origin[k] = nbox.lo[k];
-            const double ext = (double)nbox.hi[k] - (double)nbox.lo[k];
-            int e = 1;   // smallest normal exponent
-            if (ext > 0) { int ex; std::frexp(ext / 255.0, &ex); e = ex + 127; /* 2^ex >= ext/255 */ if (e < 1) e = 1; if (e > 254) e = 254; }
-            e_out[k] = (uint8_t)e;
-            const double step = std::ldexp(1.0, e - 127);
-            for (int c = 0; c < n; c++) {
-                long lo = (long)std::floor(((double)cbox[c].lo[k] - (double)origin[k]) / step);
-                long hi = (long)std::ceil(((double)cbox[c].hi[k] - (double)origin[k]) / step);
-                // the device evaluates origin + step * q in fp32 (one rounding): keep the box conservative under that rounding too
-                while (lo > 0 && (float)((double)origin[k] + step * (double)lo) > cbox[c].lo[k]) lo--;
-                while (hi < 255 && (float)((double)origin[k] + step * (double)hi) < cbox[c].hi[k]) hi++;
-                qlo[k][c] = (uint8_t)std::min(255L, std::max(0L, lo)); qhi[k][c] = (uint8_t)std::min(255L, std::max(0L, hi));
-            }
-        }
-    };
     int wdepth = 0;
-    if (out.width == 8) {
-        std::vector<wide8_node> W;
-        collapse_bvh8(R, W, wdepth);
-        out.nodes8.resize(W.size());
-        for (size_t i = 0; i < W.size(); i++) {
-            const wide8_node& w = W[i]; flat8_node& f = out.nodes8[i];
-            std::memset(&f, 0, sizeof(f));
-            uint8_t qlo[3][8] = {}, qhi[3][8] = {};
-            quantise(w.box, w.cbox, w.n, f.origin, f.e, qlo, qhi);
-            uint32_t* ql[3] = { f.qlo_x, f.qlo_y, f.qlo_z }; uint32_t* qh[3] = { f.qhi_x, f.qhi_y, f.qhi_z };
-            for (int k = 0; k < 3; k++) for (int c = 0; c < w.n; c++) { ql[k][c / 4] |= (uint32_t)qlo[k][c] << (8 * (c % 4)); qh[k][c / 4] |= (uint32_t)qhi[k][c] << (8 * (c % 4)); }
-            for (int c = 0; c < 8; c++) {
-                if (c < w.n) { f.mask |= (uint8_t)(1u << c); f.child[c] = w.child[c] >= 0 ? w.child[c] * 8 : w.child[c]; }
-                else f.child[c] = 0x76543210;
-            }
+    if (out.format == kFlatF2) {
+        // the binary tree as built, in the reference's node layout; the two children of a node are stored next to each other (one
+        // 128-B line) so that a ray entering both pays one line
+        std::vector<int> new_id(R.nodes.size(), -1), order; order.reserve(R.nodes.size());
+        std::vector<std::pair<int, int>> stack;   // (node, depth)
+        new_id[0] = 0; order.push_back(0); stack.emplace_back(0, 1);
+        while (!stack.empty()) {
+            const auto [me, dep] = stack.back(); stack.pop_back();
+            wdepth = std::max(wdepth, dep);
+            int kids[2], nk = 0;
+            for (int c : { R.nodes[me].child0, R.nodes[me].child1 }) if (c >= 0 && c != 0x76543210) kids[nk++] = c / 4;
+            if (nk && (order.size() & 1)) order.push_back(-1);   // children start at an even index: a sibling pair is one 128-B line (the array is line-aligned)
+            for (int c = 0; c < nk; c++) { new_id[kids[c]] = (int)order.size(); order.push_back(kids[c]); }
+            for (int c = nk - 1; c >= 0; c--) stack.emplace_back(kids[c], dep + 1);
+        }
+        out.nodes_f2.resize(order.size());
+        for (size_t i = 0; i < order.size(); i++) {
+            if (order[i] < 0) { std::memset(&out.nodes_f2[i], 0, sizeof(ctl_bvh_node)); out.nodes_f2[i].child0 = out.nodes_f2[i].child1 = 0x76543210; continue; }   // padding
+            ctl_bvh_node n = R.nodes[order[i]];
+            if (n.child0 >= 0 && n.child0 != 0x76543210) n.child0 = new_id[n.child0 / 4] * 4;
+            if (n.child1 >= 0 && n.child1 != 0x76543210) n.child1 = new_id[n.child1 / 4] * 4;
+            // a missing child (one-leaf scenes) gets an inverted box, so that it is never entered
+            const float big = 3.402823466e+38f;   // a = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y), b = c1 likewise, c = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)
+            if (n.child0 == 0x76543210) { n.a[0] = n.a[2] = n.c[0] = big; n.a[1] = n.a[3] = n.c[1] = -big; }
+            if (n.child1 == 0x76543210) { n.b[0] = n.b[2] = n.c[2] = big; n.b[1] = n.b[3] = n.c[3] = -big; }
+            out.nodes_f2[i] = n;
         }
     } else {
-        // collapse to 4-wide nodes and quantise the child boxes conservatively
+        // collapse to 4-wide nodes
         std::vector<wide4_node> W;
         collapse_bvh4(R, W, wdepth);
-        {   // memory order: the inner children of a node sit next to each other (<= 256 B = two 128-B L2 lines), subtrees stay
-            // clustered.  Traversal is bound by the rate of random line fetches (tools/gather_probe.hip), and a ray that enters a node
-            // usually enters one or two of its children next: siblings sharing a line turn some of those fetches into L2 hits.
+        {   // memory order: the inner children of a node sit next to each other, subtrees stay clustered: a ray that enters a node
+            // usually enters one or two of its children next, and neighbouring lines share DRAM pages / L2 sets
             std::vector<int> new_id(W.size(), -1), order; order.reserve(W.size());
             std::vector<int> stack; new_id[0] = 0; order.push_back(0); stack.push_back(0);
             while (!stack.empty()) {
@@ -230,52 +232,107 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
             for (size_t i = 0; i < order.size(); i++) { W2[i] = W[order[i]]; for (int c = 0; c < W2[i].n; c++) if (W2[i].child[c] >= 0) W2[i].child[c] = new_id[W2[i].child[c]]; }
             W.swap(W2);
         }
-        out.nodes.resize(W.size());
-        parallel_for(W.size(), [&](size_t i0, size_t i1) {
-        for (size_t i = i0; i < i1; i++) {
-            const wide4_node& w = W[i]; flat4_node& f = out.nodes[i];
-            std::memset(&f, 0, sizeof(f));
-            uint32_t* q[3][2] = { { &f.qlo_x, &f.qhi_x }, { &f.qlo_y, &f.qhi_y }, { &f.qlo_z, &f.qhi_z } };
-            for (int k = 0; k < 3; k++) {
-                f.origin[k] = w.box.lo[k];
-                const double ext = (double)w.box.hi[k] - (double)w.box.lo[k];
-                int e = 1;   // smallest normal exponent
-                if (ext > 0) { int ex; std::frexp(ext / 255.0, &ex); e = ex + 127; /* 2^ex >= ext/255 */ if (e < 1) e = 1; if (e > 254) e = 254; }
-                f.e[k] = (uint8_t)e;
-                const double step = std::ldexp(1.0, e - 127);
-                for (int c = 0; c < w.n; c++) {
-                    long lo = (long)std::floor(((double)w.cbox[c].lo[k] - (double)f.origin[k]) / step);
-                    long hi = (long)std::ceil(((double)w.cbox[c].hi[k] - (double)f.origin[k]) / step);
-                    // the device evaluates origin + step * q in fp32 (one rounding): keep the box conservative under that rounding too
-                    while (lo > 0 && (float)((double)f.origin[k] + step * (double)lo) > w.cbox[c].lo[k]) lo--;
-                    while (hi < 255 && (float)((double)f.origin[k] + step * (double)hi) < w.cbox[c].hi[k]) hi++;
-                    lo = std::min(255L, std::max(0L, lo)); hi = std::min(255L, std::max(0L, hi));
-                    *q[k][0] |= (uint32_t)lo << (8 * c); *q[k][1] |= (uint32_t)hi << (8 * c);
+        if (out.format == kFlatF4) {
+            out.nodes_f4.resize(W.size());
+            parallel_for(W.size(), [&](size_t i0, size_t i1) {
+                for (size_t i = i0; i < i1; i++) {
+                    const wide4_node& w = W[i]; flat4f_node& f = out.nodes_f4[i];
+                    std::memset(&f, 0, sizeof(f));
+                    float* lo[3] = { f.lo_x, f.lo_y, f.lo_z }; float* hi[3] = { f.hi_x, f.hi_y, f.hi_z };
+                    for (int c = 0; c < 4; c++) {
+                        const bool have = c < w.n;
+                        for (int k = 0; k < 3; k++) { lo[k][c] = have ? w.cbox[c].lo[k] : 3.402823466e+38f; hi[k][c] = have ? w.cbox[c].hi[k] : -3.402823466e+38f; }
+                        f.child[c] = have ? (w.child[c] >= 0 ? w.child[c] * 8 : w.child[c]) : 0x76543210;
+                    }
+                }
+            });
+        } else {
+            // quantise the child boxes conservatively against the node's own box (one exponent per axis)
+            out.nodes.resize(W.size());
+            parallel_for(W.size(), [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) {
+                const wide4_node& w = W[i]; flat4_node& f = out.nodes[i];
+                std::memset(&f, 0, sizeof(f));
+                uint32_t* q[3][2] = { { &f.qlo_x, &f.qhi_x }, { &f.qlo_y, &f.qhi_y }, { &f.qlo_z, &f.qhi_z } };
+                for (int k = 0; k < 3; k++) {
+                    f.origin[k] = w.box.lo[k];
+                    const double ext = (double)w.box.hi[k] - (double)w.box.lo[k];
+                    int e = 1;   // smallest normal exponent
+                    if (ext > 0) { int ex; std::frexp(ext / 255.0, &ex); e = ex + 127; /* 2^ex >= ext/255 */ if (e < 1) e = 1; if (e > 254) e = 254; }
+                    f.e[k] = (uint8_t)e;
+                    const double step = std::ldexp(1.0, e - 127);
+                    for (int c = 0; c < w.n; c++) {
+                        long lo = (long)std::floor(((double)w.cbox[c].lo[k] - (double)f.origin[k]) / step);
+                        long hi = (long)std::ceil(((double)w.cbox[c].hi[k] - (double)f.origin[k]) / step);
+                        // the device evaluates origin + step * q in fp32 (one rounding): keep the box conservative under that rounding too
+                        while (lo > 0 && (float)((double)f.origin[k] + step * (double)lo) > w.cbox[c].lo[k]) lo--;
+                        while (hi < 255 && (float)((double)f.origin[k] + step * (double)hi) < w.cbox[c].hi[k]) hi++;
+                        lo = std::min(255L, std::max(0L, lo)); hi = std::min(255L, std::max(0L, hi));
+                        *q[k][0] |= (uint32_t)lo << (8 * c); *q[k][1] |= (uint32_t)hi << (8 * c);
+                    }
+                }
+                for (int c = 0; c < 4; c++) {
+                    if (c < w.n) { f.mask |= (uint8_t)(1u << c); f.child[c] = w.child[c] >= 0 ? w.child[c] * 4 : w.child[c]; }
+                    else f.child[c] = 0x76543210;
                 }
             }
-            for (int c = 0; c < 4; c++) {
-                if (c < w.n) { f.mask |= (uint8_t)(1u << c); f.child[c] = w.child[c] >= 0 ? w.child[c] * 4 : w.child[c]; }
-                else f.child[c] = 0x76543210;
-            }
+            });
         }
-        });
     }
-    pt.lap("collapse+quantise");
-    out.leaves.resize(R.leaf_prims.size());
-    parallel_for(R.leaf_prims.size(), [&](size_t i0, size_t i1) {
+    pt.lap("node layout");
+    // leaf entries.  Wide formats: in node order, the leaf children of a node one after the other in slot order (flat4_node's implied links).
+    std::vector<uint32_t> entry_src;   // new entry -> position in R.leaf_prims
+    if (out.format == kFlatF2) { entry_src.resize(R.leaf_prims.size()); for (size_t i = 0; i < entry_src.size(); i++) entry_src[i] = (uint32_t)i; }
+    else {
+        entry_src.reserve(R.leaf_prims.size());
+        auto relink = [&](int32_t* child, int n_children, uint32_t* links, uint8_t* mask) {
+            uint32_t counts[4] = { 0, 0, 0, 0 }; const uint32_t leaf_base = (uint32_t)entry_src.size(); uint32_t inner_base = 0; bool have_inner = false;
+            for (int c = 0; c < n_children; c++) {
+                if (child[c] == 0x76543210) continue;
+                if (child[c] >= 0) { if (!have_inner) { inner_base = (uint32_t)child[c]; have_inner = true; } continue; }
+                const uint32_t first = (uint32_t)entry_src.size();
+                for (uint32_t e = (uint32_t)~child[c];; e++) { entry_src.push_back(e); counts[c]++; if (R.leaf_last[e]) break; }
+                child[c] = ~(int32_t)first;
+                if (mask) *mask |= (uint8_t)(16u << c);
+            }
+            if (links) {
+                bool fits = leaf_base < (1u << 30);
+                for (int c = 0; c < 4; c++) if (counts[c] > 4) fits = false;
+                if (!fits) return false;
+                links[0] = (inner_base << 6) | ((counts[0] ? counts[0] - 1 : 0) << 0) | ((counts[1] ? counts[1] - 1 : 0) << 2) | ((counts[2] ? counts[2] - 1 : 0) << 4);
+                links[1] = (leaf_base << 2) | (counts[3] ? counts[3] - 1 : 0);
+            }
+            return true;
+        };
+        if (out.format == kFlatQ4) {
+            for (auto& n : out.nodes) {
+                // inner children are consecutive nodes already (memory order above); their index, not the float4 address, goes into the links
+                int32_t tmp[4]; for (int c = 0; c < 4; c++) tmp[c] = n.child[c] >= 0 && n.child[c] != 0x76543210 ? n.child[c] / 4 : n.child[c];
+                uint32_t prev = 0xffffffffu; bool consecutive = true;
+                for (int c = 0; c < 4; c++) if (tmp[c] >= 0 && tmp[c] != 0x76543210) { if (prev != 0xffffffffu && (uint32_t)tmp[c] != prev + 1) consecutive = false; prev = (uint32_t)tmp[c]; }
+                if (!relink(tmp, 4, n.links, &n.mask) || !consecutive || out.nodes.size() >= (1u << 26)) out.compact_links = false;
+                for (int c = 0; c < 4; c++) if (tmp[c] < 0) n.child[c] = tmp[c];
+            }
+        } else for (auto& n : out.nodes_f4) relink(n.child, 4, nullptr, nullptr);
+    }
+    out.leaves.resize(entry_src.size());
+    parallel_for(entry_src.size(), [&](size_t i0, size_t i1) {
         for (size_t i = i0; i < i1; i++) {
-            const wtri& t = tris[R.leaf_prims[i]];
+            const uint32_t src = entry_src[i];
+            const wtri& t = tris[R.leaf_prims[src]];
             flat_leaf& L = out.leaves[i];
             std::memset(&L, 0, sizeof(L));
-            if (!woop_rows(t.v, L.a, L.b, L.c)) { L.a[3] = 0; }   // all-zero rows: t = 0/0 = NaN, never accepted
-            L.index = (t.tri << 1) | (R.leaf_last[i] ? 1u : 0u); L.node = t.node;
+            const ctl_woop_tri& w = d.woop[t.woop];   // the mesh's own rows: the kernel applies the instance transform to the ray
+            std::memcpy(L.a, w.a, 16); std::memcpy(L.b, w.b, 16); std::memcpy(L.c, w.c, 16);
+            std::memcpy(L.inv, d.node_inv_transforms[t.node].m, 48); L.w33 = d.node_inv_transforms[t.node].m[15];
+            L.index = (t.tri << 1) | (R.leaf_last[src] ? 1u : 0u); L.node = t.node;
         }
     });
     pt.lap("leaf entries");
     out.max_depth = wdepth;
     if (!key.empty()) {
         cache_writer wr("flat", key);
-        if (wr.active()) { wr.value(out.width); wr.value(out.max_depth); wr.vector(out.nodes); wr.vector(out.nodes8); wr.vector(out.leaves); wr.commit(); pt.lap("cache write"); }
+        if (wr.active()) { wr.value(out.format); wr.value(out.max_depth); { const int cl = out.compact_links ? 1 : 0; wr.value(cl); } wr.vector(out.nodes); wr.vector(out.nodes_f4); wr.vector(out.nodes_f2); wr.vector(out.leaves); wr.commit(); pt.lap("cache write"); }
     }
     return true;
 }

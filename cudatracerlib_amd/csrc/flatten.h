@@ -1,4 +1,10 @@
-// flatten.h — world-space single-level re-layout of a two-level scene (see flatten.cpp).
+// flatten.h — single-level world-space acceleration structure over every instanced triangle of a two-level scene (see flatten.cpp).
+//
+// The flattened structure is a CULLING structure only: its boxes live in world space, but every leaf entry carries the
+// OBJECT-space Woop rows of its triangle and the node that instances it, and the traversal kernel evaluates it with the
+// reference's two-level arithmetic (instance inverse transform, object-space Woop test, exact division — Kernel/TraceHelper.cu
+// :526-560, :646-682).  The reported (t, u, v, triangle, node) are therefore the reference's bit for bit; the tree only decides
+// which entries are looked at.
 #pragma once
 #include "../../include/ctl_amd.h"
 #include <vector>
@@ -6,47 +12,63 @@
 
 namespace ctl {
 
-struct flat_leaf { float a[4], b[4], c[4]; uint32_t index; uint32_t node; uint32_t pad[2]; };   // 64 B: Woop rows + (globalTri << 1 | last) + node
-static_assert(sizeof(flat_leaf) == 64, "flat leaf entry is one 64-B fetch group");
+// leaf entry, 128 B = one L2 line holding everything the exact test of one instanced triangle needs, so that a leaf step is ONE dependent
+// fetch: the mesh's own Woop rows (TriIntersectorData, Engine/TriIntersectorData.h:10-40), unchanged; index = globalTri << 1 | lastEntryOfLeaf;
+// node = the instancing node; inv = rows 0..2 of the node's inverse transform and w33 = its element (3,3) (float4x4.h:402-406 divides by it).
+// Measured alternatives on synthetic-SM: 64-B entries + a second, dependent fetch of the instance record 2.17 Grays/s,
+// 16-B entries pointing into the meshes' shared Woop stream 2.16, these 128-B entries 2.25.
+struct flat_leaf { float a[4], b[4], c[4]; uint32_t index; uint32_t node; uint32_t pad[2]; float inv[12]; float w33; uint32_t pad2[3]; };
+static_assert(sizeof(flat_leaf) == 128, "flat leaf entry is one 128-B line");
 
-// 4-wide node with child boxes quantised to 8 bits relative to the node's own box: 64 B = ONE fetch group per visit for
-// four children (the reference's BVH2 node spends the same 64 B on two).  Child box c, axis k:
-//   lo = origin[k] + 2^e[k] * qlo[k][c],  hi = origin[k] + 2^e[k] * qhi[k][c]   (conservative: lo <= true lo, hi >= true hi)
+// node formats (one per flat_scene; the traversal kernels are instantiated per format)
+enum flat_format : int {
+    kFlatQ4 = 0,   // 4-wide, 64 B, child boxes quantised to 8 bits against the node's own box
+    kFlatF4 = 1,   // 4-wide, 128 B (one L2 line), fp32 child boxes stored plane-major
+    kFlatF2 = 2,   // 2-wide, 64 B, fp32 child boxes: the reference's BVHNodeData layout (Engine/TriIntersectorData.h:42-117)
+};
+
+// Q4.  Child box c, axis k:  lo = origin[k] + 2^(e[k]-127) * qlo[k][c],  hi = origin[k] + 2^(e[k]-127) * qhi[k][c]  (conservative).
+// Everything a traversal step needs sits in the first 48 B (three 16-B loads per lane instead of four: the kernels are bound by the
+// number of per-lane L1 accesses): the child links are implied by the layout — the inner children of a node are
+// consecutive nodes, the entries of its leaf children are consecutive leaf entries, both in slot order:
+//   inner child c  = node  (links[0] >> 6) + popcount(inner children in slots < c)
+//   leaf child c   = entry (links[1] >> 2) + sum over leaf children in slots < c of their entry counts
+// with the per-slot entry count - 1 in two bits each: slots 0..2 in links[0] bits 0..5, slot 3 in links[1] bits 0..1 (a leaf has at most
+// four entries; 2^26 nodes, 2^30 entries).  child[] repeats the links explicitly (host code, the test oracle).
 struct flat4_node {
     float origin[3];
-    uint8_t e[3];          // biased float exponents of the per-axis quantisation step (the step is 2^(e-127))
-    uint8_t mask;          // bit c set <=> child c exists
+    uint8_t e[3];          // biased float exponents of the per-axis quantisation step
+    uint8_t mask;          // bit c set <=> child c exists; bit 4 + c set <=> child c is a leaf
     uint32_t qlo_x, qhi_x, qlo_y, qhi_y, qlo_z, qhi_z;   // byte c = child c
-    int32_t child[4];      // >= 0: node index * 4 (float4 units); < 0: ~firstLeafEntry
-    uint32_t pad[2];
+    uint32_t links[2];
+    int32_t child[4];      // >= 0: node index * 4 (float4 units); < 0: ~firstLeafEntry; 0x76543210: none
 };
-static_assert(sizeof(flat4_node) == 64, "wide node is one 64-B fetch group");
+static_assert(sizeof(flat4_node) == 64, "quantised wide node is one 64-B fetch group");
 
-// 8-wide node, 128 B = ONE L2 line per visit.  tools/gather_probe.hip: an MI355X gathers ~56-60 G random records/s from HBM
-// (95-127 G/s from L2) whether a record is 16, 64 or 128 bytes — traversal time is the NUMBER of records fetched, so a node
-// should fill the line it costs.  Eight children per visit need ~20 node fetches per ray where the 4-wide node needs ~34.
-// Child c, axis k: lo = origin[k] + 2^(e[k]-127) * qlo[k][c] (conservative, as flat4_node).  96 B are used; the device loads 6 float4.
-struct flat8_node {
-    float origin[3];
-    uint8_t e[3];
-    uint8_t mask;                  // bit c set <=> child c exists
-    uint32_t qlo_x[2], qhi_x[2];   // byte c of the 8-byte group = child c
-    uint32_t qlo_y[2], qhi_y[2];
-    uint32_t qlo_z[2], qhi_z[2];
-    int32_t child[8];              // >= 0: node index * 8 (float4 units); < 0: ~firstLeafEntry
-    uint32_t pad[8];
+// F4.  Plane-major so that a lane picks the near / far plane of all four children by ADDRESS (the sign of its ray direction
+// selects lo or hi), not by four selects per axis: lo_x[4] hi_x[4] lo_y[4] hi_y[4] lo_z[4] hi_z[4] child[4] pad[4].
+// A missing child has an inverted box (lo = +FLT_MAX, hi = -FLT_MAX) and is never entered.
+struct flat4f_node {
+    float lo_x[4], hi_x[4], lo_y[4], hi_y[4], lo_z[4], hi_z[4];
+    int32_t child[4];      // >= 0: node index * 8 (float4 units); < 0: ~firstLeafEntry; 0x76543210: none
+    uint32_t pad[4];
 };
-static_assert(sizeof(flat8_node) == 128, "8-wide node is one 128-B line");
+static_assert(sizeof(flat4f_node) == 128, "fp32 wide node is one 128-B L2 line");
 
 struct flat_scene {
-    int width = 4;                     // 4: nodes, 8: nodes8
-    std::vector<flat8_node> nodes8;
-    std::vector<flat4_node> nodes;     // node 0 is the root
+    int format = kFlatQ4;
+    std::vector<flat4_node> nodes;        // kFlatQ4; node 0 is the root
+    std::vector<flat4f_node> nodes_f4;    // kFlatF4
+    std::vector<ctl_bvh_node> nodes_f2;   // kFlatF2 (child >= 0: node index * 4)
     std::vector<flat_leaf> leaves;
-    int max_depth = 0;                 // of the 4-wide tree
+    int max_depth = 0;                    // of the stored tree
+    bool compact_links = true;            // Q4: every node's implied links (flat4_node::links) are valid; false -> the kernels read child[]
+    size_t node_bytes() const { return nodes.size() * sizeof(flat4_node) + nodes_f4.size() * sizeof(flat4f_node) + nodes_f2.size() * sizeof(ctl_bvh_node); }
+    int stack_need() const { return format == kFlatF2 ? max_depth + 2 : 3 * max_depth + 2; }   // traversal-stack entries a ray can need
 };
 
 // false when the scene has no triangles or more than `max_triangles` instanced triangles
-bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangles, int width = 8);
+bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangles, int format = kFlatQ4);
+int default_flat_format();   // kFlatQ4 unless $CTL_FLAT_FORMAT says q4 / f4 / f2 (measurement knob)
 
 }  // namespace ctl

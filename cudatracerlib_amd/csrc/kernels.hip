@@ -4,7 +4,7 @@
 // (Integrators/PathTracer.cu:10-113) re-cut at its two trace points; see DESIGN.md "Kernels".
 #include "kernels.h"
 #include "traverse.h"
-#include "traverse8.h"
+#include "traverse_flat.h"
 #include "shading.h"
 #include "compaction.h"
 #include <cstdlib>
@@ -50,15 +50,17 @@ __global__ __launch_bounds__(kWideBlock) void k_raygen(dev_scene S, wave_queues 
 // ------------------------------------------------------------------------------------------------ intersection
 // Persistent waves with lane refill and an LDS traversal stack — see traverse.h (the reference's g_warpCounter pool,
 // Kernel/TraceHelper.cu:386-399, re-derived for 64-wide waves).
-template <bool ANY_HIT, bool COUNT, int FLAT, bool ALPHA>   // FLAT: 0 two-level, 4 / 8 flattened BVH with 4- / 8-wide nodes; ALPHA: alpha-test candidate hits
-__global__ __launch_bounds__(kBlock) void k_intersect(dev_scene S, const float4* __restrict__ ro, const float4* __restrict__ rd, const uint32_t* __restrict__ n_ptr,
+#ifndef CTL_INTERSECT_MIN_WAVES
+#define CTL_INTERSECT_MIN_WAVES 6   // waves per SIMD the register allocation of the traversal kernels leaves room for (80 VGPRs).  Measured: 8 (64 VGPRs) spills and loses a third
+#endif
+template <bool ANY_HIT, bool COUNT, int LAYOUT, bool ALPHA>   // LAYOUT: 0 two-level, 1 + flat_format for the flattened structure; ALPHA: alpha-test candidate hits
+__global__ __launch_bounds__(kBlock, CTL_INTERSECT_MIN_WAVES) void k_intersect(dev_scene S, const float4* __restrict__ ro, const float4* __restrict__ rd, const uint32_t* __restrict__ n_ptr,
                                                        uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ,
                                                        unsigned long long* __restrict__ counts3) {
-    __shared__ int lds_stack[(FLAT ? kLdsStackFlat + 1 : kLdsStack) * kBlock];   // flat: + one spare row that absorbs unused push slots
+    __shared__ int lds_stack[(LAYOUT ? kFlatLdsRows + 1 : kLdsStack) * kBlock];   // flat: + one spare row that absorbs unused push slots
     const uint32_t n = *n_ptr;
     trav_counts tc{ 0, 0, 0, 0, 0 };
-    if (FLAT == 8) intersect_flat8<ANY_HIT, COUNT>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
-    else if (FLAT == 4) intersect_flat<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
+    if (LAYOUT) intersect_flat<ANY_HIT, COUNT, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
     else intersect_persistent<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
     if (COUNT) {
         atomicAdd(&counts3[0], (unsigned long long)tc.n_inner); atomicAdd(&counts3[1], (unsigned long long)tc.n_tri); atomicAdd(&counts3[2], (unsigned long long)tc.n_inst);
@@ -119,22 +121,25 @@ void apply_tuning_from_env() {
     if (done) return;
     done = true;
     if (const char* e = getenv("CTL_REFILL_IDLE")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refill_idle), &v, sizeof(v)); }
-    if (const char* e = getenv("CTL_ANY_SORTED")) { int v = atoi(e) != 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_any_sorted), &v, sizeof(v)); }
     if (const char* e = getenv("CTL_CHUNK_GUIDED")) { int v = atoi(e) != 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chunk_guided), &v, sizeof(v)); }
-    if (const char* e = getenv("CTL_TRI_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tri_batch), &v, sizeof(v)); }
+    if (const char* e = getenv("CTL_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_leaf_batch), &v, sizeof(v)); }
 }
 
 // ------------------------------------------------------------------------------------------------ launch wrappers
 void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P) {
     hipLaunchKernelGGL(k_raygen, dim3(lc.grid_blocks / 4), dim3(kWideBlock), 0, lc.stream, S, Q, P);
 }
+#define CTL_LAUNCH_INTERSECT_L(ANY, CNT, L, ...)                                                                                     \
+    do {                                                                                                                             \
+        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect<ANY, CNT, L, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((k_intersect<ANY, CNT, L, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__);     \
+    } while (0)
 #define CTL_LAUNCH_INTERSECT(ANY, CNT, ...)                                                                                          \
     do {                                                                                                                             \
-        if (S.flat_nodes && S.flat_width == 8) hipLaunchKernelGGL((k_intersect<ANY, CNT, 8, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
-        else if (S.flat_nodes && lc.alpha_test) hipLaunchKernelGGL((k_intersect<ANY, CNT, 4, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
-        else if (S.flat_nodes) hipLaunchKernelGGL((k_intersect<ANY, CNT, 4, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
-        else if (lc.alpha_test) hipLaunchKernelGGL((k_intersect<ANY, CNT, 0, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((k_intersect<ANY, CNT, 0, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__);     \
+        if (!S.flat_nodes) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 0, __VA_ARGS__);                                                         \
+        else if (S.flat_format == kFmtF4) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 2, __VA_ARGS__);                                          \
+        else if (S.flat_format == kFmtQ4) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 1, __VA_ARGS__);                                          \
+        else CTL_LAUNCH_INTERSECT_L(ANY, CNT, 3, __VA_ARGS__);                                                                       \
     } while (0)
 void launch_intersect_closest(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node) {
     CTL_LAUNCH_INTERSECT(false, false, S, ro, rd, n_ptr, work, hit, hit_node, (uint32_t*)nullptr, (unsigned long long*)nullptr);

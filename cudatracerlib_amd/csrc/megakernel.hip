@@ -6,69 +6,16 @@
 #include "shading.h"
 #include "compaction.h"
 #include "tracer.h"
-#include "traverse.h"
+#include "traverse_flat.h"
 #include "mitsuba_loader.h"   // unsupported_error
 #include <climits>
 
 namespace ctl {
 
-// single-ray traversal of the flattened 4-wide BVH (flatten.h): closest hit, or any hit in (tmin, tmax)
+// single-ray traversal of the flattened BVH (traverse_flat.h): closest hit, or any hit in (tmin, tmax)
 template <bool ANY_HIT>
 __device__ bool trace_single(const dev_scene& S, f3 o, f3 d, float tmin, float tmax, float& ht, float& hu, float& hv, int& htri, int& hnode) {
-    const float4* __restrict__ nodes = S.flat_nodes;
-    const float4* __restrict__ leaves = S.flat_leaves;
-    const float idx = rcp_guarded(d.x), idy = rcp_guarded(d.y), idz = rcp_guarded(d.z);
-    const float oox = o.x * idx, ooy = o.y * idy, ooz = o.z * idz;
-    int stack[kStackSize]; int sp = 0; stack[0] = kSentinel;
-    int node = S.flat_root;
-    ht = tmax; hu = hv = 0.0f; htri = -1; hnode = -1;
-    while (node != kSentinel) {
-        if (node >= 0) {
-            const float4 q0 = nodes[node], q1 = nodes[node + 1], q2 = nodes[node + 2], q3 = nodes[node + 3];
-            const uint32_t meta = __float_as_uint(q0.w);
-            const float ax = __uint_as_float((meta & 0xffu) << 23) * idx, ay = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy, az = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
-            const float bx = __builtin_fmaf(q0.x, idx, -oox), by = __builtin_fmaf(q0.y, idy, -ooy), bz = __builtin_fmaf(q0.z, idz, -ooz);
-            const uint32_t lx = __float_as_uint(q1.x), hx = __float_as_uint(q1.y), ly = __float_as_uint(q1.z), hy = __float_as_uint(q1.w), lz = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
-            const bool px = idx >= 0.0f, py = idy >= 0.0f, pz = idz >= 0.0f;
-            const uint32_t nx = px ? lx : hx, fx = px ? hx : lx, ny = py ? ly : hy, fy = py ? hy : ly, nz = pz ? lz : hz, fz = pz ? hz : lz;
-            const int ch[4] = { __float_as_int(q2.z), __float_as_int(q2.w), __float_as_int(q3.x), __float_as_int(q3.y) };
-            uint32_t key[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const float tnx = __builtin_fmaf((float)((nx >> (8 * c)) & 0xffu), ax, bx), tfx = __builtin_fmaf((float)((fx >> (8 * c)) & 0xffu), ax, bx);
-                const float tny = __builtin_fmaf((float)((ny >> (8 * c)) & 0xffu), ay, by), tfy = __builtin_fmaf((float)((fy >> (8 * c)) & 0xffu), ay, by);
-                const float tnz = __builtin_fmaf((float)((nz >> (8 * c)) & 0xffu), az, bz), tfz = __builtin_fmaf((float)((fz >> (8 * c)) & 0xffu), az, bz);
-                const float cmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin)), cmax = fminf(fminf(tfx, tfy), fminf(tfz, ht));
-                key[c] = ((cmax >= cmin) && ((meta >> (24 + c)) & 1u)) ? ((__float_as_uint(cmin) & ~3u) | (uint32_t)c) : 0xffffffffu;
-            }
-#define CTL_CSWAP(a, b) { const uint32_t lo_ = key[a] < key[b] ? key[a] : key[b], hi_ = key[a] < key[b] ? key[b] : key[a]; key[a] = lo_; key[b] = hi_; }
-            CTL_CSWAP(0, 1) CTL_CSWAP(2, 3) CTL_CSWAP(0, 2) CTL_CSWAP(1, 3) CTL_CSWAP(1, 2)
-#undef CTL_CSWAP
-            for (int i = 3; i >= 1; i--) if (key[i] != 0xffffffffu) stack[++sp] = ch[key[i] & 3u];
-            node = key[0] != 0xffffffffu ? ch[key[0] & 3u] : stack[sp--];
-        } else {
-            const float4* p = leaves + (size_t)(~node) * 4;
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-            const uint32_t index = __float_as_uint(q3.x);
-            const float Oz = q0.w - o.x * q0.x - o.y * q0.y - o.z * q0.z;
-            const float invDz = __builtin_amdgcn_rcpf(d.x * q0.x + d.y * q0.y + d.z * q0.z);
-            const float t = Oz * invDz;
-            if (t > tmin && t < ht) {
-                const float Ox = q1.w + o.x * q1.x + o.y * q1.y + o.z * q1.z, Dx = d.x * q1.x + d.y * q1.y + d.z * q1.z;
-                const float u = Ox + t * Dx;
-                if (u >= 0.0f) {
-                    const float Oy = q2.w + o.x * q2.x + o.y * q2.y + o.z * q2.z, Dy = d.x * q2.x + d.y * q2.y + d.z * q2.z;
-                    const float v = Oy + t * Dy;
-                    // USE_ALPHA of __traceRay_internal__ (TraceHelper.cu:135-153): scenes with alpha maps test every candidate hit
-                    if (v >= 0.0f && u + v <= 1.0f && (!S.alpha_maps || alpha_survives(S.tri_data, S.node_info, S.mats, S.images, (int)(index >> 1), (int)__float_as_uint(q3.y), u, v))) {
-                        ht = t; hu = u; hv = v; htri = (int)(index >> 1); hnode = (int)__float_as_uint(q3.y); if (ANY_HIT) return true;
-                    }
-                }
-            }
-            node = (index & 1) ? stack[sp--] : node - 1;
-        }
-    }
-    return htri >= 0;
+    return trace_single_flat<ANY_HIT, true>(S, o, d, tmin, tmax, ht, hu, hv, htri, hnode);
 }
 
 // pathKernel2<DIRECT> + PathTrace<DIRECT> (Integrators/PathTracer.cu:182-194, 10-113), no participating media
@@ -166,7 +113,7 @@ PathTracer::PathTracer() {
     grid_blocks = prop.multiProcessorCount * 8;
 }
 void PathTracer::InitializeScene(Scene* s) {
-    if (!s->S.flat_nodes || s->S.flat_width != 4) throw unsupported_error("PathTracer (megakernel): the scene must be created with CTL_SCENE_FLATTEN (4-wide nodes)");
+    if (!s->S.flat_nodes) throw unsupported_error("PathTracer (megakernel): the scene must be created with CTL_SCENE_FLATTEN");
     Tracer<true>::InitializeScene(s);
 }
 void PathTracer::Resize(unsigned int _w, unsigned int _h) {

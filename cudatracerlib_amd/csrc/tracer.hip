@@ -22,7 +22,7 @@ int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 
 void require_device() { if (device_count() <= 0) throw hip_error("no HIP device: the MI355X path tracer has no CPU fallback"); apply_tuning_from_env(); }
 
 // ------------------------------------------------------------------------------------------------ Scene
-Scene::Scene(const ctl_scene_desc& d, bool flatten) {
+Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
     require_device();
     if (!d.n_nodes) throw std::runtime_error("ctl_scene_create: scene has no nodes");
     if (d.env_map_index != 0xffffffffu && (d.env_map_index >= d.n_lights_buf || d.lights[d.env_map_index].type != CTL_LIGHT_INFINITE))
@@ -242,24 +242,23 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten) {
             throw std::runtime_error("ctl_scene_create: scene BVH depth " + std::to_string(top) + " + mesh BVH depth " + std::to_string(bottom) +
                                      " does not fit the traversal stack of " + std::to_string(kStackSize) + " entries (rebuild the meshes with CTL_BVH_BINNED, whose depth is bounded)");
     }
-    S.flat_nodes = nullptr; S.flat_leaves = nullptr; S.flat_root = 0; S.flat_width = 0;
+    S.flat_nodes = nullptr; S.flat_leaves = nullptr; S.flat_root = 0; S.flat_format = 0; S.flat_compact = 0; S.inst_w_one = 0;
     if (flatten) {
-        // node width: 4 (64-byte nodes).  CTL_FLAT_WIDTH=8 selects the 128-byte 8-wide layout (traverse8.h) — measured on MI355X it
-        // needs 24 instead of 34 node visits per ray on synthetic-SM but runs 1.85x slower (the kernel is bound by VALU issue, and an
-        // 8-wide node costs more than twice the instructions of a 4-wide one); kept as an experiment, see DESIGN.md §3.
-        int width = 4;
-        if (const char* e = getenv("CTL_FLAT_WIDTH")) { if (atoi(e) == 8) width = 8; }
+        // node format: Q4 (64-B 4-wide nodes with 8-bit child boxes) unless the caller or $CTL_FLAT_FORMAT asks for F4 / F2 (DESIGN.md §3 has the measurements)
         flat_scene F;
-        bool ok = flatten_scene(d, F, (size_t)1 << 30, width);   // up to 2^30 instanced triangles (64 GiB of leaf entries)
-        if (ok && width == 8 && 7 * F.max_depth + 4 > kStackSize) { width = 4; ok = flatten_scene(d, F, (size_t)1 << 30, 4); }
-        if (ok) {
-            if (width == 4 && 3 * F.max_depth + 4 > kStackSize) throw std::runtime_error("ctl_scene_create: flattened BVH too deep for the traversal stack");
-            if (width == 8) flat_nodes_.upload((const float4*)F.nodes8.data(), F.nodes8.size() * 8);
-            else flat_nodes_.upload((const float4*)F.nodes.data(), F.nodes.size() * 4);
-            F.leaves.emplace_back(); std::memset(&F.leaves.back(), 0, sizeof(flat_leaf));   // one spare entry behind the last leaf
-            flat_leaves_.upload((const float4*)F.leaves.data(), F.leaves.size() * 4);
+        if (flatten_scene(d, F, (size_t)1 << 30, flat_format < 0 ? default_flat_format() : flat_format)) {   // up to 2^30 instanced triangles (64 GiB of leaf entries)
+            if (F.stack_need() + 2 > kStackSize) throw std::runtime_error("ctl_scene_create: flattened BVH too deep for the traversal stack");
+            if (F.format == kFlatQ4) flat_nodes_.upload((const float4*)F.nodes.data(), F.nodes.size() * 4);
+            else if (F.format == kFlatF4) flat_nodes_.upload((const float4*)F.nodes_f4.data(), F.nodes_f4.size() * 8);
+            else flat_nodes_.upload((const float4*)F.nodes_f2.data(), F.nodes_f2.size() * 4);
+            for (const flat_leaf& L : F.leaves) if (L.node >= d.n_nodes) throw std::runtime_error("ctl_scene_create: flattened leaf entry out of range");
+            F.leaves.emplace_back(); std::memset(&F.leaves.back(), 0, sizeof(flat_leaf)); F.leaves.back().index = 1;   // one spare (closing) entry behind the last leaf
+            flat_leaves_.upload((const float4*)F.leaves.data(), F.leaves.size() * 8);
+            // every node transform affine with w == 1 exactly (what add_node produces): the kernels skip the load of w and the division by it
+            S.inst_w_one = 1; for (uint32_t k = 0; k < d.n_nodes; k++) if (d.node_inv_transforms[k].m[15] != 1.0f) S.inst_w_one = 0;
             CTL_HIP(hipDeviceSynchronize());
-            S.flat_nodes = flat_nodes_.p; S.flat_leaves = flat_leaves_.p; S.flat_root = 0; S.flat_width = width;
+            S.flat_nodes = flat_nodes_.p; S.flat_leaves = flat_leaves_.p; S.flat_root = 0; S.flat_format = F.format; S.flat_compact = (F.format == kFlatQ4 && F.compact_links) ? 1 : 0;
+            if (const char* e = getenv("CTL_FLAT_COMPACT")) { if (atoi(e) == 0) S.flat_compact = 0; }   // measurement knob
         }
     }
     CTL_HIP(hipDeviceSynchronize());
@@ -515,7 +514,6 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     Q.counts = counts_.p; Q.work = work_.p; Q.mat_counts = mat_counts_.p;
     const dev_scene& S = m_pScene->S;
     const launch_ctx lc{ stream, grid_blocks, m_sParameters.getValue("AlphaTest") != 0 && S.alpha_maps != 0 };
-    if (lc.alpha_test && S.flat_nodes && S.flat_width == 8) throw std::runtime_error("AlphaTest is not available with the 8-wide flattened BVH");
     pass_params P{};
     P.t1 = d_t1p; P.t2 = (const float2*)d_t2p;
     P.batch = n_batch;

@@ -1,0 +1,294 @@
+// traverse_flat.h — traversal of the flattened world-space BVH (flatten.h) by persistent wave64 waves, one ray per lane.
+//
+// What is reported is the reference's: every leaf entry is evaluated with the two-level arithmetic of intersectKernel
+// (Kernel/TraceHelper.cu:526-560 ray into the instance's object space, :646-682 Woop test with an exact division), in the
+// reference's expression order, so (t, u, v, triangle, node) are bit-identical to the two-level traversal (traverse.h) whenever
+// both look at the winning triangle; the world-space tree only culls.  Rays that hit two triangles at exactly the same t may
+// report either (the visiting order differs), as between any two BVHs.
+//
+// Execution model (measured on MI355X, profiles/r02*): the kernel is bound by VALU issue, not by HBM — so the design minimises
+// instructions per useful lane:
+//  * lane refill as in traverse.h (a wave claims rays from a device cursor, idle lanes are refilled together);
+//  * node steps and leaf steps are separate wave-wide phases.  A lane that reaches a leaf POSTPONES it (one pending leaf per
+//    lane) and keeps descending the tree speculatively; the wave runs the leaf code only once enough lanes hold a pending leaf
+//    (or nobody has an inner node left); a leaf step tests one entry per lane.  In a unified loop the Woop code ran with ~8 of 64 lanes;
+//  * the node step is branch-free: children sorted by entry distance with a compare + select network, pushes are unconditional LDS
+//    stores (unused ones land in a spare row), the pop is an LDS read issued before the slab arithmetic;
+//  * F4 nodes are plane-major: the sign of the ray direction picks the near / far plane of all four children by address.
+#pragma once
+#include "traverse.h"
+
+namespace ctl {
+
+enum { kFmtQ4 = 0, kFmtF4 = 1, kFmtF2 = 2 };   // = flat_format (flatten.h)
+
+constexpr int kFlatLdsRows = 19;          // stack entries per lane in LDS; + 1 spare row = 20 KiB per 256-thread workgroup -> 8 workgroups per CU
+__device__ int g_leaf_batch = 24;         // run the leaf phase once this many lanes hold a pending leaf entry (CTL_LEAF_BATCH)
+
+struct flat_stack {
+    int* lds;                             // this lane's column, stride 256
+    int ovf[kStackSize - kFlatLdsRows];
+    __device__ __forceinline__ int get(int i) const { return i < kFlatLdsRows ? lds[i * 256] : ovf[i - kFlatLdsRows]; }
+    __device__ __forceinline__ void set(int i, int v) { if (i < kFlatLdsRows) lds[i * 256] = v; else ovf[i - kFlatLdsRows] = v; }
+};
+
+__device__ __forceinline__ float rcp_cull(float d) {   // slab tests only cull: the hardware reciprocal (1 ulp) of the guarded direction
+    const float ooeps = 8.271806125530277e-25f;   // exp2(-80), TraceHelper.cu:417-420
+    return __builtin_amdgcn_rcpf(fabsf(d) > ooeps ? d : copysign_bits(ooeps, d));
+}
+
+// One Woop triangle against the object-space ray (TraceHelper.cu:646-682), the reference's expression order, exact division.
+// Returns true when the entry is the new closest hit (ht, hu, hv, htri, hnode updated).
+template <bool ALPHA>
+__device__ __forceinline__ bool flat_woop_test(const dev_scene& S, const float4 v00, const float4 v11, const float4 v22, uint32_t index, int nd, const f3 o, const f3 d, float tmin,
+                                               float& ht, float& hu, float& hv, int& htri, int& hnode) {
+    const float Oz = v00.w - o.x * v00.x - o.y * v00.y - o.z * v00.z;
+    const float invDz = 1.0f / (d.x * v00.x + d.y * v00.y + d.z * v00.z);
+    const float t = Oz * invDz;
+    if (t > tmin && t < ht) {
+        const float Ox = v11.w + o.x * v11.x + o.y * v11.y + o.z * v11.z;
+        const float Dx = d.x * v11.x + d.y * v11.y + d.z * v11.z;
+        const float u = Ox + t * Dx;
+        if (u >= 0.0f) {
+            const float Oy = v22.w + o.x * v22.x + o.y * v22.y + o.z * v22.z;
+            const float Dy = d.x * v22.x + d.y * v22.y + d.z * v22.z;
+            const float v = Oy + t * Dy;
+            if (v >= 0.0f && u + v <= 1.0f && (!ALPHA || alpha_survives(S.tri_data, S.node_info, S.mats, S.images, (int)(index >> 1), nd, u, v))) {
+                ht = t; hu = u; hv = v; htri = (int)(index >> 1); hnode = nd;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+// One leaf entry (flat_leaf, 128 B) against the world-space ray: the ray through the node's inverse transform (TraceHelper.cu:526-560; the rows
+// travel with the entry), then the Woop test.  Returns the next entry of the leaf, or -1 when this was its last one.
+template <bool ANY_HIT, bool ALPHA>
+__device__ __forceinline__ int flat_leaf_test(const dev_scene& S, uint32_t e, float orgx, float orgy, float orgz, float dirx, float diry, float dirz, float tmin,
+                                              float& ht, float& hu, float& hv, int& htri, int& hnode, bool& got) {
+    const float4* __restrict__ p = S.flat_leaves + (size_t)e * 8;
+    const float4 v00 = p[0], v11 = p[1], v22 = p[2];
+    const uint2 iw = *(const uint2*)(p + 3);   // {globalTri << 1 | last, node}
+    const float4 r0 = p[4], r1 = p[5], r2 = p[6];
+    m34 m; m.r[0][0] = r0.x; m.r[0][1] = r0.y; m.r[0][2] = r0.z; m.r[0][3] = r0.w; m.r[1][0] = r1.x; m.r[1][1] = r1.y; m.r[1][2] = r1.z; m.r[1][3] = r1.w;
+    m.r[2][0] = r2.x; m.r[2][1] = r2.y; m.r[2][2] = r2.z; m.r[2][3] = r2.w;
+    const f3 d = xform_dir(m, f3(dirx, diry, dirz));
+    f3 o = xform_point(m, f3(orgx, orgy, orgz));
+    if (!S.inst_w_one) { const float w33 = p[7].x; o = f3(o.x / w33, o.y / w33, o.z / w33); }   // float4x4.h:402-406 divides by w; x / 1.0f == x, so scenes whose w are all 1 skip it
+    if (flat_woop_test<ALPHA>(S, v00, v11, v22, iw.x, (int)iw.y, o, d, tmin, ht, hu, hv, htri, hnode)) { got = true; if (ANY_HIT) return -1; }
+    return (iw.x & 1u) ? -1 : (int)(e + 1);
+}
+
+// ---- node steps.  Each returns the children the ray enters, nearest first, in c[0..n_hit): links as stored in the node.
+struct ray_cull { float idx, idy, idz, oox, ooy, ooz; int sx, sy, sz; };   // sx/sy/sz = 1 where the direction component is negative
+
+#define CTL_CSWAP_PAIR(i, j) { const bool s_ = dd[j] < dd[i]; const float td_ = s_ ? dd[j] : dd[i]; dd[j] = s_ ? dd[i] : dd[j]; dd[i] = td_; \
+                               const int tc_ = s_ ? c[j] : c[i]; c[j] = s_ ? c[i] : c[j]; c[i] = tc_; }
+
+// F4: 128-B plane-major node (flat4f_node)
+__device__ __forceinline__ int node_step_f4(const float4* __restrict__ nodes, int node, const ray_cull& R, float tmin, float ht, int c[4]) {
+    const float4* __restrict__ p = nodes + node;
+    const float4 nx = p[R.sx], fx = p[1 - R.sx], ny = p[2 + R.sy], fy = p[3 - R.sy], nz = p[4 + R.sz], fz = p[5 - R.sz];
+    const float4 lk = p[6];
+    const float nxa[4] = { nx.x, nx.y, nx.z, nx.w }, fxa[4] = { fx.x, fx.y, fx.z, fx.w }, nya[4] = { ny.x, ny.y, ny.z, ny.w }, fya[4] = { fy.x, fy.y, fy.z, fy.w };
+    const float nza[4] = { nz.x, nz.y, nz.z, nz.w }, fza[4] = { fz.x, fz.y, fz.z, fz.w };
+    c[0] = __float_as_int(lk.x); c[1] = __float_as_int(lk.y); c[2] = __float_as_int(lk.z); c[3] = __float_as_int(lk.w);
+    float dd[4];
+    const float inf = __builtin_huge_valf();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float tnx = __builtin_fmaf(nxa[k], R.idx, -R.oox), tfx = __builtin_fmaf(fxa[k], R.idx, -R.oox);
+        const float tny = __builtin_fmaf(nya[k], R.idy, -R.ooy), tfy = __builtin_fmaf(fya[k], R.idy, -R.ooy);
+        const float tnz = __builtin_fmaf(nza[k], R.idz, -R.ooz), tfz = __builtin_fmaf(fza[k], R.idz, -R.ooz);
+        const float cmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+        const float cmax = fminf(fminf(tfx, tfy), fminf(tfz, ht));
+        dd[k] = (cmax >= cmin) ? cmin : inf;
+    }
+    CTL_CSWAP_PAIR(0, 1) CTL_CSWAP_PAIR(2, 3) CTL_CSWAP_PAIR(0, 2) CTL_CSWAP_PAIR(1, 3) CTL_CSWAP_PAIR(1, 2)
+    return dd[3] < inf ? 4 : (dd[2] < inf ? 3 : (dd[1] < inf ? 2 : (dd[0] < inf ? 1 : 0)));
+}
+
+// Q4: 64-B node with 8-bit child boxes (flat4_node).  compact: the child links are implied by the layout and only the first 48 B are
+// loaded — three per-lane L1 accesses instead of four.
+__device__ __forceinline__ int node_step_q4(const float4* __restrict__ nodes, int node, const ray_cull& R, float tmin, float ht, int c[4], bool compact) {
+    const float4* __restrict__ p = nodes + node;
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    const uint32_t meta = __float_as_uint(q0.w);
+    if (compact) {
+        const uint32_t w0 = __float_as_uint(q2.z), w1 = __float_as_uint(q2.w);
+        const uint32_t leafm = meta >> 28, innerm = (meta >> 24) & ~leafm & 15u;
+        const uint32_t inner_base = w0 >> 6, leaf_base = w1 >> 2;
+        // entries of the leaf children in slots 0..2 (0 for an inner child), prefix sums = first entry of each leaf child
+        const uint32_t n0 = (leafm & 1u) ? (w0 & 3u) + 1u : 0u, n1 = (leafm & 2u) ? ((w0 >> 2) & 3u) + 1u : 0u, n2 = (leafm & 4u) ? ((w0 >> 4) & 3u) + 1u : 0u;
+        const uint32_t i1 = innerm & 1u, i2 = i1 + ((innerm >> 1) & 1u), i3 = i2 + ((innerm >> 2) & 1u);
+        c[0] = (leafm & 1u) ? ~(int)leaf_base : (int)(inner_base << 2);
+        c[1] = (leafm & 2u) ? ~(int)(leaf_base + n0) : (int)((inner_base + i1) << 2);
+        c[2] = (leafm & 4u) ? ~(int)(leaf_base + n0 + n1) : (int)((inner_base + i2) << 2);
+        c[3] = (leafm & 8u) ? ~(int)(leaf_base + n0 + n1 + n2) : (int)((inner_base + i3) << 2);
+    } else {
+        const float4 q3 = p[3];
+        c[0] = __float_as_int(q3.x); c[1] = __float_as_int(q3.y); c[2] = __float_as_int(q3.z); c[3] = __float_as_int(q3.w);
+    }
+    const float ax = __uint_as_float((meta & 0xffu) << 23) * R.idx, ay = __uint_as_float(((meta >> 8) & 0xffu) << 23) * R.idy, az = __uint_as_float(((meta >> 16) & 0xffu) << 23) * R.idz;
+    const float bx = __builtin_fmaf(q0.x, R.idx, -R.oox), by = __builtin_fmaf(q0.y, R.idy, -R.ooy), bz = __builtin_fmaf(q0.z, R.idz, -R.ooz);
+    const uint32_t lx = __float_as_uint(q1.x), hx = __float_as_uint(q1.y), ly = __float_as_uint(q1.z), hy = __float_as_uint(q1.w), lz = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
+    const uint32_t nx = R.sx ? hx : lx, fx = R.sx ? lx : hx, ny = R.sy ? hy : ly, fy = R.sy ? ly : hy, nz = R.sz ? hz : lz, fz = R.sz ? lz : hz;
+    float dd[4];
+    const float inf = __builtin_huge_valf();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float tnx = __builtin_fmaf((float)((nx >> (8 * k)) & 0xffu), ax, bx), tfx = __builtin_fmaf((float)((fx >> (8 * k)) & 0xffu), ax, bx);
+        const float tny = __builtin_fmaf((float)((ny >> (8 * k)) & 0xffu), ay, by), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 0xffu), ay, by);
+        const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 0xffu), az, bz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 0xffu), az, bz);
+        const float cmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+        const float cmax = fminf(fminf(tfx, tfy), fminf(tfz, ht));
+        dd[k] = ((cmax >= cmin) && ((meta >> (24 + k)) & 1u)) ? cmin : inf;
+    }
+    CTL_CSWAP_PAIR(0, 1) CTL_CSWAP_PAIR(2, 3) CTL_CSWAP_PAIR(0, 2) CTL_CSWAP_PAIR(1, 3) CTL_CSWAP_PAIR(1, 2)
+    return dd[3] < inf ? 4 : (dd[2] < inf ? 3 : (dd[1] < inf ? 2 : (dd[0] < inf ? 1 : 0)));
+}
+
+// F2: the reference's BVHNodeData (two fp32 child boxes, 64 B)
+__device__ __forceinline__ int node_step_f2(const float4* __restrict__ nodes, int node, const ray_cull& R, float tmin, float ht, int c[4]) {
+    const float4* __restrict__ p = nodes + node;
+    const float4 n0 = p[0], n1 = p[1], nz = p[2], cn = p[3];
+    float c0min, c0max, c1min, c1max;
+    slab2(n0, n1, nz, R.idx, R.idy, R.idz, R.oox, R.ooy, R.ooz, tmin, ht, c0min, c0max, c1min, c1max);
+    const bool t0 = c0max >= c0min, t1 = c1max >= c1min;
+    const int k0 = __float_as_int(cn.x), k1 = __float_as_int(cn.y);
+    const bool swap = t1 && (!t0 || c1min < c0min);   // child 1 first
+    c[0] = swap ? k1 : k0; c[1] = swap ? k0 : k1;
+    return (t0 ? 1 : 0) + (t1 ? 1 : 0);
+}
+#undef CTL_CSWAP_PAIR
+
+// The whole intersect kernel body over the flattened structure: `n` rays (ro, rd) -> hit / hit_node (closest) and/or occ (any-hit flag).
+template <bool ANY_HIT, bool COUNT, bool ALPHA, int FMT>
+__device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4* __restrict__ ro, const float4* __restrict__ rd, uint32_t n, uint32_t* __restrict__ work,
+                                               float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack, trav_counts& cnt) {
+    const int lane = threadIdx.x & 63;
+    const int refill_idle = g_refill_idle, leaf_batch = g_leaf_batch;
+    const bool compact = S.flat_compact != 0;
+    flat_stack st; st.lds = lds_stack + threadIdx.x;
+    bool has_ray = false;
+    uint32_t ray_id = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, tmin = 0;
+    ray_cull R{ 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    float ht = 0, hu = 0, hv = 0; int htri = -1, hnode = -1;
+    int sp = 0, node = kSentinel, pend = -1;      // pend: postponed leaf (its first entry in flat_leaves), -1 = none
+    const float4* __restrict__ nodes = S.flat_nodes;
+    uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = (n == 0);
+
+    for (;;) {
+        // ---- refill idle lanes
+        const unsigned long long idle = __ballot(!has_ray);
+        if (idle != 0ull && !exhausted && (__popcll(idle) >= refill_idle || idle == ~0ull)) {
+            if (chunk_next >= chunk_end) {
+                const uint32_t claim = guided_chunk(n, chunk_end);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work, claim);
+                base = __shfl(base, 0, 64);
+                chunk_next = base; chunk_end = base + claim < n ? base + claim : n;
+                if (base >= n) { exhausted = true; chunk_next = chunk_end = n; }
+            }
+            if (!exhausted) {
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
+                const uint32_t avail = chunk_end - chunk_next, want = (uint32_t)__popcll(idle);
+                const uint32_t my = chunk_next + prefix;
+                if (!has_ray && prefix < avail) {
+                    const float4 o = ro[my], d = rd[my];
+                    ray_id = my; has_ray = true;
+                    ox = o.x; oy = o.y; oz = o.z; tmin = o.w; dx = d.x; dy = d.y; dz = d.z;
+                    R.idx = rcp_cull(dx); R.idy = rcp_cull(dy); R.idz = rcp_cull(dz);
+                    R.oox = ox * R.idx; R.ooy = oy * R.idy; R.ooz = oz * R.idz;
+                    R.sx = R.idx < 0.0f ? 1 : 0; R.sy = R.idy < 0.0f ? 1 : 0; R.sz = R.idz < 0.0f ? 1 : 0;
+                    ht = d.w; hu = hv = 0.0f; htri = -1; hnode = -1;
+                    sp = 0; st.lds[0] = kSentinel; node = S.flat_root; pend = -1;
+                }
+                chunk_next += want < avail ? want : avail;
+            }
+        }
+        if (__ballot(has_ray) == 0ull) { if (exhausted) break; continue; }
+
+        // ---- a lane standing on a leaf with a free slot postpones it and goes on with the next stack entry
+        if (has_ray && node < 0 && pend < 0) { pend = ~node; node = st.get(sp); sp--; }
+        const bool at_inner = has_ray && (unsigned)node < (unsigned)kSentinel;
+        const bool at_leaf = has_ray && pend >= 0;
+        const unsigned long long m_inner = __ballot(at_inner), m_leaf = __ballot(at_leaf);
+        bool finished = false;
+        if (m_leaf != 0ull && (__popcll(m_leaf) >= leaf_batch || m_inner == 0ull)) {
+            // ---- leaf phase: every lane that holds a leaf tests its next entry
+            if (at_leaf) {
+                if (COUNT) { cnt.n_tri++; if (lane == (int)__builtin_ctzll(m_leaf)) cnt.w_tri++; }
+                bool got = false;
+                pend = flat_leaf_test<ANY_HIT, ALPHA>(S, (uint32_t)pend, ox, oy, oz, dx, dy, dz, tmin, ht, hu, hv, htri, hnode, got);
+                if (ANY_HIT && got) finished = true;
+            }
+        } else {
+            // ---- node phase
+            if (at_inner) {
+                if (COUNT) { cnt.n_inner++; if (lane == (int)__builtin_ctzll(m_inner)) cnt.w_inner++; }
+                const int popped = st.get(sp);   // issued early: used when no child is entered
+                int c[4]; int n_hit;
+                if (FMT == kFmtF4) n_hit = node_step_f4(nodes, node, R, tmin, ht, c);
+                else if (FMT == kFmtQ4) n_hit = node_step_q4(nodes, node, R, tmin, ht, c, compact);
+                else n_hit = node_step_f2(nodes, node, R, tmin, ht, c);
+                node = n_hit ? c[0] : popped;
+                const int top = sp + n_hit - 1;    // n_hit == 0: one entry popped
+                if (FMT == kFmtF2) {
+                    if (n_hit == 2) st.set(top, c[1]);
+                } else if (top < kFlatLdsRows) {   // common case: unconditional LDS stores, unused ones into the spare row
+                    st.lds[(n_hit >= 2 ? top : kFlatLdsRows) * 256] = c[1];
+                    st.lds[(n_hit >= 3 ? top - 1 : kFlatLdsRows) * 256] = c[2];
+                    st.lds[(n_hit >= 4 ? top - 2 : kFlatLdsRows) * 256] = c[3];
+                } else {
+                    if (n_hit >= 4) st.set(top - 2, c[3]);
+                    if (n_hit >= 3) st.set(top - 1, c[2]);
+                    if (n_hit >= 2) st.set(top, c[1]);
+                }
+                sp = top;
+            }
+        }
+        if (has_ray && !finished) finished = (node == kSentinel) && pend < 0;
+        if (finished) {
+            if (ANY_HIT && occ) occ[ray_id] = htri >= 0 ? 1u : 0u;
+            if (hit) { hit[ray_id] = make_float4(ht, hu, hv, __int_as_float(htri)); hit_node[ray_id] = hnode; }
+            has_ray = false; node = kSentinel; pend = -1;
+        }
+    }
+}
+
+// Single-ray form for the megakernel plugin (one lane walks a whole path): same node steps, same entry test, private stack.
+template <bool ANY_HIT, bool ALPHA_DYNAMIC>
+__device__ bool trace_single_flat(const dev_scene& S, f3 o, f3 d, float tmin, float tmax, float& ht, float& hu, float& hv, int& htri, int& hnode) {
+    const float4* __restrict__ nodes = S.flat_nodes;
+    ray_cull R;
+    R.idx = rcp_cull(d.x); R.idy = rcp_cull(d.y); R.idz = rcp_cull(d.z);
+    R.oox = o.x * R.idx; R.ooy = o.y * R.idy; R.ooz = o.z * R.idz;
+    R.sx = R.idx < 0.0f ? 1 : 0; R.sy = R.idy < 0.0f ? 1 : 0; R.sz = R.idz < 0.0f ? 1 : 0;
+    int stack[kStackSize]; int sp = 0; stack[0] = kSentinel;
+    int node = S.flat_root;
+    const int fmt = S.flat_format;
+    ht = tmax; hu = hv = 0.0f; htri = -1; hnode = -1;
+    while (node != kSentinel) {
+        if (node >= 0) {
+            int c[4]; int n_hit;
+            if (fmt == kFmtF4) n_hit = node_step_f4(nodes, node, R, tmin, ht, c);
+            else if (fmt == kFmtQ4) n_hit = node_step_q4(nodes, node, R, tmin, ht, c, S.flat_compact != 0);
+            else n_hit = node_step_f2(nodes, node, R, tmin, ht, c);
+            for (int i = n_hit - 1; i >= 1; i--) stack[++sp] = c[i];
+            node = n_hit ? c[0] : stack[sp--];
+        } else {
+            bool got = false; int next = ~node;
+            // USE_ALPHA of __traceRay_internal__ (TraceHelper.cu:135-153): scenes with alpha maps test every candidate hit
+            while (next >= 0 && !(ANY_HIT && got))
+                next = (ALPHA_DYNAMIC && S.alpha_maps) ? flat_leaf_test<ANY_HIT, true>(S, (uint32_t)next, o.x, o.y, o.z, d.x, d.y, d.z, tmin, ht, hu, hv, htri, hnode, got)
+                                                       : flat_leaf_test<ANY_HIT, false>(S, (uint32_t)next, o.x, o.y, o.z, d.x, d.y, d.z, tmin, ht, hu, hv, htri, hnode, got);
+            if (ANY_HIT && got) return true;
+            node = stack[sp--];
+        }
+    }
+    return htri >= 0;
+}
+
+} // namespace ctl

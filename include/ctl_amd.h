@@ -298,10 +298,15 @@ int ctl_builder_finalize(ctl_builder* b, ctl_scene_desc* out);
 typedef struct ctl_scene ctl_scene;
 /* UpdateKernel(scene) (Kernel/TraceHelper.cu:182-217): uploads + re-lays-out the arrays in HBM. */
 int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out);
-/* flags: CTL_SCENE_FLATTEN = additionally bake every node's transform into its triangles and traverse ONE world-space BVH
- * (64 B of HBM per instanced triangle).  Same triangle/node/material per hit; t,u,v agree with the two-level traversal to
- * fp32 round-off instead of bit-for-bit. */
+/* flags: CTL_SCENE_FLATTEN = additionally build ONE world-space BVH over all instanced triangles (128 B of HBM per instanced
+ * triangle) and traverse that.  The flattened tree only culls: every leaf entry is evaluated with the reference's instance
+ * transform + object-space Woop arithmetic (Kernel/TraceHelper.cu:526-560,646-682), so t,u,v,triangle,node equal the two-level
+ * traversal bit for bit.  CTL_SCENE_FLAT_FORMAT(f) picks the node format (measurement; default Q4). */
 enum { CTL_SCENE_FLATTEN = 1 };
+enum { CTL_FLAT_Q4 = 0,    /* 4-wide, 64-B nodes, 8-bit child boxes (default) */
+       CTL_FLAT_F4 = 1,    /* 4-wide, 128-B nodes, fp32 child boxes           */
+       CTL_FLAT_F2 = 2 };  /* 2-wide, 64-B nodes in the reference's BVHNodeData layout */
+#define CTL_SCENE_FLAT_FORMAT(f) ((((uint32_t)(f)) + 1u) << 8)
 int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out);
 void ctl_scene_destroy(ctl_scene* s);
 /* On-disk cache of compiled geometry — the role of the reference's .xmsh files (Engine/Mesh.cpp:46-98,199-290; DynamicScene::CreateNode
@@ -309,9 +314,20 @@ void ctl_scene_destroy(ctl_scene* s);
  * (TriangleData, BVH nodes, Woop rows) and CTL_SCENE_FLATTEN stores / reloads the flattened BVH, both keyed by a hash of their
  * inputs.  NULL or "" disables; the default comes from the environment variable CTL_CACHE_DIR.  Host only. */
 int ctl_set_cache_dir(const char* dir);
-/* The host half of CTL_SCENE_FLATTEN without a device (tests, cache warming): builds (or loads) the flattened BVH of `desc` with
- * `width` = 4 or 8 and reports out4 = { inner nodes, leaf entries, depth of the wide tree, low 64 bits of a hash of the arrays }. */
-int ctl_flatten_probe(const ctl_scene_desc* desc, uint32_t width, uint64_t* out4);
+/* The host half of CTL_SCENE_FLATTEN without a device (tests, cache warming): builds (or loads) the flattened BVH of `desc` in
+ * node format `format` (CTL_FLAT_*) and reports out4 = { inner nodes, leaf entries, depth of the tree, low 64 bits of a hash of the arrays }. */
+int ctl_flatten_probe(const ctl_scene_desc* desc, uint32_t format, uint64_t* out4);
+/* The same, handing out the arrays (host memory owned by the handle): what ctl_scene_create_ex uploads.  The test oracle
+ * traverses these very arrays on the CPU (counts "with the same BVH").  Layouts: cudatracerlib_amd/csrc/flatten.h. */
+typedef struct ctl_flat_bvh ctl_flat_bvh;
+typedef struct {
+    uint32_t format, max_depth;      /* CTL_FLAT_*, depth of the stored tree                                      */
+    const void* nodes; uint64_t n_nodes; uint32_t node_bytes;   /* node 0 is the root; child >= 0: node index * node_bytes / 16 */
+    const void* leaves; uint64_t n_leaves;   /* 128 B each: object-space Woop rows a,b,c, {globalTri << 1 | last, node, 0, 0}, rows 0..2 of the node's inverse transform, {w33,0,0,0} */
+} ctl_flat_bvh_desc;
+int ctl_flat_bvh_build(const ctl_scene_desc* desc, uint32_t format, ctl_flat_bvh** out);
+int ctl_flat_bvh_arrays(const ctl_flat_bvh* h, ctl_flat_bvh_desc* out);
+void ctl_flat_bvh_destroy(ctl_flat_bvh* h);
 /* ParseMitsubaScene (Engine/SceneLoader/Mitsuba/MitsubaLoader.h:13): fills a builder from a Mitsuba-0.5 XML file. */
 int ctl_parse_mitsuba_scene(ctl_builder* b, const char* xml_path, int32_t* width_inout, int32_t* height_inout);
 

@@ -42,6 +42,9 @@ def load():
     o.orc_render.restype = u64
     o.orc_render.argtypes = [C.c_void_p, u32, u32, u32, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, u32, u32, C.c_int]
     o.orc_intersect.argtypes = [C.c_void_p, C.c_void_p, u32, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    o.orc_set_flat_bvh.argtypes = [C.c_void_p]; o.orc_set_flat_bvh.restype = None
+    o.orc_render_counting.argtypes = [C.c_int]; o.orc_render_counting.restype = None
+    o.orc_render_counts.argtypes = [C.c_void_p]; o.orc_render_counts.restype = None
     o.orc_fresnel_dielectric_ext.restype = f32; o.orc_fresnel_dielectric_ext.argtypes = [f32, f32, C.c_void_p]
     o.orc_fresnel_conductor_exact.argtypes = [f32, C.c_void_p, C.c_void_p, C.c_void_p]
     o.orc_sensor_sample_ray.argtypes = [C.c_void_p, f32, f32, C.c_void_p, C.c_void_p]
@@ -104,19 +107,27 @@ class Oracle:
     def __init__(self):
         self.lib = load()
 
-    def intersect(self, desc, rays, any_hit=False, count=False, threads=8, alpha_test=False):
+    def intersect(self, desc, rays, any_hit=False, count=False, threads=8, alpha_test=False, flat=None):
+        """flat: a ctl_flat_bvh_desc (cudatracerlib_amd.FlatBvh(...).desc) -> traverse the product's flattened BVH instead of the two-level structure"""
         r = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         hits = np.zeros(len(r), dtype=[("dist", "f4"), ("node_idx", "i4"), ("tri_idx", "i4"), ("u", "f4"), ("v", "f4")])
         cnt = (u64 * 5)()
-        self.lib.orc_intersect(C.addressof(desc), r.ctypes.data, len(r), hits.ctypes.data, (1 if any_hit else 0) | (2 if alpha_test else 0), C.addressof(cnt) if count else None, threads)
+        self.lib.orc_set_flat_bvh(C.addressof(flat) if flat is not None else None)
+        try:
+            self.lib.orc_intersect(C.addressof(desc), r.ctypes.data, len(r), hits.ctypes.data, (1 if any_hit else 0) | (2 if alpha_test else 0), C.addressof(cnt) if count else None, threads)
+        finally:
+            self.lib.orc_set_flat_bvh(None)
         if count:
             return hits, dict(n_inner=cnt[0], n_tri=cnt[1], n_inst=cnt[2])
         return hits
 
-    def render(self, desc, width, height, n_passes=1, tables=None, direct=True, max_path_length=8, rr_start=5, threads=8, rows=None, half_host_quirk=False, alpha_test=False, block_counts=None):
+    def render(self, desc, width, height, n_passes=1, tables=None, direct=True, max_path_length=8, rr_start=5, threads=8, rows=None, half_host_quirk=False, alpha_test=False, block_counts=None,
+               flat=None, counts=None):
         """pathKernel2<DIRECT,false> over all pixels (Integrators/PathTracer.cu:182-194). tables = list of (t1, t2) per pass or None.
         alpha_test: traceRay<USE_ALPHA> when the scene has alpha maps (what the reference's single-ray path does; its wavefront
         intersectKernel has no alpha test).
+        flat: a ctl_flat_bvh_desc -> every ray walks the product's flattened BVH (same hits, other visiting order).
+        counts: a dict that receives the traversal statistics of this render (path_rays, path_inner, path_tri, path_inst, occ_rays, ...).
         Returns (pixel_data (h, w, 7), rays)."""
         img = np.zeros((height, width, 7), np.float32)
         y0, y1 = (0, height) if rows is None else rows
@@ -130,10 +141,20 @@ class Oracle:
         if block_counts is not None:   # samples per 64x64 block for these passes (what a block sampler decided), row-major blocks
             bc = np.ascontiguousarray(block_counts, np.uint8).ravel()
             self.lib.orc_set_block_counts(bc.ctypes.data, (width + 63) // 64)
+        self.lib.orc_set_flat_bvh(C.addressof(flat) if flat is not None else None)
+        if counts is not None:
+            self.lib.orc_render_counting(1)
         try:
             rays = self.lib.orc_render(C.addressof(desc), width, height, n_passes, p1, p2, 1 if direct else 0, max_path_length, rr_start,
                                        img.ctypes.data, threads, y0, y1, (1 if half_host_quirk else 0) | (2 if alpha_test else 0))
         finally:
+            self.lib.orc_set_flat_bvh(None)
+            if counts is not None:
+                c8 = (u64 * 8)()
+                self.lib.orc_render_counts(c8)
+                self.lib.orc_render_counting(0)
+                for i, k in enumerate(("path_rays", "path_inner", "path_tri", "path_inst", "occ_rays", "occ_inner", "occ_tri", "occ_inst")):
+                    counts[k] = counts.get(k, 0) + int(c8[i])
             if block_counts is not None:
                 self.lib.orc_set_block_counts(None, 0)
         return img, int(rays)

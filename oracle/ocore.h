@@ -122,6 +122,7 @@ struct Scene {
     ctl_scene_desc d;
     bool half_host_quirk = false;   // reproduce half::ToFloat's host branch (Math/half.h:76-83)
     bool alpha_test = false;        // KernelDynamicScene::doAlphaMapping (DynamicScene.cpp:586): traceRay<USE_ALPHA = true>
+    const ctl_flat_bvh_desc* flat = nullptr;   // when set, traceRay walks the product's flattened BVH (the arrays ctl_flat_bvh_build hands out)
 };
 inline bool sceneHasAlphaMaps(const ctl_scene_desc& d) {   // MaterialBuffer::hasAlphaMappings
     for (uint32_t i = 0; i < d.n_materials; i++) if (d.materials[i].alpha_state != CTL_ALPHA_DISABLED) return true;
@@ -131,7 +132,86 @@ inline bool alphaSurvive(const Scene& S, uint32_t tri, uint32_t nodeIdx, float u
 
 // Kernel/TraceHelper.cu:88-180 (__traceRay_internal__<false> + traceRay).  any_hit/tmax generalise it to the
 // wavefront kernel's interface (TraceHelper.cu:326-734): a ctl_ray carries tmin in a.w and tmax in b.w.
+// Traversal of the product's FLATTENED world-space BVH (cudatracerlib_amd/csrc/flatten.h; not a reference structure).  The tree only
+// culls: every leaf entry is evaluated exactly as the two-level traversal evaluates a triangle — the ray through the node's inverse
+// transform (TraceHelper.cu:526-560), then the Woop test (:646-682) — so the accepted hit is the reference's.  Plain depth-first
+// order, children nearest first (the product's kernel visits speculatively and may count more nodes; the counts returned here are the
+// algorithmic ones).  n_inst stays 0: there is no instance entry.
+inline bool traceRayFlat(const Scene& S, V3 ori, V3 dir, float tmin_tri, float tmax, bool any_hit, float node_tmin, Hit& res, TravCounts* cnt) {
+    const ctl_scene_desc& g = S.d; const ctl_flat_bvh_desc& F = *S.flat;
+    res.init(); res.dist = tmax;
+    if (!F.n_nodes || !F.n_leaves) return false;
+    const float ooeps = exp2f(-80.0f);
+    const float idx = 1.0f / (fabsf(dir.x) > ooeps ? dir.x : copysign_bits(ooeps, dir.x)), idy = 1.0f / (fabsf(dir.y) > ooeps ? dir.y : copysign_bits(ooeps, dir.y)),
+                idz = 1.0f / (fabsf(dir.z) > ooeps ? dir.z : copysign_bits(ooeps, dir.z));
+    const float oox = ori.x * idx, ooy = ori.y * idy, ooz = ori.z * idz;
+    const int sx = idx < 0.0f, sy = idy < 0.0f, sz = idz < 0.0f;
+    const float* nodes = (const float*)F.nodes; const uint32_t* leaves = (const uint32_t*)F.leaves;
+    std::vector<int> stack(4 * (size_t)F.max_depth + 8); int sp = 0; stack[0] = EntrypointSentinel;
+    int node = 0; bool found = false;
+    while (node != EntrypointSentinel) {
+        if (node >= 0) {
+            if (cnt) cnt->n_inner++;
+            const float* p = nodes + (size_t)node * 4;
+            float dd[4]; int c[4]; int width = 4;
+            const float inf = INFINITY;
+            if (F.format == CTL_FLAT_F4) {
+                const float *nx = p + 4 * sx, *fx = p + 4 * (1 - sx), *ny = p + 4 * (2 + sy), *fy = p + 4 * (3 - sy), *nz = p + 4 * (4 + sz), *fz = p + 4 * (5 - sz);
+                for (int k = 0; k < 4; k++) {
+                    const float tnx = std::fmaf(nx[k], idx, -oox), tfx = std::fmaf(fx[k], idx, -oox), tny = std::fmaf(ny[k], idy, -ooy), tfy = std::fmaf(fy[k], idy, -ooy);
+                    const float tnz = std::fmaf(nz[k], idz, -ooz), tfz = std::fmaf(fz[k], idz, -ooz);
+                    const float cmin = fmax2(fmax2(tnx, tny), fmax2(tnz, node_tmin)), cmax = fmin2(fmin2(tfx, tfy), fmin2(tfz, res.dist));
+                    dd[k] = (cmax >= cmin) ? cmin : inf; std::memcpy(&c[k], p + 24 + k, 4);
+                }
+            } else if (F.format == CTL_FLAT_Q4) {
+                uint32_t w[16]; std::memcpy(w, p, 64);
+                const uint32_t meta = w[3];
+                auto p2 = [](uint32_t e) { uint32_t b = e << 23; float f; std::memcpy(&f, &b, 4); return f; };
+                const float ax = p2(meta & 0xffu) * idx, ay = p2((meta >> 8) & 0xffu) * idy, az = p2((meta >> 16) & 0xffu) * idz;
+                const float bx = std::fmaf(p[0], idx, -oox), by = std::fmaf(p[1], idy, -ooy), bz = std::fmaf(p[2], idz, -ooz);
+                const uint32_t nx = sx ? w[5] : w[4], fx = sx ? w[4] : w[5], ny = sy ? w[7] : w[6], fy = sy ? w[6] : w[7], nz = sz ? w[9] : w[8], fz = sz ? w[8] : w[9];
+                for (int k = 0; k < 4; k++) {
+                    const float tnx = std::fmaf((float)((nx >> (8 * k)) & 0xffu), ax, bx), tfx = std::fmaf((float)((fx >> (8 * k)) & 0xffu), ax, bx);
+                    const float tny = std::fmaf((float)((ny >> (8 * k)) & 0xffu), ay, by), tfy = std::fmaf((float)((fy >> (8 * k)) & 0xffu), ay, by);
+                    const float tnz = std::fmaf((float)((nz >> (8 * k)) & 0xffu), az, bz), tfz = std::fmaf((float)((fz >> (8 * k)) & 0xffu), az, bz);
+                    const float cmin = fmax2(fmax2(tnx, tny), fmax2(tnz, node_tmin)), cmax = fmin2(fmin2(tfx, tfy), fmin2(tfz, res.dist));
+                    dd[k] = ((cmax >= cmin) && ((meta >> (24 + k)) & 1u)) ? cmin : inf; c[k] = (int)w[12 + k];
+                }
+            } else {   // CTL_FLAT_F2: BVHNodeData
+                width = 2;
+                const float c0lox = std::fmaf(p[0], idx, -oox), c0hix = std::fmaf(p[1], idx, -oox), c0loy = std::fmaf(p[2], idy, -ooy), c0hiy = std::fmaf(p[3], idy, -ooy);
+                const float c1lox = std::fmaf(p[4], idx, -oox), c1hix = std::fmaf(p[5], idx, -oox), c1loy = std::fmaf(p[6], idy, -ooy), c1hiy = std::fmaf(p[7], idy, -ooy);
+                const float c0loz = std::fmaf(p[8], idz, -ooz), c0hiz = std::fmaf(p[9], idz, -ooz), c1loz = std::fmaf(p[10], idz, -ooz), c1hiz = std::fmaf(p[11], idz, -ooz);
+                const float c0min = spanBegin(c0lox, c0hix, c0loy, c0hiy, c0loz, c0hiz, node_tmin), c0max = spanEnd(c0lox, c0hix, c0loy, c0hiy, c0loz, c0hiz, res.dist);
+                const float c1min = spanBegin(c1lox, c1hix, c1loy, c1hiy, c1loz, c1hiz, node_tmin), c1max = spanEnd(c1lox, c1hix, c1loy, c1hiy, c1loz, c1hiz, res.dist);
+                dd[0] = (c0max >= c0min) ? c0min : inf; dd[1] = (c1max >= c1min) ? c1min : inf; dd[2] = dd[3] = inf;
+                std::memcpy(&c[0], p + 12, 4); std::memcpy(&c[1], p + 13, 4); c[2] = c[3] = EntrypointSentinel;
+            }
+            auto cswap = [&](int i, int j) { if (dd[j] < dd[i]) { std::swap(dd[i], dd[j]); std::swap(c[i], c[j]); } };
+            if (width == 4) { cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2); } else cswap(0, 1);
+            int n_hit = 0; for (int k = 0; k < 4; k++) if (dd[k] < inf) n_hit++;
+            for (int i = n_hit - 1; i >= 1; i--) stack[++sp] = c[i];
+            node = n_hit ? c[0] : stack[sp--];
+        } else {
+            const uint32_t* e = leaves + (size_t)(uint32_t)(~node) * 32;   // 128 B: Woop rows a, b, c, {globalTri << 1 | last, node, 0, 0}, then a copy of the node's inverse transform
+            const uint32_t index = e[12], nodeIdx = e[13];
+            if (cnt) cnt->n_tri++;
+            ctl_woop_tri w; std::memcpy(&w, e, 48);
+            M44 modl; std::memcpy(modl.d, g.node_inv_transforms[nodeIdx].m, 64);
+            const V3 d = transformDir(modl, dir), o = transformPoint(modl, ori);   // TraceHelper.cu:526-560 (per entry here; per instance there)
+            float t, u, v;
+            if (woopIntersect(w, o, d, tmin_tri, res.dist, t, u, v) && (!S.alpha_test || alphaSurvive(S, index >> 1, nodeIdx, u, v))) {
+                res.node = nodeIdx; res.tri = index >> 1; res.u = u; res.v = v; res.dist = t; found = true;
+                if (any_hit) return true;
+            }
+            node = (index & 1) ? stack[sp--] : node - 1;
+        }
+    }
+    return found;
+}
+
 inline bool traceRay(const Scene& S, V3 ori, V3 dir, float tmin_tri, float tmax, bool any_hit, float node_tmin, Hit& res, TravCounts* cnt = nullptr) {
+    if (S.flat) return traceRayFlat(S, ori, dir, tmin_tri, tmax, any_hit, node_tmin, res, cnt);
     const ctl_scene_desc& g = S.d;
     res.init(); res.dist = tmax;
     if (!g.n_nodes) return false;
@@ -165,12 +245,17 @@ inline bool traceRay(const Scene& S, V3 ori, V3 dir, float tmin_tri, float tmax,
     // any-hit: `stop` ends both levels as intersectKernel<true> does (TraceHelper.cu:684-688)
     return tracerayTemplate(ori, dir, res.dist, node_tmin, nodeClb, (const float*)g.scene_bvh_nodes, 0, g.scene_start_node, cnt, &stop);
 }
-inline Hit traceRayClosest(const Scene& S, V3 ori, V3 dir) {   // traceRay(const Ray&) TraceHelper.h:31-37
-    Hit h; traceRay(S, ori, dir, S.d.ray_trace_eps, FLT_MAX, false, 0.0f, h); if (!h.hasHit()) h.dist = FLT_MAX; return h;
+// per-thread traversal counters of a render in counting mode (orc_render_counts): [0] path rays, [1] occlusion rays
+struct RenderCounts { TravCounts c[2]; uint64_t rays[2] = { 0, 0 }; };
+inline RenderCounts*& renderCounts() { static thread_local RenderCounts* p = nullptr; return p; }
+inline Hit traceRayClosest(const Scene& S, V3 ori, V3 dir, int kind = 0) {   // traceRay(const Ray&) TraceHelper.h:31-37
+    RenderCounts* rc = renderCounts();
+    if (rc) rc->rays[kind]++;
+    Hit h; traceRay(S, ori, dir, S.d.ray_trace_eps, FLT_MAX, false, 0.0f, h, rc ? &rc->c[kind] : nullptr); if (!h.hasHit()) h.dist = FLT_MAX; return h;
 }
 // Engine/KernelDynamicScene.cu:70-80
 inline bool occluded(const Scene& S, V3 o, V3 d, float tmin, float tmax) {
-    Hit r2 = traceRayClosest(S, o, d);
+    Hit r2 = traceRayClosest(S, o, d, 1);
     bool end = r2.dist < tmax - S.d.ray_trace_eps;
     if (std::isinf(tmax) && !r2.hasHit()) end = false;
     return r2.dist > tmin + S.d.ray_trace_eps && end;

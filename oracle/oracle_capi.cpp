@@ -2,6 +2,7 @@
 #include "ocore.h"
 #include "orng.h"
 #include <thread>
+#include <mutex>
 #include <atomic>
 #include <vector>
 
@@ -91,8 +92,12 @@ void orc_sensor_sample_ray(const ctl_sensor* s, float px, float py, float* o, fl
 // ---- intersect ------------------------------------------------------------------------------------------------
 // intersectKernel semantics (TraceHelper.cu:326-734): tmin = ray.a.w at node and triangle level, tmax = ray.b.w.
 // any_hit: bit 0 = first hit ends the ray, bit 1 = alpha-test candidate hits (traceRay<USE_ALPHA>, TraceHelper.cu:135-153)
+// the flattened BVH the following orc_intersect / orc_render calls traverse instead of the two-level structure (NULL = two-level, the reference's).
+// The arrays are the product's (ctl_flat_bvh_arrays): "the CPU restatement in counting mode with the same BVH" (SURVEY §8d).
+static const ctl_flat_bvh_desc* g_flat = nullptr;
+void orc_set_flat_bvh(const ctl_flat_bvh_desc* f) { g_flat = f; }
 void orc_intersect(const ctl_scene_desc* desc, const ctl_ray* rays, uint32_t n, ctl_hit* hits, int any_hit, ctl_traversal_counts* counts, int n_threads) {
-    Scene S; S.d = *desc; S.alpha_test = (any_hit & 2) != 0; any_hit &= 1;
+    Scene S; S.d = *desc; S.alpha_test = (any_hit & 2) != 0; any_hit &= 1; S.flat = g_flat;
     if (n_threads < 1) n_threads = 1;
     std::vector<TravCounts> tc(n_threads);
     auto work = [&](int tid) {
@@ -182,13 +187,18 @@ int orc_alpha_test(const ctl_scene_desc* desc, const ctl_material* mat, float u,
 // samples per 64x64 block for the following orc_render calls (a block sampler's decision for one pass); NULL = one sample everywhere
 static const uint8_t* g_block_counts = nullptr; static uint32_t g_blocks_x = 0;
 void orc_set_block_counts(const uint8_t* counts, uint32_t blocks_x) { g_block_counts = counts; g_blocks_x = blocks_x; }
+// counting mode of orc_render: traversal statistics of every ray the following renders trace.  out8 = {path rays, n_inner, n_tri, n_inst,
+// occlusion rays, n_inner, n_tri, n_inst}; orc_render_counts(NULL) switches counting off, a non-NULL call reads and resets the totals.
+static bool g_count_render = false; static uint64_t g_render_counts[8] = {};
+void orc_render_counting(int on) { g_count_render = on != 0; for (auto& v : g_render_counts) v = 0; }
+void orc_render_counts(uint64_t* out8) { for (int i = 0; i < 8; i++) { out8[i] = g_render_counts[i]; g_render_counts[i] = 0; } }
 // tables: n_passes consecutive (t1[30*4096], t2[30*4096*2]) pairs, or NULL -> own SequenceGenerator
 // (one Compute() per pass, as Tracer<true>::DoPass -> UpdateKernel does, Kernel/Tracer.h:229).
 // Renders rows [y0,y1) only (bounded CPU-baseline samples).  Returns the number of rays traced.
 uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t n_passes, const float* tables1, const float* tables2,
                     int direct, int maxPathLength, int rrStart, ctl_pixel_data* img, int n_threads, uint32_t y0, uint32_t y1, int half_host_quirk) {
     // half_host_quirk: bit 0 = half::ToFloat host branch, bit 1 = alpha test on (doAlphaMapping: every traceRay, incl. Occluded)
-    Scene S; S.d = *desc; S.half_host_quirk = (half_host_quirk & 1) != 0; S.alpha_test = (half_host_quirk & 2) != 0 && sceneHasAlphaMaps(*desc);
+    Scene S; S.d = *desc; S.half_host_quirk = (half_host_quirk & 1) != 0; S.alpha_test = (half_host_quirk & 2) != 0 && sceneHasAlphaMaps(*desc); S.flat = g_flat;
     PerspectiveSensor sensor; sensor.update(desc->camera);
     if (n_threads < 1) n_threads = 1;
     if (y1 > H) y1 = H;
@@ -197,6 +207,7 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
     const size_t N1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH, N2 = N1 * 2;
     if (!tables1) { own1.resize(N1); own2.resize(N2); }
     std::atomic<uint64_t> total(0);
+    std::mutex cmu;
     for (uint32_t pass = 0; pass < n_passes; pass++) {
         const float *t1, *t2;
         if (tables1) { t1 = tables1 + pass * N1; t2 = tables2 + pass * N2; }
@@ -204,6 +215,7 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
         std::atomic<uint32_t> nextRow(y0);
         auto work = [&]() {
             uint64_t rays = 0;
+            RenderCounts rc; renderCounts() = g_count_render ? &rc : nullptr;
             for (;;) {
                 uint32_t y = nextRow.fetch_add(1);
                 if (y >= y1) break;
@@ -221,6 +233,8 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
                 }
             }
             total += rays;
+            renderCounts() = nullptr;
+            if (g_count_render) { std::lock_guard<std::mutex> l(cmu); for (int k = 0; k < 2; k++) { g_render_counts[k * 4 + 0] += rc.rays[k]; g_render_counts[k * 4 + 1] += rc.c[k].n_inner; g_render_counts[k * 4 + 2] += rc.c[k].n_tri; g_render_counts[k * 4 + 3] += rc.c[k].n_inst; } }
         };
         std::vector<std::thread> th;
         for (int t = 1; t < n_threads; t++) th.emplace_back(work);

@@ -41,7 +41,8 @@ def render(gpu, cls, scene, tables, passes=None, shard=None, **params):
 
 def test_oracle_band_equals_the_gpu_rows(gpu, orc, workload):
     """Bands of the full-size frame rendered by the oracle against the same rows of the GPU frame, for the two-level layout (the
-    reference's traversal arithmetic, bit for bit) and the flattened layout that bench.py times (t, u, v to fp32 round-off)."""
+    reference's traversal arithmetic, bit for bit) and the flattened layout that bench.py times — held to the SAME thresholds: its leaf
+    entries are evaluated with the reference's instance-transform + Woop arithmetic, the world-space tree only culls."""
     sc, d, flat, tables = workload
     two_level = gpu.Scene(d)
     bands = (0, 531, 1072)                                            # top edge, middle, bottom edge of the frame
@@ -74,8 +75,8 @@ def test_oracle_band_equals_the_gpu_rows(gpu, orc, workload):
     # is tight where paths are short and statistical (band mean) at the full depth.
     check(two_level, 2, 0.998, 1e-3)
     check(two_level, DEPTH, 0.97, 5e-3)
-    check(flat, 2, 0.99, 5e-3)
-    check(flat, DEPTH, 0.5, 2e-2)
+    check(flat, 2, 0.998, 1e-3)
+    check(flat, DEPTH, 0.97, 5e-3)
     outside = np.ones(H, bool); outside[1072:1080] = False
     assert not np.any(want[DEPTH, 1072][outside])                     # the oracle really rendered the band only
 

@@ -73,23 +73,59 @@ def test_traversal_counts_match_oracle(gpu, orc):
         assert abs(g[k] - o[k]) <= 0.15 * o[k], (k, g[k], o[k])
 
 
-@pytest.mark.parametrize("any_hit", [False, True])
-def test_flattened_world_space_bvh(gpu, orc, any_hit):
-    """CTL_SCENE_FLATTEN: one world-space BVH over all instanced triangles.  Same triangle and node per ray as the
-    two-level traversal; t,u,v to fp32 round-off (the world-space Woop rows are recomputed in double), not bit-for-bit."""
-    sc = scenes.synthetic_sm(64, 64, n_instances=300, subdiv=2)
-    rays = camera_and_random_rays(sc.desc, 30000, 7, any_tmax=any_hit)
-    scene = gpu.Scene(sc.desc, flatten=True)
+def check_flat(gpu, orc, desc, rays, any_hit, fmt):
+    """the flattened layout against the oracle's restatement of the reference's TWO-LEVEL traversal: bit for bit, equal-t ties excepted"""
+    scene = gpu.Scene(desc, flatten=True, flat_format=fmt)
     got = gpu.intersect(scene, rays, any_hit=any_hit)
-    want = orc.intersect(sc.desc, rays, any_hit=any_hit)
-    if any_hit:
-        assert (np.array_equal(got["tri_idx"] >= 0, want["tri_idx"] >= 0)) or ((got["tri_idx"] >= 0) != (want["tri_idx"] >= 0)).mean() < 2e-4
-        return
+    want = orc.intersect(desc, rays, any_hit=any_hit)
+    if any_hit:   # which triangle is found first depends on the visiting order; occlusion itself must agree
+        assert np.array_equal(got["tri_idx"] >= 0, want["tri_idx"] >= 0)
+        return got
+    for k in ("tri_idx", "node_idx"):
+        bad = np.nonzero(got[k] != want[k])[0]
+        assert all(got["dist"][i] == want["dist"][i] for i in bad), (k, bad[:10])      # only rays that hit two triangles at the same t
+        assert len(bad) <= len(rays) // 1000
     same = got["tri_idx"] == want["tri_idx"]
-    assert same.mean() > 0.9995          # grazing edges / equal-t ties may pick a neighbour
-    assert np.array_equal(got["node_idx"][same], want["node_idx"][same])
-    h = same & (want["tri_idx"] >= 0)
-    # world-space vertices are recovered from the fp32 Woop rows (relative error ~1e-6 of the coordinate magnitude)
-    diag = float(np.linalg.norm(np.array(sc.desc.box_max[:]) - np.array(sc.desc.box_min[:])))
-    assert np.allclose(got["dist"][h], want["dist"][h], rtol=2e-5, atol=5e-6 * diag)
-    assert np.allclose(got["u"][h], want["u"][h], atol=2e-3) and np.allclose(got["v"][h], want["v"][h], atol=2e-3)
+    for k in ("dist", "u", "v"):
+        assert np.array_equal(got[k][same].view(np.uint32), want[k][same].view(np.uint32)), k
+    assert (want["tri_idx"] >= 0).mean() > 0.2
+    return got
+
+
+@pytest.mark.parametrize("fmt", ["f4", "q4", "f2"])
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_flattened_world_space_bvh(gpu, orc, any_hit, fmt):
+    """CTL_SCENE_FLATTEN: one world-space BVH over all instanced triangles, every node format.  The tree only culls — each leaf entry is
+    evaluated with the reference's instance-transform + Woop arithmetic — so (t, u, v, triangle, node) equal the two-level traversal."""
+    sc = scenes.synthetic_sm(64, 64, n_instances=300, subdiv=2)
+    check_flat(gpu, orc, sc.desc, camera_and_random_rays(sc.desc, 30000, 7, any_tmax=any_hit), any_hit, fmt)
+
+
+def test_flattened_cornell_and_ragged(gpu, orc):
+    sc = scenes.cornell_box(64, 64, glass_sphere=True)
+    check_flat(gpu, orc, sc.desc, camera_and_random_rays(sc.desc, 20000, 11), False, "f4")
+    scene = gpu.Scene(sc.desc, flatten=True)
+    assert len(gpu.intersect(scene, np.zeros((0, 8), np.float32))) == 0
+    for n in (1, 63, 64, 65, 1000):
+        rays = camera_and_random_rays(sc.desc, max(n, 6), 3)[:n]
+        got, want = gpu.intersect(scene, rays), orc.intersect(sc.desc, rays)
+        assert np.array_equal(got["tri_idx"], want["tri_idx"]) and np.array_equal(got["dist"].view(np.uint32), want["dist"].view(np.uint32))
+
+
+@pytest.mark.parametrize("fmt", ["f4", "q4", "f2"])
+def test_flattened_counts_against_the_oracle_on_the_same_arrays(gpu, orc, fmt):
+    """N_inner / N_tri from the CPU restatement in counting mode with the SAME BVH.  The oracle walks the product's own
+    flattened arrays depth-first; the kernel postpones leaves and descends speculatively, so it may visit somewhat more nodes, never fewer
+    leaf entries than the closest hit needs."""
+    from cudatracerlib_amd import api
+    sc = scenes.synthetic_sm(64, 64, n_instances=200, subdiv=2)
+    rays = camera_and_random_rays(sc.desc, 20000, 4)
+    fb = api.FlatBvh(sc.desc, api.FLAT_FORMATS[fmt])
+    want_hits, o = orc.intersect(sc.desc, rays, count=True, flat=fb.desc)
+    two_level = orc.intersect(sc.desc, rays)
+    assert np.array_equal(want_hits["dist"].view(np.uint32), two_level["dist"].view(np.uint32))    # the oracle's two traversals agree
+    scene = gpu.Scene(sc.desc, flatten=True, flat_format=fmt)
+    g = gpu.intersect_count(scene, rays)
+    assert g["n_inst"] == 0 and o["n_inst"] == 0
+    assert 0.98 * o["n_inner"] <= g["n_inner"] <= 1.35 * o["n_inner"], (g, o)
+    assert 0.98 * o["n_tri"] <= g["n_tri"] <= 1.35 * o["n_tri"], (g, o)

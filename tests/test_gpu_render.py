@@ -147,8 +147,8 @@ def test_megakernel_path_tracer_plugin(gpu, orc, scene_kw):
     got, rays_mega = out["PathTracer"]
     g, w = got[..., :3], want[..., :3]
     assert np.array_equal(got[..., 6], want[..., 6])
-    assert (np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2).mean() >= 0.99        # flattened layout: t,u,v to fp32 round-off
-    assert abs(g.mean() - w.mean()) <= 5e-3 * w.mean()
+    assert (np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2).mean() >= 0.995       # the flattened layout reports the reference's t,u,v
+    assert abs(g.mean() - w.mean()) <= 1e-3 * w.mean()
     wave, rays_wave = out["WavefrontPathTracer"]
     assert np.isclose(got[..., :3], wave[..., :3], rtol=1e-3, atol=1e-3).all(axis=2).mean() >= 0.995
     assert abs(int(rays_mega) - int(rays_wave)) <= 1e-3 * rays_wave
@@ -184,11 +184,11 @@ def test_material_maps(gpu, orc, surface_map, alpha):
     assert_close(_render(gpu, gpu.WavefrontPathTracer, two_level, tables, w, h), want_off)
     assert_close(_render(gpu, gpu.WavefrontPathTracer, two_level, tables, w, h, AlphaTest=True), want_on)
 
-    def close_flat(got, want):                                       # flattened layout: t, u, v to fp32 round-off
+    def close_flat(got, want):                                       # flattened layout: the same bar as the two-level one
         g, wv = got[..., :3], want[..., :3]
         assert np.array_equal(got[..., 6], want[..., 6])
-        assert (np.abs(g - wv) <= 2e-3 * (1 + np.abs(wv))).all(axis=2).mean() >= 0.985
-        assert abs(g.mean() - wv.mean()) <= 5e-3 * wv.mean()
+        assert (np.abs(g - wv) <= 2e-3 * (1 + np.abs(wv))).all(axis=2).mean() >= 0.995
+        assert abs(g.mean() - wv.mean()) <= 1e-3 * wv.mean()
     close_flat(_render(gpu, gpu.WavefrontPathTracer, flat, tables, w, h, AlphaTest=True), want_on)
     close_flat(_render(gpu, gpu.WavefrontPathTracer, flat, tables, w, h), want_off)
     close_flat(_render(gpu, gpu.PathTracer, flat, tables, w, h), want_on)
@@ -308,7 +308,7 @@ def test_parameters_and_errors(gpu):
 
 
 def test_flattened_scene_renders_like_two_level(gpu, orc):
-    """the flattened re-layout changes t,u,v only in the last bits -> same radiance within the stated tolerance"""
+    """the flattened re-layout reports the reference's t,u,v bit for bit -> the two-level tolerance applies unchanged"""
     sc = scenes.synthetic_sm(96, 64, n_instances=120, subdiv=2)
     d = sc.desc
     tables = orc.sequence_tables(2)
@@ -322,8 +322,8 @@ def test_flattened_scene_renders_like_two_level(gpu, orc):
     got = img.getPixelData()
     g, w = got[..., :3], want[..., :3]
     ok = (np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2).mean()
-    assert ok >= 0.99, ok
-    assert abs(g.mean() - w.mean()) <= 5e-3 * w.mean()
+    assert ok >= 0.995, ok
+    assert abs(g.mean() - w.mean()) <= 1e-3 * w.mean()
 
 
 def test_pass_batching_is_equivalent(gpu, orc):

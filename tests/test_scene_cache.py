@@ -46,7 +46,7 @@ def test_warm_run_returns_the_cold_run(cache_dir):
     for a, b, c in zip(want, _arrays(cold.desc), _arrays(warm.desc)):
         assert np.array_equal(a, b) and np.array_equal(a, c)
     assert want_flat == cold_flat == warm_flat
-    assert api.flatten_probe(warm.desc, 8) != warm_flat           # the node width is part of the key
+    assert api.flatten_probe(warm.desc, api.FLAT_F4) != warm_flat  # the node format is part of the key
     assert len(os.listdir(cache_dir)) == len(files) + 1
 
 

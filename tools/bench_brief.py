@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""one-line digest of a bench.py JSON line on stdin"""
+import json, sys
+for l in sys.stdin:
+    l = l.strip()
+    if not l.startswith("{"):
+        continue
+    b = json.loads(l); r = b.get("roofline", {})
+    print("  %.1f Mrays/s  %.3f ms/step  closest %.2f shadow %.2f shade %.2f ms | per ray %s  util %s  frac %.3f" % (
+        b["value"], b["ms_per_step"], r.get("ms_intersect", 0) / b["steps"], r.get("shadow_kernel", {}).get("ms", 0) / b["steps"], r.get("ms_shade", 0) / b["steps"],
+        r.get("per_ray"), r.get("lane_utilisation"), r.get("frac", 0)))
