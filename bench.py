@@ -43,32 +43,74 @@ def b_ray(counts, rays):
     return 48.0 * rays + 64.0 * counts.n_inner + 52.0 * counts.n_tri + 108.0 * counts.n_inst
 
 
-def cpu_baseline(desc, args):
-    """oracle (CPU restatement of PathTrace<DIRECT>) on a bounded sample of the same workload: 1 pass over a band of
-    rows, all host cores, grown until ~10 s of wall time (the whole frame first, then additional whole-frame passes)."""
+def cpu_baseline(desc, args, flat_desc):
+    """The oracle (CPU restatement of PathTrace<DIRECT> over the reference's two-level BVH) on a bounded sample of the same workload:
+    (1) one thread on a band of rows (per-core figure), (2) all host cores on growing bands, then whole frames, for ~10 s (the baseline),
+    (3) a band in counting mode over the product's flattened BVH: N_inner / N_tri per ray for the roofline.
+    The oracle runs persistent threads over 64x16 tiles handed out dynamically and is built -O3 -march=x86-64-v3."""
     import oracle
     orc = oracle.Oracle()
     cores = os.cpu_count() or 1
-    rows, y0 = 8, 0
-    total_rays, total_t, done_rows, extra_passes = 0, 0.0, 0, 0
+    kw = dict(direct=True, max_path_length=args.depth, rr_start=5)
+    mid = args.height // 2
+    # (1) one thread, >= ~3 s
+    rows1, t1, rays1 = 4, 0.0, 0
+    while t1 < 3.0 and rows1 <= args.height:
+        t = time.time(); _, r = orc.render(desc, args.width, args.height, n_passes=1, threads=1, rows=(mid, min(args.height, mid + rows1)), **kw); t1 = time.time() - t; rays1 = r
+        if t1 < 3.0: rows1 *= 2
+    per_core = rays1 / t1 / 1e6
+    # (2) as many threads as the host rewards: on the GPU box (2 x 64 cores / 256 hardware threads, and whatever CPU share its container gets) the oracle's
+    # rays/s peaks far below 256 threads (tools/cpu_scaling_probe.py: 16.9 Mrays/s at 32 threads, 9.8 at 256), so the thread count is calibrated first
+    host_threads = cores
+    best = (0.0, 1)
+    th = 8
+    while th <= host_threads or th // 2 < host_threads:
+        n_th = min(th, host_threads)
+        t = time.time(); _, r = orc.render(desc, args.width, args.height, n_passes=1, threads=n_th, rows=(mid, min(args.height, mid + max(8, 2 * n_th))), **kw); dt = time.time() - t
+        if r / dt > best[0]: best = (r / dt, n_th)
+        if n_th == host_threads: break
+        th *= 2
+    cores = best[1]
+    rows, total_rays, total_t, done_rows, extra_passes = 16, 0, 0.0, 0, 0
     while total_t < 10.0 and done_rows < args.height:
-        a, b = y0 + done_rows, min(args.height, y0 + done_rows + rows)
-        t = time.time()
-        _, rays = orc.render(desc, args.width, args.height, n_passes=1, direct=True, max_path_length=args.depth, rr_start=5, threads=cores, rows=(a, b))
-        total_t += time.time() - t
-        total_rays += rays
-        done_rows += b - a
-        rows = min(rows * 2, 256)
+        a, b = done_rows, min(args.height, done_rows + rows)
+        t = time.time(); _, rays = orc.render(desc, args.width, args.height, n_passes=1, threads=cores, rows=(a, b), **kw); total_t += time.time() - t
+        total_rays += rays; done_rows += b - a; rows = min(rows * 2, 512)
     n = 2
     while total_t < 10.0 and extra_passes < 64:      # many-core hosts finish the frame in ~2 s: add whole-frame passes
-        t = time.time()
-        _, rays = orc.render(desc, args.width, args.height, n_passes=n, direct=True, max_path_length=args.depth, rr_start=5, threads=cores)
-        total_t += time.time() - t
-        total_rays += rays
-        extra_passes += n
-        n = min(n * 2, 16)
-    return {"value": round(total_rays / total_t / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "1 pass over rows %d..%d of the %dx%d frame + %d more whole-frame passes, depth %d, %d threads, %.1f s wall" % (y0, y0 + done_rows, args.width, args.height, extra_passes, args.depth, cores, total_t)}
+        t = time.time(); _, rays = orc.render(desc, args.width, args.height, n_passes=n, threads=cores, **kw); total_t += time.time() - t
+        total_rays += rays; extra_passes += n; n = min(n * 2, 16)
+    value = total_rays / total_t / 1e6
+    out = {"value": round(value, 4), "unit": "Mrays/s", "cores": cores, "host_threads": host_threads, "kind": "port",
+           "per_core": round(per_core, 4), "scaling_efficiency": round(value / (per_core * cores), 3),
+           "sample": "two-level BVH (the reference's layout); best thread count (calibrated over 8..%d): 1 pass over rows 0..%d of the %dx%d frame + %d more whole-frame passes, depth %d, %d threads, %.1f s wall; "
+                     "per-core: 1 thread, rows %d..%d, %.1f s" % (host_threads, done_rows, args.width, args.height, extra_passes, args.depth, cores, total_t, mid, min(args.height, mid + rows1), t1)}
+    counts = None
+    if flat_desc is not None:
+        counts = {}
+        rows_c = min(args.height, max(16, int(rows1 * max(1, cores // 4))))
+        t = time.time(); _, rays = orc.render(desc, args.width, args.height, n_passes=1, threads=cores, rows=(mid, min(args.height, mid + rows_c)), flat=flat_desc, counts=counts, **kw)
+        out["flat_bvh_value"] = round(rays / (time.time() - t) / 1e6, 4)   # the same oracle over the product's flattened BVH (not the reference's layout; for information)
+        counts["rows"] = (mid, min(args.height, mid + rows_c))
+    return out, counts
+
+
+def calibrated_traffic(workload_key):
+    """HBM-side bytes per ray of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload and kernel build
+    (profiles/roofline_traffic.json, written by tools/summarize_profile.py): 2 x FETCH_SIZE + WRITE_SIZE, the x2 calibrated on random 64-B gathers
+    (profiles/README.md).  None when the profile is of another workload or another kernel."""
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    try:
+        t = json.load(open(tpath))
+    except Exception:
+        return None
+    e = t.get("workloads", {}).get(workload_key)
+    if not e or e.get("kernel_build") != KERNEL_BUILD:
+        return None
+    return e
+
+
+KERNEL_BUILD = "r02-flat-q4-exact"   # changes when the traversal kernel or the flattened layout changes: a traffic profile of another build is not quoted
 
 
 def main():
@@ -118,6 +160,7 @@ def main():
         dist.barrier()                      # rank 0 compiles and fills the cache first
     sc = build_scene(args)
     desc = sc.desc
+    scene_source = "builder API (cudatracerlib_amd/scenes.py)"
     scene = ctl.Scene(desc, flatten=bool(args.flatten))
     if world > 1 and rank == 0 and not args.no_cache:
         dist.barrier()
@@ -170,45 +213,61 @@ def main():
 
     out = None
     if rank == 0:
-        # traversal statistics of the SAME rays (one extra, untimed pass in counting mode) -> algorithmic bytes
+        # traversal statistics of the SAME rays on the GPU (one extra, untimed pass in counting mode): lane utilisation, visited nodes
         tr.setCounting(True)
         tr.DoPasses(img, 1, new_trace=False)
         cs = tr.stats()
         tr.setCounting(False)
-        per_ray_closest = b_ray(cs.closest_counts, cs.intersect_rays) / max(1, cs.intersect_rays)
+        gpu_counts = {"n_inner": cs.closest_counts.n_inner / max(1, cs.intersect_rays), "n_tri": cs.closest_counts.n_tri / max(1, cs.intersect_rays), "n_inst": cs.closest_counts.n_inst / max(1, cs.intersect_rays)}
+        cpu, oc = None, None
+        if world == 1 and not args.no_cpu_baseline:
+            from cudatracerlib_amd import api as _api
+            fb = _api.FlatBvh(desc, _api.FLAT_Q4) if args.flatten else None
+            cpu, oc = cpu_baseline(desc, args, fb.desc if fb is not None else None)
+        # algorithmic bytes per ray from the CPU restatement in counting mode over the same BVH; the GPU's own counters when the oracle leg is off
+        if oc and oc.get("path_rays"):
+            per_ray = {"n_inner": oc["path_inner"] / oc["path_rays"], "n_tri": oc["path_tri"] / oc["path_rays"], "n_inst": oc["path_inst"] / oc["path_rays"]}
+            count_source = "oracle (CPU restatement, counting mode, the product's flattened BVH, rows %d..%d of one pass)" % oc["rows"]
+        else:
+            per_ray = gpu_counts; count_source = "GPU counting kernel (the oracle leg is off)"
+        per_ray_closest = 48.0 + 64.0 * per_ray["n_inner"] + 52.0 * per_ray["n_tri"] + 108.0 * per_ray["n_inst"]
         per_ray_any = b_ray(cs.any_counts, cs.shadow_rays) / max(1, cs.shadow_rays)
         # dominant kernel = closest-hit intersect: bytes per launch / average launch duration (HIP events on the tracer's stream)
         avg_launch_ms = k_ms_closest / max(1, launches_closest)
-        bytes_per_launch = per_ray_closest * n_closest / max(1, launches_closest)
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("k_intersect_closest_bytes_per_launch")
-            except Exception:
-                traffic = None
+        rays_per_launch = n_closest / max(1, launches_closest)
+        achieved = per_ray_closest * rays_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        records_per_s = (per_ray["n_inner"] + per_ray["n_tri"]) * rays_per_launch / (avg_launch_ms * 1e-3) if avg_launch_ms > 0 else 0.0
+        wl_key = "%s %dx%d depth %d" % (args.workload, args.width, args.height, args.depth) + ("" if args.workload != "synthetic-sm" else " %d inst subdiv %d" % (args.instances, args.subdiv)) + (" flat" if args.flatten else " two-level")
+        cal = calibrated_traffic(wl_key)
+        traffic = cal["bytes_per_ray"] * rays_per_launch if cal else None
+        frac = achieved / HBM_PEAK_GBS
+        roof = {"bound": "hbm", "kernel": "k_intersect<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(frac, 4), "saturated": bool(frac >= 0.9), "traffic": traffic,
+                "hbm_frac_measured": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None,
+                "l2_hit_rate": cal.get("l2_hit_rate") if cal else None, "traffic_profile": cal.get("tag") if cal else None, "workload_key": wl_key, "kernel_build": KERNEL_BUILD,
+                "bytes_per_ray": round(per_ray_closest, 1), "per_ray": {k: round(v, 2) for k, v in per_ray.items()}, "per_ray_source": count_source,
+                "per_ray_gpu_visited": {k: round(v, 2) for k, v in gpu_counts.items()},
+                "records_per_s": round(records_per_s / 1e9, 2), "records_per_s_unit": "G node+leaf records/s (gather ceilings, tools/gather_probe.hip: ~58 G/s from HBM, ~170 G/s from L2)",
+                "lane_utilisation": {"inner": round(cs.closest_counts.n_inner / max(1, 64 * cs.closest_counts.wave_inner_iters), 3), "tri": round(cs.closest_counts.n_tri / max(1, 64 * cs.closest_counts.wave_tri_iters), 3)},
+                "rays_per_launch": int(rays_per_launch), "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches_closest,
+                "shadow_kernel": {"bytes_per_ray": round(per_ray_any, 1), "rays": n_any, "ms": round(k_ms_any, 3),
+                                  "achieved": round(per_ray_any * n_any / (k_ms_any * 1e-3) / 1e9, 2) if k_ms_any > 0 else 0.0},
+                "ms_intersect": round(k_ms_closest, 3), "ms_shade": round(st.ms_shade, 3), "ms_raygen": round(st.ms_raygen, 3)}
         out = {
-            "metric": "Mrays/s at %dx%dx%dspp depth-%d; achieved HBM GB/s vs peak" % (args.width, args.height, args.steps, args.depth),
+            "metric": "Mrays/s at %dx%d, %d spp (steps), depth-%d; achieved HBM GB/s vs peak" % (args.width, args.height, args.steps, args.depth),
             "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic-SM %dx%d, 1 spp/step, depth %d, NEE on, %d instances x icosphere(%d)/boxes, %d instanced triangles"
                        % (args.width, args.height, args.depth, args.instances, args.subdiv, int(_instanced_tris(desc))) if args.workload == "synthetic-sm" else args.workload,
-                       "bvh": "flattened world-space BVH4 (64 B nodes with 8-bit quantised child boxes, 64 B leaf entries)" if args.flatten else "two-level (scene BVH + instanced mesh BVHs)",
+                       "bvh": "flattened world-space BVH4 (64 B nodes with 8-bit quantised child boxes; 128 B leaf entries evaluated with the reference's object-space arithmetic)" if args.flatten else "two-level (scene BVH + instanced mesh BVHs)",
+                       "scene_source": scene_source,
                        "parallelism": "image tiles 64x64 round-robin over %d GPU(s), 1 RCCL reduce of the framebuffer" % world,
                        "rays_per_step": int(rays / args.steps), "scene_build_s": round(t_build, 2)},
-            "roofline": {"bound": "hbm", "kernel": "k_intersect<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_ray": round(per_ray_closest, 1), "per_ray": {"n_inner": round(cs.closest_counts.n_inner / max(1, cs.intersect_rays), 2), "n_tri": round(cs.closest_counts.n_tri / max(1, cs.intersect_rays), 2), "n_inst": round(cs.closest_counts.n_inst / max(1, cs.intersect_rays), 2)},
-                         "lane_utilisation": {"inner": round(cs.closest_counts.n_inner / max(1, 64 * cs.closest_counts.wave_inner_iters), 3), "tri": round(cs.closest_counts.n_tri / max(1, 64 * cs.closest_counts.wave_tri_iters), 3)}, "rays_per_launch": int(n_closest / max(1, launches_closest)),
-                         "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches_closest,
-                         "shadow_kernel": {"bytes_per_ray": round(per_ray_any, 1), "rays": n_any, "ms": round(k_ms_any, 3),
-                                           "achieved": round(per_ray_any * n_any / (k_ms_any * 1e-3) / 1e9, 2) if k_ms_any > 0 else 0.0},
-                         "ms_intersect": round(k_ms_closest, 3), "ms_shade": round(st.ms_shade, 3), "ms_raygen": round(st.ms_raygen, 3)},
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(desc, args)
+        if cpu:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -134,6 +134,9 @@ void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& 
         if (lc.alpha_test) hipLaunchKernelGGL((k_intersect<ANY, CNT, L, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
         else hipLaunchKernelGGL((k_intersect<ANY, CNT, L, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__);     \
     } while (0)
+// The product traverses Q4 nodes.  The F4 / F2 node formats are measured experiments (0.69x and 0.66x of Q4's rays/s); their kernels are
+// compiled only with -DCTL_FLAT_EXPERIMENTS, and a scene asking for them is refused otherwise (tracer.hip).
+#ifdef CTL_FLAT_EXPERIMENTS
 #define CTL_LAUNCH_INTERSECT(ANY, CNT, ...)                                                                                          \
     do {                                                                                                                             \
         if (!S.flat_nodes) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 0, __VA_ARGS__);                                                         \
@@ -141,6 +144,13 @@ void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& 
         else if (S.flat_format == kFmtQ4) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 1, __VA_ARGS__);                                          \
         else CTL_LAUNCH_INTERSECT_L(ANY, CNT, 3, __VA_ARGS__);                                                                       \
     } while (0)
+#else
+#define CTL_LAUNCH_INTERSECT(ANY, CNT, ...)                                                                                          \
+    do {                                                                                                                             \
+        if (!S.flat_nodes) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 0, __VA_ARGS__);                                                         \
+        else CTL_LAUNCH_INTERSECT_L(ANY, CNT, 1, __VA_ARGS__);                                                                       \
+    } while (0)
+#endif
 void launch_intersect_closest(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node) {
     CTL_LAUNCH_INTERSECT(false, false, S, ro, rd, n_ptr, work, hit, hit_node, (uint32_t*)nullptr, (unsigned long long*)nullptr);
 }

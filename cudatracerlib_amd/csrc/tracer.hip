@@ -248,6 +248,9 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
         flat_scene F;
         if (flatten_scene(d, F, (size_t)1 << 30, flat_format < 0 ? default_flat_format() : flat_format)) {   // up to 2^30 instanced triangles (64 GiB of leaf entries)
             if (F.stack_need() + 2 > kStackSize) throw std::runtime_error("ctl_scene_create: flattened BVH too deep for the traversal stack");
+#ifndef CTL_FLAT_EXPERIMENTS
+            if (F.format != kFlatQ4) throw unsupported_error("ctl_scene_create: the F4 / F2 node formats are measurement builds (-DCTL_FLAT_EXPERIMENTS)");
+#endif
             if (F.format == kFlatQ4) flat_nodes_.upload((const float4*)F.nodes.data(), F.nodes.size() * 4);
             else if (F.format == kFlatF4) flat_nodes_.upload((const float4*)F.nodes_f4.data(), F.nodes_f4.size() * 8);
             else flat_nodes_.upload((const float4*)F.nodes_f2.data(), F.nodes_f2.size() * 4);

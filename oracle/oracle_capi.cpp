@@ -3,6 +3,7 @@
 #include "orng.h"
 #include <thread>
 #include <mutex>
+#include <condition_variable>
 #include <atomic>
 #include <vector>
 
@@ -203,23 +204,36 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
     if (n_threads < 1) n_threads = 1;
     if (y1 > H) y1 = H;
     SequenceGenerator gen;
-    std::vector<float> own1, own2;
     const size_t N1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH, N2 = N1 * 2;
-    if (!tables1) { own1.resize(N1); own2.resize(N2); }
     std::atomic<uint64_t> total(0);
     std::mutex cmu;
-    for (uint32_t pass = 0; pass < n_passes; pass++) {
-        const float *t1, *t2;
-        if (tables1) { t1 = tables1 + pass * N1; t2 = tables2 + pass * N2; }
-        else { gen.compute(own1.data(), own2.data()); t1 = own1.data(); t2 = own2.data(); }
-        std::atomic<uint32_t> nextRow(y0);
-        auto work = [&]() {
-            uint64_t rays = 0;
-            RenderCounts rc; renderCounts() = g_count_render ? &rc : nullptr;
+    // Persistent worker threads for the whole call, 64 x 16 pixel tiles handed out dynamically inside a pass; passes stay sequential (two passes
+    // never add to one pixel at the same time), a reusable barrier separates them.
+    const uint32_t TW = 64, TH = 16, tiles_x = (W + TW - 1) / TW, tiles_y = (y1 > y0) ? (y1 - y0 + TH - 1) / TH : 0, n_tiles = tiles_x * tiles_y;
+    std::vector<std::vector<float>> gen1, gen2;
+    if (!tables1) { gen1.resize(n_passes); gen2.resize(n_passes); for (uint32_t p = 0; p < n_passes; p++) { gen1[p].resize(N1); gen2[p].resize(N2); gen.compute(gen1[p].data(), gen2[p].data()); } }
+    std::vector<std::atomic<uint32_t>> nextTile(n_passes);
+    for (auto& a : nextTile) a.store(0);
+    std::mutex bmu; std::condition_variable bcv; uint32_t arrived = 0, generation = 0;
+    auto barrier = [&]() {
+        std::unique_lock<std::mutex> l(bmu);
+        const uint32_t g = generation;
+        if (++arrived == (uint32_t)n_threads) { arrived = 0; generation++; bcv.notify_all(); }
+        else bcv.wait(l, [&] { return generation != g; });
+    };
+    auto work = [&]() {
+        uint64_t rays = 0;
+        RenderCounts rc; renderCounts() = g_count_render ? &rc : nullptr;
+        for (uint32_t pass = 0; pass < n_passes; pass++) {
+            const float* t1 = tables1 ? tables1 + pass * N1 : gen1[pass].data();
+            const float* t2 = tables1 ? tables2 + pass * N2 : gen2[pass].data();
             for (;;) {
-                uint32_t y = nextRow.fetch_add(1);
-                if (y >= y1) break;
-                for (uint32_t x = 0; x < W; x++)
+                const uint32_t tile = nextTile[pass].fetch_add(1);
+                if (tile >= n_tiles) break;
+                const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+                const uint32_t xa = tx * TW, xb = std::min(W, xa + TW), ya = y0 + ty * TH, yb = std::min(y1, ya + TH);
+                for (uint32_t y = ya; y < yb; y++)
+                for (uint32_t x = xa; x < xb; x++)
                 for (uint32_t smp = 0, n_smp = g_block_counts ? g_block_counts[(y / 64) * g_blocks_x + x / 64] : 1u; smp < n_smp; smp++) {
                     // BlockSamplerBuffer::getNumSamplesPerPixel (WavefrontPathTracer.cu:31-36): the samples of a pixel in one pass continue one sampler
                     Sampler rng(t1, t2, y * W + x);   // TracerBase::getPixelIndex
@@ -232,15 +246,16 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
                     addSample(img, (int)W, (int)H, pX.x, pX.y, col);
                 }
             }
-            total += rays;
-            renderCounts() = nullptr;
-            if (g_count_render) { std::lock_guard<std::mutex> l(cmu); for (int k = 0; k < 2; k++) { g_render_counts[k * 4 + 0] += rc.rays[k]; g_render_counts[k * 4 + 1] += rc.c[k].n_inner; g_render_counts[k * 4 + 2] += rc.c[k].n_tri; g_render_counts[k * 4 + 3] += rc.c[k].n_inst; } }
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < n_threads; t++) th.emplace_back(work);
-        work();
-        for (auto& t : th) t.join();
-    }
+            if (pass + 1 < n_passes) barrier();
+        }
+        total += rays;
+        renderCounts() = nullptr;
+        if (g_count_render) { std::lock_guard<std::mutex> l(cmu); for (int k = 0; k < 2; k++) { g_render_counts[k * 4 + 0] += rc.rays[k]; g_render_counts[k * 4 + 1] += rc.c[k].n_inner; g_render_counts[k * 4 + 2] += rc.c[k].n_tri; g_render_counts[k * 4 + 3] += rc.c[k].n_inst; } }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
     return total.load();
 }
 

@@ -3,13 +3,12 @@
 
   <tag>_bench.json          the bench.py JSON line of that run
   <tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats per-kernel summary (verbatim)
-  <tag>_pmc_summary.csv     per kernel: launches, FETCH_SIZE / WRITE_SIZE (KB, as rocprofv3 reports them), TCC hit rate
-  roofline_traffic.json     HBM bytes per launch of the dominant kernel (read by bench.py -> roofline.traffic)
+  <tag>_pmc_summary.csv     per kernel: launches, FETCH_SIZE / WRITE_SIZE (KB, as rocprofv3 reports them), memory-side read requests, TCC hit rate, SQ counters
+  roofline_traffic.json     per workload: HBM-side bytes per RAY of the dominant kernel (bench.py multiplies by the rays of its own launches)
 
-FETCH_SIZE/WRITE_SIZE are reported by rocprofv3 in KB.  MI355X_MICROARCH.md ("HBM"): on gfx950 FETCH_SIZE counts
-128-B requests as 64 B for wide coalesced streams (x2 correction); other access shapes are uncalibrated.  The traversal
-kernel issues 16 B/lane loads of scattered 64-B groups, so both the raw figure and the x2 figure are kept; bench.py's
-`traffic` uses the x2 (upper) figure for reads and the raw figure for writes.
+FETCH_SIZE / WRITE_SIZE are reported in KB.  Calibration (profiles/README.md, tools/gather_probe.hip under --pmc): on gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B
+while every request of these kernels is a 128-B line (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ), for random 64-B gathers as for streams: memory-side bytes =
+2 x FETCH_SIZE.  WRITE_SIZE is taken as reported.
 """
 import csv
 import glob
@@ -43,35 +42,43 @@ def main():
     for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, tag + "_kernel_stats.csv"))
     rows = {}
-    for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC"):
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC", "SQ"):
         acc, n = read_counters(os.path.join(src, "pmc_" + c))
         for k in acc:
             rows.setdefault(k, {})
             for name, v in acc[k].items():
                 rows[k][name] = v; rows[k]["launches"] = n[k][name]
+    cols = ["FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU",
+            "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_THREAD_CYCLES_VALU"]
     out = os.path.join(dst, tag + "_pmc_summary.csv")
     with open(out, "w") as fh:
-        fh.write("kernel,launches,FETCH_SIZE_KB_total,WRITE_SIZE_KB_total,fetch_bytes_per_launch_raw,fetch_bytes_per_launch_x2,write_bytes_per_launch,TCC_hit_rate\n")
+        fh.write("kernel,launches," + ",".join(cols) + ",memory_side_read_bytes(2xFETCH_SIZE),TCC_hit_rate,valu_lane_utilisation\n")
         for k, r in sorted(rows.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0)):
-            L = max(1, r.get("launches", 1)); fe, wr = r.get("FETCH_SIZE", 0.0), r.get("WRITE_SIZE", 0.0)
             hit, miss = r.get("TCC_HIT_sum", 0.0), r.get("TCC_MISS_sum", 0.0)
-            fh.write("%s,%d,%.1f,%.1f,%.0f,%.0f,%.0f,%s\n" % (k, L, fe, wr, fe * 1024 / L, 2 * fe * 1024 / L, wr * 1024 / L, ("%.3f" % (hit / (hit + miss))) if hit + miss > 0 else ""))
-    # dominant kernel = closest-hit intersect without counters: k_intersect<false, false, FLAT>
+            lane = r.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * r["SQ_INSTS_VALU"]) if r.get("SQ_INSTS_VALU") else None
+            fh.write("%s,%d,%s,%.0f,%s,%s\n" % (k, r.get("launches", 0), ",".join("%.6g" % r.get(c, 0.0) for c in cols), 2 * r.get("FETCH_SIZE", 0.0) * 1024,
+                                               ("%.3f" % (hit / (hit + miss))) if hit + miss > 0 else "", ("%.3f" % lane) if lane else ""))
+    # dominant kernel = closest-hit intersect without counters
+    b = json.load(open(os.path.join(src, "bench.json"))); rf = b["roofline"]
     dom = [k for k in rows if k.startswith("k_intersect<false, false")]
-    if dom:
-        k = max(dom, key=lambda k: rows[k].get("FETCH_SIZE", 0)); r = rows[k]; L = max(1, r.get("launches", 1))
-        # The profiled run's launches are not all alike (warm-up launches carry 2 passes, timed ones up to 32): per-launch figures are quoted for
-        # a TIMED launch = bytes per ray of the whole run x the rays of one timed launch (bench.json of the same tag).
-        b = json.load(open(os.path.join(src, "bench.json"))); rf = b["roofline"]
+    if dom and rf.get("workload_key"):
+        k = max(dom, key=lambda k: rows[k].get("FETCH_SIZE", 0)); r = rows[k]
+        # rays of the profiled run's closest-hit launches: timed launches + warm-up launches (same rays per pass)
         rays_run = rf["rays_per_launch"] * rf["launches"] * (b["steps"] + b["warmup"]) / b["steps"]
         fe_ray, wr_ray = r.get("FETCH_SIZE", 0) * 1024 / rays_run, r.get("WRITE_SIZE", 0) * 1024 / rays_run
-        R = rf["rays_per_launch"]
-        json.dump({"tag": tag, "kernel": k, "launches_profiled": L, "rays_profiled": rays_run, "rays_per_timed_launch": R,
-                   "fetch_bytes_per_ray_raw": fe_ray, "write_bytes_per_ray": wr_ray,
-                   "fetch_bytes_per_launch_raw": fe_ray * R, "write_bytes_per_launch": wr_ray * R,
-                   "k_intersect_closest_bytes_per_launch": (2 * fe_ray + wr_ray) * R,
-                   "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), per ray over every closest-hit launch of the profiled `python bench.py --no-cpu-baseline` run, times the rays of one timed launch"},
-                  open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
+        hit, miss = r.get("TCC_HIT_sum", 0.0), r.get("TCC_MISS_sum", 0.0)
+        tpath = os.path.join(dst, "roofline_traffic.json")
+        try:
+            t = json.load(open(tpath))
+            if "workloads" not in t: t = {"workloads": {}}
+        except Exception:
+            t = {"workloads": {}}
+        t["note"] = "HBM-side bytes per ray of the closest-hit traversal kernel = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes) over every closest-hit launch of the profiled bench.py run / the rays of those launches; bench.py quotes an entry only for the same workload key and kernel build"
+        t["workloads"][rf["workload_key"]] = {"tag": tag, "kernel": k, "kernel_build": rf.get("kernel_build"), "rays_profiled": rays_run,
+                                               "fetch_bytes_per_ray_raw": fe_ray, "write_bytes_per_ray": wr_ray, "bytes_per_ray": 2 * fe_ray + wr_ray,
+                                               "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss > 0 else None,
+                                               "memory_side_read_requests_per_ray": r.get("TCC_EA0_RDREQ_sum", 0.0) / rays_run}
+        json.dump(t, open(tpath, "w"), indent=1)
     print(open(out).read())
 
 
