@@ -134,18 +134,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    share_gpu = os.environ.get("CTL_BENCH_SHARE_GPU") == "1"
     if world > 1:
+        # torch.distributed (gloo, CPU tensors) is plumbing only: the barrier, the broadcast of the RCCL unique id and two scalar reductions.  The framebuffer —
+        # the one data-path collective — goes through the library's own ncclReduce (ctl_image_reduce, csrc/comm.cpp).
+        # CTL_BENCH_SHARE_GPU=1 is a test hook for a 1-GPU box: every rank on device 0 (RCCL refuses two ranks on one device, so the reduce falls back to gloo).
         import torch
         import torch.distributed as dist
-        # test hook for a 1-GPU box: CTL_BENCH_SHARE_GPU=1 puts every rank on device 0 and swaps RCCL for gloo, so that the multi-rank flow
-        # (cache staging barrier, tile shards, framebuffer reduce) can be exercised without N GPUs.  Never set by the driver.
-        if os.environ.get("CTL_BENCH_SHARE_GPU") == "1":
+        if share_gpu:
             local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group(backend="gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo")
     import cudatracerlib_amd as ctl
     if ctl.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
@@ -177,17 +175,39 @@ def main():
     tr.reservePasses(args.steps)      # queue memory for the batch size the timed call will use: allocated here, not inside the timed region
     img = ctl.Image(args.width, args.height)
 
-    fb = None
+    comm, reduce_kind = None, "none (1 GPU)"
     if world > 1:
         import torch
-        fb = torch.zeros(args.width * args.height * 7, dtype=torch.float32, device="cuda")
+        try:
+            if share_gpu:
+                raise RuntimeError("CTL_BENCH_SHARE_GPU: all ranks share device 0")
+            ident = [ctl.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            comm = ctl.Comm(ident[0], rank, world)
+            reduce_kind = "ncclReduce in libctl_amd.so (ctl_image_reduce)"
+        except Exception as e:   # never silently: the JSON line says which path ran
+            print("bench.py: native RCCL reduce unavailable (%s); falling back to torch.distributed" % e, file=sys.stderr, flush=True)
+            reduce_kind = "torch.distributed gloo all-reduce through host memory (native RCCL unavailable: %s)" % str(e)[:120]
+        ok = torch.tensor([1 if comm is not None else 0]); dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks take the same path
+        if int(ok.item()) == 0:
+            comm = None
 
     def sync():
         ctl.api._check(ctl.lib.ctl_device_synchronize())
         if world > 1:
             import torch
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
             dist.barrier()
+
+    def reduce_frame():
+        if comm is not None:
+            comm.reduce(img, 0)
+        else:
+            import torch
+            fb = torch.from_numpy(img.getPixelData()); dist.all_reduce(fb, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                img.setPixelData(fb.numpy())
 
     if args.warmup > 0:
         tr.DoPasses(img, args.warmup, new_trace=True)
@@ -195,10 +215,7 @@ def main():
     t0 = time.perf_counter()
     tr.DoPasses(img, args.steps, new_trace=(args.warmup == 0))
     if world > 1:
-        # the single framebuffer exchange of the render: PixelData sums -> rank 0 over RCCL/xGMI
-        ctl.api._check(ctl.lib.ctl_memcpy_d2d(fb.data_ptr(), img.device_ptr(), args.width * args.height * 28))
-        from cudatracerlib_amd.parallel import reduce_framebuffer
-        reduce_framebuffer(fb, dst=0)
+        reduce_frame()   # the single framebuffer exchange of the render: PixelData sums -> rank 0 over RCCL / xGMI
     sync()
     elapsed = time.perf_counter() - t0
     st = tr.stats()
@@ -208,8 +225,8 @@ def main():
     launches_closest = int(st.intersect_launches)
     if world > 1:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
-        r = torch.tensor([rays], dtype=torch.float64, device="cuda"); dist.all_reduce(r, op=dist.ReduceOp.SUM); rays = float(r.item())
+        t = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        r = torch.tensor([rays], dtype=torch.float64); dist.all_reduce(r, op=dist.ReduceOp.SUM); rays = float(r.item())
 
     out = None
     if rank == 0:
@@ -262,7 +279,7 @@ def main():
                        % (args.width, args.height, args.depth, args.instances, args.subdiv, int(_instanced_tris(desc))) if args.workload == "synthetic-sm" else args.workload,
                        "bvh": "flattened world-space BVH4 (64 B nodes with 8-bit quantised child boxes; 128 B leaf entries evaluated with the reference's object-space arithmetic)" if args.flatten else "two-level (scene BVH + instanced mesh BVHs)",
                        "scene_source": scene_source,
-                       "parallelism": "image tiles 64x64 round-robin over %d GPU(s), 1 RCCL reduce of the framebuffer" % world,
+                       "parallelism": "image tiles 64x64 round-robin over %d GPU(s), 1 reduce of the framebuffer per render" % world, "framebuffer_reduce": reduce_kind,
                        "rays_per_step": int(rays / args.steps), "scene_build_s": round(t_build, 2)},
             "roofline": roof,
         }

@@ -6,7 +6,7 @@ This package is a thin ctypes mirror of that C-ABI using the reference's class a
 There is no CPU fallback: without the built extension, importing the API raises.
 """
 from .api import (  # noqa: F401
-    lib, CtlError, DynamicScene, Scene, Image, WavefrontPathTracer, PathTracer, SequenceGenerator,
+    lib, CtlError, DynamicScene, Scene, Image, Comm, WavefrontPathTracer, PathTracer, SequenceGenerator,
     ctl_material, ctl_texture, ctl_light, ctl_sensor, ctl_scene_desc, ctl_ray, ctl_hit, ctl_pixel_data,
     ctl_tracer_stats, ctl_traversal_counts, ctl_float4x4,
     diffuse, dielectric, conductor, roughconductor, device_count, intersect, intersect_count,

@@ -114,7 +114,7 @@ lib.ctl_last_error.restype = C.c_char_p
 lib.ctl_version.restype = C.c_char_p
 lib.ctl_image_device_ptr.restype = C.c_void_p
 lib.ctl_image_device_ptr.argtypes = [C.c_void_p]
-for _n in ("ctl_builder_destroy", "ctl_scene_destroy", "ctl_image_destroy", "ctl_tracer_destroy", "ctl_sequence_generator_destroy"):
+for _n in ("ctl_builder_destroy", "ctl_scene_destroy", "ctl_image_destroy", "ctl_tracer_destroy", "ctl_sequence_generator_destroy", "ctl_comm_destroy", "ctl_flat_bvh_destroy"):
     getattr(lib, _n).restype = None
     getattr(lib, _n).argtypes = [C.c_void_p]
 lib.ctl_device_malloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
@@ -637,6 +637,31 @@ def intersect_count(scene, rays, any_hit=False):
     c = ctl_traversal_counts()
     _check(lib.ctl_intersect_count(scene._h, rp, u32(len(r)), 1 if any_hit else 0, C.byref(c)))
     return dict(n_inner=c.n_inner, n_tri=c.n_tri, n_inst=c.n_inst, wave_inner_iters=c.wave_inner_iters, wave_tri_iters=c.wave_tri_iters)
+
+
+class Comm:
+    """The framebuffer reduce of a multi-GPU render (ctl_comm_*, comm.cpp): one rank per process and GPU, RCCL over xGMI.
+    Comm.unique_id() on one rank -> the 128 bytes to every rank -> Comm(id, rank, world) on every rank (collective) -> reduce(image, root)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        _check(lib.ctl_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, world):
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _check(lib.ctl_comm_create(buf, C.c_int32(rank), C.c_int32(world), C.byref(self._h)))
+
+    def reduce(self, image, root=0):
+        """sum of all ranks' PixelData frames into `root`'s image, in place, one ncclReduce; returns when it is complete"""
+        _check(lib.ctl_image_reduce(image._h, self._h, C.c_int32(root)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.ctl_comm_destroy(self._h)
+            self._h = None
 
 
 class Image:

@@ -155,6 +155,15 @@ void ctl_image_destroy(ctl_image* img) { delete img; }
 int ctl_image_clear(ctl_image* img) { CTL_REQUIRE(img, "null image"); CTL_TRY img->img.Clear(); CTL_CATCH }
 int ctl_image_read_pixels(ctl_image* img, ctl_pixel_data* host_out) { CTL_REQUIRE(img && host_out, "null argument"); CTL_TRY img->img.read(host_out); CTL_CATCH }
 int ctl_image_write_pixels(ctl_image* img, const ctl_pixel_data* host_in) { CTL_REQUIRE(img && host_in, "null argument"); CTL_TRY img->img.write(host_in); CTL_CATCH }
+// ---- multi-GPU: the one collective (comm.cpp)
+struct ctl_comm { Comm* c; };
+int ctl_comm_get_unique_id(uint8_t out128[128]) { CTL_REQUIRE(out128, "null argument"); CTL_TRY comm_unique_id(out128); CTL_CATCH }
+int ctl_comm_create(const uint8_t id128[128], int32_t rank, int32_t world, ctl_comm** out) {
+    CTL_REQUIRE(id128 && out, "null argument");
+    CTL_TRY *out = new ctl_comm{ comm_create(id128, rank, world) }; CTL_CATCH
+}
+void ctl_comm_destroy(ctl_comm* c) { if (c) { comm_destroy(c->c); delete c; } }
+int ctl_image_reduce(ctl_image* img, ctl_comm* comm, int32_t root) { CTL_REQUIRE(img && comm, "null argument"); CTL_TRY comm_reduce_image(comm->c, &img->img, root); CTL_CATCH }
 void* ctl_image_device_ptr(ctl_image* img) { return img ? (void*)img->img.device() : nullptr; }
 int ctl_image_resolve_rgb(ctl_image* img, float splat_scale, float* host_rgb_out) { CTL_REQUIRE(img && host_rgb_out, "null argument"); CTL_TRY img->img.resolve_rgb(splat_scale, host_rgb_out); CTL_CATCH }
 

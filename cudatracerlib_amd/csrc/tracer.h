@@ -197,4 +197,11 @@ private:
 int device_count();
 void require_device();
 
+// comm.cpp: the framebuffer reduce of a multi-GPU render over RCCL (ctl_comm_* in include/ctl_amd.h)
+struct Comm;
+void comm_unique_id(unsigned char out[128]);
+Comm* comm_create(const unsigned char id[128], int rank, int world);
+void comm_destroy(Comm* c);
+void comm_reduce_image(Comm* c, Image* img, int root);
+
 } // namespace ctl

@@ -374,6 +374,18 @@ int ctl_image_apply_pipeline_ex(ctl_image* img, float splat_scale, const ctl_rec
  * Other formats (the reference saves through FreeImage) -> CTL_ERR_UNSUPPORTED. */
 int ctl_image_write_file(ctl_image* img, float splat_scale, const char* path);
 
+/* ---------------------------------------------------------------- multi-GPU */
+/* The one exchange step of a multi-GPU render (the reference is single-device): rank r renders the 64x64 image tiles t with
+ * t % world == r (ctl_tracer_set_tile_shard) into a cleared full-size Image; ctl_image_reduce sums the PixelData frames of all ranks into
+ * `root`'s image with ONE ncclReduce over RCCL / xGMI — the tiles are disjoint, so the sum is the gather.  One rank per process and GPU:
+ * call ctl_set_device first.  ctl_comm_get_unique_id on one rank, hand the 128 bytes to the others by any means (MPI_Bcast, a file,
+ * torch.distributed), then ctl_comm_create on every rank (collective).  RCCL is loaded on first use. */
+typedef struct ctl_comm ctl_comm;
+int ctl_comm_get_unique_id(uint8_t out128[128]);
+int ctl_comm_create(const uint8_t id128[128], int32_t rank, int32_t world, ctl_comm** out);
+void ctl_comm_destroy(ctl_comm* c);
+int ctl_image_reduce(ctl_image* img, ctl_comm* comm, int32_t root);
+
 /* ------------------------------------------------------------------- tracer */
 typedef struct ctl_tracer ctl_tracer;
 /* plugin names: "WavefrontPathTracer" (Integrators/PseudoRealtime/WavefrontPathTracer.h:24). */

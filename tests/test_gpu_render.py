@@ -342,3 +342,20 @@ def test_pass_batching_is_equivalent(gpu, orc):
     assert ra == rb
     assert np.array_equal(a[..., 6], b[..., 6])
     assert np.allclose(a[..., :3], b[..., :3], rtol=1e-5, atol=1e-5)   # float atomics accumulate in a different order
+
+
+def test_native_framebuffer_reduce_single_rank(gpu):
+    """ctl_comm_* / ctl_image_reduce (csrc/comm.cpp): RCCL is loaded, a communicator of one rank is created and the PixelData frame goes through
+    ncclReduce unchanged.  (Two ranks need two GPUs — RCCL refuses two ranks on one device; the N-rank flow of bench.py is exercised on one GPU
+    with CTL_BENCH_SHARE_GPU=1, where the reduce falls back to gloo.)"""
+    img = gpu.Image(96, 64)
+    a = np.random.RandomState(2).uniform(0, 4, size=(64, 96, 7)).astype(np.float32)
+    img.setPixelData(a)
+    ident = gpu.Comm.unique_id()
+    assert len(ident) == 128
+    comm = gpu.Comm(ident, 0, 1)
+    comm.reduce(img, 0)
+    assert np.array_equal(img.getPixelData(), a)
+    with pytest.raises(gpu.CtlError):
+        comm.reduce(img, 3)
+    del comm
