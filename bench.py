@@ -27,14 +27,30 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def build_scene(args):
+def build_scene(args, rank=0, barrier=None):
+    """-> (DynamicScene, how it was built).  --scene FILE: a Mitsuba XML file through ctl_parse_mitsuba_scene.  --via-loader: the synthetic workload written
+    as a Mitsuba-0.5 scene (XML + .serialized meshes) and loaded back through the same loader — the reference's flow ParseMitsubaScene -> UpdateScene -> tracer."""
     from cudatracerlib_amd import scenes
+    if args.scene:
+        sc = scenes.load_mitsuba(args.scene, args.width, args.height)
+        return sc, "Mitsuba XML %s through ctl_parse_mitsuba_scene" % os.path.basename(args.scene)
+    if args.via_loader:
+        if args.workload != "synthetic-sm":
+            raise SystemExit("--via-loader is implemented for the synthetic-sm workload")
+        d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ctl_scene_sm_%d_%d_%dx%d" % (args.instances, args.subdiv, args.width, args.height))
+        xml = os.path.join(d, "scene.xml")
+        if rank == 0 and not os.path.exists(xml):
+            desc = scenes.with_explicit_normals(scenes.synthetic_sm_description(args.width, args.height, n_instances=args.instances, subdiv=args.subdiv))
+            scenes.export_mitsuba(desc, d)
+        if barrier:
+            barrier()
+        return scenes.load_mitsuba(xml), "Mitsuba XML + .serialized meshes (scenes.export_mitsuba) through ctl_parse_mitsuba_scene"
     if args.workload == "synthetic-sm":
-        return scenes.synthetic_sm(args.width, args.height, n_instances=args.instances, subdiv=args.subdiv)
+        return scenes.synthetic_sm(args.width, args.height, n_instances=args.instances, subdiv=args.subdiv), "builder API (cudatracerlib_amd/scenes.py)"
     if args.workload == "cornell-glass":      # BASELINE configs[1] (quote it with --width 1024 --height 1024)
-        return scenes.cornell_box(args.width, args.height, glass_sphere=True)
+        return scenes.cornell_box(args.width, args.height, glass_sphere=True), "builder API (cudatracerlib_amd/scenes.py)"
     if args.workload == "synthetic-bathroom":  # stand-in for BASELINE configs[4]: rough BSDFs + environment emitter, the shading stress
-        return scenes.synthetic_bathroom(args.width, args.height)
+        return scenes.synthetic_bathroom(args.width, args.height), "builder API (cudatracerlib_amd/scenes.py)"
     raise SystemExit("unknown workload " + args.workload)
 
 
@@ -125,6 +141,8 @@ def main():
     ap.add_argument("--instances", type=int, default=2000)
     ap.add_argument("--subdiv", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene", default=None, metavar="FILE.xml", help="render a Mitsuba-0.5 scene file (ParseMitsubaScene) instead of a built-in workload")
+    ap.add_argument("--via-loader", action="store_true", help="write the synthetic workload as a Mitsuba scene and load it through ctl_parse_mitsuba_scene")
     ap.add_argument("--tracer-param", action="append", default=[], metavar="KEY=VALUE")
     ap.add_argument("--no-cache", action="store_true", help="do not use the compiled-geometry cache ($CTL_CACHE_DIR, default $TMPDIR/ctl_amd_cache)")
     ap.add_argument("--flatten", type=int, default=1, help="traverse one world-space BVH over all instanced triangles (64 B of HBM per triangle)")
@@ -156,9 +174,8 @@ def main():
     t_build = time.perf_counter()
     if world > 1 and rank != 0 and not args.no_cache:
         dist.barrier()                      # rank 0 compiles and fills the cache first
-    sc = build_scene(args)
+    sc, scene_source = build_scene(args, rank, dist.barrier if (world > 1 and args.via_loader) else None)
     desc = sc.desc
-    scene_source = "builder API (cudatracerlib_amd/scenes.py)"
     scene = ctl.Scene(desc, flatten=bool(args.flatten))
     if world > 1 and rank == 0 and not args.no_cache:
         dist.barrier()

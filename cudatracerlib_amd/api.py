@@ -584,6 +584,10 @@ class DynamicScene:
             m = ctl_float4x4(); m.m[:] = [float(x) for x in np.asarray(to_world, np.float32).reshape(16)]
         _check(lib.ctl_builder_set_environment_map(self._h, u32(image), (f32 * 3)(*scale), C.byref(m) if m is not None else None))
 
+    def setSensor(self, sensor):
+        """the camera as a ctl_sensor struct (ctl_builder_set_camera), e.g. another scene's desc.camera"""
+        _check(lib.ctl_builder_set_camera(self._h, C.byref(sensor)))
+
     def ParseMitsubaScene(self, path, width=-1, height=-1):
         """ParseMitsubaScene (Engine/SceneLoader/Mitsuba/MitsubaLoader.h:13)."""
         w, h = i32(width), i32(height)

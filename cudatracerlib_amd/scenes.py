@@ -167,22 +167,147 @@ def _rotation(rs):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
-def synthetic_sm(width=1920, height=1080, n_instances=2000, subdiv=4, seed=42):
+# ---- scene descriptions: one description, two ways into the library ------------------------------------------------------------------
+# A description is a plain dict { meshes: [ {V, F, N | None, material} ], nodes: [ (mesh, 4x4 | None) ], lights: [ (node, radiance) ], camera: (pos, target, up,
+# fov_deg, w, h) } with material = ("diffuse", rgb) | ("roughconductor", alpha, eta, k)  (GGX, visible-normal sampling).
+# build_scene() feeds it to the builder API (DynamicScene); export_mitsuba() writes it as a Mitsuba-0.5 scene (scene.xml + meshes.serialized) that
+# ctl_parse_mitsuba_scene loads — the reference's flow ParseMitsubaScene -> UpdateScene -> tracer (MitsubaLoader.cpp:11-73, main.cpp:135-180).
+def _material_of(m):
+    if m[0] == "diffuse":
+        return api.diffuse(m[1])
+    if m[0] == "roughconductor":
+        return api.roughconductor(alpha=m[1], distribution=1, sample_visible=True, eta=m[2], k=m[3])
+    raise ValueError("unknown material " + str(m[0]))
+
+
+def build_scene(desc, sensor=None):
+    """the description through the builder API -> DynamicScene (after UpdateScene).  sensor: a ctl_sensor that replaces the description's camera."""
+    sc = api.DynamicScene()
+    meshes = [sc.add_mesh(m["V"], m["F"], normals=m.get("N"), materials=[_material_of(m["material"])]) for m in desc["meshes"]]
+    nodes = [sc.CreateNode(meshes[mi], None if xf is None else np.asarray(xf, np.float32)) for mi, xf in desc["nodes"]]
+    for ni, rad in desc["lights"]:
+        sc.CreateLight(nodes[ni], 0, rad)
+    pos, target, up, fov, w, h = desc["camera"]
+    sc.setCamera(pos, target, up, fov, w, h)
+    if sensor is not None:
+        sc.setSensor(sensor)
+    sc.UpdateScene()
+    return sc
+
+
+def vertex_normals(V, F):
+    """area-weighted vertex normals of an indexed mesh with the clockwise-outward winding used here (float32); gives a description explicit normals, so that
+    both ways into the library see the same numbers"""
+    V64 = np.asarray(V, np.float64); F = np.asarray(F, np.int64)
+    fn = -np.cross(V64[F[:, 1]] - V64[F[:, 0]], V64[F[:, 2]] - V64[F[:, 0]])
+    N = np.zeros_like(V64)
+    for k in range(3):
+        np.add.at(N, F[:, k], fn)
+    N /= np.maximum(np.linalg.norm(N, axis=1, keepdims=True), 1e-30)
+    return N.astype(np.float32)
+
+
+def with_explicit_normals(desc):
+    """the description as a scene file can carry it: every mesh with explicit normals, meshes in the order the nodes first use them, unused ones dropped
+    (a loader creates a mesh when a shape first names it)"""
+    order, new_nodes = [], []
+    for mi, xf in desc["nodes"]:
+        if mi not in order:
+            order.append(mi)
+        new_nodes.append((order.index(mi), xf))
+    meshes = [dict(desc["meshes"][mi]) for mi in order]
+    for m in meshes:
+        if m.get("N") is None:
+            m["N"] = vertex_normals(m["V"], m["F"])
+    return dict(desc, meshes=meshes, nodes=new_nodes)
+
+
+def _f32s(a):
+    return " ".join("%.9g" % float(np.float32(x)) for x in np.asarray(a, np.float32).ravel())   # nine significant digits round-trip a float32
+
+
+def _serialized_mesh(V, F, N):
+    """one sub-mesh of a Mitsuba .serialized file, format version 4 (ObjectParser.cpp:9-204): u16 0x041C, u16 4, then a zlib stream of
+    flags u32, name \\0, #vertices u64, #triangles u64, positions, normals, indices u32.  The importers reverse the index order of every face, so it is stored reversed."""
+    import struct, zlib
+    V = np.ascontiguousarray(V, np.float32); N = np.ascontiguousarray(N, np.float32); F = np.ascontiguousarray(np.asarray(F, np.uint32)[:, ::-1])
+    body = struct.pack("<I", 0x0001 | 0x1000) + b"mesh\0" + struct.pack("<QQ", len(V), len(F)) + V.tobytes() + N.tobytes() + F.tobytes()
+    return struct.pack("<HH", 0x041C, 4) + zlib.compress(body, 6)
+
+
+def export_mitsuba(desc, directory, name="scene.xml"):
+    """writes <directory>/<name> and <directory>/meshes.serialized; returns the path of the XML file.  Every mesh needs explicit normals (with_explicit_normals)."""
+    import os, struct
+    os.makedirs(directory, exist_ok=True)
+    blobs, offsets, pos = [], [], 0
+    for m in desc["meshes"]:
+        if m.get("N") is None:
+            raise ValueError("export_mitsuba: mesh without normals (use with_explicit_normals)")
+        b = _serialized_mesh(m["V"], m["F"], m["N"]); offsets.append(pos); blobs.append(b); pos += len(b)
+    with open(os.path.join(directory, "meshes.serialized"), "wb") as fh:
+        for b in blobs:
+            fh.write(b)
+        fh.write(struct.pack("<%dQ" % len(offsets), *offsets)); fh.write(struct.pack("<I", len(offsets)))
+    light_of = {ni: rad for ni, rad in desc["lights"]}
+    cam_pos, target, up, fov, w, h = desc["camera"]
+    x = ['<?xml version="1.0" encoding="utf-8"?>', '<scene version="0.5.0">', '  <integrator type="path"/>',
+         '  <sensor type="perspective">', '    <float name="fov" value="%s"/>' % _f32s([fov]), '    <string name="fovAxis" value="x"/>',
+         '    <transform name="toWorld"><lookat origin="%s" target="%s" up="%s"/></transform>' % (_f32s(cam_pos).replace(" ", ", "), _f32s(target).replace(" ", ", "), _f32s(up).replace(" ", ", ")),
+         '    <film type="hdrfilm"><integer name="width" value="%d"/><integer name="height" value="%d"/></film>' % (w, h), '  </sensor>']
+    for ni, (mi, xf) in enumerate(desc["nodes"]):
+        mat = desc["meshes"][mi]["material"]
+        x.append('  <shape type="serialized">')
+        x.append('    <string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="%d"/>' % mi)
+        if xf is not None:
+            x.append('    <transform name="toWorld"><matrix value="%s"/></transform>' % _f32s(xf))
+        if mat[0] == "diffuse":
+            x.append('    <bsdf type="diffuse"><rgb name="reflectance" value="%s"/></bsdf>' % _f32s(mat[1]).replace(" ", ", "))
+        else:
+            x.append('    <bsdf type="roughconductor"><string name="distribution" value="ggx"/><float name="alpha" value="%s"/><float name="extEta" value="1"/>'
+                     '<rgb name="eta" value="%s"/><rgb name="k" value="%s"/></bsdf>' % (_f32s([mat[1]]), _f32s(mat[2]).replace(" ", ", "), _f32s(mat[3]).replace(" ", ", ")))
+        if ni in light_of:
+            x.append('    <emitter type="area"><rgb name="radiance" value="%s"/></emitter>' % _f32s(light_of[ni]).replace(" ", ", "))
+        x.append('  </shape>')
+    x.append('</scene>')
+    path = os.path.join(directory, name)
+    open(path, "w").write("\n".join(x) + "\n")
+    return path
+
+
+def load_mitsuba(path, width=-1, height=-1):
+    """ParseMitsubaScene -> UpdateScene: the DynamicScene of a Mitsuba XML file"""
+    sc = api.DynamicScene()
+    sc.ParseMitsubaScene(path, width, height)
+    sc.UpdateScene()
+    return sc
+
+
+def _camera(pos, target, fov, w, h):
+    """camera tuple with the up vector perpendicular to the view direction (Sensor::SetToWorld(pos, f), SceneTypes/Sensor.cu:680-686: r = f x (0,1,0), u = r x f):
+    DynamicScene.setCamera takes its up vector as given, a scene loader derives it this way"""
+    f = np.asarray(target, np.float64) - np.asarray(pos, np.float64); f /= np.linalg.norm(f)
+    r = np.cross(f, [0.0, 1.0, 0.0]); r /= np.linalg.norm(r)
+    u = np.cross(r, f); u /= np.linalg.norm(u)
+    return (tuple(float(x) for x in pos), tuple(float(x) for x in target), tuple(float(np.float32(x)) for x in u), fov, w, h)
+
+
+def synthetic_sm_description(width=1920, height=1080, n_instances=2000, subdiv=4, seed=42):
     """"synthetic-SM": n_instances instanced icosphere / box meshes (icosphere(4) = 5120 triangles) with seeded random
     rotations, scales and positions in a 100^3 volume inside a closed room; 4 diffuse + 2 microfacet materials; 4 quad lights."""
     rs = np.random.RandomState(seed)   # MT19937
-    sc = api.DynamicScene()
-    mats = [api.diffuse((0.7, 0.7, 0.7)), api.diffuse((0.7, 0.25, 0.2)), api.diffuse((0.2, 0.55, 0.25)), api.diffuse((0.25, 0.3, 0.7)),
-            api.roughconductor(alpha=0.2, distribution=1, sample_visible=True), api.roughconductor(alpha=0.05, distribution=1, sample_visible=True, eta=(0.14, 0.37, 1.44), k=(3.98, 2.38, 1.6))]
-    base = []
+    mats = [("diffuse", (0.7, 0.7, 0.7)), ("diffuse", (0.7, 0.25, 0.2)), ("diffuse", (0.2, 0.55, 0.25)), ("diffuse", (0.25, 0.3, 0.7)),
+            ("roughconductor", 0.2, (0.2, 0.92, 1.1), (3.9, 2.45, 2.14)), ("roughconductor", 0.05, (0.14, 0.37, 1.44), (3.98, 2.38, 1.6))]
+    meshes, nodes, lights = [], [], []
     V, F = icosphere(subdiv)
+    base = []
     for mi in range(len(mats)):
         # a bumpy variant per material keeps the per-mesh BVHs distinct
         bump = 1.0 + 0.08 * np.sin(V[:, :1] * (3 + mi)) * np.cos(V[:, 1:2] * (5 + mi))
-        Vb = (V * bump).astype(np.float32)
-        base.append(sc.add_mesh(Vb, F, normals=None, materials=[mats[mi]]))
+        base.append(len(meshes)); meshes.append(dict(V=(V * bump).astype(np.float32), F=F, N=None, material=mats[mi]))
     Pb, Ib, Nb = unit_box()
-    box_meshes = [sc.add_mesh(Pb, Ib, normals=Nb, materials=[mats[i]]) for i in range(4)]
+    box_meshes = []
+    for i in range(4):
+        box_meshes.append(len(meshes)); meshes.append(dict(V=Pb, F=Ib, N=Nb, material=mats[i]))
     for i in range(n_instances):
         pos = rs.uniform(-50, 50, size=3)
         s = rs.uniform(1.0, 3.5)
@@ -195,25 +320,26 @@ def synthetic_sm(width=1920, height=1080, n_instances=2000, subdiv=4, seed=42):
             mesh = box_meshes[rs.randint(len(box_meshes))]
             xf[:3, :3] = R @ np.diag(rs.uniform(0.6, 2.5, size=3) * s * 0.6)
         xf[:3, 3] = pos
-        sc.CreateNode(mesh, xf.astype(np.float32))
-    # room (inward-facing) and 4 quad lights under the ceiling
-    m = _MeshAcc()
+        nodes.append((mesh, xf.astype(np.float32)))
+    # room (inward-facing; one mesh per wall material) and 4 quad lights under the ceiling
     R0 = 70.0
     c = np.array([[-R0, -R0, -R0], [R0, -R0, -R0], [R0, R0, -R0], [-R0, R0, -R0], [-R0, -R0, R0], [R0, -R0, R0], [R0, R0, R0], [-R0, R0, R0]], np.float32)
+    walls = {0: _MeshAcc(), 1: _MeshAcc(), 2: _MeshAcc()}
     for idx, n, mat in (([0, 3, 2, 1], [0, 0, 1], 0), ([4, 5, 6, 7], [0, 0, -1], 0), ([0, 1, 5, 4], [0, 1, 0], 0), ([3, 7, 6, 2], [0, -1, 0], 0), ([0, 4, 7, 3], [1, 0, 0], 1), ([1, 2, 6, 5], [-1, 0, 0], 2)):
         P, I, N = _quad(c[idx], n)
-        m.add(P, I, N, mat)
-    P, I, N, M = m.arrays()
-    room = sc.add_mesh(P, I, normals=N, tri_material=M, materials=[api.diffuse(WHITE), api.diffuse(RED), api.diffuse(GREEN)])
-    sc.CreateNode(room)
+        walls[mat].add(P, I, N, 0)
+    for mat, col in ((0, WHITE), (1, RED), (2, GREEN)):
+        P, I, N, _ = walls[mat].arrays()
+        nodes.append((len(meshes), None)); meshes.append(dict(V=P, F=I, N=N, material=("diffuse", tuple(col))))
     for lx, lz in ((-35, -35), (35, -35), (-35, 35), (35, 35)):
         P, I, N = _quad([[lx - 12, R0 - 0.5, lz - 12], [lx + 12, R0 - 0.5, lz - 12], [lx + 12, R0 - 0.5, lz + 12], [lx - 12, R0 - 0.5, lz + 12]], [0, -1, 0])
-        lm = sc.add_mesh(P, I, normals=N, materials=[api.diffuse((0.5, 0.5, 0.5))])
-        ln = sc.CreateNode(lm)
-        sc.CreateLight(ln, 0, (40.0, 38.0, 34.0))
-    sc.setCamera((0, 5, -68.0), (0, 0, 0), (0, 1, 0), 60.0, width, height)
-    sc.UpdateScene()
-    return sc
+        lights.append((len(nodes), (40.0, 38.0, 34.0)))
+        nodes.append((len(meshes), None)); meshes.append(dict(V=P, F=I, N=N, material=("diffuse", (0.5, 0.5, 0.5))))
+    return dict(meshes=meshes, nodes=nodes, lights=lights, camera=_camera((0, 5, -68.0), (0, 0, 0), 60.0, width, height))
+
+
+def synthetic_sm(width=1920, height=1080, n_instances=2000, subdiv=4, seed=42):
+    return build_scene(synthetic_sm_description(width, height, n_instances, subdiv, seed))
 
 
 def procedural_envmap(w=64, h=32):

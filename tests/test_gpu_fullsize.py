@@ -117,3 +117,29 @@ def test_linearity_and_plugin_agreement(gpu, workload):
     assert np.array_equal(mega[..., 6], a[..., 6])
     close = np.isclose(mega[..., :3], a[..., :3], rtol=1e-3, atol=1e-3).all(axis=2)
     assert close.mean() >= 0.999 and abs(mega[..., :3].mean() - a[..., :3].mean()) <= 1e-4 * a[..., :3].mean()
+
+
+def test_loader_fed_frame_equals_the_builder_fed_frame(gpu, orc, tmp_path):
+    """row J1 at BASELINE size: the bench workload written as a Mitsuba-0.5 scene (XML + .serialized meshes), loaded through ctl_parse_mitsuba_scene,
+    flattened and rendered at 1920x1080, against the same description through the builder API.  Geometry, transforms, materials and lights of the two
+    scenes are bit-identical (tests/test_mitsuba_loader.py).  The loader derives the camera frame the reference's way (Sensor::SetToWorld(pos, f)), one unit
+    in the last place away from DynamicScene.setCamera's — enough to move every path by an ulp, which eight bounces off small spheres amplify past any
+    tight tolerance — so the builder-fed scene is given the loader's ctl_sensor: then the two frames must agree like two runs of one scene (same ray count,
+    same samples per pixel, sums to rtol 1e-5: float atomics accumulate in another order)."""
+    d = scenes.with_explicit_normals(scenes.synthetic_sm_description(W, H, n_instances=2000, subdiv=4))
+    sc_b = scenes.load_mitsuba(scenes.export_mitsuba(d, str(tmp_path)))
+    sc_a = scenes.build_scene(d, sensor=sc_b.desc.camera)
+    assert sc_a.desc.n_tri_data == sc_b.desc.n_tri_data and sc_a.desc.n_nodes == sc_b.desc.n_nodes
+    tables = orc.sequence_tables(2)
+    frames = []
+    gpu.api.set_cache_dir(os.environ.get("CTL_CACHE_DIR") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "ctl_amd_cache"))
+    try:
+        for sc in (sc_a, sc_b):
+            scene = gpu.Scene(sc.desc, flatten=True)
+            frames.append(render(gpu, gpu.WavefrontPathTracer, scene, tables))
+    finally:
+        gpu.api.set_cache_dir(None)
+    (a, rays_a), (b, rays_b) = frames
+    assert rays_a == rays_b and rays_a > 2 * W * H
+    assert np.array_equal(a[..., 6], b[..., 6])
+    assert np.allclose(a[..., :3], b[..., :3], rtol=1e-5, atol=1e-5)
