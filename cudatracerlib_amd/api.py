@@ -124,6 +124,7 @@ lib.ctl_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.ctl_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.ctl_intersect_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(f32)]
 lib.ctl_image_resolve_rgb.argtypes = [C.c_void_p, f32, C.c_void_p]
+lib.ctl_tracer_set_param_float.argtypes = [C.c_void_p, C.c_char_p, f32]
 lib.ctl_builder_add_spot_light.argtypes = [C.c_void_p, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), f32, f32]
 lib.ctl_builder_add_distant_light.argtypes = [C.c_void_p, C.POINTER(f32), C.POINTER(f32), f32]
 lib.ctl_builder_add_image.argtypes = [C.c_void_p, C.c_void_p, u32, u32, u32, u32, u32, C.POINTER(u32)]
@@ -724,10 +725,20 @@ class _Parameters:
         self._t = tracer
 
     def setValue(self, key, value):
+        """bool, int (also the index of an enum value), float, or the name of an enum value (TracerParameterCollection::setValue, Kernel/TracerSettings.h:277)"""
         if isinstance(value, bool):
             _check(lib.ctl_tracer_set_param_bool(self._t._h, key.encode(), 1 if value else 0))
+        elif isinstance(value, str):
+            _check(lib.ctl_tracer_set_param_enum(self._t._h, key.encode(), value.encode()))
+        elif isinstance(value, float):
+            _check(lib.ctl_tracer_set_param_float(self._t._h, key.encode(), f32(value)))
         else:
             _check(lib.ctl_tracer_set_param_int(self._t._h, key.encode(), int(value)))
+
+    def getFloat(self, key):
+        v = f32()
+        _check(lib.ctl_tracer_get_param_float(self._t._h, key.encode(), C.byref(v)))
+        return v.value
 
     def getValue(self, key):
         v = C.c_int()

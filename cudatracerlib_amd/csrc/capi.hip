@@ -182,7 +182,13 @@ int ctl_tracer_create(const char* plugin, ctl_tracer** out) {
 }
 void ctl_tracer_destroy(ctl_tracer* t) { delete t; }
 int ctl_tracer_set_param_bool(ctl_tracer* t, const char* key, int value) { CTL_REQUIRE(t && key, "null argument"); CTL_TRY t->t->getParameters().setValue(key, value ? 1 : 0, TracerParameter::Bool); CTL_CATCH }
-int ctl_tracer_set_param_int(ctl_tracer* t, const char* key, int value) { CTL_REQUIRE(t && key, "null argument"); CTL_TRY t->t->getParameters().setValue(key, value, TracerParameter::Int); CTL_CATCH }
+int ctl_tracer_set_param_int(ctl_tracer* t, const char* key, int value) { CTL_REQUIRE(t && key, "null argument"); CTL_TRY
+    auto& P = t->t->getParameters();
+    P.setValue(key, value, P.kindOf(key) == TracerParameter::Enum ? TracerParameter::Enum : TracerParameter::Int);   // an enum may be set by its index
+CTL_CATCH }
+int ctl_tracer_set_param_float(ctl_tracer* t, const char* key, float value) { CTL_REQUIRE(t && key, "null argument"); CTL_TRY t->t->getParameters().setFloat(key, value); CTL_CATCH }
+int ctl_tracer_get_param_float(ctl_tracer* t, const char* key, float* value_out) { CTL_REQUIRE(t && key && value_out, "null argument"); CTL_TRY *value_out = t->t->getParameters().getFloat(key); CTL_CATCH }
+int ctl_tracer_set_param_enum(ctl_tracer* t, const char* key, const char* value_name) { CTL_REQUIRE(t && key && value_name, "null argument"); CTL_TRY t->t->getParameters().setEnumByName(key, value_name); CTL_CATCH }
 int ctl_tracer_get_param_int(ctl_tracer* t, const char* key, int* value_out) { CTL_REQUIRE(t && key && value_out, "null argument"); CTL_TRY *value_out = t->t->getParameters().getValue(key); CTL_CATCH }
 int ctl_tracer_resize(ctl_tracer* t, uint32_t width, uint32_t height) { CTL_REQUIRE(t && width && height, "bad argument"); CTL_TRY t->t->Resize(width, height); CTL_CATCH }
 int ctl_tracer_initialize_scene(ctl_tracer* t, ctl_scene* s) { CTL_REQUIRE(t && s, "null argument"); CTL_TRY t->t->InitializeScene(&s->s); CTL_CATCH }

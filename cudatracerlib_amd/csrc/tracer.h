@@ -64,25 +64,46 @@ private:
     uint32_t w_, h_; dbuf<ctl_pixel_data> px_; dbuf<float> rgb_; dbuf<uint32_t> out_, filtered_; dbuf<int> lum_;   // filtered_: m_filteredColorsDevice (RGBE)
 };
 
-// Kernel/TracerSettings.h:196-350 — typed parameters with interval / set constraints
+// Kernel/TracerSettings.h:14-350 — typed parameters with interval / set constraints: bool, int and float intervals (IntervalParameterConstraint), and
+// enumerations (SetParameterConstraint over the enum's values, addressed by value or by name as TracerParameter<enum> does through its string table)
 struct TracerParameter {
-    enum kind_t { Bool, Int } kind; int value, lo, hi;
+    enum kind_t { Bool, Int, Float, Enum } kind; int value, lo, hi;
+    float fvalue = 0, flo = 0, fhi = 0;
+    std::vector<std::string> names;   // Enum: name of value i
 };
 class TracerParameterCollection {
 public:
     void addBool(const std::string& key, bool v) { p_[key] = { TracerParameter::Bool, v ? 1 : 0, 0, 1 }; }
     void addInterval(const std::string& key, int v, int lo, int hi) { p_[key] = { TracerParameter::Int, v, lo, hi }; }
-    int getValue(const std::string& key) const { auto it = p_.find(key); if (it == p_.end()) throw std::runtime_error("Unknown parameter key: " + key); return it->second.value; }
+    void addFloatInterval(const std::string& key, float v, float lo, float hi) { TracerParameter p{ TracerParameter::Float, 0, 0, 0 }; p.fvalue = v; p.flo = lo; p.fhi = hi; p_[key] = p; }
+    void addEnum(const std::string& key, int v, const std::vector<std::string>& names) { TracerParameter p{ TracerParameter::Enum, v, 0, (int)names.size() - 1 }; p.names = names; p_[key] = p; }
+    int getValue(const std::string& key) const { const TracerParameter& p = find(key); if (p.kind == TracerParameter::Float) throw std::runtime_error("Parameter type mismatch for key: " + key); return p.value; }
+    float getFloat(const std::string& key) const { const TracerParameter& p = find(key); if (p.kind != TracerParameter::Float) throw std::runtime_error("Parameter type mismatch for key: " + key); return p.fvalue; }
+    const std::string& getEnumName(const std::string& key) const { const TracerParameter& p = find(key); if (p.kind != TracerParameter::Enum) throw std::runtime_error("Parameter type mismatch for key: " + key); return p.names[p.value]; }
     void setValue(const std::string& key, int v, TracerParameter::kind_t kind) {
-        auto it = p_.find(key);
-        if (it == p_.end()) throw std::runtime_error("Unknown parameter key: " + key);
-        if (it->second.kind != kind) throw std::runtime_error("Parameter type mismatch for key: " + key);
-        if (v < it->second.lo || v > it->second.hi) throw std::runtime_error("Parameter value outside of its interval: " + key);
-        it->second.value = v;
+        TracerParameter& p = find(key);
+        if (p.kind != kind) throw std::runtime_error("Parameter type mismatch for key: " + key);
+        if (v < p.lo || v > p.hi) throw std::runtime_error("Parameter value outside of its interval: " + key);
+        p.value = v;
     }
+    void setFloat(const std::string& key, float v) {
+        TracerParameter& p = find(key);
+        if (p.kind != TracerParameter::Float) throw std::runtime_error("Parameter type mismatch for key: " + key);
+        if (!(v >= p.flo && v <= p.fhi)) throw std::runtime_error("Parameter value outside of its interval: " + key);
+        p.fvalue = v;
+    }
+    void setEnumByName(const std::string& key, const std::string& name) {
+        TracerParameter& p = find(key);
+        if (p.kind != TracerParameter::Enum) throw std::runtime_error("Parameter type mismatch for key: " + key);
+        for (size_t i = 0; i < p.names.size(); i++) if (p.names[i] == name) { p.value = (int)i; return; }
+        throw std::runtime_error("Parameter value outside of its set: " + key + " = " + name);
+    }
+    TracerParameter::kind_t kindOf(const std::string& key) const { return find(key).kind; }
     bool has(const std::string& key) const { return p_.count(key) != 0; }
 private:
     std::map<std::string, TracerParameter> p_;
+    const TracerParameter& find(const std::string& key) const { auto it = p_.find(key); if (it == p_.end()) throw std::runtime_error("Unknown parameter key: " + key); return it->second; }
+    TracerParameter& find(const std::string& key) { auto it = p_.find(key); if (it == p_.end()) throw std::runtime_error("Unknown parameter key: " + key); return it->second; }
 };
 
 class event_timer {   // hipEvent pairs on the tracer's stream, summed per kernel class after synchronisation

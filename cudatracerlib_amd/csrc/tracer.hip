@@ -334,7 +334,7 @@ void event_timer::collect(double ms_out[4]) {
 // ------------------------------------------------------------------------------------------------ TracerBase / Tracer<true>
 TracerBase::TracerBase() {
     require_device();
-    m_sParameters.addInterval("BlockSamplerType", 0, 0, 3);          // Tracer.cpp:19 (BlockSamplerTypes::Uniform)
+    m_sParameters.addEnum("BlockSamplerType", 0, { "Uniform", "Variance", "Difference", "Select" });   // Tracer.cpp:19 (BlockSamplerTypes::Uniform), an enum parameter as there
     m_sParameters.addInterval("FractionDeterministic", 2, 1, INT_MAX);   // IBlockSampler.h:157-163 (the sampler's own parameter collection there)
     m_sParameters.addInterval("FractionWeighted", 4, 1, INT_MAX);
     CTL_HIP(hipEventCreate(&start)); CTL_HIP(hipEventCreate(&stop));

@@ -395,7 +395,12 @@ void ctl_tracer_destroy(ctl_tracer* t);
  * RRStartDepth(int>=1) (WavefrontPathTracer.h:29-39). Out-of-interval values -> CTL_ERR_INVALID. */
 int ctl_tracer_set_param_bool(ctl_tracer* t, const char* key, int value);
 int ctl_tracer_set_param_int(ctl_tracer* t, const char* key, int value);
-int ctl_tracer_get_param_int(ctl_tracer* t, const char* key, int* value_out);
+int ctl_tracer_get_param_int(ctl_tracer* t, const char* key, int* value_out);   /* bool, int and enum (its index) parameters */
+/* float intervals and enumerations (TracerParameter<float>, TracerParameter<enum> with its string table, Kernel/TracerSettings.h:14-195):
+ * an enum is set by the NAME of the value ("Uniform", "Variance", ...) or, through ctl_tracer_set_param_int, by its index */
+int ctl_tracer_set_param_float(ctl_tracer* t, const char* key, float value);
+int ctl_tracer_get_param_float(ctl_tracer* t, const char* key, float* value_out);
+int ctl_tracer_set_param_enum(ctl_tracer* t, const char* key, const char* value_name);
 int ctl_tracer_resize(ctl_tracer* t, uint32_t width, uint32_t height);       /* Tracer::Resize (Tracer.h:196-208)          */
 int ctl_tracer_initialize_scene(ctl_tracer* t, ctl_scene* s);                /* TracerBase::InitializeScene (Tracer.h:102) */
 /* image-tile sharding for multi-GPU: this tracer renders the 64x64 tiles t with t % world == rank. */

@@ -359,3 +359,16 @@ def test_native_framebuffer_reduce_single_rank(gpu):
     with pytest.raises(gpu.CtlError):
         comm.reduce(img, 3)
     del comm
+
+
+def test_tracer_parameter_kinds(gpu):
+    """TracerParameterCollection (Kernel/TracerSettings.h:14-350): bool / int intervals, and enumerations addressed by value name or index"""
+    tr = gpu.WavefrontPathTracer(); p = tr.getParameters()
+    p.setValue("BlockSamplerType", "Variance"); assert p.getValue("BlockSamplerType") == 1
+    p.setValue("BlockSamplerType", 3); assert p.getValue("BlockSamplerType") == 3
+    p.setValue("BlockSamplerType", "Uniform"); assert p.getValue("BlockSamplerType") == 0
+    for bad in (("BlockSamplerType", "NoSuchSampler"), ("BlockSamplerType", 7), ("MaxPathLength", "Uniform"), ("MaxPathLength", 0), ("MaxPathLength", 1.5), ("NoSuchKey", 1)):
+        with pytest.raises(gpu.CtlError):
+            p.setValue(*bad)
+    with pytest.raises(gpu.CtlError):
+        p.getFloat("MaxPathLength")
