@@ -16,7 +16,10 @@ struct dev_sensor {
     float s2c[16];        // m_sampleToCamera, row-major 4x4 (projective: TransformPoint divides by w)
     float to_world[12];   // rows 0..2 of toWorld
     float inv_res[2];
+    float dx[3], dy[3];   // m_dx, m_dy: camera-space offsets of the neighbouring pixels' rays (Sensor.cu:86-89, sampleRayDifferential)
 };
+// the levels behind level 0 of an image (KernelMIPMap::m_uLevels, m_sOffsets; Engine/MIPMap_device.h:57-69): texel offsets relative to the image's level 0
+struct dev_mip_levels { uint32_t levels; uint32_t offsets[15]; };
 
 struct dev_scene {
     const float4* top_nodes;     // scene BVH: 4 x float4 per node, addressed in float4 units (reference encoding)
@@ -35,7 +38,9 @@ struct dev_scene {
     const ctl_material* mats;
     const ctl_light* lights;
     const unsigned char* anim;
-    const ctl_mipmap* images;    // level-0 KernelMIPMap descriptors with device texel pointers
+    const ctl_mipmap* images;    // level-0 KernelMIPMap descriptors with device texel pointers (every image's further levels follow its level 0 in the pool)
+    const dev_mip_levels* mip_levels;   // per image: the pyramid behind level 0 (first-hit texture filtering of the PathTracer plugin)
+    const float* mip_weight_lut; // KernelMIPMap::m_weightLut[64] (EWA)
     const ctl_rough_transmittance* rough_transmittance;   // 3 tables with device pointers, or nullptr
     const float* rt_reduced;     // per rough-plastic material with constant alpha: its transmittance table reduced to 1-D in cos(theta) + the diffuse value (tracer.hip)
     int start_node;

@@ -3,6 +3,7 @@
 // Same device functions as the wavefront tracer (shading.h), same sampler draws in the same order, shadow rays resolved inline.
 // It exists for A/B comparison behind the same plugin API; the wavefront formulation is the fast one.
 #include "kernels.h"
+#define CTL_TEX_PARTIALS 1   // this integrator computes ray differentials at the first hit (PathTracer.cu:60-61) and filters image textures there
 #include "shading.h"
 #include "compaction.h"
 #include "tracer.h"
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void k_path_trace(dev_scene S, pass_params P, 
         const f2 j = rng.next2();
         const f2 pX{ (float)x + j.x, (float)y + j.y };
         (void)rng.next2();   // aperture sample
-        f3 r_o, r_d; sensor_sample_ray(S.cam, pX, r_o, r_d);
+        f3 r_o, r_d, r_dx, r_dy; sensor_sample_ray_differential(S.cam, pX, r_o, r_d, r_dx, r_dy);   // pathKernel2: sampleSensorRay(r, rX, rY, ...) (PathTracer.cu:186-190)
         f3 cl(0.0f), cf(1.0f), last_nor(0.0f);
         int depth = 0; bool specularBounce = false, had_hit = false;
         float brdf_scattering_pdf = 0;
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256) void k_path_trace(dev_scene S, pass_params P, 
             const ctl_material& mat = S.mats[ninfo.x + tri_mat_index(S, tri)];
             if (mat.map_kind != CTL_MAP_NONE) sample_normal_map(mat, b.dg);
             if (mat.two_sided && b.wi.z < 0) { b.dg.n = -b.dg.n; b.dg.sys.n = -b.dg.sys.n; b.wi.z *= -1.0f; }
+            if (depth == 1) compute_partials(b.dg, r_o, r_dx, r_dy);   // PathTracer.cu:60-61
             const uint32_t nli = mat.node_light_index;
             if (nli != 0xffffffffu) {
                 const uint32_t li2 = nli == 0 ? ninfo.y : ninfo.z;

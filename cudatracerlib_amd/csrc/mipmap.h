@@ -72,6 +72,76 @@ __device__ __forceinline__ void mip_eval_gradient(const ctl_mipmap& M, f2 uv, f3
     g0 = (p10 + p00 * (dy - 1) - tmp * dy) * dim.x;
     g1 = (p01 + p00 * (dx - 1) - tmp * dx) * dim.y;
 }
+// ---- the pyramid behind level 0 and the filtered lookup of a first hit with ray differentials (PathTracer plugin only; Engine/MIPMap.cu:21-114,193-278)
+__device__ __forceinline__ uint32_t mip_offset(const dev_mip_levels& L, uint32_t level) { return level ? L.offsets[level - 1] : 0u; }
+__device__ __forceinline__ f3 mip_texel_l(const ctl_mipmap& M, const dev_mip_levels& L, uint32_t level, f2 uv) {   // KernelMIPMap::Texel(level, uv)
+    const int wl = (int)(M.width >> level), hl = (int)(M.height >> level);
+    f2 l;
+    if (!wrap_coordinates(uv, f2{ (float)wl, (float)hl }, M.wrap_mode, l)) return f3(0.0f);
+    const int x = clampi((int)l.x, 0, wl - 1), y = clampi((int)l.y, 0, hl - 1);
+    return texel_decode(M.texels[(size_t)mip_offset(L, level) + (size_t)y * wl + x], M.texel_type);
+}
+__device__ __forceinline__ f3 mip_triangle_l(const ctl_mipmap& M, const dev_mip_levels& L, uint32_t level, f2 uv) {   // KernelMIPMap::triangle(level, uv)
+    level = level > L.levels - 1 ? L.levels - 1 : level;
+    const f2 sz{ (float)(M.width >> level), (float)(M.height >> level) }, is{ 1.0f / sz.x, 1.0f / sz.y };
+    const float ds = fracf_(uv.x * sz.x), dt = fracf_(uv.y * sz.y);
+    return ((1.f - ds) * (1.f - dt)) * mip_texel_l(M, L, level, uv) + ((1.f - ds) * dt) * mip_texel_l(M, L, level, f2{ uv.x + 0, uv.y + is.y }) +
+           (ds * (1.f - dt)) * mip_texel_l(M, L, level, f2{ uv.x + is.x, uv.y + 0 }) + (ds * dt) * mip_texel_l(M, L, level, f2{ uv.x + is.x, uv.y + is.y });
+}
+__device__ inline f3 mip_eval_ewa(const ctl_mipmap& M, const dev_mip_levels& L, const float* __restrict__ lut, uint32_t level, f2 uv, float A, float B, float C) {   // KernelMIPMap::evalEWA
+    if (level >= L.levels) return mip_texel_l(M, L, L.levels - 1, f2{ 0, 0 });
+    const f2 size{ (float)(M.width >> level), (float)(M.height >> level) };
+    const float u = uv.x * size.x - 0.5f, v = uv.y * size.y - 0.5f;
+    const f2 ratio{ size.x / (float)M.width, size.y / (float)M.height };
+    A /= ratio.x * ratio.x; B /= ratio.x * ratio.y; C /= ratio.y * ratio.y;
+    const float invDet = 1.0f / (-B * B + 4.0f * A * C), deltaU = 2.0f * sqrtf(C * invDet), deltaV = 2.0f * sqrtf(A * invDet);
+    const int u0 = (int)ceilf(u - deltaU), u1 = (int)floorf(u + deltaU), v0 = (int)ceilf(v - deltaV), v1 = (int)floorf(v + deltaV);
+    const float As = A * 64, Bs = B * 64, Cs = C * 64;
+    f3 result(0.0f); float denominator = 0.0f; const float ddq = 2 * As, uu0 = u0 - u;
+    for (int vt = v0; vt <= v1; ++vt) {
+        const float vv = vt - v;
+        float q = As * uu0 * uu0 + (Bs * uu0 + Cs * vv) * vv, dq = As * (2 * uu0 + 1) + Bs * vv;
+        for (int ut = u0; ut <= u1; ++ut) {
+            if (q < 64) { const unsigned qi = (unsigned)q; if (qi < 64) { const float w = lut[(int)q]; result = result + mip_texel_l(M, L, level, f2{ (float)ut / size.x, (float)vt / size.y }) * w; denominator += w; } }
+            q += dq; dq += ddq;
+        }
+    }
+    if (denominator == 0) return mip_triangle_l(M, L, level, uv);
+    return result / denominator;
+}
+__device__ inline f3 mip_eval(const ctl_mipmap& M, const dev_mip_levels& L, const float* __restrict__ lut, f2 uv, f2 d0, f2 d1) {   // KernelMIPMap::eval(uv, d0, d1)
+    const float dimx = (float)M.width, dimy = (float)M.height;
+    const float du0 = d0.x * dimx, dv0 = d0.y * dimy, du1 = d1.x * dimx, dv1 = d1.y * dimy, du = (du0 + du1) / 2.0f, dv = (dv0 + dv1) / 2.0f;
+    if (M.filter_mode == CTL_FILTER_POINT) return mip_texel_l(M, L, 0, uv);
+    if (M.filter_mode == CTL_FILTER_BILINEAR) return mip_triangle_l(M, L, 0, uv);
+    if (M.filter_mode == CTL_FILTER_TRILINEAR) {
+        const float levela = log2f(dimx / fabsf(du)), levelb = log2f(dimy / fabsf(dv)), level = (float)L.levels - clampf((levela + levelb) / 2.0f, 1.0f, (float)L.levels);
+        const int iLevel = (int)floorf(level), iLevel2 = clampi(iLevel + 1, 0, (int)L.levels - 1);
+        const float p = level - iLevel;
+        return p * mip_triangle_l(M, L, (uint32_t)iLevel, uv) + (1 - p) * mip_triangle_l(M, L, (uint32_t)iLevel2, uv);
+    }
+    float A = dv0 * dv0 + dv1 * dv1, B = -2.0f * (du0 * dv0 + du1 * dv1), C = du0 * du0 + du1 * du1, F = A * C - B * B * 0.25f;
+    const float root = sqrtf((A - C) * (A - C) + B * B), Aprime = 0.5f * (A + C - root), Cprime = 0.5f * (A + C + root);
+    const float majorRadius = Aprime != 0 ? sqrtf(F / Aprime) : 0; float minorRadius = Cprime != 0 ? sqrtf(F / Cprime) : 0;
+    if (!(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
+        const float level = log2f(max2(majorRadius, 1e-4f)); const int ilevel = (int)floorf(level);
+        if (ilevel < 0) return mip_triangle_l(M, L, 0, uv);
+        const float a = level - ilevel;
+        return mip_triangle_l(M, L, (uint32_t)ilevel, uv) * (1.0f - a) + mip_triangle_l(M, L, (uint32_t)(ilevel + 1), uv) * a;
+    }
+    const float maxAnisotropy = 16;
+    if (minorRadius * maxAnisotropy < majorRadius) {
+        minorRadius = majorRadius / maxAnisotropy;
+        const float theta = 0.5f * atanf(B / (A - C)), sinTheta = sinf(theta), cosTheta = cosf(theta);
+        const float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius, sinTheta2 = sinTheta * sinTheta, cosTheta2 = cosTheta * cosTheta, sin2Theta = 2 * sinTheta * cosTheta;
+        A = a2 * cosTheta2 + b2 * sinTheta2; B = (a2 - b2) * sin2Theta; C = a2 * sinTheta2 + b2 * cosTheta2; F = a2 * b2;
+    }
+    const float scale = 1.0f / F; A *= scale; B *= scale; C *= scale;
+    const float level = max2(0.0f, log2f(minorRadius)); const int ilevel = (int)level; const float a = level - ilevel;
+    if (majorRadius < 1 || !(A > 0 && C > 0)) return mip_triangle_l(M, L, (uint32_t)ilevel, uv);
+    return mip_eval_ewa(M, L, lut, (uint32_t)ilevel, uv, A, B, C) * (1.0f - a) + mip_eval_ewa(M, L, lut, (uint32_t)(ilevel + 1), uv, A, B, C) * a;
+}
+
 __device__ __forceinline__ f2 tex_map_point(const ctl_texture& t, f2 uv) { return f2{ t.uv_scale[0] * uv.x + 0 * uv.y + t.uv_offset[0], 0 * uv.x + t.uv_scale[1] * uv.y + t.uv_offset[1] }; }   // TextureMapping2D::TransformPoint
 
 // sample_fast (Material.cu:141-158): constant / checkerboard / image texture at an interpolated uv

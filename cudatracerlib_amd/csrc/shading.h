@@ -43,12 +43,31 @@ __device__ __forceinline__ void sensor_sample_ray(const dev_sensor& c, f2 pixelS
     d = xform_dir(m, dn);
 }
 
+// PerspectiveSensor::sampleRayDifferential (SceneTypes/Sensor.cu:130-144): the ray and the directions of its x / y neighbours
+__device__ __forceinline__ void sensor_sample_ray_differential(const dev_sensor& c, f2 pixelSample, f3& o, f3& d, f3& dX, f3& dY) {
+    const float px = pixelSample.x * c.inv_res[0], py = pixelSample.y * c.inv_res[1];
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { float s = c.s2c[i * 4] * px; s += c.s2c[i * 4 + 1] * py; s += c.s2c[i * 4 + 2] * 0.0f; s += c.s2c[i * 4 + 3] * 1.0f; r[i] = s; }
+    const f3 nearP(r[0] / r[3], r[1] / r[3], r[2] / r[3]);
+    m34 m;
+#pragma unroll
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) m.r[i][j] = c.to_world[i * 4 + j];
+    o = xform_point(m, f3(0.0f));
+    d = xform_dir(m, normalize(nearP));
+    dX = xform_dir(m, normalize(nearP + f3(c.dx[0], c.dx[1], c.dx[2]))); dY = xform_dir(m, normalize(nearP + f3(c.dy[0], c.dy[1], c.dy[2])));
+}
+
 // ---- differential geometry at a hit (Kernel/TraceHelper.cu:274-307 -> Engine/TriangleData.cu:75-103)
 struct diff_geom {
     f3 P; frame sys; f3 n; f2 uv; const ctl_mipmap* images; const ctl_rough_transmittance* rough_transmittance; const ctl_material* mats;
     const float* rt_reduced;   // dev_scene::rt_reduced
-#if CTL_SHADE_FEATURES & 32
-    f3 dpdu, dpdv;   // world space, for height maps only
+#if (CTL_SHADE_FEATURES & 32) || defined(CTL_TEX_PARTIALS)
+    f3 dpdu, dpdv;   // world space, for height maps and ray differentials
+#endif
+#ifdef CTL_TEX_PARTIALS
+    // ray differentials of the first hit (DifferentialGeometry::computePartials; megakernel PathTracer only, PathTracer.cu:60-61)
+    bool has_uv_partials; float dudx, dudy, dvdx, dvdy; const dev_mip_levels* mip_levels; const float* mip_weight_lut;
 #endif
 };   // images: g_SceneData.m_sTexData; tables of RoughTransmittanceManager (both uniform)
 __device__ __forceinline__ void fill_dg(const dev_scene& S, float u, float v, int tri, int node, diff_geom& dg) {
@@ -68,14 +87,38 @@ __device__ __forceinline__ void fill_dg(const dev_scene& S, float u, float v, in
     dg.sys.s = normalize(s); dg.sys.t = normalize(t); dg.sys.n = normalize(cross(t, s));
     const f3 wdpdu = xform_dir(l2w, dpdu), wdpdv = xform_dir(l2w, dpdv);
     dg.n = normalize(cross(wdpdu, wdpdv));
-#if CTL_SHADE_FEATURES & 32
+#if (CTL_SHADE_FEATURES & 32) || defined(CTL_TEX_PARTIALS)
     dg.dpdu = wdpdu; dg.dpdv = wdpdv;
+#endif
+#ifdef CTL_TEX_PARTIALS
+    dg.has_uv_partials = false; dg.mip_levels = S.mip_levels; dg.mip_weight_lut = S.mip_weight_lut;   // TraceResult::fillDG (Kernel/TraceResult.cu:13-21)
 #endif
     const f2 uva{ half_to_float((uint16_t)tb.y), half_to_float((uint16_t)(tb.y >> 16)) }, uvb{ half_to_float((uint16_t)tb.z), half_to_float((uint16_t)(tb.z >> 16)) },
         uvc{ half_to_float((uint16_t)tb.w), half_to_float((uint16_t)(tb.w >> 16)) };
     dg.uv = f2{ u * uva.x + v * uvb.x + w * uvc.x, u * uva.y + v * uvb.y + w * uvc.y };
     if (dot(dg.n, dg.sys.n) < 0.0f) dg.n = -dg.n;
 }
+#ifdef CTL_TEX_PARTIALS
+// DifferentialGeometry::computePartials (Engine/DifferentialGeometry.cu:9-90); the three rays share their origin
+__device__ inline void compute_partials(diff_geom& dg, f3 ro, f3 rxd, f3 ryd) {
+    dg.has_uv_partials = true;
+    if (dot(dg.dpdu, dg.dpdu) == 0 && dot(dg.dpdv, dg.dpdv) == 0) { dg.dudx = dg.dvdx = dg.dudy = dg.dvdy = 0.0f; return; }
+    const float pp = dot(dg.n, dg.P), pox = dot(dg.n, ro), poy = dot(dg.n, ro), prx = dot(dg.n, rxd), pry = dot(dg.n, ryd);
+    if (prx == 0 || pry == 0) { dg.dudx = dg.dvdx = dg.dudy = dg.dvdy = 0.0f; return; }
+    const float tx = (pp - pox) / prx, ty = (pp - poy) / pry;
+    const float absX = fabsf(dg.n.x), absY = fabsf(dg.n.y), absZ = fabsf(dg.n.z);
+    const int a0 = (absX > absY && absX > absZ) ? 1 : 0, a1 = (absX > absY && absX > absZ) ? 2 : (absY > absZ ? 2 : 1);
+    auto comp = [](f3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); };
+    const float A00 = comp(dg.dpdu, a0), A01 = comp(dg.dpdv, a0), A10 = comp(dg.dpdu, a1), A11 = comp(dg.dpdv, a1);
+    const f3 px = ro + rxd * tx, py = ro + ryd * ty;
+    const float Bx0 = comp(px, a0) - comp(dg.P, a0), Bx1 = comp(px, a1) - comp(dg.P, a1), By0 = comp(py, a0) - comp(dg.P, a0), By1 = comp(py, a1) - comp(dg.P, a1);
+    const float det = A00 * A11 - A01 * A10;   // AlgebraHelper::solveLinearSystem2x2 (Math/AlgebraHelper.h:11-24)
+    if (fabsf(det) <= 2.93873587705571876e-39f) { dg.dudx = 1; dg.dvdx = 0; dg.dudy = 0; dg.dvdy = 1; return; }
+    const float inverse = 1.0f / det;
+    dg.dudx = (A11 * Bx0 - A01 * Bx1) * inverse; dg.dvdx = (A00 * Bx1 - A10 * Bx0) * inverse;
+    dg.dudy = (A11 * By0 - A01 * By1) * inverse; dg.dvdy = (A00 * By1 - A10 * By0) * inverse;
+}
+#endif
 __device__ __forceinline__ uint32_t tri_mat_index(const dev_scene& S, int tri) { return (S.tri_data[tri * 2].y >> 16) & 0xff; }   // TriangleData.h:40-44
 
 // ImageTexture::Evaluate(uv) (Texture.cu:6-13); out of line: tex_eval is inlined at every BSDF parameter fetch and the bitmap
@@ -96,6 +139,14 @@ __device__ __forceinline__ f3 tex_eval(const ctl_texture& t, const diff_geom& dg
         return (x * y == 1) ? f3(t.value[0], t.value[1], t.value[2]) : f3(t.value1[0], t.value1[1], t.value1[2]);
     }
 #if CTL_SHADE_FEATURES & 4
+#ifdef CTL_TEX_PARTIALS
+    if (t.type == CTL_TEX_IMAGE && dg.has_uv_partials && t.image != 0xffffffffu) {   // ImageTexture::Evaluate(dg) with uv partials (Texture.cu:15-29): differentiate (Texture.h:52-59, m12 = m21 = 0) -> KernelMIPMap::eval
+        const f2 uv{ t.uv_scale[0] * dg.uv.x + 0 * dg.uv.y + t.uv_offset[0], 0 * dg.uv.x + t.uv_scale[1] * dg.uv.y + t.uv_offset[1] };
+        const float dsdx = t.uv_scale[0] * dg.dudx + 0 * dg.dvdx, dsdy = t.uv_scale[0] * dg.dudy + 0 * dg.dvdy;
+        const float dtdx = 0 * dg.dudx + t.uv_scale[1] * dg.dvdx, dtdy = 0 * dg.dudy + t.uv_scale[1] * dg.dvdy;
+        return mip_eval(dg.images[t.image], dg.mip_levels[t.image], dg.mip_weight_lut, uv, f2{ dsdx, dtdx }, f2{ dsdy, dtdy }) * f3(t.value[0], t.value[1], t.value[2]);
+    }
+#endif
     if (t.type == CTL_TEX_IMAGE) return tex_eval_image(t, dg.uv, dg.images);
 #endif
     return f3(t.value[0], t.value[1], t.value[2]);

@@ -43,7 +43,7 @@ public:
 private:
     dbuf<float4> top_nodes_, bot_nodes_, leaf_tris_, inst_, inst_fwd_, flat_nodes_, flat_leaves_;
     dbuf<uint4> tri_data_, node_info_;
-    dbuf<ctl_material> mats_; dbuf<ctl_light> lights_; dbuf<unsigned char> anim_; dbuf<uint32_t> texels_; dbuf<ctl_mipmap> images_; dbuf<float> rt_data_, rt_reduced_; dbuf<ctl_rough_transmittance> rt_;
+    dbuf<ctl_material> mats_; dbuf<ctl_light> lights_; dbuf<unsigned char> anim_; dbuf<uint32_t> texels_; dbuf<ctl_mipmap> images_; dbuf<dev_mip_levels> mip_levels_; dbuf<float> mip_lut_; dbuf<float> rt_data_, rt_reduced_; dbuf<ctl_rough_transmittance> rt_;
 };
 
 // Engine/Image.h:31-91 (accumulator part)

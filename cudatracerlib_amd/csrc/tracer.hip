@@ -77,22 +77,45 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
     for (auto& m : dmats) m.reserved_[0] = m.reserved_[1] = 0;
     if (d.n_lights_buf) lights_.upload(d.lights, d.n_lights_buf); else lights_.alloc(1);
     if (d.n_anim_bytes) anim_.upload(d.anim, d.n_anim_bytes); else anim_.alloc(16);
-    // KernelMIPMap level 0 of every image: one texel pool + a table of descriptors with device pointers
+    // KernelMIPMap of every image: one texel pool (level 0, then the pyramid MIPMap::CompileToBinary builds, Engine/MIPMap.cpp:41-95: nLevels = 1 + log2(min(w, h)),
+    // level i = the 2x2 box average of level i-1, decoded, averaged and re-encoded) + a table of level-0 descriptors with device pointers + the level offsets
     {
-        size_t total = 0;
-        for (uint32_t i = 0; i < d.n_images; i++) total += (size_t)d.images[i].width * d.images[i].height;
-        std::vector<uint32_t> pool; pool.reserve(total);
+        std::vector<uint32_t> pool;
         std::vector<size_t> off(d.n_images);
+        std::vector<dev_mip_levels> lv(std::max<uint32_t>(1, d.n_images));
+        auto decode = [](uint32_t v, uint32_t type, float c[3]) {
+            const uint32_t x = v & 0xff, y = (v >> 8) & 0xff, z = (v >> 16) & 0xff, w = v >> 24;
+            if (type == CTL_TEXEL_RGBE) { if (!w) { c[0] = c[1] = c[2] = 0; return; } const float e = std::ldexp(1.0f, (int)w - (128 + 8)); c[0] = x * e; c[1] = y * e; c[2] = z * e; }
+            else { c[0] = float(x) / 255.0f; c[1] = float(y) / 255.0f; c[2] = float(z) / 255.0f; }
+        };
         for (uint32_t i = 0; i < d.n_images; i++) {
             const ctl_mipmap& m = d.images[i];
             if (!m.texels || !m.width || !m.height) throw std::runtime_error("ctl_scene_create: empty image");
             off[i] = pool.size(); pool.insert(pool.end(), m.texels, m.texels + (size_t)m.width * m.height);
+            dev_mip_levels& L = lv[i]; std::memset(&L, 0, sizeof(L)); L.levels = 1;
+            for (uint32_t mn = std::min(m.width, m.height); (mn >>= 1) && L.levels < 16;) L.levels++;
+            uint32_t o = m.width * m.height, pw = m.width; size_t prev = off[i];
+            for (uint32_t l = 1, j = m.width / 2, k = m.height / 2; l < L.levels; l++, j >>= 1, k >>= 1) {
+                L.offsets[l - 1] = o; pool.resize(off[i] + o + (size_t)j * k);
+                for (uint32_t t = 0; t < k; t++) for (uint32_t x = 0; x < j; x++) {
+                    float a[3], b[3], c[3], e[3];
+                    decode(pool[prev + (size_t)(2 * t) * pw + 2 * x], m.texel_type, a); decode(pool[prev + (size_t)(2 * t) * pw + 2 * x + 1], m.texel_type, b);
+                    decode(pool[prev + (size_t)(2 * t + 1) * pw + 2 * x], m.texel_type, c); decode(pool[prev + (size_t)(2 * t + 1) * pw + 2 * x + 1], m.texel_type, e);
+                    float v[3]; for (int q = 0; q < 3; q++) { float s2 = a[q] + b[q]; s2 = s2 + c[q]; s2 = s2 + e[q]; v[q] = 0.25f * s2; }
+                    pool[off[i] + o + (size_t)t * j + x] = m.texel_type == CTL_TEXEL_RGBE ? float3_to_rgbe(v[0], v[1], v[2]) : float3_to_rgbcol(v[0], v[1], v[2]);
+                }
+                prev = off[i] + o; pw = j; o += j * k;
+            }
         }
-        if (total) texels_.upload(pool.data(), pool.size()); else texels_.alloc(4);
+        if (!pool.empty()) texels_.upload(pool.data(), pool.size()); else texels_.alloc(4);
         std::vector<ctl_mipmap> tab(d.n_images);
         for (uint32_t i = 0; i < d.n_images; i++) { tab[i] = d.images[i]; tab[i].texels = texels_.p + off[i]; }
         if (d.n_images) images_.upload(tab.data(), tab.size()); else images_.alloc(1);
-        S.images = images_.p;
+        mip_levels_.upload(lv.data(), lv.size());
+        float lut[64];   // MIPMap.cpp:87-92
+        for (int i = 0; i < 64; i++) { const float r2 = (float)i / (float)(64 - 1); lut[i] = std::exp(-2.0f * r2) - std::exp(-2.0f); }
+        mip_lut_.upload(lut, 64);
+        S.images = images_.p; S.mip_levels = mip_levels_.p; S.mip_weight_lut = mip_lut_.p;
     }
     // RoughTransmittanceManager's tables (roughplastic): one float pool + 3 descriptors with device pointers
     S.rough_transmittance = nullptr;
@@ -282,6 +305,15 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
     mat_inverse(c2s, S.cam.s2c);
     std::memcpy(S.cam.to_world, c.to_world, 48);
     S.cam.inv_res[0] = 1.0f / c.resolution[0]; S.cam.inv_res[1] = 1.0f / c.resolution[1];
+    {   // m_dx, m_dy (Sensor.cu:86-89): sampleToCamera(1/w, 0, 0) - sampleToCamera(0), projective TransformPoint
+        auto tp = [&](float x, float y, float out[3]) {
+            float r[4];
+            for (int i = 0; i < 4; i++) { float s2 = 0.0f; s2 += S.cam.s2c[i * 4] * x; s2 += S.cam.s2c[i * 4 + 1] * y; s2 += S.cam.s2c[i * 4 + 2] * 0.0f; s2 += S.cam.s2c[i * 4 + 3] * 1.0f; r[i] = s2; }
+            out[0] = r[0] / r[3]; out[1] = r[1] / r[3]; out[2] = r[2] / r[3];
+        };
+        float p0[3], px[3], py[3]; tp(0, 0, p0); tp(S.cam.inv_res[0], 0, px); tp(0, S.cam.inv_res[1], py);
+        for (int k = 0; k < 3; k++) { S.cam.dx[k] = px[k] - p0[k]; S.cam.dy[k] = py[k] - p0[k]; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ Image

@@ -43,6 +43,10 @@ def load():
     o.orc_render.argtypes = [C.c_void_p, u32, u32, u32, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, u32, u32, C.c_int]
     o.orc_intersect.argtypes = [C.c_void_p, C.c_void_p, u32, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     o.orc_set_flat_bvh.argtypes = [C.c_void_p]; o.orc_set_flat_bvh.restype = None
+    o.orc_compute_partials.argtypes = [C.c_void_p] * 8
+    o.orc_sensor_sample_ray_differential.argtypes = [C.c_void_p, f32, f32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    o.orc_mip_eval.argtypes = [C.c_void_p, f32, f32, C.c_void_p, C.c_void_p, C.c_void_p]
+    o.orc_mip_pyramid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u32]; o.orc_mip_pyramid.restype = u32
     o.orc_render_counting.argtypes = [C.c_int]; o.orc_render_counting.restype = None
     o.orc_render_counts.argtypes = [C.c_void_p]; o.orc_render_counts.restype = None
     o.orc_fresnel_dielectric_ext.restype = f32; o.orc_fresnel_dielectric_ext.argtypes = [f32, f32, C.c_void_p]
@@ -98,6 +102,9 @@ def load_ref():
     r.ref_woop_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p]
     r.ref_construct_bvh.argtypes = [C.c_void_p, C.c_void_p, u32, u32, C.c_void_p, C.c_void_p]
     r.ref_construct_bvh_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    if hasattr(r, "ref_compute_partials"):
+        r.ref_compute_partials.argtypes = [C.c_void_p] * 9
+        r.ref_sensor_sample_ray_differential.argtypes = [C.c_void_p, f32, f32, f32, C.c_int, C.c_int, f32, f32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return r
 
 
@@ -122,10 +129,11 @@ class Oracle:
         return hits
 
     def render(self, desc, width, height, n_passes=1, tables=None, direct=True, max_path_length=8, rr_start=5, threads=8, rows=None, half_host_quirk=False, alpha_test=False, block_counts=None,
-               flat=None, counts=None):
+               flat=None, counts=None, partials=False):
         """pathKernel2<DIRECT,false> over all pixels (Integrators/PathTracer.cu:182-194). tables = list of (t1, t2) per pass or None.
         alpha_test: traceRay<USE_ALPHA> when the scene has alpha maps (what the reference's single-ray path does; its wavefront
         intersectKernel has no alpha test).
+        partials: first-hit ray differentials + filtered (trilinear / EWA) texture lookups, as the megakernel PathTracer does (PathTracer.cu:60-61).
         flat: a ctl_flat_bvh_desc -> every ray walks the product's flattened BVH (same hits, other visiting order).
         counts: a dict that receives the traversal statistics of this render (path_rays, path_inner, path_tri, path_inst, occ_rays, ...).
         Returns (pixel_data (h, w, 7), rays)."""
@@ -146,7 +154,7 @@ class Oracle:
             self.lib.orc_render_counting(1)
         try:
             rays = self.lib.orc_render(C.addressof(desc), width, height, n_passes, p1, p2, 1 if direct else 0, max_path_length, rr_start,
-                                       img.ctypes.data, threads, y0, y1, (1 if half_host_quirk else 0) | (2 if alpha_test else 0))
+                                       img.ctypes.data, threads, y0, y1, (1 if half_host_quirk else 0) | (2 if alpha_test else 0) | (4 if partials else 0))
         finally:
             self.lib.orc_set_flat_bvh(None)
             if counts is not None:

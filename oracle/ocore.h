@@ -123,6 +123,7 @@ struct Scene {
     bool half_host_quirk = false;   // reproduce half::ToFloat's host branch (Math/half.h:76-83)
     bool alpha_test = false;        // KernelDynamicScene::doAlphaMapping (DynamicScene.cpp:586): traceRay<USE_ALPHA = true>
     const ctl_flat_bvh_desc* flat = nullptr;   // when set, traceRay walks the product's flattened BVH (the arrays ctl_flat_bvh_build hands out)
+    const struct MipPyramid* pyramids = nullptr;   // one per image (built by the caller) when first-hit ray differentials are on
 };
 inline bool sceneHasAlphaMaps(const ctl_scene_desc& d) {   // MaterialBuffer::hasAlphaMappings
     for (uint32_t i = 0; i < d.n_materials; i++) if (d.materials[i].alpha_state != CTL_ALPHA_DISABLED) return true;
@@ -267,6 +268,9 @@ struct DG {   // Engine/DifferentialGeometry.h:11-47
     const ctl_mipmap* images = nullptr;   // g_SceneData.m_sTexData (ImageTexture::getTexture, Texture.cu:39-42)
     const ctl_rough_transmittance* rough_transmittance = nullptr;   // RoughTransmittanceManager's three tables (RoughTransmittance.cu:121-131)
     const ctl_material* materials = nullptr;   // g_SceneData.m_sMatData: nested BSDFs of coating / roughcoating / blend are entries of it
+    // ray differentials of the first hit (DifferentialGeometry::computePartials; PathTracer.cu:60-61 — the wavefront tracer never computes them)
+    bool hasUVPartials = false; float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
+    const struct MipPyramid* pyramids = nullptr;   // one per image: the levels behind level 0 (KernelMIPMap::m_sOffsets)
 };
 // Engine/TriangleData.cu:22-32 + 34-65
 inline void triDataSetUV(ctl_triangle_data& T, V2 a, V2 b, V2 c) {
@@ -375,6 +379,116 @@ inline Spec mipFetch(const ctl_mipmap& M, int x, int y) {
     return texelDecode(M.texels[(size_t)y * M.width + x], M.texel_type);
 }
 
+// ---- the levels behind level 0 and the filtered lookup of a first hit with ray differentials
+// SpectrumConverter::Float3ToCOLORREF / Float3ToRGBE (Math/Spectrum.h:521-555)
+inline uint32_t float3ToRGBCOL(Spec c) {
+    auto q = [](float x) { return (uint32_t)(uint8_t)(clampf(x, 0.0f, 1.0f) * 255.0f); };
+    return q(c.x) | (q(c.y) << 8) | (q(c.z) << 16) | (255u << 24);
+}
+inline uint32_t float3ToRGBE(Spec c) {
+    float mx = fmax2(c.x, fmax2(c.y, c.z));
+    if (mx < 1e-32) return 0;
+    int e; mx = (float)std::frexp((double)mx, &e) * 256.0f / mx;
+    return (uint32_t)(uint8_t)(c.x * mx) | ((uint32_t)(uint8_t)(c.y * mx) << 8) | ((uint32_t)(uint8_t)(c.z * mx) << 16) | ((uint32_t)(uint8_t)(e + 128) << 24);
+}
+// MIPMap::CompileToBinary (Engine/MIPMap.cpp:41-95): nLevels = 1 + log2(min(w, h)); level i = the 2x2 box average of level i-1, decoded, averaged and re-encoded
+struct MipPyramid {
+    std::vector<uint32_t> texels; uint32_t levels = 1; uint32_t offsets[16] = {};
+    void build(const ctl_mipmap& M) {
+        texels.assign(M.texels, M.texels + (size_t)M.width * M.height);
+        uint32_t mn = M.width < M.height ? M.width : M.height; levels = 1; while ((mn >>= 1) && levels < 16) levels++;
+        offsets[0] = 0;
+        uint32_t off = M.width * M.height, pw = M.width;
+        size_t prev = 0;
+        for (uint32_t i = 1, j = M.width / 2, k = M.height / 2; i < levels; i++, j >>= 1, k >>= 1) {
+            offsets[i] = off; texels.resize((size_t)off + (size_t)j * k);
+            for (uint32_t t = 0; t < k; t++) for (uint32_t x = 0; x < j; x++) {
+                auto ld = [&](uint32_t xx, uint32_t yy) { return texelDecode(texels[prev + (size_t)yy * pw + xx], M.texel_type); };
+                Spec v = 0.25f * (ld(2 * x, 2 * t) + ld(2 * x + 1, 2 * t) + ld(2 * x, 2 * t + 1) + ld(2 * x + 1, 2 * t + 1));
+                texels[(size_t)off + (size_t)t * j + x] = M.texel_type == CTL_TEXEL_RGBE ? float3ToRGBE(v) : float3ToRGBCOL(v);
+            }
+            prev = off; pw = j; off += j * k;
+        }
+    }
+};
+inline const float* mipWeightLut() {   // MIPMap.cpp:87-92, MTS_MIPMAP_LUT_SIZE = 64
+    static float lut[64]; static bool init = false;
+    if (!init) { for (int i = 0; i < 64; i++) { float r2 = (float)i / (float)(64 - 1); lut[i] = expf(-2.0f * r2) - expf(-2.0f); } init = true; }
+    return lut;
+}
+// KernelMIPMap::Texel(level, uv) (MIPMap.cu:21-44)
+inline Spec mipTexelL(const ctl_mipmap& M, const MipPyramid& P, uint32_t level, V2 uv) {
+    const int wl = (int)(M.width >> level), hl = (int)(M.height >> level);
+    V2 l;
+    if (!wrapCoordinates(uv, V2{ (float)wl, (float)hl }, M.wrap_mode, l)) return Spec(0.0f);
+    int x = clampi((int)l.x, 0, wl - 1), y = clampi((int)l.y, 0, hl - 1);
+    return texelDecode(P.texels[(size_t)P.offsets[level] + (size_t)y * wl + x], M.texel_type);
+}
+// KernelMIPMap::triangle(level, uv) (MIPMap.cu:46-57)
+inline Spec mipTriangleL(const ctl_mipmap& M, const MipPyramid& P, uint32_t level, V2 uv) {
+    level = level > P.levels - 1 ? P.levels - 1 : level;
+    V2 s{ (float)(M.width >> level), (float)(M.height >> level) }, is{ 1.0f / s.x, 1.0f / s.y };
+    float ds = fracf(uv.x * s.x), dt = fracf(uv.y * s.y);
+    return ((1.f - ds) * (1.f - dt)) * mipTexelL(M, P, level, uv) + ((1.f - ds) * dt) * mipTexelL(M, P, level, V2{ uv.x + 0, uv.y + is.y }) +
+           (ds * (1.f - dt)) * mipTexelL(M, P, level, V2{ uv.x + is.x, uv.y + 0 }) + (ds * dt) * mipTexelL(M, P, level, V2{ uv.x + is.x, uv.y + is.y });
+}
+// KernelMIPMap::evalEWA (MIPMap.cu:59-114)
+inline Spec mipEvalEWA(const ctl_mipmap& M, const MipPyramid& P, uint32_t level, V2 uv, float A, float B, float C) {
+    if (level >= P.levels) return mipTexelL(M, P, P.levels - 1, V2{ 0, 0 });
+    V2 size{ (float)(M.width >> level), (float)(M.height >> level) };
+    float u = uv.x * size.x - 0.5f, v = uv.y * size.y - 0.5f;
+    V2 ratio{ size.x / (float)M.width, size.y / (float)M.height };
+    A /= ratio.x * ratio.x; B /= ratio.x * ratio.y; C /= ratio.y * ratio.y;
+    float invDet = 1.0f / (-B * B + 4.0f * A * C), deltaU = 2.0f * sqrtf(C * invDet), deltaV = 2.0f * sqrtf(A * invDet);
+    int u0 = (int)ceilf(u - deltaU), u1 = (int)floorf(u + deltaU), v0 = (int)ceilf(v - deltaV), v1 = (int)floorf(v + deltaV);
+    float As = A * 64, Bs = B * 64, Cs = C * 64;
+    Spec result(0.0f); float denominator = 0.0f, ddq = 2 * As, uu0 = u0 - u;
+    const float* lut = mipWeightLut();
+    for (int vt = v0; vt <= v1; ++vt) {
+        const float vv = vt - v;
+        float q = As * uu0 * uu0 + (Bs * uu0 + Cs * vv) * vv, dq = As * (2 * uu0 + 1) + Bs * vv;
+        for (int ut = u0; ut <= u1; ++ut) {
+            if (q < 64) { unsigned qi = (unsigned)q; if (qi < 64) { const float w = lut[(int)q]; result = result + mipTexelL(M, P, level, V2{ (float)ut / size.x, (float)vt / size.y }) * w; denominator += w; } }
+            q += dq; dq += ddq;
+        }
+    }
+    if (denominator == 0) return mipTriangleL(M, P, level, uv);
+    return result / denominator;
+}
+// KernelMIPMap::eval(uv, d0, d1) (MIPMap.cu:193-278)
+inline Spec mipEval(const ctl_mipmap& M, const MipPyramid& P, V2 uv, V2 d0, V2 d1) {
+    const float dimx = (float)M.width, dimy = (float)M.height;
+    float du0 = d0.x * dimx, dv0 = d0.y * dimy, du1 = d1.x * dimx, dv1 = d1.y * dimy, du = (du0 + du1) / 2.0f, dv = (dv0 + dv1) / 2.0f;
+    if (M.filter_mode == CTL_FILTER_POINT) return mipTexelL(M, P, 0, uv);
+    if (M.filter_mode == CTL_FILTER_BILINEAR) return mipTriangleL(M, P, 0, uv);
+    if (M.filter_mode == CTL_FILTER_TRILINEAR) {
+        float levela = log2f(dimx / fabsf(du)), levelb = log2f(dimy / fabsf(dv)), level = (float)P.levels - clampf((levela + levelb) / 2.0f, 1.0f, (float)P.levels);
+        int iLevel = (int)floorf(level), iLevel2 = clampi(iLevel + 1, 0, (int)P.levels - 1);
+        float p = level - iLevel;
+        return p * mipTriangleL(M, P, (uint32_t)iLevel, uv) + (1 - p) * mipTriangleL(M, P, (uint32_t)iLevel2, uv);
+    }
+    float A = dv0 * dv0 + dv1 * dv1, B = -2.0f * (du0 * dv0 + du1 * dv1), C = du0 * du0 + du1 * du1, F = A * C - B * B * 0.25f;
+    float root = sqrtf((A - C) * (A - C) + B * B), Aprime = 0.5f * (A + C - root), Cprime = 0.5f * (A + C + root);
+    float majorRadius = Aprime != 0 ? sqrtf(F / Aprime) : 0, minorRadius = Cprime != 0 ? sqrtf(F / Cprime) : 0;
+    if (!(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
+        float level = log2f(fmax2(majorRadius, 1e-4f)); int ilevel = (int)floorf(level);
+        if (ilevel < 0) return mipTriangleL(M, P, 0, uv);
+        float a = level - ilevel;
+        return mipTriangleL(M, P, (uint32_t)ilevel, uv) * (1.0f - a) + mipTriangleL(M, P, (uint32_t)(ilevel + 1), uv) * a;
+    }
+    const float maxAnisotropy = 16;
+    if (minorRadius * maxAnisotropy < majorRadius) {
+        minorRadius = majorRadius / maxAnisotropy;
+        float theta = 0.5f * atanf(B / (A - C)), sinTheta = sinf(theta), cosTheta = cosf(theta);
+        float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius, sinTheta2 = sinTheta * sinTheta, cosTheta2 = cosTheta * cosTheta, sin2Theta = 2 * sinTheta * cosTheta;
+        A = a2 * cosTheta2 + b2 * sinTheta2; B = (a2 - b2) * sin2Theta; C = a2 * sinTheta2 + b2 * cosTheta2; F = a2 * b2;
+    }
+    float scale = 1.0f / F; A *= scale; B *= scale; C *= scale;
+    float level = fmax2(0.0f, log2f(minorRadius)); int ilevel = (int)level; float a = level - ilevel;
+    if (majorRadius < 1 || !(A > 0 && C > 0)) return mipTriangleL(M, P, (uint32_t)ilevel, uv);
+    return mipEvalEWA(M, P, (uint32_t)ilevel, uv, A, B, C) * (1.0f - a) + mipEvalEWA(M, P, (uint32_t)(ilevel + 1), uv, A, B, C) * a;
+}
+
 // --------------------------------------------------------------------------- textures (SceneTypes/Texture.h: constant, checkerboard, image)
 inline Spec texEval(const ctl_texture& t, const DG& dg) {
     if (t.type == CTL_TEX_CHECKER) {
@@ -386,6 +500,11 @@ inline Spec texEval(const ctl_texture& t, const DG& dg) {
     if (t.type == CTL_TEX_IMAGE) {   // ImageTexture::Evaluate(dg) without uv partials -> Evaluate(uv) (Texture.cu:6-29)
         if (t.image == 0xffffffffu || dg.images == nullptr) return Spec(0.0f);
         V2 uv{ t.uv_scale[0] * dg.uv.x + 0 * dg.uv.y + t.uv_offset[0], 0 * dg.uv.x + t.uv_scale[1] * dg.uv.y + t.uv_offset[1] };   // TextureMapping2D::TransformPoint (Texture.h:34-41)
+        if (dg.hasUVPartials && dg.pyramids) {   // Texture.cu:15-29: mapping.differentiate (Texture.h:52-59, m12 = m21 = 0) -> KernelMIPMap::eval
+            const float dsdx = t.uv_scale[0] * dg.dudx + 0 * dg.dvdx, dsdy = t.uv_scale[0] * dg.dudy + 0 * dg.dvdy;
+            const float dtdx = 0 * dg.dudx + t.uv_scale[1] * dg.dvdx, dtdy = 0 * dg.dudy + t.uv_scale[1] * dg.dvdy;
+            return mipEval(dg.images[t.image], dg.pyramids[t.image], uv, V2{ dsdx, dtdx }, V2{ dsdy, dtdy }) * Spec(t.value[0], t.value[1], t.value[2]);
+        }
         return mipSample(dg.images[t.image], uv) * Spec(t.value[0], t.value[1], t.value[2]);
     }
     return Spec(t.value[0], t.value[1], t.value[2]);
@@ -508,6 +627,13 @@ struct PerspectiveSensor {
         V3 dn = normalize(nearP);
         o = transformPoint(toWorld, V3(0.0f));   // toWorld.Translation() (float4x4.h:93-96)
         d = transformDir(toWorld, dn);
+    }
+    // Sensor.cu:130-144
+    void sampleRayDifferential(V2 pixelSample, V3& o, V3& d, V3& dX, V3& dY) const {
+        V3 nearP = transformPoint(sampleToCamera, V3(pixelSample.x * invRes.x, pixelSample.y * invRes.y, 0.0f));
+        o = transformPoint(toWorld, V3(0.0f));
+        d = transformDir(toWorld, normalize(nearP));
+        dX = transformDir(toWorld, normalize(nearP + dx)); dY = transformDir(toWorld, normalize(nearP + dy));
     }
 };
 
@@ -1037,6 +1163,7 @@ inline uint32_t hitLightIndex(const Scene& S, const Hit& h) {        // TraceRes
 // TraceResult.cu:11-43.  wi is taken in the frame BEFORE the normal / height map perturbs it, as the reference does (:30-34)
 inline void getBsdfSample(const Scene& S, const Hit& h, V3 rayO, V3 rayD, BRec& bRec) {
     bRec.eta = 1.0f; bRec.sampledType = 0; bRec.typeMask = EAll;
+    bRec.dg.hasUVPartials = false;      // TraceResult::fillDG (Kernel/TraceResult.cu:13-21)
     bRec.dg.P = rayO + rayD * h.dist;   // Ray::operator()(t) (Math/Ray.h)
     fillDG(S, V2{ h.u, h.v }, h.tri, h.node, bRec.dg);
     bRec.wi = bRec.dg.sys.toLocal(-rayD);
@@ -1080,7 +1207,36 @@ inline Spec uniformSampleOneLight(const Scene& S, const BRec& bRec, const ctl_ma
 }
 
 // --------------------------------------------------------------------------- PathTrace<DIRECT> (Integrators/PathTracer.cu:10-113), no volumes
-inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, int maxPathLength, int rrStartDepth, uint64_t* rays) {
+// DifferentialGeometry::computePartials (Engine/DifferentialGeometry.cu:9-90); the three rays share their origin
+inline void computePartials(DG& dg, V3 ro, V3 rxd, V3 ryd) {
+    dg.hasUVPartials = true;
+    if (dot(dg.dpdu, dg.dpdu) == 0 && dot(dg.dpdv, dg.dpdv) == 0) { dg.dudx = dg.dvdx = dg.dudy = dg.dvdy = 0.0f; return; }
+    const float pp = dot(dg.n, dg.P), pox = dot(dg.n, ro), poy = dot(dg.n, ro), prx = dot(dg.n, rxd), pry = dot(dg.n, ryd);
+    if (prx == 0 || pry == 0) { dg.dudx = dg.dvdx = dg.dudy = dg.dvdy = 0.0f; return; }
+    const float tx = (pp - pox) / prx, ty = (pp - poy) / pry;
+    const float absX = fabsf(dg.n.x), absY = fabsf(dg.n.y), absZ = fabsf(dg.n.z);
+    int axes[2];
+    if (absX > absY && absX > absZ) { axes[0] = 1; axes[1] = 2; } else if (absY > absZ) { axes[0] = 0; axes[1] = 2; } else { axes[0] = 0; axes[1] = 1; }
+    const float dpduA[3] = { dg.dpdu.x, dg.dpdu.y, dg.dpdu.z }, dpdvA[3] = { dg.dpdv.x, dg.dpdv.y, dg.dpdv.z };
+    const float A[2][2] = { { dpduA[axes[0]], dpdvA[axes[0]] }, { dpduA[axes[1]], dpdvA[axes[1]] } };
+    const V3 px = ro + rxd * tx, py = ro + ryd * ty;
+    const float pA[3] = { dg.P.x, dg.P.y, dg.P.z }, pxA[3] = { px.x, px.y, px.z }, pyA[3] = { py.x, py.y, py.z };
+    const float Bx[2] = { pxA[axes[0]] - pA[axes[0]], pxA[axes[1]] - pA[axes[1]] }, By[2] = { pyA[axes[0]] - pA[axes[0]], pyA[axes[1]] - pA[axes[1]] };
+    auto solve = [&](const float b[2], float x[2]) {   // AlgebraHelper::solveLinearSystem2x2 (Math/AlgebraHelper.h:11-24), RCPOVERFLOW = 2.93873587705571876e-39f
+        const float det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+        if (fabsf(det) <= 2.93873587705571876e-39f) return false;
+        const float inverse = 1.0f / det;
+        x[0] = (A[1][1] * b[0] - A[0][1] * b[1]) * inverse; x[1] = (A[0][0] * b[1] - A[1][0] * b[0]) * inverse;
+        return true;
+    };
+    float x[2];
+    if (solve(Bx, x)) { dg.dudx = x[0]; dg.dvdx = x[1]; } else { dg.dudx = 1; dg.dvdx = 0; }
+    if (solve(By, x)) { dg.dudy = x[0]; dg.dvdy = x[1]; } else { dg.dudy = 0; dg.dvdy = 1; }
+}
+
+// rxd / ryd: directions of the sensor's differential rays (sampleRayDifferential); non-null = the megakernel integrator's first-hit texture filtering
+// (PathTracer.cu:60-61), null = no partials (what the wavefront tracer does)
+inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, int maxPathLength, int rrStartDepth, uint64_t* rays, const V3* rxd = nullptr, const V3* ryd = nullptr) {
     Spec cl(0.0f), cf(1.0f);
     int depth = 0; bool specularBounce = false;
     BRec bRec; Hit r2; r2.init();
@@ -1090,6 +1246,7 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
         if (rays) (*rays)++;
         if (r2.hasHit()) {
             getBsdfSample(S, r2, ro, rd, bRec);
+            if (depth == 1 && rxd && S.pyramids) { bRec.dg.pyramids = S.pyramids; computePartials(bRec.dg, ro, *rxd, *ryd); }
             const ctl_material& mat = hitMat(S, r2);
             uint32_t li = hitLightIndex(S, r2);
             if (li != UINT32_MAX) {

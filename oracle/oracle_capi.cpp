@@ -116,6 +116,30 @@ void orc_intersect(const ctl_scene_desc* desc, const ctl_ray* rays, uint32_t n, 
     if (counts) { counts->n_inner = counts->n_tri = counts->n_inst = 0; for (auto& c : tc) { counts->n_inner += c.n_inner; counts->n_tri += c.n_tri; counts->n_inst += c.n_inst; } }
 }
 
+// ---- first-hit ray differentials and filtered texture lookup (probes for the tests)
+// levels and offsets of the pyramid of an image, and the pyramid's texels (caller: n_texels_cap words); returns the number of texels
+uint32_t orc_mip_pyramid(const ctl_mipmap* M, uint32_t* levels_out, uint32_t* offsets16_out, uint32_t* texels_out, uint32_t cap) {
+    MipPyramid P; P.build(*M);
+    *levels_out = P.levels; std::memcpy(offsets16_out, P.offsets, 64);
+    if (texels_out) std::memcpy(texels_out, P.texels.data(), 4 * std::min<size_t>(cap, P.texels.size()));
+    return (uint32_t)P.texels.size();
+}
+void orc_mip_eval(const ctl_mipmap* M, float u, float v, const float* d0, const float* d1, float* rgb) {
+    MipPyramid P; P.build(*M);
+    const Spec s = mipEval(*M, P, V2{ u, v }, V2{ d0[0], d0[1] }, V2{ d1[0], d1[1] });
+    rgb[0] = s.x; rgb[1] = s.y; rgb[2] = s.z;
+}
+// in: P, n, dpdu, dpdv (3 floats each), ray origin, directions of the x / y differential rays; out: dudx, dudy, dvdx, dvdy
+void orc_compute_partials(const float* P, const float* n, const float* dpdu, const float* dpdv, const float* ro, const float* rxd, const float* ryd, float* out4) {
+    DG dg; dg.P = V3(P[0], P[1], P[2]); dg.n = V3(n[0], n[1], n[2]); dg.dpdu = V3(dpdu[0], dpdu[1], dpdu[2]); dg.dpdv = V3(dpdv[0], dpdv[1], dpdv[2]);
+    computePartials(dg, V3(ro[0], ro[1], ro[2]), V3(rxd[0], rxd[1], rxd[2]), V3(ryd[0], ryd[1], ryd[2]));
+    out4[0] = dg.dudx; out4[1] = dg.dudy; out4[2] = dg.dvdx; out4[3] = dg.dvdy;
+}
+void orc_sensor_sample_ray_differential(const ctl_sensor* s, float px, float py, float* o, float* d, float* dX, float* dY) {
+    PerspectiveSensor ps; ps.update(*s); V3 O, D, X, Y; ps.sampleRayDifferential(V2{ px, py }, O, D, X, Y);
+    o[0] = O.x; o[1] = O.y; o[2] = O.z; d[0] = D.x; d[1] = D.y; d[2] = D.z; dX[0] = X.x; dX[1] = X.y; dX[2] = X.z; dY[0] = Y.x; dY[1] = Y.y; dY[2] = Y.z;
+}
+
 // ---- BSDF / light probes --------------------------------------------------------------------------------------
 // tables used by the BSDF probes below (roughplastic); the pointer must stay valid
 static const ctl_rough_transmittance* g_probe_rt = nullptr;
@@ -198,9 +222,13 @@ void orc_render_counts(uint64_t* out8) { for (int i = 0; i < 8; i++) { out8[i] =
 // Renders rows [y0,y1) only (bounded CPU-baseline samples).  Returns the number of rays traced.
 uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t n_passes, const float* tables1, const float* tables2,
                     int direct, int maxPathLength, int rrStart, ctl_pixel_data* img, int n_threads, uint32_t y0, uint32_t y1, int half_host_quirk) {
-    // half_host_quirk: bit 0 = half::ToFloat host branch, bit 1 = alpha test on (doAlphaMapping: every traceRay, incl. Occluded)
+    // half_host_quirk: bit 0 = half::ToFloat host branch, bit 1 = alpha test on (doAlphaMapping: every traceRay, incl. Occluded),
+    // bit 2 = first-hit ray differentials and filtered texture lookups (what the megakernel PathTracer does, PathTracer.cu:60-61; the wavefront tracer does not)
     Scene S; S.d = *desc; S.half_host_quirk = (half_host_quirk & 1) != 0; S.alpha_test = (half_host_quirk & 2) != 0 && sceneHasAlphaMaps(*desc); S.flat = g_flat;
     PerspectiveSensor sensor; sensor.update(desc->camera);
+    std::vector<MipPyramid> pyramids;
+    const bool partials = (half_host_quirk & 4) != 0;
+    if (partials) { pyramids.resize(desc->n_images); for (uint32_t i = 0; i < desc->n_images; i++) pyramids[i].build(desc->images[i]); S.pyramids = pyramids.data(); }
     if (n_threads < 1) n_threads = 1;
     if (y1 > H) y1 = H;
     SequenceGenerator gen;
@@ -241,8 +269,9 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
                     V2 j = rng.randomFloat2();
                     V2 pX{ (float)x + j.x, (float)y + j.y };
                     V2 ap = rng.randomFloat2(); (void)ap;
-                    V3 o, d; sensor.sampleRay(pX, o, d);
-                    Spec col = pathTrace(S, direct != 0, o, d, rng, maxPathLength, rrStart, &rays);   // imp == 1 (Sensor.cu:127)
+                    V3 o, d, dX, dY;
+                    if (partials) sensor.sampleRayDifferential(pX, o, d, dX, dY); else sensor.sampleRay(pX, o, d);
+                    Spec col = pathTrace(S, direct != 0, o, d, rng, maxPathLength, rrStart, &rays, partials ? &dX : nullptr, partials ? &dY : nullptr);   // imp == 1 (Sensor.cu:127)
                     addSample(img, (int)W, (int)H, pX.x, pX.y, col);
                 }
             }

@@ -107,6 +107,27 @@ void ref_sensor_sample_ray(const float* to_world, float fov_rad, float nearD, fl
     o[0] = r.ori().x; o[1] = r.ori().y; o[2] = r.ori().z; d[0] = r.dir().x; d[1] = r.dir().y; d[2] = r.dir().z;
 }
 
+// DifferentialGeometry::computePartials (Engine/DifferentialGeometry.cu:9-90).  out = dudx, dudy, dvdx, dvdy
+void ref_compute_partials(const float* P, const float* n, const float* dpdu, const float* dpdv, const float* ro, const float* rd, const float* rxd, const float* ryd, float* out4) {
+    DifferentialGeometry dg;
+    dg.P = Vec3f(P[0], P[1], P[2]); dg.n = NormalizedT<Vec3f>(Vec3f(n[0], n[1], n[2])); dg.dpdu = Vec3f(dpdu[0], dpdu[1], dpdu[2]); dg.dpdv = Vec3f(dpdv[0], dpdv[1], dpdv[2]);
+    const Vec3f o(ro[0], ro[1], ro[2]);
+    dg.computePartials(Ray(o, Vec3f(rd[0], rd[1], rd[2])), Ray(o, Vec3f(rxd[0], rxd[1], rxd[2])), Ray(o, Vec3f(ryd[0], ryd[1], ryd[2])));
+    out4[0] = dg.dudx; out4[1] = dg.dudy; out4[2] = dg.dvdx; out4[3] = dg.dvdy;
+}
+// PerspectiveSensor::sampleRayDifferential (SceneTypes/Sensor.cu:130-144)
+void ref_sensor_sample_ray_differential(const float* to_world, float fov_rad, float nearD, float farD, int w, int h, float px, float py, float* o, float* d, float* dX, float* dY) {
+    PerspectiveSensor s(w, h, 90.0f);
+    s.SetNearFarDepth(nearD, farD);
+    s.fov = fov_rad;
+    NormalizedT<OrthogonalAffineMap> m; std::memcpy(m.data, to_world, 64);
+    s.SetToWorld(m);
+    NormalizedT<Ray> r, rx, ry;
+    s.sampleRayDifferential(r, rx, ry, Vec2f(px, py), Vec2f(0.0f));
+    o[0] = r.ori().x; o[1] = r.ori().y; o[2] = r.ori().z; d[0] = r.dir().x; d[1] = r.dir().y; d[2] = r.dir().z;
+    dX[0] = rx.dir().x; dX[1] = rx.dir().y; dX[2] = rx.dir().z; dY[0] = ry.dir().x; dY[1] = ry.dir().y; dY[2] = ry.dir().z;
+}
+
 // ConstructBVH (Engine/MeshLoader/BVHBuilderHelper.cpp:116-127): SBVH with max leaf size 8.
 // Two-call protocol: first with NULL outputs to get the counts, then with buffers.
 static BVH_Construction_Result g_last;

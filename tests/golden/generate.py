@@ -144,5 +144,33 @@ def main():
     print("golden fixtures written to", HERE)
 
 
+    # ---- first-hit ray differentials (added in round 2; own random stream, so that the fixtures above stay byte-identical):
+    #      PerspectiveSensor::sampleRayDifferential (SceneTypes/Sensor.cu:130-144) and DifferentialGeometry::computePartials (Engine/DifferentialGeometry.cu:9-90)
+    rs2 = np.random.RandomState(20260930)
+    n = 256
+    px = np.zeros((n, 2), np.float32); par = np.zeros((n, 5), np.float32); tw = np.zeros((n, 16), np.float32); rays = np.zeros((n, 12), np.float32)
+    dgs = np.zeros((n, 12), np.float32); parts = np.zeros((n, 4), np.float32)
+    for i in range(n):
+        w, h = int(rs2.choice([64, 256, 1920])), int(rs2.choice([64, 256, 1080]))
+        fov = np.float32(np.radians(rs2.uniform(20, 100)))
+        q, _ = np.linalg.qr(rs2.normal(size=(3, 3)))
+        m = np.eye(4, dtype=np.float32); m[:3, :3] = q; m[:3, 3] = rs2.normal(size=3) * 20
+        tw[i] = m.reshape(16); par[i] = [fov, 1e-2, 1e4, w, h]
+        p = (rs2.uniform(0, 1, size=2) * [w, h]).astype(np.float32); px[i] = p
+        r.ref_sensor_sample_ray_differential(tw[i].ctypes.data, f32(fov), f32(1e-2), f32(1e4), w, h, f32(p[0]), f32(p[1]),
+                                             rays[i, 0:3].ctypes.data, rays[i, 3:6].ctypes.data, rays[i, 6:9].ctypes.data, rays[i, 9:12].ctypes.data)
+        # a surface point in front of the camera with a random frame; every 16th case is degenerate (zero dpdu / dpdv, or a normal at right angles to a differential ray)
+        t = rs2.uniform(1, 50)
+        P = (rays[i, 0:3] + t * rays[i, 3:6]).astype(np.float32)
+        nrm = rs2.normal(size=3); nrm = (nrm / np.linalg.norm(nrm)).astype(np.float32)
+        dpdu = (rs2.normal(size=3) * rs2.uniform(0.01, 10)).astype(np.float32); dpdv = (rs2.normal(size=3) * rs2.uniform(0.01, 10)).astype(np.float32)
+        if i % 16 == 5: dpdu[:] = 0; dpdv[:] = 0
+        if i % 16 == 9: dpdv = (dpdu * np.float32(2)).astype(np.float32)          # singular 2x2 system
+        if i % 16 == 13: nrm = np.array([1, 0, 0], np.float32); rays[i, 6:9] = [0, 1, 0]   # n . rx.dir == 0
+        dgs[i] = np.concatenate([P, nrm, dpdu, dpdv])
+        r.ref_compute_partials(dgs[i, 0:3].ctypes.data, dgs[i, 3:6].ctypes.data, dgs[i, 6:9].ctypes.data, dgs[i, 9:12].ctypes.data,
+                               rays[i, 0:3].ctypes.data, rays[i, 3:6].ctypes.data, rays[i, 6:9].ctypes.data, rays[i, 9:12].ctypes.data, parts[i].ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "partials.npz"), to_world=tw, params=par, pixel=px, rays=rays, dg=dgs, partials=parts)
+
 if __name__ == "__main__":
     main()

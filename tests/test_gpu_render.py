@@ -134,7 +134,7 @@ def test_megakernel_path_tracer_plugin(gpu, orc, scene_kw):
     sc = scenes.cornell_box(64, 64, **scene_kw)
     d = sc.desc
     tables = orc.sequence_tables(3)
-    want, _ = orc.render(d, 64, 64, n_passes=3, tables=tables, max_path_length=8)
+    want, _ = orc.render(d, 64, 64, n_passes=3, tables=tables, max_path_length=8, partials=True)
     scene = gpu.Scene(d, flatten=True)
     out = {}
     for cls in (gpu.PathTracer, gpu.WavefrontPathTracer):
@@ -191,7 +191,8 @@ def test_material_maps(gpu, orc, surface_map, alpha):
         assert abs(g.mean() - wv.mean()) <= 1e-3 * wv.mean()
     close_flat(_render(gpu, gpu.WavefrontPathTracer, flat, tables, w, h, AlphaTest=True), want_on)
     close_flat(_render(gpu, gpu.WavefrontPathTracer, flat, tables, w, h), want_off)
-    close_flat(_render(gpu, gpu.PathTracer, flat, tables, w, h), want_on)
+    want_mega, _ = orc.render(d, w, h, n_passes=2, tables=tables, max_path_length=5, alpha_test=True, partials=True)   # the megakernel integrator: first-hit ray differentials
+    close_flat(_render(gpu, gpu.PathTracer, flat, tables, w, h), want_mega)
 
 
 def test_image_pipeline_filters_and_tonemap(gpu):
@@ -372,3 +373,42 @@ def test_tracer_parameter_kinds(gpu):
             p.setValue(*bad)
     with pytest.raises(gpu.CtlError):
         p.getFloat("MaxPathLength")
+
+
+@pytest.mark.parametrize("filter_mode", ["anisotropic", "trilinear"])
+def test_first_hit_ray_differentials_and_filtered_textures(gpu, orc, filter_mode):
+    """PathTrace computes uv partials at depth 1 (Integrators/PathTracer.cu:60-61, DifferentialGeometry::computePartials) and ImageTexture::Evaluate(dg)
+    then filters through the mip pyramid — EWA for the default TEXTURE_Anisotropic, two bilinear taps for TEXTURE_Trilinear (Texture.cu:15-29,
+    MIPMap.cu:193-278); the wavefront tracer never computes partials and reads level 0.  A noise-textured ground plane seen at a grazing angle:
+    the PathTracer plugin equals the oracle with partials, the wavefront plugin equals the oracle without, and the two differ on the textured first hits."""
+    from cudatracerlib_amd import api
+    w, h = 96, 64
+    sc = api.DynamicScene()
+    rs = np.random.RandomState(4)
+    tex = rs.uniform(0.05, 0.95, size=(64, 64, 3)).astype(np.float32)
+    tex[::2, ::2] *= 0.2                                                  # high-frequency content: minification changes the mean seen through a pixel
+    fm = api.FILTER_ANISOTROPIC if filter_mode == "anisotropic" else api.FILTER_TRILINEAR
+    img = sc.add_image(api.float3_to_rgbcol(tex), api.TEXEL_RGBCOL, api.WRAP_REPEAT, fm)
+    P = np.array([[-40, 0, -40], [-40, 0, 40], [40, 0, 40], [40, 0, -40]], np.float32)
+    uv = np.array([[0, 0], [0, 12], [12, 12], [12, 0]], np.float32)
+    ground = api.diffuse((1, 1, 1)); ground.tex[0] = api.image_texture(img)
+    sc.CreateNode(sc.add_mesh(P, np.array([[0, 1, 2], [0, 2, 3]], np.uint32), normals=np.tile(np.array([0, 1, 0], np.float32), (4, 1)), uvs=uv, materials=[ground]))
+    L = np.array([[-6, 12, -6], [6, 12, -6], [6, 12, 6], [-6, 12, 6]], np.float32)
+    ln = sc.CreateNode(sc.add_mesh(L, np.array([[0, 1, 2], [0, 2, 3]], np.uint32), normals=np.tile(np.array([0, -1, 0], np.float32), (4, 1)), materials=[api.diffuse((0.5, 0.5, 0.5))]))
+    sc.CreateLight(ln, 0, (30.0, 30.0, 30.0))
+    sc.setCamera((0, 1.5, -30), (0, 0.5, 0), (0, 1, 0), 50.0, w, h)
+    d = sc.UpdateScene()
+    tables = orc.sequence_tables(2)
+    want_plain, _ = orc.render(d, w, h, n_passes=2, tables=tables, max_path_length=3)
+    want_filtered, _ = orc.render(d, w, h, n_passes=2, tables=tables, max_path_length=3, partials=True)
+    scene = gpu.Scene(d, flatten=True)
+    mega = _render(gpu, gpu.PathTracer, scene, tables, w, h, max_len=3)
+    wave = _render(gpu, gpu.WavefrontPathTracer, scene, tables, w, h, max_len=3)
+
+    def frac_close(a, b):
+        return (np.abs(a[..., :3] - b[..., :3]) <= 2e-3 * (1 + np.abs(b[..., :3]))).all(axis=2).mean()
+    assert np.array_equal(mega[..., 6], want_filtered[..., 6]) and np.array_equal(wave[..., 6], want_plain[..., 6])
+    assert frac_close(wave, want_plain) >= 0.995
+    assert frac_close(mega, want_filtered) >= 0.99, frac_close(mega, want_filtered)
+    assert abs(mega[..., :3].mean() - want_filtered[..., :3].mean()) <= 2e-3 * want_filtered[..., :3].mean()
+    assert frac_close(mega, want_plain) < 0.9 and frac_close(want_filtered, want_plain) < 0.9          # the filtering is visible: the distant ground differs
