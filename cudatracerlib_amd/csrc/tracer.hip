@@ -485,6 +485,8 @@ WavefrontPathTracer::WavefrontPathTracer() {
     // Off by default: measured on the synthetic-bathroom workload it LOSES (shade 9.1 -> 11.5 ms / pass) — the time goes into the spline
     // lookups of the rough plastics, not into divergence, and the sorted order turns the path-state reads into gathers
     m_sParameters.addBool("SortMaterials", false);
+    // build-specific: the full shade kernel regroups the paths of each workgroup by BSDF model before shading them (shade_kernel.inc)
+    m_sParameters.addBool("BlockSort", true);
     // build-specific: the rays a shade workgroup emits are appended grouped by direction octant (compaction.h block_append3_keyed).
     // Off by default: measured on synthetic-SM the traversal kernels gain 1 % (6.10 -> 6.05 ms / pass) and the shade kernel pays 0.5 ms for it
     m_sParameters.addBool("SortOctants", false);
@@ -555,6 +557,7 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     P.width = w; P.height = h; P.tile_rank = shard_rank; P.tile_world = shard_world; P.n_local_pixels = n_local_pixels;
     P.direct = direct ? 1 : 0; P.max_path_length = maxPathLength; P.rr_start_depth = rrStart;
     P.sort_materials = (m_sParameters.getValue("SortMaterials") != 0 && S.shade_features != 0) ? 1 : 0;
+    P.block_sort = m_sParameters.getValue("BlockSort") != 0 ? 1 : 0;
     P.sort_octants = m_sParameters.getValue("SortOctants") != 0 ? 1 : 0;
     P.block_counts = pass_block_counts_; P.max_block_count = pass_max_block_count_;
     if (pass_block_counts_ && pass_paths_ > capacity) throw std::runtime_error("ray queue overflow: the block sampler asks for more samples in one pass than the queues hold (DoubleRayBuffer.h:86-89)");

@@ -143,3 +143,50 @@ def test_loader_fed_frame_equals_the_builder_fed_frame(gpu, orc, tmp_path):
     assert rays_a == rays_b and rays_a > 2 * W * H
     assert np.array_equal(a[..., 6], b[..., 6])
     assert np.allclose(a[..., :3], b[..., :3], rtol=1e-5, atol=1e-5)
+
+
+def test_bathroom_workload_at_full_size(gpu, orc):
+    """synthetic-bathroom (the stand-in for BASELINE config 5: rough plastic / conductor / dielectric, coating, textures, height map, environment
+    emitter) at 1920x1080, depth 8, through the full shade kernel:
+      * two bands of rows rendered by the oracle equal the same rows of the GPU frame (per pixel where paths are short, band mean at full depth);
+      * the workgroup-local regrouping of the shade kernel (BlockSort) and the device-wide material sort only reorder work: same frame, same rays;
+      * 2 x (1 pass) accumulates to the same sums as 2 passes; the megakernel plugin renders the same frame."""
+    gpu.api.set_cache_dir(os.environ.get("CTL_CACHE_DIR") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "ctl_amd_cache"))
+    sc = scenes.synthetic_bathroom(W, H)
+    d = sc.desc
+    flat = gpu.Scene(d, flatten=True)
+    gpu.api.set_cache_dir(None)
+    tables = orc.sequence_tables(2)
+    bands = (531, 1040)                                               # spheres and back wall; the textured, height-mapped floor
+    for depth, frac, mean_tol in ((2, 0.995, 1e-3), (DEPTH, 0.95, 1e-2)):
+        tr = gpu.WavefrontPathTracer(); tr.getParameters().setValue("MaxPathLength", depth)
+        tr.Resize(W, H); tr.InitializeScene(flat)
+        img = gpu.Image(W, H)
+        for k in range(2):
+            tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
+        got = img.getPixelData()
+        assert np.isfinite(got[..., :3]).all() and (got[..., :3] >= 0).all()
+        for y0 in bands:
+            want = orc.render(d, W, H, n_passes=2, tables=tables, max_path_length=depth, rows=(y0, y0 + 8), threads=os.cpu_count() or 8)[0]
+            g, w = got[y0 + 1:y0 + 7, :, :3], want[y0 + 1:y0 + 7, :, :3]
+            same_n = got[y0 + 1:y0 + 7, :, 6] == want[y0 + 1:y0 + 7, :, 6]
+            assert same_n.mean() >= 0.999
+            g, w = g[same_n][None], w[same_n][None]
+            ok = (np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2)
+            assert ok.mean() >= frac, (depth, y0, ok.mean())
+            assert abs(g.mean() - w.mean()) <= mean_tol * w.mean(), (depth, y0, g.mean(), w.mean())
+    base, rays = render(gpu, gpu.WavefrontPathTracer, flat, tables)
+    assert rays > 4 * W * H
+    for params in (dict(BlockSort=False), dict(SortMaterials=True)):
+        other, rays_o = render(gpu, gpu.WavefrontPathTracer, flat, tables, **params)
+        assert rays_o == rays
+        assert np.array_equal(other[..., 6], base[..., 6])
+        assert np.allclose(other[..., :3], base[..., :3], rtol=1e-5, atol=1e-5)
+    a, rays_a = render(gpu, gpu.WavefrontPathTracer, flat, tables, passes=[0])
+    b, rays_b = render(gpu, gpu.WavefrontPathTracer, flat, tables, passes=[1])
+    assert rays_a + rays_b == rays
+    assert np.allclose(a[..., :3] + b[..., :3], base[..., :3], rtol=1e-5, atol=1e-5)
+    mega, rays_mega = render(gpu, gpu.PathTracer, flat, tables)
+    assert abs(int(rays_mega) - int(rays)) <= 1e-3 * rays
+    close = np.isclose(mega[..., :3], base[..., :3], rtol=1e-3, atol=1e-3).all(axis=2)
+    assert close.mean() >= 0.995 and abs(mega[..., :3].mean() - base[..., :3].mean()) <= 1e-3 * base[..., :3].mean()
