@@ -219,3 +219,37 @@ def test_fresnel_diffuse_reflectance_matches_reference_values():
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "math.npz"))
     for eta, want in zip(z["fdr_eta"], z["fdr_value"]):
         assert api.fresnel_diffuse_reflectance(float(eta)) == pytest.approx(float(want), rel=2e-5)
+
+
+def test_rough_transmittance_lookup_interpolates_its_table(lib):
+    """RoughTransmittance::Evaluate / EvaluateDiffuse (RoughTransmittance.cu:55-119) cannot be pinned on the reference (Spline.cu does not build
+    outside nvcc).  What the restatement is held to instead: the cubic interpolant reproduces the table at its knots — the knots sit at
+    t^4 of a uniform grid in (cos theta, alpha, eta), the warp the lookup undoes — and stays within the hull of the neighbouring knots' values plus
+    the Catmull-Rom overshoot bound between them."""
+    keep, tabs = lib._keep
+    for slot in (0, 1):
+        tr = keep[2 * slot]; df = keep[2 * slot + 1]; t = tabs[slot]
+        n_eta, n_alpha, n_theta = t.eta_samples, t.alpha_samples, t.theta_samples
+        w = lambda n: (np.linspace(0, 1, n, dtype=np.float64) ** 4)
+        etas = t.eta_min + (t.eta_max - t.eta_min) * w(n_eta); alphas = t.alpha_min + (t.alpha_max - t.alpha_min) * w(n_alpha); mus = w(n_theta)
+        worst = 0.0
+        for i in range(1, n_eta):
+            for j in range(1, n_alpha):
+                for k in range(1, n_theta):
+                    got = lib.orc_rough_transmittance_eval(slot, float(mus[k]), float(alphas[j]), float(etas[i]))
+                    worst = max(worst, abs(got - min(1.0, max(0.0, float(tr[i, j, k])))))
+                    got_in = lib.orc_rough_transmittance_eval(slot, -float(mus[k]), float(alphas[j]), float(etas[i]))    # from inside: the 1 / eta block
+                    worst = max(worst, abs(got_in - min(1.0, max(0.0, float(tr[n_eta + i, j, k])))))
+                gd = lib.orc_rough_transmittance_eval_diffuse(slot, float(alphas[j]), float(etas[i]))
+                worst = max(worst, abs(gd - min(1.0, max(0.0, float(df[i, j])))))
+        assert worst <= 2e-4, worst                                   # the knot positions go through powf(x, 0.25) in fp32
+        # between knots: bounded by the surrounding values (+ 12.5 % of their spread per axis for a Catmull-Rom segment)
+        rs = np.random.RandomState(5 + slot)
+        for _ in range(200):
+            i, j, k = rs.randint(1, n_eta - 1), rs.randint(1, n_alpha - 1), rs.randint(1, n_theta - 1)
+            f = rs.uniform(0, 1, 3)
+            wm = ((k + f[0]) / (n_theta - 1)) ** 4; wa = ((j + f[1]) / (n_alpha - 1)) ** 4; we = ((i + f[2]) / (n_eta - 1)) ** 4
+            got = lib.orc_rough_transmittance_eval(slot, float(wm), float(t.alpha_min + (t.alpha_max - t.alpha_min) * wa), float(t.eta_min + (t.eta_max - t.eta_min) * we))
+            nb = tr[max(i - 1, 0):i + 3, max(j - 1, 0):j + 3, max(k - 1, 0):k + 3]
+            spread = float(nb.max() - nb.min())
+            assert nb.min() - 0.4 * spread - 1e-4 <= got <= min(1.0, nb.max() + 0.4 * spread) + 1e-4
