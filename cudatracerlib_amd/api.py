@@ -491,6 +491,19 @@ def blend(index0, nested0, index1, nested1, weight=0.5):
 
 
 # ---------------------------------------------------------------- DynamicScene (Engine/DynamicScene.h:70-187, loader-facing subset)
+def decode_image_file(path):
+    """ctl_decode_image_file: (H, W, 3) float32 for HDR / PFM / EXR files, (H, W, 4) uint8 otherwise; rows top-down"""
+    w, h, fl = u32(0), u32(0), i32(0)
+    _check(lib.ctl_decode_image_file(path.encode(), C.byref(w), C.byref(h), C.byref(fl), None, None))
+    if fl.value:
+        out = np.zeros((h.value, w.value, 3), np.float32)
+        _check(lib.ctl_decode_image_file(path.encode(), C.byref(w), C.byref(h), C.byref(fl), out.ctypes.data_as(C.POINTER(C.c_float)), None))
+    else:
+        out = np.zeros((h.value, w.value, 4), np.uint8)
+        _check(lib.ctl_decode_image_file(path.encode(), C.byref(w), C.byref(h), C.byref(fl), None, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out
+
+
 class DynamicScene:
     def __init__(self):
         self._h = C.c_void_p()

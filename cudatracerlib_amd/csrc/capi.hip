@@ -5,6 +5,7 @@
 #include "scene_builder.h"
 #include "mitsuba_loader.h"
 #include "flatten.h"
+#include "image_io.h"
 #include <memory>
 #include "scene_cache.h"
 #include <cstdlib>
@@ -136,6 +137,15 @@ void ctl_flat_bvh_destroy(ctl_flat_bvh* h) { delete h; }
 int ctl_parse_mitsuba_scene(ctl_builder* b, const char* xml_path, int32_t* width_inout, int32_t* height_inout) {
     CTL_REQUIRE(b && xml_path, "null argument");
     CTL_TRY parse_mitsuba_scene(b->b, xml_path, width_inout, height_inout); CTL_CATCH
+}
+int ctl_decode_image_file(const char* path, uint32_t* width, uint32_t* height, int32_t* is_float, float* rgb, uint8_t* rgba8) {
+    CTL_REQUIRE(path && width && height && is_float, "null argument");
+    CTL_TRY
+        const decoded_image img = load_image_file(path);
+        *width = img.width; *height = img.height; *is_float = img.is_float ? 1 : 0;
+        if (img.is_float && rgb) std::memcpy(rgb, img.rgb.data(), img.rgb.size() * sizeof(float));
+        if (!img.is_float && rgba8) std::memcpy(rgba8, img.rgba8.data(), img.rgba8.size());
+    CTL_CATCH
 }
 
 // ---- sampler

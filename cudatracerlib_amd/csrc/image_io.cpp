@@ -204,16 +204,130 @@ static decoded_image decode_hdr(const std::vector<uint8_t>& d, const std::string
     return img;
 }
 
+// ------------------------------------------------------------------------------------------------ OpenEXR
+// Single-part scanline files (OpenEXR file layout: magic, version, attribute list, chunk offset table, chunks of 1 / 16 scanlines), channels
+// R, G, B (or Y alone) of type HALF, FLOAT or UINT with 1:1 sampling, compression NONE, RLE, ZIPS or ZIP.  Tiled, multi-part and deep files and
+// the PIZ / PXR24 / B44 / DWA codecs are rejected with a message naming what was found.
+static float half_bits_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31, m = h & 1023;
+    uint32_t bits;
+    if (e == 0) {
+        if (m == 0) bits = sign;
+        else { int sh = 0; uint32_t mm = m; while (!(mm & 1024)) { mm <<= 1; sh++; } bits = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 1023) << 13); }
+    } else if (e == 31) bits = sign | 0x7f800000u | (m << 13);
+    else bits = sign | ((e + 112) << 23) | (m << 13);
+    float f; std::memcpy(&f, &bits, 4); return f;
+}
+static void exr_unpredict_and_interleave(std::vector<uint8_t>& buf, std::vector<uint8_t>& tmp) {
+    // the writer splits the bytes of a block into even / odd halves and stores differences + 128 (ImfZip.cpp / ImfRle.cpp)
+    for (size_t i = 1; i < buf.size(); i++) buf[i] = (uint8_t)(buf[i - 1] + buf[i] - 128);
+    tmp.resize(buf.size());
+    const size_t half = (buf.size() + 1) / 2;
+    for (size_t i = 0; i < buf.size(); i++) tmp[i] = (i & 1) ? buf[half + i / 2] : buf[i / 2];
+    buf.swap(tmp);
+}
+static decoded_image decode_exr(const std::vector<uint8_t>& d, const std::string& path) {
+    if (d.size() < 8 || le32(&d[0]) != 20000630u) throw io_error("not an OpenEXR file : " + path);
+    const uint32_t version = le32(&d[4]);
+    if ((version & 0xff) != 2) throw unsupported_error("OpenEXR file format version " + std::to_string(version & 0xff) + " : " + path);
+    if (version & 0x200) throw unsupported_error("tiled OpenEXR files are not read (re-save as scanline) : " + path);
+    if (version & 0x1800) throw unsupported_error("multi-part / deep OpenEXR files are not read : " + path);
+    struct channel { std::string name; int type; int xs, ys; size_t offset_in_line; };
+    std::vector<channel> chans; int compression = -1, line_order = 0; int dw[4] = { 0, 0, -1, -1 }; bool have_dw = false;
+    size_t p = 8;
+    auto cstr = [&](size_t limit) { std::string t; while (p < d.size() && d[p] && t.size() < limit) t += (char)d[p++]; if (p >= d.size() || d[p]) throw io_error("corrupt OpenEXR header : " + path); p++; return t; };
+    for (;;) {
+        if (p >= d.size()) throw io_error("truncated OpenEXR header : " + path);
+        if (d[p] == 0) { p++; break; }
+        const std::string name = cstr(255), type = cstr(255);
+        if (p + 4 > d.size()) throw io_error("truncated OpenEXR header : " + path);
+        const uint32_t size = le32(&d[p]); p += 4;
+        if (p + size > d.size()) throw io_error("truncated OpenEXR header : " + path);
+        const size_t a = p; p += size;
+        if (name == "channels" && type == "chlist") {
+            size_t q = a;
+            while (q < a + size && d[q]) {
+                channel c; while (q < a + size && d[q]) c.name += (char)d[q++]; q++;
+                if (q + 16 > a + size) throw io_error("corrupt OpenEXR channel list : " + path);
+                c.type = (int)le32(&d[q]); c.xs = (int)le32(&d[q + 8]); c.ys = (int)le32(&d[q + 12]); c.offset_in_line = 0; q += 16;
+                chans.push_back(c);
+            }
+        } else if (name == "compression" && size >= 1) compression = d[a];
+        else if (name == "dataWindow" && size >= 16) { for (int k = 0; k < 4; k++) dw[k] = (int)le32(&d[a + 4 * k]); have_dw = true; }
+        else if (name == "lineOrder" && size >= 1) line_order = d[a];
+    }
+    if (chans.empty() || !have_dw || compression < 0) throw io_error("OpenEXR header lacks channels / dataWindow / compression : " + path);
+    static const char* kCodec[] = { "NONE", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB" };
+    if (compression > 3) throw unsupported_error(std::string("OpenEXR compression ") + (compression < 10 ? kCodec[compression] : "?") + " is not read (NONE, RLE, ZIPS and ZIP are; re-save with one of them) : " + path);
+    const long w = (long)dw[2] - dw[0] + 1, h = (long)dw[3] - dw[1] + 1;
+    if (w <= 0 || h <= 0 || w > 65536 || h > 65536) throw io_error("corrupt OpenEXR dataWindow : " + path);
+    size_t line_bytes = 0; int idx[3] = { -1, -1, -1 }, lum = -1;
+    for (size_t k = 0; k < chans.size(); k++) {
+        channel& c = chans[k];
+        if (c.xs != 1 || c.ys != 1) throw unsupported_error("sub-sampled OpenEXR channel " + c.name + " : " + path);
+        if (c.type < 0 || c.type > 2) throw io_error("corrupt OpenEXR channel type : " + path);
+        c.offset_in_line = line_bytes; line_bytes += (size_t)w * (c.type == 1 ? 2 : 4);
+        if (c.name == "R") idx[0] = (int)k; else if (c.name == "G") idx[1] = (int)k; else if (c.name == "B") idx[2] = (int)k; else if (c.name == "Y") lum = (int)k;
+    }
+    if (idx[0] < 0 || idx[1] < 0 || idx[2] < 0) { if (lum < 0) throw unsupported_error("OpenEXR file without R, G, B or Y channels : " + path); idx[0] = idx[1] = idx[2] = lum; }
+    const int lines_per_block = compression == 3 ? 16 : 1;
+    const size_t n_blocks = (size_t)(h + lines_per_block - 1) / lines_per_block;
+    if (p + 8 * n_blocks > d.size()) throw io_error("truncated OpenEXR offset table : " + path);
+    decoded_image img; img.width = (uint32_t)w; img.height = (uint32_t)h; img.is_float = true; img.rgb.assign((size_t)w * h * 3, 0.0f);
+    std::vector<uint8_t> buf, tmp;
+    for (size_t b = 0; b < n_blocks; b++) {
+        uint64_t off = 0; for (int k = 7; k >= 0; k--) off = (off << 8) | d[p + 8 * b + k];
+        if (off + 8 > d.size()) throw io_error("truncated OpenEXR (chunk offset) : " + path);
+        const long y0 = (long)(int)le32(&d[off]) - dw[1]; const uint32_t size = le32(&d[off + 4]);
+        if (y0 < 0 || y0 >= h || off + 8 + size > d.size()) throw io_error("corrupt OpenEXR chunk : " + path);
+        const long lines = std::min<long>(lines_per_block, h - y0);
+        const size_t raw = line_bytes * (size_t)lines;
+        const uint8_t* src = &d[off + 8];
+        if (size == raw || compression == 0) { if (size < raw) throw io_error("corrupt OpenEXR chunk : " + path); buf.assign(src, src + raw); }   // stored: the codec did not shrink it
+        else if (compression == 1) {
+            buf.clear(); buf.reserve(raw);
+            for (size_t q = 0; q < size;) {
+                const int n = (int8_t)src[q++];
+                if (n < 0) { if (q + (size_t)-n > size) throw io_error("corrupt OpenEXR RLE data : " + path); buf.insert(buf.end(), src + q, src + q - n); q += (size_t)-n; }
+                else { if (q >= size) throw io_error("corrupt OpenEXR RLE data : " + path); buf.insert(buf.end(), (size_t)n + 1, src[q++]); }
+                if (buf.size() > raw) throw io_error("corrupt OpenEXR RLE data : " + path);
+            }
+            if (buf.size() != raw) throw io_error("corrupt OpenEXR RLE data : " + path);
+            exr_unpredict_and_interleave(buf, tmp);
+        } else {
+            buf.resize(raw); uLongf got = (uLongf)raw;
+            if (uncompress(buf.data(), &got, src, size) != Z_OK || got != raw) throw io_error("corrupt OpenEXR ZIP data : " + path);
+            exr_unpredict_and_interleave(buf, tmp);
+        }
+        for (long l = 0; l < lines; l++) {
+            const uint8_t* line = &buf[line_bytes * (size_t)l];
+            float* o = &img.rgb[(size_t)(y0 + l) * w * 3];
+            for (int c = 0; c < 3; c++) {
+                const channel& ch = chans[idx[c]]; const uint8_t* s = line + ch.offset_in_line;
+                for (long x = 0; x < w; x++) {
+                    float v;
+                    if (ch.type == 1) v = half_bits_to_float(le16(s + 2 * x));
+                    else if (ch.type == 2) { const uint32_t u = le32(s + 4 * x); std::memcpy(&v, &u, 4); }
+                    else v = (float)le32(s + 4 * x);
+                    o[x * 3 + c] = v;
+                }
+            }
+        }
+    }
+    (void)line_order;   // every chunk names its own y: increasing, decreasing and random order read the same way
+    return img;
+}
+
 decoded_image load_image_file(const std::string& path) {
     const std::string ext = lower_ext(path);
     if (ext == "jpg" || ext == "jpeg" || ext == "jpe") return decode_jpeg(read_file(path), path);
-    if (ext == "exr") throw unsupported_error("OpenEXR decoding is not built in (convert to .hdr or .pfm) : " + path);
     const std::vector<uint8_t> d = read_file(path);
     if (ext == "png") return decode_png(d, path);
     if (ext == "bmp") return decode_bmp(d, path);
     if (ext == "tga") return decode_tga(d, path);
     if (ext == "ppm" || ext == "pgm" || ext == "pnm" || ext == "pfm") return decode_pnm(d, path);
     if (ext == "hdr" || ext == "rgbe" || ext == "pic") return decode_hdr(d, path);
+    if (ext == "exr") return decode_exr(d, path);
     throw unsupported_error("image format not supported : " + path);
 }
 

@@ -1,6 +1,7 @@
 // image_io.h — image file decoding / encoding for textures, environment maps and render output.
 // The reference goes through FreeImage (Engine/MIPMap.cu:542-592, Engine/Image.cpp:67-75), which is not vendored; this reads
-// PNG (zlib), baseline JPEG, BMP, TGA, PPM/PGM, PFM and Radiance HDR and writes PNG, HDR and PFM.  Progressive JPEG and OpenEXR are not built in.
+// PNG (zlib), JPEG (baseline, extended sequential and progressive Huffman), BMP, TGA, PPM/PGM, PFM, Radiance HDR and OpenEXR (single-part scanline files,
+// HALF / FLOAT / UINT channels, NONE / RLE / ZIPS / ZIP) and writes PNG, HDR and PFM.  PIZ and the lossy EXR codecs, tiled EXR and arithmetic-coded JPEG are rejected.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -17,7 +18,7 @@ struct decoded_image {
 
 // throws io_error (missing / corrupt file) or unsupported_error (format not built in)
 decoded_image load_image_file(const std::string& path);
-decoded_image decode_jpeg(const std::vector<uint8_t>& bytes, const std::string& path);   // jpeg_decode.cpp: baseline / extended-sequential Huffman JPEG
+decoded_image decode_jpeg(const std::vector<uint8_t>& bytes, const std::string& path);   // jpeg_decode.cpp: sequential and progressive Huffman JPEG
 
 // Level 0 of a KernelMIPMap as parseImage builds it (Engine/MIPMap.cu:565-586): FreeImage scanlines are bottom-up, so texel row 0
 // is the BOTTOM row of the picture; float images become RGBE (SpectrumConverter::Float3ToRGBE), others RGBCOL.

@@ -1,7 +1,8 @@
-// jpeg_decode.cpp — baseline / extended-sequential Huffman JPEG (ITU T.81, SOF0 / SOF1, 8-bit samples) for texture files.
-// The reference reads JPEG through FreeImage -> libjpeg; this decoder follows the standard's decoding procedure with a float
-// inverse DCT and libjpeg's default "fancy" (triangle) chroma up-sampling, so texels agree with libjpeg's to about one 8-bit step
-// (its integer IDCT rounds differently).  Progressive (SOF2), arithmetic-coded and 12-bit files are rejected with a message.
+// jpeg_decode.cpp — Huffman JPEG (ITU T.81; SOF0 baseline, SOF1 extended sequential, SOF2 progressive; 8-bit samples) for texture files.
+// The reference reads JPEG through FreeImage -> libjpeg; this decoder follows the standard's decoding procedures (F.2 sequential, G.1.2
+// progressive: spectral selection + successive approximation, any number of scans) into a coefficient buffer, then a float inverse DCT and
+// libjpeg's default "fancy" (triangle) chroma up-sampling, so texels agree with libjpeg's to about one 8-bit step (its integer IDCT rounds
+// differently).  Arithmetic-coded, lossless, hierarchical and 12-bit files are rejected with a message.
 #include "image_io.h"
 #include "mitsuba_loader.h"   // io_error / unsupported_error
 #include <cmath>
@@ -30,7 +31,14 @@ struct huff_table {   // canonical code tables of Annex C / F.2.2.3
     }
 };
 
-struct component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; int bw = 0, bh = 0; std::vector<uint8_t> plane; };
+struct component {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0;
+    int bw = 0, bh = 0;            // plane size in samples, padded to whole MCUs
+    int nbx = 0, nby = 0;          // blocks that carry picture (a non-interleaved scan codes exactly these, A.2.3)
+    std::vector<int16_t> coef;     // [block row][block column][64], natural order, not yet dequantised
+    std::vector<uint8_t> plane;
+    int16_t* block(int bx, int by) { return &coef[((size_t)by * (bw / 8) + bx) * 64]; }
+};
 
 struct bit_reader {
     const uint8_t* p; const uint8_t* end; uint32_t acc = 0; int n = 0; bool hit_marker = false;
@@ -73,20 +81,89 @@ void idct8x8(const float* in, uint8_t* out, int stride) {   // separable inverse
 
 uint16_t be16(const uint8_t* p) { return (uint16_t)((p[0] << 8) | p[1]); }
 
+// ---- per-block entropy decoding: F.2.2 (sequential) and G.1.2 (progressive)
+struct scan_params { int ss = 0, se = 63, ah = 0, al = 0; int eobrun = 0; bool progressive = false; };
+
+static void decode_block(bit_reader& br, component& c, int16_t* blk, scan_params& sp, const huff_table* dc, const huff_table* ac, const std::string& path) {
+    if (!sp.progressive) {   // DC difference + the 63 AC coefficients of one block
+        const int t = decode_symbol(br, dc[c.td], path);
+        if (t > 11) throw io_error("corrupt JPEG (DC size) : " + path);
+        c.pred += t ? extend(br.bits(t), t) : 0;
+        blk[0] = (int16_t)c.pred;
+        for (int k = 1; k < 64;) {
+            const int rs = decode_symbol(br, ac[c.ta], path), r = rs >> 4, sz = rs & 15;
+            if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+            k += r;
+            if (k > 63) throw io_error("corrupt JPEG (AC run) : " + path);
+            blk[kZigzag[k]] = (int16_t)extend(br.bits(sz), sz);
+            k++;
+        }
+        return;
+    }
+    if (sp.ss == 0) {        // DC scan: first pass codes the difference of the point-transformed value, a refinement pass one more bit (G.1.2.1)
+        if (sp.ah == 0) {
+            const int t = decode_symbol(br, dc[c.td], path);
+            if (t > 11) throw io_error("corrupt JPEG (DC size) : " + path);
+            c.pred += t ? extend(br.bits(t), t) : 0;
+            blk[0] = (int16_t)(c.pred * (1 << sp.al));
+        } else if (br.bit()) blk[0] = (int16_t)(blk[0] | (1 << sp.al));
+        return;
+    }
+    const int p1 = 1 << sp.al, m1 = -(1 << sp.al);
+    if (sp.ah == 0) {        // AC first pass of a band (G.1.2.2): run / size symbols plus end-of-band runs that span blocks
+        if (sp.eobrun > 0) { sp.eobrun--; return; }
+        for (int k = sp.ss; k <= sp.se; k++) {
+            const int rs = decode_symbol(br, ac[c.ta], path), r = rs >> 4, sz = rs & 15;
+            if (sz) {
+                k += r;
+                if (k > sp.se) throw io_error("corrupt JPEG (AC run) : " + path);
+                blk[kZigzag[k]] = (int16_t)(extend(br.bits(sz), sz) * p1);
+            } else if (r == 15) k += 15;
+            else { sp.eobrun = (1 << r) - 1 + (r ? br.bits(r) : 0); break; }
+        }
+        return;
+    }
+    // AC refinement pass (G.1.2.3): every coefficient that is already non-zero gets one correction bit as it is passed; zero-history
+    // coefficients are counted by the run lengths, and a newly non-zero coefficient is +-1 << Al
+    int k = sp.ss;
+    if (sp.eobrun == 0) {
+        for (; k <= sp.se; k++) {
+            const int rs = decode_symbol(br, ac[c.ta], path); int r = rs >> 4; const int sz = rs & 15; int value = 0;
+            if (sz) {
+                if (sz != 1) throw io_error("corrupt JPEG (refinement size) : " + path);
+                value = br.bit() ? p1 : m1;
+            } else if (r != 15) { sp.eobrun = (1 << r) + (r ? br.bits(r) : 0); break; }
+            for (; k <= sp.se; k++) {
+                int16_t& co = blk[kZigzag[k]];
+                if (co != 0) { if (br.bit() && (co & p1) == 0) co = (int16_t)(co + (co >= 0 ? p1 : m1)); }
+                else { if (r == 0) break; r--; }
+            }
+            if (value && k <= sp.se) blk[kZigzag[k]] = (int16_t)value;
+        }
+    }
+    if (sp.eobrun > 0) {
+        for (; k <= sp.se; k++) {
+            int16_t& co = blk[kZigzag[k]];
+            if (co != 0 && br.bit() && (co & p1) == 0) co = (int16_t)(co + (co >= 0 ? p1 : m1));
+        }
+        sp.eobrun--;
+    }
+}
+
 }  // namespace
 
 decoded_image decode_jpeg(const std::vector<uint8_t>& d, const std::string& path) {
     if (d.size() < 4 || d[0] != 0xff || d[1] != 0xd8) throw io_error("not a JPEG file : " + path);
     uint16_t qt[4][64] = {}; bool have_qt[4] = {};
     huff_table dc[4], ac[4];
-    std::vector<component> comps; int width = 0, height = 0, restart_interval = 0, adobe_transform = -1; bool have_frame = false;
+    std::vector<component> comps; int width = 0, height = 0, restart_interval = 0, adobe_transform = -1; bool have_frame = false, progressive = false;
+    int hmax = 1, vmax = 1, mcux = 0, mcuy = 0, n_scans = 0;
     size_t pos = 2;
-    const uint8_t* scan_begin = nullptr;
     while (pos + 4 <= d.size()) {
         if (d[pos] != 0xff) { pos++; continue; }
         const uint8_t m = d[pos + 1];
         if (m == 0xff) { pos++; continue; }
-        if (m == 0xd8 || (m >= 0xd0 && m <= 0xd7) || m == 0x01) { pos += 2; continue; }
+        if (m == 0xd8 || (m >= 0xd0 && m <= 0xd7) || m == 0x01 || m == 0x00) { pos += 2; continue; }
         if (m == 0xd9) break;
         const size_t len = be16(&d[pos + 2]);
         if (len < 2 || pos + 2 + len > d.size()) throw io_error("corrupt JPEG (segment length) : " + path);
@@ -108,70 +185,96 @@ decoded_image decode_jpeg(const std::vector<uint8_t>& d, const std::string& path
                 (tc ? ac : dc)[th].build(&s[i + 1], &s[i + 17]);
                 i += 17 + total;
             }
-        } else if (m == 0xc0 || m == 0xc1) {   // SOF0 / SOF1
+        } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {   // SOF0 / SOF1 / SOF2
+            if (have_frame) throw io_error("corrupt JPEG (two frame headers) : " + path);
             if (n < 6 || s[0] != 8) throw unsupported_error("JPEG with a sample precision other than 8 bits : " + path);
+            progressive = m == 0xc2;
             height = be16(&s[1]); width = be16(&s[3]);
             const int nc = s[5];
             if ((nc != 1 && nc != 3) || n < (size_t)(6 + 3 * nc) || width <= 0 || height <= 0) throw unsupported_error("JPEG with " + std::to_string(nc) + " components (only greyscale and YCbCr / RGB are read) : " + path);
             comps.resize(nc);
             for (int k = 0; k < nc; k++) { comps[k].id = s[6 + 3 * k]; comps[k].h = s[7 + 3 * k] >> 4; comps[k].v = s[7 + 3 * k] & 15; comps[k].tq = s[8 + 3 * k];
                 if (comps[k].h < 1 || comps[k].h > 4 || comps[k].v < 1 || comps[k].v > 4 || comps[k].tq > 3) throw io_error("corrupt JPEG (SOF) : " + path); }
+            for (auto& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+            mcux = (width + 8 * hmax - 1) / (8 * hmax); mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+            for (auto& c : comps) {
+                c.bw = mcux * c.h * 8; c.bh = mcuy * c.v * 8;
+                c.nbx = ((width * c.h + hmax - 1) / hmax + 7) / 8; c.nby = ((height * c.v + vmax - 1) / vmax + 7) / 8;
+                c.coef.assign((size_t)c.bw * c.bh, 0);
+            }
             have_frame = true;
-        } else if (m == 0xc2) throw unsupported_error("progressive JPEG is not read (re-save as baseline JPEG or PNG) : " + path);
-        else if (m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) throw unsupported_error("lossless / hierarchical / arithmetic-coded JPEG is not read : " + path);
+        } else if (m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) throw unsupported_error("lossless / hierarchical / arithmetic-coded JPEG is not read : " + path);
         else if (m == 0xdd) { if (n >= 2) restart_interval = be16(s); }
         else if (m == 0xee) { if (n >= 12 && !std::memcmp(s, "Adobe", 5)) adobe_transform = s[11]; }
-        else if (m == 0xda) {   // SOS
+        else if (m == 0xda) {   // SOS: scan header, then the entropy-coded segment up to the next marker that is not RSTn
             if (!have_frame) throw io_error("corrupt JPEG (scan before frame header) : " + path);
-            const int ns = s[0];
-            if (ns != (int)comps.size() || n < (size_t)(1 + 2 * ns + 3)) throw unsupported_error("JPEG with several scans is not read : " + path);
+            const int ns = n ? s[0] : 0;
+            if (ns < 1 || ns > (int)comps.size() || n < (size_t)(1 + 2 * ns + 3)) throw io_error("corrupt JPEG (SOS) : " + path);
+            std::vector<component*> in_scan;
             for (int k = 0; k < ns; k++) {
-                bool found = false;
-                for (auto& c : comps) if (c.id == s[1 + 2 * k]) { c.td = s[2 + 2 * k] >> 4; c.ta = s[2 + 2 * k] & 15; found = true; }
-                if (!found) throw io_error("corrupt JPEG (SOS component) : " + path);
+                component* found = nullptr;
+                for (auto& c : comps) if (c.id == s[1 + 2 * k]) { c.td = s[2 + 2 * k] >> 4; c.ta = s[2 + 2 * k] & 15; found = &c; }
+                if (!found || found->td > 3 || found->ta > 3) throw io_error("corrupt JPEG (SOS component) : " + path);
+                in_scan.push_back(found);
             }
-            scan_begin = &d[pos + 2 + len];
-            break;
+            scan_params sp; sp.progressive = progressive;
+            sp.ss = s[1 + 2 * ns]; sp.se = s[2 + 2 * ns]; sp.ah = s[3 + 2 * ns] >> 4; sp.al = s[3 + 2 * ns] & 15;
+            if (!progressive) { sp.ss = 0; sp.se = 63; sp.ah = sp.al = 0; }
+            else if (sp.ss > sp.se || sp.se > 63 || sp.al > 13 || (sp.ss == 0 && sp.se != 0) || (sp.ss > 0 && ns != 1)) throw io_error("corrupt JPEG (progressive scan parameters) : " + path);
+            for (component* c : in_scan) {
+                const bool need_dc = !progressive || (sp.ss == 0 && sp.ah == 0), need_ac = !progressive || sp.ss > 0;
+                if ((need_dc && !dc[c->td].present) || (need_ac && !ac[c->ta].present)) throw io_error("corrupt JPEG (missing table) : " + path);
+                c->pred = 0;
+            }
+            const uint8_t* scan_begin = &d[pos + 2 + len];
+            const uint8_t* scan_end = scan_begin;   // the next marker other than RSTn / a stuffed zero
+            while (scan_end + 1 < d.data() + d.size() && !(scan_end[0] == 0xff && scan_end[1] != 0 && scan_end[1] != 0xff && !(scan_end[1] >= 0xd0 && scan_end[1] <= 0xd7))) scan_end++;
+            if (scan_end + 1 >= d.data() + d.size()) scan_end = d.data() + d.size();
+            bit_reader br{ scan_begin, scan_end };
+            int to_restart = restart_interval;
+            auto maybe_restart = [&]() {
+                if (!restart_interval) return;
+                if (to_restart == 0) {   // RSTn: byte-align, skip the marker, reset the predictors and the end-of-band run
+                    const uint8_t* q = br.p;
+                    while (q + 1 < br.end && !(q[0] == 0xff && q[1] >= 0xd0 && q[1] <= 0xd7)) q++;
+                    if (q + 1 < br.end) br.p = q + 2;
+                    br.restart();
+                    for (component* c : in_scan) c->pred = 0;
+                    sp.eobrun = 0;
+                    to_restart = restart_interval;
+                }
+                to_restart--;
+            };
+            if (ns == 1) {   // non-interleaved: the component's own blocks in raster order, one block per MCU
+                component& c = *in_scan[0];
+                for (int by = 0; by < c.nby; by++)
+                    for (int bx = 0; bx < c.nbx; bx++) { maybe_restart(); decode_block(br, c, c.block(bx, by), sp, dc, ac, path); }
+            } else {
+                for (int my = 0; my < mcuy; my++)
+                    for (int mx = 0; mx < mcux; mx++) {
+                        maybe_restart();
+                        for (component* c : in_scan)
+                            for (int by = 0; by < c->v; by++)
+                                for (int bx = 0; bx < c->h; bx++) decode_block(br, *c, c->block(mx * c->h + bx, my * c->v + by), sp, dc, ac, path);
+                    }
+            }
+            n_scans++;
+            pos = (size_t)(scan_end - d.data());
+            continue;
         }
         pos += 2 + len;
     }
-    if (!scan_begin) throw io_error("corrupt JPEG (no scan) : " + path);
-    int hmax = 1, vmax = 1;
-    for (auto& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); if (!have_qt[c.tq] || c.td > 3 || c.ta > 3 || !dc[c.td].present || !ac[c.ta].present) throw io_error("corrupt JPEG (missing table) : " + path); }
-    const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
-    for (auto& c : comps) { c.bw = mcux * c.h * 8; c.bh = mcuy * c.v * 8; c.plane.assign((size_t)c.bw * c.bh, 128); }
-    bit_reader br{ scan_begin, d.data() + d.size() };
-    int to_restart = restart_interval;
-    for (int my = 0; my < mcuy; my++)
-        for (int mx = 0; mx < mcux; mx++) {
-            if (restart_interval && to_restart == 0) {   // RSTn: byte-align, skip the marker, reset the predictors
-                const uint8_t* q = br.p;
-                while (q + 1 < br.end && !(q[0] == 0xff && q[1] >= 0xd0 && q[1] <= 0xd7)) q++;
-                if (q + 1 < br.end) br.p = q + 2;
-                br.restart();
-                for (auto& c : comps) c.pred = 0;
-                to_restart = restart_interval;
+    if (!n_scans) throw io_error("corrupt JPEG (no scan) : " + path);
+    for (auto& c : comps) {   // dequantise + inverse DCT of every block
+        if (!have_qt[c.tq]) throw io_error("corrupt JPEG (missing table) : " + path);
+        c.plane.assign((size_t)c.bw * c.bh, 128);
+        for (int by = 0; by < c.bh / 8; by++)
+            for (int bx = 0; bx < c.bw / 8; bx++) {
+                const int16_t* co = c.block(bx, by); float blk[64];
+                for (int k = 0; k < 64; k++) blk[k] = (float)co[k] * qt[c.tq][k];
+                idct8x8(blk, &c.plane[(size_t)(by * 8) * c.bw + bx * 8], c.bw);
             }
-            for (auto& c : comps)
-                for (int by = 0; by < c.v; by++)
-                    for (int bx = 0; bx < c.h; bx++) {
-                        float blk[64] = {};
-                        const int t = decode_symbol(br, dc[c.td], path);
-                        if (t > 11) throw io_error("corrupt JPEG (DC size) : " + path);
-                        c.pred += t ? extend(br.bits(t), t) : 0;
-                        blk[0] = (float)c.pred * qt[c.tq][0];
-                        for (int k = 1; k < 64;) {
-                            const int rs = decode_symbol(br, ac[c.ta], path), r = rs >> 4, sz = rs & 15;
-                            if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
-                            k += r;
-                            if (k > 63) throw io_error("corrupt JPEG (AC run) : " + path);
-                            blk[kZigzag[k]] = (float)extend(br.bits(sz), sz) * qt[c.tq][kZigzag[k]];
-                            k++;
-                        }
-                        idct8x8(blk, &c.plane[(size_t)((my * c.v + by) * 8) * c.bw + (mx * c.h + bx) * 8], c.bw);
-                    }
-            if (restart_interval) to_restart--;
-        }
+    }
     // up-sample every component to full resolution: libjpeg's "fancy" triangle filters for 2:1, replication otherwise
     auto sample = [&](const component& c, int x, int y) -> float {
         const int sx = hmax / c.h, sy = vmax / c.v;

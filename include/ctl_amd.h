@@ -330,6 +330,10 @@ int ctl_flat_bvh_arrays(const ctl_flat_bvh* h, ctl_flat_bvh_desc* out);
 void ctl_flat_bvh_destroy(ctl_flat_bvh* h);
 /* ParseMitsubaScene (Engine/SceneLoader/Mitsuba/MitsubaLoader.h:13): fills a builder from a Mitsuba-0.5 XML file. */
 int ctl_parse_mitsuba_scene(ctl_builder* b, const char* xml_path, int32_t* width_inout, int32_t* height_inout);
+/* The bitmap reader behind the loader's textures and environment maps (the reference goes through FreeImage, Engine/MIPMap.cu:542-592): PNG, JPEG
+ * (sequential and progressive), BMP, TGA, PNM, PFM, Radiance HDR, OpenEXR (scanline; NONE / RLE / ZIPS / ZIP).  Rows top-down.  *is_float = 1: `rgb`
+ * receives 3 floats per pixel; 0: `rgba8` receives 4 bytes per pixel.  With both buffers NULL only the size and kind are returned. */
+int ctl_decode_image_file(const char* path, uint32_t* width, uint32_t* height, int32_t* is_float, float* rgb, uint8_t* rgba8);
 
 /* ------------------------------------------------------------------ sampler */
 /* SequenceSamplerData(4096, 30) (Kernel/Sampler_device.h:11-57). tables_1d[30*4096], tables_2d[30*4096*2]:

@@ -1,6 +1,8 @@
-"""Baseline JPEG decoding for bitmap textures (csrc/jpeg_decode.cpp; the reference reads JPEG through FreeImage / libjpeg).
-The files come from the encoder in tests/jpeg_encode.py; decoded texels are compared with the source picture (quantisation table of
-ones: only DCT rounding and, for sub-sampled chroma, the box-down / triangle-up filter pair separate them)."""
+"""JPEG decoding for bitmap textures (csrc/jpeg_decode.cpp; the reference reads JPEG through FreeImage / libjpeg).
+Baseline files come from the encoder in tests/jpeg_encode.py; decoded texels are compared with the source picture (quantisation table of
+ones: only DCT rounding and, for sub-sampled chroma, the box-down / triangle-up filter pair separate them).  Progressive files (spectral
+selection + successive approximation, ten scans) were written by libjpeg (Pillow) and are compared with libjpeg's own decode of the same
+file (tests/golden/jpeg_progressive.npz, generator tests/golden/generate_jpeg.py)."""
 import os
 import numpy as np
 import pytest
@@ -64,12 +66,41 @@ def test_greyscale_and_coarse_quantisation(tmp_path):
 
 def test_rejected_and_damaged_files(tmp_path):
     good = encode(_picture(16, 16))
-    prog = good.replace(b"\xFF\xC0", b"\xFF\xC2", 1)               # pretend progressive
+    lossless = good.replace(b"\xFF\xC0", b"\xFF\xC3", 1)           # pretend lossless (SOF3)
     with pytest.raises(ctl.CtlError) as e:
-        _decode(tmp_path, "p.jpg", prog)
-    assert e.value.code == -5 and "progressive" in str(e.value)
+        _decode(tmp_path, "p.jpg", lossless)
+    assert e.value.code == -5 and "lossless" in str(e.value)
     with pytest.raises(ctl.CtlError) as e:
         _decode(tmp_path, "n.jpg", b"not a jpeg at all")
     assert e.value.code == -6
     sc, cut = _decode(tmp_path, "c.jpg", good[:len(good) * 2 // 3])  # truncated entropy data decodes (to grey) instead of crashing
     assert cut.shape == (16, 16, 3)
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_progressive.npz")
+
+
+@pytest.mark.parametrize("name", ["p444", "p420", "p422_rst", "pgrey", "seq420_opt"])
+def test_progressive_files_against_libjpeg(tmp_path, name):
+    """DC first / refinement scans, AC bands with end-of-band runs, AC refinement (correction bits), non-interleaved scans over the
+    component's own block grid, restart markers inside progressive scans; and an optimised-Huffman sequential file.  libjpeg's integer
+    IDCT and this decoder's float IDCT round differently: texels agree to two 8-bit steps, 95 % of them to one."""
+    g = np.load(GOLDEN)
+    data = g[name + "_file"].tobytes(); want = g[name + "_rgb"].astype(np.int64)
+    assert (b"\xff\xc2" in data) == name.startswith("p")
+    sc, got = _decode(tmp_path, name + ".jpg", data)
+    assert got.shape == want.shape
+    err = np.abs(got - want)
+    assert err.max() <= 2, err.max()
+    assert (err <= 1).mean() >= 0.95
+
+
+def test_progressive_truncated_file_decodes_what_it_has(tmp_path):
+    """a progressive file cut after its first scans is a coarse picture, not an error (later scans only refine)"""
+    g = np.load(GOLDEN)
+    data = g["p444_file"].tobytes(); want = g["p444_rgb"].astype(np.int64)
+    cut = data[:data.index(b"\xff\xda", data.index(b"\xff\xda") + 2)]      # keep the first scan (DC of all components) only
+    sc, got = _decode(tmp_path, "cut.jpg", cut + b"\xff\xd9")
+    assert got.shape == want.shape
+    blocks = want.reshape(5, 8, 7, 8, 3).mean(axis=(1, 3)); got_blocks = got.reshape(5, 8, 7, 8, 3).mean(axis=(1, 3))
+    assert np.abs(blocks - got_blocks).max() < 12                    # block means survive (DC was sent with a point transform of one bit)
