@@ -45,7 +45,7 @@ class ctl_light(C.Structure):
                 ("orthogonal", u32), ("node_idx", u32), ("position", f32 * 3), ("direction", f32 * 3),
                 ("cutoff_angle", f32), ("beam_width", f32), ("cos_cutoff_angle", f32), ("cos_beam_width", f32), ("inv_transition_width", f32),
                 ("to_world", f32 * 16), ("env_image", u32), ("env_scale", f32 * 3), ("bsphere_center", f32 * 3), ("bsphere_radius", f32),
-                ("cdf_rows_index", u32), ("cdf_cols_index", u32), ("row_weights_index", u32), ("normalization", f32)]
+                ("cdf_rows_index", u32), ("cdf_cols_index", u32), ("row_weights_index", u32), ("normalization", f32), ("rad_texture", ctl_texture)]
 
 
 class ctl_mipmap(C.Structure):
@@ -541,10 +541,14 @@ class DynamicScene:
         _check(lib.ctl_builder_add_node(self._h, u32(mesh_index), None if m is None else C.byref(m), C.byref(out)))
         return out.value
 
-    def CreateLight(self, node, local_material, radiance):
-        """DynamicScene::CreateLight(node, materialName, L) (DynamicScene.cpp:689-711); materials are addressed by local index."""
+    def CreateLight(self, node, local_material, radiance, rad_texture=None, orthogonal=False):
+        """DynamicScene::CreateLight(node, materialName, L) (DynamicScene.cpp:689-711); materials are addressed by local index.
+        rad_texture / orthogonal: DiffuseLight::m_rad_texture (a checker or image ctl_texture) and m_bOrthogonal (Light.h:100-101)."""
         L = (f32 * 3)(*[float(x) for x in radiance])
-        _check(lib.ctl_builder_add_area_light(self._h, u32(node), u32(local_material), L))
+        if rad_texture is None and not orthogonal:
+            _check(lib.ctl_builder_add_area_light(self._h, u32(node), u32(local_material), L))
+        else:
+            _check(lib.ctl_builder_add_area_light_ex(self._h, u32(node), u32(local_material), L, C.byref(rad_texture) if rad_texture is not None else None, i32(1 if orthogonal else 0)))
 
     def CreatePointLight(self, position, intensity):
         _check(lib.ctl_builder_add_point_light(self._h, (f32 * 3)(*map(float, position)), (f32 * 3)(*map(float, intensity))))

@@ -58,6 +58,10 @@ int ctl_builder_add_area_light(ctl_builder* b, uint32_t node_index, uint32_t loc
     CTL_REQUIRE(b && radiance, "null argument");
     CTL_TRY b->b.add_area_light(node_index, local_material, radiance); CTL_CATCH
 }
+int ctl_builder_add_area_light_ex(ctl_builder* b, uint32_t node_index, uint32_t local_material, const float radiance[3], const ctl_texture* rad_texture, int32_t orthogonal) {
+    CTL_REQUIRE(b && radiance, "null argument");
+    CTL_TRY b->b.add_area_light(node_index, local_material, radiance, rad_texture, orthogonal != 0); CTL_CATCH
+}
 int ctl_builder_add_point_light(ctl_builder* b, const float position[3], const float intensity[3]) {
     CTL_REQUIRE(b && position && intensity, "null argument");
     CTL_TRY b->b.add_point_light(position, intensity); CTL_CATCH

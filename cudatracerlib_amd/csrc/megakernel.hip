@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_path_trace(dev_scene S, pass_params P, 
                 const ctl_light& light = S.lights[li2];
                 float misWeight = 1.0f;
                 if (!(!P.direct || depth == 1 || specularBounce)) misWeight = power_heuristic(brdf_scattering_pdf, light_pdf_direct(light, r_d, last_nor, b.dg.n, t) * pdf_emitter(S, li2));
-                cl = cl + misWeight * cf * light_eval(light, b.dg.sys.n, -r_d);
+                cl = cl + misWeight * cf * light_eval(S, light, b.dg.P, b.dg.sys.n, -r_d);
             }
             const f3 f = bsdf_sample_top(mat, b, brdf_scattering_pdf, rng.next2());
             last_nor = b.dg.sys.n;

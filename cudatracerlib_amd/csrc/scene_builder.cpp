@@ -278,7 +278,7 @@ aabb scene_builder::scene_box() const {
 }
 
 // DynamicScene::CreateLight(node, matName, L) + CreateShape (Engine/DynamicScene.cpp:689-767) + ShapeSet (Engine/ShapeSet.cpp:17-59)
-uint32_t scene_builder::add_area_light(uint32_t node_index, uint32_t local_material, const float radiance[3]) {
+uint32_t scene_builder::add_area_light(uint32_t node_index, uint32_t local_material, const float radiance[3], const ctl_texture* rad_texture, bool orthogonal) {
     if (node_index >= nodes.size()) throw std::runtime_error("ctl_builder_add_area_light: bad node index");
     ctl_node& N = nodes[node_index];
     const mesh_rec& mr = mesh_info[N.mesh_index];
@@ -316,7 +316,12 @@ uint32_t scene_builder::add_area_light(uint32_t node_index, uint32_t local_mater
     std::memcpy(anim.data() + tri_off, st.data(), st.size() * sizeof(ctl_shape_tri));
     ctl_light L{};
     L.type = CTL_LIGHT_DIFFUSE; L.radiance[0] = radiance[0]; L.radiance[1] = radiance[1]; L.radiance[2] = radiance[2];
-    L.area_dist_index = cdf_off; L.triangles_index = tri_off; L.sum_area = sumArea; L.count = count; L.orthogonal = 0; L.node_idx = node_index;
+    L.area_dist_index = cdf_off; L.triangles_index = tri_off; L.sum_area = sumArea; L.count = count; L.orthogonal = orthogonal ? 1u : 0u; L.node_idx = node_index;
+    if (rad_texture) {
+        if (rad_texture->type != CTL_TEX_CONSTANT && rad_texture->type != CTL_TEX_CHECKER && rad_texture->type != CTL_TEX_IMAGE) throw std::runtime_error("ctl_builder_add_area_light_ex: unknown texture type");
+        L.rad_texture = *rad_texture;
+        if (rad_texture->type == CTL_TEX_CONSTANT) { L.radiance[0] = rad_texture->value[0]; L.radiance[1] = rad_texture->value[1]; L.radiance[2] = rad_texture->value[2]; }
+    }
     uint32_t li;
     if (mat.node_light_index != 0xffffffffu) { li = N.lights[mat.node_light_index]; lights[li] = L; }
     else { li = (uint32_t)lights.size(); lights.push_back(L); mat.node_light_index = N.n_lights; N.lights[N.n_lights++] = li; }

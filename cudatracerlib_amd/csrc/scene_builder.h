@@ -52,7 +52,7 @@ struct scene_builder {
     uint32_t add_aux_material(const ctl_material& m);   // a material no triangle refers to: the nested BSDF of a coating / roughcoating / blend; returns its absolute index
     const ctl_material& node_material(uint32_t node_index, uint32_t local_material) const;
     aabb scene_box() const;
-    uint32_t add_area_light(uint32_t node_index, uint32_t local_material, const float radiance[3]);
+    uint32_t add_area_light(uint32_t node_index, uint32_t local_material, const float radiance[3], const ctl_texture* rad_texture = nullptr, bool orthogonal = false);
     uint32_t add_point_light(const float position[3], const float intensity[3]);
     uint32_t add_spot_light(const float position[3], const float target[3], const float intensity[3], float cutoff_deg, float beam_deg);
     uint32_t add_distant_light(const float direction[3], const float irradiance[3], float scene_radius);

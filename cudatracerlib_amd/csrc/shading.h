@@ -604,6 +604,41 @@ __device__ f3 env_eval(const dev_scene& S, const ctl_light& L, f3 dir) {
 }
 // InfiniteLight::pdfDirect, solid-angle measure (SceneTypes/Light.cu:368-378)
 __device__ __forceinline__ float env_pdf_direct(const dev_scene& S, const ctl_light& L, f3 d) { return env_pdf_direction(S, L, xform_dir_transpose(L.to_world, d)); }
+#if CTL_SHADE_FEATURES & 8
+// ---- area lights with a radiance texture or m_bOrthogonal (SceneTypes/Light.cu:50-53, :67-81, :83-134; Engine/ShapeSet.cu:25-31, :71-91)
+__device__ __forceinline__ bool light_needs_uv(const ctl_light& L) { return L.rad_texture.type == CTL_TEX_CHECKER || L.rad_texture.type == CTL_TEX_IMAGE; }
+__device__ __forceinline__ f2 shape_tri_uv(const dev_scene& S, const ctl_shape_tri& sn, f2 bary) {   // getUV: TriangleData::getUVSetData(0, a, b, c)
+    const uint4 tb = S.tri_data[sn.t_dat * 2 + 1];
+    const f2 a{ half_to_float((uint16_t)tb.y), half_to_float((uint16_t)(tb.y >> 16)) }, b{ half_to_float((uint16_t)tb.z), half_to_float((uint16_t)(tb.z >> 16)) },
+        c{ half_to_float((uint16_t)tb.w), half_to_float((uint16_t)(tb.w >> 16)) };
+    const float u = bary.x, v = bary.y, w = 1 - u - v;
+    return f2{ u * a.x + v * b.x + w * c.x, u * a.y + v * b.y + w * c.y };
+}
+__device__ __forceinline__ bool barycentric(f3 p, f3 a, f3 b, f3 c, float& u, float& v) {   // AlgebraHelper::Barycentric (Math/AlgebraHelper.h:46-59)
+    const f3 v0 = b - a, v1 = c - a, v2 = p - a;
+    const float d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
+    const float denom = d00 * d11 - d01 * d01;
+    v = (d11 * d20 - d01 * d21) / denom;
+    const float w = (d00 * d21 - d01 * d20) / denom;
+    u = 1.0f - v - w;
+    return 0 <= v && v <= 1 && 0 <= u && u <= 1 && 0 <= w && w <= 1;
+}
+__device__ __noinline__ f2 shape_get_position_uv(const dev_scene& S, const ctl_light& L, f3 pos) {   // ShapeSet::getPosition: first triangle of the set that holds the point
+    const ctl_shape_tri* tris = (const ctl_shape_tri*)(S.anim + L.triangles_index);
+    for (uint32_t i = 0; i < L.count; i++) {
+        const ctl_shape_tri& sn = tris[i]; f2 b;
+        if (barycentric(pos, f3(sn.p[0][0], sn.p[0][1], sn.p[0][2]), f3(sn.p[1][0], sn.p[1][1], sn.p[1][2]), f3(sn.p[2][0], sn.p[2][1], sn.p[2][2]), b.x, b.y)) return shape_tri_uv(S, sn, b);
+    }
+    return f2{ 0.0f, 0.0f };
+}
+__device__ __noinline__ f3 light_radiance_tex(const dev_scene& S, const ctl_light& L, f2 uv) {   // m_rad_texture.Evaluate(dg), dg = {P, bary, uv}
+    diff_geom dg; dg.uv = uv; dg.images = S.images;
+#ifdef CTL_TEX_PARTIALS
+    dg.has_uv_partials = false;
+#endif
+    return tex_eval(L.rad_texture, dg);
+}
+#endif
 // DiffuseLight / PointLight / SpotLight / DistantLight / InfiniteLight ::sampleDirect (SceneTypes/Light.cu:83-137, 13-31, 287-301, 224-245, 350-366)
 // with ShapeSet::SamplePosition (Engine/ShapeSet.cu:51-69)
 __device__ f3 light_sample_direct(const dev_scene& S, const ctl_light& L, direct_rec& r, f2 smp) {
@@ -649,34 +684,70 @@ __device__ f3 light_sample_direct(const dev_scene& S, const ctl_light& L, direct
 #endif
     const float* cdf = (const float*)(S.anim + L.area_dist_index);
     const ctl_shape_tri* tris = (const ctl_shape_tri*)(S.anim + L.triangles_index);
-    float pdfTri;
-    const uint32_t index = sample_reuse(cdf, L.count, smp.y, pdfTri);
-    const ctl_shape_tri& sn = tris[index];
-    const f2 bary = square_to_uniform_triangle(smp);
-    const f3 p0(sn.p[0][0], sn.p[0][1], sn.p[0][2]), p1(sn.p[1][0], sn.p[1][1], sn.p[1][2]), p2(sn.p[2][0], sn.p[2][1], sn.p[2][2]);
-    r.p = bary.x * p0 + bary.y * p1 + (1.f - bary.x - bary.y) * p2;
-    r.n = f3(sn.n[0], sn.n[1], sn.n[2]);
-    r.pdf = 1.0f / L.sum_area;
+    float pdfTri, sc = 1;
+#if CTL_SHADE_FEATURES & 8
+    f2 uv{ 0.0f, 0.0f };
+    if (L.orthogonal) {   // the point of a random triangle's plane straight above / below the reference point (Light.cu:87-107)
+        sc = kPi;
+        const ctl_shape_tri& sn = tris[sample_reuse(cdf, L.count, smp.x, pdfTri)];   // ShapeSet::sampleTriangle
+        const f3 p0(sn.p[0][0], sn.p[0][1], sn.p[0][2]), p1(sn.p[1][0], sn.p[1][1], sn.p[1][2]), p2(sn.p[2][0], sn.p[2][1], sn.p[2][2]);
+        const f3 n = normalize(cross(p1 - p0, p2 - p0));
+        const float lambda = dot(p0, n) - dot(r.ref, n);
+        r.p = r.ref + lambda * n;
+        f2 b;
+        if (!barycentric(r.p, p0, p1, p2, b.x, b.y)) { r.pdf = 0.0f; return f3(0.0f); }
+        r.n = n;
+        r.pdf = 1.0f / float(L.count);
+        if (light_needs_uv(L)) uv = shape_tri_uv(S, sn, b);
+    } else
+#endif
+    {
+        const uint32_t index = sample_reuse(cdf, L.count, smp.y, pdfTri);
+        const ctl_shape_tri& sn = tris[index];
+        const f2 bary = square_to_uniform_triangle(smp);
+        const f3 p0(sn.p[0][0], sn.p[0][1], sn.p[0][2]), p1(sn.p[1][0], sn.p[1][1], sn.p[1][2]), p2(sn.p[2][0], sn.p[2][1], sn.p[2][2]);
+        r.p = bary.x * p0 + bary.y * p1 + (1.f - bary.x - bary.y) * p2;
+        r.n = f3(sn.n[0], sn.n[1], sn.n[2]);
+        r.pdf = 1.0f / L.sum_area;
+#if CTL_SHADE_FEATURES & 8
+        if (light_needs_uv(L)) uv = shape_tri_uv(S, sn, bary);
+#endif
+    }
     const f3 dir = r.p - r.ref;
     const float distSquared = len_sqr(dir);
     r.dist = sqrtf(distSquared);
     r.d = dir / r.dist;
     const float dp = absdot(r.d, r.n);
-    r.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
     r.measure = kMeasureSolidAngle;
-    if (dot(r.d, r.refN) >= 0 && dot(r.d, r.n) < 0 && r.pdf != 0) return f3(L.radiance[0], L.radiance[1], L.radiance[2]) / r.pdf * 1.0f;
+#if CTL_SHADE_FEATURES & 8
+    if (L.orthogonal) r.measure = kMeasureDiscrete; else
+#endif
+    r.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+    if (dot(r.d, r.refN) >= 0 && dot(r.d, r.n) < 0 && r.pdf != 0) {
+#if CTL_SHADE_FEATURES & 8
+        if (light_needs_uv(L)) return light_radiance_tex(S, L, uv) / r.pdf * sc;
+#endif
+        return f3(L.radiance[0], L.radiance[1], L.radiance[2]) / r.pdf * sc;
+    }
     r.pdf = 0.0f;
     return f3(0.0f);
 }
 // DiffuseLight::pdfDirect (SceneTypes/Light.cu:139-159), solid-angle measure
 __device__ __forceinline__ float light_pdf_direct(const ctl_light& L, f3 d, f3 refN, f3 n, float dist) {
     if (L.type != CTL_LIGHT_DIFFUSE) return 0.0f;
+#if CTL_SHADE_FEATURES & 8
+    if (L.orthogonal) return 0.0f;   // Light.cu:140-141: an orthogonal light has a pdf in the discrete measure only; the path tracer asks in solid angle
+#endif
     if (dot(d, refN) >= 0 && dot(d, n) < 0) { const float pdfPos = 1.0f / L.sum_area; return pdfPos * (dist * dist) / absdot(d, n); }
     return 0.0f;
 }
-// DiffuseLight::eval (SceneTypes/Light.cu:67-81), constant radiance texture
-__device__ __forceinline__ f3 light_eval(const ctl_light& L, f3 sys_n, f3 d) {
+// DiffuseLight::eval (SceneTypes/Light.cu:67-81)
+__device__ __forceinline__ f3 light_eval(const dev_scene& S, const ctl_light& L, f3 p, f3 sys_n, f3 d) {
     if (L.type != CTL_LIGHT_DIFFUSE || dot(sys_n, d) <= 0) return f3(0.0f);
+#if CTL_SHADE_FEATURES & 8
+    if (L.orthogonal && dot(d, sys_n) < 1 - 1e-3f) return f3(0.0f);   // DeltaEpsilon (Math/MathFunc.h:26)
+    if (light_needs_uv(L)) return light_radiance_tex(S, L, shape_get_position_uv(S, L, p));
+#endif
     return f3(L.radiance[0], L.radiance[1], L.radiance[2]);
 }
 // KernelDynamicScene::sampleEmitter / pdfEmitter (Engine/KernelDynamicScene.cu:25-46)

@@ -204,7 +204,13 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
     for (uint32_t i = 0; i < d.n_lights_buf; i++) {
         const ctl_light& L = d.lights[i];
         if (L.type < CTL_LIGHT_POINT || L.type > CTL_LIGHT_INFINITE) throw std::runtime_error("ctl_scene_create: unknown light type " + std::to_string(L.type));
-        if (L.type == CTL_LIGHT_DIFFUSE && L.orthogonal) throw std::runtime_error("ctl_scene_create: orthogonal area lights have no HIP implementation yet");
+        if (L.type == CTL_LIGHT_DIFFUSE && (L.orthogonal || L.rad_texture.type == CTL_TEX_CHECKER || L.rad_texture.type == CTL_TEX_IMAGE)) {
+            S.shade_features |= kShadeMoreLights;   // orthogonal / textured area lights live in the full build
+            if (L.rad_texture.type == CTL_TEX_IMAGE) {
+                if (L.rad_texture.image != 0xffffffffu && L.rad_texture.image >= d.n_images) throw std::runtime_error("ctl_scene_create: light texture references a missing image");
+                S.shade_features |= kShadeImageTextures;
+            }
+        }
         if (L.type == CTL_LIGHT_INFINITE && L.env_image >= d.n_images) throw std::runtime_error("ctl_scene_create: InfiniteLight references a missing image");
     }
     for (uint32_t i = 0; i < d.n_materials; i++) {

@@ -471,6 +471,33 @@ def normal_image(n=64, strength=0.08):
     return (nrm * 0.5 + 0.5).astype(np.float32)
 
 
+def area_lights_scene(width=96, height=64, kind="checker"):
+    """A floor, two diffuse boxes and a ceiling panel whose DiffuseLight carries the members an application sets after CreateLight
+    (SceneTypes/Light.h:100-101): kind "checker" / "image" = a radiance texture that needs the panel's uv, "orthogonal" = m_bOrthogonal (the panel
+    lights only what lies straight below it), "orthogonal_image" = both.  A weak point light keeps the rest of the room visible."""
+    sc = api.DynamicScene()
+    P, I, N = _quad([[-6, 0, -6], [-6, 0, 6], [6, 0, 6], [6, 0, -6]], [0, 1, 0])
+    sc.CreateNode(sc.add_mesh(P, I, normals=N, materials=[api.diffuse((0.7, 0.7, 0.7))]))
+    Pb, Ib, Nb = unit_box()
+    box = sc.add_mesh(Pb, Ib, normals=Nb, materials=[api.diffuse((0.7, 0.3, 0.2))])
+    for pos, s in (((-2.0, 0.8, 0.5), 0.8), ((1.8, 0.5, -1.0), 0.5)):
+        xf = np.eye(4, dtype=np.float32); xf[:3, :3] *= s; xf[:3, 3] = pos
+        sc.CreateNode(box, xf)
+    P, I, N = _quad([[-2.5, 4.0, -2.0], [2.5, 4.0, -2.0], [2.5, 4.0, 2.0], [-2.5, 4.0, 2.0]], [0, -1, 0])
+    panel = sc.CreateNode(sc.add_mesh(P, I, normals=N, uvs=np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32), materials=[api.diffuse((0.5, 0.5, 0.5))]))
+    tex = None
+    if kind == "checker":
+        tex = api.checker_texture((9.0, 8.0, 6.0), (0.5, 1.0, 3.0), uv_scale=(3.0, 2.0))
+    elif kind in ("image", "orthogonal_image"):
+        img = sc.add_image(api.float3_to_rgbe(8.0 * bump_image(16, seed=5) * np.array([1.0, 0.8, 0.5], np.float32) + 0.2), api.TEXEL_RGBE, api.WRAP_REPEAT, api.FILTER_BILINEAR)
+        tex = api.image_texture(img, scale=(1.0, 1.0, 1.0), uv_scale=(1.0, 1.0))
+    sc.CreateLight(panel, 0, (9.0, 8.0, 6.0), rad_texture=tex, orthogonal=kind.startswith("orthogonal"))
+    sc.CreatePointLight((0.0, 2.5, -5.0), (3.0, 3.0, 3.0))
+    sc.setCamera((0, 3.0, -9.0), (0, 1.5, 0), (0, 1, 0), 55.0, width, height)
+    sc.UpdateScene()
+    return sc
+
+
 def maps_scene(width=96, height=64, surface_map="normal", alpha="luminance"):
     """Material maps in miniature: a ground quad with a normal map (``surface_map`` = "normal"), a height map ("height") or neither
     (None) under a glossy BSDF, and an upright card whose material carries an alpha map (``alpha`` = "luminance": checkerboard

@@ -198,6 +198,9 @@ typedef struct {
     uint32_t cdf_cols_index;       /* float[height * (width + 1)]                              */
     uint32_t row_weights_index;    /* float[height]                                            */
     float normalization;           /* m_normalization                                          */
+    /* DiffuseLight::m_rad_texture when it is not a ConstantTexture (SceneTypes/Light.cu:50-53 needsUVSample): CTL_TEX_CHECKER / CTL_TEX_IMAGE;
+     * any other type (0, CTL_TEX_CONSTANT) = the constant `radiance` above */
+    ctl_texture rad_texture;
 } ctl_light;
 
 /* ids = TYPE_FUNC ids of SceneTypes/Sensor.h:107,191,272,364,445 */
@@ -264,6 +267,9 @@ int ctl_builder_add_node(ctl_builder* b, uint32_t mesh_index, const ctl_float4x4
 /* DynamicScene::CreateLight(node, matName, L) (DynamicScene.cpp:689-711): all triangles of the node whose local
  * material index is `local_material` become one DiffuseLight. */
 int ctl_builder_add_area_light(ctl_builder* b, uint32_t node_index, uint32_t local_material, const float radiance[3]);
+/* The same with the two DiffuseLight members an application sets on the light afterwards (SceneTypes/Light.h:100-101): a radiance texture that is
+ * not constant (NULL = constant `radiance`) and m_bOrthogonal (the light emits along its surface normal only). */
+int ctl_builder_add_area_light_ex(ctl_builder* b, uint32_t node_index, uint32_t local_material, const float radiance[3], const ctl_texture* rad_texture, int32_t orthogonal);
 /* DynamicScene::CreateLight(Light) for point lights (SceneTypes/Light.h:31-94) */
 int ctl_builder_add_point_light(ctl_builder* b, const float position[3], const float intensity[3]);
 /* SpotLight(p, t, L, width, fall) (SceneTypes/Light.cu:268-277): cutoff/beam angles in degrees as the loader passes them

@@ -674,6 +674,55 @@ inline void shapeSamplePosition(const Scene& S, const ctl_light& L, DirectRec& p
     pRec.measure = EArea;
     pRec.uv = bary;
 }
+// getUV (Engine/ShapeSet.cu:25-31): TriangleData::getUVSetData(0, a, b, c), uv = u a + v b + w c
+inline V2 shapeTriUV(const Scene& S, const ctl_shape_tri& sn, V2 bary) {
+    const ctl_triangle_data& T = S.d.tri_data[sn.t_dat];
+    auto h = [&](uint32_t bits) { return halfToFloat((uint16_t)bits, S.half_host_quirk); };
+    V2 a{ h(T.uv[0]), h(T.uv[0] >> 16) }, b{ h(T.uv[1]), h(T.uv[1] >> 16) }, c{ h(T.uv[2]), h(T.uv[2] >> 16) };
+    float u = bary.x, v = bary.y, w = 1 - u - v;
+    return V2{ u * a.x + v * b.x + w * c.x, u * a.y + v * b.y + w * c.y };
+}
+// AlgebraHelper::Barycentric (Math/AlgebraHelper.h:46-59)
+inline bool barycentric(V3 p, V3 a, V3 b, V3 c, float& u, float& v) {
+    V3 v0 = b - a, v1 = c - a, v2 = p - a;
+    float d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
+    float denom = d00 * d11 - d01 * d01;
+    v = (d11 * d20 - d01 * d21) / denom;
+    float w = (d00 * d21 - d01 * d20) / denom;
+    u = 1.0f - v - w;
+    return 0 <= v && v <= 1 && 0 <= u && u <= 1 && 0 <= w && w <= 1;
+}
+// ShapeSet::getPosition (Engine/ShapeSet.cu:71-91): the first triangle of the set that contains the point
+inline bool shapeGetPosition(const Scene& S, const ctl_light& L, V3 pos, V2* bary, V2* uv) {
+    const ctl_shape_tri* triangles = (const ctl_shape_tri*)(S.d.anim + L.triangles_index);
+    for (unsigned i = 0; i < L.count; i++) {
+        const ctl_shape_tri& sn = triangles[i]; V2 b;
+        if (barycentric(pos, V3(sn.p[0][0], sn.p[0][1], sn.p[0][2]), V3(sn.p[1][0], sn.p[1][1], sn.p[1][2]), V3(sn.p[2][0], sn.p[2][1], sn.p[2][2]), b.x, b.y)) {
+            if (bary) *bary = b;
+            if (uv) *uv = shapeTriUV(S, sn, b);
+            return true;
+        }
+    }
+    return false;
+}
+// ShapeSet::PdfTriangle (Engine/ShapeSet.cu:93-106)
+inline float shapePdfTriangle(const Scene& S, const ctl_light& L, V3 pos) {
+    const float* areaDistribution = (const float*)(S.d.anim + L.area_dist_index);
+    const ctl_shape_tri* triangles = (const ctl_shape_tri*)(S.d.anim + L.triangles_index);
+    for (unsigned i = 0; i < L.count; i++) {
+        const ctl_shape_tri& sn = triangles[i]; V2 b;
+        if (barycentric(pos, V3(sn.p[0][0], sn.p[0][1], sn.p[0][2]), V3(sn.p[1][0], sn.p[1][1], sn.p[1][2]), V3(sn.p[2][0], sn.p[2][1], sn.p[2][2]), b.x, b.y))
+            return areaDistribution[i + 1] - areaDistribution[i];
+    }
+    return 0.0f;
+}
+inline bool lightNeedsUV(const ctl_light& L) { return L.rad_texture.type == CTL_TEX_CHECKER || L.rad_texture.type == CTL_TEX_IMAGE; }   // needsUVSample (Light.cu:50-53)
+// m_rad_texture.Evaluate(dg) for a DifferentialGeometry that only carries P, bary and uv (Light.cu:72-80, :125-130)
+inline Spec lightRadiance(const Scene& S, const ctl_light& L, V3 P, V2 bary, V2 uv) {
+    if (!lightNeedsUV(L)) return Spec(L.radiance[0], L.radiance[1], L.radiance[2]);
+    DG dg; dg.P = P; dg.bary = bary; dg.uv = uv; dg.images = S.d.images;
+    return texEval(L.rad_texture, dg);
+}
 inline Frame lightFrame(const ctl_light& L) {   // Spot / Distant `Frame ToWorld`
     return Frame(V3(L.to_world[0], L.to_world[1], L.to_world[2]), V3(L.to_world[4], L.to_world[5], L.to_world[6]), V3(L.to_world[8], L.to_world[9], L.to_world[10]));
 }
@@ -736,7 +785,7 @@ inline Spec envEval(const Scene& S, const ctl_light& L, V3 dir) {
     V2 uv{ atan2f(v.x, -v.z) * INV_TWOPI, safe_acos(v.y) * INV_PI };
     return mipTriangle(S.d.images[L.env_image], uv) * Spec(L.env_scale[0], L.env_scale[1], L.env_scale[2]);
 }
-// SceneTypes/Light.cu:83-137 (m_bOrthogonal == false branch), :13-31 (point), :287-301 (spot), :224-245 (distant), :350-366 (infinite)
+// SceneTypes/Light.cu:83-137, :13-31 (point), :287-301 (spot), :224-245 (distant), :350-366 (infinite)
 inline Spec lightSampleDirect(const Scene& S, const ctl_light& L, DirectRec& dRec, V2 sample) {
     if (L.type == CTL_LIGHT_POINT) {
         dRec.p = V3(L.position[0], L.position[1], L.position[2]);
@@ -776,16 +825,41 @@ inline Spec lightSampleDirect(const Scene& S, const ctl_light& L, DirectRec& dRe
         dRec.measure = ESolidAngle;
         return value / pdf;
     }
-    shapeSamplePosition(S, L, dRec, sample);
+    V2 uv{ 0.0f, 0.0f }; float sc = 1;
+    if (L.orthogonal) {   // the point of a random triangle's plane straight above / below the reference point (Light.cu:87-107)
+        sc = PI;
+        const float* areaDistribution = (const float*)(S.d.anim + L.area_dist_index);
+        const ctl_shape_tri* triangles = (const ctl_shape_tri*)(S.d.anim + L.triangles_index);
+        float sx = sample.x;
+        const ctl_shape_tri& sn = triangles[sampleReuse(areaDistribution, L.count, sx, dRec.pdf)];   // ShapeSet::sampleTriangle (ShapeSet.cu:38-49)
+        V3 p0(sn.p[0][0], sn.p[0][1], sn.p[0][2]), p1(sn.p[1][0], sn.p[1][1], sn.p[1][2]), p2(sn.p[2][0], sn.p[2][1], sn.p[2][2]);
+        V3 n = normalize(cross(p1 - p0, p2 - p0));
+        float lambda = dot(p0, n) - dot(dRec.ref, n);
+        dRec.p = dRec.ref + lambda * n;
+        if (!barycentric(dRec.p, p0, p1, p2, dRec.uv.x, dRec.uv.y)) { dRec.pdf = 0.0f; return Spec(0.0f); }
+        dRec.n = n;
+        dRec.pdf = 1.0f / float(L.count);
+        dRec.measure = EArea;
+        if (lightNeedsUV(L)) uv = shapeTriUV(S, sn, dRec.uv);
+    } else {
+        shapeSamplePosition(S, L, dRec, sample);
+        if (lightNeedsUV(L)) {
+            const ctl_shape_tri* triangles = (const ctl_shape_tri*)(S.d.anim + L.triangles_index);
+            float pdfTri; V2 s2 = sample;
+            uv = shapeTriUV(S, triangles[sampleReuse((const float*)(S.d.anim + L.area_dist_index), L.count, s2.y, pdfTri)], dRec.uv);
+        }
+    }
     V3 dir = dRec.p - dRec.ref;
     float distSquared = lenSqr(dir);
     dRec.dist = std::sqrt(distSquared);
     dRec.d = dir / dRec.dist;
     float dp = absdot(dRec.d, dRec.n);
-    dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
-    dRec.measure = ESolidAngle;
+    if (!L.orthogonal) {
+        dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+        dRec.measure = ESolidAngle;
+    } else dRec.measure = EDiscrete;
     if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0)
-        return Spec(L.radiance[0], L.radiance[1], L.radiance[2]) / dRec.pdf * 1.0f;
+        return lightRadiance(S, L, dRec.p, dRec.uv, uv) / dRec.pdf * sc;
     dRec.pdf = 0.0f;
     return Spec(0.0f);
 }
@@ -799,6 +873,7 @@ inline float lightPdfDirect(const Scene& S, const ctl_light& L, const DirectRec&
         else return 0.0f;
     }
     if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
+        if (L.orthogonal) return dRec.measure == EDiscrete ? shapePdfTriangle(S, L, dRec.p) : 0.0f;
         float pdfPos = 1.0f / L.sum_area;
         if (dRec.measure == ESolidAngle) return pdfPos * (dRec.dist * dRec.dist) / absdot(dRec.d, dRec.n);
         else if (dRec.measure == EArea) return pdfPos;
@@ -807,10 +882,12 @@ inline float lightPdfDirect(const Scene& S, const ctl_light& L, const DirectRec&
     return 0.0f;
 }
 // SceneTypes/Light.cu:67-81
-inline Spec lightEval(const ctl_light& L, const Frame& sys, V3 d) {
+inline Spec lightEval(const Scene& S, const ctl_light& L, V3 p, const Frame& sys, V3 d) {
     if (L.type != CTL_LIGHT_DIFFUSE) return Spec(0.0f);
-    if (dot(sys.n, d) <= 0) return Spec(0.0f);
-    return Spec(L.radiance[0], L.radiance[1], L.radiance[2]);
+    if (dot(sys.n, d) <= 0 || (L.orthogonal && dot(d, sys.n) < 1 - DeltaEpsilon)) return Spec(0.0f);
+    V2 bary{ 0.0f, 0.0f }, uv{ 0.0f, 0.0f };
+    if (lightNeedsUV(L)) shapeGetPosition(S, L, p, &bary, &uv);   // CTL_ASSERT in the reference: a point that is on no triangle keeps uv = 0
+    return lightRadiance(S, L, p, bary, uv);
 }
 // Engine/KernelDynamicScene.cu:25-46
 inline const ctl_light* sampleEmitter(const Scene& S, float& emPdf, V2& sample) {
@@ -1259,7 +1336,7 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
                     float direct_pdf = lightPdfDirect(S, *light, dRec) * pdfEmitter(S, light);
                     misWeight = powerHeuristic(1, brdf_scattering_pdf, 1, direct_pdf);
                 }
-                cl = cl + misWeight * cf * lightEval(S.d.lights[li], bRec.dg.sys, -rd);
+                cl = cl + misWeight * cf * lightEval(S, S.d.lights[li], bRec.dg.P, bRec.dg.sys, -rd);
             }
             Spec f = bsdfSample(mat, bRec, brdf_scattering_pdf, rnd.randomFloat2());
             last_nor = bRec.dg.sys.n;

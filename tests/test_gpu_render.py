@@ -86,6 +86,22 @@ def test_environment_map_bitmap_texture_and_delta_lights(gpu, orc, kw):
     assert want[..., :3].mean() > 0.1
 
 
+@pytest.mark.parametrize("kind", ["checker", "image", "orthogonal", "orthogonal_image"])
+def test_textured_and_orthogonal_area_lights(gpu, orc, kind):
+    """DiffuseLight::m_rad_texture that needs uv (NEE: uv of the sampled triangle; emitter hit: ShapeSet::getPosition finds the triangle again) and
+    m_bOrthogonal (discrete-measure NEE straight along the normal, eval only within DeltaEpsilon of it) — wavefront and megakernel plugins"""
+    sc = scenes.area_lights_scene(96, 64, kind)
+    got, want, tr, rays = render_pair(gpu, orc, sc, 96, 64, 3)
+    assert_close(got, want)
+    assert want[..., :3].mean() > 0.02
+    tables = orc.sequence_tables(3)
+    mk = gpu.PathTracer(); mk.Resize(96, 64); mk.InitializeScene(gpu.Scene(sc.desc, flatten=True))
+    img = gpu.Image(96, 64)
+    for k in range(3):
+        mk.setSamplerTables(*tables[k]); mk.DoPass(img, new_trace=(k == 0))
+    assert_close(img.getPixelData(), want)
+
+
 def test_synthetic_bathroom_workload(gpu, orc):
     """the stand-in for BASELINE config 5 in miniature: nine BSDF models (both distributions, visible normals, coating, rough glass),
     bitmap texture + height map, environment emitter + area light, instanced meshes — two-level layout, per-pixel bar"""

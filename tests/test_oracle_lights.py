@@ -165,3 +165,63 @@ def test_rgbe_roundtrip():
     back = np.stack([(t >> (8 * k)) & 0xff for k in range(3)], -1).astype(np.float64) * np.ldexp(1.0, e - 136)[..., None]
     mx = c.max(-1, keepdims=True)
     assert np.all(np.abs(back - c) <= mx / 128)
+
+
+def _panel(kind):
+    sc = scenes.area_lights_scene(32, 24, kind)
+    d = sc.desc
+    li = [i for i in range(d.n_lights_buf) if d.lights[i].type == 2][0]
+    return sc, d, li
+
+
+def test_textured_area_light_samples_its_texture(lib):
+    """DiffuseLight with a radiance texture that needs uv (Light.cu:50-53, :83-134): sampleDirect returns texture(uv of the sampled point) / pdf with
+    the solid-angle pdf of a constant light, and the uv is the sampled triangle's getUVSetData(0) interpolated with the sampled barycentrics — the
+    panel's uv are its x / z extent mapped to [0, 1]^2, so the checker cell can be read off the sampled position."""
+    sc, d, li = _panel("checker")
+    L = d.lights[li]
+    assert L.rad_texture.type == 3 and not L.orthogonal
+    ref, refN = _vec(0.4, 0.2, -0.3), _vec(0, 1, 0)
+    rs = np.random.RandomState(3)
+    c0, c1 = np.array(L.rad_texture.value[:]), np.array(L.rad_texture.value1[:])
+    seen = set()
+    for _ in range(400):
+        o = _sample(lib, d, li, ref, refN, rs.uniform(0, 1, 2))
+        p, n, dist, pdf = o[8:11], o[11:14], o[7], o[3]
+        assert pdf == pytest.approx(dist * dist / (abs(np.dot(o[4:7], n)) * L.sum_area), rel=1e-4)
+        u, v = (p[0] + 2.5) / 5.0, (p[2] + 2.0) / 4.0            # the panel's uv layout (scenes.area_lights_scene); stored as halves
+        cu, cv = u * 3.0 * 2, v * 2.0 * 2
+        if min(abs(cu - round(cu)), abs(cv - round(cv))) < 0.02:
+            continue                                             # too close to a cell border for half-precision uv
+        x, y = 2 * (int(cu) % 2) - 1, 2 * (int(cv) % 2) - 1
+        want = c0 if x * y == 1 else c1
+        assert o[:3] == pytest.approx(want / pdf, rel=2e-4)
+        seen.add(x * y)
+    assert seen == {1, -1}
+
+
+def test_orthogonal_area_light(lib):
+    """m_bOrthogonal (Light.cu:87-107, :117-122): the sampled point is the foot of the perpendicular from the reference point onto the plane of a
+    randomly chosen triangle; it counts only if it lies inside that triangle; value = radiance * pi * numTriangles, measure discrete."""
+    sc, d, li = _panel("orthogonal")
+    L = d.lights[li]
+    assert L.orthogonal == 1 and L.count == 2
+    refN = _vec(0, 1, 0)
+    rs = np.random.RandomState(4)
+    hits = 0
+    for _ in range(200):
+        ref = _vec(rs.uniform(-2.4, 2.4), rs.uniform(0.1, 2.0), rs.uniform(-1.9, 1.9))      # below the panel
+        o = _sample(lib, d, li, ref, refN, rs.uniform(0, 1, 2))
+        if o[3] == 0:
+            assert not np.any(o[:3])                              # the other triangle of the quad was chosen
+            continue
+        hits += 1
+        assert np.allclose(o[8:11], [ref[0], 4.0, ref[2]], atol=1e-5) and np.allclose(o[4:7], [0, 1, 0], atol=1e-6)
+        assert o[3] == pytest.approx(0.5) and o[7] == pytest.approx(4.0 - ref[1], rel=1e-5)
+        assert o[:3] == pytest.approx(np.array(L.radiance[:]) * np.pi * 2, rel=1e-5)
+    assert 60 < hits < 140                                        # each triangle is half the panel
+    o = _sample(lib, d, li, _vec(4.0, 1.0, 0.0), refN, (0.3, 0.3))    # beside the panel: nothing
+    assert o[3] == 0 and not np.any(o[:3])
+    # pdfDirect in the solid-angle measure is 0 for an orthogonal light (Light.cu:140-141): BSDF-sampled hits of the panel carry MIS weight 1
+    dvec, nvec = _vec(0, 1, 0), _vec(0, -1, 0)
+    assert lib.orc_light_pdf_direct(C.byref(d), li, _vec(0, 1, 0).ctypes.data, refN.ctypes.data, dvec.ctypes.data, 3.0, nvec.ctypes.data) == 0.0
