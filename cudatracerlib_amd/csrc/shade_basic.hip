@@ -1,7 +1,13 @@
-// shade_basic.hip — shade kernel for scenes that use only diffuse / dielectric / conductor / roughconductor BSDFs, constant and
-// checkerboard textures, area and point lights (no spills at 128 VGPRs; the benchmark scene and the Cornell configs run this).
+// shade_basic.hip — shade kernel for scenes that only use the BSDFs, textures and emitters of the basic feature set (shading.h).
+// CTL_BASIC_SHADE_BLOCK / CTL_BASIC_SHADE_WAVES: workgroup size and waves per SIMD the register allocation is held to (measured choices in DESIGN.md §3).
 #define CTL_SHADE_FEATURES 0
-#define CTL_SHADE_BLOCK 1024
+#ifndef CTL_BASIC_SHADE_BLOCK
+#define CTL_BASIC_SHADE_BLOCK 1024
+#endif
+#define CTL_SHADE_BLOCK CTL_BASIC_SHADE_BLOCK
+#ifdef CTL_BASIC_SHADE_WAVES
+#define CTL_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(CTL_BASIC_SHADE_WAVES, CTL_BASIC_SHADE_WAVES)))
+#endif
 #define CTL_SHADE_KERNEL k_shade_basic
 #define CTL_SHADE_LAUNCH launch_shade_basic
 #include "shade_kernel.inc"
