@@ -63,6 +63,9 @@ void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& 
 // intersect `n = counts[count_slot]` rays (device-side count) from (ro, rd) into (hit, hit_node) or into occ (any-hit)
 void launch_intersect_closest(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node);
 void launch_intersect_any(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, uint32_t* occ, float4* hit = nullptr, int* hit_node = nullptr);
+// the two above in one persistent launch: closest hits of (ro, rd), then occlusion of (sro, srd)
+void launch_intersect_pair(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node,
+                           const float4* sro, const float4* srd, const uint32_t* sn_ptr, uint32_t* swork, uint32_t* occ);
 void launch_intersect_count(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node,
                             uint32_t* occ, int any_hit, unsigned long long* counts3);
 void launch_shade(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);

@@ -68,6 +68,26 @@ __global__ __launch_bounds__(kBlock, CTL_INTERSECT_MIN_WAVES) void k_intersect(d
     }
 }
 
+// Closest-hit traversal of one bounce's path rays, then any-hit traversal of the previous bounce's shadow rays, in ONE persistent launch: a wave that finds
+// the first queue exhausted goes straight on to the second, so the drain of the first set (waves running down their last long rays, ~0.4 ms per launch
+// whatever its size) is filled with the second set's work.  Same code, same results as the two separate launches (tracer.hip decides which to use).
+template <int LAYOUT, bool ALPHA>
+__global__ __launch_bounds__(kBlock, CTL_INTERSECT_MIN_WAVES) void k_intersect_pair(dev_scene S, const float4* __restrict__ ro, const float4* __restrict__ rd, const uint32_t* __restrict__ n_ptr,
+                                                            uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node,
+                                                            const float4* __restrict__ sro, const float4* __restrict__ srd, const uint32_t* __restrict__ sn_ptr,
+                                                            uint32_t* __restrict__ swork, uint32_t* __restrict__ occ) {
+    __shared__ int lds_stack[(LAYOUT ? kFlatLdsRows + 1 : kLdsStack) * kBlock];
+    const uint32_t n = *n_ptr, sn = *sn_ptr;
+    trav_counts tc{ 0, 0, 0, 0, 0 };
+    if (LAYOUT) {
+        intersect_flat<false, false, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, nullptr, lds_stack, tc);
+        intersect_flat<true, false, ALPHA, LAYOUT - 1>(S, sro, srd, sn, swork, nullptr, nullptr, occ, lds_stack, tc);
+    } else {
+        intersect_persistent<false, false, ALPHA>(S, ro, rd, n, work, hit, hit_node, nullptr, lds_stack, tc);
+        intersect_persistent<true, false, ALPHA>(S, sro, srd, sn, swork, nullptr, nullptr, occ, lds_stack, tc);
+    }
+}
+
 // terminated paths whose last NEE shadow ray has now been traced
 __global__ __launch_bounds__(kBlock) void k_finalize(wave_queues Q, pass_params P, int depth, ctl_pixel_data* __restrict__ image) {
     const uint32_t n = Q.counts[depth * 4 + 2];
@@ -86,6 +106,7 @@ __global__ void k_accumulate_stats(wave_queues Q, int max_depth) {
         unsigned long long r = 0, s = 0;
         for (int d = 0; d <= max_depth; d++) { r += (unsigned long long)Q.counts[d * 4 + 0]; s += (unsigned long long)Q.counts[d * 4 + 1]; }
         Q.stats[0] += r; Q.stats[1] += s;
+        Q.stats[12] += (unsigned long long)Q.counts[max_depth * 4 + 1];   // the shadow rays of the last bounce: always their own launch (tracer.hip)
     }
 }
 
@@ -156,6 +177,16 @@ void launch_intersect_closest(const launch_ctx& lc, const dev_scene& S, const fl
 }
 void launch_intersect_any(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, uint32_t* occ, float4* hit, int* hit_node) {
     CTL_LAUNCH_INTERSECT(true, false, S, ro, rd, n_ptr, work, hit, hit_node, occ, (unsigned long long*)nullptr);
+}
+void launch_intersect_pair(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node,
+                           const float4* sro, const float4* srd, const uint32_t* sn_ptr, uint32_t* swork, uint32_t* occ) {
+    if (!S.flat_nodes) {
+        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<0, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        else hipLaunchKernelGGL((k_intersect_pair<0, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+    } else {
+        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<1, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        else hipLaunchKernelGGL((k_intersect_pair<1, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+    }
 }
 void launch_intersect_count(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node,
                             uint32_t* occ, int any_hit, unsigned long long* counts3) {

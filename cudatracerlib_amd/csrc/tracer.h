@@ -157,7 +157,7 @@ protected:
     uint32_t shard_rank = 0, shard_world = 1;
     std::unique_ptr<BlockSampler> block_sampler_; const unsigned char* pass_block_counts_ = nullptr; uint32_t pass_max_block_count_ = 1; uint64_t pass_paths_ = 0;
     event_timer timer; double kernel_ms[4] = { 0, 0, 0, 0 };   // 0 raygen, 1 closest-hit intersect, 2 shade/finalize, 3 any-hit intersect
-    uint64_t intersect_rays = 0, intersect_launches = 0, shadow_rays = 0, shadow_launches = 0;
+    uint64_t intersect_rays = 0, intersect_launches = 0, shadow_rays = 0, shadow_launches = 0, fused_launches = 0, fused_shadow_rays = 0;
     bool counting = false; ctl_traversal_counts closest_counts{}, any_counts{};
 public:
     void setCounting(bool on) { counting = on; }
