@@ -866,3 +866,10 @@ class SequenceGenerator:
         t2 = np.zeros((n, 2 * SAMPLER_N1), np.float32)
         _check(lib.ctl_sequence_generator_compute_many(self._h, u32(n), _fp(t1), _fp(t2), u32(threads)))
         return t1, t2
+
+    def compute_many_device(self, n):
+        """the same tables written in HBM by the tracers' k_sequence_fill and copied back (needs a HIP device)"""
+        t1 = np.zeros((n, SAMPLER_N1), np.float32)
+        t2 = np.zeros((n, 2 * SAMPLER_N1), np.float32)
+        _check(lib.ctl_sequence_generator_compute_many_device(self._h, u32(n), _fp(t1), _fp(t2)))
+        return t1, t2

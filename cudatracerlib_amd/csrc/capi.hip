@@ -2,6 +2,7 @@
 // error convention, Defines.cpp:15-29) are mapped to ctl_status codes + ctl_last_error().
 #include "../../include/ctl_amd.h"
 #include "tracer.h"
+#include "kernels.h"
 #include "scene_builder.h"
 #include "mitsuba_loader.h"
 #include "flatten.h"
@@ -161,6 +162,25 @@ int ctl_sequence_generator_compute_many(ctl_sequence_generator* g, uint32_t n_pa
     CTL_REQUIRE(g && tables_1d && tables_2d, "null argument");
     const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH;
     CTL_TRY g->g.compute_many(tables_1d, tables_2d, n_passes, n1, 2 * n1, threads); CTL_CATCH
+}
+int ctl_sequence_generator_compute_many_device(ctl_sequence_generator* g, uint32_t n_passes, float* tables_1d, float* tables_2d) {
+    CTL_REQUIRE(g && tables_1d && tables_2d, "null argument");
+    const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH;
+    CTL_TRY
+        require_device();
+        if (n_passes == 0) return CTL_OK;
+        std::vector<sequence_generator::pass_start> starts(n_passes);
+        g->g.take_pass_starts(n_passes, starts.data());
+        const std::vector<uint32_t>& J = sequence_generator::chunk_jump_matrices();
+        dbuf<uint32_t> dj, ds; dbuf<float> d1, d2;
+        dj.alloc(J.size()); ds.alloc(starts.size() * sizeof(sequence_generator::pass_start) / 4); d1.alloc(n1 * n_passes); d2.alloc(2 * n1 * n_passes);
+        CTL_HIP(hipMemcpy(dj.p, J.data(), J.size() * 4, hipMemcpyHostToDevice));
+        CTL_HIP(hipMemcpy(ds.p, starts.data(), starts.size() * sizeof(sequence_generator::pass_start), hipMemcpyHostToDevice));
+        launch_sequence_fill(nullptr, dj.p, ds.p, n_passes, d1.p, d2.p);
+        CTL_HIP(hipDeviceSynchronize());
+        CTL_HIP(hipMemcpy(tables_1d, d1.p, n1 * n_passes * 4, hipMemcpyDeviceToHost));
+        CTL_HIP(hipMemcpy(tables_2d, d2.p, 2 * n1 * n_passes * 4, hipMemcpyDeviceToHost));
+    CTL_CATCH
 }
 
 // ---- image

@@ -57,6 +57,9 @@ struct pass_params {
 
 struct launch_ctx { hipStream_t stream; int grid_blocks; bool alpha_test = false; };   // alpha_test: intersect kernels run Material::AlphaTest on candidate hits
 
+// sampling-sequence tables of n_passes passes written to (t1, t2) in HBM; jumps = sequence_generator::chunk_jump_matrices(), starts = n_passes x sequence_generator::pass_start
+void launch_sequence_fill(hipStream_t stream, const uint32_t* jumps, const void* starts, uint32_t n_passes, float* t1, float* t2);
+
 // measurement knobs (environment: CTL_REFILL_IDLE), applied once per process
 void apply_tuning_from_env();
 void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P);

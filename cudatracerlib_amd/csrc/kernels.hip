@@ -110,6 +110,44 @@ __global__ void k_accumulate_stats(wave_queues Q, int max_depth) {
     }
 }
 
+// ---- sampling-sequence tables of a batch of passes, generated in HBM (sequence_generator.h: the same single XORWOW stream the host generator draws from,
+// Kernel/Sampler.h:57-85).  One lane = one chunk of 16 sequences = 1440 consecutive draws; its start state is two GF(2) jumps from the pass's start state.
+struct seq_pass_start { uint32_t v[5]; uint32_t d; };
+__device__ __forceinline__ void xorwow_jump(const uint32_t* __restrict__ M, uint32_t* v) {   // v <- M v over GF(2); M: 160 rows x 5 words, row = image of a state bit
+    uint32_t o[5] = { 0, 0, 0, 0, 0 };
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 32; j++) if (v[i] & (1u << j)) { const uint32_t* r = M + (i * 32 + j) * 5; for (int k = 0; k < 5; k++) o[k] ^= r[k]; }
+    for (int k = 0; k < 5; k++) v[k] = o[k];
+}
+__global__ __launch_bounds__(kBlock) void k_sequence_fill(const uint32_t* __restrict__ jumps, const seq_pass_start* __restrict__ starts, uint32_t n_passes,
+                                                           float* __restrict__ t1, float* __restrict__ t2) {
+    constexpr uint32_t N = CTL_SAMPLER_NUM_SEQUENCES, L = CTL_SAMPLER_SEQUENCE_LENGTH, kSeq = 16, kChunks = N / kSeq, kDraws = kSeq * L * 3;
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n_passes * kChunks) return;
+    const uint32_t pass = g / kChunks, c = g % kChunks;
+    uint32_t v[5]; for (int k = 0; k < 5; k++) v[k] = starts[pass].v[k];
+    uint32_t d = starts[pass].d + 362437u * (kDraws * c);   // the Weyl counter advances linearly
+    xorwow_jump(jumps + (c & 15u) * 800u, v);
+    xorwow_jump(jumps + (16u + (c >> 4)) * 800u, v);
+    auto uniform = [&]() {   // xorwow::next + uniform (sequence_generator.h; Base/CudaRandom.h:112-127)
+        const uint32_t t = (v[0] ^ (v[0] >> 2));
+        v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = v[4];
+        v[4] = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+        d += 362437u;
+        const float inv = 2.3283064e-10f;
+        const float f = (float)(v[4] + d) * inv + (inv / 2.0f);
+        return f * (1 - 1e-5f);
+    };
+    float* p1 = t1 + (size_t)pass * N * L; float* p2 = t2 + (size_t)pass * N * L * 2;
+    for (uint32_t s = c * kSeq; s < (c + 1) * kSeq; s++) {
+        for (uint32_t i = 0; i < L; i++) p1[i * N + s] = uniform();
+        for (uint32_t i = 0; i < L; i++) { const float y = uniform(), x = uniform(); p2[2 * (i * N + s)] = x; p2[2 * (i * N + s) + 1] = y; }   // .y is drawn first (Sampler.h:83)
+    }
+}
+void launch_sequence_fill(hipStream_t stream, const uint32_t* jumps, const void* starts, uint32_t n_passes, float* t1, float* t2) {
+    const uint32_t lanes = n_passes * (CTL_SAMPLER_NUM_SEQUENCES / 16);
+    hipLaunchKernelGGL(k_sequence_fill, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, jumps, (const seq_pass_start*)starts, n_passes, t1, t2);
+}
+
 // copySamplesToOutput (Kernel/ImagePipeline/ImagePipeline.cu:14-30) up to the linear-RGB value (PixelData::toSpectrum, Engine/Image.h:21-28)
 __global__ __launch_bounds__(kBlock) void k_resolve_rgb(const ctl_pixel_data* __restrict__ image, uint32_t n, float splat_scale, float* __restrict__ out) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {

@@ -105,6 +105,33 @@ public:
     sequence_generator() { rng_.init(1234, 7539414); }
     // tables for the next pass: t1[e*4096 + s], t2[2*(e*4096 + s) + {0,1}]
     void compute(float* t1, float* t2) { fill(rng_, t1, t2); }
+    // ---- generation on the GPU (k_sequence_fill, kernels.hip): the host only advances the stream.
+    // A pass is cut into kChunks chunks of kSeqPerChunk sequences; chunk c = 16 a + b starts (90 * kSeqPerChunk * c) draws into the pass, reached
+    // from the pass's start state with two jump matrices, hi[a] = step^(draws(16 a)) and lo[b] = step^(draws(b)).
+    static constexpr unsigned kSeqPerChunk = 16, kChunks = N / kSeqPerChunk;   // 256 chunks of 1440 draws
+    static constexpr uint32_t kDrawsPerChunk = kSeqPerChunk * L * 3;
+    struct pass_start { uint32_t v[5]; uint32_t d; };
+    // start states of the next n passes; the generator moves on by n passes
+    void take_pass_starts(unsigned n, pass_start* out) {
+        if (!have_jump_) { pass_jump_ = xorwow_matrix::power(kDrawsPerPass); have_jump_ = true; }
+        for (unsigned k = 0; k < n; k++) {
+            std::memcpy(out[k].v, rng_.v, 20); out[k].d = rng_.d;
+            xorwow nx = rng_; pass_jump_.apply(rng_.v, nx.v); nx.d = rng_.d + (uint32_t)(362437u * (uint32_t)kDrawsPerPass); rng_ = nx;
+        }
+    }
+    // 32 matrices x 160 rows x 5 words: lo[0..15] then hi[0..15]
+    static const std::vector<uint32_t>& chunk_jump_matrices() {
+        static const std::vector<uint32_t> M = [] {
+            std::vector<uint32_t> m; m.reserve(32 * 800);
+            const xorwow_matrix lo1 = xorwow_matrix::power(kDrawsPerChunk), hi1 = xorwow_matrix::power((uint64_t)kDrawsPerChunk * 16);
+            for (const xorwow_matrix* step : { &lo1, &hi1 }) {
+                xorwow_matrix cur = xorwow_matrix::power(0);
+                for (int k = 0; k < 16; k++) { m.insert(m.end(), cur.r.begin(), cur.r.end()); cur = cur.then(*step); }
+            }
+            return m;
+        }();
+        return M;
+    }
     // tables of the next n passes, generated by up to `threads` host threads.  The stream is the same single XORWOW stream the
     // reference draws from: pass k starts kDrawsPerPass * k draws further on, reached with the GF(2) jump matrix of one pass
     // (the Weyl counter d advances linearly).

@@ -174,13 +174,15 @@ protected:
     virtual void DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) = 0;
     virtual void takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) = 0;
     dbuf<float> d_t1, d_t2;                       // ring of sampler-table sets in HBM
-    float *h_t1 = nullptr, *h_t2 = nullptr; size_t h_cap = 0;   // their pinned host staging
+    float *h_t1 = nullptr, *h_t2 = nullptr; size_t h_cap = 0;   // their pinned host staging (tables handed in by setSamplerTables, host-generated tables)
+    // tables generated in HBM (k_sequence_fill): the chunk jump matrices, and a ring of the batches' pass start states
+    dbuf<uint32_t> d_jumps, d_starts; sequence_generator::pass_start* h_starts = nullptr; size_t starts_cap = 0;
     std::vector<hipEvent_t> slot_done;
     virtual unsigned int passBatch() const { return 1; }
     static constexpr unsigned int kTableRing = 2;
     void ensureTableRing(unsigned int B);   // device + pinned host staging for `kTableRing` batches of B passes
 public:
-    ~Tracer() override { if (h_t1) (void)hipHostFree(h_t1); if (h_t2) (void)hipHostFree(h_t2); for (auto e : slot_done) (void)hipEventDestroy(e); }
+    ~Tracer() override { if (h_t1) (void)hipHostFree(h_t1); if (h_t2) (void)hipHostFree(h_t2); if (h_starts) (void)hipHostFree(h_starts); for (auto e : slot_done) (void)hipEventDestroy(e); }
 };
 
 // Integrators/PseudoRealtime/WavefrontPathTracer.h:24-67

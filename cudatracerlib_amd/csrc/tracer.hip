@@ -410,12 +410,22 @@ template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::ensureTableRing(unsigned i
     const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH, n2 = n1 * 2;
     const unsigned int ring = kTableRing;
     if (d_t1.n < n1 * ring * B) { d_t1.alloc(n1 * ring * B); d_t2.alloc(n2 * ring * B); }
-    if (h_cap < n1 * ring * B) {   // pinned staging so that the uploads really are asynchronous
+    if (h_cap < n1 * ring) {   // pinned staging for the one pass per batch whose tables the caller may hand in (setSamplerTables)
         if (h_t1) { (void)hipHostFree(h_t1); (void)hipHostFree(h_t2); h_t1 = h_t2 = nullptr; }
-        CTL_HIP(hipHostMalloc((void**)&h_t1, n1 * ring * B * sizeof(float))); CTL_HIP(hipHostMalloc((void**)&h_t2, n2 * ring * B * sizeof(float)));
-        h_cap = n1 * ring * B;
+        CTL_HIP(hipHostMalloc((void**)&h_t1, n1 * ring * sizeof(float))); CTL_HIP(hipHostMalloc((void**)&h_t2, n2 * ring * sizeof(float)));
+        h_cap = n1 * ring;
     }
     if (slot_done.empty()) { slot_done.resize(ring); for (auto& e : slot_done) CTL_HIP(hipEventCreate(&e)); }
+    if (starts_cap < (size_t)ring * B) {
+        if (h_starts) { (void)hipHostFree(h_starts); h_starts = nullptr; }
+        CTL_HIP(hipHostMalloc((void**)&h_starts, (size_t)ring * B * sizeof(sequence_generator::pass_start)));
+        d_starts.alloc((size_t)ring * B * sizeof(sequence_generator::pass_start) / sizeof(uint32_t));
+        starts_cap = (size_t)ring * B;
+    }
+    if (!d_jumps.p) {
+        const std::vector<uint32_t>& J = sequence_generator::chunk_jump_matrices();
+        d_jumps.alloc(J.size()); CTL_HIP(hipMemcpy(d_jumps.p, J.data(), J.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
 }
 template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_NewTrace, unsigned int n) {
     if (!m_pScene) throw std::runtime_error("DoPass: InitializeScene was not called");
@@ -441,15 +451,24 @@ template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_
     for (unsigned int k = 0; k < n; batch_idx++) {
         const unsigned int nb = std::min(B, n - k), slot = batch_idx % ring;
         if (batch_idx >= ring) CTL_HIP(hipEventSynchronize(slot_done[slot]));   // the batch that last used this slot has finished
-        float* a = h_t1 + (size_t)slot * B * n1; float* b = h_t2 + (size_t)slot * B * n2;
+        // One XORWOW stream as in the reference (Kernel/Sampler.h:57-85).  The host only advances it (one GF(2) jump per pass); the tables of the batch are
+        // written in HBM by k_sequence_fill — 256 lanes per pass, each two jumps and 1440 draws from the pass's start state — in the time the host threads
+        // needed for one pass, and without the 1.5 MB-per-pass upload (measured: 1.9 ms at the head of every 20-pass call -> 0.1 ms).
+        float* dst1 = d_t1.p + (size_t)slot * B * n1; float* dst2 = d_t2.p + (size_t)slot * B * n2;
         unsigned int j0 = 0;
-        if (have_user_tables) { std::memcpy(a, user_t1.data(), n1 * 4); std::memcpy(b, user_t2.data(), n2 * 4); have_user_tables = false; j0 = 1; }
-        // one XORWOW stream as in the reference (Kernel/Sampler.h:57-85), generated by several host threads through skip-ahead:
-        // the first batch of a call cannot overlap with rendering, and a rank that owns 1/8 of the frame renders 64 passes in 75 ms: one thread
-        // per pass (measured: 16 threads left 4-5 ms of every DoPasses call to table generation)
-        m_SamplingSequenceGenerator.compute_many(a + j0 * n1, b + j0 * n2, nb - j0, n1, n2, std::min(64u, std::max(1u, std::thread::hardware_concurrency())));
-        CTL_HIP(hipMemcpyAsync(d_t1.p + (size_t)slot * B * n1, a, (size_t)nb * n1 * 4, hipMemcpyHostToDevice, stream));
-        CTL_HIP(hipMemcpyAsync(d_t2.p + (size_t)slot * B * n2, b, (size_t)nb * n2 * 4, hipMemcpyHostToDevice, stream));
+        if (have_user_tables) {   // setSamplerTables: the caller's tables serve the first pass of the call
+            float* a = h_t1 + (size_t)slot * n1; float* b = h_t2 + (size_t)slot * n2;
+            std::memcpy(a, user_t1.data(), n1 * 4); std::memcpy(b, user_t2.data(), n2 * 4); have_user_tables = false; j0 = 1;
+            CTL_HIP(hipMemcpyAsync(dst1, a, n1 * 4, hipMemcpyHostToDevice, stream));
+            CTL_HIP(hipMemcpyAsync(dst2, b, n2 * 4, hipMemcpyHostToDevice, stream));
+        }
+        if (nb > j0) {
+            sequence_generator::pass_start* hs = h_starts + (size_t)slot * B;
+            uint32_t* ds = d_starts.p + (size_t)slot * B * (sizeof(sequence_generator::pass_start) / sizeof(uint32_t));
+            m_SamplingSequenceGenerator.take_pass_starts(nb - j0, hs);
+            CTL_HIP(hipMemcpyAsync(ds, hs, (size_t)(nb - j0) * sizeof(sequence_generator::pass_start), hipMemcpyHostToDevice, stream));
+            launch_sequence_fill(stream, d_jumps.p, ds, nb - j0, dst1 + (size_t)j0 * n1, dst2 + (size_t)j0 * n2);
+        }
         m_uPassesDone += nb;
         std::vector<unsigned char> block_counts;
         pass_block_counts_ = nullptr; pass_max_block_count_ = 1;

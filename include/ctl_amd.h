@@ -355,6 +355,9 @@ int ctl_sequence_generator_compute(ctl_sequence_generator* g, float* tables_1d, 
 /* the tables of the next n_passes passes (consecutive [30*4096] / [30*4096*2] blocks), generated by up to `threads` host
  * threads; same values as n_passes calls of ctl_sequence_generator_compute (XORWOW skip-ahead) */
 int ctl_sequence_generator_compute_many(ctl_sequence_generator* g, uint32_t n_passes, float* tables_1d, float* tables_2d, uint32_t threads);
+/* The same tables written in HBM by the kernel the tracers use (k_sequence_fill: the host only advances the stream) and copied back: bit-identical to
+ * ctl_sequence_generator_compute_many.  Needs a HIP device. */
+int ctl_sequence_generator_compute_many_device(ctl_sequence_generator* g, uint32_t n_passes, float* tables_1d, float* tables_2d);
 
 /* -------------------------------------------------------------------- image */
 typedef struct ctl_image ctl_image;

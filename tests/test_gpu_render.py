@@ -428,3 +428,16 @@ def test_first_hit_ray_differentials_and_filtered_textures(gpu, orc, filter_mode
     assert frac_close(mega, want_filtered) >= 0.99, frac_close(mega, want_filtered)
     assert abs(mega[..., :3].mean() - want_filtered[..., :3].mean()) <= 2e-3 * want_filtered[..., :3].mean()
     assert frac_close(mega, want_plain) < 0.9 and frac_close(want_filtered, want_plain) < 0.9          # the filtering is visible: the distant ground differs
+
+
+def test_sequence_tables_generated_on_the_gpu_equal_the_host_generator(gpu):
+    """k_sequence_fill (256 lanes per pass, two GF(2) jumps + 1440 draws each) against the host generator on the same XORWOW stream
+    (SamplingSequenceGeneratorHost<IndependantSamplingSequenceGenerator>, Kernel/Sampler.h:36-85): bit for bit, and the stream goes on correctly"""
+    host, dev = gpu.SequenceGenerator(), gpu.SequenceGenerator()
+    for n in (1, 3, 5):
+        h1, h2 = host.compute_many(n, threads=4)
+        d1, d2 = dev.compute_many_device(n)
+        assert np.array_equal(h1.view(np.uint32), d1.view(np.uint32))
+        assert np.array_equal(h2.view(np.uint32), d2.view(np.uint32))
+    a1, a2 = host.compute(); b1, b2 = dev.compute()               # both generators stand at the same place of the stream afterwards
+    assert np.array_equal(a1, b1) and np.array_equal(a2, b2)
