@@ -126,7 +126,7 @@ def calibrated_traffic(workload_key):
     return e
 
 
-KERNEL_BUILD = "r02-flat-q4-exact"   # changes when the traversal kernel or the flattened layout changes: a traffic profile of another build is not quoted
+KERNEL_BUILD = "r02-flat-q4-exact-pair"   # changes when the traversal kernel or the flattened layout changes: a traffic profile of another build is not quoted
 
 
 def main():
@@ -240,7 +240,8 @@ def main():
     k_ms_closest, k_ms_any = st.ms_intersect, st.ms_intersect_any
     n_closest, n_any = int(st.intersect_rays), int(st.shadow_rays)
     launches_closest = int(st.intersect_launches)
-    fused_launches, fused_any = int(st.fused_launches), int(st.fused_shadow_rays)   # small launches trace path rays + the previous bounce's shadow rays together
+    # FuseTraversal (default): bounce d's path rays and bounce d-1's shadow rays share one persistent launch; those launches are the dominant kernel then
+    fused_launches, fused_any, fused_closest, k_ms_fused = int(st.fused_launches), int(st.fused_shadow_rays), int(st.fused_closest_rays), st.ms_fused
     if world > 1:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
@@ -266,33 +267,44 @@ def main():
         else:
             per_ray = gpu_counts; count_source = "GPU counting kernel (the oracle leg is off)"
         per_ray_closest = 48.0 + 64.0 * per_ray["n_inner"] + 52.0 * per_ray["n_tri"] + 108.0 * per_ray["n_inst"]
-        per_ray_any = b_ray(cs.any_counts, cs.shadow_rays) / max(1, cs.shadow_rays)
-        # dominant kernel = closest-hit intersect: bytes per launch / average launch duration (HIP events on the tracer's stream)
-        avg_launch_ms = k_ms_closest / max(1, launches_closest)
-        rays_per_launch = n_closest / max(1, launches_closest)
-        # fused launches (FuseTraversal: fewer than 32 M paths per launch, i.e. a tile shard of a multi-GPU render) also carry shadow rays: their bytes count too
-        bytes_per_launch = (per_ray_closest * n_closest + per_ray_any * fused_any) / max(1, launches_closest)
+        any_visits = {"n_inner": cs.any_counts.n_inner / max(1, cs.shadow_rays), "n_tri": cs.any_counts.n_tri / max(1, cs.shadow_rays), "n_inst": cs.any_counts.n_inst / max(1, cs.shadow_rays)}
+        # (the oracle's shadow test is the megakernel's Occluded = a full closest-hit search, KernelDynamicScene.cu:70-80; the wavefront's any-hit traversal stops at the
+        #  first hit, so the shadow rays' visits are taken from the any-hit kernel's own counting instantiation)
+        per_ray_any = 48.0 + 64.0 * any_visits["n_inner"] + 52.0 * any_visits["n_tri"] + 108.0 * any_visits["n_inst"]
+        if fused_launches:
+            # dominant kernel = k_intersect_pair: algorithmic bytes of the path rays AND the shadow rays of a launch / average launch duration (HIP events on the tracer's stream)
+            avg_launch_ms = k_ms_fused / fused_launches
+            rays_per_launch = (fused_closest + fused_any) / fused_launches
+            bytes_per_launch = (per_ray_closest * fused_closest + per_ray_any * fused_any) / fused_launches
+            records_per_launch = ((per_ray["n_inner"] + per_ray["n_tri"]) * fused_closest + (any_visits["n_inner"] + any_visits["n_tri"]) * fused_any) / fused_launches
+            launches_dom = fused_launches
+        else:
+            # dominant kernel = closest-hit intersect: bytes per launch / average launch duration
+            avg_launch_ms = k_ms_closest / max(1, launches_closest)
+            rays_per_launch = n_closest / max(1, launches_closest)
+            bytes_per_launch = per_ray_closest * rays_per_launch
+            records_per_launch = (per_ray["n_inner"] + per_ray["n_tri"]) * rays_per_launch
+            launches_dom = launches_closest
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        any_records = (cs.any_counts.n_inner + cs.any_counts.n_tri) / max(1, cs.shadow_rays)
-        records_per_s = ((per_ray["n_inner"] + per_ray["n_tri"]) * n_closest + any_records * fused_any) / max(1, launches_closest) / (avg_launch_ms * 1e-3) if avg_launch_ms > 0 else 0.0
+        records_per_s = records_per_launch / (avg_launch_ms * 1e-3) if avg_launch_ms > 0 else 0.0
         wl_key = "%s %dx%d depth %d" % (args.workload, args.width, args.height, args.depth) + ("" if args.workload != "synthetic-sm" else " %d inst subdiv %d" % (args.instances, args.subdiv)) + (" flat" if args.flatten else " two-level")
         cal = calibrated_traffic(wl_key)
-        if fused_launches:
-            cal = None   # the calibration is per ray of the plain closest-hit kernel
         traffic = cal["bytes_per_ray"] * rays_per_launch if cal else None
         frac = achieved / HBM_PEAK_GBS
-        roof = {"bound": "hbm", "kernel": "k_intersect<closest>" if not fused_launches else "k_intersect_pair (closest hits of bounce d + occlusion of bounce d-1 in one launch; %d of the %d launches)" % (fused_launches, launches_closest), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": "k_intersect<closest>" if not fused_launches else "k_intersect_pair (closest hits of bounce d + occlusion of bounce d-1 in one persistent launch)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(frac, 4), "saturated": bool(frac >= 0.9), "traffic": traffic,
                 "hbm_frac_measured": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None,
                 "l2_hit_rate": cal.get("l2_hit_rate") if cal else None, "traffic_profile": cal.get("tag") if cal else None, "workload_key": wl_key, "kernel_build": KERNEL_BUILD,
-                "bytes_per_ray": round(per_ray_closest, 1), "per_ray": {k: round(v, 2) for k, v in per_ray.items()}, "per_ray_source": count_source,
+                "bytes_per_ray": round(bytes_per_launch / max(1.0, rays_per_launch), 1), "bytes_per_path_ray": round(per_ray_closest, 1), "bytes_per_shadow_ray": round(per_ray_any, 1),
+                "per_ray": {k: round(v, 2) for k, v in per_ray.items()}, "per_shadow_ray": {k: round(v, 2) for k, v in any_visits.items()}, "per_ray_source": count_source, "per_shadow_ray_source": "GPU any-hit counting kernel",
                 "per_ray_gpu_visited": {k: round(v, 2) for k, v in gpu_counts.items()},
                 "records_per_s": round(records_per_s / 1e9, 2), "records_per_s_unit": "G node+leaf records/s (gather ceilings, tools/gather_probe.hip: ~58 G/s from HBM, ~170 G/s from L2)",
                 "lane_utilisation": {"inner": round(cs.closest_counts.n_inner / max(1, 64 * cs.closest_counts.wave_inner_iters), 3), "tri": round(cs.closest_counts.n_tri / max(1, 64 * cs.closest_counts.wave_tri_iters), 3)},
-                "rays_per_launch": int(rays_per_launch), "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches_closest,
-                "shadow_kernel": {"bytes_per_ray": round(per_ray_any, 1), "rays": n_any - fused_any, "rays_in_fused_launches": fused_any, "ms": round(k_ms_any, 3),
-                                  "achieved": round(per_ray_any * (n_any - fused_any) / (k_ms_any * 1e-3) / 1e9, 2) if k_ms_any > 0 else 0.0},
-                "ms_intersect": round(k_ms_closest, 3), "ms_shade": round(st.ms_shade, 3), "ms_raygen": round(st.ms_raygen, 3)}
+                "rays_per_launch": int(rays_per_launch), "path_rays_per_launch": int(fused_closest / fused_launches) if fused_launches else int(rays_per_launch),
+                "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches_dom,
+                "separate_launches": {"closest_hit": {"rays": n_closest - fused_closest, "ms": round(k_ms_closest, 3), "launches": launches_closest},
+                                      "any_hit": {"rays": n_any - fused_any, "ms": round(k_ms_any, 3)}},
+                "ms_intersect": round(k_ms_closest + k_ms_fused + k_ms_any, 3), "ms_shade": round(st.ms_shade, 3), "ms_raygen": round(st.ms_raygen, 3)}
         out = {
             "metric": "Mrays/s at %dx%d, %d spp (steps), depth-%d; achieved HBM GB/s vs peak" % (args.width, args.height, args.steps, args.depth),
             "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -86,7 +86,7 @@ class ctl_tracer_stats(C.Structure):
     _fields_ = [("rays_last_pass", u64), ("rays_total", u64), ("seconds_last_pass", C.c_double), ("seconds_total", C.c_double), ("passes_done", u32),
                 ("ms_intersect", C.c_double), ("ms_shade", C.c_double), ("ms_raygen", C.c_double), ("ms_intersect_any", C.c_double),
                 ("intersect_rays", u64), ("intersect_launches", u64), ("shadow_rays", u64), ("shadow_launches", u64),
-                ("closest_counts", ctl_traversal_counts), ("any_counts", ctl_traversal_counts), ("fused_launches", u64), ("fused_shadow_rays", u64)]
+                ("closest_counts", ctl_traversal_counts), ("any_counts", ctl_traversal_counts), ("fused_launches", u64), ("fused_shadow_rays", u64), ("fused_closest_rays", u64), ("ms_fused", C.c_double)]
 
 
 class ctl_scene_desc(C.Structure):

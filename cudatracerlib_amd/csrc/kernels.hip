@@ -106,7 +106,8 @@ __global__ void k_accumulate_stats(wave_queues Q, int max_depth) {
         unsigned long long r = 0, s = 0;
         for (int d = 0; d <= max_depth; d++) { r += (unsigned long long)Q.counts[d * 4 + 0]; s += (unsigned long long)Q.counts[d * 4 + 1]; }
         Q.stats[0] += r; Q.stats[1] += s;
-        Q.stats[12] += (unsigned long long)Q.counts[max_depth * 4 + 1];   // the shadow rays of the last bounce: always their own launch (tracer.hip)
+        Q.stats[12] += (unsigned long long)Q.counts[max_depth * 4 + 1];   // the shadow rays of the last bounce and the path rays of the first: always their own launches (tracer.hip)
+        Q.stats[13] += (unsigned long long)Q.counts[0];
     }
 }
 

@@ -111,7 +111,7 @@ public:
     ~event_timer();
     void begin(hipStream_t s, int cls);
     void end(hipStream_t s);
-    void collect(double ms_out[4]);   // adds elapsed ms per class, recycles the events
+    void collect(double ms_out[5]);   // adds elapsed ms per class, recycles the events
 private:
     struct rec { hipEvent_t a, b; int cls; };
     std::vector<rec> used_; std::vector<hipEvent_t> free_;
@@ -156,8 +156,8 @@ protected:
     std::vector<float> user_t1, user_t2; bool have_user_tables = false;
     uint32_t shard_rank = 0, shard_world = 1;
     std::unique_ptr<BlockSampler> block_sampler_; const unsigned char* pass_block_counts_ = nullptr; uint32_t pass_max_block_count_ = 1; uint64_t pass_paths_ = 0;
-    event_timer timer; double kernel_ms[4] = { 0, 0, 0, 0 };   // 0 raygen, 1 closest-hit intersect, 2 shade/finalize, 3 any-hit intersect
-    uint64_t intersect_rays = 0, intersect_launches = 0, shadow_rays = 0, shadow_launches = 0, fused_launches = 0, fused_shadow_rays = 0;
+    event_timer timer; double kernel_ms[5] = { 0, 0, 0, 0, 0 };   // 0 raygen, 1 closest-hit intersect, 2 shade/finalize, 3 any-hit intersect, 4 fused closest + any-hit launches
+    uint64_t intersect_rays = 0, intersect_launches = 0, shadow_rays = 0, shadow_launches = 0, fused_launches = 0, fused_shadow_rays = 0, fused_closest_rays = 0;
     bool counting = false; ctl_traversal_counts closest_counts{}, any_counts{};
 public:
     void setCounting(bool on) { counting = on; }

@@ -364,7 +364,7 @@ event_timer::~event_timer() { for (auto& r : used_) { (void)hipEventDestroy(r.a)
 hipEvent_t event_timer::get() { if (!free_.empty()) { hipEvent_t e = free_.back(); free_.pop_back(); return e; } hipEvent_t e; CTL_HIP(hipEventCreate(&e)); return e; }
 void event_timer::begin(hipStream_t s, int cls) { rec r{ get(), get(), cls }; CTL_HIP(hipEventRecord(r.a, s)); used_.push_back(r); }
 void event_timer::end(hipStream_t s) { CTL_HIP(hipEventRecord(used_.back().b, s)); }
-void event_timer::collect(double ms_out[4]) {
+void event_timer::collect(double ms_out[5]) {
     for (auto& r : used_) { float ms = 0; CTL_HIP(hipEventElapsedTime(&ms, r.a, r.b)); ms_out[r.cls] += ms; free_.push_back(r.a); free_.push_back(r.b); }
     used_.clear();
 }
@@ -398,8 +398,8 @@ void TracerBase::setSamplerTables(const float* t1, const float* t2) {
 void TracerBase::getKernelStats(ctl_tracer_stats& s) const {
     std::memset(&s, 0, sizeof(s));
     s.rays_last_pass = m_uLastNumRaysTraced; s.rays_total = m_uAccNumRaysTraced; s.seconds_last_pass = m_fLastRuntime; s.seconds_total = m_fAccRuntime;
-    s.passes_done = m_uPassesDone; s.ms_raygen = kernel_ms[0]; s.ms_intersect = kernel_ms[1]; s.ms_shade = kernel_ms[2]; s.ms_intersect_any = kernel_ms[3];
-    s.intersect_rays = intersect_rays; s.intersect_launches = intersect_launches; s.shadow_rays = shadow_rays; s.shadow_launches = shadow_launches; s.fused_launches = fused_launches; s.fused_shadow_rays = fused_shadow_rays;
+    s.passes_done = m_uPassesDone; s.ms_raygen = kernel_ms[0]; s.ms_intersect = kernel_ms[1]; s.ms_shade = kernel_ms[2]; s.ms_intersect_any = kernel_ms[3]; s.ms_fused = kernel_ms[4];
+    s.intersect_rays = intersect_rays; s.intersect_launches = intersect_launches; s.shadow_rays = shadow_rays; s.shadow_launches = shadow_launches; s.fused_launches = fused_launches; s.fused_shadow_rays = fused_shadow_rays; s.fused_closest_rays = fused_closest_rays;
     s.closest_counts = closest_counts; s.any_counts = any_counts;
 }
 
@@ -444,8 +444,8 @@ template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_
     const unsigned int B = adaptive ? 1u : std::min(passBatch(), n);
     const unsigned int ring = kTableRing;   // batches in flight; slot reuse is guarded by an event per slot
     ensureTableRing(B);
-    for (int i = 0; i < 4; i++) kernel_ms[i] = 0;
-    intersect_rays = intersect_launches = shadow_rays = shadow_launches = fused_launches = fused_shadow_rays = 0;
+    for (int i = 0; i < 5; i++) kernel_ms[i] = 0;
+    intersect_rays = intersect_launches = shadow_rays = shadow_launches = fused_launches = fused_shadow_rays = fused_closest_rays = 0;
     CTL_HIP(hipEventRecord(start, stream));
     unsigned int batch_idx = 0;
     for (unsigned int k = 0; k < n; batch_idx++) {
@@ -516,10 +516,9 @@ WavefrontPathTracer::WavefrontPathTracer() {
     // Off by default: measured on synthetic-SM the traversal kernels gain 1 % (6.10 -> 6.05 ms / pass) and the shade kernel pays 0.5 ms for it
     m_sParameters.addBool("SortOctants", false);
     // build-specific: trace a bounce's path rays and the previous bounce's shadow rays in one persistent launch (k_intersect_pair).  Every traversal launch
-    // pays ~0.4 ms of ramp and drain whatever its size (tools/shard_time_probe.py: one rank of eight spends a quarter of its time there); the fused launch
-    // fills the drain of the first set with the second.  0 = when a launch carries fewer than 32 M paths (a tile shard of a multi-GPU render, DoPass(1)),
-    // 1 = never, 2 = always.  Large launches stay separate so that the closest-hit kernel can be timed on its own (bench.py's roofline)
-    m_sParameters.addInterval("FuseTraversal", 0, 0, 2);
+    // pays ~0.4 ms of ramp and drain whatever its size (tools/shard_time_probe.py: 4 % of the time at 20 passes per launch on one GPU, a quarter on one rank
+    // of eight); the fused launch fills the drain of the first set with the second: +2 % on the whole frame, +7 % on a rank of eight.  false = two launches
+    m_sParameters.addBool("FuseTraversal", true);
     int dev = 0; hipDeviceProp_t prop; CTL_HIP(hipGetDevice(&dev)); CTL_HIP(hipGetDeviceProperties(&prop, dev));
     grid_blocks = prop.multiProcessorCount * 8;   // 8 x 256-thread workgroups per CU = 32 waves/CU
 }
@@ -539,7 +538,7 @@ void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
     }
     Q.hit = new_f4(capacity); hit_node_.alloc(capacity); Q.hit_node = hit_node_.p;
     Q.fin.rad = new_f4(capacity); Q.fin.dir = new_f4(capacity); px_[2].alloc(capacity); Q.fin.px = px_[2].p;
-    stats_.alloc(13); Q.stats = stats_.p; CTL_HIP(hipMemset(stats_.p, 0, 13 * sizeof(unsigned long long)));
+    stats_.alloc(14); Q.stats = stats_.p; CTL_HIP(hipMemset(stats_.p, 0, 14 * sizeof(unsigned long long)));
     Q.capacity = capacity;
     order_.alloc(capacity); Q.order = order_.p; mat_key_.alloc(capacity); Q.mat_key = mat_key_.p;
     counts_.free(); work_.free(); mat_counts_.free();
@@ -547,11 +546,11 @@ void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
 
 // stats: [0] path rays, [1] shadow rays, [2..6] closest-hit traversal counts, [7..11] any-hit traversal counts
 void WavefrontPathTracer::takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) {
-    unsigned long long r[13];   // [12]: shadow rays of the last bounce (never part of a fused launch)
+    unsigned long long r[14];   // [12]: shadow rays of the last bounce, [13]: path rays of the first (never part of a fused launch)
     CTL_HIP(hipMemcpy(r, stats_.p, sizeof(r), hipMemcpyDeviceToHost));
     CTL_HIP(hipMemset(stats_.p, 0, sizeof(r)));
     path_rays = r[0]; shadow_rays_ = r[1];
-    fused_shadow_rays = fused_launches ? r[1] - r[12] : 0;
+    fused_shadow_rays = fused_launches ? r[1] - r[12] : 0; fused_closest_rays = fused_launches ? r[0] - r[13] : 0;
     closest_counts = ctl_traversal_counts{ r[2], r[3], r[4], r[5], r[6] };
     any_counts = ctl_traversal_counts{ r[7], r[8], r[9], r[10], r[11] };
 }
@@ -603,17 +602,16 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
         timer.end(stream);
         shadow_launches++;
     };
-    const int fuse_mode = m_sParameters.getValue("FuseTraversal");
-    const bool fuse = !counting && direct && (fuse_mode == 2 || (fuse_mode == 0 && (uint64_t)n_local_pixels * n_batch < (32u << 20)));
+    const bool fuse = !counting && direct && m_sParameters.getValue("FuseTraversal") != 0;
     for (int depth = 1; depth <= maxPathLength; depth++) {
         const int cur = (depth - 1) & 1;
         if (fuse && depth > 1) {   // path rays of this bounce + shadow rays of the previous one in one launch
             const int d = depth - 1;
-            timer.begin(stream, 1);
+            timer.begin(stream, 4);
             launch_intersect_pair(lc, S, Q.path[cur].ray_o, Q.path[cur].ray_d, &Q.counts[(depth - 1) * 4 + 0], &Q.work[2 * depth], Q.hit, Q.hit_node,
                                   Q.sh_o[d & 1], Q.sh_d[d & 1], &Q.counts[d * 4 + 1], &Q.work[2 * d + 3], Q.sh_occ[d & 1]);
             timer.end(stream);
-            intersect_launches++; fused_launches++;
+            fused_launches++;
             timer.begin(stream, 2);
             launch_finalize(lc, Q, P, depth - 1, I->device());
             launch_shade(lc, S, Q, P, depth, I->device());

@@ -445,9 +445,12 @@ typedef struct {
     uint64_t shadow_launches;
     /* traversal statistics, filled only while ctl_tracer_set_counting(t, 1): sums over all rays of the call */
     ctl_traversal_counts closest_counts, any_counts;
-    /* small launches trace a bounce's path rays and the previous bounce's shadow rays in ONE persistent launch (parameter FuseTraversal): the launches
-     * that did, and the shadow rays they carried; their time is part of ms_intersect, their count part of intersect_launches */
-    uint64_t fused_launches, fused_shadow_rays;
+    /* FuseTraversal (default): the path rays of bounce d >= 2 and the shadow rays of bounce d - 1 are traced by ONE persistent launch (k_intersect_pair).
+     * Those launches, the rays they carried and their time are reported here; ms_intersect / intersect_launches and ms_intersect_any / shadow_launches
+     * then cover only the launches that stayed separate (the first bounce's path rays, the last bounce's shadow rays).  intersect_rays and shadow_rays
+     * remain the totals of the call. */
+    uint64_t fused_launches, fused_shadow_rays, fused_closest_rays;
+    double ms_fused;
 } ctl_tracer_stats;
 int ctl_tracer_get_stats(ctl_tracer* t, ctl_tracer_stats* out);
 /* Block samplers of Tracer<true> (Kernel/BlockSampler/, Kernel/Tracer.h:209-248; wavefront plugin only).  The int parameter

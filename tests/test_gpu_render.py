@@ -118,7 +118,7 @@ def test_queue_ordering_options_do_not_change_the_image(gpu, orc):
     scene = gpu.Scene(sc.desc, flatten=True)
     tables = orc.sequence_tables(3)
     out = []
-    for params in (dict(), dict(SortMaterials=True), dict(SortOctants=True), dict(SortMaterials=True, SortOctants=True), dict(BlockSort=False), dict(BlockSort=False, SortMaterials=True), dict(FuseTraversal=1), dict(FuseTraversal=2)):
+    for params in (dict(), dict(SortMaterials=True), dict(SortOctants=True), dict(SortMaterials=True, SortOctants=True), dict(BlockSort=False), dict(BlockSort=False, SortMaterials=True), dict(FuseTraversal=False)):
         tr = gpu.WavefrontPathTracer(); p = tr.getParameters(); p.setValue("MaxPathLength", 6)
         for k, v in params.items():
             p.setValue(k, v)

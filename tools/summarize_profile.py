@@ -58,12 +58,12 @@ def main():
             lane = r.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * r["SQ_INSTS_VALU"]) if r.get("SQ_INSTS_VALU") else None
             fh.write("%s,%d,%s,%.0f,%s,%s\n" % (k, r.get("launches", 0), ",".join("%.6g" % r.get(c, 0.0) for c in cols), 2 * r.get("FETCH_SIZE", 0.0) * 1024,
                                                ("%.3f" % (hit / (hit + miss))) if hit + miss > 0 else "", ("%.3f" % lane) if lane else ""))
-    # dominant kernel = closest-hit intersect without counters
+    # dominant kernel = the one bench.py's roofline names: the fused closest + any-hit launch (FuseTraversal, default) or the plain closest-hit intersect
     b = json.load(open(os.path.join(src, "bench.json"))); rf = b["roofline"]
-    dom = [k for k in rows if k.startswith("k_intersect<false, false")]
+    dom = [k for k in rows if k.startswith("k_intersect_pair")] if "pair" in rf.get("kernel", "") else [k for k in rows if k.startswith("k_intersect<false, false")]
     if dom and rf.get("workload_key"):
         k = max(dom, key=lambda k: rows[k].get("FETCH_SIZE", 0)); r = rows[k]
-        # rays of the profiled run's closest-hit launches: timed launches + warm-up launches (same rays per pass)
+        # rays of the profiled run's launches of that kernel (path + shadow rays for the fused kernel): timed launches + warm-up launches (same rays per pass)
         rays_run = rf["rays_per_launch"] * rf["launches"] * (b["steps"] + b["warmup"]) / b["steps"]
         fe_ray, wr_ray = r.get("FETCH_SIZE", 0) * 1024 / rays_run, r.get("WRITE_SIZE", 0) * 1024 / rays_run
         hit, miss = r.get("TCC_HIT_sum", 0.0), r.get("TCC_MISS_sum", 0.0)
@@ -73,7 +73,7 @@ def main():
             if "workloads" not in t: t = {"workloads": {}}
         except Exception:
             t = {"workloads": {}}
-        t["note"] = "HBM-side bytes per ray of the closest-hit traversal kernel = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes) over every closest-hit launch of the profiled bench.py run / the rays of those launches; bench.py quotes an entry only for the same workload key and kernel build"
+        t["note"] = "HBM-side bytes per ray of the dominant traversal kernel (k_intersect_pair: per path-or-shadow ray) = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes) over every launch of that kernel in the profiled bench.py run / the rays of those launches; bench.py quotes an entry only for the same workload key and kernel build"
         t["workloads"][rf["workload_key"]] = {"tag": tag, "kernel": k, "kernel_build": rf.get("kernel_build"), "rays_profiled": rays_run,
                                                "fetch_bytes_per_ray_raw": fe_ray, "write_bytes_per_ray": wr_ray, "bytes_per_ray": 2 * fe_ray + wr_ray,
                                                "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss > 0 else None,
