@@ -40,6 +40,7 @@ public:
     bool flattened() const { return S.flat_nodes != nullptr; }
     dev_scene S{};
     uint32_t n_nodes = 0;
+    float box_min[3] = { 0, 0, 0 }, box_max[3] = { 0, 0, 0 };   // KernelDynamicScene::m_sBox
 private:
     dbuf<float4> top_nodes_, bot_nodes_, leaf_tris_, inst_, inst_fwd_, flat_nodes_, flat_leaves_;
     dbuf<uint4> tri_data_, node_info_;
@@ -213,7 +214,7 @@ protected:
     void DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) override;
     void takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) override;
 private:
-    dbuf<unsigned long long> count_; unsigned long long host_count_ = 0; uint64_t total_rays_ = 0;
+    dbuf<unsigned long long> count_; unsigned long long host_count_ = 0; uint64_t total_rays_ = 0; dbuf<float> mollifier_;
     uint32_t n_local_pixels = 0; int grid_blocks = 0;
 };
 

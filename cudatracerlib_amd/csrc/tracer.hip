@@ -23,6 +23,7 @@ void require_device() { if (device_count() <= 0) throw hip_error("no HIP device:
 
 // ------------------------------------------------------------------------------------------------ Scene
 Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
+    for (int k = 0; k < 3; k++) { box_min[k] = d.box_min[k]; box_max[k] = d.box_max[k]; }
     require_device();
     if (!d.n_nodes) throw std::runtime_error("ctl_scene_create: scene has no nodes");
     if (d.env_map_index != 0xffffffffu && (d.env_map_index >= d.n_lights_buf || d.lights[d.env_map_index].type != CTL_LIGHT_INFINITE))

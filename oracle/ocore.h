@@ -1366,6 +1366,94 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
     return cl;
 }
 
+// ---- PathTraceRegularization<DIRECT> (Integrators/PathTracer.cu:115-173): the PathTracer plugin with Regularization = true
+// Light::samplePosition of the emitters the mollified connection uses (SceneTypes/Light.cu:33-40 point, :304-311 spot, :246-258 distant); area and
+// environment emitters are skipped by the caller (PathTracer.cu:139), so only their sample consumption matters
+inline Spec lightSamplePosition(const ctl_light& L, V2 sample, V3& p) {
+    if (L.type == CTL_LIGHT_POINT || L.type == CTL_LIGHT_SPOT) { p = V3(L.position[0], L.position[1], L.position[2]); return Spec(L.radiance[0], L.radiance[1], L.radiance[2]) * (4 * PI); }
+    if (L.type == CTL_LIGHT_DISTANT) {
+        const V2 q = squareToUniformDiskConcentric(sample);
+        const Frame F = lightFrame(L);
+        const V3 perpOffset = F.toWorld(V3(q.x, q.y, 0) * L.bsphere_radius), d = F.toWorld(V3(0.0f, 0.0f, 1.0f));
+        p = d * L.bsphere_radius + perpOffset;
+        const float surfaceArea = PI * L.bsphere_radius * L.bsphere_radius, invSurfaceArea = 1.0f / surfaceArea;   // Light.h:159-165
+        return Spec(L.radiance[0], L.radiance[1], L.radiance[2]) / invSurfaceArea;                                 // m_power (Light.cu:208-212)
+    }
+    p = V3(0.0f); return Spec(0.0f);
+}
+// UniformSampleAllLights (Kernel/TraceAlgorithms.cu:75-90), nSamples = 1
+inline Spec uniformSampleAllLights(const Scene& S, const BRec& bRec, const ctl_material& mat, Sampler& rng, uint64_t* rays) {
+    Spec L(0.0f);
+    for (unsigned i = 0; i < S.d.num_lights; i++) L = L + estimateDirect(S, bRec, mat, S.d.lights + S.d.light_indices[i], 1.0f, EAll & ~EDelta, rng, rays) / 1.0f;
+    return L;
+}
+// InfiniteLight::evalEnvironment(ray, rX, rY) (SceneTypes/Light.cu:496-518)
+inline Spec envEvalDifferential(const Scene& S, const ctl_light& L, V3 dir, V3 dirX, V3 dirY) {
+    V3 v = transformDirTranspose(L.to_world, dir);
+    V2 uv{ atan2f(v.x, -v.z) * INV_TWOPI, safe_acos(v.y) * INV_PI };
+    V3 dvdx = transformDirTranspose(L.to_world, dirX) - v, dvdy = transformDirTranspose(L.to_world, dirY) - v;
+    float t1 = INV_TWOPI / (v.x * v.x + v.z * v.z), t2 = -INV_PI / fmax2(safe_sqrt(1.0f - v.y * v.y), 1e-4f);
+    V2 dudx{ t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y }, dudy{ t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y };
+    return mipEval(S.d.images[L.env_image], S.pyramids[L.env_image], uv, dudx, dudy) * Spec(L.env_scale[0], L.env_scale[1], L.env_scale[2]);
+}
+inline Spec pathTraceRegularization(const Scene& S, bool DIRECT, V3 ro, V3 rd, V3 rxd, V3 ryd, Sampler& rnd, float g_fRMollifier, int maxPathLength, int rrStartDepth, uint64_t* rays) {
+    Hit r2; r2.init();
+    Spec cl(0.0f), cf(1.0f);
+    int depth = 0; bool specularBounce = false;
+    BRec bRec;
+    for (;;) {   // while (traceRay(r, &r2) && depth++ < maxPathLength)
+        r2 = traceRayClosest(S, ro, rd);
+        if (rays) (*rays)++;
+        if (!(r2.hasHit() && depth++ < maxPathLength)) break;
+        getBsdfSample(S, r2, ro, rd, bRec);
+        if (depth == 1 && S.pyramids) { bRec.dg.pyramids = S.pyramids; computePartials(bRec.dg, ro, rxd, ryd); }
+        const ctl_material& mat = hitMat(S, r2);
+        if (!DIRECT || (depth == 1 || specularBounce)) {
+            uint32_t li = hitLightIndex(S, r2);
+            if (li != UINT32_MAX) cl = cl + cf * lightEval(S, S.d.lights[li], bRec.dg.P, bRec.dg.sys, -rd);   // TraceResult::Le
+        }
+        float pdf_unused;
+        Spec f = bsdfSample(mat, bRec, pdf_unused, rnd.randomFloat2());
+        if (DIRECT) {
+            if (bsdfHasComponent(mat, EDelta)) {   // connect the sampled direction of a BSDF with delta lobes to a point / spot / distant emitter inside a cone that shrinks with the passes
+                V2 sample = rnd.randomFloat2();
+                if (S.d.num_lights) {
+                    float emPdf; const ctl_light* l = sampleEmitter(S, emPdf, sample);   // KernelDynamicScene::sampleEmitterPosition (KernelDynamicScene.cu:156-168)
+                    V3 lp; Spec l_s = lightSamplePosition(*l, sample, lp) / emPdf;
+                    float lDist = length(lp - bRec.dg.P);
+                    V3 lDir = (lp - bRec.dg.P) / lDist;
+                    if (!(l->type == CTL_LIGHT_DIFFUSE || l->type == CTL_LIGHT_INFINITE)) {
+                        if (rays) (*rays)++;
+                        if (!occluded(S, bRec.dg.P, lDir, 0, lDist)) {
+                            float eps = atanf(g_fRMollifier / lDist);
+                            float normalization = 1.0f / (2 * PI * (1 - cosf(eps)));
+                            float l_dot_o = dot(lDir, bRec.dg.sys.toWorld(bRec.wo));
+                            float indicator = acosf(l_dot_o) <= eps ? 1.0f : 0.0f;
+                            cl = cl + cf * f * l_s * (normalization * indicator);
+                        }
+                    }
+                }
+            } else cl = cl + cf * uniformSampleAllLights(S, bRec, mat, rnd, rays);
+        }
+        specularBounce = (bRec.sampledType & EDelta) != 0;
+        cf = cf * f;
+        if (depth > rrStartDepth) {
+            if (rnd.randomFloat() < vmax(cf)) cf = cf / vmax(cf);
+            else break;
+        }
+        ro = bRec.dg.P; rd = bRec.dg.sys.toWorld(bRec.wo);
+        r2.init();
+    }
+    // PathTracer.cu:168-171: the environment is added for the LAST ray whether it escaped or not (a path cut by the roulette or by the
+    // depth limit adds the environment radiance seen along the ray that produced its last hit); reproduced as written
+    if (S.d.env_map_index != 0xffffffffu) {
+        const ctl_light& env = S.d.lights[S.d.env_map_index];
+        if (!r2.hasHit() && depth == 0) cl = cf * (S.pyramids ? envEvalDifferential(S, env, rd, rxd, ryd) : envEval(S, env, rd));
+        else cl = cl + cf * envEval(S, env, rd);
+    } else if (!r2.hasHit() && depth == 0) cl = Spec(0.0f);
+    return cl;
+}
+
 // Engine/Image.cu:22-44 (host branch)
 inline void addSample(ctl_pixel_data* img, int W, int H, float sx, float sy, Spec L) {
     L = V3(fmax2(L.x, 0.0f), fmax2(L.y, 0.0f), fmax2(L.z, 0.0f));   // Spectrum::clampNegative

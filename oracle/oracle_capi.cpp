@@ -223,11 +223,13 @@ void orc_render_counts(uint64_t* out8) { for (int i = 0; i < 8; i++) { out8[i] =
 uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t n_passes, const float* tables1, const float* tables2,
                     int direct, int maxPathLength, int rrStart, ctl_pixel_data* img, int n_threads, uint32_t y0, uint32_t y1, int half_host_quirk) {
     // half_host_quirk: bit 0 = half::ToFloat host branch, bit 1 = alpha test on (doAlphaMapping: every traceRay, incl. Occluded),
-    // bit 2 = first-hit ray differentials and filtered texture lookups (what the megakernel PathTracer does, PathTracer.cu:60-61; the wavefront tracer does not)
+    // bit 2 = first-hit ray differentials and filtered texture lookups (what the megakernel PathTracer does, PathTracer.cu:60-61; the wavefront tracer does not),
+    // bit 3 = PathTraceRegularization (the PathTracer plugin's Regularization = true; implies bit 2), pass k (1-based) with the mollifier of PathTracer::RenderBlock
     Scene S; S.d = *desc; S.half_host_quirk = (half_host_quirk & 1) != 0; S.alpha_test = (half_host_quirk & 2) != 0 && sceneHasAlphaMaps(*desc); S.flat = g_flat;
     PerspectiveSensor sensor; sensor.update(desc->camera);
     std::vector<MipPyramid> pyramids;
-    const bool partials = (half_host_quirk & 4) != 0;
+    const bool regularization = (half_host_quirk & 8) != 0;
+    const bool partials = (half_host_quirk & 4) != 0 || regularization;
     if (partials) { pyramids.resize(desc->n_images); for (uint32_t i = 0; i < desc->n_images; i++) pyramids[i].build(desc->images[i]); S.pyramids = pyramids.data(); }
     if (n_threads < 1) n_threads = 1;
     if (y1 > H) y1 = H;
@@ -271,7 +273,14 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
                     V2 ap = rng.randomFloat2(); (void)ap;
                     V3 o, d, dX, dY;
                     if (partials) sensor.sampleRayDifferential(pX, o, d, dX, dY); else sensor.sampleRay(pX, o, d);
-                    Spec col = pathTrace(S, direct != 0, o, d, rng, maxPathLength, rrStart, &rays, partials ? &dX : nullptr, partials ? &dY : nullptr);   // imp == 1 (Sensor.cu:127)
+                    Spec col;
+                    if (regularization) {   // PathTracer::RenderBlock (PathTracer.cu:196-203): radius2 from the scene box and the passes done (this pass included)
+                        const float initialRadius = ((desc->box_max[0] - desc->box_min[0]) + (desc->box_max[1] - desc->box_min[1]) + (desc->box_max[2] - desc->box_min[2])) / 100;
+                        const float ALPHA = 0.75f;
+                        const float radius2 = powf(powf(initialRadius, float(2)) / powf(float(pass + 1), 0.5f * (1 - ALPHA)), 1.0f / 2.0f);
+                        col = pathTraceRegularization(S, direct != 0, o, d, dX, dY, rng, radius2, maxPathLength, rrStart, &rays);
+                    } else
+                    col = pathTrace(S, direct != 0, o, d, rng, maxPathLength, rrStart, &rays, partials ? &dX : nullptr, partials ? &dY : nullptr);   // imp == 1 (Sensor.cu:127)
                     addSample(img, (int)W, (int)H, pX.x, pX.y, col);
                 }
             }

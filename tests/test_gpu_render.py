@@ -441,3 +441,24 @@ def test_sequence_tables_generated_on_the_gpu_equal_the_host_generator(gpu):
         assert np.array_equal(h2.view(np.uint32), d2.view(np.uint32))
     a1, a2 = host.compute(); b1, b2 = dev.compute()               # both generators stand at the same place of the stream afterwards
     assert np.array_equal(a1, b1) and np.array_equal(a2, b2)
+
+
+@pytest.mark.parametrize("direct", [True, False])
+def test_path_tracer_regularization(gpu, orc, direct):
+    """PathTracer plugin with Regularization = true (PathTraceRegularization, Integrators/PathTracer.cu:115-173): emitters seen only at depth 1 / after delta
+    bounces, UniformSampleAllLights on BSDFs without delta lobes, the mollified connection to point / spot / distant emitters on BSDFs with them (cone
+    shrinking with the pass number), roulette from RRStartDepth regardless of the bounce type, and the environment term exactly as the reference writes it"""
+    sc = scenes.env_scene(96, 64, extra_lights=True)
+    tables = orc.sequence_tables(3)
+    want, want_rays = orc.render(sc.desc, 96, 64, n_passes=3, tables=tables, direct=direct, max_path_length=6, rr_start=3, regularization=True)
+    tr = gpu.PathTracer(); p = tr.getParameters()
+    p.setValue("Regularization", True); p.setValue("Direct", direct); p.setValue("MaxPathLength", 6); p.setValue("RRStartDepth", 3)
+    tr.Resize(96, 64); tr.InitializeScene(gpu.Scene(sc.desc, flatten=True))
+    img = gpu.Image(96, 64)
+    for k in range(3):
+        tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
+    got = img.getPixelData()
+    assert_close(got, want)
+    assert abs(int(tr.stats().rays_total) - int(want_rays)) <= 2e-3 * want_rays
+    plain, _ = orc.render(sc.desc, 96, 64, n_passes=3, tables=tables, direct=direct, max_path_length=6, rr_start=3, partials=True)
+    assert np.abs(plain[..., :3] - want[..., :3]).mean() > 1e-3       # it really is a different estimator

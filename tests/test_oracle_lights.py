@@ -225,3 +225,17 @@ def test_orthogonal_area_light(lib):
     # pdfDirect in the solid-angle measure is 0 for an orthogonal light (Light.cu:140-141): BSDF-sampled hits of the panel carry MIS weight 1
     dvec, nvec = _vec(0, 1, 0), _vec(0, -1, 0)
     assert lib.orc_light_pdf_direct(C.byref(d), li, _vec(0, 1, 0).ctypes.data, refN.ctypes.data, dvec.ctypes.data, 3.0, nvec.ctypes.data) == 0.0
+
+
+def test_regularized_path_tracer_of_the_oracle(env):
+    """PathTraceRegularization (Integrators/PathTracer.cu:115-173) in the oracle: finite, deterministic, a different estimator from PathTrace, and its
+    mollified point-light term shrinks with the pass number (radius2 ~ passes^-1/8): the later pass connects fewer delta-BSDF vertices to the delta lights"""
+    sc, d = env
+    o = oracle.Oracle()
+    tables = o.sequence_tables(2)
+    a, rays_a = o.render(d, 32, 24, n_passes=2, tables=tables, max_path_length=5, rr_start=3, regularization=True, threads=4)
+    b, rays_b = o.render(d, 32, 24, n_passes=2, tables=tables, max_path_length=5, rr_start=3, regularization=True, threads=2)
+    assert rays_a == rays_b and np.array_equal(a, b)
+    assert np.isfinite(a[..., :3]).all() and (a[..., :3] >= 0).all() and a[..., :3].mean() > 0.05
+    plain, _ = o.render(d, 32, 24, n_passes=2, tables=tables, max_path_length=5, rr_start=3, partials=True, threads=4)
+    assert np.array_equal(plain[..., 6], a[..., 6]) and np.abs(plain[..., :3] - a[..., :3]).mean() > 1e-3
