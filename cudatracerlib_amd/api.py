@@ -59,7 +59,7 @@ class ctl_rough_transmittance(C.Structure):
 
 class ctl_sensor(C.Structure):
     _fields_ = [("type", u32), ("to_world", f32 * 16), ("fov", f32), ("near_depth", f32), ("far_depth", f32), ("resolution", f32 * 2),
-                ("aperture_radius", f32), ("focus_distance", f32)]
+                ("aperture_radius", f32), ("focus_distance", f32), ("screen_scale", f32 * 2)]
 
 
 class ctl_float4x4(C.Structure):

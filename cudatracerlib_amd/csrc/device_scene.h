@@ -17,6 +17,8 @@ struct dev_sensor {
     float to_world[12];   // rows 0..2 of toWorld
     float inv_res[2];
     float dx[3], dy[3];   // m_dx, m_dy: camera-space offsets of the neighbouring pixels' rays (Sensor.cu:86-89, sampleRayDifferential)
+    uint32_t type;        // CTL_SENSOR_PERSPECTIVE / THINLENS / ORTHOGRAPHIC / TELECENTRIC
+    float aperture_radius, focus_distance, screen_scale_x;   // ThinLens / Telecentric
 };
 // the levels behind level 0 of an image (KernelMIPMap::m_uLevels, m_sOffsets; Engine/MIPMap_device.h:57-69): texel offsets relative to the image's level 0
 struct dev_mip_levels { uint32_t levels; uint32_t offsets[15]; };

@@ -33,8 +33,8 @@ __global__ __launch_bounds__(kWideBlock) void k_raygen(dev_scene S, wave_queues 
         sampler rng{ P.t1 + pass_b * n1, P.t2 + pass_b * n1, pixel, 0, 2 * smp };
         const f2 j = rng.next2();
         const f2 pX{ (float)x + j.x, (float)y + j.y };
-        (void)rng.next2();   // aperture sample, unused by the perspective sensor but drawn (PathTracer.cu:190)
-        f3 o, d; sensor_sample_ray(S.cam, pX, o, d);
+        const f2 ap = rng.next2();   // aperture sample (PathTracer.cu:190; thin-lens and telecentric sensors use it)
+        f3 o, d; sensor_sample_ray(S.cam, pX, ap, o, d);
         const path_soa& A = Q.path[0];
         A.ray_o[slot] = make_float4(o.x, o.y, o.z, S.eps);          // DoubleRayBuffer::convert (Kernel/DoubleRayBuffer.h:224-230)
         A.ray_d[slot] = make_float4(d.x, d.y, d.z, 3.402823466e+38f);

@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256) void k_path_trace(dev_scene S, pass_params P, 
         sampler rng{ P.t1 + pass_b * n1, P.t2 + pass_b * n1, y * P.width + x, 0, 0 };
         const f2 j = rng.next2();
         const f2 pX{ (float)x + j.x, (float)y + j.y };
-        (void)rng.next2();   // aperture sample
-        f3 r_o, r_d, r_dx, r_dy; sensor_sample_ray_differential(S.cam, pX, r_o, r_d, r_dx, r_dy);   // pathKernel2: sampleSensorRay(r, rX, rY, ...) (PathTracer.cu:186-190)
+        const f2 ap = rng.next2();   // aperture sample
+        f3 r_o, r_d, r_ox, r_dx, r_oy, r_dy; sensor_sample_ray_differential(S.cam, pX, ap, r_o, r_d, r_ox, r_dx, r_oy, r_dy);   // pathKernel2: sampleSensorRay(r, rX, rY, ...) (PathTracer.cu:186-190)
         f3 cl(0.0f), cf(1.0f), last_nor(0.0f);
         int depth = 0; bool specularBounce = false, had_hit = false;
         float brdf_scattering_pdf = 0;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_path_trace(dev_scene S, pass_params P, 
             const ctl_material& mat = S.mats[ninfo.x + tri_mat_index(S, tri)];
             if (mat.map_kind != CTL_MAP_NONE) sample_normal_map(mat, b.dg);
             if (mat.two_sided && b.wi.z < 0) { b.dg.n = -b.dg.n; b.dg.sys.n = -b.dg.sys.n; b.wi.z *= -1.0f; }
-            if (depth == 1) compute_partials(b.dg, r_o, r_dx, r_dy);   // PathTracer.cu:60-61
+            if (depth == 1) compute_partials(b.dg, r_ox, r_dx, r_oy, r_dy);   // PathTracer.cu:60-61
             const uint32_t nli = mat.node_light_index;
             if (nli != 0xffffffffu) {
                 const uint32_t li2 = nli == 0 ? ninfo.y : ninfo.z;
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256) void k_path_trace_regularization(dev_scene S, 
         sampler rng{ P.t1 + pass_b * n1, P.t2 + pass_b * n1, y * P.width + x, 0, 0 };
         const f2 j = rng.next2();
         const f2 pX{ (float)x + j.x, (float)y + j.y };
-        (void)rng.next2();   // aperture sample
-        f3 r_o, r_d, r_dx, r_dy; sensor_sample_ray_differential(S.cam, pX, r_o, r_d, r_dx, r_dy);
+        const f2 ap = rng.next2();   // aperture sample
+        f3 r_o, r_d, r_ox, r_dx, r_oy, r_dy; sensor_sample_ray_differential(S.cam, pX, ap, r_o, r_d, r_ox, r_dx, r_oy, r_dy);
         const float g_fRMollifier = mollifier[pass_b];
         f3 cl(0.0f), cf(1.0f);
         int depth = 0; bool specularBounce = false, had_hit = false;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_path_trace_regularization(dev_scene S, 
             const ctl_material& mat = S.mats[ninfo.x + tri_mat_index(S, tri)];
             if (mat.map_kind != CTL_MAP_NONE) sample_normal_map(mat, b.dg);
             if (mat.two_sided && b.wi.z < 0) { b.dg.n = -b.dg.n; b.dg.sys.n = -b.dg.sys.n; b.wi.z *= -1.0f; }
-            if (depth == 1) compute_partials(b.dg, r_o, r_dx, r_dy);
+            if (depth == 1) compute_partials(b.dg, r_ox, r_dx, r_oy, r_dy);
             const uint32_t nli = mat.node_light_index;
             if (nli != 0xffffffffu && (!P.direct || depth == 1 || specularBounce)) cl = cl + cf * light_eval(S, S.lights[nli == 0 ? ninfo.y : ninfo.z], b.dg.P, b.dg.sys.n, -r_d);
             float pdf_unused;

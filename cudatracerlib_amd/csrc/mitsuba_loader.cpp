@@ -444,10 +444,13 @@ struct loader {
         return R;
     }
 
-    // ---- sensor (ObjectParser.h:226-345): perspective only
+    // ---- sensor (ObjectParser.h:226-345): perspective, thinlens, orthographic.  `telecentric` is refused: the reference default-constructs it and never sets its
+    //      aperture, focus distance or screen scale (ObjectParser.h:329-334, Sensor.h:453-457), i.e. it renders from uninitialised memory; the sensor itself is
+    //      available through ctl_builder_set_camera
     void parse_sensor(const xml_node& n) {
         const std::string T = n.attr("type");
-        if (T != "perspective") { if (T == "thinlens" || T == "orthographic" || T == "telecentric") throw unsupported_error("ParseMitsubaScene: sensor type " + T + " has no HIP implementation yet"); bad("invalid Sensor type : " + T); }
+        if (T == "telecentric") throw unsupported_error("ParseMitsubaScene: the reference leaves a telecentric sensor's aperture, focus distance and screen scale uninitialised; set the camera through ctl_builder_set_camera");
+        if (T != "perspective" && T != "thinlens" && T != "orthographic") bad("invalid Sensor type : " + T);
         int width = 768, height = 576;
         if (const xml_node* film = n.child("film")) { width = prop_i(*film, "width", width); height = prop_i(*film, "height", height); }
         film_w = width; film_h = height; have_film = true;
@@ -473,6 +476,11 @@ struct loader {
         const float p3[3] = { pos.x, pos.y, pos.z }, t3[3] = { tar.x, tar.y, tar.z }, u3[3] = { u.x, u.y, u.z };
         B.set_camera_lookat(p3, t3, u3, fov_deg, (uint32_t)width, (uint32_t)height);
         B.camera.near_depth = prop_f(n, "nearClip", 1e-2f); B.camera.far_depth = prop_f(n, "farClip", 10000.0f);
+        if (T == "thinlens") {   // ObjectParser.h:309-320: SetApperture(0) in parseGeneric, then focusDistance (default 0) and apertureRadius when present
+            B.camera.type = CTL_SENSOR_THINLENS;
+            B.camera.focus_distance = prop_f(n, "focusDistance", 0.0f);
+            B.camera.aperture_radius = n.property("apertureRadius") ? prop_f(n, "apertureRadius") : 0.0f;
+        } else if (T == "orthographic") B.camera.type = CTL_SENSOR_ORTHOGRAPHIC;
         have_sensor = true;
     }
 

@@ -28,34 +28,67 @@ struct sampler {
     }
 };
 
-// ---- PerspectiveSensor::sampleRay (SceneTypes/Sensor.cu:116-128)
-__device__ __forceinline__ void sensor_sample_ray(const dev_sensor& c, f2 pixelSample, f3& o, f3& d) {
+// ---- sampleRay / sampleRayDifferential of the four projective sensors (SceneTypes/Sensor.cu: perspective :116-144, thin lens :267-311,
+// orthographic :429-450, telecentric :537-574)
+__device__ __forceinline__ f3 sensor_near_point(const dev_sensor& c, f2 pixelSample) {   // m_sampleToCamera.TransformPoint(pixelSample * invResolution, 0)
     const float px = pixelSample.x * c.inv_res[0], py = pixelSample.y * c.inv_res[1];
     float r[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { float s = c.s2c[i * 4] * px; s += c.s2c[i * 4 + 1] * py; s += c.s2c[i * 4 + 2] * 0.0f; s += c.s2c[i * 4 + 3] * 1.0f; r[i] = s; }
-    const f3 nearP(r[0] / r[3], r[1] / r[3], r[2] / r[3]);
-    const f3 dn = normalize(nearP);
-    m34 m;
-#pragma unroll
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) m.r[i][j] = c.to_world[i * 4 + j];
-    o = xform_point(m, f3(0.0f));   // toWorld.Translation()
-    d = xform_dir(m, dn);
+    return f3(r[0] / r[3], r[1] / r[3], r[2] / r[3]);
 }
-
-// PerspectiveSensor::sampleRayDifferential (SceneTypes/Sensor.cu:130-144): the ray and the directions of its x / y neighbours
-__device__ __forceinline__ void sensor_sample_ray_differential(const dev_sensor& c, f2 pixelSample, f3& o, f3& d, f3& dX, f3& dY) {
-    const float px = pixelSample.x * c.inv_res[0], py = pixelSample.y * c.inv_res[1];
-    float r[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { float s = c.s2c[i * 4] * px; s += c.s2c[i * 4 + 1] * py; s += c.s2c[i * 4 + 2] * 0.0f; s += c.s2c[i * 4 + 3] * 1.0f; r[i] = s; }
-    const f3 nearP(r[0] / r[3], r[1] / r[3], r[2] / r[3]);
+__device__ __forceinline__ m34 sensor_to_world(const dev_sensor& c) {
     m34 m;
 #pragma unroll
     for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) m.r[i][j] = c.to_world[i * 4 + j];
-    o = xform_point(m, f3(0.0f));
-    d = xform_dir(m, normalize(nearP));
-    dX = xform_dir(m, normalize(nearP + f3(c.dx[0], c.dx[1], c.dx[2]))); dY = xform_dir(m, normalize(nearP + f3(c.dy[0], c.dy[1], c.dy[2])));
+    return m;
+}
+__device__ __forceinline__ void sensor_sample_ray(const dev_sensor& c, f2 pixelSample, f2 apertureSample, f3& o, f3& d) {
+    const f3 nearP = sensor_near_point(c, pixelSample);
+    const m34 m = sensor_to_world(c);
+    if (c.type == CTL_SENSOR_PERSPECTIVE) {
+        o = xform_point(m, f3(0.0f));   // toWorld.Translation()
+        d = xform_dir(m, normalize(nearP));
+    } else if (c.type == CTL_SENSOR_THINLENS) {
+        const f2 tmp = square_to_disk_concentric(apertureSample);
+        const f3 apertureP(tmp.x * c.aperture_radius, tmp.y * c.aperture_radius, 0.0f);
+        const f3 focusP = nearP * (c.focus_distance / nearP.z);
+        o = xform_point(m, apertureP); d = xform_dir(m, normalize(focusP - apertureP));
+    } else if (c.type == CTL_SENSOR_ORTHOGRAPHIC) {
+        o = xform_point(m, f3(nearP.x, nearP.y, 0.0f)); d = xform_dir(m, f3(0.0f, 0.0f, 1.0f));   // toWorld.Forward()
+    } else {
+        const f2 q = square_to_disk_concentric(apertureSample); const float sc = c.aperture_radius / c.screen_scale_x;
+        f3 focusP = nearP; focusP.z = c.focus_distance;
+        const f3 orig(q.x * sc + focusP.x, q.y * sc + focusP.y, 0.0f);
+        o = xform_point(m, orig); d = normalize(xform_dir(m, focusP - orig));
+    }
+}
+// the ray and its x / y neighbours (perspective sensors shift the direction, orthographic ones the origin)
+__device__ __forceinline__ void sensor_sample_ray_differential(const dev_sensor& c, f2 pixelSample, f2 apertureSample, f3& o, f3& d, f3& oX, f3& dX, f3& oY, f3& dY) {
+    const f3 nearP = sensor_near_point(c, pixelSample);
+    const m34 m = sensor_to_world(c);
+    const f3 ddx(c.dx[0], c.dx[1], c.dx[2]), ddy(c.dy[0], c.dy[1], c.dy[2]);
+    if (c.type == CTL_SENSOR_PERSPECTIVE) {
+        o = xform_point(m, f3(0.0f));
+        d = xform_dir(m, normalize(nearP));
+        oX = oY = o; dX = xform_dir(m, normalize(nearP + ddx)); dY = xform_dir(m, normalize(nearP + ddy));
+    } else if (c.type == CTL_SENSOR_THINLENS) {
+        const f2 tmp = square_to_disk_concentric(apertureSample);
+        const f3 apertureP(tmp.x * c.aperture_radius, tmp.y * c.aperture_radius, 0.0f);
+        const float fDist = c.focus_distance / nearP.z;
+        const f3 focusP = nearP * fDist, focusPx = (nearP + ddx) * fDist, focusPy = (nearP + ddy) * fDist;
+        o = xform_point(m, apertureP); d = xform_dir(m, normalize(focusP - apertureP));
+        oX = oY = o; dX = xform_dir(m, normalize(focusPx - apertureP)); dY = xform_dir(m, normalize(focusPy - apertureP));
+    } else if (c.type == CTL_SENSOR_ORTHOGRAPHIC) {
+        o = xform_point(m, nearP); d = xform_dir(m, f3(0.0f, 0.0f, 1.0f));
+        oX = xform_point(m, nearP + ddx); oY = xform_point(m, nearP + ddy); dX = dY = d;
+    } else {
+        const f2 q = square_to_disk_concentric(apertureSample); const float sc = c.aperture_radius / c.screen_scale_x;
+        f3 focusP = nearP; focusP.z = c.focus_distance;
+        const f3 orig(q.x * sc + focusP.x, q.y * sc + focusP.y, 0.0f);
+        o = xform_point(m, orig); d = normalize(xform_dir(m, focusP - orig));
+        oX = xform_point(m, orig + ddx); oY = xform_point(m, orig + ddy); dX = dY = d;
+    }
 }
 
 // ---- differential geometry at a hit (Kernel/TraceHelper.cu:274-307 -> Engine/TriangleData.cu:75-103)
@@ -99,18 +132,18 @@ __device__ __forceinline__ void fill_dg(const dev_scene& S, float u, float v, in
     if (dot(dg.n, dg.sys.n) < 0.0f) dg.n = -dg.n;
 }
 #ifdef CTL_TEX_PARTIALS
-// DifferentialGeometry::computePartials (Engine/DifferentialGeometry.cu:9-90); the three rays share their origin
-__device__ inline void compute_partials(diff_geom& dg, f3 ro, f3 rxd, f3 ryd) {
+// DifferentialGeometry::computePartials (Engine/DifferentialGeometry.cu:9-90); rox / roy: origins of the x / y differential rays
+__device__ inline void compute_partials(diff_geom& dg, f3 rox, f3 rxd, f3 roy, f3 ryd) {
     dg.has_uv_partials = true;
     if (dot(dg.dpdu, dg.dpdu) == 0 && dot(dg.dpdv, dg.dpdv) == 0) { dg.dudx = dg.dvdx = dg.dudy = dg.dvdy = 0.0f; return; }
-    const float pp = dot(dg.n, dg.P), pox = dot(dg.n, ro), poy = dot(dg.n, ro), prx = dot(dg.n, rxd), pry = dot(dg.n, ryd);
+    const float pp = dot(dg.n, dg.P), pox = dot(dg.n, rox), poy = dot(dg.n, roy), prx = dot(dg.n, rxd), pry = dot(dg.n, ryd);
     if (prx == 0 || pry == 0) { dg.dudx = dg.dvdx = dg.dudy = dg.dvdy = 0.0f; return; }
     const float tx = (pp - pox) / prx, ty = (pp - poy) / pry;
     const float absX = fabsf(dg.n.x), absY = fabsf(dg.n.y), absZ = fabsf(dg.n.z);
     const int a0 = (absX > absY && absX > absZ) ? 1 : 0, a1 = (absX > absY && absX > absZ) ? 2 : (absY > absZ ? 2 : 1);
     auto comp = [](f3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); };
     const float A00 = comp(dg.dpdu, a0), A01 = comp(dg.dpdv, a0), A10 = comp(dg.dpdu, a1), A11 = comp(dg.dpdv, a1);
-    const f3 px = ro + rxd * tx, py = ro + ryd * ty;
+    const f3 px = rox + rxd * tx, py = roy + ryd * ty;
     const float Bx0 = comp(px, a0) - comp(dg.P, a0), Bx1 = comp(px, a1) - comp(dg.P, a1), By0 = comp(py, a0) - comp(dg.P, a0), By1 = comp(py, a1) - comp(dg.P, a1);
     const float det = A00 * A11 - A01 * A10;   // AlgebraHelper::solveLinearSystem2x2 (Math/AlgebraHelper.h:11-24)
     if (fabsf(det) <= 2.93873587705571876e-39f) { dg.dudx = 1; dg.dvdx = 0; dg.dudy = 0; dg.dvdy = 1; return; }

@@ -299,12 +299,20 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
     S.tri_data = tri_data_.p; S.node_info = node_info_.p; S.mats = mats_.p; S.lights = lights_.p; S.anim = anim_.p;
     S.start_node = d.scene_start_node; S.n_nodes = d.n_nodes; S.num_lights = d.num_lights; S.env_map_index = d.env_map_index; S.eps = d.ray_trace_eps;
     for (int i = 0; i < CTL_MAX_NUM_LIGHTS; i++) { S.light_indices[i] = d.light_indices[i]; S.light_cdf[i] = d.light_cdf[i]; }
-    // PerspectiveSensor::Update (SceneTypes/Sensor.cu:76-96)
+    // PerspectiveSensor / ThinLensSensor / OrthographicSensor / TelecentricSensor ::Update (SceneTypes/Sensor.cu:76-96, :226-246, :408-427, :515-535)
     const ctl_sensor& c = d.camera;
-    if (c.type != CTL_SENSOR_PERSPECTIVE) throw std::runtime_error("ctl_scene_create: only the perspective sensor is implemented");
+    if (c.type != CTL_SENSOR_PERSPECTIVE && c.type != CTL_SENSOR_THINLENS && c.type != CTL_SENSOR_ORTHOGRAPHIC && c.type != CTL_SENSOR_TELECENTRIC)
+        throw std::runtime_error("ctl_scene_create: sensor type " + std::to_string(c.type) + " is not implemented (perspective, thin lens, orthographic and telecentric are)");
+    const bool ortho = c.type == CTL_SENSOR_ORTHOGRAPHIC || c.type == CTL_SENSOR_TELECENTRIC;
     const float aspect = c.resolution[0] / c.resolution[1];
     const float recip = 1.0f / (c.far_depth - c.near_depth), cot = 1.0f / tanf(c.fov / 2.0f);
-    const float persp[16] = { cot, 0, 0, 0, 0, cot, 0, 0, 0, 0, c.far_depth * recip, -c.near_depth * c.far_depth * recip, 0, 0, 1, 0 };
+    float persp[16] = { cot, 0, 0, 0, 0, cot, 0, 0, 0, 0, c.far_depth * recip, -c.near_depth * c.far_depth * recip, 0, 0, 1, 0 };
+    if (ortho) {   // float4x4::orthographic (float4x4.h:625-628) = Scale(1, 1, 1 / (far - near)) % Translate(0, 0, -near)
+        const float so[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1.0f / (c.far_depth - c.near_depth), 0, 0, 0, 0, 1 };
+        const float to[16] = { 1, 0, 0, 0.0f, 0, 1, 0, 0.0f, 0, 0, 1, -c.near_depth, 0, 0, 0, 1 };
+        mat_mul(so, to, persp);
+    }
+    S.cam.type = c.type; S.cam.aperture_radius = c.aperture_radius; S.cam.focus_distance = c.focus_distance; S.cam.screen_scale_x = c.screen_scale[0] != 0.0f ? c.screen_scale[0] : 1.0f;
     const float sc[16] = { -0.5f, 0, 0, 0, 0, -0.5f * aspect, 0, 0, 0, 0, 1.0f, 0, 0, 0, 0, 1 };
     const float tr[16] = { 1, 0, 0, -1.0f, 0, 1, 0, -1.0f / aspect, 0, 0, 1, 0.0f, 0, 0, 0, 1 };
     float a[16], c2s[16];

@@ -211,7 +211,8 @@ typedef struct {
     float fov;                     /* radians, horizontal (SceneTypes/Sensor.h:72-76)          */
     float near_depth, far_depth;   /* SensorBase::m_fNearFarDepths                             */
     float resolution[2];           /* film size in pixels                                      */
-    float aperture_radius, focus_distance;
+    float aperture_radius, focus_distance;   /* ThinLens / Telecentric: SensorBase::m_apertureRadius, m_focusDistance */
+    float screen_scale[2];         /* Telecentric: screenScale (its aperture is aperture_radius / screen_scale[0]); 0 = 1 */
 } ctl_sensor;
 
 #define CTL_MAX_NUM_LIGHTS 16      /* Engine/KernelDynamicScene.h:26 */

@@ -102,6 +102,9 @@ def load_ref():
     r.ref_woop_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p]
     r.ref_construct_bvh.argtypes = [C.c_void_p, C.c_void_p, u32, u32, C.c_void_p, C.c_void_p]
     r.ref_construct_bvh_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    if hasattr(r, "ref_sensor_rays"):
+        r.ref_sensor_rays.argtypes = [C.c_int, C.c_void_p, f32, f32, f32, C.c_int, C.c_int, f32, f32, f32, f32, f32, f32, f32, C.c_void_p, C.c_void_p]
+        r.ref_compute_partials_origins.argtypes = [C.c_void_p] * 11
     if hasattr(r, "ref_compute_partials"):
         r.ref_compute_partials.argtypes = [C.c_void_p] * 9
         r.ref_sensor_sample_ray_differential.argtypes = [C.c_void_p, f32, f32, f32, C.c_int, C.c_int, f32, f32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -610,32 +610,63 @@ struct Sampler {
 };
 
 // --------------------------------------------------------------------------- sensor (SceneTypes/Sensor.cu:76-128)
-struct PerspectiveSensor {
-    M44 toWorld, sampleToCamera; V2 invRes; V3 dx, dy;
+// PerspectiveSensor / ThinLensSensor / OrthographicSensor / TelecentricSensor (SceneTypes/Sensor.cu: Update :76-96, :226-246, :408-427, :515-535)
+struct SensorO {
+    uint32_t type = CTL_SENSOR_PERSPECTIVE;
+    M44 toWorld, sampleToCamera; V2 invRes; V3 dx, dy; float apertureRadius = 0, focusDistance = 0, screenScaleX = 1;
     void update(const ctl_sensor& s) {
+        type = s.type;
+        if (type != CTL_SENSOR_PERSPECTIVE && type != CTL_SENSOR_THINLENS && type != CTL_SENSOR_ORTHOGRAPHIC && type != CTL_SENSOR_TELECENTRIC) throw std::runtime_error("oracle: sensor type not restated");
         std::memcpy(toWorld.d, s.to_world, 64);
         float aspect = s.resolution[0] / s.resolution[1];
         invRes = V2{ 1.0f / s.resolution[0], 1.0f / s.resolution[1] };
-        M44 c2s = mul(mul(scaleM(V3(-0.5f, -0.5f * aspect, 1.0f)), translateM(V3(-1.0f, -1.0f / aspect, 0.0f))), perspective(s.fov, s.near_depth, s.far_depth));
+        const bool ortho = type == CTL_SENSOR_ORTHOGRAPHIC || type == CTL_SENSOR_TELECENTRIC;
+        // float4x4::orthographic (float4x4.h:625-628) = Scale(1, 1, 1 / (far - near)) % Translate(0, 0, -near)
+        M44 proj = ortho ? mul(scaleM(V3(1.0f, 1.0f, 1.0f / (s.far_depth - s.near_depth))), translateM(V3(0.0f, 0.0f, -s.near_depth))) : perspective(s.fov, s.near_depth, s.far_depth);
+        M44 c2s = mul(mul(scaleM(V3(-0.5f, -0.5f * aspect, 1.0f)), translateM(V3(-1.0f, -1.0f / aspect, 0.0f))), proj);
         sampleToCamera = inverse(c2s);
         dx = transformPoint(sampleToCamera, V3(invRes.x, 0.0f, 0.0f)) - transformPoint(sampleToCamera, V3(0.0f));
         dy = transformPoint(sampleToCamera, V3(0.0f, invRes.y, 0.0f)) - transformPoint(sampleToCamera, V3(0.0f));
+        apertureRadius = s.aperture_radius; focusDistance = s.focus_distance; screenScaleX = s.screen_scale[0] != 0.0f ? s.screen_scale[0] : 1.0f;
     }
-    // Sensor.cu:116-128
-    void sampleRay(V2 pixelSample, V3& o, V3& d) const {
+    // sampleRayDifferential of the four types (Sensor.cu:130-144, :292-311, :440-450, :558-574); sampleRay (:116-128, :267-290, :429-438, :537-556) is its first ray,
+    // except that OrthographicSensor::sampleRay starts on the plane z = 0 of the camera while its differential version starts at nearP
+    void sampleRayDifferential(V2 pixelSample, V2 apertureSample, V3& o, V3& d, V3& oX, V3& dX, V3& oY, V3& dY, bool plain = false) const {
         V3 nearP = transformPoint(sampleToCamera, V3(pixelSample.x * invRes.x, pixelSample.y * invRes.y, 0.0f));
-        V3 dn = normalize(nearP);
-        o = transformPoint(toWorld, V3(0.0f));   // toWorld.Translation() (float4x4.h:93-96)
-        d = transformDir(toWorld, dn);
+        if (type == CTL_SENSOR_PERSPECTIVE) {
+            o = transformPoint(toWorld, V3(0.0f));   // toWorld.Translation() (float4x4.h:93-96)
+            d = transformDir(toWorld, normalize(nearP));
+            oX = oY = o; dX = transformDir(toWorld, normalize(nearP + dx)); dY = transformDir(toWorld, normalize(nearP + dy));
+        } else if (type == CTL_SENSOR_THINLENS) {
+            V2 tmp = squareToUniformDiskConcentric(apertureSample) * apertureRadius;
+            V3 apertureP(tmp.x, tmp.y, 0.0f);
+            float fDist = focusDistance / nearP.z;
+            V3 focusP = nearP * fDist, focusPx = (nearP + dx) * fDist, focusPy = (nearP + dy) * fDist;
+            o = transformPoint(toWorld, apertureP); d = transformDir(toWorld, normalize(focusP - apertureP));
+            oX = oY = o; dX = transformDir(toWorld, normalize(focusPx - apertureP)); dY = transformDir(toWorld, normalize(focusPy - apertureP));
+        } else if (type == CTL_SENSOR_ORTHOGRAPHIC) {
+            o = transformPoint(toWorld, plain ? V3(nearP.x, nearP.y, 0.0f) : nearP); d = transformDir(toWorld, V3(0.0f, 0.0f, 1.0f));   // toWorld.Forward()
+            oX = transformPoint(toWorld, nearP + dx); oY = transformPoint(toWorld, nearP + dy); dX = dY = d;
+        } else {
+            V2 diskSample = squareToUniformDiskConcentric(apertureSample) * (apertureRadius / screenScaleX);
+            V3 focusP = nearP; focusP.z = focusDistance;
+            V3 orig(diskSample.x + focusP.x, diskSample.y + focusP.y, 0.0f);
+            o = transformPoint(toWorld, orig); d = normalize(transformDir(toWorld, focusP - orig));
+            oX = transformPoint(toWorld, orig + dx); oY = transformPoint(toWorld, orig + dy); dX = dY = d;
+        }
     }
-    // Sensor.cu:130-144
-    void sampleRayDifferential(V2 pixelSample, V3& o, V3& d, V3& dX, V3& dY) const {
-        V3 nearP = transformPoint(sampleToCamera, V3(pixelSample.x * invRes.x, pixelSample.y * invRes.y, 0.0f));
-        o = transformPoint(toWorld, V3(0.0f));
-        d = transformDir(toWorld, normalize(nearP));
-        dX = transformDir(toWorld, normalize(nearP + dx)); dY = transformDir(toWorld, normalize(nearP + dy));
+    void sampleRay(V2 pixelSample, V2 apertureSample, V3& o, V3& d) const {
+        if (type == CTL_SENSOR_THINLENS) {   // ThinLensSensor::sampleRay scales nearP by (focusDistance / nearP.z) in one product (Sensor.cu:279), the differential version through fDist
+            V3 nearP = transformPoint(sampleToCamera, V3(pixelSample.x * invRes.x, pixelSample.y * invRes.y, 0.0f));
+            V2 tmp = squareToUniformDiskConcentric(apertureSample) * apertureRadius;
+            V3 apertureP(tmp.x, tmp.y, 0.0f), focusP = nearP * (focusDistance / nearP.z);
+            o = transformPoint(toWorld, apertureP); d = transformDir(toWorld, normalize(focusP - apertureP));
+            return;
+        }
+        V3 a, b, c, e; sampleRayDifferential(pixelSample, apertureSample, o, d, a, b, c, e, true);
     }
 };
+using PerspectiveSensor = SensorO;
 
 // --------------------------------------------------------------------------- records (SceneTypes/Samples.h)
 enum EMeasure { EInvalidMeasure = 0, ESolidAngle = 1, ELength = 2, EArea = 3, EDiscrete = 4 };
@@ -1284,11 +1315,11 @@ inline Spec uniformSampleOneLight(const Scene& S, const BRec& bRec, const ctl_ma
 }
 
 // --------------------------------------------------------------------------- PathTrace<DIRECT> (Integrators/PathTracer.cu:10-113), no volumes
-// DifferentialGeometry::computePartials (Engine/DifferentialGeometry.cu:9-90); the three rays share their origin
-inline void computePartials(DG& dg, V3 ro, V3 rxd, V3 ryd) {
+// DifferentialGeometry::computePartials (Engine/DifferentialGeometry.cu:9-90); rox / roy: origins of the x / y differential rays (= the ray's own for perspective sensors)
+inline void computePartials(DG& dg, V3 rox, V3 rxd, V3 roy, V3 ryd) {
     dg.hasUVPartials = true;
     if (dot(dg.dpdu, dg.dpdu) == 0 && dot(dg.dpdv, dg.dpdv) == 0) { dg.dudx = dg.dvdx = dg.dudy = dg.dvdy = 0.0f; return; }
-    const float pp = dot(dg.n, dg.P), pox = dot(dg.n, ro), poy = dot(dg.n, ro), prx = dot(dg.n, rxd), pry = dot(dg.n, ryd);
+    const float pp = dot(dg.n, dg.P), pox = dot(dg.n, rox), poy = dot(dg.n, roy), prx = dot(dg.n, rxd), pry = dot(dg.n, ryd);
     if (prx == 0 || pry == 0) { dg.dudx = dg.dvdx = dg.dudy = dg.dvdy = 0.0f; return; }
     const float tx = (pp - pox) / prx, ty = (pp - poy) / pry;
     const float absX = fabsf(dg.n.x), absY = fabsf(dg.n.y), absZ = fabsf(dg.n.z);
@@ -1296,7 +1327,7 @@ inline void computePartials(DG& dg, V3 ro, V3 rxd, V3 ryd) {
     if (absX > absY && absX > absZ) { axes[0] = 1; axes[1] = 2; } else if (absY > absZ) { axes[0] = 0; axes[1] = 2; } else { axes[0] = 0; axes[1] = 1; }
     const float dpduA[3] = { dg.dpdu.x, dg.dpdu.y, dg.dpdu.z }, dpdvA[3] = { dg.dpdv.x, dg.dpdv.y, dg.dpdv.z };
     const float A[2][2] = { { dpduA[axes[0]], dpdvA[axes[0]] }, { dpduA[axes[1]], dpdvA[axes[1]] } };
-    const V3 px = ro + rxd * tx, py = ro + ryd * ty;
+    const V3 px = rox + rxd * tx, py = roy + ryd * ty;
     const float pA[3] = { dg.P.x, dg.P.y, dg.P.z }, pxA[3] = { px.x, px.y, px.z }, pyA[3] = { py.x, py.y, py.z };
     const float Bx[2] = { pxA[axes[0]] - pA[axes[0]], pxA[axes[1]] - pA[axes[1]] }, By[2] = { pyA[axes[0]] - pA[axes[0]], pyA[axes[1]] - pA[axes[1]] };
     auto solve = [&](const float b[2], float x[2]) {   // AlgebraHelper::solveLinearSystem2x2 (Math/AlgebraHelper.h:11-24), RCPOVERFLOW = 2.93873587705571876e-39f
@@ -1311,9 +1342,10 @@ inline void computePartials(DG& dg, V3 ro, V3 rxd, V3 ryd) {
     if (solve(By, x)) { dg.dudy = x[0]; dg.dvdy = x[1]; } else { dg.dudy = 0; dg.dvdy = 1; }
 }
 
-// rxd / ryd: directions of the sensor's differential rays (sampleRayDifferential); non-null = the megakernel integrator's first-hit texture filtering
+struct RayDiff { V3 ox, dx, oy, dy; };   // the sensor's x / y differential rays (sampleRayDifferential)
+// diff non-null = the megakernel integrator's first-hit texture filtering
 // (PathTracer.cu:60-61), null = no partials (what the wavefront tracer does)
-inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, int maxPathLength, int rrStartDepth, uint64_t* rays, const V3* rxd = nullptr, const V3* ryd = nullptr) {
+inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, int maxPathLength, int rrStartDepth, uint64_t* rays, const RayDiff* diff = nullptr) {
     Spec cl(0.0f), cf(1.0f);
     int depth = 0; bool specularBounce = false;
     BRec bRec; Hit r2; r2.init();
@@ -1323,7 +1355,7 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
         if (rays) (*rays)++;
         if (r2.hasHit()) {
             getBsdfSample(S, r2, ro, rd, bRec);
-            if (depth == 1 && rxd && S.pyramids) { bRec.dg.pyramids = S.pyramids; computePartials(bRec.dg, ro, *rxd, *ryd); }
+            if (depth == 1 && diff && S.pyramids) { bRec.dg.pyramids = S.pyramids; computePartials(bRec.dg, diff->ox, diff->dx, diff->oy, diff->dy); }
             const ctl_material& mat = hitMat(S, r2);
             uint32_t li = hitLightIndex(S, r2);
             if (li != UINT32_MAX) {
@@ -1396,7 +1428,7 @@ inline Spec envEvalDifferential(const Scene& S, const ctl_light& L, V3 dir, V3 d
     V2 dudx{ t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y }, dudy{ t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y };
     return mipEval(S.d.images[L.env_image], S.pyramids[L.env_image], uv, dudx, dudy) * Spec(L.env_scale[0], L.env_scale[1], L.env_scale[2]);
 }
-inline Spec pathTraceRegularization(const Scene& S, bool DIRECT, V3 ro, V3 rd, V3 rxd, V3 ryd, Sampler& rnd, float g_fRMollifier, int maxPathLength, int rrStartDepth, uint64_t* rays) {
+inline Spec pathTraceRegularization(const Scene& S, bool DIRECT, V3 ro, V3 rd, const RayDiff& diff, Sampler& rnd, float g_fRMollifier, int maxPathLength, int rrStartDepth, uint64_t* rays) {
     Hit r2; r2.init();
     Spec cl(0.0f), cf(1.0f);
     int depth = 0; bool specularBounce = false;
@@ -1406,7 +1438,7 @@ inline Spec pathTraceRegularization(const Scene& S, bool DIRECT, V3 ro, V3 rd, V
         if (rays) (*rays)++;
         if (!(r2.hasHit() && depth++ < maxPathLength)) break;
         getBsdfSample(S, r2, ro, rd, bRec);
-        if (depth == 1 && S.pyramids) { bRec.dg.pyramids = S.pyramids; computePartials(bRec.dg, ro, rxd, ryd); }
+        if (depth == 1 && S.pyramids) { bRec.dg.pyramids = S.pyramids; computePartials(bRec.dg, diff.ox, diff.dx, diff.oy, diff.dy); }
         const ctl_material& mat = hitMat(S, r2);
         if (!DIRECT || (depth == 1 || specularBounce)) {
             uint32_t li = hitLightIndex(S, r2);
@@ -1448,7 +1480,7 @@ inline Spec pathTraceRegularization(const Scene& S, bool DIRECT, V3 ro, V3 rd, V
     // depth limit adds the environment radiance seen along the ray that produced its last hit); reproduced as written
     if (S.d.env_map_index != 0xffffffffu) {
         const ctl_light& env = S.d.lights[S.d.env_map_index];
-        if (!r2.hasHit() && depth == 0) cl = cf * (S.pyramids ? envEvalDifferential(S, env, rd, rxd, ryd) : envEval(S, env, rd));
+        if (!r2.hasHit() && depth == 0) cl = cf * (S.pyramids ? envEvalDifferential(S, env, rd, diff.dx, diff.dy) : envEval(S, env, rd));
         else cl = cl + cf * envEval(S, env, rd);
     } else if (!r2.hasHit() && depth == 0) cl = Spec(0.0f);
     return cl;

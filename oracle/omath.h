@@ -36,6 +36,7 @@ inline float copysign_bits(float a, float b) {                                  
 }
 
 struct V2 { float x, y; };
+inline V2 operator*(V2 a, float s) { return V2{ a.x * s, a.y * s }; }
 struct V3 {
     float x, y, z;
     V3() : x(0), y(0), z(0) {}

@@ -86,8 +86,17 @@ void orc_sampler_float2(const float* t1, const float* t2, uint32_t idx, uint32_t
 
 // ---- sensor ---------------------------------------------------------------------------------------------------
 void orc_sensor_sample_ray(const ctl_sensor* s, float px, float py, float* o, float* d) {
-    PerspectiveSensor ps; ps.update(*s); V3 O, D; ps.sampleRay(V2{ px, py }, O, D);
+    PerspectiveSensor ps; ps.update(*s); V3 O, D; ps.sampleRay(V2{ px, py }, V2{ 0.0f, 0.0f }, O, D);
     o[0] = O.x; o[1] = O.y; o[2] = O.z; d[0] = D.x; d[1] = D.y; d[2] = D.z;
+}
+// every sensor type, with the aperture sample; out18 = sampleRay (o, d), then sampleRayDifferential's x ray (o, d) and y ray (o, d); out6b = sampleRayDifferential's own ray
+void orc_sensor_sample_rays(const ctl_sensor* s, float px, float py, float ax, float ay, float* out18, float* out6b) {
+    SensorO ps; ps.update(*s); V3 O, D, o2, d2, oX, dX, oY, dY;
+    ps.sampleRay(V2{ px, py }, V2{ ax, ay }, O, D);
+    ps.sampleRayDifferential(V2{ px, py }, V2{ ax, ay }, o2, d2, oX, dX, oY, dY);
+    const V3 v[6] = { O, D, oX, dX, oY, dY };
+    for (int k = 0; k < 6; k++) { out18[3 * k] = v[k].x; out18[3 * k + 1] = v[k].y; out18[3 * k + 2] = v[k].z; }
+    out6b[0] = o2.x; out6b[1] = o2.y; out6b[2] = o2.z; out6b[3] = d2.x; out6b[4] = d2.y; out6b[5] = d2.z;
 }
 
 // ---- intersect ------------------------------------------------------------------------------------------------
@@ -132,11 +141,17 @@ void orc_mip_eval(const ctl_mipmap* M, float u, float v, const float* d0, const 
 // in: P, n, dpdu, dpdv (3 floats each), ray origin, directions of the x / y differential rays; out: dudx, dudy, dvdx, dvdy
 void orc_compute_partials(const float* P, const float* n, const float* dpdu, const float* dpdv, const float* ro, const float* rxd, const float* ryd, float* out4) {
     DG dg; dg.P = V3(P[0], P[1], P[2]); dg.n = V3(n[0], n[1], n[2]); dg.dpdu = V3(dpdu[0], dpdu[1], dpdu[2]); dg.dpdv = V3(dpdv[0], dpdv[1], dpdv[2]);
-    computePartials(dg, V3(ro[0], ro[1], ro[2]), V3(rxd[0], rxd[1], rxd[2]), V3(ryd[0], ryd[1], ryd[2]));
+    computePartials(dg, V3(ro[0], ro[1], ro[2]), V3(rxd[0], rxd[1], rxd[2]), V3(ro[0], ro[1], ro[2]), V3(ryd[0], ryd[1], ryd[2]));
+    out4[0] = dg.dudx; out4[1] = dg.dudy; out4[2] = dg.dvdx; out4[3] = dg.dvdy;
+}
+// the same with separate origins of the two differential rays (orthographic / telecentric sensors)
+void orc_compute_partials_origins(const float* P, const float* n, const float* dpdu, const float* dpdv, const float* rox, const float* rxd, const float* roy, const float* ryd, float* out4) {
+    DG dg; dg.P = V3(P[0], P[1], P[2]); dg.n = V3(n[0], n[1], n[2]); dg.dpdu = V3(dpdu[0], dpdu[1], dpdu[2]); dg.dpdv = V3(dpdv[0], dpdv[1], dpdv[2]);
+    computePartials(dg, V3(rox[0], rox[1], rox[2]), V3(rxd[0], rxd[1], rxd[2]), V3(roy[0], roy[1], roy[2]), V3(ryd[0], ryd[1], ryd[2]));
     out4[0] = dg.dudx; out4[1] = dg.dudy; out4[2] = dg.dvdx; out4[3] = dg.dvdy;
 }
 void orc_sensor_sample_ray_differential(const ctl_sensor* s, float px, float py, float* o, float* d, float* dX, float* dY) {
-    PerspectiveSensor ps; ps.update(*s); V3 O, D, X, Y; ps.sampleRayDifferential(V2{ px, py }, O, D, X, Y);
+    PerspectiveSensor ps; ps.update(*s); V3 O, D, X, Y, oX, oY; ps.sampleRayDifferential(V2{ px, py }, V2{ 0.0f, 0.0f }, O, D, oX, X, oY, Y);
     o[0] = O.x; o[1] = O.y; o[2] = O.z; d[0] = D.x; d[1] = D.y; d[2] = D.z; dX[0] = X.x; dX[1] = X.y; dX[2] = X.z; dY[0] = Y.x; dY[1] = Y.y; dY[2] = Y.z;
 }
 
@@ -270,17 +285,17 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
                     rng.d2 = 2 * smp;
                     V2 j = rng.randomFloat2();
                     V2 pX{ (float)x + j.x, (float)y + j.y };
-                    V2 ap = rng.randomFloat2(); (void)ap;
-                    V3 o, d, dX, dY;
-                    if (partials) sensor.sampleRayDifferential(pX, o, d, dX, dY); else sensor.sampleRay(pX, o, d);
+                    V2 ap = rng.randomFloat2();
+                    V3 o, d; RayDiff diff;
+                    if (partials) sensor.sampleRayDifferential(pX, ap, o, d, diff.ox, diff.dx, diff.oy, diff.dy); else sensor.sampleRay(pX, ap, o, d);
                     Spec col;
                     if (regularization) {   // PathTracer::RenderBlock (PathTracer.cu:196-203): radius2 from the scene box and the passes done (this pass included)
                         const float initialRadius = ((desc->box_max[0] - desc->box_min[0]) + (desc->box_max[1] - desc->box_min[1]) + (desc->box_max[2] - desc->box_min[2])) / 100;
                         const float ALPHA = 0.75f;
                         const float radius2 = powf(powf(initialRadius, float(2)) / powf(float(pass + 1), 0.5f * (1 - ALPHA)), 1.0f / 2.0f);
-                        col = pathTraceRegularization(S, direct != 0, o, d, dX, dY, rng, radius2, maxPathLength, rrStart, &rays);
+                        col = pathTraceRegularization(S, direct != 0, o, d, diff, rng, radius2, maxPathLength, rrStart, &rays);
                     } else
-                    col = pathTrace(S, direct != 0, o, d, rng, maxPathLength, rrStart, &rays, partials ? &dX : nullptr, partials ? &dY : nullptr);   // imp == 1 (Sensor.cu:127)
+                    col = pathTrace(S, direct != 0, o, d, rng, maxPathLength, rrStart, &rays, partials ? &diff : nullptr);   // imp == 1 (Sensor.cu:127)
                     addSample(img, (int)W, (int)H, pX.x, pX.y, col);
                 }
             }

@@ -25,6 +25,18 @@
 
 using namespace CudaTracerLib;
 
+template <class T> static void sensor_rays(T& s, const float* to_world, float nearD, float farD, float px, float py, float ax, float ay, float* out18, float* out6b) {
+    s.SetNearFarDepth(nearD, farD);
+    NormalizedT<OrthogonalAffineMap> m; std::memcpy(m.data, to_world, 64);
+    s.SetToWorld(m);   // -> Update()
+    NormalizedT<Ray> r, r2, rx, ry;
+    s.sampleRay(r, Vec2f(px, py), Vec2f(ax, ay));
+    s.sampleRayDifferential(r2, rx, ry, Vec2f(px, py), Vec2f(ax, ay));
+    const Vec3f v[6] = { r.ori(), r.dir(), rx.ori(), rx.dir(), ry.ori(), ry.dir() };
+    for (int k = 0; k < 6; k++) { out18[3 * k] = v[k].x; out18[3 * k + 1] = v[k].y; out18[3 * k + 2] = v[k].z; }
+    out6b[0] = r2.ori().x; out6b[1] = r2.ori().y; out6b[2] = r2.ori().z; out6b[3] = r2.dir().x; out6b[4] = r2.dir().y; out6b[5] = r2.dir().z;
+}
+
 extern "C" {
 
 void ref_woop_set_data(const float* v0, const float* v1, const float* v2, float* out12) {
@@ -126,6 +138,23 @@ void ref_sensor_sample_ray_differential(const float* to_world, float fov_rad, fl
     s.sampleRayDifferential(r, rx, ry, Vec2f(px, py), Vec2f(0.0f));
     o[0] = r.ori().x; o[1] = r.ori().y; o[2] = r.ori().z; d[0] = r.dir().x; d[1] = r.dir().y; d[2] = r.dir().z;
     dX[0] = rx.dir().x; dX[1] = rx.dir().y; dX[2] = rx.dir().z; dY[0] = ry.dir().x; dY[1] = ry.dir().y; dY[2] = ry.dir().z;
+}
+
+// The four projective sensors (SceneTypes/Sensor.cu): type = TYPE_FUNC id (2 perspective, 3 thin lens, 4 orthographic, 5 telecentric).
+// out18 = sampleRay (o, d), then the x ray (o, d) and the y ray (o, d) of sampleRayDifferential; out6b = sampleRayDifferential's own ray
+void ref_sensor_rays(int type, const float* to_world, float fov_rad, float nearD, float farD, int w, int h, float aperture, float focus, float screen_scale,
+                     float px, float py, float ax, float ay, float* out18, float* out6b) {
+    if (type == 2) { PerspectiveSensor s(w, h, 90.0f); s.fov = fov_rad; sensor_rays(s, to_world, nearD, farD, px, py, ax, ay, out18, out6b); }
+    else if (type == 3) { ThinLensSensor s(w, h, 90.0f, aperture, focus); s.fov = fov_rad; sensor_rays(s, to_world, nearD, farD, px, py, ax, ay, out18, out6b); }
+    else if (type == 4) { OrthographicSensor s(w, h, screen_scale, screen_scale); sensor_rays(s, to_world, nearD, farD, px, py, ax, ay, out18, out6b); }
+    else { TelecentricSensor s(w, h, aperture, focus, screen_scale, screen_scale); sensor_rays(s, to_world, nearD, farD, px, py, ax, ay, out18, out6b); }
+}
+// computePartials with the differential rays' own origins (orthographic / telecentric sensors)
+void ref_compute_partials_origins(const float* P, const float* n, const float* dpdu, const float* dpdv, const float* ro, const float* rd, const float* rox, const float* rxd, const float* roy, const float* ryd, float* out4) {
+    DifferentialGeometry dg;
+    dg.P = Vec3f(P[0], P[1], P[2]); dg.n = NormalizedT<Vec3f>(Vec3f(n[0], n[1], n[2])); dg.dpdu = Vec3f(dpdu[0], dpdu[1], dpdu[2]); dg.dpdv = Vec3f(dpdv[0], dpdv[1], dpdv[2]);
+    dg.computePartials(Ray(Vec3f(ro[0], ro[1], ro[2]), Vec3f(rd[0], rd[1], rd[2])), Ray(Vec3f(rox[0], rox[1], rox[2]), Vec3f(rxd[0], rxd[1], rxd[2])), Ray(Vec3f(roy[0], roy[1], roy[2]), Vec3f(ryd[0], ryd[1], ryd[2])));
+    out4[0] = dg.dudx; out4[1] = dg.dudy; out4[2] = dg.dvdx; out4[3] = dg.dvdy;
 }
 
 // ConstructBVH (Engine/MeshLoader/BVHBuilderHelper.cpp:116-127): SBVH with max leaf size 8.

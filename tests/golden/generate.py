@@ -172,5 +172,34 @@ def main():
                                rays[i, 0:3].ctypes.data, rays[i, 3:6].ctypes.data, rays[i, 6:9].ctypes.data, rays[i, 9:12].ctypes.data, parts[i].ctypes.data)
     np.savez_compressed(os.path.join(HERE, "partials.npz"), to_world=tw, params=par, pixel=px, rays=rays, dg=dgs, partials=parts)
 
+    # ---- the four projective sensors (added in round 2, own random stream): PerspectiveSensor, ThinLensSensor, OrthographicSensor, TelecentricSensor
+    #      sampleRay + sampleRayDifferential (SceneTypes/Sensor.cu), and computePartials fed with the differential rays' own origins
+    rs3 = np.random.RandomState(20260931)
+    n = 384
+    typ = np.zeros(n, np.int32); par = np.zeros((n, 8), np.float32); tw = np.zeros((n, 16), np.float32); smp = np.zeros((n, 4), np.float32)
+    rays = np.zeros((n, 18), np.float32); ray_d = np.zeros((n, 6), np.float32); dgs = np.zeros((n, 12), np.float32); parts = np.zeros((n, 4), np.float32)
+    for i in range(n):
+        typ[i] = 2 + i % 4
+        w, h = int(rs3.choice([64, 256, 1920])), int(rs3.choice([64, 256, 1080]))
+        fov = np.float32(np.radians(rs3.uniform(20, 100)))
+        q, _ = np.linalg.qr(rs3.normal(size=(3, 3)))
+        m = np.eye(4, dtype=np.float32); m[:3, :3] = q; m[:3, 3] = rs3.normal(size=3) * 20
+        tw[i] = m.reshape(16)
+        aperture, focus, sscale = np.float32(rs3.uniform(0.0, 0.5)), np.float32(rs3.uniform(0.5, 30.0)), np.float32(rs3.choice([1.0, 2.0, 0.5]))
+        nearD, farD = (np.float32(1e-2), np.float32(1e4)) if typ[i] in (2, 3) else (np.float32(1e-5), np.float32(1e5))
+        par[i] = [fov, nearD, farD, w, h, aperture, focus, sscale]
+        smp[i, :2] = (rs3.uniform(0, 1, size=2) * [w, h]).astype(np.float32); smp[i, 2:] = rs3.uniform(0, 1, size=2).astype(np.float32)
+        r.ref_sensor_rays(int(typ[i]), tw[i].ctypes.data, f32(fov), f32(nearD), f32(farD), w, h, f32(aperture), f32(focus), f32(sscale),
+                          f32(smp[i, 0]), f32(smp[i, 1]), f32(smp[i, 2]), f32(smp[i, 3]), rays[i].ctypes.data, ray_d[i].ctypes.data)
+        t = rs3.uniform(1, 50)
+        P = (ray_d[i, 0:3] + t * ray_d[i, 3:6]).astype(np.float32)
+        nrm = rs3.normal(size=3); nrm = (nrm / np.linalg.norm(nrm)).astype(np.float32)
+        dpdu = (rs3.normal(size=3) * rs3.uniform(0.01, 10)).astype(np.float32); dpdv = (rs3.normal(size=3) * rs3.uniform(0.01, 10)).astype(np.float32)
+        dgs[i] = np.concatenate([P, nrm, dpdu, dpdv])
+        r.ref_compute_partials_origins(dgs[i, 0:3].ctypes.data, dgs[i, 3:6].ctypes.data, dgs[i, 6:9].ctypes.data, dgs[i, 9:12].ctypes.data,
+                                       ray_d[i, 0:3].ctypes.data, ray_d[i, 3:6].ctypes.data, rays[i, 6:9].ctypes.data, rays[i, 9:12].ctypes.data,
+                                       rays[i, 12:15].ctypes.data, rays[i, 15:18].ctypes.data, parts[i].ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "sensors.npz"), type=typ, to_world=tw, params=par, samples=smp, rays=rays, ray_diff=ray_d, dg=dgs, partials=parts)
+
 if __name__ == "__main__":
     main()

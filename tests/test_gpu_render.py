@@ -462,3 +462,32 @@ def test_path_tracer_regularization(gpu, orc, direct):
     assert abs(int(tr.stats().rays_total) - int(want_rays)) <= 2e-3 * want_rays
     plain, _ = orc.render(sc.desc, 96, 64, n_passes=3, tables=tables, direct=direct, max_path_length=6, rr_start=3, partials=True)
     assert np.abs(plain[..., :3] - want[..., :3]).mean() > 1e-3       # it really is a different estimator
+
+
+@pytest.mark.parametrize("kind", ["thinlens", "orthographic", "telecentric"])
+def test_thinlens_orthographic_and_telecentric_sensors(gpu, orc, kind):
+    """ray generation of the other projective sensors (SceneTypes/Sensor.cu; the oracle's restatement is pinned on the reference's own code, tests/golden/sensors.npz):
+    the aperture sample is used, orthographic cameras differentiate the ray ORIGIN (computePartials with the differential rays' own origins) — wavefront plugin
+    and, with an image texture under first-hit filtering, the megakernel plugin"""
+    sc = scenes.area_lights_scene(96, 64, "image")
+    s = gpu.api.ctl_sensor.from_buffer_copy(sc.desc.camera)
+    s.type = {"thinlens": 3, "orthographic": 4, "telecentric": 5}[kind]
+    s.aperture_radius, s.focus_distance = (0.25, 9.0) if kind == "thinlens" else (0.05, 6.0)
+    s.screen_scale[:] = [2.0, 2.0]
+    if kind != "thinlens":                                            # an orthographic view covers [-1, 1] camera units: look at the boxes from close by
+        s.near_depth, s.far_depth = 1e-5, 1e5
+    sc.setSensor(s); sc.UpdateScene()
+    assert sc.desc.camera.type == s.type
+    got, want, tr, rays = render_pair(gpu, orc, sc, 96, 64, 3)
+    assert_close(got, want)
+    assert want[..., :3].mean() > 0.01
+    base = scenes.area_lights_scene(96, 64, "image")
+    ref_img, _ = orc.render(base.desc, 96, 64, n_passes=3, tables=orc.sequence_tables(3))
+    assert np.abs(ref_img[..., :3] - want[..., :3]).mean() > 1e-2       # a different camera, not the perspective one
+    tables = orc.sequence_tables(3)
+    want_f, _ = orc.render(sc.desc, 96, 64, n_passes=3, tables=tables, partials=True)
+    mk = gpu.PathTracer(); mk.Resize(96, 64); mk.InitializeScene(gpu.Scene(sc.desc, flatten=True))
+    img = gpu.Image(96, 64)
+    for k in range(3):
+        mk.setSamplerTables(*tables[k]); mk.DoPass(img, new_trace=(k == 0))
+    assert_close(img.getPixelData(), want_f)
