@@ -102,6 +102,12 @@ def load_ref():
     r.ref_woop_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p]
     r.ref_construct_bvh.argtypes = [C.c_void_p, C.c_void_p, u32, u32, C.c_void_p, C.c_void_p]
     r.ref_construct_bvh_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    if hasattr(r, "ref_float3_to_rgbe"):
+        r.ref_float3_to_rgbe.restype = u32; r.ref_float3_to_rgbe.argtypes = [f32, f32, f32]
+        r.ref_float3_to_rgbcol.restype = u32; r.ref_float3_to_rgbcol.argtypes = [f32, f32, f32]
+        r.ref_rgbe_to_float3.argtypes = [u32, C.c_void_p]; r.ref_rgbcol_to_float3.argtypes = [u32, C.c_void_p]
+    if hasattr(r, "ref_filter_evaluate"):
+        r.ref_filter_evaluate.restype = f32; r.ref_filter_evaluate.argtypes = [C.c_int, f32, f32, f32, f32, f32, f32]
     if hasattr(r, "ref_sensor_rays"):
         r.ref_sensor_rays.argtypes = [C.c_int, C.c_void_p, f32, f32, f32, C.c_int, C.c_int, f32, f32, f32, f32, f32, f32, f32, C.c_void_p, C.c_void_p]
         r.ref_compute_partials_origins.argtypes = [C.c_void_p] * 11

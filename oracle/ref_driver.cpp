@@ -20,6 +20,7 @@
 #include <Math/MonteCarlo.h>
 #include <Math/Ray.h>
 #include <SceneTypes/Sensor.h>
+#include <SceneTypes/Filter.h>
 #include <cstdint>
 #include <cstring>
 
@@ -155,6 +156,21 @@ void ref_compute_partials_origins(const float* P, const float* n, const float* d
     dg.P = Vec3f(P[0], P[1], P[2]); dg.n = NormalizedT<Vec3f>(Vec3f(n[0], n[1], n[2])); dg.dpdu = Vec3f(dpdu[0], dpdu[1], dpdu[2]); dg.dpdv = Vec3f(dpdv[0], dpdv[1], dpdv[2]);
     dg.computePartials(Ray(Vec3f(ro[0], ro[1], ro[2]), Vec3f(rd[0], rd[1], rd[2])), Ray(Vec3f(rox[0], rox[1], rox[2]), Vec3f(rxd[0], rxd[1], rxd[2])), Ray(Vec3f(roy[0], roy[1], roy[2]), Vec3f(ryd[0], ryd[1], ryd[2])));
     out4[0] = dg.dudx; out4[1] = dg.dudy; out4[2] = dg.dvdx; out4[3] = dg.dvdy;
+}
+
+// Texel / frame codecs (Math/Spectrum.h:521-565): SpectrumConverter::Float3ToRGBE / RGBEToFloat3 / Float3ToCOLORREF / COLORREFToFloat3
+uint32_t ref_float3_to_rgbe(float r, float g, float b) { RGBE v = SpectrumConverter::Float3ToRGBE(Vec3f(r, g, b)); return (uint32_t)v.x | ((uint32_t)v.y << 8) | ((uint32_t)v.z << 16) | ((uint32_t)v.w << 24); }
+void ref_rgbe_to_float3(uint32_t q, float* out) { RGBE v; v.x = q & 255; v.y = (q >> 8) & 255; v.z = (q >> 16) & 255; v.w = q >> 24; Vec3f c = SpectrumConverter::RGBEToFloat3(v); out[0] = c.x; out[1] = c.y; out[2] = c.z; }
+uint32_t ref_float3_to_rgbcol(float r, float g, float b) { RGBCOL v = SpectrumConverter::Float3ToCOLORREF(Vec3f(r, g, b)); return (uint32_t)v.x | ((uint32_t)v.y << 8) | ((uint32_t)v.z << 16) | ((uint32_t)v.w << 24); }
+void ref_rgbcol_to_float3(uint32_t q, float* out) { RGBCOL v; v.x = q & 255; v.y = (q >> 8) & 255; v.z = (q >> 16) & 255; v.w = q >> 24; Vec3f c = SpectrumConverter::COLORREFToFloat3(v); out[0] = c.x; out[1] = c.y; out[2] = c.z; }
+
+// Reconstruction filters of the image pipeline (SceneTypes/Filter.h:28-171): type = TYPE_FUNC id (1 box, 2 Gaussian, 3 Mitchell, 4 Lanczos-sinc, 5 triangle)
+float ref_filter_evaluate(int type, float xw, float yw, float p0, float p1, float x, float y) {
+    if (type == 1) return BoxFilter(xw, yw).Evaluate(x, y);
+    if (type == 2) return GaussianFilter(xw, yw, p0).Evaluate(x, y);
+    if (type == 3) return MitchellFilter(p0, p1, xw, yw).Evaluate(x, y);
+    if (type == 4) return LanczosSincFilter(xw, yw, p0).Evaluate(x, y);
+    return TriangleFilter(xw, yw).Evaluate(x, y);
 }
 
 // ConstructBVH (Engine/MeshLoader/BVHBuilderHelper.cpp:116-127): SBVH with max leaf size 8.

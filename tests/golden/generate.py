@@ -201,5 +201,33 @@ def main():
                                        rays[i, 12:15].ctypes.data, rays[i, 15:18].ctypes.data, parts[i].ctypes.data)
     np.savez_compressed(os.path.join(HERE, "sensors.npz"), type=typ, to_world=tw, params=par, samples=smp, rays=rays, ray_diff=ray_d, dg=dgs, partials=parts)
 
+    # ---- reconstruction filters of the image pipeline (SceneTypes/Filter.h), own random stream
+    rs4 = np.random.RandomState(20260932)
+    n = 600
+    cfg = np.zeros((n, 5), np.float32); xy = np.zeros((n, 2), np.float32); val = np.zeros(n, np.float32)
+    for i in range(n):
+        t = 1 + i % 5
+        xw, yw = np.float32(rs4.choice([1.0, 2.0, 3.0, 6.0])), np.float32(rs4.choice([1.0, 2.0, 3.0, 6.0]))
+        p0, p1 = {1: (0, 0), 2: (rs4.choice([2.0, 0.5, 1.0]), 0), 3: (rs4.choice([1 / 3.0, 0.0, 1.0]), rs4.choice([1 / 3.0, 0.5])), 4: (rs4.choice([3.0, 2.0]), 0), 5: (0, 0)}[t]
+        cfg[i] = [t, xw, yw, p0, p1]
+        xy[i] = (rs4.uniform(0, 1.1, size=2) * [xw, yw]).astype(np.float32)          # |dx|, |dy| as CanonicalFilter passes them, a little beyond the support
+        if i % 50 < 5: xy[i, 0] = 0.0                                                # the sinc's small-argument branch
+        val[i] = r.ref_filter_evaluate(int(t), f32(xw), f32(yw), f32(cfg[i, 3]), f32(cfg[i, 4]), f32(xy[i, 0]), f32(xy[i, 1]))
+    np.savez_compressed(os.path.join(HERE, "filters.npz"), cfg=cfg, xy=xy, value=val)
+
+    # ---- texel / frame codecs (Math/Spectrum.h:521-565), own random stream: RGBE and RGBCOL both ways
+    rs5 = np.random.RandomState(20260933)
+    n = 4096
+    rgb = (rs5.uniform(0, 1, size=(n, 3)) * np.exp2(rs5.randint(-20, 21, size=(n, 1)))).astype(np.float32)
+    rgb[:16] = 0; rgb[16:32] = [[1e-33, 0, 0]] * 16; rgb[32] = [1.0, 0.5, 0.25]; rgb[33] = [255.9999, 256.0, 1.0]; rgb[34] = [-1.0, 0.5, 2.0]; rgb[35] = [0.5, 0.5, 0.5]
+    rgb[36:300] = rs5.uniform(-0.2, 1.2, size=(264, 3)).astype(np.float32)                     # the RGBCOL clamp range
+    enc_e = np.zeros(n, np.uint32); enc_c = np.zeros(n, np.uint32); dec_e = np.zeros((n, 3), np.float32); dec_c = np.zeros((n, 3), np.float32)
+    words = rs5.randint(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    for i in range(n):
+        enc_e[i] = r.ref_float3_to_rgbe(f32(rgb[i, 0]), f32(rgb[i, 1]), f32(rgb[i, 2])) if rgb[i].min() >= 0 else 0
+        enc_c[i] = r.ref_float3_to_rgbcol(f32(rgb[i, 0]), f32(rgb[i, 1]), f32(rgb[i, 2]))
+        r.ref_rgbe_to_float3(int(words[i]), dec_e[i].ctypes.data); r.ref_rgbcol_to_float3(int(words[i]), dec_c[i].ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "spectrum_codecs.npz"), rgb=rgb, rgbe=enc_e, rgbcol=enc_c, words=words, from_rgbe=dec_e, from_rgbcol=dec_c)
+
 if __name__ == "__main__":
     main()

@@ -81,3 +81,21 @@ def test_reinhard_of_a_grey_image():
     lw = 0.5 * scale
     y = lambda L: (L * scale) * (1 + L * scale / lw ** 2) / (1 + L * scale)
     assert abs(out[0, 0, 0] - int(y(lo) * 255)) <= 1 and out[0, 5, 0] >= 253
+
+
+def test_filter_functions_against_the_reference():
+    """Box / Gaussian / Mitchell / Lanczos-sinc / triangle Evaluate (SceneTypes/Filter.h:28-171) of the numpy restatement against values computed by the
+    reference's own header (tests/golden/filters.npz).  Box, Mitchell and triangle are polynomial: bit for bit.  Gaussian and Lanczos go through
+    exp / sin of the C library there and of numpy here: 4 ulp of the larger factor."""
+    import os
+    from oracle import pipeline as P
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "filters.npz"))
+    worst = {}
+    for cfg, xy, want in zip(g["cfg"], g["xy"], g["value"]):
+        t = int(cfg[0])
+        got = np.float32(P.filter_eval(dict(type=t, xw=float(cfg[1]), yw=float(cfg[2]), p0=float(cfg[3]), p1=float(cfg[4])), xy[0], xy[1]))
+        if t in (1, 3, 5):
+            assert got.view(np.uint32) == want.view(np.uint32), (t, cfg, xy, got, want)
+        else:
+            err = abs(float(got) - float(want)); worst[t] = max(worst.get(t, 0.0), err / max(abs(float(want)), 1e-3))
+    assert set(worst) == {2, 4} and max(worst.values()) <= 4 * 1.2e-7 * 8, worst
