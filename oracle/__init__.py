@@ -102,6 +102,9 @@ def load_ref():
     r.ref_woop_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p]
     r.ref_construct_bvh.argtypes = [C.c_void_p, C.c_void_p, u32, u32, C.c_void_p, C.c_void_p]
     r.ref_construct_bvh_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    if hasattr(r, "ref_wrap_coordinates"):
+        r.ref_wrap_coordinates.argtypes = [f32, f32, f32, f32, C.c_int, C.c_void_p]
+        r.ref_checkerboard_select.argtypes = [f32] * 6
     if hasattr(r, "ref_float3_to_rgbe"):
         r.ref_float3_to_rgbe.restype = u32; r.ref_float3_to_rgbe.argtypes = [f32, f32, f32]
         r.ref_float3_to_rgbcol.restype = u32; r.ref_float3_to_rgbcol.argtypes = [f32, f32, f32]

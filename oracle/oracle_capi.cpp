@@ -205,6 +205,7 @@ void orc_env_eval(const ctl_scene_desc* desc, const float* dir, float* out) {
     out[0] = v.x; out[1] = v.y; out[2] = v.z;
 }
 // ImageTexture / checkerboard / constant evaluation at a uv (Texture::Evaluate(dg))
+int orc_wrap_coordinates(float u, float v, float w, float h, uint32_t mode, float* loc) { V2 l{ 0.0f, 0.0f }; const bool ok = wrapCoordinates(V2{ u, v }, V2{ w, h }, mode, l); loc[0] = l.x; loc[1] = l.y; return ok ? 1 : 0; }
 void orc_texture_eval(const ctl_scene_desc* desc, const ctl_texture* t, float u, float v, float* out) {
     DG dg; dg.uv = V2{ u, v }; dg.images = desc ? desc->images : nullptr;
     Spec s = texEval(*t, dg); out[0] = s.x; out[1] = s.y; out[2] = s.z;

@@ -21,6 +21,8 @@
 #include <Math/Ray.h>
 #include <SceneTypes/Sensor.h>
 #include <SceneTypes/Filter.h>
+#include <SceneTypes/Texture.h>
+#include <Engine/MIPMap_device.h>
 #include <cstdint>
 #include <cstring>
 
@@ -163,6 +165,16 @@ uint32_t ref_float3_to_rgbe(float r, float g, float b) { RGBE v = SpectrumConver
 void ref_rgbe_to_float3(uint32_t q, float* out) { RGBE v; v.x = q & 255; v.y = (q >> 8) & 255; v.z = (q >> 16) & 255; v.w = q >> 24; Vec3f c = SpectrumConverter::RGBEToFloat3(v); out[0] = c.x; out[1] = c.y; out[2] = c.z; }
 uint32_t ref_float3_to_rgbcol(float r, float g, float b) { RGBCOL v = SpectrumConverter::Float3ToCOLORREF(Vec3f(r, g, b)); return (uint32_t)v.x | ((uint32_t)v.y << 8) | ((uint32_t)v.z << 16) | ((uint32_t)v.w << 24); }
 void ref_rgbcol_to_float3(uint32_t q, float* out) { RGBCOL v; v.x = q & 255; v.y = (q >> 8) & 255; v.z = (q >> 16) & 255; v.w = q >> 24; Vec3f c = SpectrumConverter::COLORREFToFloat3(v); out[0] = c.x; out[1] = c.y; out[2] = c.z; }
+
+// WrapCoordinates (Engine/MIPMap_device.h:33-55): texture addressing of the four wrap modes; returns 0 when the lookup is black
+int ref_wrap_coordinates(float u, float v, float w, float h, int mode, float* loc) {
+    Vec2f l(0.0f); const bool ok = WrapCoordinates(Vec2f(u, v), Vec2f(w, h), (ImageWrap)mode, &l); loc[0] = l.x; loc[1] = l.y; return ok ? 1 : 0;
+}
+// CheckerboardTexture::Evaluate over TextureMapping2D(su, sv, du, dv) (SceneTypes/Texture.h:127-146, :10-41): 0 = val0, 1 = val1
+int ref_checkerboard_select(float u, float v, float su, float sv, float du, float dv) {
+    CheckerboardTexture t(Spectrum(1.0f), Spectrum(0.0f), TextureMapping2D(su, sv, du, dv));
+    Spectrum s = t.Evaluate(Vec2f(u, v)); return s[0] > 0.5f ? 0 : 1;
+}
 
 // Reconstruction filters of the image pipeline (SceneTypes/Filter.h:28-171): type = TYPE_FUNC id (1 box, 2 Gaussian, 3 Mitchell, 4 Lanczos-sinc, 5 triangle)
 float ref_filter_evaluate(int type, float xw, float yw, float p0, float p1, float x, float y) {

@@ -229,5 +229,18 @@ def main():
         r.ref_rgbe_to_float3(int(words[i]), dec_e[i].ctypes.data); r.ref_rgbcol_to_float3(int(words[i]), dec_c[i].ctypes.data)
     np.savez_compressed(os.path.join(HERE, "spectrum_codecs.npz"), rgb=rgb, rgbe=enc_e, rgbcol=enc_c, words=words, from_rgbe=dec_e, from_rgbcol=dec_c)
 
+    # ---- texture addressing and the checkerboard (Engine/MIPMap_device.h:33-55, SceneTypes/Texture.h:10-41, :127-146), own random stream
+    rs6 = np.random.RandomState(20260934)
+    n = 2048
+    uv = rs6.uniform(-3, 3, size=(n, 2)).astype(np.float32); uv[:64] = rs6.randint(-3, 4, size=(64, 2)).astype(np.float32)   # exact integers: frac == 0
+    dim = rs6.choice([1.0, 7.0, 64.0, 300.0], size=(n, 2)).astype(np.float32); mode = (np.arange(n) % 4).astype(np.int32)
+    loc = np.zeros((n, 2), np.float32); ok = np.zeros(n, np.int32)
+    mp = np.stack([rs6.choice([1.0, 2.0, 0.5, 12.0], size=n), rs6.choice([1.0, 3.0, 0.25], size=n), rs6.uniform(-1, 1, size=n), rs6.uniform(-1, 1, size=n)], axis=1).astype(np.float32)
+    sel = np.zeros(n, np.int32)
+    for i in range(n):
+        ok[i] = r.ref_wrap_coordinates(f32(uv[i, 0]), f32(uv[i, 1]), f32(dim[i, 0]), f32(dim[i, 1]), int(mode[i]), loc[i].ctypes.data)
+        sel[i] = r.ref_checkerboard_select(f32(uv[i, 0]), f32(uv[i, 1]), f32(mp[i, 0]), f32(mp[i, 1]), f32(mp[i, 2]), f32(mp[i, 3]))
+    np.savez_compressed(os.path.join(HERE, "texture_addressing.npz"), uv=uv, dim=dim, mode=mode, loc=loc, ok=ok, mapping=mp, checker=sel)
+
 if __name__ == "__main__":
     main()
