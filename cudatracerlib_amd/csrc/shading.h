@@ -44,8 +44,15 @@ __device__ __forceinline__ m34 sensor_to_world(const dev_sensor& c) {
     return m;
 }
 __device__ __forceinline__ void sensor_sample_ray(const dev_sensor& c, f2 pixelSample, f2 apertureSample, f3& o, f3& d) {
-    const f3 nearP = sensor_near_point(c, pixelSample);
     const m34 m = sensor_to_world(c);
+    if (c.type == CTL_SENSOR_SPHERICAL) {   // SphericalSensor::sampleRay (Sensor.cu:6-17)
+        float sinPhi, cosPhi, sinTheta, cosTheta;
+        sincosf((1.0f - pixelSample.x * c.inv_res[0]) * 2 * kPi, &sinPhi, &cosPhi);
+        sincosf((1.0f - pixelSample.y * c.inv_res[1]) * kPi, &sinTheta, &cosTheta);
+        o = xform_point(m, f3(0.0f)); d = xform_dir(m, f3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta));
+        return;
+    }
+    const f3 nearP = sensor_near_point(c, pixelSample);
     if (c.type == CTL_SENSOR_PERSPECTIVE) {
         o = xform_point(m, f3(0.0f));   // toWorld.Translation()
         d = xform_dir(m, normalize(nearP));
@@ -65,6 +72,9 @@ __device__ __forceinline__ void sensor_sample_ray(const dev_sensor& c, f2 pixelS
 }
 // the ray and its x / y neighbours (perspective sensors shift the direction, orthographic ones the origin)
 __device__ __forceinline__ void sensor_sample_ray_differential(const dev_sensor& c, f2 pixelSample, f2 apertureSample, f3& o, f3& d, f3& oX, f3& dX, f3& oY, f3& dY) {
+    if (c.type == CTL_SENSOR_SPHERICAL) {   // SphericalSensor::sampleRayDifferential (Sensor.h:122-125) sets the ray only and leaves rayX / rayY as they were: the ray itself is used
+        sensor_sample_ray(c, pixelSample, apertureSample, o, d); oX = oY = o; dX = dY = d; return;
+    }
     const f3 nearP = sensor_near_point(c, pixelSample);
     const m34 m = sensor_to_world(c);
     const f3 ddx(c.dx[0], c.dx[1], c.dx[2]), ddy(c.dy[0], c.dy[1], c.dy[2]);

@@ -301,8 +301,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
     for (int i = 0; i < CTL_MAX_NUM_LIGHTS; i++) { S.light_indices[i] = d.light_indices[i]; S.light_cdf[i] = d.light_cdf[i]; }
     // PerspectiveSensor / ThinLensSensor / OrthographicSensor / TelecentricSensor ::Update (SceneTypes/Sensor.cu:76-96, :226-246, :408-427, :515-535)
     const ctl_sensor& c = d.camera;
-    if (c.type != CTL_SENSOR_PERSPECTIVE && c.type != CTL_SENSOR_THINLENS && c.type != CTL_SENSOR_ORTHOGRAPHIC && c.type != CTL_SENSOR_TELECENTRIC)
-        throw std::runtime_error("ctl_scene_create: sensor type " + std::to_string(c.type) + " is not implemented (perspective, thin lens, orthographic and telecentric are)");
+    if (c.type < CTL_SENSOR_SPHERICAL || c.type > CTL_SENSOR_TELECENTRIC) throw std::runtime_error("ctl_scene_create: unknown sensor type " + std::to_string(c.type));
     const bool ortho = c.type == CTL_SENSOR_ORTHOGRAPHIC || c.type == CTL_SENSOR_TELECENTRIC;
     const float aspect = c.resolution[0] / c.resolution[1];
     const float recip = 1.0f / (c.far_depth - c.near_depth), cot = 1.0f / tanf(c.fov / 2.0f);

@@ -616,10 +616,11 @@ struct SensorO {
     M44 toWorld, sampleToCamera; V2 invRes; V3 dx, dy; float apertureRadius = 0, focusDistance = 0, screenScaleX = 1;
     void update(const ctl_sensor& s) {
         type = s.type;
-        if (type != CTL_SENSOR_PERSPECTIVE && type != CTL_SENSOR_THINLENS && type != CTL_SENSOR_ORTHOGRAPHIC && type != CTL_SENSOR_TELECENTRIC) throw std::runtime_error("oracle: sensor type not restated");
+        if (type < CTL_SENSOR_SPHERICAL || type > CTL_SENSOR_TELECENTRIC) throw std::runtime_error("oracle: unknown sensor type");
         std::memcpy(toWorld.d, s.to_world, 64);
         float aspect = s.resolution[0] / s.resolution[1];
         invRes = V2{ 1.0f / s.resolution[0], 1.0f / s.resolution[1] };
+        if (type == CTL_SENSOR_SPHERICAL) return;
         const bool ortho = type == CTL_SENSOR_ORTHOGRAPHIC || type == CTL_SENSOR_TELECENTRIC;
         // float4x4::orthographic (float4x4.h:625-628) = Scale(1, 1, 1 / (far - near)) % Translate(0, 0, -near)
         M44 proj = ortho ? mul(scaleM(V3(1.0f, 1.0f, 1.0f / (s.far_depth - s.near_depth))), translateM(V3(0.0f, 0.0f, -s.near_depth))) : perspective(s.fov, s.near_depth, s.far_depth);
@@ -632,6 +633,13 @@ struct SensorO {
     // sampleRayDifferential of the four types (Sensor.cu:130-144, :292-311, :440-450, :558-574); sampleRay (:116-128, :267-290, :429-438, :537-556) is its first ray,
     // except that OrthographicSensor::sampleRay starts on the plane z = 0 of the camera while its differential version starts at nearP
     void sampleRayDifferential(V2 pixelSample, V2 apertureSample, V3& o, V3& d, V3& oX, V3& dX, V3& oY, V3& dY, bool plain = false) const {
+        if (type == CTL_SENSOR_SPHERICAL) {   // SphericalSensor::sampleRay (Sensor.cu:6-17); its sampleRayDifferential (Sensor.h:122-125) leaves rayX / rayY unset: the ray itself is used here
+            float sinPhi = sinf((1.0f - pixelSample.x * invRes.x) * 2 * PI), cosPhi = cosf((1.0f - pixelSample.x * invRes.x) * 2 * PI);
+            float sinTheta = sinf((1.0f - pixelSample.y * invRes.y) * PI), cosTheta = cosf((1.0f - pixelSample.y * invRes.y) * PI);
+            o = transformPoint(toWorld, V3(0.0f)); d = transformDir(toWorld, V3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta));
+            oX = oY = o; dX = dY = d;
+            return;
+        }
         V3 nearP = transformPoint(sampleToCamera, V3(pixelSample.x * invRes.x, pixelSample.y * invRes.y, 0.0f));
         if (type == CTL_SENSOR_PERSPECTIVE) {
             o = transformPoint(toWorld, V3(0.0f));   // toWorld.Translation() (float4x4.h:93-96)

@@ -147,7 +147,9 @@ void ref_sensor_sample_ray_differential(const float* to_world, float fov_rad, fl
 // out18 = sampleRay (o, d), then the x ray (o, d) and the y ray (o, d) of sampleRayDifferential; out6b = sampleRayDifferential's own ray
 void ref_sensor_rays(int type, const float* to_world, float fov_rad, float nearD, float farD, int w, int h, float aperture, float focus, float screen_scale,
                      float px, float py, float ax, float ay, float* out18, float* out6b) {
-    if (type == 2) { PerspectiveSensor s(w, h, 90.0f); s.fov = fov_rad; sensor_rays(s, to_world, nearD, farD, px, py, ax, ay, out18, out6b); }
+    if (type == 1) { SphericalSensor s(w, h); NormalizedT<OrthogonalAffineMap> m; std::memcpy(m.data, to_world, 64); s.SetToWorld(m); NormalizedT<Ray> r; s.sampleRay(r, Vec2f(px, py), Vec2f(ax, ay));
+        const Vec3f v[2] = { r.ori(), r.dir() }; for (int k = 0; k < 6; k++) { out18[3 * k] = v[k & 1].x; out18[3 * k + 1] = v[k & 1].y; out18[3 * k + 2] = v[k & 1].z; } for (int k = 0; k < 6; k++) out6b[k] = out18[k]; }
+    else if (type == 2) { PerspectiveSensor s(w, h, 90.0f); s.fov = fov_rad; sensor_rays(s, to_world, nearD, farD, px, py, ax, ay, out18, out6b); }
     else if (type == 3) { ThinLensSensor s(w, h, 90.0f, aperture, focus); s.fov = fov_rad; sensor_rays(s, to_world, nearD, farD, px, py, ax, ay, out18, out6b); }
     else if (type == 4) { OrthographicSensor s(w, h, screen_scale, screen_scale); sensor_rays(s, to_world, nearD, farD, px, py, ax, ay, out18, out6b); }
     else { TelecentricSensor s(w, h, aperture, focus, screen_scale, screen_scale); sensor_rays(s, to_world, nearD, farD, px, py, ax, ay, out18, out6b); }

@@ -242,5 +242,17 @@ def main():
         sel[i] = r.ref_checkerboard_select(f32(uv[i, 0]), f32(uv[i, 1]), f32(mp[i, 0]), f32(mp[i, 1]), f32(mp[i, 2]), f32(mp[i, 3]))
     np.savez_compressed(os.path.join(HERE, "texture_addressing.npz"), uv=uv, dim=dim, mode=mode, loc=loc, ok=ok, mapping=mp, checker=sel)
 
+    # ---- SphericalSensor::sampleRay (SceneTypes/Sensor.cu:6-17), own random stream
+    rs7 = np.random.RandomState(20260935)
+    n = 256
+    tw = np.zeros((n, 16), np.float32); res = np.zeros((n, 2), np.float32); px = np.zeros((n, 2), np.float32); rays = np.zeros((n, 18), np.float32); tmp6 = np.zeros(6, np.float32)
+    for i in range(n):
+        w, h = int(rs7.choice([64, 512, 2048])), int(rs7.choice([32, 256, 1024]))
+        q, _ = np.linalg.qr(rs7.normal(size=(3, 3)))
+        m = np.eye(4, dtype=np.float32); m[:3, :3] = q; m[:3, 3] = rs7.normal(size=3) * 20
+        tw[i] = m.reshape(16); res[i] = [w, h]; px[i] = (rs7.uniform(0, 1, size=2) * [w, h]).astype(np.float32)
+        r.ref_sensor_rays(1, tw[i].ctypes.data, f32(1.0), f32(1e-2), f32(1e4), w, h, f32(0), f32(0), f32(1), f32(px[i, 0]), f32(px[i, 1]), f32(0.5), f32(0.5), rays[i].ctypes.data, tmp6.ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "sensor_spherical.npz"), to_world=tw, resolution=res, pixel=px, ray=rays[:, :6])
+
 if __name__ == "__main__":
     main()

@@ -464,17 +464,17 @@ def test_path_tracer_regularization(gpu, orc, direct):
     assert np.abs(plain[..., :3] - want[..., :3]).mean() > 1e-3       # it really is a different estimator
 
 
-@pytest.mark.parametrize("kind", ["thinlens", "orthographic", "telecentric"])
+@pytest.mark.parametrize("kind", ["thinlens", "orthographic", "telecentric", "spherical"])
 def test_thinlens_orthographic_and_telecentric_sensors(gpu, orc, kind):
     """ray generation of the other projective sensors (SceneTypes/Sensor.cu; the oracle's restatement is pinned on the reference's own code, tests/golden/sensors.npz):
     the aperture sample is used, orthographic cameras differentiate the ray ORIGIN (computePartials with the differential rays' own origins) — wavefront plugin
     and, with an image texture under first-hit filtering, the megakernel plugin"""
     sc = scenes.area_lights_scene(96, 64, "image")
     s = gpu.api.ctl_sensor.from_buffer_copy(sc.desc.camera)
-    s.type = {"thinlens": 3, "orthographic": 4, "telecentric": 5}[kind]
+    s.type = {"thinlens": 3, "orthographic": 4, "telecentric": 5, "spherical": 1}[kind]
     s.aperture_radius, s.focus_distance = (0.25, 9.0) if kind == "thinlens" else (0.05, 6.0)
     s.screen_scale[:] = [2.0, 2.0]
-    if kind != "thinlens":                                            # an orthographic view covers [-1, 1] camera units: look at the boxes from close by
+    if kind in ("orthographic", "telecentric"):                       # an orthographic view covers [-1, 1] camera units: look at the boxes from close by
         s.near_depth, s.far_depth = 1e-5, 1e5
     sc.setSensor(s); sc.UpdateScene()
     assert sc.desc.camera.type == s.type
