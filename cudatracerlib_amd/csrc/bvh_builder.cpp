@@ -244,15 +244,124 @@ struct collapser {
         return me;
     }
 };
+
+// SAH-optimal collapse (the dynamic programme of Ylitie, Karras & Laine, "Efficient incoherent ray traversal on GPUs through compressed wide BVHs",
+// HPG 2017, section 4.1, for 4 slots): for every BVH2 subtree v and k = 1..4 slots of a parent, F(v, k) = the cheapest way to hang v's primitives into at most k
+// slots — one slot holding v as a wide node (area * node_cost + the best split of its two children over 4 slots), one slot holding ALL of v's primitives as one
+// leaf (area * count * 1, when count <= max_leaf), or v's two children sharing the k slots.  The greedy collapse leaves 42 % of the nodes of the bench
+// scene with two children (a binary bottom node over two one-triangle leaves becomes a wide node of its own); this one fills the slots and sizes the leaves.
+struct dp_collapser {
+    bvh_result& R; std::vector<wide4_node>& out; const float node_cost; const int max_leaf;
+    int max_depth = 0;
+    struct rec { float F[4]; uint32_t first, count; float area; uint8_t one_is_leaf; uint8_t split[4]; };   // split[k]: slots given to child 0 when v spreads over k + 1 slots (0 = v stays in one slot)
+    std::vector<rec> T;   // per inner BVH2 node
+
+    static bool inner(int code) { return code >= 0 && code != 0x76543210; }
+    uint32_t leaf_count(int code) const { uint32_t n = 1; for (uint32_t e = (uint32_t)~code; !R.leaf_last[e]; e++) n++; return n; }
+    // F(child, k) for k = 1..4 (index k - 1)
+    void child_cost(int code, const aabb& box, float F[4]) const {
+        if (code == 0x76543210) { F[0] = F[1] = F[2] = F[3] = 0.0f; return; }
+        if (inner(code)) { for (int k = 0; k < 4; k++) F[k] = T[code / 4].F[k]; return; }
+        const float c = box.area() * (float)leaf_count(code);
+        F[0] = F[1] = F[2] = F[3] = c;
+    }
+    void solve() {
+        T.resize(R.nodes.size());
+        for (int v = (int)R.nodes.size() - 1; v >= 0; v--) {   // children are emitted after their parent (bvh_builder's emitter): reverse index order is a post-order
+            const ctl_bvh_node& n = R.nodes[v];
+            rec& t = T[v];
+            aabb b0 = node_child_box(n, 0), b1 = node_child_box(n, 1), box; box.reset();
+            const bool has0 = n.child0 != 0x76543210, has1 = n.child1 != 0x76543210;
+            if (has0) box.grow(b0); if (has1) box.grow(b1);
+            t.area = box.area();
+            auto first_of = [&](int code) { return inner(code) ? T[code / 4].first : (uint32_t)~code; };
+            auto count_of = [&](int code) { return inner(code) ? T[code / 4].count : leaf_count(code); };
+            t.first = has0 ? first_of(n.child0) : first_of(n.child1);
+            t.count = (has0 ? count_of(n.child0) : 0u) + (has1 ? count_of(n.child1) : 0u);
+            float F0[4], F1[4];
+            child_cost(n.child0, b0, F0); child_cost(n.child1, b1, F1);
+            // D[k]: the two children share k + 1 slots (k = 1..3); a missing child takes none
+            float D[4] = { 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f }; uint8_t Di[4] = { 0, 0, 0, 0 };
+            if (has0 && has1) {
+                for (int k = 1; k < 4; k++) for (int i = 1; i <= k; i++) { const float c = F0[i - 1] + F1[k - i]; if (c < D[k]) { D[k] = c; Di[k] = (uint8_t)i; } }
+            } else {
+                const float* Fc = has0 ? F0 : F1;
+                for (int k = 1; k < 4; k++) { D[k] = Fc[k]; Di[k] = has0 ? (uint8_t)(k + 1) : 0; }
+            }
+            const float as_node = t.area * node_cost + D[3];
+            const float as_leaf = (int)t.count <= max_leaf ? t.area * (float)t.count : 3.402823466e+38f;
+            t.one_is_leaf = as_leaf <= as_node;
+            t.F[0] = t.one_is_leaf ? as_leaf : as_node; t.split[0] = 0;
+            for (int k = 1; k < 4; k++) {
+                t.F[k] = t.F[k - 1]; t.split[k] = t.split[k - 1] ? t.split[k - 1] : 0;
+                uint8_t how = t.split[k - 1] ? (uint8_t)(0x80 | (k - 1)) : 0;   // 0x80 | j: use the arrangement found for j + 1 slots
+                if (D[k] < t.F[k]) { t.F[k] = D[k]; how = (uint8_t)(0x40 | Di[k]); }   // 0x40 | i: spread over exactly k + 1 slots, i of them to child 0
+                t.split[k] = how;
+            }
+        }
+    }
+    struct item { int code; aabb box; bool merged_leaf; };
+    // the slots subtree `code` occupies when it may use up to k + 1 of them
+    void collect(int code, const aabb& box, int k, item* it, int& n) {
+        if (!inner(code)) { it[n++] = { code, box, false }; return; }
+        const rec& t = T[code / 4];
+        uint8_t how = t.split[k]; int kk = k;
+        while (how & 0x80) { kk = how & 3; how = t.split[kk]; }
+        if (!(how & 0x40)) { it[n++] = { code, box, t.one_is_leaf != 0 }; return; }   // one slot
+        const int i = how & 7;
+        const ctl_bvh_node& nd = R.nodes[code / 4];
+        const bool has0 = nd.child0 != 0x76543210, has1 = nd.child1 != 0x76543210;
+        if (has0 && has1) { collect(nd.child0, node_child_box(nd, 0), i - 1, it, n); collect(nd.child1, node_child_box(nd, 1), kk - i, it, n); }
+        else if (has0) collect(nd.child0, node_child_box(nd, 0), kk, it, n);
+        else collect(nd.child1, node_child_box(nd, 1), kk, it, n);
+    }
+    int emit(int code2, const aabb& box, int depth) {
+        if (depth > max_depth) max_depth = depth;
+        item it[4]; int n = 0;
+        const ctl_bvh_node& nd = R.nodes[code2 / 4];
+        const bool has0 = nd.child0 != 0x76543210, has1 = nd.child1 != 0x76543210;
+        if (has0 && has1) {
+            // the best split of the node's own 4 slots (D[3] of solve())
+            float F0[4], F1[4]; child_cost(nd.child0, node_child_box(nd, 0), F0); child_cost(nd.child1, node_child_box(nd, 1), F1);
+            int bi = 1; float bc = 3.402823466e+38f;
+            for (int i = 1; i <= 3; i++) { const float c = F0[i - 1] + F1[3 - i]; if (c < bc) { bc = c; bi = i; } }
+            collect(nd.child0, node_child_box(nd, 0), bi - 1, it, n); collect(nd.child1, node_child_box(nd, 1), 3 - bi, it, n);
+        } else if (has0) collect(nd.child0, node_child_box(nd, 0), 3, it, n);
+        else if (has1) collect(nd.child1, node_child_box(nd, 1), 3, it, n);
+        const int me = (int)out.size();
+        out.emplace_back();
+        out[me].box = box; out[me].n = n;
+        for (int i = 0; i < 4; i++) { out[me].child[i] = 0x76543210; out[me].cbox[i].reset(); }
+        for (int i = 0; i < n; i++) {
+            int c;
+            if (!inner(it[i].code)) c = it[i].code;
+            else if (it[i].merged_leaf) {   // the whole subtree as one leaf: its entries are consecutive in leaf_prims (depth-first emission); only the last one closes it
+                const rec& t = T[it[i].code / 4];
+                for (uint32_t e = t.first; e + 1 < t.first + t.count; e++) R.leaf_last[e] = 0;
+                R.leaf_last[t.first + t.count - 1] = 1;
+                c = ~(int)t.first;
+            } else c = emit(it[i].code, it[i].box, depth + 1);
+            out[me].child[i] = c; out[me].cbox[i] = it[i].box;
+        }
+        return me;
+    }
+};
 } // namespace
 
-void collapse_bvh4(const bvh_result& R, std::vector<wide4_node>& out, int& max_depth) {
+void collapse_bvh4(bvh_result& R, std::vector<wide4_node>& out, int& max_depth, int mode, float node_cost, int max_leaf) {
     out.clear(); max_depth = 0;
     if (R.nodes.empty()) return;
     aabb box; box.reset();
     box.grow(node_child_box(R.nodes[0], 0)); if (R.nodes[0].child1 != 0x76543210) box.grow(node_child_box(R.nodes[0], 1));
-    collapser C{ R, out };
-    C.emit(0, box, 0);
-    max_depth = C.max_depth;
+    if (mode == 0) {
+        collapser C{ R, out };
+        C.emit(0, box, 0);
+        max_depth = C.max_depth;
+    } else {
+        dp_collapser C{ R, out, node_cost, max_leaf };
+        C.solve();
+        C.emit(0, box, 0);
+        max_depth = C.max_depth;
+    }
 }
 } // namespace ctl

@@ -39,8 +39,10 @@ void build_sbvh(const float* positions, const uint32_t* indices, uint32_t n_tri,
 } // namespace ctl
 
 namespace ctl {
-// 4-wide node obtained by collapsing the BVH2 (greedy: repeatedly open the inner child with the largest surface area).
-// child >= 0: index into the wide-node array; child < 0: ~firstLeafEntry (same leaf entries as the BVH2); n = children used.
+// 4-wide node obtained by collapsing the BVH2.  mode 0: greedy (repeatedly open the inner child with the largest surface area).  mode 1: SAH-optimal dynamic
+// programme over (subtree, slots) with `node_cost` per wide-node visit and 1 per leaf entry; it may also merge a subtree of <= max_leaf primitives into ONE
+// leaf, which rewrites R.leaf_last (the primitives of a subtree are consecutive in R.leaf_prims).
+// child >= 0: index into the wide-node array; child < 0: ~firstLeafEntry (entries of R.leaf_prims up to the next leaf_last flag); n = children used.
 struct wide4_node { aabb box; aabb cbox[4]; int child[4]; int n; };
-void collapse_bvh4(const bvh_result& R, std::vector<wide4_node>& out, int& max_depth);
+void collapse_bvh4(bvh_result& R, std::vector<wide4_node>& out, int& max_depth, int mode = 1, float node_cost = 0.75f, int max_leaf = 4);
 } // namespace ctl

@@ -24,6 +24,10 @@ namespace {
 // a 4-wide node covers two levels of the binary tree in one fetch + one loop iteration, a leaf entry costs one of each per triangle.
 // Measured on synthetic-SM: node cost 1 -> 34.0 nodes + 8.45 triangles per ray, 0.5 -> 35.3 + 6.28 and +1 % rays/s; leaf size 2 / 4 / 8: no difference
 int flat_max_leaf() { static const int v = [] { const char* e = getenv("CTL_FLAT_MAX_LEAF"); const int x = e ? atoi(e) : 0; return x >= 1 && x <= 16 ? x : 4; }(); return v; }
+// collapse of the binary tree into 4-wide nodes: 1 = SAH-optimal dynamic programme (bvh_builder.h), 0 = greedy; its node cost is in leaf-entry tests:
+// k_intersect spends ~277 lane-slots on a node step and ~365 on a leaf-entry step at its measured lane utilisation
+int flat_collapse_mode() { static const int v = [] { const char* e = getenv("CTL_FLAT_COLLAPSE"); return e ? atoi(e) : 0; }(); return v; }
+float flat_collapse_node_cost() { static const float v = [] { const char* e = getenv("CTL_FLAT_COLLAPSE_NODE_COST"); const float x = e ? (float)atof(e) : 0.0f; return x > 0.0f ? x : 0.75f; }(); return v; }
 float flat_node_cost() { static const float v = [] { const char* e = getenv("CTL_FLAT_NODE_COST"); const float x = e ? (float)atof(e) : 0.0f; return x > 0.0f ? x : 0.5f; }(); return v; }
 
 // 4x4 inverse in double (cofactor expansion)
@@ -129,8 +133,8 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node format only
     std::string key;
     if (!cache_dir().empty()) {
-        content_hash H; const uint32_t version = 7;
-        H.add_value(version); H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
+        content_hash H; const uint32_t version = 8;
+        H.add_value(version); H.add_value(flat_collapse_mode()); H.add_value(flat_collapse_node_cost()); H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
         for (uint32_t k = 0; k < d.n_nodes; k++) { H.add_value(d.nodes[k].mesh_index); H.add(d.node_transforms[k].m, 64); }
@@ -216,7 +220,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     } else {
         // collapse to 4-wide nodes
         std::vector<wide4_node> W;
-        collapse_bvh4(R, W, wdepth);
+        collapse_bvh4(R, W, wdepth, flat_collapse_mode(), flat_collapse_node_cost(), std::min(flat_max_leaf(), 4));
         {   // memory order: the inner children of a node sit next to each other, subtrees stay clustered: a ray that enters a node
             // usually enters one or two of its children next, and neighbouring lines share DRAM pages / L2 sets
             std::vector<int> new_id(W.size(), -1), order; order.reserve(W.size());

@@ -99,3 +99,48 @@ def test_render_counts_in_flat_mode(orc):
     assert rays == rays_f and np.array_equal(got[..., 6], want[..., 6])
     assert np.allclose(got[..., :3], want[..., :3], rtol=1e-6, atol=1e-7)
     assert counts["path_rays"] + counts["occ_rays"] == rays and counts["path_inner"] > counts["path_rays"] and counts["path_inst"] == 0
+
+
+def test_sah_optimal_collapse_builds_a_valid_smaller_tree():
+    """CTL_FLAT_COLLAPSE=1 (the dynamic-programming collapse of bvh_builder.h; the knob is read once per process, hence the child process): the tree
+    has fewer 4-wide nodes than the greedy one, leaves of up to four entries, implied links that equal the explicit ones, and the oracle's traversal
+    of it reports the two-level (t, u, v, triangle, node) bit for bit."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from cudatracerlib_amd import api, scenes
+import oracle
+sys.path.insert(0, %r)
+from test_oracle_flat import rays_for
+orc = oracle.Oracle()
+sc = scenes.synthetic_sm(32, 32, n_instances=60, subdiv=2)
+d = sc.desc
+fb = api.FlatBvh(d, api.FLAT_Q4)
+N, L = fb.nodes(), fb.leaves()
+last = L[:, 12] & 1
+sizes = np.diff(np.concatenate([[-1], np.nonzero(last)[0]]))
+assert sizes.max() <= 4 and sizes.min() >= 1
+rays = rays_for(d, 6000, 5)
+want = orc.intersect(d, rays)
+got = orc.intersect(d, rays, flat=fb.desc)
+same = ~((got["tri_idx"] != want["tri_idx"]) & (got["dist"] == want["dist"]))
+assert same.mean() > 0.999
+for k in ("tri_idx", "node_idx"):
+    assert np.array_equal(got[k][same], want[k][same]), k
+for k in ("dist", "u", "v"):
+    assert np.array_equal(got[k][same].view(np.uint32), want[k][same].view(np.uint32)), k
+print("NODES", fb.desc.n_nodes, "MULTI", int((sizes > 1).sum()))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, CTL_FLAT_COLLAPSE=mode)
+        r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"))], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("NODES")][-1].split()
+        out[mode] = (int(line[1]), int(line[3]))
+    assert out["1"][0] < 0.9 * out["0"][0], out     # fewer wide nodes
+    assert out["1"][1] > out["0"][1], out           # some leaves were merged

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Quality of the flattened world-space BVH4, measured WITHOUT a GPU: the oracle renders a small frame of the bench workload in counting mode over the
+product's own flattened arrays (the roofline's N_inner / N_tri, bench.py `per_ray`) and prints visits per path ray plus the traversal-cost proxy
+`277 N_inner + 365 N_tri` (lane-slots per node step / leaf-entry step of k_intersect at its measured lane utilisation).  Builder knobs come
+from the environment ($CTL_FLAT_MAX_LEAF, $CTL_FLAT_NODE_COST, $CTL_FLAT_BINS, $CTL_FLAT_SWEEP, $CTL_FLAT_COLLAPSE ...), one process per setting."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cudatracerlib_amd as ctl  # noqa: E402
+from cudatracerlib_amd import scenes, api  # noqa: E402
+import oracle  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=480); ap.add_argument("--height", type=int, default=270)
+    ap.add_argument("--instances", type=int, default=2000); ap.add_argument("--subdiv", type=int, default=4)
+    ap.add_argument("--workload", default="synthetic-sm")
+    ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    a = ap.parse_args()
+    if a.workload == "synthetic-sm":
+        sc = scenes.synthetic_sm(a.width, a.height, n_instances=a.instances, subdiv=a.subdiv)
+    elif a.workload == "synthetic-bathroom":
+        sc = scenes.synthetic_bathroom(a.width, a.height)
+    else:
+        sc = scenes.cornell_box(a.width, a.height, glass_sphere=True)
+    t0 = time.time(); fb = api.FlatBvh(sc.desc, api.FLAT_Q4); t_build = time.time() - t0
+    orc = oracle.Oracle()
+    counts = {}
+    t0 = time.time()
+    _, rays = orc.render(sc.desc, a.width, a.height, n_passes=1, threads=a.threads, flat=fb.desc, counts=counts, direct=True, max_path_length=8, rr_start=5)
+    t_r = time.time() - t0
+    pr = counts["path_rays"]
+    ni, nt = counts["path_inner"] / pr, counts["path_tri"] / pr
+    knobs = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("CTL_FLAT"))
+    print("%-60s nodes %9d leaves %9d depth %2d | per path ray: inner %.2f tri %.2f | cost proxy %.0f | build %.1f s, count %.1f s" % (
+        knobs or "(defaults)", fb.desc.n_nodes, fb.desc.n_leaves, fb.desc.max_depth, ni, nt, 277 * ni + 365 * nt, t_build, t_r), flush=True)
+
+
+if __name__ == "__main__":
+    main()
