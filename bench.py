@@ -97,7 +97,12 @@ def cpu_baseline(desc, args, flat_desc):
         t = time.time(); _, rays = orc.render(desc, args.width, args.height, n_passes=n, threads=cores, **kw); total_t += time.time() - t
         total_rays += rays; extra_passes += n; n = min(n * 2, 16)
     value = total_rays / total_t / 1e6
-    out = {"value": round(value, 4), "unit": "Mrays/s", "cores": cores, "host_threads": host_threads, "kind": "port",
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()      # "max 100000" or "<quota> <period>": the CPU share this container may use
+        cpu_quota = None if quota[0] == "max" else round(float(quota[0]) / float(quota[1]), 2)
+    except Exception:
+        cpu_quota = None
+    out = {"value": round(value, 4), "unit": "Mrays/s", "cores": cores, "host_threads": host_threads, "affinity_cpus": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": cpu_quota, "kind": "port",
            "per_core": round(per_core, 4), "scaling_efficiency": round(value / (per_core * cores), 3),
            "sample": "two-level BVH (the reference's layout); best thread count (calibrated over 8..%d): 1 pass over rows 0..%d of the %dx%d frame + %d more whole-frame passes, depth %d, %d threads, %.1f s wall; "
                      "per-core: 1 thread, rows %d..%d, %.1f s" % (host_threads, done_rows, args.width, args.height, extra_passes, args.depth, cores, total_t, mid, min(args.height, mid + rows1), t1)}

@@ -34,7 +34,7 @@ def build(force=False, verbose=True, out=None, defines=()):
     procs = []
     for s in SRCS:
         o = os.path.join(bdir, s + ".o")
-        cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc] + FLAGS + os.environ.get("CTL_BUILD_EXTRA_FLAGS", "").split() + ["-D" + d for d in defines] + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

@@ -595,3 +595,135 @@ def write_cornell_mitsuba(directory, width=256, height=256, glass_sphere=False):
     with open(path, "w") as f:
         f.write(xml)
     return path
+
+
+def write_interior_mitsuba(directory, width=128, height=72):
+    """A small interior in the form the Tungsten -> Mitsuba exporter writes (the distributions BASELINE configs 3 and 5 come in): `scene version="0.5.0"`,
+    a 4x4 `<matrix>` toWorld on the sensor and on every shape, `ldrfilm` + `rfilter`, a `sobol` sampler element, `twosided` wrappers with ids and `<ref id>`
+    from the shapes, one OBJ per shape with v / vt / vn and `f a/b/c`, a bitmap texture with `filterType`, a `rectangle` area emitter and an `envmap` with its
+    own transform.  Geometry: textured rough-plastic floor, a rough-conductor and a glass ball, a light panel, a Radiance .hdr environment.  Returns the XML path."""
+    import os
+    import struct
+    import zlib
+    os.makedirs(os.path.join(directory, "models"), exist_ok=True); os.makedirs(os.path.join(directory, "textures"), exist_ok=True)
+
+    def obj(name, V, F, N, T):
+        with open(os.path.join(directory, "models", name), "w") as f:
+            f.write("# exported mesh\no %s\n" % name[:-4])
+            f.writelines("v %.6f %.6f %.6f\n" % tuple(v) for v in V)
+            f.writelines("vt %.6f %.6f\n" % tuple(t) for t in T)
+            f.writelines("vn %.6f %.6f %.6f\n" % tuple(n) for n in N)
+            f.write("s off\n")
+            f.writelines("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a + 1, a + 1, a + 1, b + 1, b + 1, b + 1, c + 1, c + 1, c + 1) for a, b, c in F)
+    quad = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float64) * 5
+    obj("Mesh000.obj", quad, [(0, 2, 1), (0, 3, 2)], np.array([[0, 1, 0]] * 4, np.float64), np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float64))
+    Vs, Fs = icosphere(2)
+    Ns = Vs / np.linalg.norm(Vs, axis=1, keepdims=True)
+    obj("Mesh001.obj", Vs * 0.7 + np.array([0, 0.7, 0]), Fs, Ns, np.zeros((len(Vs), 2)))
+    obj("Mesh002.obj", Vs * 0.5 + np.array([1.5, 0.5, 0.5]), Fs, Ns, np.zeros((len(Vs), 2)))
+    rs = np.random.RandomState(11)
+    tex = (64 + rs.rand(16, 16, 3) * 160).astype(np.uint8)
+    raw = b"".join(b"\x00" + tex[y].tobytes() for y in range(16))
+    ch = lambda t, d: struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    with open(os.path.join(directory, "textures", "wood.png"), "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", 16, 16, 8, 2, 0, 0, 0)) + ch(b"IDAT", zlib.compress(raw)) + ch(b"IEND", b""))
+    env = (0.2 + rs.rand(8, 16, 3) * 1.5).astype(np.float32)
+    m = env.max(axis=2); man, ex = np.frexp(m); scale = man * 256.0 / m
+    rgbe = np.concatenate([(env * scale[..., None]).astype(np.uint8), (ex + 128).astype(np.uint8)[..., None]], axis=2)
+    with open(os.path.join(directory, "textures", "envmap.hdr"), "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 8 +X 16\n" + rgbe.tobytes())   # flat (not run-length encoded) scanlines
+    ident = '<transform name="toWorld" >\n\t\t\t<matrix value="1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1"/>\n\t\t</transform>'
+    xml = """<?xml version="1.0" encoding="utf-8"?>
+
+<scene version="0.5.0" >
+	<integrator type="path" >
+		<integer name="maxDepth" value="65" />
+		<boolean name="strictNormals" value="true" />
+	</integrator>
+	<sensor type="perspective" >
+		<float name="fov" value="55" />
+		<transform name="toWorld" >
+			<matrix value="-0.999914 0.000835626 0.013058 -0.587317 -5.82126e-011 0.997959 -0.063863 2.7623 -0.0130847 -0.0638576 -0.997873 9.71429 0 0 0 1"/>
+		</transform>
+		<sampler type="sobol" >
+			<integer name="sampleCount" value="64" />
+		</sampler>
+		<film type="ldrfilm" >
+			<integer name="width" value="%d" />
+			<integer name="height" value="%d" />
+			<string name="fileFormat" value="png" />
+			<string name="pixelFormat" value="rgb" />
+			<float name="gamma" value="2.2" />
+			<boolean name="banner" value="false" />
+			<rfilter type="tent" />
+		</film>
+	</sensor>
+	<bsdf type="twosided" id="Chrome" >
+		<bsdf type="roughconductor" >
+			<float name="alpha" value="0.05" />
+			<string name="distribution" value="ggx" />
+			<float name="extEta" value="1" />
+			<rgb name="specularReflectance" value="1, 1, 1"/>
+			<rgb name="eta" value="4.36968, 2.9167, 1.6547"/>
+			<rgb name="k" value="5.20643, 4.23136, 3.75495"/>
+		</bsdf>
+	</bsdf>
+	<bsdf type="twosided" id="WoodFloor" >
+		<bsdf type="roughplastic" >
+			<float name="alpha" value="0.1" />
+			<string name="distribution" value="ggx" />
+			<float name="intIOR" value="1.5" />
+			<float name="extIOR" value="1" />
+			<boolean name="nonlinear" value="true" />
+			<texture name="diffuseReflectance" type="bitmap" >
+				<string name="filename" value="textures/wood.png" />
+				<string name="filterType" value="trilinear" />
+			</texture>
+		</bsdf>
+	</bsdf>
+	<bsdf type="dielectric" id="Glass" >
+		<float name="intIOR" value="1.5" />
+		<float name="extIOR" value="1" />
+	</bsdf>
+	<bsdf type="twosided" id="Panel" >
+		<bsdf type="diffuse" >
+			<rgb name="reflectance" value="0.578596, 0.578596, 0.578596"/>
+		</bsdf>
+	</bsdf>
+	<shape type="obj" >
+		<string name="filename" value="models/Mesh000.obj" />
+		%s
+		<boolean name="faceNormals" value="true" />
+		<ref id="WoodFloor" />
+	</shape>
+	<shape type="obj" >
+		<string name="filename" value="models/Mesh001.obj" />
+		%s
+		<ref id="Chrome" />
+	</shape>
+	<shape type="obj" >
+		<string name="filename" value="models/Mesh002.obj" />
+		%s
+		<ref id="Glass" />
+	</shape>
+	<shape type="rectangle" >
+		<transform name="toWorld" >
+			<matrix value="0.5 0 0 0 0 -2.18557e-008 0.5 4 0 -0.5 -2.18557e-008 0 0 0 0 1"/>
+		</transform>
+		<ref id="Panel" />
+		<emitter type="area" >
+			<rgb name="radiance" value="17, 12, 4"/>
+		</emitter>
+	</shape>
+	<emitter type="envmap" >
+		<transform name="toWorld" >
+			<matrix value="-0.922278 0 0.386527 0 0 1 0 0 -0.386527 0 -0.922278 1.17369 0 0 0 1"/>
+		</transform>
+		<string name="filename" value="textures/envmap.hdr" />
+	</emitter>
+</scene>
+""" % (width, height, ident, ident, ident)
+    path = os.path.join(directory, "scene.xml")
+    with open(path, "w") as f:
+        f.write(xml)
+    return path

@@ -143,6 +143,27 @@ def test_mitsuba_xml_scene(gpu, orc, tmp_path):
     assert_close(got, want)
 
 
+def test_tungsten_style_interior_through_the_loader(gpu, orc, tmp_path):
+    """A scene file in the form the BASELINE distributions take (scenes.write_interior_mitsuba: matrix transforms, twosided wrappers by id, OBJ shapes, trilinear
+    bitmap on a rough plastic, glass, rough conductor, rectangle emitter, rotated .hdr environment) -> ParseMitsubaScene -> both plugins against the oracle: the
+    wavefront plugin at texture level 0, the PathTracer plugin with first-hit ray differentials (trilinear lookup of the floor's bitmap)."""
+    from cudatracerlib_amd import rough_tables
+    w, h, n = 128, 72, 3
+    path = scenes.write_interior_mitsuba(str(tmp_path), w, h)
+    sc = gpu.DynamicScene()
+    tr_, df, er, ar = rough_tables.make_table(1, n_eta=3, n_alpha=3, n_theta=4, quad=8)
+    sc.setRoughTransmittance(1, tr_, df, er, ar)
+    assert sc.ParseMitsubaScene(path) == (w, h)
+    d = sc.UpdateScene()
+    tables = orc.sequence_tables(n)
+    scene = gpu.Scene(d, flatten=True)
+    for cls, partials in ((gpu.WavefrontPathTracer, False), (gpu.PathTracer, True)):
+        want, _ = orc.render(d, w, h, n_passes=n, tables=tables, max_path_length=8, partials=partials)
+        got = _render(gpu, cls, scene, tables, w, h, max_len=8)
+        assert_close(got, want)
+        assert want[..., :3].mean() > 0.05
+
+
 @pytest.mark.parametrize("scene_kw", [dict(glass_sphere=True), dict(extra_materials=6), dict(extra_materials=8)])
 def test_megakernel_path_tracer_plugin(gpu, orc, scene_kw):
     """ctl_tracer_create("PathTracer"): PathTrace<DIRECT> as one kernel — same image as the oracle (and as the wavefront tracer),
