@@ -166,6 +166,8 @@ def main():
         import torch.distributed as dist
         if share_gpu:
             local_rank = 0
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)   # torch.cuda.synchronize() in sync() then waits on this rank's own GPU instead of opening a context on device 0
         dist.init_process_group(backend="gloo")
     import cudatracerlib_amd as ctl
     if ctl.device_count() < 1:
@@ -200,19 +202,32 @@ def main():
     comm, reduce_kind = None, "none (1 GPU)"
     if world > 1:
         import torch
+        # (1) every rank proves that RCCL loads in its process (ncclGetUniqueId is local) BEFORE anybody enters the collective ncclCommInitRank:
+        #     a rank that cannot load the library must not leave the others waiting inside it
+        why = ""
         try:
             if share_gpu:
                 raise RuntimeError("CTL_BENCH_SHARE_GPU: all ranks share device 0")
-            ident = [ctl.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ident, src=0)
-            comm = ctl.Comm(ident[0], rank, world)
-            reduce_kind = "ncclReduce in libctl_amd.so (ctl_image_reduce)"
-        except Exception as e:   # never silently: the JSON line says which path ran
-            print("bench.py: native RCCL reduce unavailable (%s); falling back to torch.distributed" % e, file=sys.stderr, flush=True)
-            reduce_kind = "torch.distributed gloo all-reduce through host memory (native RCCL unavailable: %s)" % str(e)[:120]
-        ok = torch.tensor([1 if comm is not None else 0]); dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks take the same path
-        if int(ok.item()) == 0:
-            comm = None
+            my_id = ctl.Comm.unique_id()
+        except Exception as e:
+            why = str(e)[:120]; my_id = None
+        ok = torch.tensor([1 if my_id is not None else 0]); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            try:
+                ident = [my_id if rank == 0 else None]
+                dist.broadcast_object_list(ident, src=0)
+                comm = ctl.Comm(ident[0], rank, world)
+                reduce_kind = "ncclReduce in libctl_amd.so (ctl_image_reduce)"
+            except Exception as e:   # never silently: the JSON line says which path ran
+                why = str(e)[:120]; comm = None
+            ok = torch.tensor([1 if comm is not None else 0]); dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks take the same path
+            if int(ok.item()) == 0:
+                comm = None
+        if comm is None:
+            whys = [None] * world; dist.all_gather_object(whys, why)
+            why = next((x for x in whys if x), "another rank failed")
+            print("bench.py: native RCCL reduce unavailable (%s); falling back to torch.distributed" % why, file=sys.stderr, flush=True)
+            reduce_kind = "torch.distributed gloo all-reduce through host memory (native RCCL unavailable: %s)" % why
 
     def sync():
         ctl.api._check(ctl.lib.ctl_device_synchronize())

@@ -8,6 +8,6 @@ ARGS=${BENCH_ARGS:---steps 32 --warmup 2 --no-cpu-baseline}
 while read -r line; do
   [ -z "$line" ] && continue
   echo "== $line" | tee -a "$OUT/runs.jsonl"
-  env $line timeout 600 python bench.py $ARGS 2> "$OUT/last.err" | tee -a "$OUT/runs.jsonl" | python tools/bench_brief.py
+  env $line timeout 600 python bench.py $ARGS $(echo "$line" | tr " " "\n" | sed -n "s/^BENCH_EXTRA=//p" | tr "," " ") 2> "$OUT/last.err" | tee -a "$OUT/runs.jsonl" | python tools/bench_brief.py
   tail -2 "$OUT/last.err"
 done < "${2:-/dev/stdin}"
