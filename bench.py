@@ -103,7 +103,8 @@ def cpu_baseline(desc, args, flat_desc):
     except Exception:
         cpu_quota = None
     out = {"value": round(value, 4), "unit": "Mrays/s", "cores": cores, "host_threads": host_threads, "affinity_cpus": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": cpu_quota, "kind": "port",
-           "per_core": round(per_core, 4), "scaling_efficiency": round(value / (per_core * cores), 3),
+           "per_core": round(per_core, 4), "effective_cores": round(min(float(cores), cpu_quota or float(cores)), 2),   # threads beyond the container's CPU quota only time-share
+           "scaling_efficiency": round(value / (per_core * min(float(cores), cpu_quota or float(cores))), 3),
            "sample": "two-level BVH (the reference's layout); best thread count (calibrated over 8..%d): 1 pass over rows 0..%d of the %dx%d frame + %d more whole-frame passes, depth %d, %d threads, %.1f s wall; "
                      "per-core: 1 thread, rows %d..%d, %.1f s" % (host_threads, done_rows, args.width, args.height, extra_passes, args.depth, cores, total_t, mid, min(args.height, mid + rows1), t1)}
     counts = None
