@@ -102,6 +102,8 @@ def load_ref():
     r.ref_woop_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p]
     r.ref_construct_bvh.argtypes = [C.c_void_p, C.c_void_p, u32, u32, C.c_void_p, C.c_void_p]
     r.ref_construct_bvh_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    if hasattr(r, "ref_trace_two_level"):
+        r.ref_trace_two_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     if hasattr(r, "ref_wrap_coordinates"):
         r.ref_wrap_coordinates.argtypes = [f32, f32, f32, f32, C.c_int, C.c_void_p]
         r.ref_checkerboard_select.argtypes = [f32] * 6
@@ -189,3 +191,19 @@ class Oracle:
             out.append((t1, t2))
         self.lib.orc_seqgen_destroy(g)
         return out
+
+
+def ref_trace_two_level(r, desc, rays):
+    """The reference's own TracerayTemplate (both levels) + float4x4 transforms + TriIntersectorData::Intersect over the arrays of a ctl_scene_desc
+    (oracle/ref_driver.cpp).  rays: (n, 8) = origin, tmin, direction, tmax; the reference's Intersect has the fixed tmin 1e-4, so the rays must carry it.
+    Returns the same record array Oracle.intersect returns (tri_idx / node_idx = -1 on a miss, dist = tmax)."""
+    import numpy as np
+    q = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+    assert (q[:, 3] == np.float32(1e-4)).all(), "TriIntersectorData::Intersect tests t > 1e-4"
+    n = len(q)
+    tuv = np.zeros((n, 3), np.float32); tri = np.zeros(n, np.int32); node = np.zeros(n, np.int32)
+    r.ref_trace_two_level(desc.scene_bvh_nodes, desc.scene_start_node, desc.bvh_nodes, desc.woop, desc.woop_index, desc.nodes, desc.meshes, desc.node_inv_transforms,
+                          n, q.ctypes.data, tuv.ctypes.data, tri.ctypes.data, node.ctypes.data)
+    hits = np.zeros(n, dtype=[("dist", "f4"), ("node_idx", "i4"), ("tri_idx", "i4"), ("u", "f4"), ("v", "f4")])
+    hits["dist"] = tuv[:, 0]; hits["u"] = tuv[:, 1]; hits["v"] = tuv[:, 2]; hits["tri_idx"] = tri; hits["node_idx"] = node
+    return hits

@@ -4,6 +4,9 @@
 // It contains no copy of reference source: it includes the reference headers and calls their functions.
 // Used by tests/ to pin the restatement in ocore.h/omath.h and to generate tests/golden/ fixtures.
 //
+// Header-only reference code driven from here as well: Warp.h, Frame.h, half.h, Compression.h, float4x4.h, MonteCarlo.h, Filter.h, and the traversal
+// template of BVHTraversal.h with the slab arithmetic of MathFunc.h (ref_trace_two_level).
+//
 // What could NOT be built from the reference here (needs curand_kernel.h from the CUDA toolkit, or
 // un-vendored boost/pugixml/FreeImage): BSDF_Simple.cu, Light.cu, KernelDynamicScene.cu, TraceHelper.cu,
 // Sampler/CudaRandom, DynamicScene, the Mitsuba loader.  See DESIGN.md "Oracle".
@@ -23,6 +26,8 @@
 #include <SceneTypes/Filter.h>
 #include <SceneTypes/Texture.h>
 #include <Engine/MIPMap_device.h>
+#include <Engine/SpatialStructures/BVH/BVHTraversal.h>
+#include <Math/float4x4.h>
 #include <cstdint>
 #include <cstring>
 
@@ -201,4 +206,39 @@ void ref_construct_bvh_fetch(void* nodes, void* tris, void* tris2) {
     std::memcpy(tris2, g_last.tris2.data(), g_last.tris2.size() * sizeof(TriIntersectorData2));
 }
 
+
+// Two-level single-ray traversal with the REFERENCE'S OWN traversal template at both levels (TracerayTemplate, Engine/SpatialStructures/BVH/BVHTraversal.h:122-232:
+// its slab arithmetic through kepler_math::spanBeginKepler / spanEndKepler, its child ordering, its postponed leaf), the reference's float4x4::TransformDirection /
+// TransformPoint for the instance (Math/float4x4.h) and the reference's TriIntersectorData::Intersect per leaf entry (fixed tmin 1e-4: the rays must carry that tmin).
+// The two callbacks have the shape of __traceRay_internal__ (Kernel/TraceHelper.cu:88-170 — that file itself needs curand through TraceHelper.h and does not build here):
+// scene-BVH leaf -> node -> mesh BVH at the mesh's node offset; mesh-BVH leaf -> entries up to the one whose index word has bit 0 set.
+// Inputs are plain arrays in the reference's layouts: BVHNodeData (64 B), TriIntersectorData (48 B), index words, ctl_node (6 words, [0] = mesh index),
+// ctl_kernel_mesh (5 words: tri_offset, bvh_node_offset, bvh_tri_offset, bvh_index_offset, -), one row-major 4x4 inverse transform per node.
+void ref_trace_two_level(const void* scene_nodes, int scene_start_node, const void* mesh_nodes, const void* woop, const uint32_t* woop_index,
+                         const uint32_t* nodes6, const uint32_t* meshes5, const float* node_inv, uint32_t n_rays, const float* rays8,
+                         float* out_tuv, int32_t* out_tri, int32_t* out_node) {
+    const BVHNodeData* SN = (const BVHNodeData*)scene_nodes; const BVHNodeData* MN = (const BVHNodeData*)mesh_nodes;
+    const TriIntersectorData* W = (const TriIntersectorData*)woop;
+    for (uint32_t i = 0; i < n_rays; i++) {
+        const float* r = rays8 + 8 * (size_t)i;
+        const Vec3f ori(r[0], r[1], r[2]), dir(r[4], r[5], r[6]);
+        float dist = r[7]; Vec2f bary(0.0f); int tri = -1, node = -1;
+        TracerayTemplate(Ray(ori, dir), dist, [&](int nodeIdx) {
+            const uint32_t* m = meshes5 + 5 * (size_t)nodes6[6 * (size_t)nodeIdx];
+            float4x4 modl; std::memcpy(modl.data, node_inv + 16 * (size_t)nodeIdx, 64);
+            const Vec3f d = modl.TransformDirection(dir), o = modl.TransformPoint(ori);
+            return TracerayTemplate(Ray(o, d), dist, [&](int triIdx) {
+                bool found = false;
+                for (int triAddr = triIdx;; triAddr++) {
+                    const uint32_t index = woop_index[m[3] + triAddr];
+                    if (W[m[2] / 3 + triAddr].Intersect(Ray(o, d), &dist, &bary)) { node = nodeIdx; tri = (int)((index >> 1) + m[0]); found = true; }
+                    if (index & 1) break;
+                }
+                return found;
+            }, MN, MN, (int)m[1], 0);
+        }, SN, SN, 0, scene_start_node);
+        out_tuv[3 * (size_t)i] = dist; out_tuv[3 * (size_t)i + 1] = bary.x; out_tuv[3 * (size_t)i + 2] = bary.y;
+        out_tri[i] = tri; out_node[i] = node;
+    }
+}
 } // extern "C"

@@ -254,5 +254,50 @@ def main():
         r.ref_sensor_rays(1, tw[i].ctypes.data, f32(1.0), f32(1e-2), f32(1e4), w, h, f32(0), f32(0), f32(1), f32(px[i, 0]), f32(px[i, 1]), f32(0.5), f32(0.5), rays[i].ctypes.data, tmp6.ctypes.data)
     np.savez_compressed(os.path.join(HERE, "sensor_spherical.npz"), to_world=tw, resolution=res, pixel=px, ray=rays[:, :6])
 
+def traceray_scenes():
+    """the scenes of traceray.npz, built by the product's host code (deterministic): (key, DynamicScene, rays)"""
+    from cudatracerlib_amd import scenes
+    out = []
+    for key, sc, seed in (("sm", scenes.synthetic_sm(32, 32, n_instances=60, subdiv=2), 31), ("cornell", scenes.cornell_box(32, 32, glass_sphere=True), 32)):
+        d = sc.desc
+        rs = np.random.RandomState(seed)
+        lo, hi = np.array(d.box_min[:]), np.array(d.box_max[:])
+        n = 3000
+        rays = np.zeros((n, 8), np.float32)
+        rays[:, :3] = rs.uniform(lo - 0.1 * (hi - lo), hi + 0.1 * (hi - lo), size=(n, 3))
+        dd = rs.normal(size=(n, 3)); dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+        rays[:, 4:7] = dd; rays[:, 3] = np.float32(1e-4); rays[:, 7] = np.float32(3.402823466e+38)
+        rays[:6, 4:7] = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)   # axis-parallel: the 2^-80 guard of the slab test
+        out.append((key, sc, rays))
+    return out
+
+
+def traceray_input_digest(d):
+    """sha256 over the arrays the traversal reads: the fixture's outputs belong to exactly these inputs"""
+    import hashlib
+    h = hashlib.sha256()
+    for name, dt, cnt, wd in (("scene_bvh_nodes", np.uint32, d.n_scene_bvh_nodes, 16), ("bvh_nodes", np.uint32, d.n_bvh_nodes, 16), ("woop", np.uint32, d.n_woop, 12),
+                              ("woop_index", np.uint32, d.n_woop, 1), ("nodes", np.uint32, d.n_nodes, 6), ("meshes", np.uint32, d.n_meshes, 5), ("node_inv_transforms", np.uint32, d.n_nodes, 16)):
+        h.update(np.ascontiguousarray(d.view(name, dt, cnt, wd)).tobytes())
+    h.update(np.int32(d.scene_start_node).tobytes())
+    return h.hexdigest()
+
+
+def gen_traceray(r):
+    # ---- two-level single-ray traversal through the reference's own TracerayTemplate (Engine/SpatialStructures/BVH/BVHTraversal.h:122-232), float4x4 transforms and
+    #      TriIntersectorData::Intersect (oracle/ref_driver.cpp ref_trace_two_level) over scenes compiled by the product's host code; own random streams
+    out = {}
+    for key, sc, rays in traceray_scenes():
+        want = oracle.ref_trace_two_level(r, sc.desc, rays)
+        out[key + "_rays"] = rays; out[key + "_digest"] = np.array(traceray_input_digest(sc.desc))
+        for f in ("dist", "u", "v", "tri_idx", "node_idx"):
+            out[key + "_" + f] = np.ascontiguousarray(want[f])
+    np.savez_compressed(os.path.join(HERE, "traceray.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["traceray"]:      # only this fixture (the others stay byte-identical)
+        gen_traceray(oracle.load_ref())
+    else:
+        main()
+        gen_traceray(oracle.load_ref())
