@@ -25,6 +25,12 @@ static std::string lower_ext(const std::string& path) {
     for (auto& c : e) c = (char)std::tolower((unsigned char)c);
     return e;
 }
+// A header may not promise more pixels than a texture can have (2^28) or than the bytes that follow could possibly hold: a 60-byte file that declares
+// 2^31 x 2^31 pixels must be refused before anything is allocated for it (found by tools/fuzz_loaders.py).  min_bytes_per_pixel: the format's densest encoding.
+static void check_image_size(uint64_t w, uint64_t h, size_t bytes_left, double min_bytes_per_pixel, const char* what, const std::string& path) {
+    if (w == 0 || h == 0 || w > 65536 || h > 65536 || w * h > (1ull << 28)) throw io_error(std::string("unreasonable ") + what + " dimensions : " + path);
+    if ((double)w * (double)h * min_bytes_per_pixel > (double)bytes_left) throw io_error(std::string("truncated ") + what + " (the header promises more pixels than the file holds) : " + path);
+}
 static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 static uint32_t le32(const uint8_t* p) { return ((uint32_t)p[3] << 24) | ((uint32_t)p[2] << 16) | ((uint32_t)p[1] << 8) | p[0]; }
 static uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -55,7 +61,8 @@ static decoded_image decode_png(const std::vector<uint8_t>& d, const std::string
     }
     const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!channels) throw io_error("bad PNG colour type : " + path);
-    const size_t bpp_bits = (size_t)channels * depth, stride = (w * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
+    check_image_size(w, h, idat.size(), (double)channels * depth / 8.0 / 1032.0, "PNG", path);   // deflate expands by at most ~1032 : 1
+    const size_t bpp_bits = (size_t)channels * depth, stride = ((size_t)w * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf out_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) throw io_error("PNG inflate failed : " + path);
@@ -97,8 +104,10 @@ static decoded_image decode_bmp(const std::vector<uint8_t>& d, const std::string
     if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') throw io_error("not a BMP file : " + path);
     const uint32_t off = le32(&d[10]); const int32_t w = (int32_t)le32(&d[18]), hs = (int32_t)le32(&d[22]); const int bpp = le16(&d[28]); const uint32_t comp = le32(&d[30]);
     if ((bpp != 24 && bpp != 32) || (comp != 0 && comp != 3) || w <= 0 || hs == 0) throw unsupported_error("only uncompressed 24/32-bit BMP is supported : " + path);
+    if (hs == INT32_MIN) throw io_error("unreasonable BMP dimensions : " + path);
     const uint32_t h = (uint32_t)std::abs(hs); const size_t stride = ((size_t)w * bpp / 8 + 3) & ~(size_t)3;
-    if (off + stride * h > d.size()) throw io_error("truncated BMP : " + path);
+    check_image_size((uint64_t)w, h, d.size(), bpp / 8.0, "BMP", path);
+    if ((size_t)off + stride * h > d.size()) throw io_error("truncated BMP : " + path);
     decoded_image img; img.width = (uint32_t)w; img.height = h; img.rgba8.resize((size_t)w * h * 4);
     for (uint32_t y = 0; y < h; y++) {
         const uint8_t* line = &d[off + stride * (hs > 0 ? h - 1 - y : y)];
@@ -111,6 +120,7 @@ static decoded_image decode_tga(const std::vector<uint8_t>& d, const std::string
     const int idlen = d[0], cmap = d[1], type = d[2], bpp = d[16], desc = d[17]; const uint32_t w = le16(&d[12]), h = le16(&d[14]);
     if (cmap || (type != 2 && type != 3 && type != 10 && type != 11) || (bpp != 8 && bpp != 24 && bpp != 32) || !w || !h) throw unsupported_error("TGA variant not supported : " + path);
     const size_t px = bpp / 8; size_t p = 18 + idlen;
+    check_image_size(w, h, d.size(), (type == 2 || type == 3) ? (double)px : (double)(px + 1) / 128.0, "TGA", path);   // a run-length packet of 1 + px bytes covers at most 128 pixels
     std::vector<uint8_t> raw((size_t)w * h * px);
     if (type == 2 || type == 3) { if (p + raw.size() > d.size()) throw io_error("truncated TGA : " + path); std::memcpy(raw.data(), &d[p], raw.size()); }
     else for (size_t o = 0; o < raw.size();) {
@@ -145,6 +155,11 @@ static decoded_image decode_pnm(const std::vector<uint8_t>& d, const std::string
     if (!pnm_token(d, p, t)) throw io_error("bad PNM header : " + path); const uint32_t h = (uint32_t)std::stoul(t);
     if (!pnm_token(d, p, t)) throw io_error("bad PNM header : " + path); const double maxv = std::stod(t);
     if (magic != "PF" && magic != "Pf" && !(maxv >= 1 && maxv <= 65535)) throw io_error("bad PNM maximum value : " + path);
+    {
+        const int ch_ = (magic == "P3" || magic == "P6" || magic == "PF") ? 3 : 1;
+        const double per_sample = pfm ? 4.0 : ((magic == "P2" || magic == "P3") ? 2.0 : (maxv > 255 ? 2.0 : 1.0));   // ASCII: a digit and a separator at least
+        check_image_size(w, h, d.size() > p ? d.size() - p : 0, per_sample * ch_ - ((magic == "P2" || magic == "P3") ? 1.0 : 0.0), pfm ? "PFM" : "PNM", path);
+    }
     decoded_image img; img.width = w; img.height = h;
     if (pfm) {
         p++;   // the single whitespace after the scale
@@ -181,6 +196,8 @@ static decoded_image decode_hdr(const std::vector<uint8_t>& d, const std::string
     l = line();
     int h = 0, w = 0; char ys = 0, xs = 0;
     if (std::sscanf(l.c_str(), "%cY %d %cX %d", &ys, &h, &xs, &w) != 4 || w <= 0 || h <= 0) throw unsupported_error("HDR orientation not supported : " + path);
+    check_image_size((uint64_t)w, (uint64_t)h, d.size() > p ? d.size() - p : 0, 8.0 / 127.0, "HDR", path);   // run-length scanlines: 2 bytes per channel per run of at most 127
+    if ((uint64_t)h * 4 > d.size() - std::min(p, d.size())) throw io_error("truncated HDR : " + path);              // and every scanline starts with 4 bytes
     decoded_image img; img.width = (uint32_t)w; img.height = (uint32_t)h; img.is_float = true; img.rgb.resize((size_t)w * h * 3);
     std::vector<uint8_t> scan((size_t)w * 4);
     for (int y = 0; y < h; y++) {
@@ -261,6 +278,7 @@ static decoded_image decode_exr(const std::vector<uint8_t>& d, const std::string
     if (compression > 3) throw unsupported_error(std::string("OpenEXR compression ") + (compression < 10 ? kCodec[compression] : "?") + " is not read (NONE, RLE, ZIPS and ZIP are; re-save with one of them) : " + path);
     const long w = (long)dw[2] - dw[0] + 1, h = (long)dw[3] - dw[1] + 1;
     if (w <= 0 || h <= 0 || w > 65536 || h > 65536) throw io_error("corrupt OpenEXR dataWindow : " + path);
+    check_image_size((uint64_t)w, (uint64_t)h, d.size(), 2.0 / 1032.0, "OpenEXR", path);   // at least one HALF channel, deflated at best ~1032 : 1
     size_t line_bytes = 0; int idx[3] = { -1, -1, -1 }, lum = -1;
     for (size_t k = 0; k < chans.size(); k++) {
         channel& c = chans[k];

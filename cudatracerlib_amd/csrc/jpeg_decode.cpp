@@ -191,6 +191,7 @@ decoded_image decode_jpeg(const std::vector<uint8_t>& d, const std::string& path
             progressive = m == 0xc2;
             height = be16(&s[1]); width = be16(&s[3]);
             const int nc = s[5];
+            if ((uint64_t)width * (uint64_t)height > (1ull << 28) || (double)width * height / 4096.0 > (double)d.size()) throw io_error("unreasonable JPEG dimensions for a file of this size : " + path);   // before the coefficient planes are allocated; an all-DC scan spends about a bit per 8x8 block
             if ((nc != 1 && nc != 3) || n < (size_t)(6 + 3 * nc) || width <= 0 || height <= 0) throw unsupported_error("JPEG with " + std::to_string(nc) + " components (only greyscale and YCbCr / RGB are read) : " + path);
             comps.resize(nc);
             for (int k = 0; k < nc; k++) { comps[k].id = s[6 + 3 * k]; comps[k].h = s[7 + 3 * k] >> 4; comps[k].v = s[7 + 3 * k] & 15; comps[k].tq = s[8 + 3 * k];

@@ -177,7 +177,10 @@ mesh_data load_ply(const std::string& path) {
         if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4; if (t == "double" || t == "float64") return 8;
         return 0; };
     auto read_num = [&](const std::string& t) -> double {
-        if (fmt == ASCII) { while (p < buf.size() && std::isspace(buf[p])) p++; size_t b = p; while (p < buf.size() && !std::isspace(buf[p])) p++; return std::strtod(std::string((const char*)&buf[b], p - b).c_str(), nullptr); }
+        if (fmt == ASCII) {
+            while (p < buf.size() && std::isspace(buf[p])) p++;
+            if (p >= buf.size()) throw io_error("truncated PLY : " + path);   // (a header that promises more elements than the file holds ends here, not in an endless row of zeros)
+            size_t b = p; while (p < buf.size() && !std::isspace(buf[p])) p++; return std::strtod(std::string((const char*)&buf[b], p - b).c_str(), nullptr); }
         const int n = tsize(t); if (!n || p + n > buf.size()) throw io_error("truncated PLY : " + path);
         uint8_t b[8]; for (int i = 0; i < n; i++) b[i] = buf[p + (fmt == BLE ? i : n - 1 - i)]; p += n;
         if (t == "float" || t == "float32") { float f; std::memcpy(&f, b, 4); return f; }
@@ -186,8 +189,15 @@ mesh_data load_ply(const std::string& path) {
         if (t == "short" || t == "int16") { int16_t v; std::memcpy(&v, b, 2); return v; } if (t == "ushort" || t == "uint16") { uint16_t v; std::memcpy(&v, b, 2); return v; }
         if (t == "int" || t == "int32") { int32_t v; std::memcpy(&v, b, 4); return v; }
         uint32_t v; std::memcpy(&v, b, 4); return v; };
+    // entries of a list property: never negative, never more than the bytes that are left could hold
+    auto read_count = [&](const prop& pr) -> int {
+        const double c = read_num(pr.count_type);
+        const size_t left = buf.size() - std::min(p, buf.size()), each = fmt == ASCII ? 1 : (size_t)std::max(1, tsize(pr.type));
+        if (!(c >= 0) || c > (double)(left / each)) throw io_error("corrupt PLY list length : " + path);
+        return (int)c; };
     mesh_data M; bool has_uv = false;
     for (auto& e : elems) {
+        if (e.count > buf.size() - std::min(p, buf.size())) throw io_error("truncated PLY (the header promises more elements than the file holds) : " + path);
         if (e.name == "vertex") {
             int ix = -1, iy = -1, iz = -1, iu = -1, iv = -1;
             for (size_t i = 0; i < e.props.size(); i++) { const std::string& n = e.props[i].name; if (n == "x") ix = (int)i; else if (n == "y") iy = (int)i; else if (n == "z") iz = (int)i; else if (n == "u" || n == "s") iu = (int)i; else if (n == "v" || n == "t") iv = (int)i; }
@@ -195,7 +205,7 @@ mesh_data load_ply(const std::string& path) {
             has_uv = iu >= 0 && iv >= 0;
             std::vector<double> vals(e.props.size());
             for (size_t k = 0; k < e.count; k++) {
-                for (size_t i = 0; i < e.props.size(); i++) { if (e.props[i].list) { const int n = (int)read_num(e.props[i].count_type); for (int j = 0; j < n; j++) read_num(e.props[i].type); vals[i] = 0; } else vals[i] = read_num(e.props[i].type); }
+                for (size_t i = 0; i < e.props.size(); i++) { if (e.props[i].list) { const int n = read_count(e.props[i]); for (int j = 0; j < n; j++) read_num(e.props[i].type); vals[i] = 0; } else vals[i] = read_num(e.props[i].type); }
                 M.positions.push_back((float)vals[ix]); M.positions.push_back((float)vals[iy]); M.positions.push_back((float)vals[iz]);
                 if (has_uv) { M.uvs.push_back((float)vals[iu]); M.uvs.push_back((float)vals[iv]); }
             }
@@ -204,13 +214,13 @@ mesh_data load_ply(const std::string& path) {
             for (size_t k = 0; k < e.count; k++)
                 for (auto& pr : e.props) {
                     if (!pr.list) { read_num(pr.type); continue; }
-                    const int n = (int)read_num(pr.count_type); poly.resize(n);
+                    const int n = read_count(pr); poly.resize(n);
                     for (int j = 0; j < n; j++) poly[j] = (uint32_t)read_num(pr.type);
                     if (pr.name != "vertex_indices" && pr.name != "vertex_index") continue;
                     for (int i = 2; i < n; i++) { M.indices.push_back(poly[i]); M.indices.push_back(poly[i - 1]); M.indices.push_back(poly[0]); }
                 }
         } else {
-            for (size_t k = 0; k < e.count; k++) for (auto& pr : e.props) { if (pr.list) { const int n = (int)read_num(pr.count_type); for (int j = 0; j < n; j++) read_num(pr.type); } else read_num(pr.type); }
+            for (size_t k = 0; k < e.count; k++) for (auto& pr : e.props) { if (pr.list) { const int n = read_count(pr); for (int j = 0; j < n; j++) read_num(pr.type); } else read_num(pr.type); }
         }
     }
     const uint32_t nv = M.n_vertices();
@@ -236,7 +246,7 @@ mesh_data load_serialized(const std::string& path, int shape_index) {
     uint64_t off = 0;
     const size_t tab = d.size() - 4 - osz * n_meshes + osz * (size_t)shape_index;
     if (osz == 8) std::memcpy(&off, &d[tab], 8); else { uint32_t o32; std::memcpy(&o32, &d[tab], 4); off = o32; }
-    if (d.size() < 4 || off > d.size() - 4 || u16(off) != 1052) throw io_error("corrupt sub-mesh header : " + path);
+    if (d.size() < 8 || off >= d.size() - 4 || u16(off) != 1052) throw io_error("corrupt sub-mesh header : " + path);
     const uint16_t version = u16(off + 2);
     if (version != 3 && version != 4) throw io_error("invalid version in serialized mesh file");
     z_stream zs; std::memset(&zs, 0, sizeof(zs));
@@ -249,7 +259,9 @@ mesh_data load_serialized(const std::string& path, int shape_index) {
     uint32_t flag; zread(&flag, 4);
     if (version == 4) { char c; do zread(&c, 1); while (c != 0); }
     uint64_t nv, nt; zread(&nv, 8); zread(&nt, 8);
-    if (nv > (1ull << 31) || nt > (1ull << 31)) { inflateEnd(&zs); throw io_error("serialized mesh too large : " + path); }
+    // deflate expands by at most ~1032 : 1: a header that promises more vertex / index bytes than the rest of the stream can inflate to is refused before the arrays are sized
+    const double inflatable = 1032.0 * (double)(d.size() - off) + 65536.0;
+    if (nv > (1ull << 31) || nt > (1ull << 31) || (double)nv * 12.0 + (double)nt * 12.0 > inflatable) { inflateEnd(&zs); throw io_error("serialized mesh: the header promises more data than the stream holds : " + path); }
     const bool dbl = (flag & 0x2000) != 0;
     mesh_data M;
     auto read_vec = [&](int dim, std::vector<float>& out) {
