@@ -76,15 +76,16 @@ struct loader {
     }
 
     // ---- DefaultValueStorage (Utils.h:148-263)
-    std::string map_default(const std::string& data) const {
+    std::string map_default(const std::string& data, int depth = 0) const {
         const size_t s = data.find('$');
         if (s == std::string::npos) return data;
+        if (depth > 64) bad("invalid default value (a <default> that refers to itself)");
         size_t e = data.find(' ', s); if (e == std::string::npos) e = data.size();
         const std::string key = data.substr(s + 1, e - s - 1);
         auto it = defaults.find(key);
         if (it == defaults.end()) bad("invalid default value");
         // (the reference keeps the '$' when the key is not at the start of the string, Utils.h:175; kept)
-        return map_default((s != 0 ? data.substr(0, s + 1) : "") + it->second + (e != data.size() ? data.substr(e) : ""));
+        return map_default((s != 0 ? data.substr(0, s + 1) : "") + it->second + (e != data.size() ? data.substr(e) : ""), depth + 1);
     }
     float as_float(const std::string& v) const { return std::stof(map_default(v)); }
     std::string attr_s(const xml_node& n, const char* a) const { return map_default(n.attr(a)); }
@@ -577,9 +578,12 @@ struct loader {
     }
 
     void parse_file(const std::string& file);
+    int include_depth = 0;   // <include> chains: a file that (directly or through others) includes itself is refused instead of recursing until the stack is gone
 };
 
 void loader::parse_file(const std::string& file) {
+    struct level { int& d; explicit level(int& x) : d(x) { d++; } ~level() { d--; } } guard(include_depth);
+    if (include_depth > 32) throw io_error("couldn't loader scene xml! (<include> nested more than 32 deep: " + file + ")");
     FILE* f = std::fopen(file.c_str(), "rb");
     if (!f) throw io_error("couldn't loader scene xml! (" + file + ")");
     std::string text; char buf[65536]; size_t n;

@@ -34,6 +34,8 @@ struct xml_node {
 
 class xml_parser {
     const std::string& s; size_t p = 0;
+    int depth = 0;                                   // element() recurses once per nesting level: a scene file is a few levels deep, a file that nests deeper than
+    static constexpr int kMaxDepth = 256;            // this is refused instead of running the parser (and every walk over the tree) out of stack
     [[noreturn]] void fail(const std::string& what) const {
         size_t line = 1; for (size_t i = 0; i < p && i < s.size(); i++) if (s[i] == '\n') line++;
         throw std::runtime_error("couldn't loader scene xml! (" + what + " at line " + std::to_string(line) + ")");
@@ -75,6 +77,8 @@ class xml_parser {
     xml_node element() {
         if (p >= s.size() || s[p] != '<') fail("expected '<'");
         p++;
+        if (depth >= kMaxDepth) fail("elements nested more than " + std::to_string(kMaxDepth) + " deep");
+        struct level { int& d; explicit level(int& x) : d(x) { d++; } ~level() { d--; } } guard(depth);
         xml_node n; n.name = read_name();
         for (;;) {
             skip_ws();

@@ -1,4 +1,4 @@
-"""Image headers that promise more pixels than the file could hold (or than a texture may have) are refused before anything is allocated for them
+"""File headers that promise more pixels than the file could hold (or than a texture may have) are refused before anything is allocated for them
 (csrc/image_io.cpp check_image_size, csrc/jpeg_decode.cpp; found by tools/fuzz_loaders.py: a 60-byte PGM declaring 2^31 x 2^31 pixels asked for exabytes).
 Host code only."""
 import os
@@ -97,3 +97,22 @@ def test_mesh_header_larger_than_the_file_is_refused(tmp_path, name):
         sc.ParseMitsubaScene(x)
     assert e.value.code in (-5, -6), (e.value.code, str(e.value))
     assert "bad_alloc" not in str(e.value) and "length_error" not in str(e.value)
+
+
+SENSOR = '<sensor type="perspective"><film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/></film></sensor>'
+SCENES = {
+    "deep": '<scene version="0.5.0">' + '<bsdf type="twosided">' * 100000 + '</bsdf>' * 100000 + '</scene>',                    # recursion depth of the XML reader
+    "include_self": '<scene version="0.5.0">' + SENSOR + '<include filename="scene.xml"/></scene>',                                 # <include> cycle
+    "default_self": '<scene version="0.5.0">' + SENSOR + '<default name="x" value="$x"/><shape type="sphere"><float name="radius" value="$x"/></shape></scene>',
+    "ref_self": '<scene version="0.5.0">' + SENSOR + '<bsdf type="twosided" id="a"><ref id="a"/></bsdf></scene>',
+    "group_self": '<scene version="0.5.0">' + SENSOR + '<shape type="shapegroup" id="g"><shape type="instance"><ref id="g"/></shape></shape></scene>',
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_scene_files_that_refer_to_themselves_are_refused(tmp_path, name):
+    """unbounded recursion (nesting, <include>, $defaults, references) ends in an error, not in a stack overflow"""
+    x = os.path.join(str(tmp_path), "scene.xml"); open(x, "w").write(SCENES[name])
+    sc = ctl.DynamicScene()
+    with pytest.raises(ctl.CtlError):
+        sc.ParseMitsubaScene(x)
