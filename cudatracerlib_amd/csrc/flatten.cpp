@@ -133,7 +133,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node format only
     std::string key;
     if (!cache_dir().empty()) {
-        content_hash H; const uint32_t version = 8;
+        content_hash H; const uint32_t version = 9;
         H.add_value(version); H.add_value(flat_collapse_mode()); H.add_value(flat_collapse_node_cost()); H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
@@ -277,7 +277,12 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
                 }
                 for (int c = 0; c < 4; c++) {
                     if (c < w.n) { f.mask |= (uint8_t)(1u << c); f.child[c] = w.child[c] >= 0 ? w.child[c] * 4 : w.child[c]; }
-                    else f.child[c] = 0x76543210;
+                    else {
+                        // a missing child gets an INVERTED box (lo = 255, hi = 0 on every axis): whatever the ray, its entry plane lies behind its exit plane
+                        // (|step / dir| is a normal float >= 2^-126, so 255 steps always differ from 0 steps), and the kernel needs no "child exists" test per slot
+                        f.child[c] = 0x76543210;
+                        for (int k = 0; k < 3; k++) { *q[k][0] |= 255u << (8 * c); *q[k][1] &= ~(255u << (8 * c)); }
+                    }
                 }
             }
             });

@@ -38,7 +38,7 @@ enum flat_format : int {
 struct flat4_node {
     float origin[3];
     uint8_t e[3];          // biased float exponents of the per-axis quantisation step
-    uint8_t mask;          // bit c set <=> child c exists; bit 4 + c set <=> child c is a leaf
+    uint8_t mask;          // bit c set <=> child c exists; bit 4 + c set <=> child c is a leaf.  A missing child also has an INVERTED box (lo = 255, hi = 0), so the kernel's slab test alone rejects it
     uint32_t qlo_x, qhi_x, qlo_y, qhi_y, qlo_z, qhi_z;   // byte c = child c
     uint32_t links[2];
     int32_t child[4];      // >= 0: node index * 4 (float4 units); < 0: ~firstLeafEntry; 0x76543210: none

@@ -79,6 +79,12 @@ __device__ __forceinline__ int flat_leaf_test(const dev_scene& S, uint32_t e, fl
     return (iw.x & 1u) ? -1 : (int)(e + 1);
 }
 
+// culling-only min / max: the hardware instructions as they are (a NaN operand loses, as with fmaxf / fminf)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float min3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // ---- node steps.  Each returns the children the ray enters, nearest first, in c[0..n_hit): links as stored in the node.
 struct ray_cull { float idx, idy, idz, oox, ooy, ooz; int sx, sy, sz; };   // sx/sy/sz = 1 where the direction component is negative
 
@@ -140,9 +146,10 @@ __device__ __forceinline__ int node_step_q4(const float4* __restrict__ nodes, in
         const float tnx = __builtin_fmaf((float)((nx >> (8 * k)) & 0xffu), ax, bx), tfx = __builtin_fmaf((float)((fx >> (8 * k)) & 0xffu), ax, bx);
         const float tny = __builtin_fmaf((float)((ny >> (8 * k)) & 0xffu), ay, by), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 0xffu), ay, by);
         const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 0xffu), az, bz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 0xffu), az, bz);
-        const float cmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-        const float cmax = fminf(fminf(tfx, tfy), fminf(tfz, ht));
-        dd[k] = ((cmax >= cmin) && ((meta >> (24 + k)) & 1u)) ? cmin : inf;
+        // v_max3 / v_min3 written out: fmaxf on a value loaded from memory (tmin, ht) makes the compiler canonicalise it first, once per node step and operand
+        const float cmin = max_raw(max3_raw(tnx, tny, tnz), tmin);
+        const float cmax = min_raw(min3_raw(tfx, tfy, tfz), ht);
+        dd[k] = (cmax >= cmin) ? cmin : inf;   // no "child exists" test: a missing child's box is inverted (flatten.cpp) and is never entered
     }
     CTL_CSWAP_PAIR(0, 1) CTL_CSWAP_PAIR(2, 3) CTL_CSWAP_PAIR(0, 2) CTL_CSWAP_PAIR(1, 3) CTL_CSWAP_PAIR(1, 2)
     return dd[3] < inf ? 4 : (dd[2] < inf ? 3 : (dd[1] < inf ? 2 : (dd[0] < inf ? 1 : 0)));

@@ -144,3 +144,18 @@ print("NODES", fb.desc.n_nodes, "MULTI", int((sizes > 1).sum()))
         out[mode] = (int(line[1]), int(line[3]))
     assert out["1"][0] < 0.9 * out["0"][0], out     # fewer wide nodes
     assert out["1"][1] > out["0"][1], out           # some leaves were merged
+
+
+def test_missing_children_have_inverted_boxes():
+    """flat4_node: a slot without a child carries lo = 255 / hi = 0 on every axis (the kernel has no per-slot "child exists" test), a slot with a child lo <= hi"""
+    for sc in (scenes.synthetic_sm(32, 32, n_instances=40, subdiv=2), scenes.cornell_box(32, 32, glass_sphere=True)):
+        fb = api.FlatBvh(sc.desc, api.FLAT_Q4)      # (the arrays belong to it)
+        N = fb.nodes()
+        exist = (N[:, 3] >> 24) & 15
+        assert ((exist != 15).sum() > 0)
+        for c in range(4):
+            has = ((exist >> c) & 1) == 1
+            for lo_w, hi_w in ((4, 5), (6, 7), (8, 9)):
+                lo = (N[:, lo_w] >> (8 * c)) & 255; hi = (N[:, hi_w] >> (8 * c)) & 255
+                assert (lo[has] <= hi[has]).all()
+                assert (lo[~has] == 255).all() and (hi[~has] == 0).all()
