@@ -53,6 +53,12 @@ void orc_triangle_fill_dg(const ctl_triangle_data* T, const float* local_to_worl
 // ---- warps / fresnel ------------------------------------------------------------------------------------------
 void orc_square_to_cosine_hemisphere(float x, float y, float* out) { V3 r = squareToCosineHemisphere(V2{ x, y }); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 void orc_square_to_uniform_triangle(float x, float y, float* out) { V2 r = squareToUniformTriangle(V2{ x, y }); out[0] = r.x; out[1] = r.y; }
+float orc_interval_to_tent(float s) { return intervalToTent(s); }
+float orc_cosine_hemisphere_pdf(const float* d) { return squareToCosineHemispherePdf(V3(d[0], d[1], d[2])); }
+void orc_square_to_uniform_sphere(float x, float y, float* out) { V3 r = squareToUniformSphere(V2{ x, y }); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+int orc_barycentric(const float* p, const float* a, const float* b, const float* c, float* uv) {
+    float u = 0, v = 0; const bool in = barycentric(V3(p[0], p[1], p[2]), V3(a[0], a[1], a[2]), V3(b[0], b[1], b[2]), V3(c[0], c[1], c[2]), u, v); uv[0] = u; uv[1] = v; return in ? 1 : 0;
+}
 void orc_square_to_uniform_disk_concentric(float x, float y, float* out) { V2 r = squareToUniformDiskConcentric(V2{ x, y }); out[0] = r.x; out[1] = r.y; }
 float orc_fresnel_dielectric_ext(float cosThetaI, float eta, float* cosThetaT) { return fresnelDielectricExt(cosThetaI, *cosThetaT, eta); }
 void orc_fresnel_conductor_exact(float cosThetaI, const float* eta, const float* k, float* out) {

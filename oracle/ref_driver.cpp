@@ -28,6 +28,7 @@
 #include <Engine/MIPMap_device.h>
 #include <Engine/SpatialStructures/BVH/BVHTraversal.h>
 #include <Math/float4x4.h>
+#include <Math/AlgebraHelper.h>
 #include <cstdint>
 #include <cstring>
 
@@ -240,5 +241,16 @@ void ref_trace_two_level(const void* scene_nodes, int scene_start_node, const vo
         out_tuv[3 * (size_t)i] = dist; out_tuv[3 * (size_t)i + 1] = bary.x; out_tuv[3 * (size_t)i + 2] = bary.y;
         out_tri[i] = tri; out_node[i] = node;
     }
+}
+
+// second batch of small functions of the path (Math/Warp.h:13-27, :29-36, :68-71, :180-186; Math/AlgebraHelper.h:46-59)
+float ref_interval_to_tent(float s) { return Warp::squareToTent(Vec2f(s, s)).x; }   // intervalToTent itself is private: squareToTent applies it per component
+void ref_square_to_tent(float x, float y, float* out) { auto r = Warp::squareToTent(Vec2f(x, y)); out[0] = r.x; out[1] = r.y; }
+float ref_cosine_hemisphere_pdf(const float* d) { return Warp::squareToCosineHemispherePdf(NormalizedT<Vec3f>(Vec3f(d[0], d[1], d[2]))); }
+void ref_square_to_uniform_sphere(float x, float y, float* out) { auto r = Warp::squareToUniformSphere(Vec2f(x, y)); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+int ref_barycentric(const float* p, const float* a, const float* b, const float* c, float* uv) {
+    float u = 0, v = 0;
+    const bool in = AlgebraHelper::Barycentric(Vec3f(p[0], p[1], p[2]), Vec3f(a[0], a[1], a[2]), Vec3f(b[0], b[1], b[2]), Vec3f(c[0], c[1], c[2]), u, v);
+    uv[0] = u; uv[1] = v; return in ? 1 : 0;
 }
 } // extern "C"

@@ -295,9 +295,37 @@ def gen_traceray(r):
     np.savez_compressed(os.path.join(HERE, "traceray.npz"), **out)
 
 
+def gen_math2(r):
+    # ---- second batch of small functions (Math/Warp.h intervalToTent / squareToTent, squareToCosineHemispherePdf, squareToUniformSphere; AlgebraHelper::Barycentric), own random stream
+    rs = np.random.RandomState(20260940)
+    n = 512
+    s = np.concatenate([rs.uniform(0, 1, size=(n - 8, 2)), np.array([[0, 0], [0.5, 0.5], [1, 1], [0.25, 0.75], [0.49999997, 0.50000006], [1e-8, 1 - 1e-7], [0.999, 0.001], [0.5, 0]])]).astype(np.float32)
+    r.ref_interval_to_tent.restype = f32; r.ref_interval_to_tent.argtypes = [f32]
+    r.ref_cosine_hemisphere_pdf.restype = f32; r.ref_cosine_hemisphere_pdf.argtypes = [C.c_void_p]
+    r.ref_square_to_uniform_sphere.argtypes = [f32, f32, C.c_void_p]
+    r.ref_barycentric.argtypes = [C.c_void_p] * 5
+    tent = np.array([r.ref_interval_to_tent(f32(x)) for x in s[:, 0]], np.float32)
+    sph = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        r.ref_square_to_uniform_sphere(f32(s[i, 0]), f32(s[i, 1]), sph[i].ctypes.data)
+    dirs = rs.normal(size=(n, 3)); dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    cpdf = np.array([r.ref_cosine_hemisphere_pdf(dirs[i].ctypes.data) for i in range(n)], np.float32)
+    # Barycentric: points in / near / outside random triangles, and on their edges
+    tri = (rs.normal(size=(n, 3, 3)) * rs.uniform(0.1, 20, size=(n, 1, 1))).astype(np.float32)
+    w = rs.dirichlet([1, 1, 1], size=n); w[n // 2:] = rs.uniform(-0.3, 1.3, size=(n - n // 2, 3)); w[:16, 2] = 0; w[:16, 1] = 1 - w[:16, 0]
+    pts = (w[:, :1] * tri[:, 0] + w[:, 1:2] * tri[:, 1] + w[:, 2:3] * tri[:, 2]).astype(np.float32)
+    uv = np.zeros((n, 2), np.float32); inside = np.zeros(n, np.int32)
+    for i in range(n):
+        inside[i] = r.ref_barycentric(pts[i].ctypes.data, tri[i, 0].ctypes.data, tri[i, 1].ctypes.data, tri[i, 2].ctypes.data, uv[i].ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "math2.npz"), s=s, tent=tent, sphere=sph, dirs=dirs, cosine_pdf=cpdf, tri=tri, pts=pts, bary_uv=uv, bary_inside=inside)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["traceray"]:      # only this fixture (the others stay byte-identical)
+    if sys.argv[1:] == ["math2"]:
+        gen_math2(oracle.load_ref())
+    elif sys.argv[1:] == ["traceray"]:      # only this fixture (the others stay byte-identical)
         gen_traceray(oracle.load_ref())
     else:
         main()
         gen_traceray(oracle.load_ref())
+        gen_math2(oracle.load_ref())
