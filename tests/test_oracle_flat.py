@@ -58,33 +58,35 @@ def test_leaf_entries_carry_the_meshes_own_woop_rows_and_the_inverse_transform(o
     assert np.array_equal(L[:, 16:28], inv[L[:, 13], :12]) and np.array_equal(L[:, 28], inv[L[:, 13], 15])
 
 
-def test_implied_child_links_of_the_quantised_nodes(orc):
+def check_implied_links(fb):
     """flat4_node: the links a traversal step derives from the first 48 B (inner children = consecutive nodes, leaf children = consecutive
-    entries, per-slot entry counts) are the explicit child[] words, for every node"""
+    entries, per-slot entry counts) are the explicit child[] words, for every node of the tree"""
+    N = fb.nodes(); L = fb.leaves()
+    assert N.shape[1] == 16
+    meta = N[:, 3]; exist = (meta >> 24) & 15; leafm = meta >> 28; innerm = exist & ~leafm & 15
+    assert (leafm & ~exist).max() == 0
+    w0, w1 = N[:, 10], N[:, 11]
+    inner_base, leaf_base = w0 >> 6, w1 >> 2
+    cnt = np.stack([w0 & 3, (w0 >> 2) & 3, (w0 >> 4) & 3, w1 & 3], 1) + 1
+    child = N[:, 12:16].view(np.int32)
+    n_leaf_before = np.zeros(len(N), np.int64); n_inner_before = np.zeros(len(N), np.int64)
+    for c in range(4):
+        is_leaf = ((leafm >> c) & 1) == 1; is_inner = ((innerm >> c) & 1) == 1
+        assert np.array_equal(child[is_leaf, c], ~(leaf_base[is_leaf].astype(np.int64) + n_leaf_before[is_leaf]).astype(np.int32))
+        assert np.array_equal(child[is_inner, c], ((inner_base[is_inner] + n_inner_before[is_inner]) * 4).astype(np.int32))
+        assert (child[~is_leaf & ~is_inner, c] == 0x76543210).all()
+        # the count of a leaf child = distance to the entry flagged last
+        first = (leaf_base + n_leaf_before)[is_leaf]; k = cnt[is_leaf, c]
+        assert (L[first + k - 1, 12] & 1).all()
+        for j in range(1, 4):
+            inside = k > j
+            assert not (L[(first + j - 1)[inside], 12] & 1).any()
+        n_leaf_before += np.where(is_leaf, cnt[:, c], 0); n_inner_before += is_inner
+
+
+def test_implied_child_links_of_the_quantised_nodes(orc):
     for sc in (scenes.synthetic_sm(32, 32, n_instances=40, subdiv=2), scenes.cornell_box(32, 32, glass_sphere=True)):
-        fb = api.FlatBvh(sc.desc, api.FLAT_Q4)
-        N = fb.nodes(); L = fb.leaves()
-        assert N.shape[1] == 16
-        meta = N[:, 3]; exist = (meta >> 24) & 15; leafm = meta >> 28; innerm = exist & ~leafm & 15
-        assert (leafm & ~exist).max() == 0
-        w0, w1 = N[:, 10], N[:, 11]
-        inner_base, leaf_base = w0 >> 6, w1 >> 2
-        cnt = np.stack([w0 & 3, (w0 >> 2) & 3, (w0 >> 4) & 3, w1 & 3], 1) + 1
-        child = N[:, 12:16].view(np.int32)
-        n_leaf_before = np.zeros(len(N), np.int64); n_inner_before = np.zeros(len(N), np.int64)
-        for c in range(4):
-            is_leaf = ((leafm >> c) & 1) == 1; is_inner = ((innerm >> c) & 1) == 1
-            assert np.array_equal(child[is_leaf, c], ~(leaf_base[is_leaf].astype(np.int64) + n_leaf_before[is_leaf]).astype(np.int32))
-            assert np.array_equal(child[is_inner, c], ((inner_base[is_inner] + n_inner_before[is_inner]) * 4).astype(np.int32))
-            assert (child[~is_leaf & ~is_inner, c] == 0x76543210).all()
-            # the count of a leaf child = distance to the entry flagged last
-            first = (leaf_base[is_leaf] + n_leaf_before[is_leaf]).astype(np.int64)
-            last = first + cnt[is_leaf, c] - 1
-            assert (L[last, 12] & 1).all()
-            for k in range(3):
-                inside = first + k < last
-                assert not (L[(first + k)[inside], 12] & 1).any()
-            n_leaf_before += np.where(is_leaf, cnt[:, c], 0); n_inner_before += is_inner
+        check_implied_links(api.FlatBvh(sc.desc, api.FLAT_Q4))
 
 
 def test_render_counts_in_flat_mode(orc):
@@ -114,7 +116,7 @@ sys.path.insert(0, %r)
 from cudatracerlib_amd import api, scenes
 import oracle
 sys.path.insert(0, %r)
-from test_oracle_flat import rays_for
+from test_oracle_flat import rays_for, check_implied_links
 orc = oracle.Oracle()
 sc = scenes.synthetic_sm(32, 32, n_instances=60, subdiv=2)
 d = sc.desc
@@ -123,6 +125,7 @@ N, L = fb.nodes(), fb.leaves()
 last = L[:, 12] & 1
 sizes = np.diff(np.concatenate([[-1], np.nonzero(last)[0]]))
 assert sizes.max() <= 4 and sizes.min() >= 1
+check_implied_links(fb)
 rays = rays_for(d, 6000, 5)
 want = orc.intersect(d, rays)
 got = orc.intersect(d, rays, flat=fb.desc)
