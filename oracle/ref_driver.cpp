@@ -253,4 +253,12 @@ int ref_barycentric(const float* p, const float* a, const float* b, const float*
     const bool in = AlgebraHelper::Barycentric(Vec3f(p[0], p[1], p[2]), Vec3f(a[0], a[1], a[2]), Vec3f(b[0], b[1], b[2]), Vec3f(c[0], c[1], c[2]), u, v);
     uv[0] = u; uv[1] = v; return in ? 1 : 0;
 }
+
+// FresnelHelper::reflect / refract about a normal (Math/FresnelHelper.h:144-155): the microfacet BSDFs' outgoing directions
+void ref_reflect_about(const float* wi, const float* n, float* out) {
+    auto r = FresnelHelper::reflect(NormalizedT<Vec3f>(Vec3f(wi[0], wi[1], wi[2])), NormalizedT<Vec3f>(Vec3f(n[0], n[1], n[2]))); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void ref_refract_about(const float* wi, const float* n, float eta, float cosThetaT, float* out) {
+    Vec3f r = FresnelHelper::refract(Vec3f(wi[0], wi[1], wi[2]), Vec3f(n[0], n[1], n[2]), eta, cosThetaT); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
 } // extern "C"

@@ -317,7 +317,17 @@ def gen_math2(r):
     uv = np.zeros((n, 2), np.float32); inside = np.zeros(n, np.int32)
     for i in range(n):
         inside[i] = r.ref_barycentric(pts[i].ctypes.data, tri[i, 0].ctypes.data, tri[i, 1].ctypes.data, tri[i, 2].ctypes.data, uv[i].ctypes.data)
-    np.savez_compressed(os.path.join(HERE, "math2.npz"), s=s, tent=tent, sphere=sph, dirs=dirs, cosine_pdf=cpdf, tri=tri, pts=pts, bary_uv=uv, bary_inside=inside)
+    # FresnelHelper::reflect / refract about a normal (drawn after everything above, so that the earlier arrays stay as they were)
+    r.ref_reflect_about.argtypes = [C.c_void_p] * 3; r.ref_refract_about.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
+    wi = rs.normal(size=(n, 3)); wi = (wi / np.linalg.norm(wi, axis=1, keepdims=True)).astype(np.float32)
+    nn = rs.normal(size=(n, 3)); nn = (nn / np.linalg.norm(nn, axis=1, keepdims=True)).astype(np.float32)
+    eta = rs.uniform(1.01, 2.5, size=n).astype(np.float32); ct = rs.uniform(-1, 1, size=n).astype(np.float32)
+    refl = np.zeros((n, 3), np.float32); refr = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        r.ref_reflect_about(wi[i].ctypes.data, nn[i].ctypes.data, refl[i].ctypes.data)
+        r.ref_refract_about(wi[i].ctypes.data, nn[i].ctypes.data, f32(eta[i]), f32(ct[i]), refr[i].ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "math2.npz"), s=s, tent=tent, sphere=sph, dirs=dirs, cosine_pdf=cpdf, tri=tri, pts=pts, bary_uv=uv, bary_inside=inside,
+                        rr_wi=wi, rr_n=nn, rr_eta=eta, rr_cos_t=ct, reflect=refl, refract=refr)
 
 
 if __name__ == "__main__":
