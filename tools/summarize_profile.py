@@ -79,6 +79,21 @@ def main():
                                                "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss > 0 else None,
                                                "memory_side_read_requests_per_ray": r.get("TCC_EA0_RDREQ_sum", 0.0) / rays_run}
         json.dump(t, open(tpath, "w"), indent=1)
+    # the contract's cross-check: rocprofv3's own durations of the dominant kernel's TIMED launches (the last `launches` dispatches of the kernel-trace run:
+    # warm-up launches come first and carry fewer passes) against the average bench.py measured with HIP events in its own, unprofiled run
+    kt = glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True)
+    if kt and dom:
+        want = "k_intersect_pair" if "pair" in rf.get("kernel", "") else "k_intersect<false, false"
+        d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(kt[0])) if short(r["Kernel_Name"]).startswith(want)]
+        d.sort()
+        timed = d[-int(rf["launches"]):] if rf.get("launches") else d
+        if timed:
+            avg_ms = sum(e - s for s, e in timed) / len(timed) / 1e6
+            chk = {"kernel": want, "profiled_dispatches": len(d), "timed_launches": len(timed), "rocprof_timed_avg_ms": round(avg_ms, 4),
+                   "bench_avg_launch_ms": rf.get("avg_launch_ms"), "ratio": round(avg_ms / rf["avg_launch_ms"], 4) if rf.get("avg_launch_ms") else None,
+                   "note": "rocprofv3 --kernel-trace durations of the last `timed_launches` dispatches of the dominant kernel (the warm-up launches precede them) vs bench.py's HIP-event average of its own unprofiled run"}
+            json.dump(chk, open(os.path.join(dst, tag + "_roofline_check.json"), "w"), indent=1)
+            print(json.dumps(chk))
     print(open(out).read())
 
 
