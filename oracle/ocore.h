@@ -2,6 +2,8 @@
 // ocore.h — scene access, Woop triangles, two-level BVH traversal, TriangleData / fillDG, sampler,
 // sensor, lights, BSDFs and the megakernel PathTrace<DIRECT> — the semantic oracle of the path.
 #pragma once
+#include <atomic>
+#include <cstdlib>
 #include "omath.h"
 #include "../include/ctl_amd.h"   // boundary structs only (data layout contract)
 #include <vector>
@@ -138,6 +140,8 @@ inline bool alphaSurvive(const Scene& S, uint32_t tri, uint32_t nodeIdx, float u
 // transform (TraceHelper.cu:526-560), then the Woop test (:646-682) — so the accepted hit is the reference's.  Plain depth-first
 // order, children nearest first (the product's kernel visits speculatively and may count more nodes; the counts returned here are the
 // algorithmic ones).  n_inst stays 0: there is no instance entry.
+// measurement probe for tools/bvh_quality_probe.py --slab (off unless orc_slab_probe(1) was called)
+inline bool g_slab_probe = false; inline std::atomic<uint64_t> g_slab_tests{ 0 }, g_slab_rejects{ 0 };
 inline bool traceRayFlat(const Scene& S, V3 ori, V3 dir, float tmin_tri, float tmax, bool any_hit, float node_tmin, Hit& res, TravCounts* cnt) {
     const ctl_scene_desc& g = S.d; const ctl_flat_bvh_desc& F = *S.flat;
     res.init(); res.dist = tmax;
@@ -201,6 +205,21 @@ inline bool traceRayFlat(const Scene& S, V3 ori, V3 dir, float tmin_tri, float t
             M44 modl; std::memcpy(modl.d, g.node_inv_transforms[nodeIdx].m, 64);
             const V3 d = transformDir(modl, dir), o = transformPoint(modl, ori);   // TraceHelper.cu:526-560 (per entry here; per instance there)
             float t, u, v;
+            if (cnt && g_slab_probe) {
+                // what an oriented slab in front of the entry fetch would reject: the ray meets the triangle's plane outside (tmin, current hit), or at a
+                // point outside the triangle's own box (padded by 2 % of its size) — a superset of the accepted hits, so never a false negative
+                V3 v0, v1, v2; woopGetData(w, v0, v1, v2);
+                const float Oz = w.a[3] - o.x * w.a[0] - o.y * w.a[1] - o.z * w.a[2], tt = Oz * (1.0f / (d.x * w.a[0] + d.y * w.a[1] + d.z * w.a[2]));
+                bool reject = !(tt > tmin_tri && tt < res.dist);
+                static const bool plane_only = getenv("ORC_SLAB_PLANE_ONLY") != nullptr;   // the part of the test that needs no box: the plane lies behind the origin or beyond the current hit
+                if (!reject && !plane_only) {
+                    const V3 P = o + d * tt;
+                    const float px[3] = { P.x, P.y, P.z }, a0[3] = { v0.x, v0.y, v0.z }, a1[3] = { v1.x, v1.y, v1.z }, a2[3] = { v2.x, v2.y, v2.z };
+                    float ext = 0; for (int k = 0; k < 3; k++) ext = fmax2(ext, fmax2(fmax2(a0[k], a1[k]), a2[k]) - fmin2(fmin2(a0[k], a1[k]), a2[k]));
+                    for (int k = 0; k < 3; k++) { const float lo = fmin2(fmin2(a0[k], a1[k]), a2[k]) - 0.02f * ext, hi = fmax2(fmax2(a0[k], a1[k]), a2[k]) + 0.02f * ext; if (px[k] < lo || px[k] > hi) reject = true; }
+                }
+                g_slab_tests.fetch_add(1, std::memory_order_relaxed); if (reject) g_slab_rejects.fetch_add(1, std::memory_order_relaxed);
+            }
             if (woopIntersect(w, o, d, tmin_tri, res.dist, t, u, v) && (!S.alpha_test || alphaSurvive(S, index >> 1, nodeIdx, u, v))) {
                 res.node = nodeIdx; res.tri = index >> 1; res.u = u; res.v = v; res.dist = t; found = true;
                 if (any_hit) return true;

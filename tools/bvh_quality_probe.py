@@ -29,12 +29,17 @@ def main():
         sc = scenes.cornell_box(a.width, a.height, glass_sphere=True)
     t0 = time.time(); fb = api.FlatBvh(sc.desc, api.FLAT_Q4); t_build = time.time() - t0
     orc = oracle.Oracle()
+    import ctypes as C
+    orc.lib.orc_slab_probe.argtypes = [C.c_int, C.c_void_p]
+    orc.lib.orc_slab_probe(1, None)   # count what an oriented slab in front of the entry fetch would reject (oracle/ocore.h traceRayFlat)
     counts = {}
     t0 = time.time()
     _, rays = orc.render(sc.desc, a.width, a.height, n_passes=1, threads=a.threads, flat=fb.desc, counts=counts, direct=True, max_path_length=8, rr_start=5)
     t_r = time.time() - t0
     pr = counts["path_rays"]
     ni, nt = counts["path_inner"] / pr, counts["path_tri"] / pr
+    sl = (C.c_uint64 * 2)(); orc.lib.orc_slab_probe(0, sl)
+    print("oriented-slab pre-test: %d of %d leaf-entry tests (path + occlusion rays) would be rejected before the fetch = %.1f %%" % (sl[1], sl[0], 100.0 * sl[1] / max(1, sl[0])), flush=True)
     knobs = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("CTL_FLAT"))
     print("%-60s nodes %9d leaves %9d depth %2d | per path ray: inner %.2f tri %.2f | cost proxy %.0f | build %.1f s, count %.1f s" % (
         knobs or "(defaults)", fb.desc.n_nodes, fb.desc.n_leaves, fb.desc.max_depth, ni, nt, 277 * ni + 365 * nt, t_build, t_r), flush=True)
