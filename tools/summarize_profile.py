@@ -56,7 +56,7 @@ def main():
         for k, r in sorted(rows.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0)):
             hit, miss = r.get("TCC_HIT_sum", 0.0), r.get("TCC_MISS_sum", 0.0)
             lane = r.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * r["SQ_INSTS_VALU"]) if r.get("SQ_INSTS_VALU") else None
-            fh.write("%s,%d,%s,%.0f,%s,%s\n" % (k, r.get("launches", 0), ",".join("%.6g" % r.get(c, 0.0) for c in cols), 2 * r.get("FETCH_SIZE", 0.0) * 1024,
+            fh.write("\"%s\",%d,%s,%.0f,%s,%s\n" % (k, r.get("launches", 0), ",".join("%.6g" % r.get(c, 0.0) for c in cols), 2 * r.get("FETCH_SIZE", 0.0) * 1024,
                                                ("%.3f" % (hit / (hit + miss))) if hit + miss > 0 else "", ("%.3f" % lane) if lane else ""))
     # dominant kernel = the one bench.py's roofline names: the fused closest + any-hit launch (FuseTraversal, default) or the plain closest-hit intersect
     b = json.load(open(os.path.join(src, "bench.json"))); rf = b["roofline"]
