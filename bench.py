@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X wavefront path tracer.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without WORLD_SIZE in the environment: bench.py launches the N ranks itself (one process per GPU, rank r on device r, the reference's
+one-process-per-device flow, main.cpp:160-172) and forwards rank 0's JSON line; under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
 
 metric   : Mrays/s (primary + continuation + shadow rays / wall time of the render loop; scene load, BVH build and
            image read-back excluded), SURVEY §8d, on the 1920x1080 depth-8 workload.
@@ -135,6 +138,58 @@ def calibrated_traffic(workload_key):
 KERNEL_BUILD = "r02-flat-q4-exact-pair-invbox-bfs64k"   # changes when the traversal kernel or the flattened layout changes: a traffic profile of another build is not quoted
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start N ranks of this same script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as
+    torch.distributed.run would set them), rank r on device r.  Rank 0's stdout is this process's stdout (ONE JSON line); the other ranks' stdout goes to stderr.
+    Non-zero exit if any rank fails or the box has fewer than N devices (CTL_BENCH_SHARE_GPU=1, the 1-GPU test hook, puts every rank on device 0)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.launch_only and os.environ.get("CTL_BENCH_SHARE_GPU") != "1":
+        import cudatracerlib_amd as ctl
+        have = ctl.device_count()     # hipGetDeviceCount: no context is created in the launcher
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (n, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CTL_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = procs[0].stdout.read().decode()      # rank 0 prints one line and then joins the final barrier, so this returns when the run is over (or rank 0 died)
+    rcs = []
+    deadline = time.time() + 120.0
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:       # a rank that hangs after rank 0 is gone: end exactly that process
+            p.kill(); rcs.append(p.wait())
+    for line in out0.splitlines():              # gloo's C++ side prints its connection banner on stdout: everything but the JSON line goes to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py --gpus %d: rank exit codes %s" % (n, rcs))
+
+
+def launch_only(rank, world, dist):
+    """--launch-only: the rendezvous plumbing of an N-rank run without a device — gloo group, barrier, the 128-byte communicator id from rank 0 to everybody,
+    the two scalar reductions — and one JSON line from rank 0.  What tests/test_bench_launcher.py runs on the CPU."""
+    import torch
+    dist.barrier()
+    ident = [bytes((7 * i + 1) & 255 for i in range(128)) if rank == 0 else None]    # stands for ncclGetUniqueId's 128 bytes
+    dist.broadcast_object_list(ident, src=0)
+    ok = torch.tensor([1 if ident[0] == bytes((7 * i + 1) & 255 for i in range(128)) else 0]); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    r = torch.tensor([1.0], dtype=torch.float64); dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_only": True, "n_gpus": world, "ranks_joined": int(r.item()), "max_over_ranks": float(t.item()), "id_broadcast_ok": bool(ok.item()),
+                          "self_launched": os.environ.get("CTL_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,10 +207,16 @@ def main():
     ap.add_argument("--tracer-param", action="append", default=[], metavar="KEY=VALUE")
     ap.add_argument("--no-cache", action="store_true", help="do not use the compiled-geometry cache ($CTL_CACHE_DIR, default $TMPDIR/ctl_amd_cache)")
     ap.add_argument("--flatten", type=int, default=1, help="traverse one world-space BVH over all instanced triangles (64 B of HBM per triangle)")
+    ap.add_argument("--dump-frame", default=None, metavar="FILE.npy", help="rank 0 saves the reduced PixelData frame (h, w, 7) after the timed region (tests compare N-rank and 1-rank frames)")
+    ap.add_argument("--launch-only", action="store_true", help="N-rank rendezvous plumbing only (no device): spawn, gloo group, id broadcast, reductions; prints n_gpus")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (one rank per GPU: launch N ranks for --gpus N, or let bench.py launch them)" % (args.gpus, world))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     share_gpu = os.environ.get("CTL_BENCH_SHARE_GPU") == "1"
@@ -170,6 +231,11 @@ def main():
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)   # torch.cuda.synchronize() in sync() then waits on this rank's own GPU instead of opening a context on device 0
         dist.init_process_group(backend="gloo")
+        if args.launch_only:
+            return launch_only(rank, world, dist)
+    elif args.launch_only:
+        print(json.dumps({"launch_only": True, "n_gpus": 1, "ranks_joined": 1, "self_launched": False}), flush=True)
+        return None
     import cudatracerlib_amd as ctl
     if ctl.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
@@ -269,6 +335,8 @@ def main():
         r = torch.tensor([rays], dtype=torch.float64); dist.all_reduce(r, op=dist.ReduceOp.SUM); rays = float(r.item())
 
     out = None
+    if rank == 0 and args.dump_frame:
+        np.save(args.dump_frame, img.getPixelData())
     if rank == 0:
         # traversal statistics of the SAME rays on the GPU (one extra, untimed pass in counting mode): lane utilisation, visited nodes
         tr.setCounting(True)

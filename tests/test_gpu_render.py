@@ -7,6 +7,7 @@ discrete decision (Russian roulette, light-triangle choice, Fresnel branch) in r
   * >= 99.5 % of pixels: |gpu - cpu| <= 2e-3 * (1 + cpu) per channel of the accumulated radiance sum, and
   * the image means agree to 1e-3 relative.
 """
+import os
 import numpy as np
 import pytest
 from cudatracerlib_amd import scenes
@@ -512,3 +513,28 @@ def test_thinlens_orthographic_and_telecentric_sensors(gpu, orc, kind):
     for k in range(3):
         mk.setSamplerTables(*tables[k]); mk.DoPass(img, new_trace=(k == 0))
     assert_close(img.getPixelData(), want_f)
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_share_one_gpu(gpu, tmp_path):
+    """`python bench.py --gpus 2` launches its two ranks itself (CTL_BENCH_SHARE_GPU=1: both on device 0, the 1-GPU box's stand-in for two devices): one JSON
+    line with n_gpus = 2, all rays accounted for, and the reduced frame equals the frame of the in-process `--gpus 1` run (tiles partition the film,
+    the sampler index is the global pixel; float atomics may add in another order)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "2", "--warmup", "1", "--width", "320", "--height", "192", "--instances", "60", "--subdiv", "2", "--no-cpu-baseline", "--no-cache"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    frames, lines = [], []
+    for n in (1, 2):
+        f = str(tmp_path / ("frame%d.npy" % n))
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--dump-frame", f] + common, env=dict(env, CTL_BENCH_SHARE_GPU="1"), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        js = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(js) == 1
+        lines.append(json.loads(js[0])); frames.append(np.load(f))
+    assert lines[0]["n_gpus"] == 1 and lines[1]["n_gpus"] == 2
+    assert "framebuffer_reduce" in lines[1]["config"] and ("ncclReduce" in lines[1]["config"]["framebuffer_reduce"] or "native RCCL unavailable" in lines[1]["config"]["framebuffer_reduce"])
+    assert lines[0]["config"]["rays_per_step"] == lines[1]["config"]["rays_per_step"]       # the shards' rays sum to the frame's
+    a, b = frames
+    assert np.array_equal(a[..., 6], b[..., 6])
+    assert np.allclose(a[..., :6], b[..., :6], rtol=1e-5, atol=1e-5)
