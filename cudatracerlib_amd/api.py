@@ -197,7 +197,7 @@ def flatten_probe(desc, format=FLAT_Q4):
 
 class FlatBvhDesc(C.Structure):
     _fields_ = [("format", u32), ("max_depth", u32), ("nodes", C.c_void_p), ("n_nodes", u64), ("node_bytes", u32),
-                ("leaves", C.c_void_p), ("n_leaves", u64)]
+                ("leaves", C.c_void_p), ("n_leaves", u64), ("child_links", C.c_void_p), ("compact", u32), ("root_slab", u32), ("n_slab_nodes", u64)]
 
 
 class FlatBvh:
@@ -213,6 +213,10 @@ class FlatBvh:
     def nodes(self):
         n = self.desc.n_nodes * self.desc.node_bytes // 4
         return np.ctypeslib.as_array(C.cast(self.desc.nodes, C.POINTER(C.c_uint32)), shape=(n,)).reshape(self.desc.n_nodes, -1)
+
+    def child_links(self):
+        """Q4: the explicit links, (n_nodes, 4) int32"""
+        return np.ctypeslib.as_array(C.cast(self.desc.child_links, C.POINTER(C.c_int32)), shape=(self.desc.n_nodes * 4,)).reshape(-1, 4)
 
     def leaves(self):
         return np.ctypeslib.as_array(C.cast(self.desc.leaves, C.POINTER(C.c_uint32)), shape=(self.desc.n_leaves * 32,)).reshape(-1, 32)

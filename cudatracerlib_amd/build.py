@@ -15,18 +15,22 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-pthread"]
 
 
-def stale():
-    if not os.path.exists(OUT):
+KNOBS_OUT = os.path.join(HERE, "libctl_knobs.so")   # the same library built -DCTL_MEASUREMENT_KNOBS (csrc/knobs.h): tools/exp.sh, tools/*probe*, the tests of builder options
+
+
+def stale(target=None):
+    target = target or OUT
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(OUT)
+    t = os.path.getmtime(target)
     deps = glob.glob(os.path.join(CSRC, "*")) + [os.path.join(HERE, "..", "include", "ctl_amd.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=True, out=None, defines=()):
     """out / defines: a variant build (tools/build_variant.sh) with extra -D flags into its own object directory"""
-    if out is None and not force and not stale():
-        return OUT
+    if not force and not stale(out):
+        return out or OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     bdir = os.path.join(HERE, "build" if out is None else "build_" + os.path.splitext(os.path.basename(out))[0])
@@ -58,3 +62,5 @@ if __name__ == "__main__":
         if a == "--out": out = os.path.abspath(args.pop(0))
         elif a.startswith("-D"): defines.append(a[2:])
     build(force="--force" in sys.argv, out=out, defines=defines, verbose=False)
+    if out is None:
+        build(force="--force" in sys.argv, out=KNOBS_OUT, defines=["CTL_MEASUREMENT_KNOBS"], verbose=False)

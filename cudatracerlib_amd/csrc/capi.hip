@@ -115,7 +115,7 @@ int ctl_flatten_probe(const ctl_scene_desc* desc, uint32_t format, uint64_t* out
     CTL_TRY
         flat_scene F;
         if (!flatten_scene(*desc, F, (size_t)1 << 30, (int)format)) throw std::runtime_error("ctl_flatten_probe: nothing to flatten");
-        content_hash H; H.add_vector(F.nodes); H.add_vector(F.nodes_f4); H.add_vector(F.nodes_f2); H.add_vector(F.leaves);
+        content_hash H; H.add_vector(F.nodes); H.add_vector(F.child_links); H.add_vector(F.nodes_f4); H.add_vector(F.nodes_f2); H.add_vector(F.leaves);
         out4[0] = F.nodes.size() + F.nodes_f4.size() + F.nodes_f2.size(); out4[1] = F.leaves.size(); out4[2] = (uint64_t)F.max_depth;
         out4[3] = std::strtoull(H.hex().substr(16).c_str(), nullptr, 16);
     CTL_CATCH
@@ -136,6 +136,8 @@ int ctl_flat_bvh_arrays(const ctl_flat_bvh* h, ctl_flat_bvh_desc* out) {
     else if (F.format == kFlatF4) { out->nodes = F.nodes_f4.data(); out->n_nodes = F.nodes_f4.size(); out->node_bytes = 128; }
     else { out->nodes = F.nodes_f2.data(); out->n_nodes = F.nodes_f2.size(); out->node_bytes = 64; }
     out->leaves = F.leaves.data(); out->n_leaves = F.leaves.size();
+    out->child_links = F.format == kFlatQ4 ? F.child_links.data() : nullptr; out->compact = (F.format == kFlatQ4 && F.compact_links) ? 1u : 0u;
+    out->root_slab = F.root_slab ? 1u : 0u; out->n_slab_nodes = F.slab_nodes;
     return CTL_OK;
 }
 void ctl_flat_bvh_destroy(ctl_flat_bvh* h) { delete h; }

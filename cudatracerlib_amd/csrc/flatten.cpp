@@ -5,6 +5,8 @@
 // kernel evaluates it with the reference's instance-transform + Woop arithmetic, so (t, u, v, triangle, node) equal the two-level traversal bit for bit
 // (flatten.h).  World-space vertices are recovered from the Woop rows in double only to compute the boxes, which are padded.
 #include "flatten.h"
+#include "knobs.h"
+#include "flat_slab.h"
 #include "bvh_builder.h"
 #include "scene_cache.h"
 #include <cmath>
@@ -23,12 +25,12 @@ namespace {
 // builder settings of the world-space BVH; the environment overrides are measurement knobs (tools/flat_build_probe.sh).  SAH node cost 0.5:
 // a 4-wide node covers two levels of the binary tree in one fetch + one loop iteration, a leaf entry costs one of each per triangle.
 // Measured on synthetic-SM: node cost 1 -> 34.0 nodes + 8.45 triangles per ray, 0.5 -> 35.3 + 6.28 and +1 % rays/s; leaf size 2 / 4 / 8: no difference
-int flat_max_leaf() { static const int v = [] { const char* e = getenv("CTL_FLAT_MAX_LEAF"); const int x = e ? atoi(e) : 0; return x >= 1 && x <= 16 ? x : 4; }(); return v; }
+int flat_max_leaf() { static const int v = [] { const char* e = knob_env("CTL_FLAT_MAX_LEAF"); const int x = e ? atoi(e) : 0; return x >= 1 && x <= 16 ? x : 4; }(); return v; }
 // collapse of the binary tree into 4-wide nodes: 1 = SAH-optimal dynamic programme (bvh_builder.h), 0 = greedy; its node cost is in leaf-entry tests:
 // k_intersect spends ~277 lane-slots on a node step and ~365 on a leaf-entry step at its measured lane utilisation
-int flat_collapse_mode() { static const int v = [] { const char* e = getenv("CTL_FLAT_COLLAPSE"); return e ? atoi(e) : 0; }(); return v; }
-float flat_collapse_node_cost() { static const float v = [] { const char* e = getenv("CTL_FLAT_COLLAPSE_NODE_COST"); const float x = e ? (float)atof(e) : 0.0f; return x > 0.0f ? x : 0.75f; }(); return v; }
-float flat_node_cost() { static const float v = [] { const char* e = getenv("CTL_FLAT_NODE_COST"); const float x = e ? (float)atof(e) : 0.0f; return x > 0.0f ? x : 0.5f; }(); return v; }
+int flat_collapse_mode() { static const int v = [] { const char* e = knob_env("CTL_FLAT_COLLAPSE"); return e ? atoi(e) : 0; }(); return v; }
+float flat_collapse_node_cost() { static const float v = [] { const char* e = knob_env("CTL_FLAT_COLLAPSE_NODE_COST"); const float x = e ? (float)atof(e) : 0.0f; return x > 0.0f ? x : 0.75f; }(); return v; }
+float flat_node_cost() { static const float v = [] { const char* e = knob_env("CTL_FLAT_NODE_COST"); const float x = e ? (float)atof(e) : 0.0f; return x > 0.0f ? x : 0.5f; }(); return v; }
 
 // 4x4 inverse in double (cofactor expansion)
 bool inv4(const double m[16], double out[16]) {
@@ -64,6 +66,13 @@ bool woop_vertices(const ctl_woop_tri& w, double v[3][3]) {
     for (int k = 0; k < 3; k++) { v[2][k] = inv[k * 4 + 3]; v[0][k] = v[2][k] + inv[k * 4 + 0]; v[1][k] = v[2][k] + inv[k * 4 + 1]; }
     return true;
 }
+// world-space length that one unit of object-space round-off of this triangle can reach: its largest object-space coordinate times the
+// largest row sum of the instance's linear part
+double woop_slack(const double v[3][3], const float* M) {
+    double m = 0; for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) m = std::max(m, std::fabs(v[j][k]));
+    double rs = 0; for (int r = 0; r < 3; r++) rs = std::max(rs, std::fabs((double)M[r * 4]) + std::fabs((double)M[r * 4 + 1]) + std::fabs((double)M[r * 4 + 2]));
+    return m * rs;
+}
 // phase timing on stderr when CTL_VERBOSE is set
 struct phase_timer {
     const bool on = std::getenv("CTL_VERBOSE") != nullptr; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -85,7 +94,20 @@ bool flat_links_valid(const flat_scene& F) {
         if (c >= 0) return c % unit == 0 && (size_t)(c / unit) < n_nodes;
         return (size_t)(~c) < nl;
     };
-    if (F.format == kFlatQ4) { for (const auto& n : F.nodes) for (int c = 0; c < 4; c++) if (((n.mask >> c) & 1) && !ok(n.child[c], F.nodes.size(), 4)) return false; }
+    if (F.format == kFlatQ4) {
+        if (F.child_links.size() != F.nodes.size() * 4) return false;
+        for (size_t i = 0; i < F.nodes.size(); i++) {
+            const flat4_node& n = F.nodes[i];
+            int32_t imp[4]; if (F.compact_links) flat4_implied_links(n, imp);
+            for (int c = 0; c < 4; c++) {
+                const int32_t k = F.child_links[i * 4 + c];
+                if (((n.mask >> c) & 1) && !ok(k, F.nodes.size(), 4)) return false;
+                // the kernels follow the IMPLIED links (and the slab flag they carry) when the tree is compact: they must be the explicit ones
+                if (F.compact_links && ((n.mask >> c) & 1) && (imp[c] & ~(k >= 0 ? 1 : 0)) != k) return false;
+                if (!F.compact_links && n.child[c] != k) return false;
+            }
+        }
+    }
     else if (F.format == kFlatF4) { for (const auto& n : F.nodes_f4) for (int c = 0; c < 4; c++) if (!ok(n.child[c], F.nodes_f4.size(), 8)) return false; }
     else for (const auto& n : F.nodes_f2) if (!ok(n.child0, F.nodes_f2.size(), 4) || !ok(n.child1, F.nodes_f2.size(), 4)) return false;
     if (F.node_bytes() == 0) return false;
@@ -98,7 +120,7 @@ float round_up(double x) { float f = (float)x; return ((double)f < x) ? std::nex
 
 int default_flat_format() {
     static const int v = [] {
-        const char* e = std::getenv("CTL_FLAT_FORMAT");
+        const char* e = knob_env("CTL_FLAT_FORMAT");
         if (e && (!std::strcmp(e, "f4") || !std::strcmp(e, "F4"))) return (int)kFlatF4;
         if (e && (!std::strcmp(e, "f2") || !std::strcmp(e, "F2"))) return (int)kFlatF2;
         return (int)kFlatQ4;
@@ -133,20 +155,20 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node format only
     std::string key;
     if (!cache_dir().empty()) {
-        content_hash H; const uint32_t version = 10;
-        H.add_value(version); H.add_value(flat_collapse_mode()); H.add_value(flat_collapse_node_cost()); { const char* e = getenv("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
+        content_hash H; const uint32_t version = 11;
+        H.add_value(version); H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
         for (uint32_t k = 0; k < d.n_nodes; k++) { H.add_value(d.nodes[k].mesh_index); H.add(d.node_transforms[k].m, 64); }
         key = H.hex();
         cache_reader rd("flat", key);
-        int c_format = -1, c_depth = 0, c_compact = 0;
-        if (rd.found() && rd.value(c_format) && rd.value(c_depth) && rd.value(c_compact) && rd.vector(out.nodes) && rd.vector(out.nodes_f4) && rd.vector(out.nodes_f2) && rd.vector(out.leaves) && rd.verify() &&
-            c_format == out.format && flat_links_valid(out)) {
-            out.max_depth = c_depth; out.compact_links = c_compact != 0; pt.lap("cache hit");
+        int c_format = -1, c_depth = 0, c_compact = 0, c_root_slab = 0; uint64_t c_slab_nodes = 0;
+        if (rd.found() && rd.value(c_format) && rd.value(c_depth) && rd.value(c_compact) && rd.vector(out.nodes) && rd.vector(out.nodes_f4) && rd.vector(out.nodes_f2) && rd.vector(out.leaves) && rd.vector(out.child_links) && rd.value(c_root_slab) && rd.value(c_slab_nodes) && rd.verify() &&
+            c_format == out.format && ((out.compact_links = c_compact != 0), flat_links_valid(out))) {
+            out.max_depth = c_depth; out.root_slab = c_root_slab != 0; out.slab_nodes = (size_t)c_slab_nodes; pt.lap("cache hit");
             return true;
         }
-        out.nodes.clear(); out.nodes_f4.clear(); out.nodes_f2.clear(); out.leaves.clear();
+        out.nodes.clear(); out.nodes_f4.clear(); out.nodes_f2.clear(); out.leaves.clear(); out.child_links.clear(); out.compact_links = true;
     }
     struct wtri { uint32_t tri, node, woop; };
     // object-space vertices of every mesh's triangles once (degenerate ones can never be hit and are dropped), then per node in parallel
@@ -176,9 +198,12 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
                     }
                 }
                 // The kernel decides a hit with the fp32 object-space Woop test, whose accepted region differs from the exact triangle by
-                // round-off: pad the box by a few units in the last place of its largest coordinate (and of its extent).
+                // round-off: pad the box by a few units in the last place of its largest coordinate (and of its extent) — and of the triangle's
+                // OBJECT-space magnitude carried through the instance transform (a mesh far from its own origin, a strongly scaled instance: the round-off
+                // of the object-space test scales with those, not with the world box)
+                const float off = (float)woop_slack(l.v, M);
                 for (int r = 0; r < 3; r++) {
-                    const float mag = std::max(std::max(std::fabs(b.lo[r]), std::fabs(b.hi[r])), b.hi[r] - b.lo[r]);
+                    const float mag = std::max(std::max(std::max(std::fabs(b.lo[r]), std::fabs(b.hi[r])), b.hi[r] - b.lo[r]), off);
                     const float e = mag * 9.5367431640625e-7f + 1e-30f;   // 8 ulp
                     b.lo[r] -= e; b.hi[r] += e;
                 }
@@ -228,7 +253,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
             // The first 65 536 nodes (4 MiB, one XCD's L2) breadth-first — the top of the tree, which every ray walks, as one contiguous block — and depth-first
             // clusters below that frontier.  Measured on synthetic-SM against the all-depth-first order (2164 / 2159 Mrays/s): 4096 nodes 2183, 32 768: 2173,
             // 262 144: 2179, everything breadth-first 2176 (profiles/r02r_node_order_ab.log).  $CTL_FLAT_BFS_TOP overrides (measurement knob, part of the cache key)
-            static const size_t bfs_top = [] { const char* e = getenv("CTL_FLAT_BFS_TOP"); return e ? (size_t)atol(e) : (size_t)65536; }();
+            static const size_t bfs_top = [] { const char* e = knob_env("CTL_FLAT_BFS_TOP"); return e ? (size_t)atol(e) : (size_t)65536; }();
             std::vector<int> frontier; frontier.push_back(0);
             for (size_t head = 0; head < frontier.size() && order.size() < bfs_top; head++) {
                 const int me = frontier[head]; frontier[head] = -1;
@@ -315,11 +340,11 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
                 if (mask) *mask |= (uint8_t)(16u << c);
             }
             if (links) {
-                bool fits = leaf_base < (1u << 30);
+                bool fits = leaf_base < (1u << 26);
                 for (int c = 0; c < 4; c++) if (counts[c] > 4) fits = false;
                 if (!fits) return false;
                 links[0] = (inner_base << 6) | ((counts[0] ? counts[0] - 1 : 0) << 0) | ((counts[1] ? counts[1] - 1 : 0) << 2) | ((counts[2] ? counts[2] - 1 : 0) << 4);
-                links[1] = (leaf_base << 2) | (counts[3] ? counts[3] - 1 : 0);
+                links[1] = (leaf_base << 6) | (counts[3] ? counts[3] - 1 : 0);   // bits 2..5: slab flags of the inner children, set below
             }
             return true;
         };
@@ -349,9 +374,115 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     });
     pt.lap("leaf entries");
     out.max_depth = wdepth;
+    out.child_links.clear(); out.root_slab = false; out.slab_nodes = 0;
+    if (out.format == kFlatQ4) {
+        out.child_links.resize(out.nodes.size() * 4);
+        for (size_t i = 0; i < out.nodes.size(); i++) std::memcpy(&out.child_links[i * 4], out.nodes[i].child, 16);
+        if (out.compact_links) {
+            // oriented slabs of the nodes that have leaf children (flat_slab.h).  World-space vertices in double from the object-space ones.
+            auto world_tri = [&](uint32_t entry, double w[3][3], double& slack) {
+                const size_t g = R.leaf_prims[entry_src[entry]]; const wtri& t = tris[g];
+                const ltri& l = mesh_local[d.nodes[t.node].mesh_index][g - node_first[t.node]];
+                const float* M = d.node_transforms[t.node].m;
+                for (int j = 0; j < 3; j++) for (int r = 0; r < 3; r++) w[j][r] = (double)M[r * 4] * l.v[j][0] + (double)M[r * 4 + 1] * l.v[j][1] + (double)M[r * 4 + 2] * l.v[j][2] + (double)M[r * 4 + 3];
+                slack = woop_slack(l.v, M);
+            };
+            std::vector<uint8_t> has_slab(out.nodes.size(), 0);
+            static const double useful_below = [] { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); return e ? atof(e) : 0.6; }();   // builder knob (part of the cache key)
+            parallel_for(out.nodes.size(), [&](size_t i0, size_t i1) {
+                for (size_t i = i0; i < i1; i++) {
+                    flat4_node& f = out.nodes[i];
+                    const int32_t* ch = &out.child_links[i * 4];
+                    f.slab_n = 0; f.slab_base = 0.0f; f.slab_lo = 0; f.slab_hi = 0xffffffffu;
+                    if (useful_below <= 0.0 || (f.mask >> 4) == 0) continue;
+                    // triangles of the leaf children
+                    struct ctri { double w[3][3]; double slack; int c; };
+                    ctri T[16]; int nt = 0;
+                    uint32_t cnt[4] = { (f.links[0] & 3u) + 1u, ((f.links[0] >> 2) & 3u) + 1u, ((f.links[0] >> 4) & 3u) + 1u, (f.links[1] & 3u) + 1u };
+                    for (int c = 0; c < 4; c++) if ((f.mask >> (4 + c)) & 1) for (uint32_t e = 0; e < cnt[c]; e++) { T[nt].c = c; world_tri((uint32_t)~ch[c] + e, T[nt].w, T[nt].slack); nt++; }
+                    double stepk[3], ext1 = 0, mag = 0;
+                    for (int k = 0; k < 3; k++) { stepk[k] = std::ldexp(1.0, (int)f.e[k] - 127); ext1 += 255.0 * stepk[k]; mag = std::max(mag, std::fabs((double)f.origin[k]) + 255.0 * stepk[k]); }
+                    // box extents of the children (decoded codes) for the usefulness measure
+                    const uint32_t ql[3] = { f.qlo_x, f.qlo_y, f.qlo_z }, qh[3] = { f.qhi_x, f.qhi_y, f.qhi_z };
+                    int best_n[3] = { 0, 0, 0 }; double best_cost = 1e300; double best_lo[4], best_hi[4];
+                    for (int cand = 0; cand < nt; cand++) {
+                        const double (*w)[3] = T[cand].w;
+                        const double a[3] = { w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2] }, b[3] = { w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2] };
+                        const double n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+                        const double m = std::max(std::max(std::fabs(n[0]), std::fabs(n[1])), std::fabs(n[2]));
+                        if (!(m > 0) || !std::isfinite(m)) continue;
+                        int nq[3]; for (int k = 0; k < 3; k++) nq[k] = (int)std::lround(n[k] / m * (double)kSlabNMax);
+                        bool dup = false; if (nq[0] == best_n[0] && nq[1] == best_n[1] && nq[2] == best_n[2]) dup = true;
+                        if (dup) continue;
+                        double lo[4] = { 1e300, 1e300, 1e300, 1e300 }, hi[4] = { -1e300, -1e300, -1e300, -1e300 };
+                        for (int t = 0; t < nt; t++) for (int j = 0; j < 3; j++) {
+                            const double D = nq[0] * (T[t].w[j][0] - (double)f.origin[0]) + nq[1] * (T[t].w[j][1] - (double)f.origin[1]) + nq[2] * (T[t].w[j][2] - (double)f.origin[2]);
+                            lo[T[t].c] = std::min(lo[T[t].c], D); hi[T[t].c] = std::max(hi[T[t].c], D);
+                        }
+                        double cost = 0; int nl = 0;
+                        for (int c = 0; c < 4; c++) if ((f.mask >> (4 + c)) & 1) {
+                            double range = 0; for (int k = 0; k < 3; k++) range += std::fabs((double)nq[k]) * stepk[k] * (double)((int)((qh[k] >> (8 * c)) & 255u) - (int)((ql[k] >> (8 * c)) & 255u));
+                            cost += range > 0 ? std::min(1.0, (hi[c] - lo[c]) / range) : 1.0; nl++;
+                        }
+                        cost /= nl;
+                        if (cost < best_cost) { best_cost = cost; for (int k = 0; k < 3; k++) best_n[k] = nq[k]; for (int c = 0; c < 4; c++) { best_lo[c] = lo[c]; best_hi[c] = hi[c]; } }
+                    }
+                    if (!(best_cost < useful_below)) continue;
+                    // static pad per child: round-off reach of the object-space test (2^-20 of the magnitudes involved) + the node-extent share of the kernel's evaluation error
+                    const double n1 = std::fabs((double)best_n[0]) + std::fabs((double)best_n[1]) + std::fabs((double)best_n[2]);
+                    double pad[4] = { 0, 0, 0, 0 };
+                    for (int t = 0; t < nt; t++) pad[T[t].c] = std::max(pad[T[t].c], n1 * 9.5367431640625e-7 * (T[t].slack + mag) + (double)kSlabRayPad * ext1);   // 2^-20 of the magnitudes: ~8 x the fp32 round-off of the object-space test
+                    // D range the codes span: the leaf children's padded intervals — and, when the node has inner children too, the whole node (its
+                    // quantisation grid's box), which their code 0 .. 255 must cover
+                    double nlo = 1e300, nhi = -1e300;
+                    for (int c = 0; c < 4; c++) if ((f.mask >> (4 + c)) & 1) { nlo = std::min(nlo, best_lo[c] - pad[c]); nhi = std::max(nhi, best_hi[c] + pad[c]); }
+                    if ((f.mask & 15u) != (uint32_t)(f.mask >> 4)) {
+                        double pmax = 0; for (int c = 0; c < 4; c++) pmax = std::max(pmax, pad[c]);
+                        double blo = 0, bhi = 0; for (int k = 0; k < 3; k++) { const double x = best_n[k] * 255.0 * stepk[k]; if (x < 0) blo += x; else bhi += x; }
+                        nlo = std::min(nlo, blo - pmax); nhi = std::max(nhi, bhi + pmax);
+                    }
+                    const float base = round_down(nlo);
+                    // step: a float with 5 mantissa bits (the top 14 bits of its pattern share a word with the normal), rounded up; 254 steps span the range
+                    float stepf = round_up((nhi - (double)base) / 254.0);
+                    if (!(stepf > 0.0f) || !std::isfinite(stepf)) stepf = 1.17549435e-38f;
+                    { uint32_t bits; std::memcpy(&bits, &stepf, 4); bits = (bits + 0x3ffffu) & 0xfffc0000u; std::memcpy(&stepf, &bits, 4); }
+                    if (!std::isfinite(stepf) || stepf < 1.17549435e-38f) continue;
+                    const double step = (double)stepf;
+                    uint32_t lo_w = 0, hi_w = 0; bool ok = true;
+                    for (int c = 0; c < 4; c++) {
+                        long lo, hi;
+                        if (!((f.mask >> c) & 1)) { lo = 255; hi = 0; }
+                        else if (!((f.mask >> (4 + c)) & 1)) { lo = 0; hi = 255; }
+                        else {
+                            lo = (long)std::floor((best_lo[c] - pad[c] - (double)base) / step);
+                            hi = (long)std::ceil((best_hi[c] + pad[c] - (double)base) / step);
+                            // conservative under the fp32 evaluation base + step * code as well
+                            while (lo > 0 && (double)(float)((double)base + step * (double)lo) > best_lo[c] - pad[c]) lo--;
+                            while (hi < 255 && (double)(float)((double)base + step * (double)hi) < best_hi[c] + pad[c]) hi++;
+                            if (lo < 0 || hi > 255 || (double)base + step * (double)lo > best_lo[c] - pad[c] || (double)base + step * (double)hi < best_hi[c] + pad[c]) ok = false;
+                        }
+                        lo_w |= (uint32_t)(lo & 255) << (8 * c); hi_w |= (uint32_t)(hi & 255) << (8 * c);
+                    }
+                    if (!ok || (double)base + 255.0 * step < nhi) continue;
+                    { uint32_t sb; std::memcpy(&sb, &stepf, 4);
+                      f.slab_n = ((uint32_t)best_n[0] & 63u) | (((uint32_t)best_n[1] & 63u) << 6) | (((uint32_t)best_n[2] & 63u) << 12) | sb; }
+                    f.slab_base = base; f.slab_lo = lo_w; f.slab_hi = hi_w;
+                    has_slab[i] = 1;
+                }
+            });
+            for (size_t i = 0; i < out.nodes.size(); i++) {
+                out.slab_nodes += has_slab[i];
+                uint32_t flags = 0;
+                for (int c = 0; c < 4; c++) { const int32_t k = out.child_links[i * 4 + c]; if (k >= 0 && k != 0x76543210 && has_slab[(size_t)k / 4]) flags |= 1u << c; }
+                out.nodes[i].links[1] |= flags << 2;
+            }
+            out.root_slab = has_slab[0] != 0;
+            pt.lap("slabs");
+        }
+    }
     if (!key.empty()) {
         cache_writer wr("flat", key);
-        if (wr.active()) { wr.value(out.format); wr.value(out.max_depth); { const int cl = out.compact_links ? 1 : 0; wr.value(cl); } wr.vector(out.nodes); wr.vector(out.nodes_f4); wr.vector(out.nodes_f2); wr.vector(out.leaves); wr.commit(); pt.lap("cache write"); }
+        if (wr.active()) { wr.value(out.format); wr.value(out.max_depth); { const int cl = out.compact_links ? 1 : 0; wr.value(cl); } wr.vector(out.nodes); wr.vector(out.nodes_f4); wr.vector(out.nodes_f2); wr.vector(out.leaves); wr.vector(out.child_links); { const int rs = out.root_slab ? 1 : 0; wr.value(rs); const uint64_t sn = out.slab_nodes; wr.value(sn); } wr.commit(); pt.lap("cache write"); }
     }
     return true;
 }

@@ -34,16 +34,33 @@ enum flat_format : int {
 //   inner child c  = node  (links[0] >> 6) + popcount(inner children in slots < c)
 //   leaf child c   = entry (links[1] >> 2) + sum over leaf children in slots < c of their entry counts
 // with the per-slot entry count - 1 in two bits each: slots 0..2 in links[0] bits 0..5, slot 3 in links[1] bits 0..1 (a leaf has at most
-// four entries; 2^26 nodes, 2^30 entries).  child[] repeats the links explicitly (host code, the test oracle).
+// four entries; 2^26 nodes, 2^26 entries).  links[1] bits 2..5: inner child c of this node carries an ORIENTED SLAB (flat_slab.h) in its
+// last 16 B; the traversal hands that bit down in the child link (bit 0 of an inner link), so a lane knows BEFORE it fetches a node whether to
+// load 48 or 64 B.  The last 16 B are that slab when the tree has implied links, else the explicit links child[4] (the kernels then read them
+// and no node has a slab); host code and the test oracle find the explicit links of every tree in flat_scene::child_links.
 struct flat4_node {
     float origin[3];
     uint8_t e[3];          // biased float exponents of the per-axis quantisation step
     uint8_t mask;          // bit c set <=> child c exists; bit 4 + c set <=> child c is a leaf.  A missing child also has an INVERTED box (lo = 255, hi = 0), so the kernel's slab test alone rejects it
     uint32_t qlo_x, qhi_x, qlo_y, qhi_y, qlo_z, qhi_z;   // byte c = child c
     uint32_t links[2];
-    int32_t child[4];      // >= 0: node index * 4 (float4 units); < 0: ~firstLeafEntry; 0x76543210: none
+    union {
+        int32_t child[4];  // explicit links (trees without implied links): >= 0: node index * 4 (float4 units); < 0: ~firstLeafEntry; 0x76543210: none
+        struct { uint32_t slab_n; float slab_base; uint32_t slab_lo, slab_hi; };   // flat_slab.h: normal (3 x int8) + step exponent, D of code 0, per-child interval codes (byte c = child c)
+    };
 };
 static_assert(sizeof(flat4_node) == 64, "quantised wide node is one 64-B fetch group");
+// the links a traversal step derives from the layout (what node_step_q4 computes): inner child = node index * 4 | slab flag, leaf child = ~first entry
+inline void flat4_implied_links(const flat4_node& n, int32_t c[4]) {
+    const uint32_t w0 = n.links[0], w1 = n.links[1], leafm = n.mask >> 4, innerm = n.mask & ~leafm & 15u, sflags = (w1 >> 2) & 15u;
+    const uint32_t inner_base = w0 >> 6, leaf_base = w1 >> 6;
+    const uint32_t cnt[4] = { (w0 & 3u) + 1u, ((w0 >> 2) & 3u) + 1u, ((w0 >> 4) & 3u) + 1u, (w1 & 3u) + 1u };
+    uint32_t ni = 0, nl = 0;
+    for (int k = 0; k < 4; k++) {
+        if ((leafm >> k) & 1u) { c[k] = ~(int32_t)(leaf_base + nl); nl += cnt[k]; }
+        else { c[k] = (int32_t)(((inner_base + ni) << 2) | ((sflags >> k) & 1u)); if ((innerm >> k) & 1u) ni++; }
+    }
+}
 
 // F4.  Plane-major so that a lane picks the near / far plane of all four children by ADDRESS (the sign of its ray direction
 // selects lo or hi), not by four selects per axis: lo_x[4] hi_x[4] lo_y[4] hi_y[4] lo_z[4] hi_z[4] child[4] pad[4].
@@ -63,6 +80,9 @@ struct flat_scene {
     std::vector<flat_leaf> leaves;
     int max_depth = 0;                    // of the stored tree
     bool compact_links = true;            // Q4: every node's implied links (flat4_node::links) are valid; false -> the kernels read child[]
+    std::vector<int32_t> child_links;     // Q4: 4 explicit links per node (as flat4_node::child), host side only
+    bool root_slab = false;               // Q4: the root node itself carries a slab (single-node trees)
+    size_t slab_nodes = 0;                // Q4: nodes that carry a slab
     size_t node_bytes() const { return nodes.size() * sizeof(flat4_node) + nodes_f4.size() * sizeof(flat4f_node) + nodes_f2.size() * sizeof(ctl_bvh_node); }
     int stack_need() const { return format == kFlatF2 ? max_depth + 2 : 3 * max_depth + 2; }   // traversal-stack entries a ray can need
 };

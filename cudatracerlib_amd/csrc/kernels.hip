@@ -5,6 +5,7 @@
 #include "kernels.h"
 #include "traverse.h"
 #include "traverse_flat.h"
+#include "knobs.h"
 #include "shading.h"
 #include "compaction.h"
 #include <cstdlib>
@@ -62,7 +63,7 @@ template <bool ANY_HIT, bool COUNT, int LAYOUT, bool ALPHA>   // LAYOUT: 0 two-l
 __global__ __launch_bounds__(kBlock, CTL_INTERSECT_MIN_WAVES) CTL_INTERSECT_WAVES_ATTR void k_intersect(dev_scene S, const float4* __restrict__ ro, const float4* __restrict__ rd, const uint32_t* __restrict__ n_ptr,
                                                        uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ,
                                                        unsigned long long* __restrict__ counts3) {
-    __shared__ int lds_stack[(LAYOUT ? kFlatLdsRows + 1 : kLdsStack) * kBlock];   // flat: + one spare row that absorbs unused push slots
+    __shared__ int lds_stack[(LAYOUT ? (kFlatLdsRows + 1) * kFlatStackInts : kLdsStack) * kBlock];   // flat: + one spare row that absorbs unused push slots
     const uint32_t n = *n_ptr;
     trav_counts tc{ 0, 0, 0, 0, 0 };
     if (LAYOUT) intersect_flat<ANY_HIT, COUNT, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(kBlock, CTL_INTERSECT_MIN_WAVES) CTL_INTERSECT_WAVE
                                                             uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node,
                                                             const float4* __restrict__ sro, const float4* __restrict__ srd, const uint32_t* __restrict__ sn_ptr,
                                                             uint32_t* __restrict__ swork, uint32_t* __restrict__ occ) {
-    __shared__ int lds_stack[(LAYOUT ? kFlatLdsRows + 1 : kLdsStack) * kBlock];
+    __shared__ int lds_stack[(LAYOUT ? (kFlatLdsRows + 1) * kFlatStackInts : kLdsStack) * kBlock];
     const uint32_t n = *n_ptr, sn = *sn_ptr;
     trav_counts tc{ 0, 0, 0, 0, 0 };
     if (LAYOUT) {
@@ -181,13 +182,15 @@ __global__ __launch_bounds__(kBlock) void k_apply_pipeline(const ctl_pixel_data*
     }
 }
 
+static unsigned g_lds_pad = 0;   // extra dynamic LDS per traversal workgroup: holds the kernels to fewer resident workgroups per CU (occupancy experiment)
 void apply_tuning_from_env() {
     static bool done = false;
     if (done) return;
     done = true;
-    if (const char* e = getenv("CTL_REFILL_IDLE")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refill_idle), &v, sizeof(v)); }
-    if (const char* e = getenv("CTL_CHUNK_GUIDED")) { int v = atoi(e) != 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chunk_guided), &v, sizeof(v)); }
-    if (const char* e = getenv("CTL_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_leaf_batch), &v, sizeof(v)); }
+    if (const char* e = knob_env("CTL_LDS_PAD")) { int v = atoi(e); if (v >= 0 && v <= 140000) g_lds_pad = (unsigned)v; }
+    if (const char* e = knob_env("CTL_REFILL_IDLE")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refill_idle), &v, sizeof(v)); }
+    if (const char* e = knob_env("CTL_CHUNK_GUIDED")) { int v = atoi(e) != 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chunk_guided), &v, sizeof(v)); }
+    if (const char* e = knob_env("CTL_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_leaf_batch), &v, sizeof(v)); }
 }
 
 // ------------------------------------------------------------------------------------------------ launch wrappers
@@ -196,8 +199,8 @@ void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& 
 }
 #define CTL_LAUNCH_INTERSECT_L(ANY, CNT, L, ...)                                                                                     \
     do {                                                                                                                             \
-        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect<ANY, CNT, L, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((k_intersect<ANY, CNT, L, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, __VA_ARGS__);     \
+        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect<ANY, CNT, L, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((k_intersect<ANY, CNT, L, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, __VA_ARGS__);     \
     } while (0)
 // The product traverses Q4 nodes.  The F4 / F2 node formats are measured experiments (0.69x and 0.66x of Q4's rays/s); their kernels are
 // compiled only with -DCTL_FLAT_EXPERIMENTS, and a scene asking for them is refused otherwise (tracer.hip).
@@ -225,11 +228,11 @@ void launch_intersect_any(const launch_ctx& lc, const dev_scene& S, const float4
 void launch_intersect_pair(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node,
                            const float4* sro, const float4* srd, const uint32_t* sn_ptr, uint32_t* swork, uint32_t* occ) {
     if (!S.flat_nodes) {
-        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<0, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
-        else hipLaunchKernelGGL((k_intersect_pair<0, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<0, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        else hipLaunchKernelGGL((k_intersect_pair<0, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
     } else {
-        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<1, true>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
-        else hipLaunchKernelGGL((k_intersect_pair<1, false>), dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<1, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        else hipLaunchKernelGGL((k_intersect_pair<1, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
     }
 }
 void launch_intersect_count(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node,

@@ -290,8 +290,8 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
             // every node transform affine with w == 1 exactly (what add_node produces): the kernels skip the load of w and the division by it
             S.inst_w_one = 1; for (uint32_t k = 0; k < d.n_nodes; k++) if (d.node_inv_transforms[k].m[15] != 1.0f) S.inst_w_one = 0;
             CTL_HIP(hipDeviceSynchronize());
-            S.flat_nodes = flat_nodes_.p; S.flat_leaves = flat_leaves_.p; S.flat_root = 0; S.flat_format = F.format; S.flat_compact = (F.format == kFlatQ4 && F.compact_links) ? 1 : 0;
-            if (const char* e = getenv("CTL_FLAT_COMPACT")) { if (atoi(e) == 0) S.flat_compact = 0; }   // measurement knob
+            S.flat_nodes = flat_nodes_.p; S.flat_leaves = flat_leaves_.p; S.flat_format = F.format; S.flat_compact = (F.format == kFlatQ4 && F.compact_links) ? 1 : 0;
+            S.flat_root = (S.flat_compact && F.root_slab) ? 1 : 0;   // bit 0 of an inner link: the node carries an oriented slab (flat_slab.h)
         }
     }
     CTL_HIP(hipDeviceSynchronize());

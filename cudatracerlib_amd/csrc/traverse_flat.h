@@ -6,8 +6,9 @@
 // both look at the winning triangle; the world-space tree only culls.  Rays that hit two triangles at exactly the same t may
 // report either (the visiting order differs), as between any two BVHs.
 //
-// Execution model (measured on MI355X, profiles/r02*): the kernel is bound by VALU issue, not by HBM — so the design minimises
-// instructions per useful lane:
+// Execution model (measured on MI355X, profiles/r02*, r03*): the kernel is bound by the NUMBER of records it gathers — per-lane L1 accesses (one
+// 16-B load of one lane = one L1 cycle: ~610 G lane-loads/s over the chip, tools/gather_probe.hip) and 128-B lines out of HBM (~58 G/s) — with
+// 15-20 % of its VALU issue slots unused (profiles/r02r_valu_headroom_ab.log).  So the design spends a little arithmetic to fetch less:
 //  * lane refill as in traverse.h (a wave claims rays from a device cursor, idle lanes are refilled together);
 //  * node steps and leaf steps are separate wave-wide phases.  A lane that reaches a leaf POSTPONES it (one pending leaf per
 //    lane) and keeps descending the tree speculatively; the wave runs the leaf code only once enough lanes hold a pending leaf
@@ -17,19 +18,48 @@
 //  * F4 nodes are plane-major: the sign of the ray direction picks the near / far plane of all four children by address.
 #pragma once
 #include "traverse.h"
+#include "flat_slab.h"
 
 namespace ctl {
 
 enum { kFmtQ4 = 0, kFmtF4 = 1, kFmtF2 = 2 };   // = flat_format (flatten.h)
 
-constexpr int kFlatLdsRows = 19;          // stack entries per lane in LDS; + 1 spare row = 20 KiB per 256-thread workgroup -> 8 workgroups per CU
+#ifndef CTL_FLAT_LDS_ROWS
+#define CTL_FLAT_LDS_ROWS 19
+#endif
+constexpr int kFlatLdsRows = CTL_FLAT_LDS_ROWS;   // stack entries per lane in LDS (+ 1 spare row); deeper entries live in scratch
 __device__ int g_leaf_batch = 24;         // run the leaf phase once this many lanes hold a pending leaf entry (CTL_LEAF_BATCH)
 
+// Stack entry = {link, entry distance of the pushed child}: a pop whose entry distance is not below the current hit distance is dropped on the spot
+// (the closest hit moved in front of that child while it waited) — counted by the oracle on the bench scene: 10 % of the node visits, 5 % of the entry tests.
+// 8 B per entry: 40 KiB of LDS per 256-lane workgroup, four workgroups per CU (the kernel runs as fast at 4 waves per SIMD as at 6).
+#ifndef CTL_STACK_DIST
+#define CTL_STACK_DIST 0
+#endif
+#if CTL_STACK_DIST
+typedef unsigned long long flat_stack_word;   // link in the low word, distance bits in the high word (a scalar type: it can live behind an address-space-qualified pointer)
+__device__ __forceinline__ flat_stack_word stack_word(int link, float dist) { return (unsigned long long)(uint32_t)link | ((unsigned long long)__float_as_uint(dist) << 32); }
+__device__ __forceinline__ bool stack_word_culled(const flat_stack_word& w, float ht) { return __uint_as_float((uint32_t)(w >> 32)) >= ht; }
+__device__ __forceinline__ int stack_word_link(const flat_stack_word& w) { return (int)(uint32_t)w; }
+#else
+typedef int flat_stack_word;
+__device__ __forceinline__ flat_stack_word stack_word(int link, float) { return link; }
+__device__ __forceinline__ bool stack_word_culled(const flat_stack_word&, float) { return false; }
+__device__ __forceinline__ int stack_word_link(const flat_stack_word& w) { return w; }
+#endif
+constexpr int kFlatStackInts = (int)(sizeof(flat_stack_word) / sizeof(int));   // ints of LDS per stack entry
+typedef __attribute__((address_space(3))) flat_stack_word flat_stack_lds_word;   // explicitly LDS: the pushes must compile to ds_write, not to generic flat stores
 struct flat_stack {
-    int* lds;                             // this lane's column, stride 256
-    int ovf[kStackSize - kFlatLdsRows];
-    __device__ __forceinline__ int get(int i) const { return i < kFlatLdsRows ? lds[i * 256] : ovf[i - kFlatLdsRows]; }
-    __device__ __forceinline__ void set(int i, int v) { if (i < kFlatLdsRows) lds[i * 256] = v; else ovf[i - kFlatLdsRows] = v; }
+    flat_stack_lds_word* lds;             // this lane's column, stride 256
+    flat_stack_word ovf[kStackSize - kFlatLdsRows];
+    __device__ __forceinline__ flat_stack_word get(int i) const {
+        flat_stack_word w = lds[(i < kFlatLdsRows ? i : kFlatLdsRows) * 256];   // a ds_read whatever the depth (the spare row when the entry lives in scratch) ...
+        if (i >= kFlatLdsRows) w = ovf[i - kFlatLdsRows];                       // ... and the rare deep entry from scratch
+        return w;
+    }
+    __device__ __forceinline__ void set(int i, flat_stack_word v) { if (i < kFlatLdsRows) lds[i * 256] = v; else ovf[i - kFlatLdsRows] = v; }
+    // pop entries until one is worth visiting (the sentinel at the bottom carries -inf and always is)
+    __device__ __forceinline__ int pop(int& sp, float ht) const { flat_stack_word w; do { w = get(sp); sp--; } while (stack_word_culled(w, ht)); return stack_word_link(w); }
 };
 
 __device__ __forceinline__ float rcp_cull(float d) {   // slab tests only cull: the hardware reciprocal (1 ulp) of the guarded direction
@@ -92,14 +122,13 @@ struct ray_cull { float idx, idy, idz, oox, ooy, ooz; int sx, sy, sz; };   // sx
                                const int tc_ = s_ ? c[j] : c[i]; c[j] = s_ ? c[i] : c[j]; c[i] = tc_; }
 
 // F4: 128-B plane-major node (flat4f_node)
-__device__ __forceinline__ int node_step_f4(const float4* __restrict__ nodes, int node, const ray_cull& R, float tmin, float ht, int c[4]) {
+__device__ __forceinline__ int node_step_f4(const float4* __restrict__ nodes, int node, const ray_cull& R, float tmin, float ht, int c[4], float dd[4]) {
     const float4* __restrict__ p = nodes + node;
     const float4 nx = p[R.sx], fx = p[1 - R.sx], ny = p[2 + R.sy], fy = p[3 - R.sy], nz = p[4 + R.sz], fz = p[5 - R.sz];
     const float4 lk = p[6];
     const float nxa[4] = { nx.x, nx.y, nx.z, nx.w }, fxa[4] = { fx.x, fx.y, fx.z, fx.w }, nya[4] = { ny.x, ny.y, ny.z, ny.w }, fya[4] = { fy.x, fy.y, fy.z, fy.w };
     const float nza[4] = { nz.x, nz.y, nz.z, nz.w }, fza[4] = { fz.x, fz.y, fz.z, fz.w };
     c[0] = __float_as_int(lk.x); c[1] = __float_as_int(lk.y); c[2] = __float_as_int(lk.z); c[3] = __float_as_int(lk.w);
-    float dd[4];
     const float inf = __builtin_huge_valf();
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -115,22 +144,32 @@ __device__ __forceinline__ int node_step_f4(const float4* __restrict__ nodes, in
 }
 
 // Q4: 64-B node with 8-bit child boxes (flat4_node).  compact: the child links are implied by the layout and only the first 48 B are
-// loaded — three per-lane L1 accesses instead of four.
-__device__ __forceinline__ int node_step_q4(const float4* __restrict__ nodes, int node, const ray_cull& R, float tmin, float ht, int c[4], bool compact) {
-    const float4* __restrict__ p = nodes + node;
+// loaded — three per-lane L1 accesses instead of four — unless the link that led here says the node carries an oriented slab (bit 0; flat_slab.h):
+// then the last 16 B are loaded too and every child's entry / exit distance is clipped by its interval along the node's slab direction.
+__device__ __forceinline__ int node_step_q4(const float4* __restrict__ nodes, int node, const ray_cull& R, float ox, float oy, float oz, float dx, float dy, float dz,
+                                            float tmin, float ht, int c[4], float dd[4], bool compact) {
+    const float4* __restrict__ p = nodes + (node & ~3);
     const float4 q0 = p[0], q1 = p[1], q2 = p[2];
     const uint32_t meta = __float_as_uint(q0.w);
+    const float inf = __builtin_huge_valf();
+    float s_alpha = 0.0f, s_bn = -inf, s_bf = inf; uint32_t s_nw = 0u, s_fw = 0u;   // no slab: [-inf, inf] for every child
     if (compact) {
         const uint32_t w0 = __float_as_uint(q2.z), w1 = __float_as_uint(q2.w);
         const uint32_t leafm = meta >> 28, innerm = (meta >> 24) & ~leafm & 15u;
-        const uint32_t inner_base = w0 >> 6, leaf_base = w1 >> 2;
+        const uint32_t inner_base = w0 >> 6, leaf_base = w1 >> 6, sflags = w1 >> 2;
         // entries of the leaf children in slots 0..2 (0 for an inner child), prefix sums = first entry of each leaf child
         const uint32_t n0 = (leafm & 1u) ? (w0 & 3u) + 1u : 0u, n1 = (leafm & 2u) ? ((w0 >> 2) & 3u) + 1u : 0u, n2 = (leafm & 4u) ? ((w0 >> 4) & 3u) + 1u : 0u;
         const uint32_t i1 = innerm & 1u, i2 = i1 + ((innerm >> 1) & 1u), i3 = i2 + ((innerm >> 2) & 1u);
-        c[0] = (leafm & 1u) ? ~(int)leaf_base : (int)(inner_base << 2);
-        c[1] = (leafm & 2u) ? ~(int)(leaf_base + n0) : (int)((inner_base + i1) << 2);
-        c[2] = (leafm & 4u) ? ~(int)(leaf_base + n0 + n1) : (int)((inner_base + i2) << 2);
-        c[3] = (leafm & 8u) ? ~(int)(leaf_base + n0 + n1 + n2) : (int)((inner_base + i3) << 2);
+        c[0] = (leafm & 1u) ? ~(int)leaf_base : (int)((inner_base << 2) | (sflags & 1u));
+        c[1] = (leafm & 2u) ? ~(int)(leaf_base + n0) : (int)(((inner_base + i1) << 2) | ((sflags >> 1) & 1u));
+        c[2] = (leafm & 4u) ? ~(int)(leaf_base + n0 + n1) : (int)(((inner_base + i2) << 2) | ((sflags >> 2) & 1u));
+        c[3] = (leafm & 8u) ? ~(int)(leaf_base + n0 + n1 + n2) : (int)(((inner_base + i3) << 2) | ((sflags >> 3) & 1u));
+        if (node & 1) {
+            const float4 q3 = p[3];
+            slab_ray SR;
+            slab_setup(__float_as_uint(q3.x), q3.y, __float_as_uint(q3.z), __float_as_uint(q3.w), q0.x, q0.y, q0.z, ox, oy, oz, dx, dy, dz, SR);
+            s_alpha = SR.alpha; s_bn = SR.beta_n; s_bf = SR.beta_f; s_nw = SR.near_w; s_fw = SR.far_w;
+        }
     } else {
         const float4 q3 = p[3];
         c[0] = __float_as_int(q3.x); c[1] = __float_as_int(q3.y); c[2] = __float_as_int(q3.z); c[3] = __float_as_int(q3.w);
@@ -139,16 +178,15 @@ __device__ __forceinline__ int node_step_q4(const float4* __restrict__ nodes, in
     const float bx = __builtin_fmaf(q0.x, R.idx, -R.oox), by = __builtin_fmaf(q0.y, R.idy, -R.ooy), bz = __builtin_fmaf(q0.z, R.idz, -R.ooz);
     const uint32_t lx = __float_as_uint(q1.x), hx = __float_as_uint(q1.y), ly = __float_as_uint(q1.z), hy = __float_as_uint(q1.w), lz = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
     const uint32_t nx = R.sx ? hx : lx, fx = R.sx ? lx : hx, ny = R.sy ? hy : ly, fy = R.sy ? ly : hy, nz = R.sz ? hz : lz, fz = R.sz ? lz : hz;
-    float dd[4];
-    const float inf = __builtin_huge_valf();
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const float tnx = __builtin_fmaf((float)((nx >> (8 * k)) & 0xffu), ax, bx), tfx = __builtin_fmaf((float)((fx >> (8 * k)) & 0xffu), ax, bx);
         const float tny = __builtin_fmaf((float)((ny >> (8 * k)) & 0xffu), ay, by), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 0xffu), ay, by);
         const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 0xffu), az, bz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 0xffu), az, bz);
+        const float tns = __builtin_fmaf((float)((s_nw >> (8 * k)) & 0xffu), s_alpha, s_bn), tfs = __builtin_fmaf((float)((s_fw >> (8 * k)) & 0xffu), s_alpha, s_bf);
         // v_max3 / v_min3 written out: fmaxf on a value loaded from memory (tmin, ht) makes the compiler canonicalise it first, once per node step and operand
-        const float cmin = max_raw(max3_raw(tnx, tny, tnz), tmin);
-        const float cmax = min_raw(min3_raw(tfx, tfy, tfz), ht);
+        const float cmin = max3_raw(max3_raw(tnx, tny, tnz), tns, tmin);
+        const float cmax = min3_raw(min3_raw(tfx, tfy, tfz), tfs, ht);
         dd[k] = (cmax >= cmin) ? cmin : inf;   // no "child exists" test: a missing child's box is inverted (flatten.cpp) and is never entered
     }
     CTL_CSWAP_PAIR(0, 1) CTL_CSWAP_PAIR(2, 3) CTL_CSWAP_PAIR(0, 2) CTL_CSWAP_PAIR(1, 3) CTL_CSWAP_PAIR(1, 2)
@@ -156,7 +194,7 @@ __device__ __forceinline__ int node_step_q4(const float4* __restrict__ nodes, in
 }
 
 // F2: the reference's BVHNodeData (two fp32 child boxes, 64 B)
-__device__ __forceinline__ int node_step_f2(const float4* __restrict__ nodes, int node, const ray_cull& R, float tmin, float ht, int c[4]) {
+__device__ __forceinline__ int node_step_f2(const float4* __restrict__ nodes, int node, const ray_cull& R, float tmin, float ht, int c[4], float dd[4]) {
     const float4* __restrict__ p = nodes + node;
     const float4 n0 = p[0], n1 = p[1], nz = p[2], cn = p[3];
     float c0min, c0max, c1min, c1max;
@@ -165,6 +203,7 @@ __device__ __forceinline__ int node_step_f2(const float4* __restrict__ nodes, in
     const int k0 = __float_as_int(cn.x), k1 = __float_as_int(cn.y);
     const bool swap = t1 && (!t0 || c1min < c0min);   // child 1 first
     c[0] = swap ? k1 : k0; c[1] = swap ? k0 : k1;
+    dd[0] = swap ? c1min : c0min; dd[1] = swap ? c0min : c1min;
     return (t0 ? 1 : 0) + (t1 ? 1 : 0);
 }
 #undef CTL_CSWAP_PAIR
@@ -172,7 +211,8 @@ __device__ __forceinline__ int node_step_f2(const float4* __restrict__ nodes, in
 // The whole intersect kernel body over the flattened structure: `n` rays (ro, rd) -> hit / hit_node (closest) and/or occ (any-hit flag).
 template <bool ANY_HIT, bool COUNT, bool ALPHA, int FMT>
 __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4* __restrict__ ro, const float4* __restrict__ rd, uint32_t n, uint32_t* __restrict__ work,
-                                               float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack, trav_counts& cnt) {
+                                               float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack_ints, trav_counts& cnt) {
+    flat_stack_lds_word* lds_stack = (flat_stack_lds_word*)lds_stack_ints;
     const int lane = threadIdx.x & 63;
     const int refill_idle = g_refill_idle, leaf_batch = g_leaf_batch;
     const bool compact = S.flat_compact != 0;
@@ -210,7 +250,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
                     R.oox = ox * R.idx; R.ooy = oy * R.idy; R.ooz = oz * R.idz;
                     R.sx = R.idx < 0.0f ? 1 : 0; R.sy = R.idy < 0.0f ? 1 : 0; R.sz = R.idz < 0.0f ? 1 : 0;
                     ht = d.w; hu = hv = 0.0f; htri = -1; hnode = -1;
-                    sp = 0; st.lds[0] = kSentinel; node = S.flat_root; pend = -1;
+                    sp = 0; st.lds[0] = stack_word(kSentinel, -__builtin_huge_valf()); node = S.flat_root; pend = -1;
                 }
                 chunk_next += want < avail ? want : avail;
             }
@@ -218,7 +258,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
         if (__ballot(has_ray) == 0ull) { if (exhausted) break; continue; }
 
         // ---- a lane standing on a leaf with a free slot postpones it and goes on with the next stack entry
-        if (has_ray && node < 0 && pend < 0) { pend = ~node; node = st.get(sp); sp--; }
+        if (has_ray && node < 0 && pend < 0) { pend = ~node; node = st.pop(sp, ht); }
         const bool at_inner = has_ray && (unsigned)node < (unsigned)kSentinel;
         const bool at_leaf = has_ray && pend >= 0;
         const unsigned long long m_inner = __ballot(at_inner), m_leaf = __ballot(at_leaf);
@@ -235,25 +275,26 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
             // ---- node phase
             if (at_inner) {
                 if (COUNT) { cnt.n_inner++; if (lane == (int)__builtin_ctzll(m_inner)) cnt.w_inner++; }
-                const int popped = st.get(sp);   // issued early: used when no child is entered
-                int c[4]; int n_hit;
-                if (FMT == kFmtF4) n_hit = node_step_f4(nodes, node, R, tmin, ht, c);
-                else if (FMT == kFmtQ4) n_hit = node_step_q4(nodes, node, R, tmin, ht, c, compact);
-                else n_hit = node_step_f2(nodes, node, R, tmin, ht, c);
-                node = n_hit ? c[0] : popped;
+                const flat_stack_word popped = st.get(sp);   // issued early: used when no child is entered
+                int c[4]; float dd[4]; int n_hit;
+                if (FMT == kFmtF4) n_hit = node_step_f4(nodes, node, R, tmin, ht, c, dd);
+                else if (FMT == kFmtQ4) n_hit = node_step_q4(nodes, node, R, ox, oy, oz, dx, dy, dz, tmin, ht, c, dd, compact);
+                else n_hit = node_step_f2(nodes, node, R, tmin, ht, c, dd);
+                node = n_hit ? c[0] : stack_word_link(popped);
                 const int top = sp + n_hit - 1;    // n_hit == 0: one entry popped
                 if (FMT == kFmtF2) {
-                    if (n_hit == 2) st.set(top, c[1]);
+                    if (n_hit == 2) st.set(top, stack_word(c[1], dd[1]));
                 } else if (top < kFlatLdsRows) {   // common case: unconditional LDS stores, unused ones into the spare row
-                    st.lds[(n_hit >= 2 ? top : kFlatLdsRows) * 256] = c[1];
-                    st.lds[(n_hit >= 3 ? top - 1 : kFlatLdsRows) * 256] = c[2];
-                    st.lds[(n_hit >= 4 ? top - 2 : kFlatLdsRows) * 256] = c[3];
+                    st.lds[(n_hit >= 2 ? top : kFlatLdsRows) * 256] = stack_word(c[1], dd[1]);
+                    st.lds[(n_hit >= 3 ? top - 1 : kFlatLdsRows) * 256] = stack_word(c[2], dd[2]);
+                    st.lds[(n_hit >= 4 ? top - 2 : kFlatLdsRows) * 256] = stack_word(c[3], dd[3]);
                 } else {
-                    if (n_hit >= 4) st.set(top - 2, c[3]);
-                    if (n_hit >= 3) st.set(top - 1, c[2]);
-                    if (n_hit >= 2) st.set(top, c[1]);
+                    if (n_hit >= 4) st.set(top - 2, stack_word(c[3], dd[3]));
+                    if (n_hit >= 3) st.set(top - 1, stack_word(c[2], dd[2]));
+                    if (n_hit >= 2) st.set(top, stack_word(c[1], dd[1]));
                 }
                 sp = top;
+                if (n_hit == 0 && stack_word_culled(popped, ht)) node = st.pop(sp, ht);   // the popped child lies behind the hit found since it was pushed: next one
             }
         }
         if (has_ray && !finished) finished = (node == kSentinel) && pend < 0;
@@ -279,10 +320,10 @@ __device__ bool trace_single_flat(const dev_scene& S, f3 o, f3 d, float tmin, fl
     ht = tmax; hu = hv = 0.0f; htri = -1; hnode = -1;
     while (node != kSentinel) {
         if (node >= 0) {
-            int c[4]; int n_hit;
-            if (fmt == kFmtF4) n_hit = node_step_f4(nodes, node, R, tmin, ht, c);
-            else if (fmt == kFmtQ4) n_hit = node_step_q4(nodes, node, R, tmin, ht, c, S.flat_compact != 0);
-            else n_hit = node_step_f2(nodes, node, R, tmin, ht, c);
+            int c[4]; float dd[4]; int n_hit;
+            if (fmt == kFmtF4) n_hit = node_step_f4(nodes, node, R, tmin, ht, c, dd);
+            else if (fmt == kFmtQ4) n_hit = node_step_q4(nodes, node, R, o.x, o.y, o.z, d.x, d.y, d.z, tmin, ht, c, dd, S.flat_compact != 0);
+            else n_hit = node_step_f2(nodes, node, R, tmin, ht, c, dd);
             for (int i = n_hit - 1; i >= 1; i--) stack[++sp] = c[i];
             node = n_hit ? c[0] : stack[sp--];
         } else {

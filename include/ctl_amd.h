@@ -331,6 +331,10 @@ typedef struct {
     uint32_t format, max_depth;      /* CTL_FLAT_*, depth of the stored tree                                      */
     const void* nodes; uint64_t n_nodes; uint32_t node_bytes;   /* node 0 is the root; child >= 0: node index * node_bytes / 16 */
     const void* leaves; uint64_t n_leaves;   /* 128 B each: object-space Woop rows a,b,c, {globalTri << 1 | last, node, 0, 0}, rows 0..2 of the node's inverse transform, {w33,0,0,0} */
+    const int32_t* child_links;      /* CTL_FLAT_Q4: 4 explicit links per node (>= 0: node index * 4, < 0: ~first leaf entry, 0x76543210: none), else NULL */
+    uint32_t compact;                /* CTL_FLAT_Q4: 1 = the kernels derive the links from the layout (flat4_node::links) and the nodes' last 16 B hold oriented slabs */
+    uint32_t root_slab;              /* CTL_FLAT_Q4: the root node carries a slab (bit 0 of the link a traversal starts with)            */
+    uint64_t n_slab_nodes;           /* nodes that carry an oriented slab (flat_slab.h)                                                  */
 } ctl_flat_bvh_desc;
 int ctl_flat_bvh_build(const ctl_scene_desc* desc, uint32_t format, ctl_flat_bvh** out);
 int ctl_flat_bvh_arrays(const ctl_flat_bvh* h, ctl_flat_bvh_desc* out);

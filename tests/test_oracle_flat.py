@@ -66,9 +66,11 @@ def check_implied_links(fb):
     meta = N[:, 3]; exist = (meta >> 24) & 15; leafm = meta >> 28; innerm = exist & ~leafm & 15
     assert (leafm & ~exist).max() == 0
     w0, w1 = N[:, 10], N[:, 11]
-    inner_base, leaf_base = w0 >> 6, w1 >> 2
+    inner_base, leaf_base, sflags = w0 >> 6, w1 >> 6, (w1 >> 2) & 15
+    assert fb.desc.compact == 1
     cnt = np.stack([w0 & 3, (w0 >> 2) & 3, (w0 >> 4) & 3, w1 & 3], 1) + 1
-    child = N[:, 12:16].view(np.int32)
+    child = fb.child_links()      # the explicit links (host side); a compact tree's last 16 B per node hold the oriented slab instead (flat_slab.h)
+    has_slab = np.zeros(len(N), bool)
     n_leaf_before = np.zeros(len(N), np.int64); n_inner_before = np.zeros(len(N), np.int64)
     for c in range(4):
         is_leaf = ((leafm >> c) & 1) == 1; is_inner = ((innerm >> c) & 1) == 1
@@ -81,7 +83,12 @@ def check_implied_links(fb):
         for j in range(1, 4):
             inside = k > j
             assert not (L[(first + j - 1)[inside], 12] & 1).any()
+        # slab flag of an inner child: the bit the traversal hands down in the link
+        kids = (inner_base + n_inner_before)[is_inner]; has_slab[kids[((sflags[is_inner] >> c) & 1) == 1]] = True
+        assert (sflags[~is_inner] >> c & 1).max(initial=0) == 0
         n_leaf_before += np.where(is_leaf, cnt[:, c], 0); n_inner_before += is_inner
+    has_slab[0] = bool(fb.desc.root_slab)
+    assert has_slab.sum() == fb.desc.n_slab_nodes and (leafm[has_slab] != 0).all()      # only nodes with leaf children carry a slab
 
 
 def test_implied_child_links_of_the_quantised_nodes(orc):
@@ -104,7 +111,8 @@ def test_render_counts_in_flat_mode(orc):
 
 
 def test_sah_optimal_collapse_builds_a_valid_smaller_tree():
-    """CTL_FLAT_COLLAPSE=1 (the dynamic-programming collapse of bvh_builder.h; the knob is read once per process, hence the child process): the tree
+    """CTL_FLAT_COLLAPSE=1 (the dynamic-programming collapse of bvh_builder.h; a measurement knob: only the -DCTL_MEASUREMENT_KNOBS build of the library
+    reads it, once per process, hence the child process with CTL_AMD_LIB): the tree
     has fewer 4-wide nodes than the greedy one, leaves of up to four entries, implied links that equal the explicit ones, and the oracle's traversal
     of it reports the two-level (t, u, v, triangle, node) bit for bit."""
     import os
@@ -140,7 +148,7 @@ print("NODES", fb.desc.n_nodes, "MULTI", int((sizes > 1).sum()))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
     for mode in ("0", "1"):
-        env = dict(os.environ, CTL_FLAT_COLLAPSE=mode)
+        env = dict(os.environ, CTL_FLAT_COLLAPSE=mode, CTL_AMD_LIB=os.path.join(root, "cudatracerlib_amd", "libctl_knobs.so"))
         r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"))], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [l for l in r.stdout.splitlines() if l.startswith("NODES")][-1].split()
