@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kWideBlock) void k_raygen(dev_scene S, wave_queues 
 // Persistent waves with lane refill and an LDS traversal stack — see traverse.h (the reference's g_warpCounter pool,
 // Kernel/TraceHelper.cu:386-399, re-derived for 64-wide waves).
 #ifndef CTL_INTERSECT_MIN_WAVES
-#define CTL_INTERSECT_MIN_WAVES 6   // waves per SIMD the register allocation of the traversal kernels leaves room for (80 VGPRs).  Measured: 8 (64 VGPRs) spills and loses a third
+#define CTL_INTERSECT_MIN_WAVES 7   // waves per SIMD the register allocation of the FLATTENED traversal kernels leaves room for (72 VGPRs, no spills; the two-level kernels stay at 6: 24 KiB of LDS stack).  Measured with the slab build (profiles/r03_occupancy.log): 6 (80 VGPRs) 18.71 ms per fused launch, 7: 18.25, 8 (64 VGPRs, 11 spilled) 20.98; fewer resident workgroups (LDS padding): 5: 20.1, 4: 22.7, 3: 27.4
 #endif
 template <bool ANY_HIT, bool COUNT, int LAYOUT, bool ALPHA>   // LAYOUT: 0 two-level, 1 + flat_format for the flattened structure; ALPHA: alpha-test candidate hits
 #ifdef CTL_INTERSECT_EXACT_WAVES   // measurement builds: hold the traversal kernels to exactly this many waves per SIMD
@@ -60,7 +60,7 @@ template <bool ANY_HIT, bool COUNT, int LAYOUT, bool ALPHA>   // LAYOUT: 0 two-l
 #else
 #define CTL_INTERSECT_WAVES_ATTR
 #endif
-__global__ __launch_bounds__(kBlock, CTL_INTERSECT_MIN_WAVES) CTL_INTERSECT_WAVES_ATTR void k_intersect(dev_scene S, const float4* __restrict__ ro, const float4* __restrict__ rd, const uint32_t* __restrict__ n_ptr,
+__global__ __launch_bounds__(kBlock, ((LAYOUT && !ALPHA) ? CTL_INTERSECT_MIN_WAVES : 6)) CTL_INTERSECT_WAVES_ATTR void k_intersect(dev_scene S, const float4* __restrict__ ro, const float4* __restrict__ rd, const uint32_t* __restrict__ n_ptr,
                                                        uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ,
                                                        unsigned long long* __restrict__ counts3) {
     __shared__ int lds_stack[(LAYOUT ? (kFlatLdsRows + 1) * kFlatStackInts : kLdsStack) * kBlock];   // flat: + one spare row that absorbs unused push slots
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kBlock, CTL_INTERSECT_MIN_WAVES) CTL_INTERSECT_WAVE
 // the first queue exhausted goes straight on to the second, so the drain of the first set (waves running down their last long rays, ~0.4 ms per launch
 // whatever its size) is filled with the second set's work.  Same code, same results as the two separate launches (tracer.hip decides which to use).
 template <int LAYOUT, bool ALPHA>
-__global__ __launch_bounds__(kBlock, CTL_INTERSECT_MIN_WAVES) CTL_INTERSECT_WAVES_ATTR void k_intersect_pair(dev_scene S, const float4* __restrict__ ro, const float4* __restrict__ rd, const uint32_t* __restrict__ n_ptr,
+__global__ __launch_bounds__(kBlock, ((LAYOUT && !ALPHA) ? CTL_INTERSECT_MIN_WAVES : 6)) CTL_INTERSECT_WAVES_ATTR void k_intersect_pair(dev_scene S, const float4* __restrict__ ro, const float4* __restrict__ rd, const uint32_t* __restrict__ n_ptr,
                                                             uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node,
                                                             const float4* __restrict__ sro, const float4* __restrict__ srd, const uint32_t* __restrict__ sn_ptr,
                                                             uint32_t* __restrict__ swork, uint32_t* __restrict__ occ) {

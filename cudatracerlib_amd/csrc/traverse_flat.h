@@ -28,7 +28,7 @@ enum { kFmtQ4 = 0, kFmtF4 = 1, kFmtF2 = 2 };   // = flat_format (flatten.h)
 #define CTL_FLAT_LDS_ROWS 19
 #endif
 constexpr int kFlatLdsRows = CTL_FLAT_LDS_ROWS;   // stack entries per lane in LDS (+ 1 spare row); deeper entries live in scratch
-__device__ int g_leaf_batch = 24;         // run the leaf phase once this many lanes hold a pending leaf entry (CTL_LEAF_BATCH)
+__device__ int g_leaf_batch = 16;         // run the leaf phase once this many lanes hold a pending leaf entry (knob CTL_LEAF_BATCH).  With the oriented slabs fewer leaves are parked: 8: 2253, 12: 2299, 16: 2315, 20: 2311, 24: 2288, 32: 2216 Mrays/s (gpurun_out r03g / r03h)
 
 // Stack entry = {link, entry distance of the pushed child}: a pop whose entry distance is not below the current hit distance is dropped on the spot
 // (the closest hit moved in front of that child while it waited) — counted by the oracle on the bench scene: 10 % of the node visits, 5 % of the entry tests.

@@ -10,7 +10,7 @@ for f in $units; do
       /Function Name:/ { name=$0; sub(/.*Function Name: /, "", name); sub(/ \[-Rpass.*/, "", name) }
       /VGPRs:/ && !/Agpr|AGPRs/ { v=$0; sub(/.*VGPRs: /, "", v); sub(/ \[.*/, "", v) }
       /ScratchSize/ { s=$0; sub(/.*: /, "", s); sub(/ \[.*/, "", s) }
-      /VGPR Spill/ { sp=$0; sub(/.*: /, "", sp); sub(/ \[.*/, "", sp) }
+      /VGPRs Spill/ { sp=$0; sub(/.*: /, "", sp); sub(/ \[.*/, "", sp) }
       /Occupancy/ { o=$0; sub(/.*: /, "", o); sub(/ \[.*/, "", o) }
       /LDS Size/ { l=$0; sub(/.*: /, "", l); sub(/ \[.*/, "", l); printf "%-12s vgpr %-4s spill %-4s scratch %-6s occ %-3s lds %-6s %s\n", unit, v, sp, s, o, l, name }'
 done
