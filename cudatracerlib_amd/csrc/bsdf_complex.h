@@ -145,7 +145,7 @@ __device__ f3 bsdf_complex_sample(const ctl_material& M, bsdf_rec& b, float& pdf
         if (!is_zero(sigmaA)) result = result * exp3(-sigmaA * (1 / fabsf(cos_theta(wiPrime)) + 1 / fabsf(cos_theta(woPrime))));
         float R21; b.wo = coat_refract_out(M, woPrime, R21);
         if (R21 == 1.0f) return f3(0.0f);
-        if (ss) { pdf *= 1.0f - ps; result = result / (1.0f - ps); }
+        if (ss) { pdf *= 1.0f - ps; result = sdiv(result, 1.0f - ps); }
         result = result * ((1 - R12) * (1 - R21));
         if (bsdf_measure(b.sampled_type) == kMeasSolidAngle) {
             result = result * (cos_theta(b.wi) / cos_theta(wiPrime));
@@ -174,7 +174,7 @@ __device__ f3 bsdf_complex_sample(const ctl_material& M, bsdf_rec& b, float& pdf
         const int measure = bsdf_measure(b.sampled_type);
         pdf = bsdf_complex_pdf(M, b, measure);
         if (pdf == 0) return f3(0.0f);
-        return bsdf_complex_f(M, b, measure) / pdf;
+        return sdiv(bsdf_complex_f(M, b, measure), pdf);
     }
     case CTL_BSDF_BLEND: {   // BSDF_Complex.cu:344-372
         float w[2]; w[1] = clampf(avg3(tex_eval(M.tex[0], b.dg)), 0.0f, 1.0f); w[0] = 1.0f - w[1];
@@ -188,7 +188,7 @@ __device__ f3 bsdf_complex_sample(const ctl_material& M, bsdf_rec& b, float& pdf
         const uint32_t other = 1 - entry;
         pdf += nested_pdf(mats[M.u[2 + other]], b, measure) * w[other];
         result = result + nested_f(mats[M.u[2 + other]], b, measure) * w[other];
-        return result / pdf;
+        return sdiv(result, pdf);
     }
     default: return f3(0.0f);
     }

@@ -12,7 +12,7 @@ __device__ __forceinline__ f3 refract_about(f3 wi, f3 n, float eta, float cosThe
 __device__ __forceinline__ float signum1(float v) { return copysign_bits(1.0f, v); }
 __device__ __forceinline__ f3 plastic_diffuse(const ctl_material& M, const diff_geom& dg) {
     const f3 d = tex_eval(M.tex[0], dg);
-    return M.u[0] ? d / (f3(1.0f) - d * M.f[0]) : d / (1 - M.f[0]);
+    return M.u[0] ? d / (f3(1.0f) - d * M.f[0]) : sdiv(d, 1 - M.f[0]);
 }
 __device__ __forceinline__ microfacet rough_dielectric_distr(const ctl_material& M, const diff_geom& dg, float cos_wi, bool scaled) {
     microfacet d((int)M.u[0], avg3(tex_eval(M.tex[2], dg)), avg3(tex_eval(M.tex[3], dg)), M.u[1] != 0);
@@ -99,7 +99,7 @@ __device__ f3 bsdf_more_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f
         b.eta = 1.0f;
         if (hd && hs) {
             const float ps = (Fi * M.f[4]) / (Fi * M.f[4] + (1 - Fi) * (1 - M.f[4]));
-            if (smp.x < ps) { b.sampled_type = CTL_EDeltaReflection; b.wo = reflect_local(b.wi); pdf = ps; return tex_eval(M.tex[1], b.dg) * Fi / ps; }
+            if (smp.x < ps) { b.sampled_type = CTL_EDeltaReflection; b.wo = reflect_local(b.wi); pdf = ps; return sdiv(tex_eval(M.tex[1], b.dg) * Fi, ps); }
             b.sampled_type = CTL_EDiffuseReflection;
             b.wo = square_to_cosine_hemisphere(f2{ (smp.x - ps) / (1 - ps), smp.y });
             const float Fo = fresnel_dielectric_ext(cos_theta(b.wo), ct, M.f[2]);
@@ -127,7 +127,7 @@ __device__ f3 bsdf_more_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f
         b.eta = 1.0f;
         pdf = phong_pdf(M, b);
         if (pdf == 0) return f3(0.0f);
-        return phong_f(M, b) / pdf;
+        return sdiv(phong_f(M, b), pdf);
     }
     default: return bsdf_rough_sample(M, b, pdf, smp);
     }

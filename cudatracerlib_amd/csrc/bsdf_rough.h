@@ -203,7 +203,7 @@ __device__ f3 roughplastic_f(const ctl_material& M, const bsdf_rec& b) {   // BS
         const float T21 = roughplastic_T(M, b, cos_theta(b.wo), distr.aU);
         const float Fdr = 1 - (M.reserved_[0] ? b.dg.rt_reduced[M.reserved_[0] - 1 + M.reserved_[1]] : rough_transmittance_diffuse_memo(b, M.u[2], distr.aU, M.f[0]));
         if (M.u[0]) diff = diff / (f3(1.0f) - diff * Fdr);
-        else diff = diff / (1 - Fdr);
+        else diff = sdiv(diff, 1 - Fdr);
         result = result + diff * (kInvPi * cos_theta(b.wo) * T12 * T21 * M.f[1]);
     }
     return result;
@@ -231,7 +231,7 @@ __device__ __noinline__ f3 bsdf_rough_sample(const ctl_material& M, bsdf_rec& b,
     case CTL_BSDF_ROUGHDIFFUSE: {   // BSDF_Simple.h:42-49
         b.wo = square_to_cosine_hemisphere(smp); b.eta = 1.0f; b.sampled_type = CTL_EGlossyReflection;
         pdf = kInvPi * cos_theta(b.wo);
-        return roughdiffuse_f(M, b) / pdf;
+        return sdiv(roughdiffuse_f(M, b), pdf);
     }
     case CTL_BSDF_WARD: {   // BSDF_Simple.cu:1173-1230
         const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
@@ -254,7 +254,7 @@ __device__ __noinline__ f3 bsdf_rough_sample(const ctl_material& M, bsdf_rec& b,
         b.eta = 1.0f;
         pdf = ward_pdf(M, b);
         if (pdf == 0) return f3(0.0f);
-        return ward_f(M, b) / pdf;
+        return sdiv(ward_f(M, b), pdf);
     }
     case CTL_BSDF_ROUGHPLASTIC: {   // BSDF_Simple.cu:890-946
         const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
@@ -274,7 +274,7 @@ __device__ __noinline__ f3 bsdf_rough_sample(const ctl_material& M, bsdf_rec& b,
         b.eta = 1.0f;
         pdf = roughplastic_pdf(M, b);
         if (pdf == 0) return f3(0.0f);
-        return roughplastic_f(M, b) / pdf;
+        return sdiv(roughplastic_f(M, b), pdf);
     }
     default: return f3(0.0f);
     }

@@ -33,6 +33,9 @@ HD f3 operator/(f3 a, f3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
 HD f3 operator*(f3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
 HD f3 operator*(float s, f3 a) { return f3(a.x * s, a.y * s, a.z * s); }
 HD f3 operator/(f3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+// Spectrum / scalar of the reference multiplies by the reciprocal (TSpectrum::operator/(Scalar), operator/=(Scalar), Math/Spectrum.h:122-128, :150-155), Vec3f / scalar
+// divides (Math/Vector.h:88): every Spectrum-by-scalar division of the path is written sdiv()
+HD f3 sdiv(f3 a, float s) { const float r = 1.0f / s; return f3(a.x * r, a.y * r, a.z * r); }
 HD f3 operator-(f3 a) { return f3(-a.x, -a.y, -a.z); }
 // Math/Vector.h:101 — accumulate from 0 in component order
 HD float dot(f3 a, f3 b) { float r = a.x * b.x; r += a.y * b.y; r += a.z * b.z; return r; }

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_path_trace(dev_scene S, pass_params P, 
                             if (!trace_single<true>(S, dr.ref, dr.d, S.eps, dr.dist - S.eps, st, su, sv, stri, snode)) {   // Occluded(r, 0, dist)
                                 float weight = 1.0f;
                                 if (dr.measure != kMeasureDiscrete) weight = power_heuristic((dr.measure == kMeasureArea ? dr.pdf * dr.dist / fabsf(dot(dr.n, dr.d)) : dr.pdf) * lpdf, bsdf_pdf_top(mat, b2));
-                                cl = cl + cf * ((value * bsdfVal * weight) / lpdf);
+                                cl = cl + cf * sdiv(value * bsdfVal * weight, lpdf);
                             }
                         }
                     }
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_path_trace(dev_scene S, pass_params P, 
             if (depth > P.rr_start_depth && !specularBounce) {
                 const float q = max3c(cf);
                 if (rng.next1() >= q) break;
-                cf = cf / q;
+                cf = sdiv(cf, q);
             }
         }
         if (!had_hit && S.env_map_index != 0xffffffffu) {   // PathTracer.cu:99-111
@@ -116,7 +116,7 @@ __device__ f3 light_sample_position(const ctl_light& L, f2 sample, f3& p) {
         const f3 perpOffset = F.to_world(f3(q.x, q.y, 0) * L.bsphere_radius), d = F.to_world(f3(0.0f, 0.0f, 1.0f));
         p = d * L.bsphere_radius + perpOffset;
         const float surfaceArea = kPi * L.bsphere_radius * L.bsphere_radius, invSurfaceArea = 1.0f / surfaceArea;
-        return f3(L.radiance[0], L.radiance[1], L.radiance[2]) / invSurfaceArea;
+        return sdiv(f3(L.radiance[0], L.radiance[1], L.radiance[2]), invSurfaceArea);
     }
     p = f3(0.0f); return f3(0.0f);
 }
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_path_trace_regularization(dev_scene S, 
                         const float fU = S.light_cdf[slot], fL = slot > 0 ? S.light_cdf[slot - 1] : 0.0f;
                         sample.x = (sample.x - fL) / (fU - fL);
                         const ctl_light& l = S.lights[li2];
-                        f3 lp; const f3 l_s = light_sample_position(l, sample, lp) / emPdf;
+                        f3 lp; const f3 l_s = sdiv(light_sample_position(l, sample, lp), emPdf);
                         const float lDist = length(lp - b.dg.P);
                         const f3 lDir = (lp - b.dg.P) / lDist;
                         if (!(l.type == CTL_LIGHT_DIFFUSE || l.type == CTL_LIGHT_INFINITE)) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_path_trace_regularization(dev_scene S, 
             cf = cf * f;
             if (depth > P.rr_start_depth) {
                 const float q = max3c(cf);
-                if (rng.next1() < q) cf = cf / q;
+                if (rng.next1() < q) cf = sdiv(cf, q);
                 else break;
             }
             r_o = b.dg.P; r_d = b.dg.sys.to_world(b.wo);

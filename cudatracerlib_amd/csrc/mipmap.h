@@ -107,7 +107,7 @@ __device__ inline f3 mip_eval_ewa(const ctl_mipmap& M, const dev_mip_levels& L, 
         }
     }
     if (denominator == 0) return mip_triangle_l(M, L, level, uv);
-    return result / denominator;
+    return sdiv(result, denominator);
 }
 __device__ inline f3 mip_eval(const ctl_mipmap& M, const dev_mip_levels& L, const float* __restrict__ lut, f2 uv, f2 d0, f2 d1) {   // KernelMIPMap::eval(uv, d0, d1)
     const float dimx = (float)M.width, dimy = (float)M.height;
@@ -115,7 +115,7 @@ __device__ inline f3 mip_eval(const ctl_mipmap& M, const dev_mip_levels& L, cons
     if (M.filter_mode == CTL_FILTER_POINT) return mip_texel_l(M, L, 0, uv);
     if (M.filter_mode == CTL_FILTER_BILINEAR) return mip_triangle_l(M, L, 0, uv);
     if (M.filter_mode == CTL_FILTER_TRILINEAR) {
-        const float levela = log2f(dimx / fabsf(du)), levelb = log2f(dimy / fabsf(dv)), level = (float)L.levels - clampf((levela + levelb) / 2.0f, 1.0f, (float)L.levels);
+        const float levela = logf(dimx / fabsf(du)) / logf(2.0f), levelb = logf(dimy / fabsf(dv)) / logf(2.0f),   /* math::log2 on the reference's host path (MathFunc.h:258-265) */ level = (float)L.levels - clampf((levela + levelb) / 2.0f, 1.0f, (float)L.levels);
         const int iLevel = (int)floorf(level), iLevel2 = clampi(iLevel + 1, 0, (int)L.levels - 1);
         const float p = level - iLevel;
         return p * mip_triangle_l(M, L, (uint32_t)iLevel, uv) + (1 - p) * mip_triangle_l(M, L, (uint32_t)iLevel2, uv);

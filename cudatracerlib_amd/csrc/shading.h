@@ -722,7 +722,7 @@ __device__ f3 light_sample_direct(const dev_scene& S, const ctl_light& L, direct
         r.dist = L.bsphere_radius;
         r.d = normalize(d);
         r.measure = kMeasureSolidAngle;
-        return value / pdf;
+        return sdiv(value, pdf);
     }
 #endif
     const float* cdf = (const float*)(S.anim + L.area_dist_index);
@@ -768,9 +768,9 @@ __device__ f3 light_sample_direct(const dev_scene& S, const ctl_light& L, direct
     r.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
     if (dot(r.d, r.refN) >= 0 && dot(r.d, r.n) < 0 && r.pdf != 0) {
 #if CTL_SHADE_FEATURES & 8
-        if (light_needs_uv(L)) return light_radiance_tex(S, L, uv) / r.pdf * sc;
+        if (light_needs_uv(L)) return sdiv(light_radiance_tex(S, L, uv), r.pdf) * sc;
 #endif
-        return f3(L.radiance[0], L.radiance[1], L.radiance[2]) / r.pdf * sc;
+        return sdiv(f3(L.radiance[0], L.radiance[1], L.radiance[2]), r.pdf) * sc;
     }
     r.pdf = 0.0f;
     return f3(0.0f);

@@ -13,7 +13,7 @@ inline float signum(float v) { return copysign_bits(1.0f, v); }   // MathFunc.h:
 inline Spec plasticDiff(const ctl_material& M, const BRec& bRec) {
     Spec diff = texEval(M.tex[0], bRec.dg);
     if (M.u[0]) return diff / (Spec(1.0f) - diff * M.f[0]);
-    return diff / (1 - M.f[0]);
+    return sdiv(diff, 1 - M.f[0]);
 }
 
 inline Spec bsdf2F(const ctl_material& M, const BRec& bRec, int measure);
@@ -81,7 +81,7 @@ inline Spec bsdf2Sample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sampl
         bRec.eta = 1.0f;
         if (hasDiffuse && hasSpecular) {
             float probSpecular = (Fi * ssw) / (Fi * ssw + (1 - Fi) * (1 - ssw));
-            if (_sample.x < probSpecular) { bRec.sampledType = CTL_EDeltaReflection; bRec.wo = Frame::reflect(bRec.wi); pdf = probSpecular; return texEval(M.tex[1], bRec.dg) * Fi / probSpecular; }
+            if (_sample.x < probSpecular) { bRec.sampledType = CTL_EDeltaReflection; bRec.wo = Frame::reflect(bRec.wi); pdf = probSpecular; return sdiv(texEval(M.tex[1], bRec.dg) * Fi, probSpecular); }
             bRec.sampledType = CTL_EDiffuseReflection;
             bRec.wo = squareToCosineHemisphere(V2{ (_sample.x - probSpecular) / (1 - probSpecular), _sample.y });
             float Fo = fresnelDielectricExt(Frame::cosTheta(bRec.wo), m_eta);
@@ -112,7 +112,7 @@ inline Spec bsdf2Sample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sampl
         bRec.eta = 1.0f;
         pdf = bsdf2Pdf(M, bRec, ESolidAngle);
         if (pdf == 0) return Spec(0.0f);
-        return bsdf2F(M, bRec, ESolidAngle) / pdf;
+        return sdiv(bsdf2F(M, bRec, ESolidAngle), pdf);
     }
     default: return bsdf3Sample(M, bRec, pdf, _sample);
     }

@@ -101,7 +101,7 @@ inline Spec bsdf3Sample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sampl
         bRec.eta = 1.0f;
         bRec.sampledType = CTL_EGlossyReflection;
         pdf = squareToCosineHemispherePdf(bRec.wo);
-        return bsdf3F(M, bRec, ESolidAngle) / pdf;
+        return sdiv(bsdf3F(M, bRec, ESolidAngle), pdf);
     }
     case CTL_BSDF_WARD: {   // BSDF_Simple.cu:1173-1230
         V2 sample = _sample;
@@ -131,7 +131,7 @@ inline Spec bsdf3Sample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sampl
         bRec.eta = 1.0f;
         pdf = bsdf3Pdf(M, bRec, ESolidAngle);
         if (pdf == 0) return Spec(0.0f);
-        return bsdf3F(M, bRec, ESolidAngle) / pdf;
+        return sdiv(bsdf3F(M, bRec, ESolidAngle), pdf);
     }
     case CTL_BSDF_ROUGHPLASTIC: {   // BSDF_Simple.cu:890-946
         bool hasSpecular = (bRec.typeMask & CTL_EGlossyReflection) != 0, hasDiffuse = (bRec.typeMask & CTL_EDiffuseReflection) != 0;
@@ -157,7 +157,7 @@ inline Spec bsdf3Sample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sampl
         bRec.eta = 1.0f;
         pdf = bsdf3Pdf(M, bRec, ESolidAngle);
         if (pdf == 0) return Spec(0.0f);
-        return bsdf3F(M, bRec, ESolidAngle) / pdf;
+        return sdiv(bsdf3F(M, bRec, ESolidAngle), pdf);
     }
     default: throw std::runtime_error("oracle: bsdf type not restated");
     }
@@ -236,7 +236,7 @@ inline Spec bsdf3F(const ctl_material& M, const BRec& bRec, int measure) {
             float T21 = roughTransmittance(bRec.dg, M.u[2], Frame::cosTheta(bRec.wo), distr.alphaU, M.f[0]);
             float Fdr = 1 - roughTransmittanceDiffuse(bRec.dg, M.u[2], distr.alphaU, M.f[0]);
             if (M.u[0]) diff = diff / (Spec(1.0f) - diff * Fdr);
-            else diff = diff / (1 - Fdr);
+            else diff = sdiv(diff, 1 - Fdr);
             result = result + diff * (INV_PI * Frame::cosTheta(bRec.wo) * T12 * T21 * M.f[1]);
         }
         return result;

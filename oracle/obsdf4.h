@@ -161,7 +161,7 @@ inline Spec bsdfComplexSample(const ctl_material& M, BRec& bRec, float& pdf, V2 
         if (!isZero(sigmaA)) result = result * specExp(-sigmaA * (1 / fabsf(Frame::cosTheta(wiPrime)) + 1 / fabsf(Frame::cosTheta(woPrime))));
         float R21; bRec.wo = coatRefractOut(M, woPrime, R21);
         if (R21 == 1.0f) return Spec(0.0f);
-        if (sampleSpecular) { pdf *= 1.0f - probSpecular; result = result / (1.0f - probSpecular); }
+        if (sampleSpecular) { pdf *= 1.0f - probSpecular; result = sdiv(result, 1.0f - probSpecular); }
         result = result * ((1 - R12) * (1 - R21));
         if (bsdfMeasure(bRec.sampledType) == ESolidAngle) {
             result = result * (Frame::cosTheta(bRec.wi) / Frame::cosTheta(wiPrime));
@@ -194,7 +194,7 @@ inline Spec bsdfComplexSample(const ctl_material& M, BRec& bRec, float& pdf, V2 
         int measure = bsdfMeasure(bRec.sampledType);
         pdf = bsdfComplexPdf(M, bRec, measure);
         if (pdf == 0) return Spec(0.0f);
-        return bsdfComplexF(M, bRec, measure) / pdf;
+        return sdiv(bsdfComplexF(M, bRec, measure), pdf);
     }
     case CTL_BSDF_BLEND: {   // BSDF_Complex.cu:344-372
         float weights[2];
@@ -211,7 +211,7 @@ inline Spec bsdfComplexSample(const ctl_material& M, BRec& bRec, float& pdf, V2 
             pdf += bsdfPdf(nestedMat(M, bRec, (int)i), bRec, measure) * weights[i];
             result = result + bsdfF(nestedMat(M, bRec, (int)i), bRec, measure) * weights[i];
         }
-        return result / pdf;
+        return sdiv(result, pdf);
     }
     default: throw std::runtime_error("oracle: bsdf type not restated");
     }

@@ -472,6 +472,23 @@ inline Spec mipTriangleL(const ctl_mipmap& M, const MipPyramid& P, uint32_t leve
     return ((1.f - ds) * (1.f - dt)) * mipTexelL(M, P, level, uv) + ((1.f - ds) * dt) * mipTexelL(M, P, level, V2{ uv.x + 0, uv.y + is.y }) +
            (ds * (1.f - dt)) * mipTexelL(M, P, level, V2{ uv.x + is.x, uv.y + 0 }) + (ds * dt) * mipTexelL(M, P, level, V2{ uv.x + is.x, uv.y + is.y });
 }
+// math::log2 on the host (Math/MathFunc.h:258-265): logf(a) / logf(2) — not log2f, which eval() calls by name in its anisotropic branch (MIPMap.cu:231, :266)
+inline float mathLog2(float a) { return logf(a) / logf(2.0f); }
+// KernelMIPMap::Sample(uv, width) (MIPMap.cu:140-153): the pyramid level from a footprint width, trilinear between two levels
+inline Spec mipSampleWidth(const ctl_mipmap& M, const MipPyramid& P, V2 uv, float width) {
+    const float level = (float)(P.levels - 1) + mathLog2(fmax2(width, 1e-8f));
+    if (level < 0) return mipTriangleL(M, P, 0, uv);
+    if (level >= (float)(P.levels - 1)) return mipTexelL(M, P, P.levels - 1, uv);
+    const int iLevel = (int)floorf(level); const float delta = level - iLevel;
+    return (1.f - delta) * mipTriangleL(M, P, (uint32_t)iLevel, uv) + delta * mipTriangleL(M, P, (uint32_t)(iLevel + 1), uv);
+}
+// KernelMIPMap::Sample(width, x, y) (MIPMap.cu:155-172): clamped direct fetch from the level the width selects
+inline Spec mipFetchL(const ctl_mipmap& M, const MipPyramid& P, float width, int x, int y) {
+    const float l = (float)(P.levels - 1) + mathLog2(fmax2(width, 1e-8f));
+    const int level = (int)clampf(l, 0.0f, (float)(P.levels - 1)), wl = (int)(M.width >> level), hl = (int)(M.height >> level);
+    x = clampi(x, 0, wl - 1); y = clampi(y, 0, hl - 1);
+    return texelDecode(P.texels[(size_t)P.offsets[level] + (size_t)y * wl + x], M.texel_type);
+}
 // KernelMIPMap::evalEWA (MIPMap.cu:59-114)
 inline Spec mipEvalEWA(const ctl_mipmap& M, const MipPyramid& P, uint32_t level, V2 uv, float A, float B, float C) {
     if (level >= P.levels) return mipTexelL(M, P, P.levels - 1, V2{ 0, 0 });
@@ -493,7 +510,7 @@ inline Spec mipEvalEWA(const ctl_mipmap& M, const MipPyramid& P, uint32_t level,
         }
     }
     if (denominator == 0) return mipTriangleL(M, P, level, uv);
-    return result / denominator;
+    return sdiv(result, denominator);
 }
 // KernelMIPMap::eval(uv, d0, d1) (MIPMap.cu:193-278)
 inline Spec mipEval(const ctl_mipmap& M, const MipPyramid& P, V2 uv, V2 d0, V2 d1) {
@@ -502,7 +519,7 @@ inline Spec mipEval(const ctl_mipmap& M, const MipPyramid& P, V2 uv, V2 d0, V2 d
     if (M.filter_mode == CTL_FILTER_POINT) return mipTexelL(M, P, 0, uv);
     if (M.filter_mode == CTL_FILTER_BILINEAR) return mipTriangleL(M, P, 0, uv);
     if (M.filter_mode == CTL_FILTER_TRILINEAR) {
-        float levela = log2f(dimx / fabsf(du)), levelb = log2f(dimy / fabsf(dv)), level = (float)P.levels - clampf((levela + levelb) / 2.0f, 1.0f, (float)P.levels);
+        float levela = mathLog2(dimx / fabsf(du)), levelb = mathLog2(dimy / fabsf(dv)), level = (float)P.levels - clampf((levela + levelb) / 2.0f, 1.0f, (float)P.levels);
         int iLevel = (int)floorf(level), iLevel2 = clampi(iLevel + 1, 0, (int)P.levels - 1);
         float p = level - iLevel;
         return p * mipTriangleL(M, P, (uint32_t)iLevel, uv) + (1 - p) * mipTriangleL(M, P, (uint32_t)iLevel2, uv);
@@ -902,7 +919,7 @@ inline Spec lightSampleDirect(const Scene& S, const ctl_light& L, DirectRec& dRe
         dRec.dist = L.bsphere_radius;
         dRec.d = normalize(d);
         dRec.measure = ESolidAngle;
-        return value / pdf;
+        return sdiv(value, pdf);
     }
     V2 uv{ 0.0f, 0.0f }; float sc = 1;
     if (L.orthogonal) {   // the point of a random triangle's plane straight above / below the reference point (Light.cu:87-107)
@@ -938,7 +955,7 @@ inline Spec lightSampleDirect(const Scene& S, const ctl_light& L, DirectRec& dRe
         dRec.measure = ESolidAngle;
     } else dRec.measure = EDiscrete;
     if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0)
-        return lightRadiance(S, L, dRec.p, dRec.uv, uv) / dRec.pdf * sc;
+        return sdiv(lightRadiance(S, L, dRec.p, dRec.uv, uv), dRec.pdf) * sc;
     dRec.pdf = 0.0f;
     return Spec(0.0f);
 }
@@ -1359,7 +1376,7 @@ inline Spec uniformSampleOneLight(const Scene& S, const BRec& bRec, const ctl_ma
     float pdf;
     const ctl_light* light = sampleEmitter(S, pdf, sample);
     if (light == nullptr) return Spec(0.0f);
-    return estimateDirect(S, bRec, mat, light, pdf, EAll & ~EDelta, rng, rays) / pdf;
+    return sdiv(estimateDirect(S, bRec, mat, light, pdf, EAll & ~EDelta, rng, rays), pdf);
 }
 
 // --------------------------------------------------------------------------- PathTrace<DIRECT> (Integrators/PathTracer.cu:10-113), no volumes
@@ -1428,7 +1445,7 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
         if (!r2.hasHit()) break;
         if (depth > rrStartDepth && !specularBounce) {
             if (rnd.randomFloat() >= vmax(cf)) break;
-            cf = cf / vmax(cf);
+            cf = sdiv(cf, vmax(cf));
         }
     }
     if (!r2.hasHit() && S.d.env_map_index != 0xffffffffu) {   // PathTracer.cu:99-111; EvalEnvironment == 0 without an environment map
@@ -1457,7 +1474,7 @@ inline Spec lightSamplePosition(const ctl_light& L, V2 sample, V3& p) {
         const V3 perpOffset = F.toWorld(V3(q.x, q.y, 0) * L.bsphere_radius), d = F.toWorld(V3(0.0f, 0.0f, 1.0f));
         p = d * L.bsphere_radius + perpOffset;
         const float surfaceArea = PI * L.bsphere_radius * L.bsphere_radius, invSurfaceArea = 1.0f / surfaceArea;   // Light.h:159-165
-        return Spec(L.radiance[0], L.radiance[1], L.radiance[2]) / invSurfaceArea;                                 // m_power (Light.cu:208-212)
+        return sdiv(Spec(L.radiance[0], L.radiance[1], L.radiance[2]), invSurfaceArea);                                 // m_power (Light.cu:208-212)
     }
     p = V3(0.0f); return Spec(0.0f);
 }
@@ -1499,7 +1516,7 @@ inline Spec pathTraceRegularization(const Scene& S, bool DIRECT, V3 ro, V3 rd, c
                 V2 sample = rnd.randomFloat2();
                 if (S.d.num_lights) {
                     float emPdf; const ctl_light* l = sampleEmitter(S, emPdf, sample);   // KernelDynamicScene::sampleEmitterPosition (KernelDynamicScene.cu:156-168)
-                    V3 lp; Spec l_s = lightSamplePosition(*l, sample, lp) / emPdf;
+                    V3 lp; Spec l_s = sdiv(lightSamplePosition(*l, sample, lp), emPdf);
                     float lDist = length(lp - bRec.dg.P);
                     V3 lDir = (lp - bRec.dg.P) / lDist;
                     if (!(l->type == CTL_LIGHT_DIFFUSE || l->type == CTL_LIGHT_INFINITE)) {
@@ -1518,7 +1535,7 @@ inline Spec pathTraceRegularization(const Scene& S, bool DIRECT, V3 ro, V3 rd, c
         specularBounce = (bRec.sampledType & EDelta) != 0;
         cf = cf * f;
         if (depth > rrStartDepth) {
-            if (rnd.randomFloat() < vmax(cf)) cf = cf / vmax(cf);
+            if (rnd.randomFloat() < vmax(cf)) cf = sdiv(cf, vmax(cf));
             else break;
         }
         ro = bRec.dg.P; rd = bRec.dg.sys.toWorld(bRec.wo);

@@ -66,6 +66,9 @@ inline bool isZero(V3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
 
 // Spectrum == RGB triple (SPECTRUM_SAMPLES 3, Math/Spectrum.h:10); toLinearRGB is the identity (Spectrum.cu:174-184)
 typedef V3 Spec;
+// TSpectrum::operator/(Scalar) and operator/=(Scalar) (Math/Spectrum.h:122-128, :150-155) multiply by the reciprocal; Vec3f / float (Math/Vector.h:88) divides.
+// Spec shares V3's operators, so every Spectrum-by-scalar division of the reference is written sdiv() here (pinned through KernelMIPMap::evalEWA, mipmap.npz).
+inline V3 sdiv(V3 s, float f) { const float recip = 1.0f / f; return V3(s.x * recip, s.y * recip, s.z * recip); }
 
 // ---------------------------------------------------------------- float4x4 (Math/float4x4.h)
 struct M44 {

@@ -150,6 +150,27 @@ void orc_mip_eval(const ctl_mipmap* M, float u, float v, const float* d0, const 
     const Spec s = mipEval(*M, P, V2{ u, v }, V2{ d0[0], d0[1] }, V2{ d1[0], d1[1] });
     rgb[0] = s.x; rgb[1] = s.y; rgb[2] = s.z;
 }
+// the lookups of KernelMIPMap one by one (same `what` / args as oracle/ref_mipmap_driver.cpp ref_mipmap_query): 0 Texel(level, uv), 1 triangle(level, uv),
+// 2 evalEWA(level, uv, A, B, C), 3 eval(uv, d0, d1), 4 Sample(uv), 5 Sample(uv, width), 6 SampleAlpha(uv), 7 Sample(width, x, y); lut_out: the 64 EWA weights
+void orc_mip_query(const ctl_mipmap* M, int what, int n, const float* args, float* out3, float* lut_out) {
+    MipPyramid P; P.build(*M);
+    if (lut_out) std::memcpy(lut_out, mipWeightLut(), 256);
+    for (int i = 0; i < n; i++) {
+        const float* a = args + 8 * i; const V2 uv{ a[0], a[1] }; const uint32_t level = (uint32_t)a[6];
+        Spec s(0.0f);
+        switch (what) {
+        case 0: s = mipTexelL(*M, P, level, uv); break;
+        case 1: s = mipTriangleL(*M, P, level, uv); break;
+        case 2: s = mipEvalEWA(*M, P, level, uv, a[2], a[3], a[4]); break;
+        case 3: s = mipEval(*M, P, uv, V2{ a[2], a[3] }, V2{ a[4], a[5] }); break;
+        case 4: s = mipSample(*M, uv); break;
+        case 5: s = mipSampleWidth(*M, P, uv, a[2]); break;
+        case 6: s = Spec(mipSampleAlpha(*M, uv)); break;
+        case 7: s = mipFetchL(*M, P, a[2], (int)a[3], (int)a[4]); break;
+        }
+        out3[3 * i] = s.x; out3[3 * i + 1] = s.y; out3[3 * i + 2] = s.z;
+    }
+}
 // in: P, n, dpdu, dpdv (3 floats each), ray origin, directions of the x / y differential rays; out: dudx, dudy, dvdx, dvdy
 void orc_compute_partials(const float* P, const float* n, const float* dpdu, const float* dpdv, const float* ro, const float* rxd, const float* ryd, float* out4) {
     DG dg; dg.P = V3(P[0], P[1], P[2]); dg.n = V3(n[0], n[1], n[2]); dg.dpdu = V3(dpdu[0], dpdu[1], dpdu[2]); dg.dpdv = V3(dpdv[0], dpdv[1], dpdv[2]);

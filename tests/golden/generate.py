@@ -330,8 +330,80 @@ def gen_math2(r):
                         rr_wi=wi, rr_n=nn, rr_eta=eta, rr_cos_t=ct, reflect=refl, refract=refr)
 
 
+def mipmap_cases():
+    """the images and queries of the KernelMIPMap fixture (shared with tests/test_oracle_golden.py: the test rebuilds the inputs from the stored arrays, not from here)"""
+    rs = np.random.RandomState(20261003)
+    imgs = []
+    for (w, h, typ) in ((32, 16, 1), (64, 64, 0), (20, 12, 1), (8, 128, 0)):
+        if typ == 1:
+            tex = rs.randint(0, 256, size=(h, w, 4)).astype(np.uint32)
+        else:   # RGBE: mantissas + exponents around 128 (values 2^-6 .. 2^5), some zero texels
+            tex = rs.randint(0, 256, size=(h, w, 4)).astype(np.uint32); tex[..., 3] = rs.randint(122, 134, size=(h, w)); tex[rs.uniform(size=(h, w)) < 0.05] = 0
+        imgs.append((w, h, typ, (tex[..., 0] | (tex[..., 1] << 8) | (tex[..., 2] << 16) | (tex[..., 3] << 24)).astype(np.uint32)))
+    n = 96
+    q = {}
+    uv = rs.uniform(-1.6, 2.6, size=(8, n, 2)).astype(np.float32); uv[:, :8] = np.array([[0, 0], [1, 1], [0.5, 0.5], [1, 0], [0, 1], [-1, -1], [2, 2], [0.999999, 1e-7]], np.float32)
+    for what in range(8):
+        a = np.zeros((n, 8), np.float32); a[:, :2] = uv[what]
+        a[:, 6] = rs.randint(0, 9, size=n)                                                                  # level (beyond the last one too)
+        if what == 2:      # ellipse coefficients as eval() forms them from texel-space derivatives
+            d = rs.normal(size=(n, 4)) * 10.0 ** rs.uniform(-1.5, 1.2, size=(n, 1))
+            A = d[:, 1] ** 2 + d[:, 3] ** 2; B = -2 * (d[:, 0] * d[:, 1] + d[:, 2] * d[:, 3]); Cc = d[:, 0] ** 2 + d[:, 2] ** 2; F = A * Cc - B * B * 0.25
+            ok = F > 1e-6; A[~ok] = 1; B[~ok] = 0; Cc[~ok] = 1; F[~ok] = 1
+            a[:, 2] = A / F; a[:, 3] = B / F; a[:, 4] = Cc / F
+        elif what == 3:    # uv derivatives over four decades, some axis-aligned, some degenerate
+            d = (rs.normal(size=(n, 4)) * 10.0 ** rs.uniform(-4.0, -0.3, size=(n, 1))).astype(np.float32)
+            d[8:16, 1] = 0; d[8:16, 2] = 0; d[16:20] = 0; d[20:24, 2:] = d[20:24, :2] * 1e-4
+            a[:, 2:6] = d
+        elif what in (5, 7):
+            a[:, 2] = 10.0 ** rs.uniform(-4, 0.3, size=n); a[:8, 2] = [0, 1e-9, 1, 2, 0.5, 0.25, 1e-3, 0.1]
+            if what == 7:
+                a[:, 3] = rs.randint(-3, 70, size=n); a[:, 4] = rs.randint(-3, 140, size=n)
+        q[what] = a
+    return imgs, q
+
+
+def gen_mipmap(r):
+    # ---- KernelMIPMap (Engine/MIPMap.cu:13-278, compiled from the reference by `make -C oracle ref`): Texel / triangle / evalEWA / eval / Sample / SampleAlpha on four
+    # images x four wrap modes x the filter modes; the pyramid levels and the EWA weight table are inputs (their builder, MIPMap.cpp, needs FreeImage and is restated only)
+    from cudatracerlib_amd import api
+    orc = oracle.Oracle()
+    lib = orc.lib
+    lib.orc_mip_pyramid.restype = C.c_uint32; lib.orc_mip_pyramid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.orc_mip_query.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    r.ref_mipmap_query.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    imgs, q = mipmap_cases()
+    out = {}
+    for ii, (w, h, typ, tex) in enumerate(imgs):
+        tex = np.ascontiguousarray(tex)
+        M = api.ctl_mipmap(tex.ctypes.data, w, h, typ, 0, 1)
+        levels = C.c_uint32(); offs = (C.c_uint32 * 16)()
+        total = lib.orc_mip_pyramid(C.byref(M), C.byref(levels), offs, None, 0)
+        pyr = np.zeros(total, np.uint32)
+        lib.orc_mip_pyramid(C.byref(M), C.byref(levels), offs, pyr.ctypes.data_as(C.c_void_p), total)
+        lut = np.zeros(64, np.float32); dummy = np.zeros(8, np.float32); o3 = np.zeros(3, np.float32)
+        lib.orc_mip_query(C.byref(M), 0, 1, dummy.ctypes.data_as(C.c_void_p), o3.ctypes.data_as(C.c_void_p), lut.ctypes.data_as(C.c_void_p))
+        out["img%d_texels" % ii] = tex; out["img%d_pyramid" % ii] = pyr; out["img%d_offsets" % ii] = np.array(list(offs), np.uint32)
+        out["img%d_hdr" % ii] = np.array([w, h, typ, levels.value], np.uint32); out["lut"] = lut
+        for wrap in range(4):
+            for what in range(8):
+                filters = (2, 3, 0, 1) if what == 3 else ((0, 1) if what == 4 else (1,))
+                for filt in filters:
+                    hdr = np.array([w, h, typ, wrap, filt, levels.value], np.uint32)
+                    a = q[what].copy(); res = np.zeros((len(a), 3), np.float32)
+                    if what == 0:
+                        a[:, 6] = np.minimum(a[:, 6], levels.value - 1)      # Texel() is only ever called with a level that exists (triangle / evalEWA clamp before)
+                    r.ref_mipmap_query(pyr.ctypes.data_as(C.c_void_p), hdr.ctypes.data_as(C.c_void_p), offs, lut.ctypes.data_as(C.c_void_p), what, len(a), a.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p))
+                    out["img%d_wrap%d_what%d_filter%d" % (ii, wrap, what, filt)] = res
+    for what in range(8):
+        out["args%d" % what] = q[what]
+    np.savez_compressed(os.path.join(HERE, "mipmap.npz"), **out)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["math2"]:
+    if sys.argv[1:] == ["mipmap"]:
+        gen_mipmap(oracle.load_ref())
+    elif sys.argv[1:] == ["math2"]:
         gen_math2(oracle.load_ref())
     elif sys.argv[1:] == ["traceray"]:      # only this fixture (the others stay byte-identical)
         gen_traceray(oracle.load_ref())
@@ -339,3 +411,4 @@ if __name__ == "__main__":
         main()
         gen_traceray(oracle.load_ref())
         gen_math2(oracle.load_ref())
+        gen_mipmap(oracle.load_ref())
