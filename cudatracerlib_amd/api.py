@@ -344,7 +344,7 @@ def roughconductor(alpha=0.1, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), distrib
 
 def thindielectric(int_ior=1.5046, ext_ior=1.000277, specular_transmittance=1.0, specular_reflectance=1.0):
     """thindielectric(eta) — BSDF_Simple.h:96-125."""
-    m = _material(4, E["DeltaReflection"] | E["Null"])
+    m = _material(4, E["DeltaReflection"] | E["DeltaTransmission"])   # the reference's constructor (BSDF_Simple.h:102-118); sample() still reports ENull for the transmitted lobe
     m.tex[0], m.tex[1] = _const_tex(specular_transmittance), _const_tex(specular_reflectance)
     m.f[0] = np.float32(np.float32(int_ior) / np.float32(ext_ior))
     return m
@@ -362,46 +362,32 @@ def roughdielectric(alpha=0.1, int_ior=1.5046, ext_ior=1.000277, distribution=1,
 
 
 def fresnel_diffuse_reflectance(eta):
-    """FresnelHelper::fresnelDiffuseReflectance(eta, false) (Math/FresnelHelper.cu:13-60): integral of F(sqrt(xi), eta) over [0,1].
-    The reference integrates adaptively to 1e-5; this is the same integral evaluated in double precision."""
-    if eta == 1:
-        return 0.0
-    # substitute xi = c^2 (d xi = 2 c dc) so the integrand is smooth at grazing incidence
-    c = np.linspace(0.0, 1.0, 400001)
-    ct2 = 1.0 - (1.0 - c * c) / (eta * eta)
-    ct = np.sqrt(np.maximum(ct2, 0.0))
-    with np.errstate(invalid="ignore", divide="ignore"):
-        rs = (c - eta * ct) / (c + eta * ct)
-        rp = (eta * c - ct) / (eta * c + ct)
-        F = np.where(ct2 <= 0, 1.0, 0.5 * (rs * rs + rp * rp))
-    y = F * 2.0 * c
-    return float(np.sum((y[1:] + y[:-1]) * 0.5 * np.diff(c)))
+    """FresnelHelper::fresnelDiffuseReflectance(eta, false) (Math/FresnelHelper.cu:57-60): the library's restatement of the reference's adaptive Gauss-Lobatto
+    quadrature (csrc/material_factory.h), bit-equal to the reference's value"""
+    lib.ctl_fresnel_diffuse_reflectance.restype = C.c_float; lib.ctl_fresnel_diffuse_reflectance.argtypes = [C.c_float]
+    return float(lib.ctl_fresnel_diffuse_reflectance(float(np.float32(eta))))
+
+
+def material_update(m):
+    """BSDF::Update(): the derived fields (fdrInt / fdrExt, invEta2, sampling weights) from the primary ones, by the library (ctl_material_update)"""
+    _check(lib.ctl_material_update(C.byref(m)))
+    return m
 
 
 def plastic(diffuse_reflectance=(0.5, 0.5, 0.5), int_ior=1.49, ext_ior=1.000277, specular_reflectance=1.0, nonlinear=False):
     """plastic(eta, diffuse, specular) — BSDF_Simple.h:234-270 incl. Update(): fdrInt/fdrExt, invEta2, specularSamplingWeight."""
     m = _material(8, E["DeltaReflection"] | E["DiffuseReflection"])
     m.tex[0], m.tex[1] = _const_tex(diffuse_reflectance), _const_tex(specular_reflectance)
-    eta = float(np.float32(np.float32(int_ior) / np.float32(ext_ior)))
-    lum = lambda t: t.value[0] * 0.212671 + t.value[1] * 0.715160 + t.value[2] * 0.072169   # Spectrum::getLuminance (Spectrum.cu:174-177)
-    d_avg, s_avg = lum(m.tex[0]), lum(m.tex[1])
-    m.f[0], m.f[1], m.f[2], m.f[3], m.f[4] = fresnel_diffuse_reflectance(1 / eta), fresnel_diffuse_reflectance(eta), eta, 1.0 / (eta * eta), s_avg / (d_avg + s_avg)
+    m.f[2] = float(np.float32(np.float32(int_ior) / np.float32(ext_ior)))
     m.u[0] = 1 if nonlinear else 0
-    return m
+    return material_update(m)
 
 
 def phong(diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(0.2, 0.2, 0.2), exponent=30.0):
     """phong(diffuse, specular, exponent) — BSDF_Simple.h:313-340; specularSamplingWeight = sAvg / (dAvg + sAvg)."""
     m = _material(10, E["GlossyReflection"] | E["DiffuseReflection"])
     m.tex[0], m.tex[1], m.tex[2] = _const_tex(diffuse_reflectance), _const_tex(specular_reflectance), _const_tex(exponent)
-    lum = lambda t: t.value[0] * 0.212671 + t.value[1] * 0.715160 + t.value[2] * 0.072169
-    d_avg, s_avg = lum(m.tex[0]), lum(m.tex[1])
-    m.f[0] = s_avg / (d_avg + s_avg)
-    return m
-
-
-def _lum(t):
-    return t.value[0] * 0.212671 + t.value[1] * 0.715160 + t.value[2] * 0.072169   # Spectrum::getLuminance of a constant texture's Average()
+    return material_update(m)
 
 
 def roughdiffuse(reflectance=(0.5, 0.5, 0.5), alpha=0.2, use_fast_approx=False):
@@ -416,26 +402,17 @@ def ward(diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(0.2, 0.2, 0.
     """ward(variant, diffuse, specular, alphaU, alphaV) — BSDF_Simple.h:342-381; variant 0 Ward, 1 Ward-Duer, 2 balanced."""
     m = _material(11, E["GlossyReflection"] | E["DiffuseReflection"])
     m.tex[0], m.tex[1], m.tex[2], m.tex[3] = _as_tex(diffuse_reflectance), _as_tex(specular_reflectance), _as_tex(alpha_u), _as_tex(alpha_v)
-    d_avg, s_avg = _lum(m.tex[0]), _lum(m.tex[1])
-    m.f[0] = s_avg / (d_avg + s_avg)
     m.u[0] = variant
-    return m
+    return material_update(m)
 
 
 def roughplastic(diffuse_reflectance=(0.5, 0.5, 0.5), alpha=0.1, int_ior=1.49, ext_ior=1.000277, distribution=0, specular_reflectance=1.0, nonlinear=False, sample_visible=True):
     """roughplastic(type, eta, alpha, diffuse, specular) — BSDF_Simple.h:272-312; needs the rough-transmittance table of slot `distribution`."""
     m = _material(9, E["GlossyReflection"] | E["DiffuseReflection"])
     m.tex[0], m.tex[1], m.tex[2] = _as_tex(diffuse_reflectance), _as_tex(specular_reflectance), _as_tex(alpha)
-    eta = float(np.float32(np.float32(int_ior) / np.float32(ext_ior)))
-    d_avg, s_avg = _lum(m.tex[0]), _lum(m.tex[1])
-    m.f[0], m.f[1], m.f[2] = eta, 1.0 / (eta * eta), s_avg / (d_avg + s_avg)
+    m.f[0] = float(np.float32(np.float32(int_ior) / np.float32(ext_ior)))
     m.u[0], m.u[1], m.u[2] = 1 if nonlinear else 0, 0 if distribution == 2 else (1 if sample_visible else 0), distribution   # getSampleVisible(type, true)
-    return m
-
-
-def _coating_ssw(sigma_a, thickness):
-    a = np.mean([np.exp(v * (-2.0 * thickness)) for v in sigma_a.value[:]])
-    return 1.0 / (a + 1.0)
+    return material_update(m)
 
 
 def coating(nested_index, nested, int_ior=1.5046, ext_ior=1.000277, thickness=1.0, sigma_a=0.0, specular_reflectance=1.0):
@@ -443,9 +420,9 @@ def coating(nested_index, nested, int_ior=1.5046, ext_ior=1.000277, thickness=1.
     m = _material(13, E["DeltaReflection"] | nested.combined_type)
     m.tex[0], m.tex[1] = _as_tex(sigma_a), _as_tex(specular_reflectance)
     eta = float(np.float32(np.float32(int_ior) / np.float32(ext_ior)))
-    m.f[0], m.f[1], m.f[2], m.f[3] = eta, 1.0 / eta, thickness, _coating_ssw(m.tex[0], thickness)
+    m.f[0], m.f[2] = eta, thickness
     m.u[2] = nested_index
-    return m
+    return material_update(m)
 
 
 def roughcoating(nested_index, nested, alpha=0.1, int_ior=1.5046, ext_ior=1.000277, thickness=1.0, sigma_a=0.0, distribution=0, specular_reflectance=1.0):
@@ -453,9 +430,9 @@ def roughcoating(nested_index, nested, alpha=0.1, int_ior=1.5046, ext_ior=1.0002
     m = _material(14, E["GlossyReflection"] | nested.combined_type)
     m.tex[0], m.tex[1], m.tex[2] = _as_tex(sigma_a), _as_tex(specular_reflectance), _as_tex(alpha)
     eta = float(np.float32(np.float32(int_ior) / np.float32(ext_ior)))
-    m.f[0], m.f[1], m.f[2], m.f[3] = eta, 1.0 / eta, thickness, _coating_ssw(m.tex[0], thickness)
+    m.f[0], m.f[2] = eta, thickness
     m.u[0], m.u[1], m.u[2] = distribution, 0 if distribution == 2 else 1, nested_index
-    return m
+    return material_update(m)
 
 
 MAP_NONE, MAP_NORMAL, MAP_HEIGHT = 0, 1, 2

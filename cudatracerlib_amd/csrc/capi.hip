@@ -6,6 +6,7 @@
 #include "scene_builder.h"
 #include "mitsuba_loader.h"
 #include "flatten.h"
+#include "material_factory.h"
 #include "image_io.h"
 #include <memory>
 #include "scene_cache.h"
@@ -102,6 +103,8 @@ int ctl_builder_set_camera_lookat(ctl_builder* b, const float pos[3], const floa
 int ctl_builder_set_camera(ctl_builder* b, const ctl_sensor* sensor) { CTL_REQUIRE(b && sensor, "null argument"); CTL_TRY b->b.set_camera(*sensor); CTL_CATCH }
 int ctl_builder_finalize(ctl_builder* b, ctl_scene_desc* out) { CTL_REQUIRE(b && out, "null argument"); CTL_TRY b->b.finalize(*out); CTL_CATCH }
 
+int ctl_material_update(ctl_material* m) { CTL_REQUIRE(m, "null argument"); CTL_REQUIRE(material_update(*m), "unknown bsdf_type"); return CTL_OK; }
+float ctl_fresnel_diffuse_reflectance(float eta) { return fresnel_diffuse_reflectance(eta); }
 // ---- scene
 int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc, false); CTL_CATCH }
 int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY

@@ -244,6 +244,15 @@ typedef struct {
     const ctl_rough_transmittance* rough_transmittance;           /* [3] or NULL (needed by roughplastic only) */
 } ctl_scene_desc;
 
+/* BSDF::Update() (SceneTypes/BSDF_Simple.h:255-264 plastic, :298-304 roughplastic, :332-337 phong, :371-376 ward; BSDF_Complex.h:37-44 coating, :117-125
+ * roughcoating): recomputes a material's DERIVED fields from its primary ones — fdrInt / fdrExt by the reference's adaptive Gauss-Lobatto quadrature
+ * (FresnelHelper::fresnelDiffuseReflectance, Math/FresnelHelper.cu:57-60), invEta / invEta2, the specular sampling weights from the textures' average
+ * luminance (constant and checkerboard textures; an image texture's average is the caller's, as ImageTexture::Average reads the coarsest MIP level).
+ * Host only.  A caller converting the reference's own objects copies their fields instead and does not need this. */
+int ctl_material_update(ctl_material* m);
+/* FresnelHelper::fresnelDiffuseReflectance(eta, false) as above. */
+float ctl_fresnel_diffuse_reflectance(float eta);
+
 /* ------------------------------------------------------------- scene builder */
 /* Host-side mirror of the subset of DynamicScene the loader drives
  * (Engine/DynamicScene.h:70-187; SURVEY §8b "Loader boundary"). */

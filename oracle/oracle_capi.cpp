@@ -208,6 +208,19 @@ void orc_bsdf_eval(const ctl_material* M, const float* wi, const float* wo, uint
     b.wi = V3(wi[0], wi[1], wi[2]); b.wo = V3(wo[0], wo[1], wo[2]); b.eta = 1.0f; b.typeMask = typeMask; b.sampledType = 0; b.dg.rough_transmittance = g_probe_rt; b.dg.materials = g_probe_mats;
     Spec f = bsdfF(*M, b); out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = bsdfPdf(*M, b);
 }
+// the same probes with a texture coordinate (checkerboard textures) and the measure as an argument (mode 1 solid angle, 2 discrete): the shape of oracle/ref_bsdf_driver.cpp
+void orc_bsdf_sample_uv(const ctl_material* M, const float* wi, float sx, float sy, float u, float v, float* out) {
+    BRec b; b.dg.P = V3(0.0f); b.dg.sys = Frame(V3(1, 0, 0), V3(0, 1, 0), V3(0, 0, 1)); b.dg.n = V3(0, 0, 1); b.dg.uv = V2{ u, v };
+    b.wi = V3(wi[0], wi[1], wi[2]); b.wo = V3(0.0f); b.eta = 1.0f; b.typeMask = EAll; b.sampledType = 0; b.dg.rough_transmittance = g_probe_rt; b.dg.materials = g_probe_mats;
+    float pdf = 0; Spec f = bsdfSample(*M, b, pdf, V2{ sx, sy });
+    out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = pdf; out[4] = b.wo.x; out[5] = b.wo.y; out[6] = b.wo.z; out[7] = (float)b.sampledType; out[8] = b.eta;
+}
+void orc_bsdf_eval_uv(const ctl_material* M, const float* wi, const float* wo, uint32_t typeMask, int mode, float u, float v, float* out) {
+    BRec b; b.dg.P = V3(0.0f); b.dg.sys = Frame(V3(1, 0, 0), V3(0, 1, 0), V3(0, 0, 1)); b.dg.n = V3(0, 0, 1); b.dg.uv = V2{ u, v };
+    b.wi = V3(wi[0], wi[1], wi[2]); b.wo = V3(wo[0], wo[1], wo[2]); b.eta = 1.0f; b.typeMask = typeMask; b.sampledType = 0; b.dg.rough_transmittance = g_probe_rt; b.dg.materials = g_probe_mats;
+    const int measure = mode == 2 ? EDiscrete : ESolidAngle;
+    Spec f = bsdfF(*M, b, measure); out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = bsdfPdf(*M, b, measure);
+}
 // f / pdf with the discrete measure (delta lobes; what the nesting BSDFs ask their children for)
 void orc_bsdf_eval_discrete(const ctl_material* M, const float* wi, const float* wo, uint32_t typeMask, float* out) {
     BRec b; b.dg.P = V3(0.0f); b.dg.sys = Frame(V3(1, 0, 0), V3(0, 1, 0), V3(0, 0, 1)); b.dg.n = V3(0, 0, 1); b.dg.uv = V2{ 0, 0 };

@@ -7,9 +7,12 @@
 // Header-only reference code driven from here as well: Warp.h, Frame.h, half.h, Compression.h, float4x4.h, MonteCarlo.h, Filter.h, and the traversal
 // template of BVHTraversal.h with the slab arithmetic of MathFunc.h (ref_trace_two_level).
 //
-// What could NOT be built from the reference here (needs curand_kernel.h from the CUDA toolkit, or
-// un-vendored boost/pugixml/FreeImage): BSDF_Simple.cu, Light.cu, KernelDynamicScene.cu, TraceHelper.cu,
-// Sampler/CudaRandom, DynamicScene, the Mitsuba loader.  See DESIGN.md "Oracle".
+// Further reference code is driven by ref_mipmap_driver.cpp (KernelMIPMap), ref_bsdf_driver.cpp (BSDF_Simple.cu, BSDF_Complex.cu) and ref_light_driver.cpp
+// (Light.cu) — files whose host-compilable part `make ref` extracts at build time.
+// What could NOT be built from the reference here (needs curand_kernel.h from the CUDA toolkit, nvcc's ::min / ::max, the global g_SceneData declared behind
+// curand, or un-vendored boost / pugixml / FreeImage): Math/Spline.cu (rough transmittance), Engine/ShapeSet.cu (area-light sampling), the two environment-map
+// sampling functions of Light.cu, KernelDynamicScene.cu, TraceHelper.cu, TraceAlgorithms.cu, PathTracer.cu, Sampler / CudaRandom, DynamicScene, the Mitsuba
+// loader.  See DESIGN.md "Oracle".
 #include <Engine/TriIntersectorData.h>
 #include <Engine/TriangleData.h>
 #include <Engine/DifferentialGeometry.h>

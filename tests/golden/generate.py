@@ -400,8 +400,113 @@ def gen_mipmap(r):
     np.savez_compressed(os.path.join(HERE, "mipmap.npz"), **out)
 
 
+def bsdf_cases():
+    """materials of the BSDF fixture: name -> list of ctl_material (the LAST one is queried; earlier ones are what it nests)"""
+    from cudatracerlib_amd import api
+    chk = api.checker_texture((0.9, 0.2, 0.1), (0.1, 0.3, 0.8), uv_scale=(3.0, 2.0), uv_offset=(0.25, 0.5))
+    rc = api.roughconductor(alpha=0.2, distribution=1, sample_visible=True)
+    dchk = api.diffuse((0.5, 0.5, 0.5)); dchk.tex[0] = chk
+    cases = {
+        "diffuse": [api.diffuse((0.8, 0.5, 0.3))], "diffuse_checker": [dchk],
+        "roughdiffuse": [api.roughdiffuse((1, 0.9, 0.8), alpha=0.5)], "roughdiffuse_fast": [api.roughdiffuse((0.8, 0.8, 0.8), alpha=0.3, use_fast_approx=True)],
+        "dielectric": [api.dielectric(int_ior=1.5, ext_ior=1.0)], "dielectric_tinted": [api.dielectric(int_ior=1.33, ext_ior=1.0, specular_transmittance=(0.9, 0.95, 1.0), specular_reflectance=(1.0, 0.9, 0.8))],
+        "thindielectric": [api.thindielectric(int_ior=1.5, ext_ior=1.0)],
+        "roughdielectric_beck_vis": [api.roughdielectric(alpha=0.2, int_ior=1.5, ext_ior=1.0, distribution=0, sample_visible=True)],
+        "roughdielectric_ggx_vis": [api.roughdielectric(alpha=0.15, int_ior=1.5, ext_ior=1.0, distribution=1, sample_visible=True)],
+        "roughdielectric_beck": [api.roughdielectric(alpha=0.3, int_ior=1.33, ext_ior=1.0, distribution=0, sample_visible=False)],
+        "roughdielectric_aniso": [api.roughdielectric(alpha=0.3, alpha_v=0.1, int_ior=1.5, ext_ior=1.0, distribution=1, sample_visible=True)],
+        "roughdielectric_phong": [api.roughdielectric(alpha=0.25, int_ior=1.5, ext_ior=1.0, distribution=2, sample_visible=False)],
+        "conductor": [api.conductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))],
+        "roughconductor_ggx_vis": [rc], "roughconductor_beck": [api.roughconductor(alpha=0.3, distribution=0, sample_visible=False)],
+        "roughconductor_beck_vis_aniso": [api.roughconductor(alpha=0.25, alpha_v=0.1, distribution=0, sample_visible=True)],
+        "roughconductor_phong": [api.roughconductor(alpha=0.2, alpha_v=0.35, distribution=2, sample_visible=False)],
+        "roughconductor_ggx": [api.roughconductor(alpha=0.1, distribution=1, sample_visible=False)],
+        "plastic": [api.plastic(diffuse_reflectance=(1, 1, 1), int_ior=1.49)], "plastic_nonlinear": [api.plastic(diffuse_reflectance=(0.5, 0.4, 0.3), int_ior=1.9, nonlinear=True)],
+        "plastic_tinted": [api.plastic(diffuse_reflectance=(0.2, 0.6, 0.3), int_ior=1.33, ext_ior=1.0, specular_reflectance=(0.9, 0.8, 0.7))],
+        "phong": [api.phong(diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(0.5, 0.5, 0.5), exponent=25.0)], "phong_sharp": [api.phong((0.1, 0.2, 0.3), (0.6, 0.5, 0.4), exponent=300.0)],
+        "ward_balanced": [api.ward((0.4, 0.4, 0.4), (0.5, 0.5, 0.5), 0.15, 0.15, variant=2)], "ward_duer_aniso": [api.ward((0.4, 0.4, 0.4), (0.3, 0.3, 0.3), 0.1, 0.3, variant=1)],
+        "ward": [api.ward((0.4, 0.3, 0.4), (0.3, 0.3, 0.2), 0.2, 0.3, variant=0)],
+    }
+    d = api.diffuse((0.6, 0.7, 0.8)); pl = api.plastic(diffuse_reflectance=(0.5, 0.4, 0.3), int_ior=1.5, ext_ior=1.0)
+    cases["coating_diffuse"] = [d, api.coating(0, d, int_ior=1.5, ext_ior=1.0, thickness=1.0, sigma_a=(0.1, 0.4, 0.9))]
+    cases["coating_roughconductor"] = [rc, api.coating(0, rc, int_ior=1.33, ext_ior=1.0, thickness=0.5, sigma_a=0.0, specular_reflectance=(0.9, 0.9, 1.0))]
+    cases["coating_plastic"] = [pl, api.coating(0, pl, int_ior=1.6, ext_ior=1.0, thickness=2.0, sigma_a=(0.3, 0.2, 0.1))]
+    cases["blend_diffuse_roughconductor"] = [d, rc, api.blend(0, d, 1, rc, weight=0.3)]
+    cases["blend_plastic_dielectric"] = [pl, api.dielectric(int_ior=1.5, ext_ior=1.0), api.blend(0, pl, 1, api.dielectric(int_ior=1.5, ext_ior=1.0), weight=0.6)]
+    return cases
+
+
+def gen_bsdf(r):
+    # ---- the reference's own BSDFs (SceneTypes/BSDF_Simple.cu without its unused curand include, BSDF_Complex.cu as it lies; oracle/ref_bsdf_driver.cpp):
+    # sample (weight, pdf, wo, sampled lobe, eta), f + pdf with the solid-angle measure under three lobe masks, f + pdf with the discrete measure, and the
+    # constants the reference's constructors derive (m_combinedType, fdrInt, fdrExt, invEta2 / invEta, specular sampling weight)
+    from cudatracerlib_amd import api
+    r.ref_bsdf_query.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    r.ref_bsdf_derived.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    rs = np.random.RandomState(20261004)
+    n = 192
+    out = {}
+    for name, mats in bsdf_cases().items():
+        arr = (api.ctl_material * len(mats))(*mats); idx = len(mats) - 1
+        wi = rs.normal(size=(n, 3)); wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+        if "dielectric" not in name:
+            wi[:, 2] = np.abs(wi[:, 2])
+        wi[:4] = [[0, 0, 1], [0.6, 0, 0.8], [0.999, 0, 0.0447101778], [-0.6, 0.64, 0.48]]
+        q = np.zeros((n, 8), np.float32); q[:, :3] = wi; q[:, 3:5] = rs.rand(n, 2); q[:, 6:8] = rs.uniform(-1, 2, size=(n, 2))
+        smp = np.zeros((n, 9), np.float32)
+        assert r.ref_bsdf_query(C.addressof(arr), idx, 0, 0x1ff, n, q.ctypes.data, smp.ctypes.data) == 0, name
+        # evaluation directions: the sampled ones of OTHER queries (so that both hemispheres and the specular directions occur), and the exact mirror / refraction directions
+        q2 = q.copy(); wo = np.roll(smp[:, 4:7], 1, axis=0).copy()
+        bad = ~(np.linalg.norm(wo, axis=1) > 0.5); alt = rs.normal(size=(n, 3)); alt /= np.linalg.norm(alt, axis=1, keepdims=True); wo[bad] = alt[bad]
+        own = smp[:, 4:7].copy(); keep = (np.arange(n) % 3 == 0) & (np.linalg.norm(own, axis=1) > 0.5); wo[keep] = own[keep]      # every third query: its own sampled direction
+        q2[:, 3:6] = wo
+        out[name + "_materials"] = np.frombuffer(bytes(arr), np.uint8).copy(); out[name + "_sample_q"] = q; out[name + "_sample"] = smp; out[name + "_eval_q"] = q2
+        for mask in (0x1ff, 0x2 | 0x4, 0x8 | 0x10, 0x20 | 0x40):
+            for mode in (1, 2):
+                ev = np.zeros((n, 9), np.float32)
+                assert r.ref_bsdf_query(C.addressof(arr), idx, mode, mask, n, q2.ctypes.data, ev.ctypes.data) == 0
+                out["%s_eval_mode%d_mask%x" % (name, mode, mask)] = ev[:, :4].copy()
+        d5 = np.zeros(5, np.float32); assert r.ref_bsdf_derived(C.addressof(arr), idx, d5.ctypes.data) == 0
+        out[name + "_derived"] = d5
+    np.savez_compressed(os.path.join(HERE, "bsdf.npz"), **out)
+
+
+def gen_lights(r):
+    # ---- the reference's own PointLight / SpotLight / DistantLight (SceneTypes/Light.cu, compiled by `make ref` without its two g_SceneData functions; oracle/ref_light_driver.cpp):
+    # constructed by the reference from primary parameters, sampleDirect from random reference points
+    r.ref_light_sample_direct.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rs = np.random.RandomState(20261005)
+    n = 128; out = {}
+    lights = []
+    for k in range(4):
+        lights.append((1, np.concatenate([rs.uniform(-5, 5, 3), rs.uniform(0.5, 40, 3)]).astype(np.float32)))
+    for k in range(6):
+        p = rs.uniform(-5, 5, 3); t = p + rs.normal(size=3) * 3; cutoff = rs.uniform(10, 60); beam = cutoff * rs.uniform(0.3, 0.95)
+        lights.append((4, np.concatenate([p, t, rs.uniform(0.5, 40, 3), [cutoff, beam]]).astype(np.float32)))
+    for k in range(4):
+        d = rs.normal(size=3); d /= np.linalg.norm(d)
+        lights.append((3, np.concatenate([d, rs.uniform(0.5, 5, 3), [rs.uniform(3, 30)]]).astype(np.float32)))
+    for i, (typ, par) in enumerate(lights):
+        q = np.zeros((n, 8), np.float32); q[:, :3] = rs.uniform(-8, 8, size=(n, 3)); nn = rs.normal(size=(n, 3)); q[:, 3:6] = nn / np.linalg.norm(nn, axis=1, keepdims=True); q[:, 6:8] = rs.rand(n, 2)
+        if typ == 4:   # half of the reference points inside the cone
+            axis = par[3:6] - par[:3]; axis = axis / np.linalg.norm(axis)
+            q[: n // 2, :3] = par[:3] + axis * rs.uniform(0.5, 6, size=(n // 2, 1)) + rs.normal(size=(n // 2, 3)) * 0.4
+        if typ == 3:   # three quarters of the reference points beyond the light's disk (centre d * 1.1 r), where the reference accepts the sample (Light.cu:224-233)
+            m = 3 * n // 4; dn = par[:3] / np.linalg.norm(par[:3])
+            q[:m, :3] = dn * (1.1 * par[6] + rs.uniform(0.05, 12, size=(m, 1))) + rs.normal(size=(m, 3)) * 3
+        res = np.zeros((n, 14), np.float32)
+        assert r.ref_light_sample_direct(typ, par.ctypes.data, n, q.ctypes.data, res.ctypes.data) == 0
+        out["light%d_type" % i] = np.int32(typ); out["light%d_params" % i] = par; out["light%d_q" % i] = q; out["light%d_out" % i] = res
+    np.savez_compressed(os.path.join(HERE, "lights.npz"), **out)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["mipmap"]:
+    if sys.argv[1:] == ["lights"]:
+        gen_lights(oracle.load_ref())
+    elif sys.argv[1:] == ["bsdf"]:
+        gen_bsdf(oracle.load_ref())
+        gen_lights(oracle.load_ref())
+    elif sys.argv[1:] == ["mipmap"]:
         gen_mipmap(oracle.load_ref())
     elif sys.argv[1:] == ["math2"]:
         gen_math2(oracle.load_ref())
@@ -412,3 +517,5 @@ if __name__ == "__main__":
         gen_traceray(oracle.load_ref())
         gen_math2(oracle.load_ref())
         gen_mipmap(oracle.load_ref())
+        gen_bsdf(oracle.load_ref())
+        gen_lights(oracle.load_ref())

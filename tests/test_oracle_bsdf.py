@@ -1,7 +1,8 @@
 """Self-consistency of the oracle's BSDF restatement (oracle/ocore.h, oracle/obsdf2.h <- SceneTypes/BSDF/BSDF_Simple.cu).
 
-BSDF_Simple.cu cannot be compiled here (needs curand_kernel.h, see oracle/ref_driver.cpp), so the three entry points
-of every model are pinned against each other the way Mitsuba's own chi-square / consistency tests do:
+The models themselves are pinned bit for bit on the reference's own BSDF_Simple.cu / BSDF_Complex.cu in tests/test_oracle_golden.py (bsdf.npz) — all but
+roughplastic / roughcoating, whose transmittance lookup (Math/Spline.cu) only nvcc compiles.  Here the three entry points of every model, those two included,
+are held against each other the way Mitsuba's own chi-square / consistency tests do:
   * sample() returns weight = f(wi, wo) / pdf(wi, wo) and the same pdf that pdf() reports for the sampled direction,
   * delta lobes report f = pdf = 0 through eval,
   * no model creates energy (mean sample weight <= 1 for unit reflectance).
