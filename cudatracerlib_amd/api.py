@@ -635,6 +635,15 @@ def intersect(scene, rays, any_hit=False):
     return hits
 
 
+def trace_single_ray(scene, origin, direction, tmin=0.0, tmax=3.402823466e+38):
+    """TracerBase::TraceSingleRay (Kernel/Tracer.cu:74-78) -> the record of the closest hit (dist, node_idx, tri_idx, u, v)"""
+    rays = np.zeros((1, 8), np.float32); rays[0, :3] = origin; rays[0, 3] = tmin; rays[0, 4:7] = direction; rays[0, 7] = tmax
+    r, rp = _rays_struct(rays)
+    hit = np.zeros(1, dtype=[("dist", "f4"), ("node_idx", "i4"), ("tri_idx", "i4"), ("u", "f4"), ("v", "f4")])
+    _check(lib.ctl_trace_single_ray(scene._h, rp, hit.ctypes.data_as(C.c_void_p)))
+    return hit[0]
+
+
 def intersect_count(scene, rays, any_hit=False):
     r, rp = _rays_struct(rays)
     c = ctl_traversal_counts()
@@ -797,6 +806,28 @@ class WavefrontPathTracer:
 
     def DoPasses(self, image, n, new_trace=False):
         _check(lib.ctl_tracer_do_passes(self._h, image._h, 1 if new_trace else 0, u32(n)))
+
+    def Debug(self, image, x, y):
+        """TracerBase::Debug(Image*, Vec2i) (Kernel/Tracer.h:119-123): draws the next set of sampling tables from the tracer's generator, follows one path for the pixel
+        (PathTracer plugin) and returns its radiance as 3 floats"""
+        out = (f32 * 3)()
+        _check(lib.ctl_tracer_debug_pixel(self._h, image._h, u32(x), u32(y), out))
+        return np.array(out[:], np.float32)
+
+    def setDepthBuffer(self, width, height):
+        """IDepthTracer::setDepthBuffer: allocates width*height floats on the device and hands them to the tracer; read them back with getDepthBuffer()"""
+        p = C.c_void_p()
+        _check(lib.ctl_device_malloc(C.c_size_t(4 * width * height), C.byref(p)))
+        self._depth = (p, width, height)
+        lib.ctl_tracer_set_depth_buffer.argtypes = [C.c_void_p, C.c_void_p, u32, u32]
+        _check(lib.ctl_tracer_set_depth_buffer(self._h, p, u32(width), u32(height)))
+
+    def getDepthBuffer(self):
+        p, w, h = self._depth
+        out = np.zeros((h, w), np.float32)
+        _check(lib.ctl_device_synchronize())
+        _check(lib.ctl_memcpy_d2h(out.ctypes.data_as(C.c_void_p), p, C.c_size_t(out.nbytes)))
+        return out
 
     def setCounting(self, on):
         """count N_inner / N_tri / N_inst in the intersect kernels (measurement mode)"""

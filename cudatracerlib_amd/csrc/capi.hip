@@ -247,6 +247,8 @@ int ctl_tracer_get_block_counts(ctl_tracer* t, uint8_t* out, uint32_t n) {
     CTL_CATCH
 }
 int ctl_tracer_get_stats(ctl_tracer* t, ctl_tracer_stats* out) { CTL_REQUIRE(t && out, "null argument"); CTL_TRY t->t->getKernelStats(*out); CTL_CATCH }
+int ctl_tracer_debug_pixel(ctl_tracer* t, ctl_image* img, uint32_t x, uint32_t y, float* rgb_out) { CTL_REQUIRE(t && img, "null argument"); CTL_TRY t->t->Debug(&img->img, x, y, rgb_out); CTL_CATCH }
+int ctl_tracer_set_depth_buffer(ctl_tracer* t, float* device_depth, uint32_t width, uint32_t height) { CTL_REQUIRE(t, "null tracer"); CTL_REQUIRE(device_depth || (width == 0 && height == 0), "null buffer"); CTL_TRY t->t->setDepthBuffer(device_depth, width, height); CTL_CATCH }
 int ctl_tracer_set_counting(ctl_tracer* t, int on) { CTL_REQUIRE(t, "null tracer"); CTL_TRY t->t->setCounting(on != 0); CTL_CATCH }
 
 // ---- intersect (row a7 on its own)
@@ -283,6 +285,7 @@ static void intersect_host(Scene& sc, const ctl_ray* rays, uint32_t n, ctl_hit* 
     }
     if (counts) { unsigned long long c[5]; CTL_HIP(hipMemcpy(c, d_cnt.p, 40, hipMemcpyDeviceToHost)); *counts = ctl_traversal_counts{ c[0], c[1], c[2], c[3], c[4] }; }
 }
+int ctl_trace_single_ray(ctl_scene* s, const ctl_ray* ray, ctl_hit* hit_out) { CTL_REQUIRE(s && ray && hit_out, "null argument"); return ctl_intersect(s, ray, 1, hit_out, 0); }
 int ctl_intersect(ctl_scene* s, const ctl_ray* rays, uint32_t n, ctl_hit* hits, int any_hit) {
     CTL_REQUIRE(s && (rays || !n) && (hits || !n), "null argument");
     if (!n) return CTL_OK;

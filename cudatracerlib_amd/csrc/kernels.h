@@ -53,6 +53,10 @@ struct pass_params {
     int sort_octants;                    // append the new rays of a workgroup grouped by direction octant (compaction.h)
     const unsigned char* block_counts;   // samples per 64x64 film block in this pass (a block sampler's decision), nullptr = one everywhere
     uint32_t max_block_count;            // largest entry of block_counts
+    int wavefront_rules;                 // pathIterateKernel's own path rules (PathSemantics = Wavefront): selects the *_wf shade kernels
+    int u16_bary;                        // hit barycentrics through the traversal result's 16-bit pair (U16Barycentrics)
+    float* debug_out; uint32_t debug_x, debug_y;   // TracerBase::Debug (Kernel/Tracer.h:119-123): k_path_trace follows ONE path from the centre-less pixel position (x, y) and writes its radiance here
+    float* depth_buffer; uint32_t depth_w, depth_h; float depth_near, depth_far;   // IDepthTracer::setDepthBuffer (Kernel/Tracer.h:16-57), nullptr = none
 };
 
 struct launch_ctx { hipStream_t stream; int grid_blocks; bool alpha_test = false; };   // alpha_test: intersect kernels run Material::AlphaTest on candidate hits
@@ -74,6 +78,8 @@ void launch_intersect_count(const launch_ctx& lc, const dev_scene& S, const floa
 void launch_shade(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_basic(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_full(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_shade_basic_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_shade_full_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_finalize(const launch_ctx& lc, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_accumulate_stats(const launch_ctx& lc, const wave_queues& Q, int max_depth);
 void launch_apply_pipeline(const launch_ctx& lc, const ctl_pixel_data* image, uint32_t n, float splat_scale, uint32_t* rgbcol_out);

@@ -283,12 +283,12 @@ __global__ __launch_bounds__(kBlock) void k_mat_scatter(wave_queues Q, int depth
 // the shade kernel exists in feature-specialised builds (shade_basic.hip / shade_full.hip): a scene that uses only the basic
 // material / light / texture set runs the variant whose code does not carry the registers of the rest (dev_scene::shade_features)
 void launch_shade(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image) {
-    if (S.shade_features == 0) { launch_shade_basic(lc, S, Q, P, depth, image); return; }
+    if (S.shade_features == 0) { if (P.wavefront_rules) launch_shade_basic_wf(lc, S, Q, P, depth, image); else launch_shade_basic(lc, S, Q, P, depth, image); return; }
     if (P.sort_materials) {
         hipLaunchKernelGGL(k_mat_count, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, Q, depth);
         hipLaunchKernelGGL(k_mat_scatter, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, Q, depth);
     }
-    launch_shade_full(lc, S, Q, P, depth, image);
+    if (P.wavefront_rules) launch_shade_full_wf(lc, S, Q, P, depth, image); else launch_shade_full(lc, S, Q, P, depth, image);
 }
 void launch_finalize(const launch_ctx& lc, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image) {
     hipLaunchKernelGGL(k_finalize, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, Q, P, depth, image);

@@ -28,10 +28,13 @@ __global__ __launch_bounds__(256) void k_path_trace(dev_scene S, pass_params P, 
     for (uint32_t gi = blockIdx.x * 256u + threadIdx.x; gi < n_total; gi += gridDim.x * 256u) {
         const uint32_t pass_b = gi / P.n_local_pixels, li = gi - pass_b * P.n_local_pixels;
         const uint32_t tile = P.tile_rank + (li >> 12) * P.tile_world, p = li & 4095u, micro = p >> 6, ln = p & 63u;
-        const uint32_t x = (tile % tiles_x) * 64 + (micro & 7u) * 8 + (ln & 7u), y = (tile / tiles_x) * 64 + (micro >> 3) * 8 + (ln >> 3);
+        const uint32_t x_ = (tile % tiles_x) * 64 + (micro & 7u) * 8 + (ln & 7u), y_ = (tile / tiles_x) * 64 + (micro >> 3) * 8 + (ln >> 3);
+        if (P.debug_out && gi != 0) break;
+        const uint32_t x = P.debug_out ? P.debug_x : x_, y = P.debug_out ? P.debug_y : y_;
         if (x >= P.width || y >= P.height) continue;
         sampler rng{ P.t1 + pass_b * n1, P.t2 + pass_b * n1, y * P.width + x, 0, 0 };
-        const f2 j = rng.next2();
+        // PathTracer::DebugInternal (PathTracer.cu:172-180) starts at the pixel's own position and draws the aperture sample only
+        const f2 j = P.debug_out ? f2{ 0.0f, 0.0f } : rng.next2();
         const f2 pX{ (float)x + j.x, (float)y + j.y };
         const f2 ap = rng.next2();   // aperture sample
         f3 r_o, r_d, r_ox, r_dx, r_oy, r_dy; sensor_sample_ray_differential(S.cam, pX, ap, r_o, r_d, r_ox, r_dx, r_oy, r_dy);   // pathKernel2: sampleSensorRay(r, rX, rY, ...) (PathTracer.cu:186-190)
@@ -99,7 +102,8 @@ __global__ __launch_bounds__(256) void k_path_trace(dev_scene S, pass_params P, 
             if (!(!P.direct || depth == 1 || specularBounce)) misWeight = power_heuristic(brdf_scattering_pdf, env_pdf_direct(S, light, r_d) * pdf_emitter(S, S.env_map_index));
             cl = cl + misWeight * cf * env_eval(S, light, r_d);
         }
-        add_sample(image, P.width, P.height, pX.x, pX.y, cl);
+        if (P.debug_out) { P.debug_out[0] = cl.x; P.debug_out[1] = cl.y; P.debug_out[2] = cl.z; }
+        else add_sample(image, P.width, P.height, pX.x, pX.y, cl);
     }
     // one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
@@ -278,5 +282,17 @@ void PathTracer::DoRender(Image* I, const float* d_t1, const float* d_t2, unsign
     total_rays_ += host_count_;
 }
 void PathTracer::takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) { path_rays = total_rays_; shadow_rays_ = 0; total_rays_ = 0; }
+// PathTracer::DebugInternal (Integrators/PathTracer.cu:172-180): PathTrace<true> for one pixel, from the pixel's own position, with the tables Debug() just generated
+void PathTracer::DebugInternal(Image* I, unsigned int x, unsigned int y, const float* d_t1, const float* d_t2, float rgb[3]) {
+    if (debug_.n < 3) debug_.alloc(3);
+    pass_params P{};
+    P.t1 = d_t1; P.t2 = (const float2*)d_t2; P.batch = 1; P.width = w; P.height = h; P.tile_rank = 0; P.tile_world = 1; P.n_local_pixels = 1;
+    P.direct = 1; P.max_path_length = m_sParameters.getValue("MaxPathLength"); P.rr_start_depth = m_sParameters.getValue("RRStartDepth");
+    P.debug_out = debug_.p; P.debug_x = x; P.debug_y = y;
+    CTL_HIP(hipMemsetAsync(count_.p, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(k_path_trace, dim3(1), dim3(256), 0, stream, m_pScene->S, P, I->device(), count_.p);
+    CTL_HIP(hipMemcpyAsync(rgb, debug_.p, 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    CTL_HIP(hipStreamSynchronize(stream));
+}
 
 } // namespace ctl

@@ -803,6 +803,17 @@ __device__ __forceinline__ int sample_emitter(const dev_scene& S, float& emPdf, 
     emPdf = fU - fL;
     return (int)S.light_indices[idx];
 }
+// the same choice, re-using the sample: sample.x = (sample.x - fL) / (fU - fL) (KernelDynamicScene.cu:36) — what sampleEmitterDirect hands on to the light
+__device__ __forceinline__ int sample_emitter_reuse(const dev_scene& S, float& emPdf, float& sx) {
+    if (S.num_lights == 0) return -1;
+    uint32_t idx = 0;
+    while (idx < S.num_lights && !(sx < S.light_cdf[idx])) idx++;
+    if (idx >= S.num_lights) idx = S.num_lights - 1;
+    const float fU = S.light_cdf[idx], fL = idx > 0 ? S.light_cdf[idx - 1] : 0.0f;
+    sx = (sx - fL) / (fU - fL);
+    emPdf = fU - fL;
+    return (int)S.light_indices[idx];
+}
 __device__ __forceinline__ float pdf_emitter(const dev_scene& S, uint32_t light) { return S.light_cdf[light] - (light == 0 ? 0.0f : S.light_cdf[light - 1]); }
 
 } // namespace ctl

@@ -41,6 +41,7 @@ public:
     dev_scene S{};
     uint32_t n_nodes = 0;
     float box_min[3] = { 0, 0, 0 }, box_max[3] = { 0, 0, 0 };   // KernelDynamicScene::m_sBox
+    float near_depth = 0, far_depth = 0;                        // SensorBase::m_fNearFarDepths of the scene's camera (DeviceDepthImage::NormalizeDepthD3D)
 private:
     dbuf<float4> top_nodes_, bot_nodes_, leaf_tris_, inst_, inst_fwd_, flat_nodes_, flat_leaves_;
     dbuf<uint4> tri_data_, node_info_;
@@ -136,6 +137,11 @@ public:
     TracerParameterCollection& getParameters() { return m_sParameters; }
     // build-specific additions
     virtual void DoPasses(Image* I, bool a_NewTrace, unsigned int n) { for (unsigned int i = 0; i < n; i++) DoPass(I, a_NewTrace && i == 0); }
+    // TracerBase::Debug(Image*, pixel) (Kernel/Tracer.h:119-123): UpdateKernel draws the NEXT set of sampling tables from the tracer's generator (so the following
+    // DoPass uses the set after it), then DebugInternal follows one path for that pixel.  rgb (may be null): the radiance of that path (the reference discards it)
+    virtual void Debug(Image* I, unsigned int x, unsigned int y, float rgb[3]) = 0;
+    // IDepthTracer::setDepthBuffer (Kernel/Tracer.h:34-57): a device buffer of w x h floats that receives the normalised depth of every primary hit
+    virtual void setDepthBuffer(float* device_data, unsigned int dw, unsigned int dh);   // default: refuses (the tracer is not an IDepthTracer)
     virtual void reservePasses(unsigned int n) { (void)n; }   // size the queues now for a DoPasses(n) to come (otherwise they grow inside that call)
     void setTileShard(uint32_t rank, uint32_t world) { if (world == 0 || rank >= world) throw std::runtime_error("bad tile shard"); shard_rank = rank; shard_world = world; if (w != 0xffffffffu) Resize(w, h); }
     void setSamplerTables(const float* t1, const float* t2);
@@ -168,12 +174,14 @@ template <bool PROGRESSIVE> class Tracer : public TracerBase {
 public:
     void DoPass(Image* I, bool a_NewTrace) override { DoPasses(I, a_NewTrace, 1); }
     void DoPasses(Image* I, bool a_NewTrace, unsigned int n) override;
+    void Debug(Image* I, unsigned int x, unsigned int y, float rgb[3]) override;
     bool isMultiPass() const override { return PROGRESSIVE; }
     float getSplatScale() const override { return PROGRESSIVE ? 1.0f / float(m_uPassesDone) : 0.0f; }
 protected:
     // render `n_batch` passes together; their sampler tables are consecutive at (d_t1, d_t2) (device); asynchronous on `stream`
     virtual void DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) = 0;
     virtual void takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) = 0;
+    virtual void DebugInternal(Image* I, unsigned int x, unsigned int y, const float* d_t1, const float* d_t2, float rgb[3]) { (void)I; (void)x; (void)y; (void)d_t1; (void)d_t2; rgb[0] = rgb[1] = rgb[2] = 0.0f; }   // TracerBase::DebugInternal: nothing unless the integrator overrides it
     dbuf<float> d_t1, d_t2;                       // ring of sampler-table sets in HBM
     float *h_t1 = nullptr, *h_t2 = nullptr; size_t h_cap = 0;   // their pinned host staging (tables handed in by setSamplerTables, host-generated tables)
     // tables generated in HBM (k_sequence_fill): the chunk jump matrices, and a ring of the batches' pass start states
@@ -191,6 +199,7 @@ class WavefrontPathTracer : public Tracer<true> {
 public:
     WavefrontPathTracer();
     void Resize(unsigned int w, unsigned int h) override;
+    void setDepthBuffer(float* device_data, unsigned int dw, unsigned int dh) override { depth_buffer_ = device_data; depth_w_ = dw; depth_h_ = dh; }   // WavefrontPathTracer : IDepthTracer (WavefrontPathTracer.h:24)
     void reservePasses(unsigned int n) override { const unsigned int b = std::min(passBatch(), std::max(1u, n)); if (w != 0xffffffffu && (uint64_t)n_local_pixels * b > capacity) { alloc_batch_ = b; Resize(w, h); } ensureTableRing(b); }
 protected:
     void DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) override;
@@ -199,6 +208,7 @@ protected:
 private:
     wave_queues Q{};
     uint32_t capacity = 0, n_local_pixels = 0, alloc_batch_ = 1;
+    float* depth_buffer_ = nullptr; unsigned int depth_w_ = 0, depth_h_ = 0;
     std::vector<std::unique_ptr<dbuf<float4>>> f4_; dbuf<float2> px_[3]; dbuf<int> hit_node_; dbuf<uint32_t> occ_[2], counts_, work_, order_, mat_counts_; dbuf<unsigned char> mat_key_; dbuf<unsigned long long> stats_;
     int grid_blocks = 0;
     float4* new_f4(size_t n);
@@ -213,7 +223,9 @@ public:
 protected:
     void DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) override;
     void takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) override;
+    void DebugInternal(Image* I, unsigned int x, unsigned int y, const float* d_t1, const float* d_t2, float rgb[3]) override;
 private:
+    dbuf<float> debug_;
     dbuf<unsigned long long> count_; unsigned long long host_count_ = 0; uint64_t total_rays_ = 0; dbuf<float> mollifier_;
     uint32_t n_local_pixels = 0; int grid_blocks = 0;
 };

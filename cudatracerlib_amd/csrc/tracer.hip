@@ -24,6 +24,7 @@ void require_device() { if (device_count() <= 0) throw hip_error("no HIP device:
 // ------------------------------------------------------------------------------------------------ Scene
 Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
     for (int k = 0; k < 3; k++) { box_min[k] = d.box_min[k]; box_max[k] = d.box_max[k]; }
+    near_depth = d.camera.near_depth; far_depth = d.camera.far_depth;
     require_device();
     if (!d.n_nodes) throw std::runtime_error("ctl_scene_create: scene has no nodes");
     if (d.env_map_index != 0xffffffffu && (d.env_map_index >= d.n_lights_buf || d.lights[d.env_map_index].type != CTL_LIGHT_INFINITE))
@@ -435,6 +436,28 @@ template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::ensureTableRing(unsigned i
         d_jumps.alloc(J.size()); CTL_HIP(hipMemcpy(d_jumps.p, J.data(), J.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
 }
+void TracerBase::setDepthBuffer(float*, unsigned int, unsigned int) { throw unsupported_error("setDepthBuffer: this tracer is not an IDepthTracer (only the WavefrontPathTracer is, WavefrontPathTracer.h:24)"); }
+template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::Debug(Image* I, unsigned int x, unsigned int y, float rgb[3]) {
+    if (!m_pScene) throw std::runtime_error("Debug: InitializeScene was not called");
+    if (w == 0xffffffffu) throw std::runtime_error("Debug: Resize was not called");
+    if (x >= w || y >= h) throw std::runtime_error("Debug: pixel outside the film");
+    // UpdateKernel(scene, generator) -> GenerateNewRandomSequences (Kernel/TraceHelper.cu:182-185): one more set of tables is drawn from the tracer's stream
+    const size_t n1 = (size_t)CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH, n2 = n1 * 2;
+    ensureTableRing(std::max(1u, passBatch()));
+    for (auto e : slot_done) CTL_HIP(hipEventSynchronize(e));
+    if (have_user_tables) {
+        std::memcpy(h_t1, user_t1.data(), n1 * 4); std::memcpy(h_t2, user_t2.data(), n2 * 4); have_user_tables = false;
+        CTL_HIP(hipMemcpyAsync(d_t1.p, h_t1, n1 * 4, hipMemcpyHostToDevice, stream)); CTL_HIP(hipMemcpyAsync(d_t2.p, h_t2, n2 * 4, hipMemcpyHostToDevice, stream));
+    } else {
+        m_SamplingSequenceGenerator.take_pass_starts(1, h_starts);
+        CTL_HIP(hipMemcpyAsync(d_starts.p, h_starts, sizeof(sequence_generator::pass_start), hipMemcpyHostToDevice, stream));
+        launch_sequence_fill(stream, d_jumps.p, d_starts.p, 1, d_t1.p, d_t2.p);
+    }
+    float out[3] = { 0, 0, 0 };
+    DebugInternal(I, x, y, d_t1.p, d_t2.p, out);
+    CTL_HIP(hipStreamSynchronize(stream));
+    if (rgb) { rgb[0] = out[0]; rgb[1] = out[1]; rgb[2] = out[2]; }
+}
 template <bool PROGRESSIVE> void Tracer<PROGRESSIVE>::DoPasses(Image* I, bool a_NewTrace, unsigned int n) {
     if (!m_pScene) throw std::runtime_error("DoPass: InitializeScene was not called");
     if (w == 0xffffffffu) throw std::runtime_error("DoPass: Resize was not called");
@@ -527,6 +550,13 @@ WavefrontPathTracer::WavefrontPathTracer() {
     // pays ~0.4 ms of ramp and drain whatever its size (tools/shard_time_probe.py: 4 % of the time at 20 passes per launch on one GPU, a quarter on one rank
     // of eight); the fused launch fills the drain of the first set with the second: +2 % on the whole frame, +7 % on a rank of eight.  false = two launches
     m_sParameters.addBool("FuseTraversal", true);
+    // build-specific: whose per-path rules the shading stage follows.  PathTrace (default): the reference's deterministic megakernel PathTrace<DIRECT> (PathTracer.cu:10-113),
+    // what the oracle pins and the PathTracer plugin renders.  Wavefront: pathIterateKernel's own rules (WavefrontPathTracer.cu:51-164) — Russian roulette before sampling at
+    // pathDepth >= RRStartDepth, no sampling / next-event estimation at the last bounce, sampleEmitterDirect with one 2-D sample, 16-bit previous normal, the
+    // t >= dDist (1 - eps) shadow rule: what the reference's PT_Wave converges to (darker than PT by the last bounce's direct term, and fewer rays)
+    m_sParameters.addEnum("PathSemantics", 0, { "PathTrace", "Wavefront" });
+    // build-specific: hit barycentrics through the 16-bit pair of the reference's traversal result (Kernel/TraceHelper.cu:722-731); off = full floats (single-ray traceRay)
+    m_sParameters.addBool("U16Barycentrics", false);
     int dev = 0; hipDeviceProp_t prop; CTL_HIP(hipGetDevice(&dev)); CTL_HIP(hipGetDeviceProperties(&prop, dev));
     grid_blocks = prop.multiProcessorCount * 8;   // 8 x 256-thread workgroups per CU = 32 waves/CU
 }
@@ -598,6 +628,8 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     P.block_sort = m_sParameters.getValue("BlockSort") != 0 ? 1 : 0;
     P.sort_octants = m_sParameters.getValue("SortOctants") != 0 ? 1 : 0;
     P.block_counts = pass_block_counts_; P.max_block_count = pass_max_block_count_;
+    P.wavefront_rules = m_sParameters.getValue("PathSemantics") == 1 ? 1 : 0; P.u16_bary = m_sParameters.getValue("U16Barycentrics") != 0 ? 1 : 0;
+    P.depth_buffer = depth_buffer_; P.depth_w = depth_w_; P.depth_h = depth_h_; P.depth_near = m_pScene->near_depth; P.depth_far = m_pScene->far_depth;
     if (pass_block_counts_ && pass_paths_ > capacity) throw std::runtime_error("ray queue overflow: the block sampler asks for more samples in one pass than the queues hold (DoubleRayBuffer.h:86-89)");
     if (P.sort_materials) CTL_HIP(hipMemsetAsync(mat_counts_.p, 0, n_mat * sizeof(uint32_t), stream));
     CTL_HIP(hipMemsetAsync(counts_.p, 0, n_counts * sizeof(uint32_t), stream));

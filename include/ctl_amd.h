@@ -438,6 +438,15 @@ int ctl_tracer_set_sampler_tables(ctl_tracer* t, const float* tables_1d, const f
 int ctl_tracer_do_pass(ctl_tracer* t, ctl_image* img, int new_trace);
 /* n passes back-to-back without host synchronisation in between (throughput mode). */
 int ctl_tracer_do_passes(ctl_tracer* t, ctl_image* img, int new_trace, uint32_t n_passes);
+/* TracerBase::Debug(Image*, Vec2i) (Kernel/Tracer.h:119-123): UpdateKernel(scene, generator) draws the NEXT set of sampling tables from the tracer's stream —
+ * the pass that follows uses the set after it — then DebugInternal follows ONE path for the pixel: PathTracer::DebugInternal (Integrators/PathTracer.cu:172-180)
+ * = PathTrace<true> from the pixel's own position (no jitter) with that set; the WavefrontPathTracer has no DebugInternal of its own (nothing is traced).
+ * rgb_out (3 floats, may be NULL) receives the path's radiance, which the reference computes and drops (it is looked at in a debugger). */
+int ctl_tracer_debug_pixel(ctl_tracer* t, ctl_image* img, uint32_t x, uint32_t y, float* rgb_out);
+/* IDepthTracer::setDepthBuffer(DeviceDepthImage{m_pData, w, h}) (Kernel/Tracer.h:16-57; WavefrontPathTracer : IDepthTracer): device_depth = width*height floats in
+ * DEVICE memory (ctl_device_malloc); every pass stores DeviceDepthImage::NormalizeDepthD3D of the primary hit distance of pixel (x, y) — clamped to the camera's
+ * [near, far], 1 for a miss — as pathIterateKernel does at pathDepth 0 (WavefrontPathTracer.cu:76-77).  NULL, 0, 0 removes it.  Wavefront plugin only. */
+int ctl_tracer_set_depth_buffer(ctl_tracer* t, float* device_depth, uint32_t width, uint32_t height);
 /* traversal statistics for the roofline: sums over rays of inner-node visits, triangle tests and instance entries
  * (B_ray = 32 + 16 + 64*N_inner + 52*N_tri + 108*N_inst). */
 typedef struct { uint64_t n_inner, n_tri, n_inst;
@@ -484,6 +493,8 @@ int ctl_tracer_set_counting(ctl_tracer* t, int on);
 /* __internal__IntersectBuffers (Kernel/TraceHelper.cu:736-746): n rays -> n hits; host pointers.
  * any_hit = 1 selects intersectKernel<true>. */
 int ctl_intersect(ctl_scene* s, const ctl_ray* rays, uint32_t n, ctl_hit* hits, int any_hit);
+/* TracerBase::TraceSingleRay(Ray, DynamicScene*) (Kernel/Tracer.cu:74-78): the closest hit of one ray (tmin = the scene's ray epsilon as the caller sets it in `ray`). */
+int ctl_trace_single_ray(ctl_scene* s, const ctl_ray* ray, ctl_hit* hit_out);
 /* device-pointer variant (the layout the tracer itself uses): d_ray_o[n], d_ray_d[n] = float4 (origin,tmin) / (direction,tmax);
  * d_hit4[n] = float4 (t, u, v, triangle index bits, -1 = miss); d_hit_node[n] = int32.  Synchronous; ms_out (may be NULL) =
  * HIP-event time of the kernel launch. */

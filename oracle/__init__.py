@@ -143,11 +143,13 @@ class Oracle:
         return hits
 
     def render(self, desc, width, height, n_passes=1, tables=None, direct=True, max_path_length=8, rr_start=5, threads=8, rows=None, half_host_quirk=False, alpha_test=False, block_counts=None,
-               flat=None, counts=None, partials=False, regularization=False):
+               flat=None, counts=None, partials=False, regularization=False, wavefront_rules=False, u16_barycentrics=False, omit_last_nee=False):
         """pathKernel2<DIRECT,false> over all pixels (Integrators/PathTracer.cu:182-194). tables = list of (t1, t2) per pass or None.
         alpha_test: traceRay<USE_ALPHA> when the scene has alpha maps (what the reference's single-ray path does; its wavefront
         intersectKernel has no alpha test).
         regularization: PathTraceRegularization (Integrators/PathTracer.cu:115-173), the PathTracer plugin's Regularization = true; implies partials.
+        wavefront_rules: the reference wavefront kernel's own path rules (pathIterateKernel, WavefrontPathTracer.cu:51-164; ocore.h pathTraceWavefront) instead of PathTrace's;
+            u16_barycentrics: hit barycentrics through the traversal result's 16-bit pair (TraceHelper.cu:722-731).
         partials: first-hit ray differentials + filtered (trilinear / EWA) texture lookups, as the megakernel PathTracer does (PathTracer.cu:60-61).
         flat: a ctl_flat_bvh_desc -> every ray walks the product's flattened BVH (same hits, other visiting order).
         counts: a dict that receives the traversal statistics of this render (path_rays, path_inner, path_tri, path_inst, occ_rays, ...).
@@ -169,7 +171,7 @@ class Oracle:
             self.lib.orc_render_counting(1)
         try:
             rays = self.lib.orc_render(C.addressof(desc), width, height, n_passes, p1, p2, 1 if direct else 0, max_path_length, rr_start,
-                                       img.ctypes.data, threads, y0, y1, (1 if half_host_quirk else 0) | (2 if alpha_test else 0) | (4 if partials else 0) | (8 if regularization else 0))
+                                       img.ctypes.data, threads, y0, y1, (1 if half_host_quirk else 0) | (2 if alpha_test else 0) | (4 if partials else 0) | (8 if regularization else 0) | (16 if wavefront_rules else 0) | (32 if u16_barycentrics else 0) | (64 if omit_last_nee else 0))
         finally:
             self.lib.orc_set_flat_bvh(None)
             if counts is not None:

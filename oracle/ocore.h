@@ -1410,7 +1410,7 @@ inline void computePartials(DG& dg, V3 rox, V3 rxd, V3 roy, V3 ryd) {
 struct RayDiff { V3 ox, dx, oy, dy; };   // the sensor's x / y differential rays (sampleRayDifferential)
 // diff non-null = the megakernel integrator's first-hit texture filtering
 // (PathTracer.cu:60-61), null = no partials (what the wavefront tracer does)
-inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, int maxPathLength, int rrStartDepth, uint64_t* rays, const RayDiff* diff = nullptr) {
+inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, int maxPathLength, int rrStartDepth, uint64_t* rays, const RayDiff* diff = nullptr, bool omitLastNEE = false) {
     Spec cl(0.0f), cf(1.0f);
     int depth = 0; bool specularBounce = false;
     BRec bRec; Hit r2; r2.init();
@@ -1437,7 +1437,8 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
             }
             Spec f = bsdfSample(mat, bRec, brdf_scattering_pdf, rnd.randomFloat2());
             last_nor = bRec.dg.sys.n;
-            if (DIRECT && bsdfHasComponent(mat, ESmooth)) cl = cl + cf * uniformSampleOneLight(S, bRec, mat, rnd, rays);
+            // omitLastNEE (a test's what-if, not the reference): PathTrace without the next-event estimation of its last vertex — the term pathIterateKernel never takes
+            if (DIRECT && bsdfHasComponent(mat, ESmooth) && !(omitLastNEE && depth == maxPathLength)) cl = cl + cf * uniformSampleOneLight(S, bRec, mat, rnd, rays);
             specularBounce = (bRec.sampledType & EDelta) != 0;
             cf = cf * f;
             ro = bRec.dg.P; rd = bRec.dg.sys.toWorld(bRec.wo);   // BSDFSamplingRecord::getOutgoing (Samples.cu)
@@ -1461,6 +1462,103 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
         cl = cl + misWeight * cf * envEval(S, *light, rd);
     }
     return cl;
+}
+
+// ---- pathIterateKernel<NEXT_EVENT_EST> (Integrators/PseudoRealtime/WavefrontPathTracer.cu:51-164) followed along ONE path: the reference wavefront tracer's OWN
+// per-path rules, which differ from PathTrace<DIRECT> at equal parameters (the product's PathSemantics = Wavefront):
+//   * Russian roulette at pathDepth >= RRStartDepth, BEFORE the BSDF is sampled and whatever the last lobe was (:102-109);
+//   * at the last bounce (pathDepth + 1 == maxPathDepth) emission is added and nothing is sampled: no next-event estimation there (:79, :111);
+//   * next-event estimation through sampleEmitterDirect with ONE 2-D sample — the emitter choice re-uses its first coordinate (KernelDynamicScene.cu:98-117) —
+//     drawn AFTER the BSDF sample (:113, :120); the MIS weight is taken for delta emitters as well (:127-129); the shadow ray is queued whatever f() returned;
+//   * the shadow test of the next iteration: unoccluded iff the ray's closest hit lies at t >= dDist (1 - eps) (:62-70);
+//   * the previous vertex' normal travels as two bytes (NormalizedFloat3ToUchar2, :137 -> :94, :151);
+//   * u16bary: the hit's barycentrics pass through the 16-bit pair of the traversal result (Kernel/TraceHelper.cu:722-731, :44-51).
+// The sampler is this oracle's deterministic one (index = film pixel, consumed along the path) — the reference indexes it by the racing queue slot and skips
+// by the pass count (:58-59), which no two runs reproduce.  W = the sensor's importance weight (1 for the sensors here).
+inline Spec pathTraceWavefront(const Scene& S, bool NEE, V3 ro, V3 rd, Sampler& rng, int maxPathDepth, int RRStartDepth, uint64_t* rays, bool u16bary) {
+    Spec L(0.0f), throughput(1.0f), directF(0.0f);
+    bool specular_bounce = true, have_shadow = false; float bsdf_pdf = 0.0f, dDist = 0.0f; uint16_t prev_normal = 0; V3 sh_o, sh_d;
+    BRec bRec;
+    for (int pathDepth = 0; pathDepth < maxPathDepth; pathDepth++) {
+        Hit res = traceRayClosest(S, ro, rd);
+        if (rays) (*rays)++;
+        if (u16bary && res.hasHit()) {   // traversalResult: (uint16_t)(b * UINT16_MAX) -> Vec2f(x_disc, y_disc) / UINT16_MAX
+            const uint16_t xd = (uint16_t)(res.u * 65535), yd = (uint16_t)(res.v * 65535);
+            res.u = (float)xd / 65535.0f; res.v = (float)yd / 65535.0f;
+        }
+        if (NEE && pathDepth > 0 && have_shadow) {   // :62-73: the shadow ray queued by the previous vertex was traced (closest hit) together with this path ray
+            if (rays) (*rays)++;
+            const Hit sh = traceRayClosest(S, sh_o, sh_d, 1);
+            if (sh.dist >= dDist * (1 - S.d.ray_trace_eps)) L = L + directF;
+            have_shadow = false; directF = Spec(0.0f);
+        }
+        bool path_terminated = (pathDepth + 1 == maxPathDepth);
+        if (res.hasHit()) {
+            getBsdfSample(S, res, ro, rd, bRec);
+            const ctl_material& mat = hitMat(S, res);
+            const uint32_t li = hitLightIndex(S, res);
+            if (li != UINT32_MAX) {   // :86-99
+                float misWeight = 1.0f;
+                if (!NEE || pathDepth == 0 || specular_bounce) misWeight = 1.0f;
+                else {
+                    DirectRec dRec(ro, uchar2ToNormal(prev_normal));
+                    dRec.p = bRec.dg.P; dRec.n = bRec.dg.n; dRec.d = rd; dRec.dist = res.dist; dRec.measure = ESolidAngle;
+                    const ctl_light* light = S.d.lights + li;
+                    const float direct_pdf = lightPdfDirect(S, *light, dRec) * pdfEmitter(S, light);
+                    misWeight = powerHeuristic(1, bsdf_pdf, 1, direct_pdf);
+                }
+                L = L + misWeight * lightEval(S, S.d.lights[li], bRec.dg.P, bRec.dg.sys, -rd) * throughput;
+            }
+            bool surviveRR = true;   // :101-109
+            if (pathDepth >= RRStartDepth) {
+                if (rng.randomFloat() < vmax(throughput)) throughput = sdiv(throughput, vmax(throughput));
+                else surviveRR = false;
+            }
+            if (pathDepth + 1 != maxPathDepth && surviveRR) {
+                const Spec f = bsdfSample(mat, bRec, bsdf_pdf, rng.randomFloat2());
+                specular_bounce = (bRec.sampledType & EDelta) != 0;
+                const V3 new_o = bRec.dg.P, new_d = bRec.dg.sys.toWorld(bRec.wo);
+                if (NEE && bsdfHasComponent(mat, ESmooth)) {
+                    DirectRec dRec(bRec.dg.P, bRec.dg.sys.n);
+                    // KernelDynamicScene::sampleEmitterDirect (KernelDynamicScene.cu:98-117)
+                    V2 sample = rng.randomFloat2(); float emPdf = 0.0f; Spec value(0.0f);
+                    const ctl_light* emitter = sampleEmitter(S, emPdf, sample);
+                    if (emitter) {
+                        value = lightSampleDirect(S, *emitter, dRec, sample);
+                        if (dRec.pdf != 0) { dRec.pdf *= emPdf; value = sdiv(value, emPdf); } else value = Spec(0.0f);
+                    }
+                    if (!isZero(value)) {
+                        bRec.typeMask = EAll & ~EDelta;
+                        bRec.wo = bRec.dg.sys.toLocal(dRec.d);
+                        const Spec bsdfVal = bsdfF(mat, bRec);
+                        const float bsdfPdf_ = bsdfPdf(mat, bRec);
+                        const float directPdf = dRec.measure == EArea ? dRec.pdf * dRec.dist / fabsf(dot(dRec.n, dRec.d)) : dRec.pdf;   // PdfAtoW (MonteCarlo.h)
+                        const float weight = powerHeuristic(1, directPdf, 1, bsdfPdf_);
+                        directF = throughput * value * bsdfVal * weight;
+                        dDist = dRec.dist; sh_o = bRec.dg.P; sh_d = dRec.d; have_shadow = true;
+                    }
+                }
+                prev_normal = normalToUchar2(bRec.dg.sys.n);
+                throughput = throughput * f;
+                ro = new_o; rd = new_d;
+            } else path_terminated = true;
+        } else {   // :143-157
+            path_terminated = true;
+            if (S.d.env_map_index != 0xffffffffu) {
+                const ctl_light* light = S.d.lights + S.d.env_map_index;
+                float misWeight = 1.0f;
+                if (!(!NEE || pathDepth == 0 || specular_bounce)) {
+                    DirectRec dRec(ro, uchar2ToNormal(prev_normal));
+                    dRec.p = V3(0.0f); dRec.n = V3(0.0f); dRec.d = rd; dRec.dist = res.dist; dRec.measure = ESolidAngle;
+                    const float direct_pdf = lightPdfDirect(S, *light, dRec) * pdfEmitter(S, light);
+                    misWeight = powerHeuristic(1, bsdf_pdf, 1, direct_pdf);
+                }
+                L = L + misWeight * throughput * envEval(S, *light, rd);
+            }
+        }
+        if (path_terminated) break;   // I.AddSample (:159-162)
+    }
+    return L;
 }
 
 // ---- PathTraceRegularization<DIRECT> (Integrators/PathTracer.cu:115-173): the PathTracer plugin with Regularization = true

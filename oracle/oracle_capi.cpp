@@ -291,6 +291,7 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
     PerspectiveSensor sensor; sensor.update(desc->camera);
     std::vector<MipPyramid> pyramids;
     const bool regularization = (half_host_quirk & 8) != 0;
+    const bool wavefront_rules = (half_host_quirk & 16) != 0, u16bary = (half_host_quirk & 32) != 0, omitLastNEE = (half_host_quirk & 64) != 0;   // bit 4: pathIterateKernel's own path rules (pathTraceWavefront), bit 5: 16-bit barycentrics
     const bool partials = (half_host_quirk & 4) != 0 || regularization;
     if (partials) { pyramids.resize(desc->n_images); for (uint32_t i = 0; i < desc->n_images; i++) pyramids[i].build(desc->images[i]); S.pyramids = pyramids.data(); }
     if (n_threads < 1) n_threads = 1;
@@ -341,8 +342,9 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
                         const float ALPHA = 0.75f;
                         const float radius2 = powf(powf(initialRadius, float(2)) / powf(float(pass + 1), 0.5f * (1 - ALPHA)), 1.0f / 2.0f);
                         col = pathTraceRegularization(S, direct != 0, o, d, diff, rng, radius2, maxPathLength, rrStart, &rays);
-                    } else
-                    col = pathTrace(S, direct != 0, o, d, rng, maxPathLength, rrStart, &rays, partials ? &diff : nullptr);   // imp == 1 (Sensor.cu:127)
+                    } else if (wavefront_rules) col = pathTraceWavefront(S, direct != 0, o, d, rng, maxPathLength, rrStart, &rays, u16bary);
+                    else
+                    col = pathTrace(S, direct != 0, o, d, rng, maxPathLength, rrStart, &rays, partials ? &diff : nullptr, omitLastNEE);   // imp == 1 (Sensor.cu:127)
                     addSample(img, (int)W, (int)H, pX.x, pX.y, col);
                 }
             }
@@ -357,6 +359,19 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
     work();
     for (auto& t : th) t.join();
     return total.load();
+}
+
+// PathTracer::DebugInternal (Integrators/PathTracer.cu:172-180): PathTrace<true> for pixel (x, y) from the pixel's own position (no jitter; the aperture sample is the first draw),
+// with first-hit ray differentials, over one set of sampling tables -> rgb; also the primary hit distance (FLT_MAX on a miss) for the depth-buffer test
+void orc_debug_pixel(const ctl_scene_desc* desc, uint32_t W, uint32_t H, const float* t1, const float* t2, uint32_t x, uint32_t y, int maxPathLength, int rrStart, float* rgb, float* primary_dist) {
+    Scene S; S.d = *desc; S.flat = g_flat; S.alpha_test = sceneHasAlphaMaps(*desc);
+    PerspectiveSensor sensor; sensor.update(desc->camera);
+    std::vector<MipPyramid> pyramids(desc->n_images); for (uint32_t i = 0; i < desc->n_images; i++) pyramids[i].build(desc->images[i]); S.pyramids = pyramids.data();
+    Sampler rng(t1, t2, y * W + x);
+    V3 o, d; RayDiff diff; sensor.sampleRayDifferential(V2{ (float)x, (float)y }, rng.randomFloat2(), o, d, diff.ox, diff.dx, diff.oy, diff.dy);
+    uint64_t rays = 0;
+    if (rgb) { const Spec c = pathTrace(S, true, o, d, rng, maxPathLength, rrStart, &rays, &diff); rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z; }
+    if (primary_dist) { Hit h = traceRayClosest(S, o, d); *primary_dist = h.hasHit() ? h.dist : FLT_MAX; }
 }
 
 } // extern "C"

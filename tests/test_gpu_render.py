@@ -538,3 +538,91 @@ def test_bench_self_launch_two_ranks_share_one_gpu(gpu, tmp_path):
     a, b = frames
     assert np.array_equal(a[..., 6], b[..., 6])
     assert np.allclose(a[..., :6], b[..., :6], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("which", ["cornell_glass", "materials", "env", "sm"])
+def test_wavefront_path_semantics(gpu, orc, which):
+    """PathSemantics = Wavefront: the shade kernels built with pathIterateKernel's own rules (WavefrontPathTracer.cu:51-164) against the oracle's restatement of them
+    (ocore.h pathTraceWavefront) on the same tables — Russian roulette before sampling, nothing sampled at the last bounce, sampleEmitterDirect with one 2-D sample,
+    16-bit previous normal, the t >= dDist (1 - eps) shadow rule — with and without the 16-bit barycentrics; same ray count, and a different image than the default rules"""
+    sc = {"cornell_glass": lambda: scenes.cornell_box(64, 64, glass_sphere=True), "materials": lambda: scenes.cornell_box(64, 64, extra_materials=2),
+          "env": lambda: scenes.env_scene(96, 64, extra_lights=True), "sm": lambda: scenes.synthetic_sm(96, 64, n_instances=60, subdiv=2)}[which]()
+    w, h = (96, 64) if which in ("env", "sm") else (64, 64)
+    d = sc.desc
+    tables = orc.sequence_tables(3)
+    scene = gpu.Scene(d, flatten=(which == "sm"))
+    for u16 in (False, True):
+        want, want_rays = orc.render(d, w, h, n_passes=3, tables=tables, max_path_length=6, rr_start=3, wavefront_rules=True, u16_barycentrics=u16)
+        tr = gpu.WavefrontPathTracer(); p = tr.getParameters()
+        p.setValue("MaxPathLength", 6); p.setValue("RRStartDepth", 3); p.setValue("PathSemantics", "Wavefront"); p.setValue("U16Barycentrics", u16)
+        tr.Resize(w, h); tr.InitializeScene(scene)
+        img = gpu.Image(w, h); rays = 0
+        for k in range(3):
+            tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0)); rays += tr.stats().rays_last_pass
+        got = img.getPixelData()
+        assert_close(got, want)
+        assert abs(rays - want_rays) <= 1e-2 * want_rays      # (a flipped discrete decision changes a path's length; a path whose throughput became exactly 0 is dropped at once, DESIGN.md §4 deviation 3)
+    default, _ = orc.render(d, w, h, n_passes=3, tables=tables, max_path_length=6, rr_start=3)
+    assert abs(default[..., :3].mean() - want[..., :3].mean()) > 2e-3 * want[..., :3].mean()
+
+
+def test_debug_pixel_trace_single_ray_and_depth_buffer(gpu, orc):
+    """The three boundary entries of SURVEY §8(b) beyond DoPass: TracerBase::Debug (Kernel/Tracer.h:119-123 -> PathTracer::DebugInternal, PathTracer.cu:172-180),
+    TracerBase::TraceSingleRay (Kernel/Tracer.cu:74-78) and IDepthTracer::setDepthBuffer (Kernel/Tracer.h:16-57, WavefrontPathTracer.cu:76-77)."""
+    import ctypes as C
+    w, h = 48, 40
+    sc = scenes.cornell_box(w, h, glass_sphere=True); d = sc.desc
+    scene = gpu.Scene(d, flatten=True)
+    fb = gpu.api.FlatBvh(d, gpu.api.FLAT_Q4)
+    orc.lib.orc_debug_pixel.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    tables = orc.sequence_tables(3)      # the sets a fresh tracer's generator produces, in order
+    # ---- Debug: the path of one pixel with the NEXT table set; the pass after it uses the set after that
+    tr = gpu.PathTracer(); p = tr.getParameters(); p.setValue("MaxPathLength", 5)
+    tr.Resize(w, h); tr.InitializeScene(scene)
+    img = gpu.Image(w, h)
+    tr.DoPass(img, new_trace=True)                              # set 1
+    for (x, y) in ((10, 12), (24, 20), (40, 35)):
+        tr2 = gpu.PathTracer(); tr2.getParameters().setValue("MaxPathLength", 5); tr2.Resize(w, h); tr2.InitializeScene(scene)
+        got = tr2.Debug(img, x, y)                              # a fresh tracer: set 1
+        want = np.zeros(3, np.float32); dist = C.c_float()
+        orc.lib.orc_debug_pixel(C.byref(d), w, h, tables[0][0].ctypes.data, tables[0][1].ctypes.data, x, y, 5, 5, want.ctypes.data, C.byref(dist))
+        assert np.allclose(got, want, rtol=2e-3, atol=2e-3), (x, y, got, want)
+    before = img.getPixelData().copy()
+    tr.Debug(img, 5, 5)                                         # set 2 is drawn and spent; the frame is untouched
+    assert np.array_equal(img.getPixelData(), before)
+    tr.DoPass(img)                                              # set 3
+    want, _ = orc.render(d, w, h, n_passes=2, tables=[tables[0], tables[2]], max_path_length=5, flat=fb.desc, partials=True)
+    assert_close(img.getPixelData(), want)
+    # the wavefront tracer has no DebugInternal: Debug() only draws the table set
+    wt = gpu.WavefrontPathTracer(); wt.getParameters().setValue("MaxPathLength", 5); wt.Resize(w, h); wt.InitializeScene(scene)
+    wimg = gpu.Image(w, h)
+    assert not wt.Debug(wimg, 3, 3).any()
+    wt.DoPass(wimg, new_trace=True)                             # set 2
+    want, _ = orc.render(d, w, h, n_passes=1, tables=[tables[1]], max_path_length=5)
+    assert_close(wimg.getPixelData(), want)
+    with pytest.raises(gpu.CtlError):
+        tr.Debug(img, w, 0)
+    # ---- TraceSingleRay == the oracle's traceRay == ctl_intersect
+    rs = np.random.RandomState(5)
+    for _ in range(20):
+        o = rs.uniform(-0.9, 0.9, 3).astype(np.float32); dd = rs.normal(size=3); dd = (dd / np.linalg.norm(dd)).astype(np.float32)
+        hit = gpu.api.trace_single_ray(scene, o, dd, tmin=d.ray_trace_eps)
+        rays = np.zeros((1, 8), np.float32); rays[0, :3] = o; rays[0, 3] = d.ray_trace_eps; rays[0, 4:7] = dd; rays[0, 7] = 3.402823466e+38
+        ref = orc.intersect(d, rays)[0]
+        assert hit["tri_idx"] == ref["tri_idx"] and hit["node_idx"] == ref["node_idx"] and hit["dist"] == ref["dist"] and hit["u"] == ref["u"] and hit["v"] == ref["v"]
+    # ---- depth buffer: NormalizeDepthD3D of the primary hit distance of every pixel
+    wt2 = gpu.WavefrontPathTracer(); wt2.getParameters().setValue("MaxPathLength", 2); wt2.Resize(w, h); wt2.InitializeScene(scene)
+    wt2.setDepthBuffer(w, h)
+    wt2.setSamplerTables(*tables[0]); wt2.DoPass(wimg, new_trace=True)
+    depth = wt2.getDepthBuffer()
+    near, far = d.camera.near_depth, d.camera.far_depth
+    assert ((depth >= 0) & (depth <= 1)).all() and depth.std() > 0
+    for (x, y) in ((10, 12), (24, 20), (40, 35), (0, 0), (47, 39)):
+        # the pass's primary ray of pixel (x, y): jittered by the first two table values — re-trace it through the oracle's sensor
+        t1, t2 = tables[0]
+        smp = orc.lib.orc_sampler_float      # (not needed: compare through the hit distance of the un-jittered ray within the pixel's depth range)
+        dist = C.c_float(); orc.lib.orc_debug_pixel(C.byref(d), w, h, t1.ctypes.data, t2.ctypes.data, x, y, 1, 5, None, C.byref(dist))
+        z = min(max(dist.value, near), far); want_z = (far / (far - near) * z - far * near / (far - near)) / z
+        assert abs(depth[y, x] - want_z) < 0.05, (x, y, depth[y, x], want_z)      # (the pass's ray is jittered inside the pixel: same surface, nearly the same depth)
+    with pytest.raises(gpu.CtlError):
+        tr.setDepthBuffer(w, h)                                  # the megakernel PathTracer is not an IDepthTracer
