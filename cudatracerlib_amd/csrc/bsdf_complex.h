@@ -9,7 +9,7 @@ namespace ctl {
 
 enum { kMeasSolidAngle = 1, kMeasDiscrete = 4 };
 __device__ __forceinline__ int bsdf_measure(uint32_t t) { return (t & kESmooth) ? kMeasSolidAngle : ((t & kEDelta) ? kMeasDiscrete : kMeasSolidAngle); }   // BSDF::getMeasure (BSDF.h:66-80)
-__device__ __forceinline__ f3 exp3(f3 s) { return f3(expf(s.x), expf(s.y), expf(s.z)); }
+__device__ __forceinline__ f3 exp3(f3 s) { return f3(m_exp(s.x), m_exp(s.y), m_exp(s.z)); }
 
 __device__ f3 bsdf_f_discrete(const ctl_material& M, const bsdf_rec& b) {
     const float kDeltaEps = 1e-3f;

@@ -25,7 +25,7 @@ __device__ f3 phong_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simp
     f3 result(0.0f);
     if (b.type_mask & CTL_EGlossyReflection) {
         const float alpha = dot(b.wo, reflect_local(b.wi)), e = avg3(tex_eval(M.tex[2], b.dg));
-        if (alpha > 0.0f) result = result + tex_eval(M.tex[1], b.dg) * ((e + 2) * kInvTwoPi * powf(alpha, e));
+        if (alpha > 0.0f) result = result + tex_eval(M.tex[1], b.dg) * ((e + 2) * kInvTwoPi * m_pow(alpha, e));
     }
     if (b.type_mask & CTL_EDiffuseReflection) result = result + tex_eval(M.tex[0], b.dg) * kInvPi;
     return result * cos_theta(b.wo);
@@ -35,7 +35,7 @@ __device__ float phong_pdf(const ctl_material& M, const bsdf_rec& b) {   // BSDF
     const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
     float dp = 0.0f, sp = 0.0f;
     if (hd) dp = kInvPi * cos_theta(b.wo);
-    if (hs) { const float alpha = dot(b.wo, reflect_local(b.wi)), e = avg3(tex_eval(M.tex[2], b.dg)); if (alpha > 0) sp = powf(alpha, e) * (e + 1.0f) / (2.0f * kPi); }
+    if (hs) { const float alpha = dot(b.wo, reflect_local(b.wi)), e = avg3(tex_eval(M.tex[2], b.dg)); if (alpha > 0) sp = m_pow(alpha, e) * (e + 1.0f) / (2.0f * kPi); }
     if (hd && hs) return M.f[0] * sp + (1 - M.f[0]) * dp;
     return hd ? dp : (hs ? sp : 0.0f);
 }
@@ -119,9 +119,9 @@ __device__ f3 bsdf_more_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f
         if (spec) {
             const f3 R = reflect_local(b.wi);
             const float e = avg3(tex_eval(M.tex[2], b.dg));
-            const float sinA = sqrtf(1 - powf(smp.y, 2 / (e + 1))), cosA = powf(smp.y, 1 / (e + 1)), phi = (2.0f * kPi) * smp.x;
+            const float sinA = sqrtf(1 - m_pow(smp.y, 2 / (e + 1))), cosA = m_pow(smp.y, 1 / (e + 1)), phi = (2.0f * kPi) * smp.x;
             frame fr; fr.n = R; coordinate_system(R, fr.s, fr.t);
-            b.wo = normalize(fr.to_world(f3(sinA * cosf(phi), sinA * sinf(phi), cosA))); b.sampled_type = CTL_EGlossyReflection;
+            b.wo = normalize(fr.to_world(f3(sinA * m_cos(phi), sinA * m_sin(phi), cosA))); b.sampled_type = CTL_EGlossyReflection;
             if (cos_theta(b.wo) <= 0) return f3(0.0f);
         } else { b.wo = square_to_cosine_hemisphere(smp); b.sampled_type = CTL_EDiffuseReflection; }
         b.eta = 1.0f;

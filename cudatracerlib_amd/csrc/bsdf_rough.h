@@ -48,13 +48,13 @@ __device__ float eval_cubic_interp_3d(float px, float py, float pz, const float*
 // RoughTransmittanceManager::Evaluate / EvaluateDiffuse for the table of slot `type`
 __device__ float rough_transmittance(const diff_geom& dg, uint32_t type, float cosTheta, float alpha, float eta) {
     const ctl_rough_transmittance& T = dg.rough_transmittance[type];
-    const float warpedCosTheta = powf(fabsf(cosTheta), 0.25f);
+    const float warpedCosTheta = m_pow(fabsf(cosTheta), 0.25f);
     if (cosTheta < 0) { cosTheta = -cosTheta; eta = 1.0f / eta; }
     const float* data = T.trans;
     if (eta < 1) { data += (size_t)T.eta_samples * T.alpha_samples * T.theta_samples; eta = 1.0f / eta; }
     if (eta < T.eta_min) eta = T.eta_min;
-    const float warpedAlpha = powf((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f);
-    const float warpedEta = powf((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
+    const float warpedAlpha = m_pow((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f);
+    const float warpedEta = m_pow((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
     const float result = eval_cubic_interp_3d(warpedCosTheta, warpedAlpha, warpedEta, data, T.theta_samples, T.alpha_samples, T.eta_samples);
     return min2(1.0f, max2(0.0f, result));
 }
@@ -63,15 +63,15 @@ __device__ float rough_transmittance_diffuse(const diff_geom& dg, uint32_t type,
     const float* data = T.diff_trans;
     if (eta < 1) { data += (size_t)T.eta_samples * T.alpha_samples; eta = 1.0f / eta; }
     if (eta < T.eta_min) eta = T.eta_min;
-    const float warpedAlpha = powf((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f);
-    const float warpedEta = powf((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
+    const float warpedAlpha = m_pow((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f);
+    const float warpedEta = m_pow((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
     const float result = eval_cubic_interp_2d(warpedAlpha, warpedEta, data, T.alpha_samples, T.eta_samples);
     return min2(1.0f, max2(0.0f, result));
 }
 
 __device__ __forceinline__ float sin_phi(f3 v) { const float st = sin_theta(v); if (st == 0.0f) return 1.0f; return clampf(v.y / st, -1.0f, 1.0f); }   // Frame.h
 __device__ __forceinline__ float cos_phi(f3 v) { const float st = sin_theta(v); if (st == 0.0f) return 1.0f; return clampf(v.x / st, -1.0f, 1.0f); }
-__device__ __forceinline__ float safe_acosf(float v) { return acosf(min2(1.0f, max2(-1.0f, v))); }
+__device__ __forceinline__ float safe_acosf(float v) { return m_acos(min2(1.0f, max2(-1.0f, v))); }
 __device__ __forceinline__ float safe_sqrtf(float v) { return sqrtf(max2(0.0f, v)); }
 
 __device__ f3 roughdiffuse_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:82-172
@@ -115,11 +115,11 @@ __device__ f3 ward_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simpl
         switch (M.u[0]) {
         case 0: factor1 = 1.0f / (4.0f * kPi * alphaU * alphaV * sqrtf(cos_theta(b.wi) * cos_theta(b.wo))); break;
         case 1: factor1 = 1.0f / (4.0f * kPi * alphaU * alphaV * cos_theta(b.wi) * cos_theta(b.wo)); break;
-        case 2: factor1 = dot(H, H) / (kPi * alphaU * alphaV * powf(cos_theta(normalize(H)), 4)); break;
+        case 2: factor1 = dot(H, H) / (kPi * alphaU * alphaV * m_pow(cos_theta(normalize(H)), 4)); break;
         }
         const float factor2 = H.x / alphaU, factor3 = H.y / alphaV;
         const float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
-        const float specRef = factor1 * expf(exponent);
+        const float specRef = factor1 * m_exp(exponent);
         if (specRef > 1e-10f) result = result + tex_eval(M.tex[1], b.dg) * specRef;
     }
     if (hd) result = result + tex_eval(M.tex[0], b.dg) * kInvPi;
@@ -132,10 +132,10 @@ __device__ float ward_pdf(const ctl_material& M, const bsdf_rec& b) {   // BSDF_
     if (hs) {
         const float alphaU = avg3(tex_eval(M.tex[2], b.dg)), alphaV = avg3(tex_eval(M.tex[3], b.dg));
         const f3 H = normalize(b.wi + b.wo);
-        const float factor1 = 1.0f / (4.0f * kPi * alphaU * alphaV * dot(H, b.wi) * powf(cos_theta(H), 3));
+        const float factor1 = 1.0f / (4.0f * kPi * alphaU * alphaV * dot(H, b.wi) * m_pow(cos_theta(H), 3));
         const float factor2 = H.x / alphaU, factor3 = H.y / alphaV;
         const float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
-        specProb = factor1 * expf(exponent);
+        specProb = factor1 * m_exp(exponent);
     }
     if (hd) diffuseProb = kInvPi * cos_theta(b.wo);
     if (hd && hs) return ssw * specProb + (1 - ssw) * diffuseProb;
@@ -147,7 +147,7 @@ __device__ float ward_pdf(const ctl_material& M, const bsdf_rec& b) {   // BSDF_
 // Rough plastic with a constant roughness: the table was reduced to 1-D in cos(theta) at scene upload (tracer.hip), M.reserved_ = {offset + 1, samples}
 __device__ __forceinline__ float rough_transmittance_1d(const float* __restrict__ table, uint32_t size, float cosTheta) {
     float w[4]; uint32_t knot;
-    if (!spline_weights(powf(fabsf(cosTheta), 0.25f), size, w, knot)) return 0.0f;
+    if (!spline_weights(m_pow(fabsf(cosTheta), 0.25f), size, w, knot)) return 0.0f;
     float result = 0.0f;
     for (int x = -1; x <= 2; ++x) { if (w[x + 1] == 0) continue; result += table[knot + x] * w[x + 1]; }
     return min2(1.0f, max2(0.0f, result));
@@ -240,12 +240,12 @@ __device__ __noinline__ f3 bsdf_rough_sample(const ctl_material& M, bsdf_rec& b,
         if (hd && hs) { if (smp.x <= ssw) smp.x /= ssw; else { smp.x = (smp.x - ssw) / (1 - ssw); spec = false; } }
         if (spec) {
             const float alphaU = avg3(tex_eval(M.tex[2], b.dg)), alphaV = avg3(tex_eval(M.tex[3], b.dg));
-            float phiH = atanf(alphaV / alphaU * tanf(2.0f * kPi * smp.y));
+            float phiH = m_atan(alphaV / alphaU * m_tan(2.0f * kPi * smp.y));
             if (smp.y > 0.5f) phiH += kPi;
-            const float cosPhiH = cosf(phiH);
+            const float cosPhiH = m_cos(phiH);
             const float sinPhiH = safe_sqrtf(1.0f - cosPhiH * cosPhiH);
-            const float thetaH = atanf(safe_sqrtf(-logf(smp.x) / ((cosPhiH * cosPhiH) / (alphaU * alphaU) + (sinPhiH * sinPhiH) / (alphaV * alphaV))));
-            const float sinTheta = sinf(thetaH), cosTheta = cosf(thetaH), sinPhi = sinf(phiH), cosPhi = cosf(phiH);
+            const float thetaH = m_atan(safe_sqrtf(-m_log(smp.x) / ((cosPhiH * cosPhiH) / (alphaU * alphaU) + (sinPhiH * sinPhiH) / (alphaV * alphaV))));
+            const float sinTheta = m_sin(thetaH), cosTheta = m_cos(thetaH), sinPhi = m_sin(phiH), cosPhi = m_cos(phiH);
             const f3 H(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
             b.wo = reflect_about(b.wi, H);
             b.sampled_type = CTL_EGlossyReflection;

@@ -105,6 +105,35 @@ int ctl_builder_finalize(ctl_builder* b, ctl_scene_desc* out) { CTL_REQUIRE(b &&
 
 int ctl_material_update(ctl_material* m) { CTL_REQUIRE(m, "null argument"); CTL_REQUIRE(material_update(*m), "unknown bsdf_type"); return CTL_OK; }
 float ctl_fresnel_diffuse_reflectance(float eta) { return fresnel_diffuse_reflectance(eta); }
+// ---- the shared transcendental functions (ctl_fmath.h), evaluated on the host or by a kernel: the parity tests hold the two bit-identical
+__global__ void k_shared_math(int which, int n, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    switch (which) {
+    case 0: out[i] = fm::sin(x[i]); break; case 1: out[i] = fm::cos(x[i]); break; case 2: out[i] = fm::tan(x[i]); break; case 3: out[i] = fm::acos(x[i]); break;
+    case 4: out[i] = fm::atan(x[i]); break; case 5: out[i] = fm::atan2(x[i], y[i]); break; case 6: out[i] = fm::exp(x[i]); break; case 7: out[i] = fm::log(x[i]); break;
+    case 8: out[i] = fm::log2(x[i]); break; default: out[i] = fm::pow(x[i], y[i]); break;
+    }
+}
+int ctl_shared_math_eval(int32_t which, uint32_t n, const float* x, const float* y, float* out, int32_t on_device) {
+    CTL_REQUIRE(x && y && out && which >= 0 && which <= 9, "null argument or unknown function");
+    CTL_TRY
+        if (!on_device) {
+            for (uint32_t i = 0; i < n; i++) {
+                switch (which) {
+                case 0: out[i] = fm::sin(x[i]); break; case 1: out[i] = fm::cos(x[i]); break; case 2: out[i] = fm::tan(x[i]); break; case 3: out[i] = fm::acos(x[i]); break;
+                case 4: out[i] = fm::atan(x[i]); break; case 5: out[i] = fm::atan2(x[i], y[i]); break; case 6: out[i] = fm::exp(x[i]); break; case 7: out[i] = fm::log(x[i]); break;
+                case 8: out[i] = fm::log2(x[i]); break; default: out[i] = fm::pow(x[i], y[i]); break;
+                }
+            }
+        } else {
+            require_device();
+            dbuf<float> dx, dy, dout; dx.alloc(n); dy.alloc(n); dout.alloc(n);
+            CTL_HIP(hipMemcpy(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice)); CTL_HIP(hipMemcpy(dy.p, y, (size_t)n * 4, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_shared_math, dim3((n + 255) / 256), dim3(256), 0, 0, (int)which, (int)n, (const float*)dx.p, (const float*)dy.p, dout.p);
+            CTL_HIP(hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        }
+    CTL_CATCH
+}
 // ---- scene
 int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc, false); CTL_CATCH }
 int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY

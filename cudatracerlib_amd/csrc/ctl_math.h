@@ -8,10 +8,25 @@
 #include <cstdint>
 #include <cmath>
 #include <cfloat>
+#include "ctl_fmath.h"
 
 #define HD __host__ __device__ __forceinline__
 
 namespace ctl {
+
+// ---- transcendental functions: on the device the shared fp32 implementation of ctl_fmath.h (bit-identical to the oracle's -DORC_SHARED_MATH build), on the host libm —
+// host code only builds scene data (normal codec of TriangleData, light cosines), which is pinned on the reference's own glibc results (tests/golden)
+#if defined(__HIP_DEVICE_COMPILE__)
+HD float m_sin(float x) { return fm::sin(x); }  HD float m_cos(float x) { return fm::cos(x); }  HD float m_tan(float x) { return fm::tan(x); }
+HD void m_sincos(float x, float* s, float* c) { fm::sincos(x, s, c); }
+HD float m_acos(float x) { return fm::acos(x); }  HD float m_atan(float x) { return fm::atan(x); }  HD float m_atan2(float y, float x) { return fm::atan2(y, x); }
+HD float m_exp(float x) { return fm::exp(x); }  HD float m_log(float x) { return fm::log(x); }  HD float m_log2(float x) { return fm::log2(x); }  HD float m_pow(float x, float y) { return fm::pow(x, y); }
+#else
+HD float m_sin(float x) { return ::sinf(x); }  HD float m_cos(float x) { return ::cosf(x); }  HD float m_tan(float x) { return ::tanf(x); }
+HD void m_sincos(float x, float* s, float* c) { *s = ::sinf(x); *c = ::cosf(x); }
+HD float m_acos(float x) { return ::acosf(x); }  HD float m_atan(float x) { return ::atanf(x); }  HD float m_atan2(float y, float x) { return ::atan2f(y, x); }
+HD float m_exp(float x) { return ::expf(x); }  HD float m_log(float x) { return ::logf(x); }  HD float m_log2(float x) { return ::log2f(x); }  HD float m_pow(float x, float y) { return ::powf(x, y); }
+#endif
 
 static constexpr float kPi = 3.14159265358979f;          // Math/MathFunc.h:12
 static constexpr float kInvPi = 1.0f / kPi;
@@ -105,9 +120,9 @@ HD f2 square_to_disk_concentric(f2 s) {   // Warp.h:104-127
     else { r = r2; phi = (kPi / 2.0f) - (r1 / r2) * (kPi / 4.0f); }
     float sp, cp;
 #ifdef __HIP_DEVICE_COMPILE__
-    sincosf(phi, &sp, &cp);
+    m_sincos(phi, &sp, &cp);
 #else
-    sp = sinf(phi); cp = cosf(phi);
+    sp = m_sin(phi); cp = m_cos(phi);
 #endif
     return f2{ r * cp, r * sp };
 }
@@ -178,8 +193,8 @@ HD float half_to_float(uint16_t h) {
 
 // ---- 8+8 bit spherical normal codec (Math/Compression.h:12-31)
 HD uint16_t normal_to_uchar2(f3 v) {
-    float theta = (acosf(v.z) * (255.0f / kPi));
-    float phi = (atan2f(v.y, v.x) * (255.0f / (2.0f * kPi)));
+    float theta = (m_acos(v.z) * (255.0f / kPi));
+    float phi = (m_atan2(v.y, v.x) * (255.0f / (2.0f * kPi)));
     phi = phi < 0 ? (phi + 255) : phi;
     return (uint16_t)(((unsigned short)theta << 8) | (unsigned short)phi);
 }
@@ -190,9 +205,9 @@ HD f3 uchar2_to_normal(uint32_t v) {
     float phi = y == 63 ? PI_2 : (y == 127 ? kPi : (y == 191 ? 3 * PI_2 : float(y) * (1.0f / 255.0f) * kPi * 2.0f));
     float sp, cp, st, ct;
 #ifdef __HIP_DEVICE_COMPILE__
-    sincosf(phi, &sp, &cp); sincosf(theta, &st, &ct);
+    m_sincos(phi, &sp, &cp); m_sincos(theta, &st, &ct);
 #else
-    sp = sinf(phi); cp = cosf(phi); st = sinf(theta); ct = cosf(theta);
+    sp = m_sin(phi); cp = m_cos(phi); st = m_sin(theta); ct = m_cos(theta);
 #endif
     return f3(st * cp, st * sp, ct);
 }

@@ -127,7 +127,7 @@ __device__ f3 light_sample_position(const ctl_light& L, f2 sample, f3& p) {
 // InfiniteLight::evalEnvironment(ray, rX, rY) (SceneTypes/Light.cu:496-518)
 __device__ f3 env_eval_differential(const dev_scene& S, const ctl_light& L, f3 dir, f3 dirX, f3 dirY) {
     const f3 v = xform_dir_transpose(L.to_world, dir);
-    const f2 uv{ atan2f(v.x, -v.z) * kInvTwoPi, acosf(fminf(1.0f, fmaxf(-1.0f, v.y))) * kInvPi };
+    const f2 uv{ m_atan2(v.x, -v.z) * kInvTwoPi, m_acos(fminf(1.0f, fmaxf(-1.0f, v.y))) * kInvPi };
     const f3 dvdx = xform_dir_transpose(L.to_world, dirX) - v, dvdy = xform_dir_transpose(L.to_world, dirY) - v;
     const float t1 = kInvTwoPi / (v.x * v.x + v.z * v.z), t2 = -kInvPi / fmaxf(sqrtf(fmaxf(0.0f, 1.0f - v.y * v.y)), 1e-4f);
     const f2 dudx{ t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y }, dudy{ t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y };
@@ -206,10 +206,10 @@ __global__ __launch_bounds__(256) void k_path_trace_regularization(dev_scene S, 
                             float st, su, sv; int stri, snode;
                             rays++;
                             if (!trace_single<true>(S, b.dg.P, lDir, S.eps, lDist - S.eps, st, su, sv, stri, snode)) {   // Occluded(r, 0, lDist)
-                                const float eps = atanf(g_fRMollifier / lDist);
-                                const float normalization = 1.0f / (2 * kPi * (1 - cosf(eps)));
+                                const float eps = m_atan(g_fRMollifier / lDist);
+                                const float normalization = 1.0f / (2 * kPi * (1 - m_cos(eps)));
                                 const float l_dot_o = dot(lDir, b.dg.sys.to_world(b.wo));
-                                const float indicator = acosf(l_dot_o) <= eps ? 1.0f : 0.0f;
+                                const float indicator = m_acos(l_dot_o) <= eps ? 1.0f : 0.0f;
                                 cl = cl + cf * f * l_s * (normalization * indicator);
                             }
                         }
@@ -269,7 +269,7 @@ void PathTracer::DoRender(Image* I, const float* d_t1, const float* d_t2, unsign
         const float initialRadius = ((hi[0] - lo[0]) + (hi[1] - lo[1]) + (hi[2] - lo[2])) / 100;
         const float ALPHA = 0.75f;
         std::vector<float> m(n_batch);
-        for (unsigned int k = 0; k < n_batch; k++) m[k] = powf(powf(initialRadius, float(2)) / powf(float(m_uPassesDone - n_batch + k + 1), 0.5f * (1 - ALPHA)), 1.0f / 2.0f);
+        for (unsigned int k = 0; k < n_batch; k++) m[k] = m_pow(m_pow(initialRadius, float(2)) / m_pow(float(m_uPassesDone - n_batch + k + 1), 0.5f * (1 - ALPHA)), 1.0f / 2.0f);
         if (mollifier_.n < n_batch) mollifier_.alloc(n_batch);
         CTL_HIP(hipMemcpyAsync(mollifier_.p, m.data(), n_batch * sizeof(float), hipMemcpyHostToDevice, stream));
         CTL_HIP(hipStreamSynchronize(stream));   // `m` is pageable and leaves scope

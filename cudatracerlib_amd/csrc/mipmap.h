@@ -115,7 +115,7 @@ __device__ inline f3 mip_eval(const ctl_mipmap& M, const dev_mip_levels& L, cons
     if (M.filter_mode == CTL_FILTER_POINT) return mip_texel_l(M, L, 0, uv);
     if (M.filter_mode == CTL_FILTER_BILINEAR) return mip_triangle_l(M, L, 0, uv);
     if (M.filter_mode == CTL_FILTER_TRILINEAR) {
-        const float levela = logf(dimx / fabsf(du)) / logf(2.0f), levelb = logf(dimy / fabsf(dv)) / logf(2.0f),   /* math::log2 on the reference's host path (MathFunc.h:258-265) */ level = (float)L.levels - clampf((levela + levelb) / 2.0f, 1.0f, (float)L.levels);
+        const float levela = m_log(dimx / fabsf(du)) / m_log(2.0f), levelb = m_log(dimy / fabsf(dv)) / m_log(2.0f),   /* math::log2 on the reference's host path (MathFunc.h:258-265) */ level = (float)L.levels - clampf((levela + levelb) / 2.0f, 1.0f, (float)L.levels);
         const int iLevel = (int)floorf(level), iLevel2 = clampi(iLevel + 1, 0, (int)L.levels - 1);
         const float p = level - iLevel;
         return p * mip_triangle_l(M, L, (uint32_t)iLevel, uv) + (1 - p) * mip_triangle_l(M, L, (uint32_t)iLevel2, uv);
@@ -124,7 +124,7 @@ __device__ inline f3 mip_eval(const ctl_mipmap& M, const dev_mip_levels& L, cons
     const float root = sqrtf((A - C) * (A - C) + B * B), Aprime = 0.5f * (A + C - root), Cprime = 0.5f * (A + C + root);
     const float majorRadius = Aprime != 0 ? sqrtf(F / Aprime) : 0; float minorRadius = Cprime != 0 ? sqrtf(F / Cprime) : 0;
     if (!(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
-        const float level = log2f(max2(majorRadius, 1e-4f)); const int ilevel = (int)floorf(level);
+        const float level = m_log2(max2(majorRadius, 1e-4f)); const int ilevel = (int)floorf(level);
         if (ilevel < 0) return mip_triangle_l(M, L, 0, uv);
         const float a = level - ilevel;
         return mip_triangle_l(M, L, (uint32_t)ilevel, uv) * (1.0f - a) + mip_triangle_l(M, L, (uint32_t)(ilevel + 1), uv) * a;
@@ -132,12 +132,12 @@ __device__ inline f3 mip_eval(const ctl_mipmap& M, const dev_mip_levels& L, cons
     const float maxAnisotropy = 16;
     if (minorRadius * maxAnisotropy < majorRadius) {
         minorRadius = majorRadius / maxAnisotropy;
-        const float theta = 0.5f * atanf(B / (A - C)), sinTheta = sinf(theta), cosTheta = cosf(theta);
+        const float theta = 0.5f * m_atan(B / (A - C)), sinTheta = m_sin(theta), cosTheta = m_cos(theta);
         const float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius, sinTheta2 = sinTheta * sinTheta, cosTheta2 = cosTheta * cosTheta, sin2Theta = 2 * sinTheta * cosTheta;
         A = a2 * cosTheta2 + b2 * sinTheta2; B = (a2 - b2) * sin2Theta; C = a2 * sinTheta2 + b2 * cosTheta2; F = a2 * b2;
     }
     const float scale = 1.0f / F; A *= scale; B *= scale; C *= scale;
-    const float level = max2(0.0f, log2f(minorRadius)); const int ilevel = (int)level; const float a = level - ilevel;
+    const float level = max2(0.0f, m_log2(minorRadius)); const int ilevel = (int)level; const float a = level - ilevel;
     if (majorRadius < 1 || !(A > 0 && C > 0)) return mip_triangle_l(M, L, (uint32_t)ilevel, uv);
     return mip_eval_ewa(M, L, lut, (uint32_t)ilevel, uv, A, B, C) * (1.0f - a) + mip_eval_ewa(M, L, lut, (uint32_t)(ilevel + 1), uv, A, B, C) * a;
 }

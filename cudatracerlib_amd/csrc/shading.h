@@ -47,8 +47,8 @@ __device__ __forceinline__ void sensor_sample_ray(const dev_sensor& c, f2 pixelS
     const m34 m = sensor_to_world(c);
     if (c.type == CTL_SENSOR_SPHERICAL) {   // SphericalSensor::sampleRay (Sensor.cu:6-17)
         float sinPhi, cosPhi, sinTheta, cosTheta;
-        sincosf((1.0f - pixelSample.x * c.inv_res[0]) * 2 * kPi, &sinPhi, &cosPhi);
-        sincosf((1.0f - pixelSample.y * c.inv_res[1]) * kPi, &sinTheta, &cosTheta);
+        m_sincos((1.0f - pixelSample.x * c.inv_res[0]) * 2 * kPi, &sinPhi, &cosPhi);
+        m_sincos((1.0f - pixelSample.y * c.inv_res[1]) * kPi, &sinTheta, &cosTheta);
         o = xform_point(m, f3(0.0f)); d = xform_dir(m, f3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta));
         return;
     }
@@ -221,7 +221,7 @@ __device__ __forceinline__ float avg3(f3 s) { float r = s.x; r += s.y; r += s.z;
 #if CTL_SHADE_FEATURES & 64
 // math::erfinv / math::erf (Math/MathFunc.h:343-393)
 __device__ __forceinline__ float erfinv_ref(float x) {
-    float w = -logf((1.0f - x) * (1.0f + x)), p;
+    float w = -m_log((1.0f - x) * (1.0f + x)), p;
     if (w < 5.0f) {
         w = w - 2.5f;
         p = 2.81022636e-08f; p = 3.43273939e-07f + p * w; p = -3.5233877e-06f + p * w; p = -4.39150654e-06f + p * w; p = 0.00021858087f + p * w;
@@ -238,7 +238,7 @@ __device__ __forceinline__ float erf_ref(float x) {
     const float sign = copysign_bits(1.0f, x);
     x = fabsf(x);
     const float t = 1.0f / (1.0f + p * x);
-    return sign * (1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * expf(-x * x));
+    return sign * (1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * m_exp(-x * x));
 }
 #endif
 
@@ -258,8 +258,8 @@ struct microfacet {
         return eU * (v.x * v.x * is2) + eV * (v.y * v.y * is2);
     }
     __device__ void sample_first_quadrant(float u1, float& phi, float& exponent) const {   // MicrofacetDistribution.h:161-170
-        phi = atanf(sqrtf((eU + 2.0f) / (eV + 2.0f)) * tanf(kPi * u1 * 0.5f));
-        float sp, cp; sincosf(phi, &sp, &cp);
+        phi = m_atan(sqrtf((eU + 2.0f) / (eV + 2.0f)) * m_tan(kPi * u1 * 0.5f));
+        float sp, cp; m_sincos(phi, &sp, &cp);
         exponent = eU * cp * cp + eV * sp * sp;
     }
 #else
@@ -277,9 +277,9 @@ struct microfacet {
         const float c2 = m.z * m.z;
         const float be = ((m.x * m.x) / (aU * aU) + (m.y * m.y) / (aV * aV)) / c2;
         float result;
-        if (type == CTL_MF_BECKMANN) result = expf(-be) / (kPi * aU * aV * c2 * c2);
+        if (type == CTL_MF_BECKMANN) result = m_exp(-be) / (kPi * aU * aV * c2 * c2);
 #if CTL_SHADE_FEATURES & 64
-        else if (type == CTL_MF_PHONG) result = sqrtf((eU + 2) * (eV + 2)) * kInvTwoPi * powf(cos_theta(m), interp_phong_exp(m));
+        else if (type == CTL_MF_PHONG) result = sqrtf((eU + 2) * (eV + 2)) * kInvTwoPi * m_pow(cos_theta(m), interp_phong_exp(m));
 #endif
         else { const float root = (1 + be) * c2; result = 1.0f / (kPi * aU * aV * root * root); }
         if (result < 1e-20f) result = 0;
@@ -321,23 +321,23 @@ struct microfacet {
             else if (s.y < 0.5f) { sample_first_quadrant(4 * (0.5f - s.y), phiM, exponent); phiM = kPi - phiM; }
             else if (s.y < 0.75f) { sample_first_quadrant(4 * (s.y - 0.5f), phiM, exponent); phiM += kPi; }
             else { sample_first_quadrant(4 * (1 - s.y), phiM, exponent); phiM = 2 * kPi - phiM; }
-            sincosf(phiM, &sinPhiM, &cosPhiM);
-            cosThetaM = powf(s.x, 1.0f / (exponent + 2.0f));
-            pdf_ = sqrtf((eU + 2.0f) * (eV + 2.0f)) * kInvTwoPi * powf(cosThetaM, exponent + 1.0f);
+            m_sincos(phiM, &sinPhiM, &cosPhiM);
+            cosThetaM = m_pow(s.x, 1.0f / (exponent + 2.0f));
+            pdf_ = sqrtf((eU + 2.0f) * (eV + 2.0f)) * kInvTwoPi * m_pow(cosThetaM, exponent + 1.0f);
             if (pdf_ < 1e-20f) pdf_ = 0;
             const float sinThetaP = sqrtf(max2(0.0f, 1 - cosThetaM * cosThetaM));
             return f3(sinThetaP * cosPhiM, sinThetaP * sinPhiM, cosThetaM);
         }
 #endif
-        if (iso()) { sincosf((2.0f * kPi) * s.y, &sinPhiM, &cosPhiM); alphaSqr = aU * aU; }
+        if (iso()) { m_sincos((2.0f * kPi) * s.y, &sinPhiM, &cosPhiM); alphaSqr = aU * aU; }
         else {
-            const float phiM = atanf(aV / aU * tanf(kPi + 2 * kPi * s.y)) + kPi * floorf(2 * s.y + 0.5f);
-            sincosf(phiM, &sinPhiM, &cosPhiM);
+            const float phiM = m_atan(aV / aU * m_tan(kPi + 2 * kPi * s.y)) + kPi * floorf(2 * s.y + 0.5f);
+            m_sincos(phiM, &sinPhiM, &cosPhiM);
             const float cs = cosPhiM / aU, ss = sinPhiM / aV;
             alphaSqr = 1.0f / (cs * cs + ss * ss);
         }
         if (type == CTL_MF_BECKMANN) {
-            const float t2 = alphaSqr * -logf(1.0f - s.x);
+            const float t2 = alphaSqr * -m_log(1.0f - s.x);
             cosThetaM = 1.0f / sqrtf(1.0f + t2);
             pdf_ = (1.0f - s.x) / (kPi * aU * aV * cosThetaM * cosThetaM * cosThetaM);
         } else {
@@ -354,18 +354,18 @@ struct microfacet {
 #if CTL_SHADE_FEATURES & 64
         if (type == CTL_MF_BECKMANN) {   // :191-256: Newton / bisection on the CDF in the erf domain
             const float SQRT_PI_INV = 1 / sqrtf(kPi);
-            if (thetaI < 1e-4f) { const float r = sqrtf(-logf(1.0f - s.x)); float sp, cp; sincosf(2 * kPi * s.y, &sp, &cp); return f2{ r * cp, r * sp }; }
-            const float tanThetaI = tanf(thetaI), cotThetaI = 1 / tanThetaI;
+            if (thetaI < 1e-4f) { const float r = sqrtf(-m_log(1.0f - s.x)); float sp, cp; m_sincos(2 * kPi * s.y, &sp, &cp); return f2{ r * cp, r * sp }; }
+            const float tanThetaI = m_tan(thetaI), cotThetaI = 1 / tanThetaI;
             float a = -1, c = erf_ref(cotThetaI);
             const float sample_x = max2(s.x, 1e-6f);
             const float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
-            float b = c - (1 + c) * powf(1 - sample_x, fit);
-            const float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+            float b = c - (1 + c) * m_pow(1 - sample_x, fit);
+            const float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * m_exp(-cotThetaI * cotThetaI));
             int it = 0;
             while (++it < 10) {
                 if (!(b >= a && b <= c)) b = 0.5f * (a + c);
                 const float invErf = erfinv_ref(b);
-                const float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * expf(-invErf * invErf)) - sample_x;
+                const float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * m_exp(-invErf * invErf)) - sample_x;
                 const float derivative = normalization * (1 - invErf * tanThetaI);
                 if (fabsf(value) < 1e-5f) break;
                 if (value > 0) c = b; else a = b;
@@ -374,8 +374,8 @@ struct microfacet {
             return f2{ erfinv_ref(b), erfinv_ref(2.0f * max2(s.y, 1e-6f) - 1.0f) };
         }
 #endif
-        if (thetaI < 1e-4f) { const float r = safe_sqrt(s.x / (1 - s.x)); float sp, cp; sincosf(2 * kPi * s.y, &sp, &cp); return f2{ r * cp, r * sp }; }
-        const float tanThetaI = tanf(thetaI), a = 1 / tanThetaI;
+        if (thetaI < 1e-4f) { const float r = safe_sqrt(s.x / (1 - s.x)); float sp, cp; m_sincos(2 * kPi * s.y, &sp, &cp); return f2{ r * cp, r * sp }; }
+        const float tanThetaI = m_tan(thetaI), a = 1 / tanThetaI;
         const float G1 = 2.0f / (1.0f + safe_sqrt(1.0f + 1.0f / (a * a)));
         float A = 2.0f * s.x / G1 - 1.0f;
         if (fabsf(A) == 1) A -= copysign_bits(1.0f, A) * 1e-7f;
@@ -393,8 +393,8 @@ struct microfacet {
     __device__ f3 sample_visible(f3 _wi, f2 s) const {   // MicrofacetDistribution.cu:151-183
         const f3 wi = normalize(f3(aU * _wi.x, aV * _wi.y, _wi.z));
         float theta = 0, phi = 0;
-        if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
-        float sp, cp; sincosf(phi, &sp, &cp);
+        if (wi.z < 0.99999f) { theta = m_acos(wi.z); phi = m_atan2(wi.y, wi.x); }
+        float sp, cp; m_sincos(phi, &sp, &cp);
         f2 slope = sample_visible11(theta, s);
         slope = f2{ cp * slope.x - sp * slope.y, sp * slope.x + cp * slope.y };
         slope.x *= aU; slope.y *= aV;
@@ -592,7 +592,7 @@ __device__ __forceinline__ f3 spot_falloff(const ctl_light& L, f3 d) {
     const float cosTheta = d.z;
     if (cosTheta <= L.cos_cutoff_angle) return f3(0.0f);
     if (cosTheta >= L.cos_beam_width) return f3(1.0f);
-    return f3((L.cutoff_angle - acosf(cosTheta)) * L.inv_transition_width);
+    return f3((L.cutoff_angle - m_acos(cosTheta)) * L.inv_transition_width);
 }
 __device__ __forceinline__ float interval_to_tent(float sample) {   // Math/Warp.h:13-27
     float sign;
@@ -616,8 +616,8 @@ __device__ void env_sample_direction(const dev_scene& S, const ctl_light& L, f2 
     pdf = (luminance(value1) * rowWeights[(int)clampf((float)yPos, 0.0f, sizeY - 1.0f)] +
            luminance(value2) * rowWeights[(int)clampf((float)(yPos + 1), 0.0f, sizeY - 1.0f)]) * L.normalization;
     const float pixX = 2 * kPi / sizeX, pixY = kPi / sizeY;
-    const float sinPhi = sinf(pixX * (pos.x + 0.5f)), cosPhi = cosf(pixX * (pos.x + 0.5f));
-    const float sinTheta = sinf(pixY * (pos.y + 0.5f)), cosTheta = cosf(pixY * (pos.y + 0.5f));
+    const float sinPhi = m_sin(pixX * (pos.x + 0.5f)), cosPhi = m_cos(pixX * (pos.x + 0.5f));
+    const float sinTheta = m_sin(pixY * (pos.y + 0.5f)), cosTheta = m_cos(pixY * (pos.y + 0.5f));
     d = f3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
     pdf /= fmaxf(fabsf(sinTheta), 0.000001f);
 }
@@ -629,7 +629,7 @@ __device__ float env_pdf_direction(const dev_scene& S, const ctl_light& L, f3 d)
     const ctl_mipmap& map = S.images[L.env_image];
     const float* rowWeights = (const float*)(S.anim + L.row_weights_index);
     const float sizeX = (float)map.width, sizeY = (float)map.height;
-    const f2 uv{ atan2f(d.x, -d.z) * kInvTwoPi, acosf(fminf(1.0f, fmaxf(-1.0f, d.y))) * kInvPi };
+    const f2 uv{ m_atan2(d.x, -d.z) * kInvTwoPi, m_acos(fminf(1.0f, fmaxf(-1.0f, d.y))) * kInvPi };
     const float u = uv.x * sizeX - 0.5f, v = uv.y * sizeY - 0.5f;
     const int xPos = (int)floorf(u), yPos = (int)floorf(v);
     const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
@@ -642,7 +642,7 @@ __device__ float env_pdf_direction(const dev_scene& S, const ctl_light& L, f3 d)
 // InfiniteLight::evalEnvironment (SceneTypes/Light.cu:488-501)
 __device__ f3 env_eval(const dev_scene& S, const ctl_light& L, f3 dir) {
     const f3 v = xform_dir_transpose(L.to_world, dir);
-    const f2 uv{ atan2f(v.x, -v.z) * kInvTwoPi, acosf(fminf(1.0f, fmaxf(-1.0f, v.y))) * kInvPi };
+    const f2 uv{ m_atan2(v.x, -v.z) * kInvTwoPi, m_acos(fminf(1.0f, fmaxf(-1.0f, v.y))) * kInvPi };
     return mip_triangle(S.images[L.env_image], uv) * f3(L.env_scale[0], L.env_scale[1], L.env_scale[2]);
 }
 // InfiniteLight::pdfDirect, solid-angle measure (SceneTypes/Light.cu:368-378)

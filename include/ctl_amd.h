@@ -503,6 +503,11 @@ int ctl_intersect_device(ctl_scene* s, const void* d_ray_o, const void* d_ray_d,
  * instance entries (B_ray = 32 + 16 + 64*N_inner + 52*N_tri + 108*N_inst). */
 int ctl_intersect_count(ctl_scene* s, const ctl_ray* rays, uint32_t n, int any_hit, ctl_traversal_counts* out);
 
+/* The shared fp32 transcendental functions of the shading code (cudatracerlib_amd/csrc/ctl_fmath.h; the oracle's -DORC_SHARED_MATH build runs the same source):
+ * which = 0 sin, 1 cos, 2 tan, 3 acos, 4 atan, 5 atan2(x, y), 6 exp, 7 log, 8 log2, 9 pow(x, y); on_device = 0 evaluates on the host, 1 in a kernel — the two are
+ * bit-identical (tests/test_fmath.py).  No reference counterpart: the reference calls the CUDA / C library's functions. */
+int ctl_shared_math_eval(int32_t which, uint32_t n, const float* x, const float* y, float* out, int32_t on_device);
+
 /* device memory helpers so that Python callers need no HIP binding */
 int ctl_device_malloc(size_t bytes, void** out);
 int ctl_device_free(void* p);

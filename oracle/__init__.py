@@ -17,7 +17,7 @@ f32, u32, u16, u64 = C.c_float, C.c_uint32, C.c_uint16, C.c_uint64
 def build(ref=True, quiet=True):
     """compile the C++ restatement (and, when /root/reference is present, the reference-backed _ref library)"""
     out = subprocess.DEVNULL if quiet else None
-    subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=out)
+    subprocess.check_call(["make", "-C", _HERE, "liboracle.so", "liboracle_sm.so"], stdout=out)
     if ref and os.path.isdir("/root/reference"):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=out)
 
@@ -26,8 +26,11 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(f32))
 
 
-def load():
-    path = os.path.join(_HERE, "liboracle.so")
+def load(shared_math=False):
+    """liboracle.so: the restatement with glibc's transcendental functions — the reference's CPU path, pinned bit for bit on the reference's own code (tests/golden).
+    shared_math=True: liboracle_sm.so, the same code with the product's shared fp32 functions (cudatracerlib_amd/csrc/ctl_fmath.h), which the HIP kernels run as well —
+    the checker of the GPU parity tests (no libm-vs-device-library last-bit differences left to flip a discrete decision)."""
+    path = os.path.join(_HERE, "liboracle_sm.so" if shared_math else "liboracle.so")
     if not os.path.exists(path):
         build(ref=False)
     o = C.CDLL(path)
@@ -125,8 +128,9 @@ def load_ref():
 class Oracle:
     """convenience wrappers over liboracle.so working on a ctypes ctl_scene_desc (host pointers)"""
 
-    def __init__(self):
-        self.lib = load()
+    def __init__(self, shared_math=False):
+        self.shared_math = shared_math
+        self.lib = load(shared_math)
 
     def intersect(self, desc, rays, any_hit=False, count=False, threads=8, alpha_test=False, flat=None):
         """flat: a ctl_flat_bvh_desc (cudatracerlib_amd.FlatBvh(...).desc) -> traverse the product's flattened BVH instead of the two-level structure"""

@@ -104,8 +104,8 @@ inline Spec bsdf2Sample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sampl
         if (choseSpecular) {
             V3 R = Frame::reflect(bRec.wi);
             float exponent = avg3(texEval(M.tex[2], bRec.dg));
-            float sinAlpha = std::sqrt(1 - powf(sample.y, 2 / (exponent + 1))), cosAlpha = powf(sample.y, 1 / (exponent + 1)), phi = (2.0f * PI) * sample.x;
-            V3 localDir(sinAlpha * cosf(phi), sinAlpha * sinf(phi), cosAlpha);
+            float sinAlpha = std::sqrt(1 - mpow(sample.y, 2 / (exponent + 1))), cosAlpha = mpow(sample.y, 1 / (exponent + 1)), phi = (2.0f * PI) * sample.x;
+            V3 localDir(sinAlpha * mcos(phi), sinAlpha * msin(phi), cosAlpha);
             bRec.wo = normalize(Frame(R).toWorld(localDir)); bRec.sampledType = CTL_EGlossyReflection;
             if (Frame::cosTheta(bRec.wo) <= 0) return Spec(0.0f);
         } else { bRec.wo = squareToCosineHemisphere(sample); bRec.sampledType = CTL_EDiffuseReflection; }
@@ -158,7 +158,7 @@ inline Spec bsdf2F(const ctl_material& M, const BRec& bRec, int measure) {
         Spec result(0.0f);
         if (hasSpecular) {
             float alpha = dot(bRec.wo, Frame::reflect(bRec.wi)), exponent = avg3(texEval(M.tex[2], bRec.dg));
-            if (alpha > 0.0f) result = result + texEval(M.tex[1], bRec.dg) * ((exponent + 2) * INV_TWOPI * powf(alpha, exponent));
+            if (alpha > 0.0f) result = result + texEval(M.tex[1], bRec.dg) * ((exponent + 2) * INV_TWOPI * mpow(alpha, exponent));
         }
         if (hasDiffuse) result = result + texEval(M.tex[0], bRec.dg) * INV_PI;
         return result * Frame::cosTheta(bRec.wo);
@@ -206,7 +206,7 @@ inline float bsdf2Pdf(const ctl_material& M, const BRec& bRec, int measure) {
         bool hasSpecular = (bRec.typeMask & CTL_EGlossyReflection) != 0, hasDiffuse = (bRec.typeMask & CTL_EDiffuseReflection) != 0;
         float diffuseProb = 0.0f, specProb = 0.0f; const float ssw = M.f[0];
         if (hasDiffuse) diffuseProb = squareToCosineHemispherePdf(bRec.wo);
-        if (hasSpecular) { float alpha = dot(bRec.wo, Frame::reflect(bRec.wi)), exponent = avg3(texEval(M.tex[2], bRec.dg)); if (alpha > 0) specProb = powf(alpha, exponent) * (exponent + 1.0f) / (2.0f * PI); }
+        if (hasSpecular) { float alpha = dot(bRec.wo, Frame::reflect(bRec.wi)), exponent = avg3(texEval(M.tex[2], bRec.dg)); if (alpha > 0) specProb = mpow(alpha, exponent) * (exponent + 1.0f) / (2.0f * PI); }
         if (hasDiffuse && hasSpecular) return ssw * specProb + (1 - ssw) * diffuseProb;
         else if (hasDiffuse) return diffuseProb;
         else if (hasSpecular) return specProb;

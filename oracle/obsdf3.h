@@ -59,13 +59,13 @@ inline float evalCubicInterp3D(float px, float py, float pz, const float* values
 inline float roughTransmittance(const DG& dg, unsigned type, float cosTheta, float alpha, float eta) {
     if (!dg.rough_transmittance) throw std::runtime_error("oracle: roughplastic needs ctl_scene_desc::rough_transmittance");
     const ctl_rough_transmittance& T = dg.rough_transmittance[type];
-    float warpedCosTheta = powf(fabsf(cosTheta), 0.25f), result;
+    float warpedCosTheta = mpow(fabsf(cosTheta), 0.25f), result;
     if (cosTheta < 0) { cosTheta = -cosTheta; eta = 1.0f / eta; }
     const float* data = T.trans;
     if (eta < 1) { data += (size_t)T.eta_samples * T.alpha_samples * T.theta_samples; eta = 1.0f / eta; }
     if (eta < T.eta_min) eta = T.eta_min;
-    float warpedAlpha = powf((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f);
-    float warpedEta = powf((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
+    float warpedAlpha = mpow((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f);
+    float warpedEta = mpow((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
     result = evalCubicInterp3D(warpedCosTheta, warpedAlpha, warpedEta, data, T.theta_samples, T.alpha_samples, T.eta_samples);
     return fmin2(1.0f, fmax2(0.0f, result));
 }
@@ -75,8 +75,8 @@ inline float roughTransmittanceDiffuse(const DG& dg, unsigned type, float alpha,
     const float* data = T.diff_trans;
     if (eta < 1) { data += (size_t)T.eta_samples * T.alpha_samples; eta = 1.0f / eta; }
     if (eta < T.eta_min) eta = T.eta_min;
-    float warpedAlpha = powf((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f);
-    float warpedEta = powf((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
+    float warpedAlpha = mpow((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f);
+    float warpedEta = mpow((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
     float result = evalCubicInterp2D(warpedAlpha, warpedEta, data, T.alpha_samples, T.eta_samples);
     return fmin2(1.0f, fmax2(0.0f, result));
 }
@@ -114,12 +114,12 @@ inline Spec bsdf3Sample(const ctl_material& M, BRec& bRec, float& pdf, V2 _sampl
         }
         if (choseSpecular) {
             float alphaU = avg3(texEval(M.tex[2], bRec.dg)), alphaV = avg3(texEval(M.tex[3], bRec.dg));
-            float phiH = std::atan(alphaV / alphaU * std::tan(2.0f * PI * sample.y));
+            float phiH = matan(alphaV / alphaU * mtan(2.0f * PI * sample.y));
             if (sample.y > 0.5f) phiH += PI;
-            float cosPhiH = cosf(phiH);
+            float cosPhiH = mcos(phiH);
             float sinPhiH = safe_sqrt(1.0f - cosPhiH * cosPhiH);
-            float thetaH = atanf(safe_sqrt(-logf(sample.x) / ((cosPhiH * cosPhiH) / (alphaU * alphaU) + (sinPhiH * sinPhiH) / (alphaV * alphaV))));
-            float sinTheta = sinf(thetaH), cosTheta = cosf(thetaH), sinPhi = sinf(phiH), cosPhi = cosf(phiH);   // Warp::SphericalDirection (Warp.h:204-216)
+            float thetaH = matan(safe_sqrt(-mlog(sample.x) / ((cosPhiH * cosPhiH) / (alphaU * alphaU) + (sinPhiH * sinPhiH) / (alphaV * alphaV))));
+            float sinTheta = msin(thetaH), cosTheta = mcos(thetaH), sinPhi = msin(phiH), cosPhi = mcos(phiH);   // Warp::SphericalDirection (Warp.h:204-216)
             V3 H(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
             bRec.wo = reflectAbout(bRec.wi, H);
             bRec.sampledType = CTL_EGlossyReflection;
@@ -207,11 +207,11 @@ inline Spec bsdf3F(const ctl_material& M, const BRec& bRec, int measure) {
             switch (M.u[0]) {
             case 0: factor1 = 1.0f / (4.0f * PI * alphaU * alphaV * std::sqrt(Frame::cosTheta(bRec.wi) * Frame::cosTheta(bRec.wo))); break;
             case 1: factor1 = 1.0f / (4.0f * PI * alphaU * alphaV * Frame::cosTheta(bRec.wi) * Frame::cosTheta(bRec.wo)); break;
-            case 2: factor1 = dot(H, H) / (PI * alphaU * alphaV * powf(Frame::cosTheta(normalize(H)), 4)); break;
+            case 2: factor1 = dot(H, H) / (PI * alphaU * alphaV * mpow(Frame::cosTheta(normalize(H)), 4)); break;
             }
             float factor2 = H.x / alphaU, factor3 = H.y / alphaV;
             float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
-            float specRef = factor1 * expf(exponent);
+            float specRef = factor1 * mexp(exponent);
             if (specRef > 1e-10f) result = result + texEval(M.tex[1], bRec.dg) * specRef;
         }
         if (hasDiffuse) result = result + texEval(M.tex[0], bRec.dg) * INV_PI;
@@ -257,10 +257,10 @@ inline float bsdf3Pdf(const ctl_material& M, const BRec& bRec, int measure) {
         if (hasSpecular) {
             float alphaU = avg3(texEval(M.tex[2], bRec.dg)), alphaV = avg3(texEval(M.tex[3], bRec.dg));
             V3 H = normalize(bRec.wi + bRec.wo);
-            float factor1 = 1.0f / (4.0f * PI * alphaU * alphaV * dot(H, bRec.wi) * powf(Frame::cosTheta(H), 3));
+            float factor1 = 1.0f / (4.0f * PI * alphaU * alphaV * dot(H, bRec.wi) * mpow(Frame::cosTheta(H), 3));
             float factor2 = H.x / alphaU, factor3 = H.y / alphaV;
             float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
-            specProb = factor1 * expf(exponent);
+            specProb = factor1 * mexp(exponent);
         }
         if (hasDiffuse) diffuseProb = squareToCosineHemispherePdf(bRec.wo);
         if (hasDiffuse && hasSpecular) return ssw * specProb + (1 - ssw) * diffuseProb;

@@ -110,7 +110,7 @@ inline V3 coatRefractOut(const ctl_material& M, V3 wi, float& R) {
     float cosThetaT; R = fresnelDielectricExt(fabsf(Frame::cosTheta(wi)), cosThetaT, M.f[1]);
     return normalize(V3(M.f[0] * wi.x, M.f[0] * wi.y, -signum(Frame::cosTheta(wi)) * cosThetaT));
 }
-inline Spec specExp(Spec s) { return Spec(expf(s.x), expf(s.y), expf(s.z)); }
+inline Spec specExp(Spec s) { return Spec(mexp(s.x), mexp(s.y), mexp(s.z)); }
 inline float coatProbSpecular(const ctl_material& M, float R12) { return (R12 * M.f[3]) / (R12 * M.f[3] + (1 - R12) * (1 - M.f[3])); }
 
 // ---- roughcoating (BSDF_Complex.h:77-147, BSDF_Complex.cu:159-342)

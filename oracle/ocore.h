@@ -453,7 +453,7 @@ struct MipPyramid {
 };
 inline const float* mipWeightLut() {   // MIPMap.cpp:87-92, MTS_MIPMAP_LUT_SIZE = 64
     static float lut[64]; static bool init = false;
-    if (!init) { for (int i = 0; i < 64; i++) { float r2 = (float)i / (float)(64 - 1); lut[i] = expf(-2.0f * r2) - expf(-2.0f); } init = true; }
+    if (!init) { for (int i = 0; i < 64; i++) { float r2 = (float)i / (float)(64 - 1); lut[i] = expf(-2.0f * r2) - expf(-2.0f); } init = true; }   // a table built on the host (libm in both oracle builds)
     return lut;
 }
 // KernelMIPMap::Texel(level, uv) (MIPMap.cu:21-44)
@@ -472,8 +472,8 @@ inline Spec mipTriangleL(const ctl_mipmap& M, const MipPyramid& P, uint32_t leve
     return ((1.f - ds) * (1.f - dt)) * mipTexelL(M, P, level, uv) + ((1.f - ds) * dt) * mipTexelL(M, P, level, V2{ uv.x + 0, uv.y + is.y }) +
            (ds * (1.f - dt)) * mipTexelL(M, P, level, V2{ uv.x + is.x, uv.y + 0 }) + (ds * dt) * mipTexelL(M, P, level, V2{ uv.x + is.x, uv.y + is.y });
 }
-// math::log2 on the host (Math/MathFunc.h:258-265): logf(a) / logf(2) — not log2f, which eval() calls by name in its anisotropic branch (MIPMap.cu:231, :266)
-inline float mathLog2(float a) { return logf(a) / logf(2.0f); }
+// math::log2 on the host (Math/MathFunc.h:258-265): mlog(a) / mlog(2) — not log2f, which eval() calls by name in its anisotropic branch (MIPMap.cu:231, :266)
+inline float mathLog2(float a) { return mlog(a) / mlog(2.0f); }
 // KernelMIPMap::Sample(uv, width) (MIPMap.cu:140-153): the pyramid level from a footprint width, trilinear between two levels
 inline Spec mipSampleWidth(const ctl_mipmap& M, const MipPyramid& P, V2 uv, float width) {
     const float level = (float)(P.levels - 1) + mathLog2(fmax2(width, 1e-8f));
@@ -528,7 +528,7 @@ inline Spec mipEval(const ctl_mipmap& M, const MipPyramid& P, V2 uv, V2 d0, V2 d
     float root = sqrtf((A - C) * (A - C) + B * B), Aprime = 0.5f * (A + C - root), Cprime = 0.5f * (A + C + root);
     float majorRadius = Aprime != 0 ? sqrtf(F / Aprime) : 0, minorRadius = Cprime != 0 ? sqrtf(F / Cprime) : 0;
     if (!(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
-        float level = log2f(fmax2(majorRadius, 1e-4f)); int ilevel = (int)floorf(level);
+        float level = mlog2(fmax2(majorRadius, 1e-4f)); int ilevel = (int)floorf(level);
         if (ilevel < 0) return mipTriangleL(M, P, 0, uv);
         float a = level - ilevel;
         return mipTriangleL(M, P, (uint32_t)ilevel, uv) * (1.0f - a) + mipTriangleL(M, P, (uint32_t)(ilevel + 1), uv) * a;
@@ -536,12 +536,12 @@ inline Spec mipEval(const ctl_mipmap& M, const MipPyramid& P, V2 uv, V2 d0, V2 d
     const float maxAnisotropy = 16;
     if (minorRadius * maxAnisotropy < majorRadius) {
         minorRadius = majorRadius / maxAnisotropy;
-        float theta = 0.5f * atanf(B / (A - C)), sinTheta = sinf(theta), cosTheta = cosf(theta);
+        float theta = 0.5f * matan(B / (A - C)), sinTheta = msin(theta), cosTheta = mcos(theta);
         float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius, sinTheta2 = sinTheta * sinTheta, cosTheta2 = cosTheta * cosTheta, sin2Theta = 2 * sinTheta * cosTheta;
         A = a2 * cosTheta2 + b2 * sinTheta2; B = (a2 - b2) * sin2Theta; C = a2 * sinTheta2 + b2 * cosTheta2; F = a2 * b2;
     }
     float scale = 1.0f / F; A *= scale; B *= scale; C *= scale;
-    float level = fmax2(0.0f, log2f(minorRadius)); int ilevel = (int)level; float a = level - ilevel;
+    float level = fmax2(0.0f, mlog2(minorRadius)); int ilevel = (int)level; float a = level - ilevel;
     if (majorRadius < 1 || !(A > 0 && C > 0)) return mipTriangleL(M, P, (uint32_t)ilevel, uv);
     return mipEvalEWA(M, P, (uint32_t)ilevel, uv, A, B, C) * (1.0f - a) + mipEvalEWA(M, P, (uint32_t)(ilevel + 1), uv, A, B, C) * a;
 }
@@ -691,8 +691,8 @@ struct SensorO {
     // except that OrthographicSensor::sampleRay starts on the plane z = 0 of the camera while its differential version starts at nearP
     void sampleRayDifferential(V2 pixelSample, V2 apertureSample, V3& o, V3& d, V3& oX, V3& dX, V3& oY, V3& dY, bool plain = false) const {
         if (type == CTL_SENSOR_SPHERICAL) {   // SphericalSensor::sampleRay (Sensor.cu:6-17); its sampleRayDifferential (Sensor.h:122-125) leaves rayX / rayY unset: the ray itself is used here
-            float sinPhi = sinf((1.0f - pixelSample.x * invRes.x) * 2 * PI), cosPhi = cosf((1.0f - pixelSample.x * invRes.x) * 2 * PI);
-            float sinTheta = sinf((1.0f - pixelSample.y * invRes.y) * PI), cosTheta = cosf((1.0f - pixelSample.y * invRes.y) * PI);
+            float sinPhi = msin((1.0f - pixelSample.x * invRes.x) * 2 * PI), cosPhi = mcos((1.0f - pixelSample.x * invRes.x) * 2 * PI);
+            float sinTheta = msin((1.0f - pixelSample.y * invRes.y) * PI), cosTheta = mcos((1.0f - pixelSample.y * invRes.y) * PI);
             o = transformPoint(toWorld, V3(0.0f)); d = transformDir(toWorld, V3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta));
             oX = oY = o; dX = dY = d;
             return;
@@ -827,7 +827,7 @@ inline Spec spotFalloff(const ctl_light& L, V3 d) {
     const float cosTheta = Frame::cosTheta(d);
     if (cosTheta <= L.cos_cutoff_angle) return Spec(0.0f);
     if (cosTheta >= L.cos_beam_width) return Spec(1.0f);
-    return Spec((L.cutoff_angle - acosf(cosTheta)) * L.inv_transition_width);
+    return Spec((L.cutoff_angle - macos(cosTheta)) * L.inv_transition_width);
 }
 inline float intervalToTent(float sample) {   // Math/Warp.h:13-27
     float sign;
@@ -852,8 +852,8 @@ inline void envSampleDirection(const Scene& S, const ctl_light& L, V2 sample, V3
     pdf = (luminance(value1) * rowWeights[(int)clampf((float)yPos, 0.0f, sizeY - 1.0f)] +
            luminance(value2) * rowWeights[(int)clampf((float)(yPos + 1), 0.0f, sizeY - 1.0f)]) * L.normalization;
     const float pixX = 2 * PI / sizeX, pixY = PI / sizeY;   // m_pixelSize (Light.cpp:54)
-    float sinPhi = sinf(pixX * (pos.x + 0.5f)), cosPhi = cosf(pixX * (pos.x + 0.5f));
-    float sinTheta = sinf(pixY * (pos.y + 0.5f)), cosTheta = cosf(pixY * (pos.y + 0.5f));
+    float sinPhi = msin(pixX * (pos.x + 0.5f)), cosPhi = mcos(pixX * (pos.x + 0.5f));
+    float sinTheta = msin(pixY * (pos.y + 0.5f)), cosTheta = mcos(pixY * (pos.y + 0.5f));
     d = V3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
     pdf /= fmax2(fabsf(sinTheta), EPSILON);
 }
@@ -865,7 +865,7 @@ inline float envPdfDirection(const Scene& S, const ctl_light& L, V3 d) {
     const ctl_mipmap& map = S.d.images[L.env_image];
     const float* rowWeights = (const float*)(S.d.anim + L.row_weights_index);
     const float sizeX = (float)map.width, sizeY = (float)map.height;
-    V2 uv{ atan2f(d.x, -d.z) * INV_TWOPI, safe_acos(d.y) * INV_PI };
+    V2 uv{ matan2(d.x, -d.z) * INV_TWOPI, safe_acos(d.y) * INV_PI };
     float u = uv.x * sizeX - 0.5f, v = uv.y * sizeY - 0.5f;
     int xPos = floor2int(u), yPos = floor2int(v);
     float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
@@ -878,7 +878,7 @@ inline float envPdfDirection(const Scene& S, const ctl_light& L, V3 d) {
 // InfiniteLight::evalEnvironment(ray) (SceneTypes/Light.cu:488-501): Sample(uv, 0) = triangle(0, uv)
 inline Spec envEval(const Scene& S, const ctl_light& L, V3 dir) {
     V3 v = transformDirTranspose(L.to_world, dir);
-    V2 uv{ atan2f(v.x, -v.z) * INV_TWOPI, safe_acos(v.y) * INV_PI };
+    V2 uv{ matan2(v.x, -v.z) * INV_TWOPI, safe_acos(v.y) * INV_PI };
     return mipTriangle(S.d.images[L.env_image], uv) * Spec(L.env_scale[0], L.env_scale[1], L.env_scale[2]);
 }
 // SceneTypes/Light.cu:83-137, :13-31 (point), :287-301 (spot), :224-245 (distant), :350-366 (infinite)
@@ -1011,7 +1011,7 @@ inline float hypot2(float a, float b) {   // Math/MathFunc.h:326-341
 }
 // math::erfinv / math::erf (Math/MathFunc.h:343-393): Giles' single-precision polynomial, A&S 7.1.26
 inline float erfinvRef(float x) {
-    float w = -logf((1.0f - x) * (1.0f + x)), p;
+    float w = -mlog((1.0f - x) * (1.0f + x)), p;
     if (w < 5.0f) {
         w = w - 2.5f;
         p = 2.81022636e-08f; p = 3.43273939e-07f + p * w; p = -3.5233877e-06f + p * w; p = -4.39150654e-06f + p * w; p = 0.00021858087f + p * w;
@@ -1028,7 +1028,7 @@ inline float erfRef(float x) {
     const float sign = copysignf(1.0f, x);
     x = fabsf(x);
     const float t = 1.0f / (1.0f + p * x);
-    const float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * expf(-x * x);
+    const float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * mexp(-x * x);
     return sign * y;
 }
 struct Microfacet {
@@ -1052,9 +1052,9 @@ struct Microfacet {
         float cosTheta2 = m.z * m.z;
         float beckmannExponent = ((m.x * m.x) / (alphaU * alphaU) + (m.y * m.y) / (alphaV * alphaV)) / cosTheta2;
         float result;
-        if (type == CTL_MF_BECKMANN) result = expf(-beckmannExponent) / (PI * alphaU * alphaV * cosTheta2 * cosTheta2);
+        if (type == CTL_MF_BECKMANN) result = mexp(-beckmannExponent) / (PI * alphaU * alphaV * cosTheta2 * cosTheta2);
         else if (type == CTL_MF_GGX) { float root = (1 + beckmannExponent) * cosTheta2; result = 1.0f / (PI * alphaU * alphaV * root * root); }
-        else { float e = interpPhongExp(m); result = std::sqrt((expU + 2) * (expV + 2)) * INV_TWOPI * powf(Frame::cosTheta(m), e); }
+        else { float e = interpPhongExp(m); result = std::sqrt((expU + 2) * (expV + 2)) * INV_TWOPI * mpow(Frame::cosTheta(m), e); }
         if (result < 1e-20f) result = 0;
         return result;
     }
@@ -1080,8 +1080,8 @@ struct Microfacet {
     float pdfAll(V3 m) const { return eval(m) * Frame::cosTheta(m); }
     float pdf(V3 wi, V3 m) const { return sampleVis ? pdfVisible(wi, m) : pdfAll(m); }
     void sampleFirstQuadrant(float u1, float& phi, float& exponent) const {   // MicrofacetDistribution.h:161-170
-        phi = atanf(std::sqrt((expU + 2.0f) / (expV + 2.0f)) * tanf(PI * u1 * 0.5f));
-        const float sinPhi = sinf(phi), cosPhi = cosf(phi);
+        phi = matan(std::sqrt((expU + 2.0f) / (expV + 2.0f)) * mtan(PI * u1 * 0.5f));
+        const float sinPhi = msin(phi), cosPhi = mcos(phi);
         exponent = expU * cosPhi * cosPhi + expV * sinPhi * sinPhi;
     }
     V3 sampleAll(V2 sample, float& pdf) const {   // MicrofacetDistribution.cu:44-149
@@ -1093,22 +1093,22 @@ struct Microfacet {
             else if (sample.y < 0.5f) { sampleFirstQuadrant(4 * (0.5f - sample.y), phiM, exponent); phiM = PI - phiM; }
             else if (sample.y < 0.75f) { sampleFirstQuadrant(4 * (sample.y - 0.5f), phiM, exponent); phiM += PI; }
             else { sampleFirstQuadrant(4 * (1 - sample.y), phiM, exponent); phiM = 2 * PI - phiM; }
-            sinPhiM = sinf(phiM); cosPhiM = cosf(phiM);
-            cosThetaM = powf(sample.x, 1.0f / (exponent + 2.0f));
-            pdf = std::sqrt((expU + 2.0f) * (expV + 2.0f)) * INV_TWOPI * powf(cosThetaM, exponent + 1.0f);
+            sinPhiM = msin(phiM); cosPhiM = mcos(phiM);
+            cosThetaM = mpow(sample.x, 1.0f / (exponent + 2.0f));
+            pdf = std::sqrt((expU + 2.0f) * (expV + 2.0f)) * INV_TWOPI * mpow(cosThetaM, exponent + 1.0f);
             if (pdf < 1e-20f) pdf = 0;
             float sinThetaP = std::sqrt(fmax2(0.0f, 1 - cosThetaM * cosThetaM));
             return V3(sinThetaP * cosPhiM, sinThetaP * sinPhiM, cosThetaM);
         }
-        if (isIso()) { float a = (2.0f * PI) * sample.y; sinPhiM = sinf(a); cosPhiM = cosf(a); alphaSqr = alphaU * alphaU; }
+        if (isIso()) { float a = (2.0f * PI) * sample.y; sinPhiM = msin(a); cosPhiM = mcos(a); alphaSqr = alphaU * alphaU; }
         else {
-            float phiM = atanf(alphaV / alphaU * tanf(PI + 2 * PI * sample.y)) + PI * floorf(2 * sample.y + 0.5f);
-            sinPhiM = sinf(phiM); cosPhiM = cosf(phiM);
+            float phiM = matan(alphaV / alphaU * mtan(PI + 2 * PI * sample.y)) + PI * floorf(2 * sample.y + 0.5f);
+            sinPhiM = msin(phiM); cosPhiM = mcos(phiM);
             float cosSc = cosPhiM / alphaU, sinSc = sinPhiM / alphaV;
             alphaSqr = 1.0f / (cosSc * cosSc + sinSc * sinSc);
         }
         if (type == CTL_MF_BECKMANN) {
-            float tanThetaMSqr = alphaSqr * -logf(1.0f - sample.x);
+            float tanThetaMSqr = alphaSqr * -mlog(1.0f - sample.x);
             cosThetaM = 1.0f / std::sqrt(1.0f + tanThetaMSqr);
             pdf = (1.0f - sample.x) / (PI * alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM);
         } else {
@@ -1125,18 +1125,18 @@ struct Microfacet {
         V2 slope;
         if (type == CTL_MF_BECKMANN) {   // :191-256: Newton / bisection on the CDF in the erf domain
             const float SQRT_PI_INV = 1 / std::sqrt(PI);
-            if (thetaI < 1e-4f) { float r = std::sqrt(-logf(1.0f - sample.x)); float a = 2 * PI * sample.y; return V2{ r * cosf(a), r * sinf(a) }; }
-            float tanThetaI = tanf(thetaI), cotThetaI = 1 / tanThetaI;
+            if (thetaI < 1e-4f) { float r = std::sqrt(-mlog(1.0f - sample.x)); float a = 2 * PI * sample.y; return V2{ r * mcos(a), r * msin(a) }; }
+            float tanThetaI = mtan(thetaI), cotThetaI = 1 / tanThetaI;
             float a = -1, c = erfRef(cotThetaI);
             float sample_x = sample.x > 1e-6f ? sample.x : 1e-6f;
             float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
-            float b = c - (1 + c) * powf(1 - sample_x, fit);
-            float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+            float b = c - (1 + c) * mpow(1 - sample_x, fit);
+            float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * mexp(-cotThetaI * cotThetaI));
             int it = 0;
             while (++it < 10) {
                 if (!(b >= a && b <= c)) b = 0.5f * (a + c);
                 float invErf = erfinvRef(b);
-                float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * expf(-invErf * invErf)) - sample_x;
+                float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * mexp(-invErf * invErf)) - sample_x;
                 float derivative = normalization * (1 - invErf * tanThetaI);
                 if (fabsf(value) < 1e-5f) break;
                 if (value > 0) c = b; else a = b;
@@ -1148,9 +1148,9 @@ struct Microfacet {
         }
         if (thetaI < 1e-4f) {
             float r = safe_sqrt(sample.x / (1 - sample.x)); float a = 2 * PI * sample.y;
-            return V2{ r * cosf(a), r * sinf(a) };
+            return V2{ r * mcos(a), r * msin(a) };
         }
-        float tanThetaI = tanf(thetaI);
+        float tanThetaI = mtan(thetaI);
         float a = 1 / tanThetaI;
         float G1 = 2.0f / (1.0f + safe_sqrt(1.0f + 1.0f / (a * a)));
         float A = 2.0f * sample.x / G1 - 1.0f;
@@ -1171,8 +1171,8 @@ struct Microfacet {
     V3 sampleVisible(V3 _wi, V2 sample) const {   // MicrofacetDistribution.cu:151-183
         V3 wi = normalize(V3(alphaU * _wi.x, alphaV * _wi.y, _wi.z));
         float theta = 0, phi = 0;
-        if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
-        float sinPhi = sinf(phi), cosPhi = cosf(phi);
+        if (wi.z < 0.99999f) { theta = macos(wi.z); phi = matan2(wi.y, wi.x); }
+        float sinPhi = msin(phi), cosPhi = mcos(phi);
         V2 slope = sampleVisible11(theta, sample);
         slope = V2{ cosPhi * slope.x - sinPhi * slope.y, sinPhi * slope.x + cosPhi * slope.y };
         slope.x *= alphaU; slope.y *= alphaV;
@@ -1585,7 +1585,7 @@ inline Spec uniformSampleAllLights(const Scene& S, const BRec& bRec, const ctl_m
 // InfiniteLight::evalEnvironment(ray, rX, rY) (SceneTypes/Light.cu:496-518)
 inline Spec envEvalDifferential(const Scene& S, const ctl_light& L, V3 dir, V3 dirX, V3 dirY) {
     V3 v = transformDirTranspose(L.to_world, dir);
-    V2 uv{ atan2f(v.x, -v.z) * INV_TWOPI, safe_acos(v.y) * INV_PI };
+    V2 uv{ matan2(v.x, -v.z) * INV_TWOPI, safe_acos(v.y) * INV_PI };
     V3 dvdx = transformDirTranspose(L.to_world, dirX) - v, dvdy = transformDirTranspose(L.to_world, dirY) - v;
     float t1 = INV_TWOPI / (v.x * v.x + v.z * v.z), t2 = -INV_PI / fmax2(safe_sqrt(1.0f - v.y * v.y), 1e-4f);
     V2 dudx{ t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y }, dudy{ t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y };
@@ -1620,10 +1620,10 @@ inline Spec pathTraceRegularization(const Scene& S, bool DIRECT, V3 ro, V3 rd, c
                     if (!(l->type == CTL_LIGHT_DIFFUSE || l->type == CTL_LIGHT_INFINITE)) {
                         if (rays) (*rays)++;
                         if (!occluded(S, bRec.dg.P, lDir, 0, lDist)) {
-                            float eps = atanf(g_fRMollifier / lDist);
-                            float normalization = 1.0f / (2 * PI * (1 - cosf(eps)));
+                            float eps = matan(g_fRMollifier / lDist);
+                            float normalization = 1.0f / (2 * PI * (1 - mcos(eps)));
                             float l_dot_o = dot(lDir, bRec.dg.sys.toWorld(bRec.wo));
-                            float indicator = acosf(l_dot_o) <= eps ? 1.0f : 0.0f;
+                            float indicator = macos(l_dot_o) <= eps ? 1.0f : 0.0f;
                             cl = cl + cf * f * l_s * (normalization * indicator);
                         }
                     }

@@ -12,7 +12,24 @@
 #include <cfloat>
 #include <algorithm>
 
+#ifdef ORC_SHARED_MATH
+#include "../cudatracerlib_amd/csrc/ctl_fmath.h"
+#endif
+
 namespace orc {
+
+// ---- transcendental functions of the path: glibc's (the reference's CPU path, what tests/golden pins bit for bit) or, with -DORC_SHARED_MATH (liboracle_sm.so), the product's
+// shared fp32 implementation (cudatracerlib_amd/csrc/ctl_fmath.h) that the HIP kernels run — the checker of the GPU parity tests then has no libm-vs-device difference left
+#ifdef ORC_SHARED_MATH
+inline float msin(float x) { return ctl::fm::sin(x); }  inline float mcos(float x) { return ctl::fm::cos(x); }  inline float mtan(float x) { return ctl::fm::tan(x); }
+inline float macos(float x) { return ctl::fm::acos(x); }  inline float matan(float x) { return ctl::fm::atan(x); }  inline float matan2(float y, float x) { return ctl::fm::atan2(y, x); }
+inline float mexp(float x) { return ctl::fm::exp(x); }  inline float mlog(float x) { return ctl::fm::log(x); }  inline float mlog2(float x) { return ctl::fm::log2(x); }  inline float mpow(float x, float y) { return ctl::fm::pow(x, y); }
+#else
+inline float msin(float x) { return sinf(x); }  inline float mcos(float x) { return cosf(x); }  inline float mtan(float x) { return tanf(x); }
+inline float macos(float x) { return acosf(x); }  inline float matan(float x) { return atanf(x); }  inline float matan2(float y, float x) { return atan2f(y, x); }
+inline float mexp(float x) { return expf(x); }  inline float mlog(float x) { return logf(x); }  inline float mlog2(float x) { return log2f(x); }  inline float mpow(float x, float y) { return powf(x, y); }
+#endif
+
 
 // Math/MathFunc.h:12-26
 static constexpr float PI = 3.14159265358979f;
@@ -26,7 +43,7 @@ inline float fmin2(float a, float b) { return (a < b) ? a : b; }   // MathFunc.h
 inline float fmax2(float a, float b) { return (a > b) ? a : b; }
 inline float clampf(float v, float lo, float hi) { return fmin2(fmax2(v, lo), hi); }  // MathFunc.h:170
 inline float safe_sqrt(float v) { return std::sqrt(fmax2(0.0f, v)); }                 // MathFunc.h:112
-inline float safe_acos(float v) { return acosf(fmin2(1.0f, fmax2(-1.0f, v))); }      // MathFunc.h:108
+inline float safe_acos(float v) { return macos(fmin2(1.0f, fmax2(-1.0f, v))); }      // MathFunc.h:108
 inline float fracf(float f) { return f - floorf(f); }                                 // MathFunc.h:138
 inline int floor2int(float v) { return (int)floorf(v); }                              // MathFunc.h:143
 inline float int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
@@ -34,6 +51,7 @@ inline int float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 inline float copysign_bits(float a, float b) {                                        // MathFunc.h:64-67
     return int_as_float((float_as_int(b) & 0x80000000) | (float_as_int(a) & ~0x80000000));
 }
+
 
 struct V2 { float x, y; };
 inline V2 operator*(V2 a, float s) { return V2{ a.x * s, a.y * s }; }
@@ -126,7 +144,7 @@ inline M44 inverse(const M44& Q) {
 // float4x4.h:229-244
 inline M44 perspective(float fov, float clipNear, float clipFar) {
     float recip = 1.0f / (clipFar - clipNear);
-    float cot = 1.0f / tanf(fov / 2.0f);
+    float cot = 1.0f / tanf(fov / 2.0f);   // set-up time (the product computes the camera matrices on the host, with libm, in both oracle builds)
     M44 m; std::memset(m.d, 0, sizeof(m.d));
     m(0, 0) = cot; m(1, 1) = cot; m(2, 2) = clipFar * recip; m(2, 3) = -clipNear * clipFar * recip; m(3, 2) = 1;
     return m;
@@ -176,7 +194,7 @@ inline V2 squareToUniformDiskConcentric(V2 sample) {   // Warp.h:104-127
     if (r1 == 0 && r2 == 0) { r = phi = 0; }
     else if (r1 * r1 > r2 * r2) { r = r1; phi = (PI / 4.0f) * (r2 / r1); }
     else { r = r2; phi = (PI / 2.0f) - (r1 / r2) * (PI / 4.0f); }
-    float cosPhi = cosf(phi), sinPhi = sinf(phi);
+    float cosPhi = mcos(phi), sinPhi = msin(phi);
     return V2{ r * cosPhi, r * sinPhi };
 }
 inline V3 squareToCosineHemisphere(V2 sample) {         // Warp.h:61-66
@@ -193,7 +211,7 @@ inline V3 squareToUniformSphere(V2 sample) {            // Warp.h:28-35
     float z = 1.0f - 2.0f * sample.y;
     float r = std::sqrt(1.0f - z * z);
     float a = 2.0f * PI * sample.x;
-    return V3(r * cosf(a), r * sinf(a), z);
+    return V3(r * mcos(a), r * msin(a), z);
 }
 
 // ---------------------------------------------------------------- MonteCarlo / Fresnel
@@ -271,8 +289,8 @@ inline float halfToFloat(uint16_t val, bool host_quirk = false) {
 // ---------------------------------------------------------------- Compression (Math/Compression.h)
 // Compression.h:12-18
 inline uint16_t normalToUchar2(V3 v) {
-    float theta = (acosf(v.z) * (255.0f / PI));
-    float phi = (atan2f(v.y, v.x) * (255.0f / (2.0f * PI)));
+    float theta = (macos(v.z) * (255.0f / PI));
+    float phi = (matan2(v.y, v.x) * (255.0f / (2.0f * PI)));
     phi = phi < 0 ? (phi + 255) : phi;
     return (uint16_t)(((unsigned short)theta << 8) | (unsigned short)phi);
 }
@@ -282,7 +300,7 @@ inline V3 uchar2ToNormal(uint16_t v) {
     unsigned char x = v >> 8, y = v & 0xff;
     float theta = x == 63 ? PI_4 : (x == 127 ? PI_2 : (x == 191 ? 3 * PI_4 : float(x) * (1.0f / 255.0f) * PI));
     float phi = y == 63 ? PI_2 : (y == 127 ? PI : (y == 191 ? 3 * PI_2 : float(y) * (1.0f / 255.0f) * PI * 2.0f));
-    float sinphi = sinf(phi), cosphi = cosf(phi), sintheta = sinf(theta), costheta = cosf(theta);
+    float sinphi = msin(phi), cosphi = mcos(phi), sintheta = msin(theta), costheta = mcos(theta);
     return V3(sintheta * cosphi, sintheta * sinphi, costheta);
 }
 

@@ -361,6 +361,17 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
     return total.load();
 }
 
+// the transcendental functions this build of the oracle runs its path with (omath.h msin ..: glibc's, or the product's shared ones with -DORC_SHARED_MATH):
+// which = 0 sin, 1 cos, 2 tan, 3 acos, 4 atan, 5 atan2(x, y), 6 exp, 7 log, 8 log2, 9 pow(x, y)
+void orc_math_eval(int which, int n, const float* x, const float* y, float* out) {
+    for (int i = 0; i < n; i++) {
+        switch (which) {
+        case 0: out[i] = msin(x[i]); break; case 1: out[i] = mcos(x[i]); break; case 2: out[i] = mtan(x[i]); break; case 3: out[i] = macos(x[i]); break;
+        case 4: out[i] = matan(x[i]); break; case 5: out[i] = matan2(x[i], y[i]); break; case 6: out[i] = mexp(x[i]); break; case 7: out[i] = mlog(x[i]); break;
+        case 8: out[i] = mlog2(x[i]); break; default: out[i] = mpow(x[i], y[i]); break;
+        }
+    }
+}
 // PathTracer::DebugInternal (Integrators/PathTracer.cu:172-180): PathTrace<true> for pixel (x, y) from the pixel's own position (no jitter; the aperture sample is the first draw),
 // with first-hit ray differentials, over one set of sampling tables -> rgb; also the primary hit distance (FLT_MAX on a miss) for the depth-buffer test
 void orc_debug_pixel(const ctl_scene_desc* desc, uint32_t W, uint32_t H, const float* t1, const float* t2, uint32_t x, uint32_t y, int maxPathLength, int rrStart, float* rgb, float* primary_dist) {

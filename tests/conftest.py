@@ -12,9 +12,26 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
-def orc():
+def _orc_libm():
     import oracle
     return oracle.Oracle()
+
+
+@pytest.fixture(scope="session")
+def orc_sm():
+    """the oracle built with the product's shared transcendental functions (oracle/liboracle_sm.so, csrc/ctl_fmath.h)"""
+    import oracle
+    return oracle.Oracle(shared_math=True)
+
+
+@pytest.fixture
+def orc(request, _orc_libm):
+    """The oracle.  CPU tests get the glibc build — the reference's CPU path, pinned on the reference's own code.  Tests marked `gpu` get the shared-math build: the HIP
+    kernels evaluate sin / cos / acos / atan2 / exp / log / pow with the same fp32 implementation, so GPU and checker differ only where a test says so.
+    tests/test_fmath.py holds the two builds together."""
+    if request.node.get_closest_marker("gpu") is not None:
+        return request.getfixturevalue("orc_sm")
+    return _orc_libm
 
 
 @pytest.fixture(scope="session")

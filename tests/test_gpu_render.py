@@ -1,11 +1,13 @@
 """Wavefront HIP path tracer vs the oracle's PathTrace<DIRECT> (Integrators/PathTracer.cu:10-113) on identical
 scenes and identical sampler tables.
 
-Tolerance (north_star: "within a stated per-pixel float tolerance"): both sides run the same fp32 expressions without
-FMA contraction; they differ only in libm vs device sin/cos/acos/atan2 (<= 2 ulp).  A 1-ulp difference can flip a
-discrete decision (Russian roulette, light-triangle choice, Fresnel branch) in rare paths, so the bar is
-  * >= 99.5 % of pixels: |gpu - cpu| <= 2e-3 * (1 + cpu) per channel of the accumulated radiance sum, and
+Tolerance (north_star: "within a stated per-pixel float tolerance"): both sides run the same fp32 expressions without FMA contraction AND the same
+transcendental functions — the kernels and the checker (the oracle's shared-math build, oracle/liboracle_sm.so) both compile csrc/ctl_fmath.h — so the bar is
+  * >= 99.95 % of pixels: |gpu - cpu| <= 2e-3 * (1 + cpu) per channel of the accumulated radiance sum,
+  * >= 98 % of pixels equal to the BIT (what is left: sums of float atomics in another order, texture filtering through the device's own exp2 / log2), and
   * the image means agree to 1e-3 relative.
+The glibc build of the oracle — the reference's CPU path, pinned on the reference's own code — differs from the shared-math build by <= 1 ulp per function
+call (tests/test_fmath.py), which is what used to separate GPU and checker.
 """
 import os
 import numpy as np
@@ -32,12 +34,14 @@ def render_pair(gpu, orc, sc, w, h, n_passes, max_len=8, rr=5, direct=True):
     return got, want, tr, want_rays
 
 
-def assert_close(got, want):
+def assert_close(got, want, exact_min=0.98):
     assert np.array_equal(got[..., 6], want[..., 6]), "weightSum differs"
     g, w = got[..., :3], want[..., :3]
     ok = np.abs(g - w) <= 2e-3 * (1 + np.abs(w))
     frac = ok.all(axis=2).mean()
-    assert frac >= 0.995, frac
+    assert frac >= 0.9995, frac
+    exact = (g == w).all(axis=2).mean()     # the shading code and the checker (the oracle's shared-math build) run the same fp32 functions: most pixels agree to the bit
+    assert exact >= exact_min, exact
     assert abs(g.mean() - w.mean()) <= 1e-3 * w.mean()
 
 
@@ -75,7 +79,8 @@ def test_cornell_plastic_roughdielectric_phong_thindielectric(gpu, orc, variant)
     11 / 12: Beckmann sampled from the visible normals (erf / erfinv iteration) and the Phong microfacet distribution"""
     sc = scenes.cornell_box(64, 64, extra_materials=variant)
     got, want, tr, rays = render_pair(gpu, orc, sc, 64, 64, 3)
-    assert_close(got, want)
+    # 6: the rough plastics look their transmittance up in the device's memoised / reduced tables (bsdf_rough.h) — the same values to fp32 round-off, not to the bit
+    assert_close(got, want, exact_min=0.98 if variant != 6 else 0.5)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(rotate_env=True, point_filter=True), dict(extra_lights=True)])
@@ -108,7 +113,7 @@ def test_synthetic_bathroom_workload(gpu, orc):
     bitmap texture + height map, environment emitter + area light, instanced meshes — two-level layout, per-pixel bar"""
     sc = scenes.synthetic_bathroom(96, 54, n_instances=60, subdiv=2)
     got, want, tr, rays = render_pair(gpu, orc, sc, 96, 54, 3, max_len=6)
-    assert_close(got, want)
+    assert_close(got, want, exact_min=0.0)      # rough plastic everywhere (reduced transmittance tables on the device, see variant 6 above): the per-pixel tolerance holds, bit equality does not
     assert want[..., :3].mean() > 0.1
 
 
@@ -161,7 +166,7 @@ def test_tungsten_style_interior_through_the_loader(gpu, orc, tmp_path):
     for cls, partials in ((gpu.WavefrontPathTracer, False), (gpu.PathTracer, True)):
         want, _ = orc.render(d, w, h, n_passes=n, tables=tables, max_path_length=8, partials=partials)
         got = _render(gpu, cls, scene, tables, w, h, max_len=8)
-        assert_close(got, want)
+        assert_close(got, want, exact_min=0.5)    # (rough plastic floor; the PathTracer plugin filters textures through the device's own arithmetic order)
         assert want[..., :3].mean() > 0.05
 
 
