@@ -295,9 +295,10 @@ static decoded_image decode_exr(const std::vector<uint8_t>& d, const std::string
     std::vector<uint8_t> buf, tmp;
     for (size_t b = 0; b < n_blocks; b++) {
         uint64_t off = 0; for (int k = 7; k >= 0; k--) off = (off << 8) | d[p + 8 * b + k];
-        if (off + 8 > d.size()) throw io_error("truncated OpenEXR (chunk offset) : " + path);
+        // compared without additions: `off` comes from the file and off + 8 wraps for offsets near 2^64
+        if (off > d.size() || d.size() - off < 8) throw io_error("truncated OpenEXR (chunk offset) : " + path);
         const long y0 = (long)(int)le32(&d[off]) - dw[1]; const uint32_t size = le32(&d[off + 4]);
-        if (y0 < 0 || y0 >= h || off + 8 + size > d.size()) throw io_error("corrupt OpenEXR chunk : " + path);
+        if (y0 < 0 || y0 >= h || size > d.size() - off - 8) throw io_error("corrupt OpenEXR chunk : " + path);
         const long lines = std::min<long>(lines_per_block, h - y0);
         const size_t raw = line_bytes * (size_t)lines;
         const uint8_t* src = &d[off + 8];

@@ -259,7 +259,8 @@ decoded_image decode_jpeg(const std::vector<uint8_t>& d, const std::string& path
                                 for (int bx = 0; bx < c->h; bx++) decode_block(br, *c, c->block(mx * c->h + bx, my * c->v + by), sp, dc, ac, path);
                     }
             }
-            n_scans++;
+            // every scan walks all blocks of its components: bound their number (libjpeg-turbo's own limit is configurable; real progressive files have ~10)
+            if (++n_scans > 256) throw io_error("corrupt JPEG (more than 256 scans) : " + path);
             pos = (size_t)(scan_end - d.data());
             continue;
         }

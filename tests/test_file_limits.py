@@ -38,7 +38,28 @@ def _jpeg(w, h):
     return b"\xff\xd8" + b"\xff\xc0" + struct.pack(">H", len(sof) + 2) + sof + b"\xff\xd9"
 
 
+def _exr_wrapping_offset():
+    """a well-formed 4x1 uncompressed header whose ONE offset-table entry is 2^64 - 4: `offset + 8` wraps around"""
+    a = lambda n, t, d: n + b"\0" + t + b"\0" + struct.pack("<I", len(d)) + d
+    chl = b"R\0" + struct.pack("<IBBBBii", 2, 0, 0, 0, 0, 1, 1) + b"\0"
+    box = struct.pack("<iiii", 0, 0, 3, 0)
+    head = a(b"channels", b"chlist", chl) + a(b"compression", b"compression", b"\x00") + a(b"dataWindow", b"box2i", box) + a(b"displayWindow", b"box2i", box) + \
+        a(b"lineOrder", b"lineOrder", b"\0") + a(b"pixelAspectRatio", b"float", struct.pack("<f", 1)) + a(b"screenWindowCenter", b"v2f", bytes(8)) + a(b"screenWindowWidth", b"float", struct.pack("<f", 1)) + b"\0"
+    return struct.pack("<II", 20000630, 2) + head + struct.pack("<Q", 0xFFFFFFFFFFFFFFFC) + bytes(64)
+
+
+def _jpeg_many_scans():
+    """a 16x16 greyscale progressive file header followed by 300 empty DC scans (each one walks every block): refused by the scan limit"""
+    sof = struct.pack(">BHHB", 8, 16, 16, 1) + bytes([1, 0x11, 0])
+    dht = bytes([0x00]) + bytes([1] + [0] * 15) + bytes([0])
+    sos = struct.pack(">B", 1) + bytes([1, 0x00]) + bytes([0, 0, 0])
+    scan = b"\xff\xda" + struct.pack(">H", len(sos) + 2) + sos
+    return b"\xff\xd8" + b"\xff\xc2" + struct.pack(">H", len(sof) + 2) + sof + b"\xff\xc4" + struct.pack(">H", len(dht) + 2) + dht + scan * 300 + b"\xff\xd9"
+
+
 CASES = {
+    "wrap.exr": _exr_wrapping_offset(),
+    "scans.jpg": _jpeg_many_scans(),
     "huge.pgm": b"P5\n2147483648 2147483648\n255\n" + bytes(32),
     "huge.ppm": b"P3\n60000 60000\n255\n1 2 3\n",
     "huge.pfm": b"PF\n70000 3\n-1.0\n" + bytes(32),
