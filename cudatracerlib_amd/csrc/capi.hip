@@ -134,6 +134,16 @@ int ctl_shared_math_eval(int32_t which, uint32_t n, const float* x, const float*
         }
     CTL_CATCH
 }
+int ctl_traversal_stack_histogram(uint64_t* out, uint32_t n_bins, int reset) {
+    CTL_REQUIRE(out && n_bins >= 1, "null argument");
+    CTL_TRY
+        require_device();
+        unsigned long long h[kStackSize];
+        read_stack_histogram(h, reset != 0);
+        for (uint32_t i = 0; i < n_bins; i++) out[i] = 0;
+        for (int i = 0; i < kStackSize; i++) out[(uint32_t)i < n_bins ? (uint32_t)i : n_bins - 1] += h[i];
+    CTL_CATCH
+}
 // ---- scene
 int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc, false); CTL_CATCH }
 int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY

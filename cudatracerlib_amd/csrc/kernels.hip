@@ -6,6 +6,7 @@
 #include "traverse.h"
 #include "traverse_flat.h"
 #include "knobs.h"
+#include <stdexcept>
 #include "shading.h"
 #include "compaction.h"
 #include <cstdlib>
@@ -182,6 +183,11 @@ __global__ __launch_bounds__(kBlock) void k_apply_pipeline(const ctl_pixel_data*
     }
 }
 
+// the counting kernels' stack-depth histogram (traverse_flat.h g_stack_hist lives in this translation unit)
+void read_stack_histogram(unsigned long long* h, bool reset) {
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stack_hist), sizeof(unsigned long long) * kStackSize) != hipSuccess) throw std::runtime_error("reading the stack histogram failed");
+    if (reset) { unsigned long long z[kStackSize] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stack_hist), z, sizeof(z)) != hipSuccess) throw std::runtime_error("clearing the stack histogram failed"); }
+}
 static unsigned g_lds_pad = 0;   // extra dynamic LDS per traversal workgroup: holds the kernels to fewer resident workgroups per CU (occupancy experiment)
 void apply_tuning_from_env() {
     static bool done = false;

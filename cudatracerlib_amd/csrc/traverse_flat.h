@@ -28,6 +28,7 @@ enum { kFmtQ4 = 0, kFmtF4 = 1, kFmtF2 = 2 };   // = flat_format (flatten.h)
 #define CTL_FLAT_LDS_ROWS 19
 #endif
 constexpr int kFlatLdsRows = CTL_FLAT_LDS_ROWS;   // stack entries per lane in LDS (+ 1 spare row); deeper entries live in scratch
+__device__ unsigned long long g_stack_hist[kStackSize];   // counting kernels only: rays by the deepest traversal-stack entry they used (ctl_traversal_stack_histogram)
 __device__ int g_leaf_batch = 16;         // run the leaf phase once this many lanes hold a pending leaf entry (knob CTL_LEAF_BATCH).  With the oriented slabs fewer leaves are parked: 8: 2253, 12: 2299, 16: 2315, 20: 2311, 24: 2288, 32: 2216 Mrays/s (gpurun_out r03g / r03h)
 
 // Stack entry = {link, entry distance of the pushed child}: a pop whose entry distance is not below the current hit distance is dropped on the spot
@@ -223,6 +224,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
     ray_cull R{ 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     float ht = 0, hu = 0, hv = 0; int htri = -1, hnode = -1;
     int sp = 0, node = kSentinel, pend = -1;      // pend: postponed leaf (its first entry in flat_leaves), -1 = none
+    int sp_max = 0;                               // COUNT: deepest stack entry of the lane's current ray
     const float4* __restrict__ nodes = S.flat_nodes;
     uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = (n == 0);
 
@@ -294,6 +296,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
                     if (n_hit >= 2) st.set(top, stack_word(c[1], dd[1]));
                 }
                 sp = top;
+                if (COUNT && sp > sp_max) sp_max = sp;
                 if (n_hit == 0 && stack_word_culled(popped, ht)) node = st.pop(sp, ht);   // the popped child lies behind the hit found since it was pushed: next one
             }
         }
@@ -301,6 +304,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
         if (finished) {
             if (ANY_HIT && occ) occ[ray_id] = htri >= 0 ? 1u : 0u;
             if (hit) { hit[ray_id] = make_float4(ht, hu, hv, __int_as_float(htri)); hit_node[ray_id] = hnode; }
+            if (COUNT) { atomicAdd(&g_stack_hist[sp_max < kStackSize ? sp_max : kStackSize - 1], 1ull); sp_max = 0; }
             has_ray = false; node = kSentinel; pend = -1;
         }
     }

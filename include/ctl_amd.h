@@ -503,6 +503,11 @@ int ctl_intersect_device(ctl_scene* s, const void* d_ray_o, const void* d_ray_d,
  * instance entries (B_ray = 32 + 16 + 64*N_inner + 52*N_tri + 108*N_inst). */
 int ctl_intersect_count(ctl_scene* s, const ctl_ray* rays, uint32_t n, int any_hit, ctl_traversal_counts* out);
 
+/* Measurement: rays of all COUNTING traversals so far (ctl_intersect_count, ctl_tracer_set_counting) over the flattened BVH, by the deepest traversal-stack entry they
+ * used; bin n_bins - 1 collects everything deeper.  The kernels keep the first 19 entries of a lane in LDS and deeper ones in scratch (csrc/traverse_flat.h): the
+ * histogram says how often that happens.  reset != 0 clears it. */
+int ctl_traversal_stack_histogram(uint64_t* out, uint32_t n_bins, int reset);
+
 /* The shared fp32 transcendental functions of the shading code (cudatracerlib_amd/csrc/ctl_fmath.h; the oracle's -DORC_SHARED_MATH build runs the same source):
  * which = 0 sin, 1 cos, 2 tan, 3 acos, 4 atan, 5 atan2(x, y), 6 exp, 7 log, 8 log2, 9 pow(x, y); on_device = 0 evaluates on the host, 1 in a kernel — the two are
  * bit-identical (tests/test_fmath.py).  No reference counterpart: the reference calls the CUDA / C library's functions. */
