@@ -15,12 +15,16 @@ namespace ctl {
 
 // single-ray traversal of the flattened BVH (traverse_flat.h): closest hit, or any hit in (tmin, tmax)
 template <bool ANY_HIT>
-__device__ bool trace_single(const dev_scene& S, f3 o, f3 d, float tmin, float tmax, float& ht, float& hu, float& hv, int& htri, int& hnode) {
-    return trace_single_flat<ANY_HIT, true>(S, o, d, tmin, tmax, ht, hu, hv, htri, hnode);
+__device__ __noinline__ bool trace_single(const dev_scene& S, f3 o, f3 d, float tmin, float tmax, float& ht, float& hu, float& hv, int& htri, int& hnode) {
+    __shared__ int s_stack[kSingleLdsRows * 256];   // one column per lane of the 256-lane workgroup (both instantiations: 2 x 20 KiB)
+    return trace_single_flat<ANY_HIT, true>(S, (lds_int*)s_stack + threadIdx.x, o, d, tmin, tmax, ht, hu, hv, htri, hnode);
 }
 
 // pathKernel2<DIRECT> + PathTrace<DIRECT> (Integrators/PathTracer.cu:182-194, 10-113), no participating media
-__global__ __launch_bounds__(256) void k_path_trace(dev_scene S, pass_params P, ctl_pixel_data* __restrict__ image, unsigned long long* __restrict__ ray_count) {
+#ifndef CTL_MEGA_WAVES
+#define CTL_MEGA_WAVES 2
+#endif
+__global__ __launch_bounds__(256, CTL_MEGA_WAVES) void k_path_trace(dev_scene S, pass_params P, ctl_pixel_data* __restrict__ image, unsigned long long* __restrict__ ray_count) {
     const uint32_t tiles_x = (P.width + 63) / 64;
     const uint32_t n_total = P.n_local_pixels * P.batch;
     const uint32_t n1 = CTL_SAMPLER_NUM_SEQUENCES * CTL_SAMPLER_SEQUENCE_LENGTH;

@@ -109,7 +109,7 @@ __device__ inline f3 mip_eval_ewa(const ctl_mipmap& M, const dev_mip_levels& L, 
     if (denominator == 0) return mip_triangle_l(M, L, level, uv);
     return sdiv(result, denominator);
 }
-__device__ inline f3 mip_eval(const ctl_mipmap& M, const dev_mip_levels& L, const float* __restrict__ lut, f2 uv, f2 d0, f2 d1) {   // KernelMIPMap::eval(uv, d0, d1)
+__device__ __noinline__ f3 mip_eval(const ctl_mipmap& M, const dev_mip_levels& L, const float* __restrict__ lut, f2 uv, f2 d0, f2 d1) {   // KernelMIPMap::eval(uv, d0, d1)
     const float dimx = (float)M.width, dimy = (float)M.height;
     const float du0 = d0.x * dimx, dv0 = d0.y * dimy, du1 = d1.x * dimx, dv1 = d1.y * dimy, du = (du0 + du1) / 2.0f, dv = (dv0 + dv1) / 2.0f;
     if (M.filter_mode == CTL_FILTER_POINT) return mip_texel_l(M, L, 0, uv);

@@ -310,15 +310,24 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
     }
 }
 
-// Single-ray form for the megakernel plugin (one lane walks a whole path): same node steps, same entry test, private stack.
+// Single-ray form for the megakernel plugin (one lane walks a whole path): same node steps, same entry test.  The stack's first kSingleLdsRows entries live in LDS
+// (`lds_col` = this lane's column of a [row][256] array, as in the wavefront kernel), deeper ones in a private array: a stack in scratch alone made every push and
+// pop a trip through the vector memory path (megakernel 64.5 -> see DESIGN.md §8 ms per pass on the bench workload).
+constexpr int kSingleLdsRows = 20;
+typedef __attribute__((address_space(3))) int lds_int;
+struct single_stack {
+    lds_int* lds; int ovf[kStackSize - kSingleLdsRows];
+    __device__ __forceinline__ int get(int i) const { int v = lds[(i < kSingleLdsRows ? i : 0) * 256]; if (i >= kSingleLdsRows) v = ovf[i - kSingleLdsRows]; return v; }
+    __device__ __forceinline__ void set(int i, int v) { if (i < kSingleLdsRows) lds[i * 256] = v; else ovf[i - kSingleLdsRows] = v; }
+};
 template <bool ANY_HIT, bool ALPHA_DYNAMIC>
-__device__ bool trace_single_flat(const dev_scene& S, f3 o, f3 d, float tmin, float tmax, float& ht, float& hu, float& hv, int& htri, int& hnode) {
+__device__ bool trace_single_flat(const dev_scene& S, lds_int* lds_col, f3 o, f3 d, float tmin, float tmax, float& ht, float& hu, float& hv, int& htri, int& hnode) {
     const float4* __restrict__ nodes = S.flat_nodes;
     ray_cull R;
     R.idx = rcp_cull(d.x); R.idy = rcp_cull(d.y); R.idz = rcp_cull(d.z);
     R.oox = o.x * R.idx; R.ooy = o.y * R.idy; R.ooz = o.z * R.idz;
     R.sx = R.idx < 0.0f ? 1 : 0; R.sy = R.idy < 0.0f ? 1 : 0; R.sz = R.idz < 0.0f ? 1 : 0;
-    int stack[kStackSize]; int sp = 0; stack[0] = kSentinel;
+    single_stack stack; stack.lds = lds_col; int sp = 0; stack.set(0, kSentinel);
     int node = S.flat_root;
     const int fmt = S.flat_format;
     ht = tmax; hu = hv = 0.0f; htri = -1; hnode = -1;
@@ -328,8 +337,8 @@ __device__ bool trace_single_flat(const dev_scene& S, f3 o, f3 d, float tmin, fl
             if (fmt == kFmtF4) n_hit = node_step_f4(nodes, node, R, tmin, ht, c, dd);
             else if (fmt == kFmtQ4) n_hit = node_step_q4(nodes, node, R, o.x, o.y, o.z, d.x, d.y, d.z, tmin, ht, c, dd, S.flat_compact != 0);
             else n_hit = node_step_f2(nodes, node, R, tmin, ht, c, dd);
-            for (int i = n_hit - 1; i >= 1; i--) stack[++sp] = c[i];
-            node = n_hit ? c[0] : stack[sp--];
+            for (int i = n_hit - 1; i >= 1; i--) stack.set(++sp, c[i]);
+            if (n_hit) node = c[0]; else { node = stack.get(sp); sp--; }
         } else {
             bool got = false; int next = ~node;
             // USE_ALPHA of __traceRay_internal__ (TraceHelper.cu:135-153): scenes with alpha maps test every candidate hit
@@ -337,7 +346,7 @@ __device__ bool trace_single_flat(const dev_scene& S, f3 o, f3 d, float tmin, fl
                 next = (ALPHA_DYNAMIC && S.alpha_maps) ? flat_leaf_test<ANY_HIT, true>(S, (uint32_t)next, o.x, o.y, o.z, d.x, d.y, d.z, tmin, ht, hu, hv, htri, hnode, got)
                                                        : flat_leaf_test<ANY_HIT, false>(S, (uint32_t)next, o.x, o.y, o.z, d.x, d.y, d.z, tmin, ht, hu, hv, htri, hnode, got);
             if (ANY_HIT && got) return true;
-            node = stack[sp--];
+            node = stack.get(sp); sp--;
         }
     }
     return htri >= 0;

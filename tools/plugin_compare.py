@@ -19,8 +19,10 @@ def main():
     ap.add_argument("--instances", type=int, default=2000)
     ap.add_argument("--subdiv", type=int, default=4)
     args = ap.parse_args()
+    args.scene = None; args.via_loader = False
     import cudatracerlib_amd as ctl
-    sc = bench.build_scene(args)
+    ctl.api.set_cache_dir(os.path.join(os.environ.get("TMPDIR", "/tmp"), "ctl_amd_cache"))
+    sc, _ = bench.build_scene(args)
     scene = ctl.Scene(sc.desc, flatten=True)
     res = {}
     for cls in (ctl.WavefrontPathTracer, ctl.PathTracer):
