@@ -148,6 +148,11 @@ CTL_FM_HD float pow(float x, float y) {
     float sign = 1.0f; double ax = (double)x;
     if (x < 0.0f) { if (!y_int) return fnan(); ax = -ax; if (y_odd) sign = -1.0f; }
     if (ax > 3.4e38) return y > 0 ? sign * finf() : sign * 0.0f;                            // x = +-inf
+    if (y_int && ay <= 6.0f) {                                                              // the shading code's cos^4, (1 - c)^5, x^2 ...: a few exact-enough double products
+        double r = ax; const int n = (int)ay;
+        for (int k = 1; k < n; k++) r *= ax;
+        return sign * (float)(y < 0 ? 1.0 / r : r);
+    }
     const double t = (double)y * log_d(ax);
     if (t > 100.0) return sign * finf();
     if (t < -120.0) return sign * 0.0f;
