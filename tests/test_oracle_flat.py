@@ -157,6 +157,38 @@ print("NODES", fb.desc.n_nodes, "MULTI", int((sizes > 1).sum()))
     assert out["1"][1] > out["0"][1], out           # some leaves were merged
 
 
+def test_product_library_reads_no_measurement_knob():
+    """csrc/knobs.h: knob_env() is getenv only in the -DCTL_MEASUREMENT_KNOBS build.  The product library builds the same tree whatever the
+    environment says (here: the collapse and the leaf-size knobs), and the knobs build does react."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, hashlib
+sys.path.insert(0, %r)
+from cudatracerlib_amd import api, scenes
+api.set_cache_dir("")
+sc = scenes.synthetic_sm(32, 32, n_instances=30, subdiv=2)
+fb = api.FlatBvh(sc.desc, api.FLAT_Q4)
+print("TREE", fb.desc.n_nodes, hashlib.sha1(fb.nodes().tobytes()).hexdigest())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(lib, **knobs):
+        env = dict(os.environ, **knobs)
+        env.pop("CTL_AMD_LIB", None)
+        if lib:
+            env["CTL_AMD_LIB"] = os.path.join(root, "cudatracerlib_amd", lib)
+        r = subprocess.run([sys.executable, "-c", code % root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("TREE")][-1]
+
+    plain = run(None)
+    assert run(None, CTL_FLAT_COLLAPSE="1", CTL_FLAT_MAX_LEAF="4", CTL_FLAT_SLAB_USEFUL="2.0", CTL_FLAT_BFS_TOP="0") == plain
+    assert run("libctl_knobs.so") == plain
+    assert run("libctl_knobs.so", CTL_FLAT_COLLAPSE="1", CTL_FLAT_MAX_LEAF="4") != plain
+
+
 def test_missing_children_have_inverted_boxes():
     """flat4_node: a slot without a child carries lo = 255 / hi = 0 on every axis (the kernel has no per-slot "child exists" test), a slot with a child lo <= hi"""
     for sc in (scenes.synthetic_sm(32, 32, n_instances=40, subdiv=2), scenes.cornell_box(32, 32, glass_sphere=True)):
