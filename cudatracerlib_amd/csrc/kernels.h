@@ -82,6 +82,7 @@ void launch_shade_full(const launch_ctx& lc, const dev_scene& S, const wave_queu
 void launch_shade_basic_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_full_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_finalize(const launch_ctx& lc, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+int flat_top_cache_nodes();   // nodes at the head of the flattened node array that the traversal workgroups keep in LDS (traverse_flat.h kTopCache)
 void launch_accumulate_stats(const launch_ctx& lc, const wave_queues& Q, int max_depth);
 void launch_apply_pipeline(const launch_ctx& lc, const ctl_pixel_data* image, uint32_t n, float splat_scale, uint32_t* rgbcol_out);
 void launch_resolve_rgb(const launch_ctx& lc, const ctl_pixel_data* image, uint32_t n, float splat_scale, float* rgb_out);

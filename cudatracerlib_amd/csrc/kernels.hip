@@ -65,9 +65,11 @@ __global__ __launch_bounds__(kBlock, ((LAYOUT && !ALPHA) ? CTL_INTERSECT_MIN_WAV
                                                        uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ,
                                                        unsigned long long* __restrict__ counts3) {
     __shared__ int lds_stack[(LAYOUT ? (kFlatLdsRows + 1) * kFlatStackInts : kLdsStack) * kBlock];   // flat: + one spare row that absorbs unused push slots
+    __shared__ __attribute__((aligned(16))) float lds_top[LAYOUT ? kTopCacheFloats : 4];
     const uint32_t n = *n_ptr;
     trav_counts tc{ 0, 0, 0, 0, 0 };
-    if (LAYOUT) intersect_flat<ANY_HIT, COUNT, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
+    if (LAYOUT) fill_top_cache(S, lds_top);
+    if (LAYOUT) intersect_flat<ANY_HIT, COUNT, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, lds_top, tc);
     else intersect_persistent<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
     if (COUNT) {
         atomicAdd(&counts3[0], (unsigned long long)tc.n_inner); atomicAdd(&counts3[1], (unsigned long long)tc.n_tri); atomicAdd(&counts3[2], (unsigned long long)tc.n_inst);
@@ -84,16 +86,20 @@ __global__ __launch_bounds__(kBlock, ((LAYOUT && !ALPHA) ? CTL_INTERSECT_MIN_WAV
                                                             const float4* __restrict__ sro, const float4* __restrict__ srd, const uint32_t* __restrict__ sn_ptr,
                                                             uint32_t* __restrict__ swork, uint32_t* __restrict__ occ) {
     __shared__ int lds_stack[(LAYOUT ? (kFlatLdsRows + 1) * kFlatStackInts : kLdsStack) * kBlock];
+    __shared__ __attribute__((aligned(16))) float lds_top[LAYOUT ? kTopCacheFloats : 4];
     const uint32_t n = *n_ptr, sn = *sn_ptr;
     trav_counts tc{ 0, 0, 0, 0, 0 };
     if (LAYOUT) {
-        intersect_flat<false, false, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, nullptr, lds_stack, tc);
-        intersect_flat<true, false, ALPHA, LAYOUT - 1>(S, sro, srd, sn, swork, nullptr, nullptr, occ, lds_stack, tc);
+        fill_top_cache(S, lds_top);
+        intersect_flat<false, false, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, nullptr, lds_stack, lds_top, tc);
+        intersect_flat<true, false, ALPHA, LAYOUT - 1>(S, sro, srd, sn, swork, nullptr, nullptr, occ, lds_stack, lds_top, tc);
     } else {
         intersect_persistent<false, false, ALPHA>(S, ro, rd, n, work, hit, hit_node, nullptr, lds_stack, tc);
         intersect_persistent<true, false, ALPHA>(S, sro, srd, sn, swork, nullptr, nullptr, occ, lds_stack, tc);
     }
 }
+
+int flat_top_cache_nodes() { return kTopCache; }
 
 // terminated paths whose last NEE shadow ray has now been traced
 __global__ __launch_bounds__(kBlock) void k_finalize(wave_queues Q, pass_params P, int depth, ctl_pixel_data* __restrict__ image) {

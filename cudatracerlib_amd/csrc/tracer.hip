@@ -273,7 +273,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
             throw std::runtime_error("ctl_scene_create: scene BVH depth " + std::to_string(top) + " + mesh BVH depth " + std::to_string(bottom) +
                                      " does not fit the traversal stack of " + std::to_string(kStackSize) + " entries (rebuild the meshes with CTL_BVH_BINNED, whose depth is bounded)");
     }
-    S.flat_nodes = nullptr; S.flat_leaves = nullptr; S.flat_root = 0; S.flat_format = 0; S.flat_compact = 0; S.inst_w_one = 0;
+    S.flat_nodes = nullptr; S.flat_leaves = nullptr; S.flat_root = 0; S.flat_format = 0; S.flat_compact = 0; S.inst_w_one = 0; S.flat_top_cached = 0;
     if (flatten) {
         // node format: Q4 (64-B 4-wide nodes with 8-bit child boxes) unless the caller or $CTL_FLAT_FORMAT asks for F4 / F2 (DESIGN.md §3 has the measurements)
         flat_scene F;
@@ -293,6 +293,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
             CTL_HIP(hipDeviceSynchronize());
             S.flat_nodes = flat_nodes_.p; S.flat_leaves = flat_leaves_.p; S.flat_format = F.format; S.flat_compact = (F.format == kFlatQ4 && F.compact_links) ? 1 : 0;
             S.flat_root = (S.flat_compact && F.root_slab) ? 1 : 0;   // bit 0 of an inner link: the node carries an oriented slab (flat_slab.h)
+            S.flat_top_cached = S.flat_compact ? (int)std::min<size_t>(F.nodes.size(), (size_t)flat_top_cache_nodes()) : 0;
         }
     }
     CTL_HIP(hipDeviceSynchronize());

@@ -24,9 +24,28 @@ namespace ctl {
 
 enum { kFmtQ4 = 0, kFmtF4 = 1, kFmtF2 = 2 };   // = flat_format (flatten.h)
 
+// Measured and NOT shipped (round 3, tools/ab_libs.sh r03e, same box): the first kTopCache nodes of the node array — the top of the tree, which flatten.cpp stores breadth-first:
+// 85 = four full levels — copied into LDS by every traversal workgroup (48 B each; a node with a slab goes the global way).  Counted by the oracle on the bench scene
+// (tools/bvh_quality_probe.py): 32 % of all node visits are visits of these 85 nodes (41 % for 341, 50 % for 1365).  Result: 2341 Mrays/s against 2457 without (64 / 128 nodes:
+// 2335 / 2340) — a wave's lanes are spread over all levels, so every step runs the LDS arm AND the global arm one after the other, and what the kernel is short of is
+// time per step, not L1 look-ups.  CTL_TOP_CACHE=85 CTL_FLAT_LDS_ROWS=17 rebuilds that variant.
+#ifndef CTL_TOP_CACHE
+#define CTL_TOP_CACHE 0
+#endif
 #ifndef CTL_FLAT_LDS_ROWS
 #define CTL_FLAT_LDS_ROWS 19
 #endif
+constexpr int kTopCache = CTL_TOP_CACHE;
+constexpr int kTopCacheFloats = (kTopCache ? kTopCache : 1) * 12;
+typedef float __attribute__((ext_vector_type(4))) lds_f4v;
+typedef __attribute__((address_space(3))) const lds_f4v lds_top_f4;
+// called by the whole workgroup before the traversal: LDS <- the first 48 B of the first S.flat_top_cached nodes
+__device__ __forceinline__ void fill_top_cache(const dev_scene& S, float* lds_top) {
+    if (!kTopCache) return;
+    const int n = S.flat_top_cached * 3;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) ((float4*)lds_top)[i] = S.flat_nodes[(i / 3) * 4 + (i % 3)];
+    __syncthreads();
+}
 constexpr int kFlatLdsRows = CTL_FLAT_LDS_ROWS;   // stack entries per lane in LDS (+ 1 spare row); deeper entries live in scratch
 __device__ unsigned long long g_stack_hist[kStackSize];   // counting kernels only: rays by the deepest traversal-stack entry they used (ctl_traversal_stack_histogram)
 __device__ int g_leaf_batch = 16;         // run the leaf phase once this many lanes hold a pending leaf entry (knob CTL_LEAF_BATCH).  With the oriented slabs fewer leaves are parked: 8: 2253, 12: 2299, 16: 2315, 20: 2311, 24: 2288, 32: 2216 Mrays/s (gpurun_out r03g / r03h)
@@ -34,6 +53,25 @@ __device__ int g_leaf_batch = 16;         // run the leaf phase once this many l
 // Stack entry = {link, entry distance of the pushed child}: a pop whose entry distance is not below the current hit distance is dropped on the spot
 // (the closest hit moved in front of that child while it waited) — counted by the oracle on the bench scene: 10 % of the node visits, 5 % of the entry tests.
 // 8 B per entry: 40 KiB of LDS per 256-lane workgroup, four workgroups per CU (the kernel runs as fast at 4 waves per SIMD as at 6).
+// Round-3 experiments on the node fetch, all measured on one box against the shipped order of loads (2462 Mrays/s; tools/ab_libs.sh r03c / r03d), none shipped:
+//   CTL_NODE_FETCH_QUAD  the four lanes of a quad read each other's nodes as contiguous 64 B and transpose them in registers (node_fetch_quad below): 2125
+//   CTL_PARK_IN_STEP     a node step whose nearest child is a leaf parks it at once and walks on with the second nearest (no trip through the stack): 2461 / 2441
+//   CTL_PREFETCH_NODE    the step touches one dword of the node it goes to next (consumed after the next step's own loads): 2044
+//   CTL_PREFETCH_LEAF    parking a leaf touches the line of its first entry: 2413
+// What DID pay: issuing the load of the slab quarter together with the other three (node_fetch_own) instead of after the link arithmetic that waits for them — the second
+// round trip through the L1 per slab node was 9 % of the whole job (2279 -> 2486).
+#ifndef CTL_NODE_FETCH_QUAD
+#define CTL_NODE_FETCH_QUAD 0
+#endif
+#ifndef CTL_PARK_IN_STEP
+#define CTL_PARK_IN_STEP 0
+#endif
+#ifndef CTL_PREFETCH_NODE
+#define CTL_PREFETCH_NODE 0
+#endif
+#ifndef CTL_PREFETCH_LEAF
+#define CTL_PREFETCH_LEAF 0
+#endif
 #ifndef CTL_STACK_DIST
 #define CTL_STACK_DIST 0
 #endif
@@ -147,10 +185,58 @@ __device__ __forceinline__ int node_step_f4(const float4* __restrict__ nodes, in
 // Q4: 64-B node with 8-bit child boxes (flat4_node).  compact: the child links are implied by the layout and only the first 48 B are
 // loaded — three per-lane L1 accesses instead of four — unless the link that led here says the node carries an oriented slab (bit 0; flat_slab.h):
 // then the last 16 B are loaded too and every child's entry / exit distance is clipped by its interval along the node's slab direction.
-__device__ __forceinline__ int node_step_q4(const float4* __restrict__ nodes, int node, const ray_cull& R, float ox, float oy, float oz, float dx, float dy, float dz,
-                                            float tmin, float ht, int c[4], float dd[4], bool compact) {
+//
+// How the 48 / 64 B reach the lane (node_words).  node_fetch_own: three / four global_load_dwordx4 of the lane's own node — 64 lanes, 64 different lines, and the L1 looks every
+// lane-load up on its own: 3-4 tag look-ups per node, which is what the kernel's time floor is made of (tools/coop_probe.hip: 174-220 G records/s for L2-resident records this way,
+// 440-520 G/s when four lanes read one record as one contiguous 64 B).  node_fetch_quad: in round r the four lanes of a quad read the node of the quad's lane r, 16 B each — one
+// look-up per node — and the 4 x 4 block of 16-B pieces is transposed inside the quad by two butterfly stages of v_cndmask_b32_dpp (32 VALU, no LDS), after which every lane holds
+// its own node exactly as node_fetch_own would have loaded it.  Lanes of the wave that are not on a node take part in the loads of their quad's other lanes.
+struct node_words { float4 q0, q1, q2, q3; };
+__device__ __forceinline__ void node_fetch_own(const float4* __restrict__ nodes, int node, bool compact, node_words& W) {
     const float4* __restrict__ p = nodes + (node & ~3);
-    const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    W.q0 = p[0]; W.q1 = p[1]; W.q2 = p[2];
+    if (!compact || (node & 1)) W.q3 = p[3];
+}
+// d = take_b ? b : a[lane ^ 1]   (dword by dword; take_b is a wave mask)
+#define CTL_SEL4_DPP(NAME, PERM) \
+__device__ __forceinline__ uint4 NAME(const uint4 a, const uint4 b, unsigned long long take_b) { \
+    uint4 d; \
+    asm("s_mov_b64 vcc, %12\n\ts_nop 1\n\t" \
+        "v_cndmask_b32_dpp %0, %4, %8, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t" \
+        "v_cndmask_b32_dpp %1, %5, %9, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t" \
+        "v_cndmask_b32_dpp %2, %6, %10, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t" \
+        "v_cndmask_b32_dpp %3, %7, %11, vcc " PERM " row_mask:0xf bank_mask:0xf" \
+        : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w) \
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "s"(take_b) : "vcc"); \
+    return d; \
+}
+CTL_SEL4_DPP(sel4_quad_xor1, "quad_perm:[1,0,3,2]")
+CTL_SEL4_DPP(sel4_quad_xor2, "quad_perm:[2,3,0,1]")
+#undef CTL_SEL4_DPP
+__device__ __forceinline__ float4 as_f4(const uint4 v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
+// node: the lane's node link (index << 2 | slab flag) or anything when !active; called by the whole wave
+__device__ __forceinline__ void node_fetch_quad(const float4* __restrict__ nodes, int node, bool active, bool compact, node_words& W) {
+    const int sub = threadIdx.x & 3;
+    const int key = active ? node : -1;
+    uint4 t[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int k = r == 0 ? __builtin_amdgcn_mov_dpp(key, 0x00, 0xf, 0xf, false) : r == 1 ? __builtin_amdgcn_mov_dpp(key, 0x55, 0xf, 0xf, false)
+                    : r == 2 ? __builtin_amdgcn_mov_dpp(key, 0xaa, 0xf, 0xf, false) : __builtin_amdgcn_mov_dpp(key, 0xff, 0xf, 0xf, false);
+        t[r] = make_uint4(0u, 0u, 0u, 0u);
+        if (k >= 0 && (sub != 3 || (k & 1) || !compact)) t[r] = *(const uint4*)(nodes + (k & ~3) + sub);   // the last quarter only where the owner's node carries a slab
+    }
+    // 4 x 4 transpose over (lane of the quad, round): piece (lane p, round q) = quarter p of the node of lane q  ->  (lane q, register p)
+    const unsigned long long odd1 = 0xaaaaaaaaaaaaaaaaull, odd2 = 0xccccccccccccccccull;   // lanes with bit 0 / bit 1 of the lane number set
+    const uint4 u0 = sel4_quad_xor1(t[1], t[0], ~odd1), u1 = sel4_quad_xor1(t[0], t[1], odd1);
+    const uint4 u2 = sel4_quad_xor1(t[3], t[2], ~odd1), u3 = sel4_quad_xor1(t[2], t[3], odd1);
+    W.q0 = as_f4(sel4_quad_xor2(u2, u0, ~odd2)); W.q2 = as_f4(sel4_quad_xor2(u0, u2, odd2));
+    W.q1 = as_f4(sel4_quad_xor2(u3, u1, ~odd2)); W.q3 = as_f4(sel4_quad_xor2(u1, u3, odd2));
+}
+
+__device__ __forceinline__ int node_step_q4(const node_words& W, int node, const ray_cull& R, float ox, float oy, float oz, float dx, float dy, float dz,
+                                            float tmin, float ht, int c[4], float dd[4], bool compact) {
+    const float4 q0 = W.q0, q1 = W.q1, q2 = W.q2;
     const uint32_t meta = __float_as_uint(q0.w);
     const float inf = __builtin_huge_valf();
     float s_alpha = 0.0f, s_bn = -inf, s_bf = inf; uint32_t s_nw = 0u, s_fw = 0u;   // no slab: [-inf, inf] for every child
@@ -166,13 +252,13 @@ __device__ __forceinline__ int node_step_q4(const float4* __restrict__ nodes, in
         c[2] = (leafm & 4u) ? ~(int)(leaf_base + n0 + n1) : (int)(((inner_base + i2) << 2) | ((sflags >> 2) & 1u));
         c[3] = (leafm & 8u) ? ~(int)(leaf_base + n0 + n1 + n2) : (int)(((inner_base + i3) << 2) | ((sflags >> 3) & 1u));
         if (node & 1) {
-            const float4 q3 = p[3];
+            const float4 q3 = W.q3;
             slab_ray SR;
             slab_setup(__float_as_uint(q3.x), q3.y, __float_as_uint(q3.z), __float_as_uint(q3.w), q0.x, q0.y, q0.z, ox, oy, oz, dx, dy, dz, SR);
             s_alpha = SR.alpha; s_bn = SR.beta_n; s_bf = SR.beta_f; s_nw = SR.near_w; s_fw = SR.far_w;
         }
     } else {
-        const float4 q3 = p[3];
+        const float4 q3 = W.q3;
         c[0] = __float_as_int(q3.x); c[1] = __float_as_int(q3.y); c[2] = __float_as_int(q3.z); c[3] = __float_as_int(q3.w);
     }
     const float ax = __uint_as_float((meta & 0xffu) << 23) * R.idx, ay = __uint_as_float(((meta >> 8) & 0xffu) << 23) * R.idy, az = __uint_as_float(((meta >> 16) & 0xffu) << 23) * R.idz;
@@ -212,8 +298,10 @@ __device__ __forceinline__ int node_step_f2(const float4* __restrict__ nodes, in
 // The whole intersect kernel body over the flattened structure: `n` rays (ro, rd) -> hit / hit_node (closest) and/or occ (any-hit flag).
 template <bool ANY_HIT, bool COUNT, bool ALPHA, int FMT>
 __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4* __restrict__ ro, const float4* __restrict__ rd, uint32_t n, uint32_t* __restrict__ work,
-                                               float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack_ints, trav_counts& cnt) {
+                                               float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack_ints, const float* lds_top_floats, trav_counts& cnt) {
     flat_stack_lds_word* lds_stack = (flat_stack_lds_word*)lds_stack_ints;
+    lds_top_f4* lds_top = (lds_top_f4*)lds_top_floats;
+    const uint32_t n_top = (FMT == kFmtQ4 && kTopCache) ? (uint32_t)S.flat_top_cached : 0u;
     const int lane = threadIdx.x & 63;
     const int refill_idle = g_refill_idle, leaf_batch = g_leaf_batch;
     const bool compact = S.flat_compact != 0;
@@ -225,6 +313,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
     float ht = 0, hu = 0, hv = 0; int htri = -1, hnode = -1;
     int sp = 0, node = kSentinel, pend = -1;      // pend: postponed leaf (its first entry in flat_leaves), -1 = none
     int sp_max = 0;                               // COUNT: deepest stack entry of the lane's current ray
+    uint32_t pf_node = 0u, pf_leaf = 0u;          // touched dwords (CTL_PREFETCH_*): loads whose only purpose is to start the line's way into the L1 early
     const float4* __restrict__ nodes = S.flat_nodes;
     uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = (n == 0);
 
@@ -260,7 +349,10 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
         if (__ballot(has_ray) == 0ull) { if (exhausted) break; continue; }
 
         // ---- a lane standing on a leaf with a free slot postpones it and goes on with the next stack entry
-        if (has_ray && node < 0 && pend < 0) { pend = ~node; node = st.pop(sp, ht); }
+        if (has_ray && node < 0 && pend < 0) {
+            pend = ~node; node = st.pop(sp, ht);
+            if (CTL_PREFETCH_LEAF) pf_leaf = *(const uint32_t*)(S.flat_leaves + (size_t)(uint32_t)pend * 8);
+        }
         const bool at_inner = has_ray && (unsigned)node < (unsigned)kSentinel;
         const bool at_leaf = has_ray && pend >= 0;
         const unsigned long long m_inner = __ballot(at_inner), m_leaf = __ballot(at_leaf);
@@ -271,18 +363,36 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
                 if (COUNT) { cnt.n_tri++; if (lane == (int)__builtin_ctzll(m_leaf)) cnt.w_tri++; }
                 bool got = false;
                 pend = flat_leaf_test<ANY_HIT, ALPHA>(S, (uint32_t)pend, ox, oy, oz, dx, dy, dz, tmin, ht, hu, hv, htri, hnode, got);
+                if (CTL_PREFETCH_LEAF) asm volatile("" :: "v"(pf_leaf));
                 if (ANY_HIT && got) finished = true;
             }
         } else {
             // ---- node phase
+            node_words W;
+            if (FMT == kFmtQ4 && CTL_NODE_FETCH_QUAD) node_fetch_quad(nodes, node, at_inner, compact, W);
             if (at_inner) {
                 if (COUNT) { cnt.n_inner++; if (lane == (int)__builtin_ctzll(m_inner)) cnt.w_inner++; }
                 const flat_stack_word popped = st.get(sp);   // issued early: used when no child is entered
                 int c[4]; float dd[4]; int n_hit;
                 if (FMT == kFmtF4) n_hit = node_step_f4(nodes, node, R, tmin, ht, c, dd);
-                else if (FMT == kFmtQ4) n_hit = node_step_q4(nodes, node, R, ox, oy, oz, dx, dy, dz, tmin, ht, c, dd, compact);
+                else if (FMT == kFmtQ4) {
+                    if (!CTL_NODE_FETCH_QUAD) {
+                        const uint32_t ni = (uint32_t)node >> 2;
+                        if (kTopCache && ni < n_top && !(node & 1)) {
+                            const lds_f4v a = lds_top[ni * 3], b = lds_top[ni * 3 + 1], cc = lds_top[ni * 3 + 2];
+                            W.q0 = make_float4(a.x, a.y, a.z, a.w); W.q1 = make_float4(b.x, b.y, b.z, b.w); W.q2 = make_float4(cc.x, cc.y, cc.z, cc.w);
+                        } else node_fetch_own(nodes, node, compact, W);
+                    }
+                    n_hit = node_step_q4(W, node, R, ox, oy, oz, dx, dy, dz, tmin, ht, c, dd, compact);
+                }
                 else n_hit = node_step_f2(nodes, node, R, tmin, ht, c, dd);
+                if (CTL_PREFETCH_NODE) asm volatile("" :: "v"(pf_node));
+                if (CTL_PARK_IN_STEP && FMT != kFmtF2 && n_hit && c[0] < 0 && pend < 0) {   // what the next iteration would do through the stack: same order of visits
+                    pend = ~c[0]; c[0] = c[1]; c[1] = c[2]; c[2] = c[3]; dd[0] = dd[1]; dd[1] = dd[2]; dd[2] = dd[3]; n_hit--;
+                    if (CTL_PREFETCH_LEAF) pf_leaf = *(const uint32_t*)(S.flat_leaves + (size_t)(uint32_t)pend * 8);
+                }
                 node = n_hit ? c[0] : stack_word_link(popped);
+                if (CTL_PREFETCH_NODE && (unsigned)node < (unsigned)kSentinel) pf_node = *(const uint32_t*)(nodes + (node & ~3));
                 const int top = sp + n_hit - 1;    // n_hit == 0: one entry popped
                 if (FMT == kFmtF2) {
                     if (n_hit == 2) st.set(top, stack_word(c[1], dd[1]));
@@ -335,7 +445,7 @@ __device__ bool trace_single_flat(const dev_scene& S, lds_int* lds_col, f3 o, f3
         if (node >= 0) {
             int c[4]; float dd[4]; int n_hit;
             if (fmt == kFmtF4) n_hit = node_step_f4(nodes, node, R, tmin, ht, c, dd);
-            else if (fmt == kFmtQ4) n_hit = node_step_q4(nodes, node, R, o.x, o.y, o.z, d.x, d.y, d.z, tmin, ht, c, dd, S.flat_compact != 0);
+            else if (fmt == kFmtQ4) { node_words W; node_fetch_own(nodes, node, S.flat_compact != 0, W); n_hit = node_step_q4(W, node, R, o.x, o.y, o.z, d.x, d.y, d.z, tmin, ht, c, dd, S.flat_compact != 0); }
             else n_hit = node_step_f2(nodes, node, R, tmin, ht, c, dd);
             for (int i = n_hit - 1; i >= 1; i--) stack.set(++sp, c[i]);
             if (n_hit) node = c[0]; else { node = stack.get(sp); sp--; }

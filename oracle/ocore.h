@@ -142,6 +142,8 @@ inline bool alphaSurvive(const Scene& S, uint32_t tri, uint32_t nodeIdx, float u
 // algorithmic ones).  n_inst stays 0: there is no instance entry.
 // measurement probe for tools/bvh_quality_probe.py --slab (off unless orc_slab_probe(1) was called)
 inline bool g_slab_probe = false; inline std::atomic<uint64_t> g_slab_tests{ 0 }, g_slab_rejects{ 0 };
+// same switch: node visits by the node's position in the array (the top of the tree is stored breadth-first): bucket b counts visits of nodes with index < g_top_probe_limits[b]
+inline const uint32_t g_top_probe_limits[8] = { 85u, 256u, 341u, 512u, 1365u, 5461u, 65536u, 0xffffffffu }; inline std::atomic<uint64_t> g_top_probe[8];
 inline bool traceRayFlat(const Scene& S, V3 ori, V3 dir, float tmin_tri, float tmax, bool any_hit, float node_tmin, Hit& res, TravCounts* cnt) {
     const ctl_scene_desc& g = S.d; const ctl_flat_bvh_desc& F = *S.flat;
     res.init(); res.dist = tmax;
@@ -161,6 +163,7 @@ inline bool traceRayFlat(const Scene& S, V3 ori, V3 dir, float tmin_tri, float t
     while (node != EntrypointSentinel) {
         if (node >= 0) {
             if (cnt) cnt->n_inner++;
+            if (cnt && g_slab_probe) { const uint32_t ni = (uint32_t)node >> 2; for (int b = 0; b < 8; b++) if (ni < g_top_probe_limits[b]) g_top_probe[b].fetch_add(1, std::memory_order_relaxed); }
             const float* p = nodes + (size_t)node * 4;
             float dd[4]; int c[4]; int width = 4;
             const float inf = INFINITY;

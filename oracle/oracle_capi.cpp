@@ -57,8 +57,9 @@ void orc_reflect_about(const float* wi, const float* n, float* out) { V3 r = ref
 void orc_refract_about(const float* wi, const float* n, float eta, float cosThetaT, float* out) { V3 r = refractAbout(V3(wi[0], wi[1], wi[2]), V3(n[0], n[1], n[2]), eta, cosThetaT); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 void orc_slab_probe(int on, uint64_t* tests_rejects) {   // tools/bvh_quality_probe.py --slab: switch the probe of traceRayFlat on / off, read its two counters
     if (tests_rejects) { tests_rejects[0] = g_slab_tests.load(); tests_rejects[1] = g_slab_rejects.load(); }
-    g_slab_probe = on != 0; if (on) { g_slab_tests = 0; g_slab_rejects = 0; }
+    g_slab_probe = on != 0; if (on) { g_slab_tests = 0; g_slab_rejects = 0; for (auto& t : g_top_probe) t = 0; }
 }
+void orc_top_probe_read(uint64_t* out8) { for (int b = 0; b < 8; b++) out8[b] = g_top_probe[b].load(); }   // visits of nodes with index < {85, 256, 341, 512, 1365, 5461, 65536, all}
 float orc_interval_to_tent(float s) { return intervalToTent(s); }
 float orc_cosine_hemisphere_pdf(const float* d) { return squareToCosineHemispherePdf(V3(d[0], d[1], d[2])); }
 void orc_square_to_uniform_sphere(float x, float y, float* out) { V3 r = squareToUniformSphere(V2{ x, y }); out[0] = r.x; out[1] = r.y; out[2] = r.z; }

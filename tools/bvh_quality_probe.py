@@ -40,6 +40,8 @@ def main():
     ni, nt = counts["path_inner"] / pr, counts["path_tri"] / pr
     sl = (C.c_uint64 * 2)(); orc.lib.orc_slab_probe(0, sl)
     print("oriented slabs: %d of %d leaf children that the box test of a slab node lets in (path + occlusion rays) are kept out by the slab = %.1f %%" % (sl[1], sl[0], 100.0 * sl[1] / max(1, sl[0])), flush=True)
+    tp = (C.c_uint64 * 8)(); orc.lib.orc_top_probe_read(tp)
+    print("node visits (path + occlusion rays) by array position (breadth-first top): " + ", ".join("< %s: %.1f %%" % (n, 100.0 * tp[i] / max(1, tp[7])) for i, n in enumerate(("85", "256", "341", "512", "1365", "5461", "65536"))), flush=True)
     knobs = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("CTL_FLAT"))
     print("%-60s nodes %9d leaves %9d depth %2d | per path ray: inner %.2f tri %.2f | cost proxy %.0f | build %.1f s, count %.1f s" % (
         knobs or "(defaults)", fb.desc.n_nodes, fb.desc.n_leaves, fb.desc.max_depth, ni, nt, 277 * ni + 365 * nt, t_build, t_r), flush=True)

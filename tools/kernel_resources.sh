@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.." || exit 1
 units=${*:-kernels shade_full shade_basic megakernel}
 for f in $units; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -munsafe-fp-atomics -c cudatracerlib_amd/csrc/$f.hip -o /tmp/kres_$$.o \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -munsafe-fp-atomics $KRES_FLAGS -c cudatracerlib_amd/csrc/$f.hip -o /tmp/kres_$$.o \
       -Rpass-analysis=kernel-resource-usage 2>&1 |
     awk -v unit="$f" '
       /Function Name:/ { name=$0; sub(/.*Function Name: /, "", name); sub(/ \[-Rpass.*/, "", name) }
