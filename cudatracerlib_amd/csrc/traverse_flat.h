@@ -58,6 +58,8 @@ __device__ int g_leaf_batch = 16;         // run the leaf phase once this many l
 //   CTL_PARK_IN_STEP     a node step whose nearest child is a leaf parks it at once and walks on with the second nearest (no trip through the stack): 2461 / 2441
 //   CTL_PREFETCH_NODE    the step touches one dword of the node it goes to next (consumed after the next step's own loads): 2044
 //   CTL_PREFETCH_LEAF    parking a leaf touches the line of its first entry: 2413
+//   merged iteration     (removed again) entry tests and node steps in ONE iteration, a lane doing either, their loads sharing registers and one wait: node-step lane
+//                        utilisation 0.58 -> 0.70, a third fewer iterations, but every iteration pays for both code paths: 2127 at 6 waves, 2173 at 5 (spills at 7: 1430)
 // What DID pay: issuing the load of the slab quarter together with the other three (node_fetch_own) instead of after the link arithmetic that waits for them — the second
 // round trip through the L1 per slab node was 9 % of the whole job (2279 -> 2486).
 #ifndef CTL_NODE_FETCH_QUAD
@@ -107,14 +109,30 @@ __device__ __forceinline__ float rcp_cull(float d) {   // slab tests only cull: 
 }
 
 // One Woop triangle against the object-space ray (TraceHelper.cu:646-682), the reference's expression order, exact division.
-// Returns true when the entry is the new closest hit (ht, hu, hv, htri, hnode updated).
-template <bool ALPHA>
-__device__ __forceinline__ bool flat_woop_test(const dev_scene& S, const float4 v00, const float4 v11, const float4 v22, uint32_t index, int nd, const f3 o, const f3 d, float tmin,
-                                               float& ht, float& hu, float& hv, int& htri, int& hnode) {
+// Returns true when the entry is the new closest hit (handed to the sink).
+// Where an accepted hit goes.  hit_in_regs: the five values the caller keeps (single-ray traversal of the megakernel).  hit_in_memory: the wavefront kernels write
+// the record to the ray's slot of the hit arrays at once — a ray accepts one to three hits on its way — and keep only the distance and a "found" bit: four registers
+// fewer per lane for the whole traversal.
+struct hit_in_regs {
+    float& ht; float& hu; float& hv; int& htri; int& hnode;
+    __device__ __forceinline__ float dist() const { return ht; }
+    __device__ __forceinline__ void accept(float t, float u, float v, int tri, int nd) { ht = t; hu = u; hv = v; htri = tri; hnode = nd; }
+};
+struct hit_in_memory {
+    float& ht; uint32_t& ray_word; float4* __restrict__ hit; int* __restrict__ hit_node;   // ray_word: ray index | found << 31
+    __device__ __forceinline__ float dist() const { return ht; }
+    __device__ __forceinline__ void accept(float t, float u, float v, int tri, int nd) {
+        ht = t;
+        if (hit) { const uint32_t id = ray_word & 0x7fffffffu; hit[id] = make_float4(t, u, v, __int_as_float(tri)); hit_node[id] = nd; }
+        ray_word |= 0x80000000u;
+    }
+};
+template <bool ALPHA, class SINK>
+__device__ __forceinline__ bool flat_woop_test(const dev_scene& S, const float4 v00, const float4 v11, const float4 v22, uint32_t index, int nd, const f3 o, const f3 d, float tmin, SINK& sink) {
     const float Oz = v00.w - o.x * v00.x - o.y * v00.y - o.z * v00.z;
     const float invDz = 1.0f / (d.x * v00.x + d.y * v00.y + d.z * v00.z);
     const float t = Oz * invDz;
-    if (t > tmin && t < ht) {
+    if (t > tmin && t < sink.dist()) {
         const float Ox = v11.w + o.x * v11.x + o.y * v11.y + o.z * v11.z;
         const float Dx = d.x * v11.x + d.y * v11.y + d.z * v11.z;
         const float u = Ox + t * Dx;
@@ -123,29 +141,39 @@ __device__ __forceinline__ bool flat_woop_test(const dev_scene& S, const float4 
             const float Dy = d.x * v22.x + d.y * v22.y + d.z * v22.z;
             const float v = Oy + t * Dy;
             if (v >= 0.0f && u + v <= 1.0f && (!ALPHA || alpha_survives(S.tri_data, S.node_info, S.mats, S.images, (int)(index >> 1), nd, u, v))) {
-                ht = t; hu = u; hv = v; htri = (int)(index >> 1); hnode = nd;
+                sink.accept(t, u, v, (int)(index >> 1), nd);
                 return true;
             }
         }
     }
     return false;
 }
-// One leaf entry (flat_leaf, 128 B) against the world-space ray: the ray through the node's inverse transform (TraceHelper.cu:526-560; the rows
-// travel with the entry), then the Woop test.  Returns the next entry of the leaf, or -1 when this was its last one.
-template <bool ANY_HIT, bool ALPHA>
-__device__ __forceinline__ int flat_leaf_test(const dev_scene& S, uint32_t e, float orgx, float orgy, float orgz, float dirx, float diry, float dirz, float tmin,
-                                              float& ht, float& hu, float& hv, int& htri, int& hnode, bool& got) {
+struct leaf_words { float4 v00, v11, v22, r0, r1, r2; uint2 iw; float w33; };
+__device__ __forceinline__ void flat_leaf_load(const dev_scene& S, uint32_t e, leaf_words& L) {
     const float4* __restrict__ p = S.flat_leaves + (size_t)e * 8;
-    const float4 v00 = p[0], v11 = p[1], v22 = p[2];
-    const uint2 iw = *(const uint2*)(p + 3);   // {globalTri << 1 | last, node}
-    const float4 r0 = p[4], r1 = p[5], r2 = p[6];
-    m34 m; m.r[0][0] = r0.x; m.r[0][1] = r0.y; m.r[0][2] = r0.z; m.r[0][3] = r0.w; m.r[1][0] = r1.x; m.r[1][1] = r1.y; m.r[1][2] = r1.z; m.r[1][3] = r1.w;
-    m.r[2][0] = r2.x; m.r[2][1] = r2.y; m.r[2][2] = r2.z; m.r[2][3] = r2.w;
+    L.v00 = p[0]; L.v11 = p[1]; L.v22 = p[2];
+    L.iw = *(const uint2*)(p + 3);   // {globalTri << 1 | last, node}
+    L.r0 = p[4]; L.r1 = p[5]; L.r2 = p[6];
+    L.w33 = 1.0f;
+    if (!S.inst_w_one) L.w33 = p[7].x;   // float4x4.h:402-406 divides by w; x / 1.0f == x, so scenes whose w are all 1 skip it
+}
+template <bool ANY_HIT, bool ALPHA, class SINK>
+__device__ __forceinline__ int flat_leaf_eval(const dev_scene& S, uint32_t e, const leaf_words& L, float orgx, float orgy, float orgz, float dirx, float diry, float dirz, float tmin,
+                                              SINK& sink, bool& got) {
+    m34 m; m.r[0][0] = L.r0.x; m.r[0][1] = L.r0.y; m.r[0][2] = L.r0.z; m.r[0][3] = L.r0.w; m.r[1][0] = L.r1.x; m.r[1][1] = L.r1.y; m.r[1][2] = L.r1.z; m.r[1][3] = L.r1.w;
+    m.r[2][0] = L.r2.x; m.r[2][1] = L.r2.y; m.r[2][2] = L.r2.z; m.r[2][3] = L.r2.w;
     const f3 d = xform_dir(m, f3(dirx, diry, dirz));
     f3 o = xform_point(m, f3(orgx, orgy, orgz));
-    if (!S.inst_w_one) { const float w33 = p[7].x; o = f3(o.x / w33, o.y / w33, o.z / w33); }   // float4x4.h:402-406 divides by w; x / 1.0f == x, so scenes whose w are all 1 skip it
-    if (flat_woop_test<ALPHA>(S, v00, v11, v22, iw.x, (int)iw.y, o, d, tmin, ht, hu, hv, htri, hnode)) { got = true; if (ANY_HIT) return -1; }
-    return (iw.x & 1u) ? -1 : (int)(e + 1);
+    if (!S.inst_w_one) o = f3(o.x / L.w33, o.y / L.w33, o.z / L.w33);
+    if (flat_woop_test<ALPHA>(S, L.v00, L.v11, L.v22, L.iw.x, (int)L.iw.y, o, d, tmin, sink)) { got = true; if (ANY_HIT) return -1; }
+    return (L.iw.x & 1u) ? -1 : (int)(e + 1);
+}
+// One leaf entry (flat_leaf, 128 B) against the world-space ray: the ray through the node's inverse transform (TraceHelper.cu:526-560; the rows
+// travel with the entry), then the Woop test.  Returns the next entry of the leaf, or -1 when this was its last one.
+template <bool ANY_HIT, bool ALPHA, class SINK>
+__device__ __forceinline__ int flat_leaf_test(const dev_scene& S, uint32_t e, float orgx, float orgy, float orgz, float dirx, float diry, float dirz, float tmin, SINK& sink, bool& got) {
+    leaf_words L; flat_leaf_load(S, e, L);
+    return flat_leaf_eval<ANY_HIT, ALPHA>(S, e, L, orgx, orgy, orgz, dirx, diry, dirz, tmin, sink, got);
 }
 
 // culling-only min / max: the hardware instructions as they are (a NaN operand loses, as with fmaxf / fminf)
@@ -155,7 +183,12 @@ __device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max
 __device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // ---- node steps.  Each returns the children the ray enters, nearest first, in c[0..n_hit): links as stored in the node.
-struct ray_cull { float idx, idy, idz, oox, ooy, ooz; int sx, sy, sz; };   // sx/sy/sz = 1 where the direction component is negative
+struct ray_cull {   // the signs of the direction are read off idx / idy / idz where they are needed: a compare either way, and three registers fewer than keeping them
+    float idx, idy, idz, oox, ooy, ooz;
+    __device__ __forceinline__ int sx() const { return idx < 0.0f ? 1 : 0; }
+    __device__ __forceinline__ int sy() const { return idy < 0.0f ? 1 : 0; }
+    __device__ __forceinline__ int sz() const { return idz < 0.0f ? 1 : 0; }
+};
 
 #define CTL_CSWAP_PAIR(i, j) { const bool s_ = dd[j] < dd[i]; const float td_ = s_ ? dd[j] : dd[i]; dd[j] = s_ ? dd[i] : dd[j]; dd[i] = td_; \
                                const int tc_ = s_ ? c[j] : c[i]; c[j] = s_ ? c[i] : c[j]; c[i] = tc_; }
@@ -163,7 +196,7 @@ struct ray_cull { float idx, idy, idz, oox, ooy, ooz; int sx, sy, sz; };   // sx
 // F4: 128-B plane-major node (flat4f_node)
 __device__ __forceinline__ int node_step_f4(const float4* __restrict__ nodes, int node, const ray_cull& R, float tmin, float ht, int c[4], float dd[4]) {
     const float4* __restrict__ p = nodes + node;
-    const float4 nx = p[R.sx], fx = p[1 - R.sx], ny = p[2 + R.sy], fy = p[3 - R.sy], nz = p[4 + R.sz], fz = p[5 - R.sz];
+    const float4 nx = p[R.sx()], fx = p[1 - R.sx()], ny = p[2 + R.sy()], fy = p[3 - R.sy()], nz = p[4 + R.sz()], fz = p[5 - R.sz()];
     const float4 lk = p[6];
     const float nxa[4] = { nx.x, nx.y, nx.z, nx.w }, fxa[4] = { fx.x, fx.y, fx.z, fx.w }, nya[4] = { ny.x, ny.y, ny.z, ny.w }, fya[4] = { fy.x, fy.y, fy.z, fy.w };
     const float nza[4] = { nz.x, nz.y, nz.z, nz.w }, fza[4] = { fz.x, fz.y, fz.z, fz.w };
@@ -264,7 +297,8 @@ __device__ __forceinline__ int node_step_q4(const node_words& W, int node, const
     const float ax = __uint_as_float((meta & 0xffu) << 23) * R.idx, ay = __uint_as_float(((meta >> 8) & 0xffu) << 23) * R.idy, az = __uint_as_float(((meta >> 16) & 0xffu) << 23) * R.idz;
     const float bx = __builtin_fmaf(q0.x, R.idx, -R.oox), by = __builtin_fmaf(q0.y, R.idy, -R.ooy), bz = __builtin_fmaf(q0.z, R.idz, -R.ooz);
     const uint32_t lx = __float_as_uint(q1.x), hx = __float_as_uint(q1.y), ly = __float_as_uint(q1.z), hy = __float_as_uint(q1.w), lz = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
-    const uint32_t nx = R.sx ? hx : lx, fx = R.sx ? lx : hx, ny = R.sy ? hy : ly, fy = R.sy ? ly : hy, nz = R.sz ? hz : lz, fz = R.sz ? lz : hz;
+    const bool negx = R.idx < 0.0f, negy = R.idy < 0.0f, negz = R.idz < 0.0f;
+    const uint32_t nx = negx ? hx : lx, fx = negx ? lx : hx, ny = negy ? hy : ly, fy = negy ? ly : hy, nz = negz ? hz : lz, fz = negz ? lz : hz;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const float tnx = __builtin_fmaf((float)((nx >> (8 * k)) & 0xffu), ax, bx), tfx = __builtin_fmaf((float)((fx >> (8 * k)) & 0xffu), ax, bx);
@@ -309,8 +343,9 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
     bool has_ray = false;
     uint32_t ray_id = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, tmin = 0;
-    ray_cull R{ 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    float ht = 0, hu = 0, hv = 0; int htri = -1, hnode = -1;
+    ray_cull R{ 0, 0, 0, 0, 0, 0 };
+    float ht = 0;                                 // distance of the closest hit so far; its record is in hit[] / hit_node[] already (hit_in_memory), bit 31 of ray_id says there is one
+    hit_in_memory sink{ ht, ray_id, hit, hit_node };
     int sp = 0, node = kSentinel, pend = -1;      // pend: postponed leaf (its first entry in flat_leaves), -1 = none
     int sp_max = 0;                               // COUNT: deepest stack entry of the lane's current ray
     uint32_t pf_node = 0u, pf_leaf = 0u;          // touched dwords (CTL_PREFETCH_*): loads whose only purpose is to start the line's way into the L1 early
@@ -339,8 +374,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
                     ox = o.x; oy = o.y; oz = o.z; tmin = o.w; dx = d.x; dy = d.y; dz = d.z;
                     R.idx = rcp_cull(dx); R.idy = rcp_cull(dy); R.idz = rcp_cull(dz);
                     R.oox = ox * R.idx; R.ooy = oy * R.idy; R.ooz = oz * R.idz;
-                    R.sx = R.idx < 0.0f ? 1 : 0; R.sy = R.idy < 0.0f ? 1 : 0; R.sz = R.idz < 0.0f ? 1 : 0;
-                    ht = d.w; hu = hv = 0.0f; htri = -1; hnode = -1;
+                    ht = d.w;
                     sp = 0; st.lds[0] = stack_word(kSentinel, -__builtin_huge_valf()); node = S.flat_root; pend = -1;
                 }
                 chunk_next += want < avail ? want : avail;
@@ -362,7 +396,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
             if (at_leaf) {
                 if (COUNT) { cnt.n_tri++; if (lane == (int)__builtin_ctzll(m_leaf)) cnt.w_tri++; }
                 bool got = false;
-                pend = flat_leaf_test<ANY_HIT, ALPHA>(S, (uint32_t)pend, ox, oy, oz, dx, dy, dz, tmin, ht, hu, hv, htri, hnode, got);
+                pend = flat_leaf_test<ANY_HIT, ALPHA>(S, (uint32_t)pend, ox, oy, oz, dx, dy, dz, tmin, sink, got);
                 if (CTL_PREFETCH_LEAF) asm volatile("" :: "v"(pf_leaf));
                 if (ANY_HIT && got) finished = true;
             }
@@ -412,8 +446,9 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
         }
         if (has_ray && !finished) finished = (node == kSentinel) && pend < 0;
         if (finished) {
-            if (ANY_HIT && occ) occ[ray_id] = htri >= 0 ? 1u : 0u;
-            if (hit) { hit[ray_id] = make_float4(ht, hu, hv, __int_as_float(htri)); hit_node[ray_id] = hnode; }
+            const uint32_t id = ray_id & 0x7fffffffu; const bool found = (ray_id >> 31) != 0u;
+            if (ANY_HIT && occ) occ[id] = found ? 1u : 0u;
+            if (hit && !found) { hit[id] = make_float4(ht, 0.0f, 0.0f, __int_as_float(-1)); hit_node[id] = -1; }   // a found hit wrote its record when it was accepted
             if (COUNT) { atomicAdd(&g_stack_hist[sp_max < kStackSize ? sp_max : kStackSize - 1], 1ull); sp_max = 0; }
             has_ray = false; node = kSentinel; pend = -1;
         }
@@ -436,7 +471,6 @@ __device__ bool trace_single_flat(const dev_scene& S, lds_int* lds_col, f3 o, f3
     ray_cull R;
     R.idx = rcp_cull(d.x); R.idy = rcp_cull(d.y); R.idz = rcp_cull(d.z);
     R.oox = o.x * R.idx; R.ooy = o.y * R.idy; R.ooz = o.z * R.idz;
-    R.sx = R.idx < 0.0f ? 1 : 0; R.sy = R.idy < 0.0f ? 1 : 0; R.sz = R.idz < 0.0f ? 1 : 0;
     single_stack stack; stack.lds = lds_col; int sp = 0; stack.set(0, kSentinel);
     int node = S.flat_root;
     const int fmt = S.flat_format;
@@ -452,9 +486,10 @@ __device__ bool trace_single_flat(const dev_scene& S, lds_int* lds_col, f3 o, f3
         } else {
             bool got = false; int next = ~node;
             // USE_ALPHA of __traceRay_internal__ (TraceHelper.cu:135-153): scenes with alpha maps test every candidate hit
+            hit_in_regs sink{ ht, hu, hv, htri, hnode };
             while (next >= 0 && !(ANY_HIT && got))
-                next = (ALPHA_DYNAMIC && S.alpha_maps) ? flat_leaf_test<ANY_HIT, true>(S, (uint32_t)next, o.x, o.y, o.z, d.x, d.y, d.z, tmin, ht, hu, hv, htri, hnode, got)
-                                                       : flat_leaf_test<ANY_HIT, false>(S, (uint32_t)next, o.x, o.y, o.z, d.x, d.y, d.z, tmin, ht, hu, hv, htri, hnode, got);
+                next = (ALPHA_DYNAMIC && S.alpha_maps) ? flat_leaf_test<ANY_HIT, true>(S, (uint32_t)next, o.x, o.y, o.z, d.x, d.y, d.z, tmin, sink, got)
+                                                       : flat_leaf_test<ANY_HIT, false>(S, (uint32_t)next, o.x, o.y, o.z, d.x, d.y, d.z, tmin, sink, got);
             if (ANY_HIT && got) return true;
             node = stack.get(sp); sp--;
         }
