@@ -21,8 +21,8 @@ namespace ctl {
 struct trav_counts { uint32_t n_inner, n_tri, n_inst, w_inner, w_tri; };
 
 constexpr int kLdsStack = 24;        // stack entries per lane kept in LDS, two-level kernel (24 x 256 x 4 B = 24 KiB per workgroup)
-__device__ int g_refill_idle = 20;   // refill as soon as this many lanes of the wave are idle (CTL_REFILL_IDLE overrides; measured 4: 2386, 8: 2433,
-                                     // 12: 2466, 20: 2483, 32: 2473 Mrays/s on synthetic-SM)
+__device__ int g_refill_idle = 12;   // refill as soon as this many lanes of the wave are idle (CTL_REFILL_IDLE overrides; round 2: 4: 2386, 8: 2433,
+                                     // 12: 2466, 20: 2483, 32: 2473 Mrays/s on synthetic-SM; with round 3's kernel, ms per fused launch: 8: 15.39, 12: 15.23, 16: 15.33, 20: 15.53, 28: 16.37)
 constexpr uint32_t kChunk = 512;     // most rays a wave claims from the global cursor per atomic
 __device__ int g_chunk_guided = 1;   // 1: claims shrink with the rays that are left (guided_chunk); 0: always kChunk (CTL_CHUNK_GUIDED=0)
 

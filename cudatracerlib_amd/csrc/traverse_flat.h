@@ -60,8 +60,18 @@ __device__ int g_leaf_batch = 16;         // run the leaf phase once this many l
 //   CTL_PREFETCH_LEAF    parking a leaf touches the line of its first entry: 2413
 //   merged iteration     (removed again) entry tests and node steps in ONE iteration, a lane doing either, their loads sharing registers and one wait: node-step lane
 //                        utilisation 0.58 -> 0.70, a third fewer iterations, but every iteration pays for both code paths: 2127 at 6 waves, 2173 at 5 (spills at 7: 1430)
+//   packed slab FMAs     (removed again) entry and exit distance of an axis in one v_pk_fma_f32, 16 instead of 32 FMA instructions per node step: 2461 against 2527 —
+//                        the packed instruction is no faster than the two it replaces, and its operands want pairing moves
+//   8 waves per SIMD     with CTL_LEAN_RAY (no o * idir per lane: three VALU more per step, three registers fewer) the kernels fit 64 VGPRs without spills: 2543 against
+//                        2543 at 7 waves — occupancy no longer buys anything, the kernel is bound by VALU issue now
+//   overlapped refill    (removed again) the ray loads of idle lanes issued in the same iteration as the other lanes' node / entry loads, their traversal state set up at
+//                        the iteration's end: 16.3-16.5 ms per fused launch against 15.5 at every refill threshold from 2 to 12 — and node-step lane utilisation moves only
+//                        from 0.61 to 0.64 even when every idle lane is refilled at once: lanes are not waiting for rays, they wait for their last entry test
 // What DID pay: issuing the load of the slab quarter together with the other three (node_fetch_own) instead of after the link arithmetic that waits for them — the second
 // round trip through the L1 per slab node was 9 % of the whole job (2279 -> 2486).
+#ifndef CTL_LEAN_RAY
+#define CTL_LEAN_RAY 0
+#endif
 #ifndef CTL_NODE_FETCH_QUAD
 #define CTL_NODE_FETCH_QUAD 0
 #endif
@@ -295,7 +305,11 @@ __device__ __forceinline__ int node_step_q4(const node_words& W, int node, const
         c[0] = __float_as_int(q3.x); c[1] = __float_as_int(q3.y); c[2] = __float_as_int(q3.z); c[3] = __float_as_int(q3.w);
     }
     const float ax = __uint_as_float((meta & 0xffu) << 23) * R.idx, ay = __uint_as_float(((meta >> 8) & 0xffu) << 23) * R.idy, az = __uint_as_float(((meta >> 16) & 0xffu) << 23) * R.idz;
+#if CTL_LEAN_RAY
+    const float bx = (q0.x - ox) * R.idx, by = (q0.y - oy) * R.idy, bz = (q0.z - oz) * R.idz;   // no o * idir kept per lane
+#else
     const float bx = __builtin_fmaf(q0.x, R.idx, -R.oox), by = __builtin_fmaf(q0.y, R.idy, -R.ooy), bz = __builtin_fmaf(q0.z, R.idz, -R.ooz);
+#endif
     const uint32_t lx = __float_as_uint(q1.x), hx = __float_as_uint(q1.y), ly = __float_as_uint(q1.z), hy = __float_as_uint(q1.w), lz = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
     const bool negx = R.idx < 0.0f, negy = R.idy < 0.0f, negz = R.idz < 0.0f;
     const uint32_t nx = negx ? hx : lx, fx = negx ? lx : hx, ny = negy ? hy : ly, fy = negy ? ly : hy, nz = negz ? hz : lz, fz = negz ? lz : hz;
