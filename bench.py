@@ -338,9 +338,10 @@ def main():
     if rank == 0 and args.dump_frame:
         np.save(args.dump_frame, img.getPixelData())
     if rank == 0:
-        # traversal statistics of the SAME rays on the GPU (one extra, untimed pass in counting mode): lane utilisation, visited nodes
+        # traversal statistics of the SAME rays on the GPU (one extra, untimed batch in counting mode, as many passes per launch as the timed region had — a single
+        # pass per launch is mostly ramp and drain and reports a lane utilisation the timed launches do not have): lane utilisation, visited nodes
         tr.setCounting(True)
-        tr.DoPasses(img, 1, new_trace=False)
+        tr.DoPasses(img, max(1, min(args.steps, 32)), new_trace=False)
         cs = tr.stats()
         tr.setCounting(False)
         gpu_counts = {"n_inner": cs.closest_counts.n_inner / max(1, cs.intersect_rays), "n_tri": cs.closest_counts.n_tri / max(1, cs.intersect_rays), "n_inst": cs.closest_counts.n_inst / max(1, cs.intersect_rays)}

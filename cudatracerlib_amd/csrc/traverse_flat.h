@@ -416,6 +416,13 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
             }
         } else {
             // ---- node phase
+#ifdef CTL_COUNT_PROBE   // where do the lanes that take no node step stand?  n_inst (unused by the flattened layout) counts one category per build: 1 blocked on a second leaf, 2 stack exhausted and waiting for the last entry test, 3 without a ray
+            if (COUNT && m_inner != 0ull) {
+                if (CTL_COUNT_PROBE == 1 && has_ray && pend >= 0 && node < 0) cnt.n_inst++;
+                if (CTL_COUNT_PROBE == 2 && has_ray && pend >= 0 && node == kSentinel) cnt.n_inst++;
+                if (CTL_COUNT_PROBE == 3 && !has_ray) cnt.n_inst++;
+            }
+#endif
             node_words W;
             if (FMT == kFmtQ4 && CTL_NODE_FETCH_QUAD) node_fetch_quad(nodes, node, at_inner, compact, W);
             if (at_inner) {
