@@ -67,6 +67,8 @@ __device__ int g_leaf_batch = 16;         // run the leaf phase once this many l
 //   overlapped refill    (removed again) the ray loads of idle lanes issued in the same iteration as the other lanes' node / entry loads, their traversal state set up at
 //                        the iteration's end: 16.3-16.5 ms per fused launch against 15.5 at every refill threshold from 2 to 12 — and node-step lane utilisation moves only
 //                        from 0.61 to 0.64 even when every idle lane is refilled at once: lanes are not waiting for rays, they wait for their last entry test
+//   comparators in VCC   (removed again) the ordering network's five compare results in VCC instead of SGPR pairs (v_cndmask_b32_e32 instead of _e64, inline asm): 15.33 against
+//                        15.32 ms — no single unit is the limit any more: VALU issue, L1 lane-loads and HBM lines all sit at 55-75 % of what the probes give them alone
 // What DID pay: issuing the load of the slab quarter together with the other three (node_fetch_own) instead of after the link arithmetic that waits for them — the second
 // round trip through the L1 per slab node was 9 % of the whole job (2279 -> 2486).
 #ifndef CTL_LEAN_RAY
