@@ -221,6 +221,27 @@ class FlatBvh:
     def leaves(self):
         return np.ctypeslib.as_array(C.cast(self.desc.leaves, C.POINTER(C.c_uint32)), shape=(self.desc.n_leaves * 32,)).reshape(-1, 32)
 
+    @staticmethod
+    def implied_links(N):
+        """Q4 nodes (n, 16) uint32 -> (n, 4) int32: the links a traversal step derives from the first 48 B (csrc/flatten.h: link = base + nibble);
+        an inner link carries the child's slab flag in bit 0.  Slots without a child decode to anything."""
+        w0, w1, leafm = N[:, 10].astype(np.uint32), N[:, 11].astype(np.uint32), N[:, 3] >> 28
+        ib4, nlb15 = w0 & np.uint32(0x03fffffc), (w1 >> 6) | np.uint32(0xfc000000)
+        t = [None, (w0 >> 26) & 15, (w1 >> 2) & 15, (w0 >> 30) | ((w1 & 3) << 2)]
+        out = np.empty((len(N), 4), np.uint32)
+        out[:, 0] = np.where((leafm & 1) == 1, nlb15 + np.uint32(15), w0 & np.uint32(0x03ffffff))
+        for k in (1, 2, 3):
+            out[:, k] = np.where(((leafm >> k) & 1) == 1, nlb15, ib4) + t[k].astype(np.uint32)
+        return out.view(np.int32)
+
+    @staticmethod
+    def clear_slab_flags(N):
+        """in place: no inner link hands a slab flag down any more"""
+        inner = ((N[:, 3] >> 24) & 15) & ~(N[:, 3] >> 28)      # bit 0 of a slot's nibble is the flag only for an inner child (a leaf child's nibble is 15 - entries before it)
+        for k, (word, bit) in enumerate(((10, 0), (10, 26), (11, 2), (10, 30))):
+            N[:, word] &= ~(((inner >> k) & 1).astype(np.uint32) << np.uint32(bit))
+        return N
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib.ctl_flat_bvh_destroy(self._h)

@@ -155,7 +155,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node format only
     std::string key;
     if (!cache_dir().empty()) {
-        content_hash H; const uint32_t version = 11;
+        content_hash H; const uint32_t version = 12;
         H.add_value(version); H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
@@ -329,33 +329,22 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     if (out.format == kFlatF2) { entry_src.resize(R.leaf_prims.size()); for (size_t i = 0; i < entry_src.size(); i++) entry_src[i] = (uint32_t)i; }
     else {
         entry_src.reserve(R.leaf_prims.size());
-        auto relink = [&](int32_t* child, int n_children, uint32_t* links, uint8_t* mask) {
-            uint32_t counts[4] = { 0, 0, 0, 0 }; const uint32_t leaf_base = (uint32_t)entry_src.size(); uint32_t inner_base = 0; bool have_inner = false;
+        auto relink = [&](int32_t* child, int n_children, uint32_t* counts, uint8_t* mask) {   // leaf children: entries appended in slot order, link = ~first new entry
             for (int c = 0; c < n_children; c++) {
-                if (child[c] == 0x76543210) continue;
-                if (child[c] >= 0) { if (!have_inner) { inner_base = (uint32_t)child[c]; have_inner = true; } continue; }
+                if (counts) counts[c] = 0;
+                if (child[c] == 0x76543210 || child[c] >= 0) continue;
                 const uint32_t first = (uint32_t)entry_src.size();
-                for (uint32_t e = (uint32_t)~child[c];; e++) { entry_src.push_back(e); counts[c]++; if (R.leaf_last[e]) break; }
+                for (uint32_t e = (uint32_t)~child[c];; e++) { entry_src.push_back(e); if (counts) counts[c]++; if (R.leaf_last[e]) break; }
                 child[c] = ~(int32_t)first;
                 if (mask) *mask |= (uint8_t)(16u << c);
             }
-            if (links) {
-                bool fits = leaf_base < (1u << 26);
-                for (int c = 0; c < 4; c++) if (counts[c] > 4) fits = false;
-                if (!fits) return false;
-                links[0] = (inner_base << 6) | ((counts[0] ? counts[0] - 1 : 0) << 0) | ((counts[1] ? counts[1] - 1 : 0) << 2) | ((counts[2] ? counts[2] - 1 : 0) << 4);
-                links[1] = (leaf_base << 6) | (counts[3] ? counts[3] - 1 : 0);   // bits 2..5: slab flags of the inner children, set below
-            }
-            return true;
         };
         if (out.format == kFlatQ4) {
             for (auto& n : out.nodes) {
-                // inner children are consecutive nodes already (memory order above); their index, not the float4 address, goes into the links
-                int32_t tmp[4]; for (int c = 0; c < 4; c++) tmp[c] = n.child[c] >= 0 && n.child[c] != 0x76543210 ? n.child[c] / 4 : n.child[c];
-                uint32_t prev = 0xffffffffu; bool consecutive = true;
-                for (int c = 0; c < 4; c++) if (tmp[c] >= 0 && tmp[c] != 0x76543210) { if (prev != 0xffffffffu && (uint32_t)tmp[c] != prev + 1) consecutive = false; prev = (uint32_t)tmp[c]; }
-                if (!relink(tmp, 4, n.links, &n.mask) || !consecutive || out.nodes.size() >= (1u << 26)) out.compact_links = false;
-                for (int c = 0; c < 4; c++) if (tmp[c] < 0) n.child[c] = tmp[c];
+                // inner children are consecutive nodes already (memory order above); flat4_encode_links refuses a node whose links the layout does not imply
+                uint32_t counts[4];
+                relink(n.child, 4, counts, &n.mask);
+                if (!flat4_encode_links(n.child, counts, 0u, n.links) || out.nodes.size() >= (1u << 24)) out.compact_links = false;   // slab flags: set below
             }
         } else for (auto& n : out.nodes_f4) relink(n.child, 4, nullptr, nullptr);
     }
@@ -398,8 +387,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
                     // triangles of the leaf children
                     struct ctri { double w[3][3]; double slack; int c; };
                     ctri T[16]; int nt = 0;
-                    uint32_t cnt[4] = { (f.links[0] & 3u) + 1u, ((f.links[0] >> 2) & 3u) + 1u, ((f.links[0] >> 4) & 3u) + 1u, (f.links[1] & 3u) + 1u };
-                    for (int c = 0; c < 4; c++) if ((f.mask >> (4 + c)) & 1) for (uint32_t e = 0; e < cnt[c]; e++) { T[nt].c = c; world_tri((uint32_t)~ch[c] + e, T[nt].w, T[nt].slack); nt++; }
+                    for (int c = 0; c < 4; c++) if ((f.mask >> (4 + c)) & 1) for (uint32_t e = (uint32_t)~ch[c];; e++) { T[nt].c = c; world_tri(e, T[nt].w, T[nt].slack); nt++; if ((out.leaves[e].index & 1u) || nt == 16) break; }
                     double stepk[3], ext1 = 0, mag = 0;
                     for (int k = 0; k < 3; k++) { stepk[k] = std::ldexp(1.0, (int)f.e[k] - 127); ext1 += 255.0 * stepk[k]; mag = std::max(mag, std::fabs((double)f.origin[k]) + 255.0 * stepk[k]); }
                     // box extents of the children (decoded codes) for the usefulness measure
@@ -472,9 +460,12 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
             });
             for (size_t i = 0; i < out.nodes.size(); i++) {
                 out.slab_nodes += has_slab[i];
-                uint32_t flags = 0;
-                for (int c = 0; c < 4; c++) { const int32_t k = out.child_links[i * 4 + c]; if (k >= 0 && k != 0x76543210 && has_slab[(size_t)k / 4]) flags |= 1u << c; }
-                out.nodes[i].links[1] |= flags << 2;
+                // slab flag of an inner child = bit 0 of its link: bit 0 of links[0] for slot 0, bit 0 of the slot's nibble otherwise (flatten.h)
+                for (int c = 0; c < 4; c++) {
+                    const int32_t k = out.child_links[i * 4 + c];
+                    if (k < 0 || k == 0x76543210 || !has_slab[(size_t)k / 4]) continue;
+                    if (c == 0) out.nodes[i].links[0] |= 1u; else if (c == 1) out.nodes[i].links[0] |= 1u << 26; else if (c == 2) out.nodes[i].links[1] |= 1u << 2; else out.nodes[i].links[0] |= 1u << 30;
+                }
             }
             out.root_slab = has_slab[0] != 0;
             pt.lap("slabs");

@@ -28,16 +28,18 @@ enum flat_format : int {
 };
 
 // Q4.  Child box c, axis k:  lo = origin[k] + 2^(e[k]-127) * qlo[k][c],  hi = origin[k] + 2^(e[k]-127) * qhi[k][c]  (conservative).
-// Everything a traversal step needs sits in the first 48 B (three 16-B loads per lane instead of four: the kernels are bound by the
-// number of per-lane L1 accesses): the child links are implied by the layout — the inner children of a node are
-// consecutive nodes, the entries of its leaf children are consecutive leaf entries, both in slot order:
-//   inner child c  = node  (links[0] >> 6) + popcount(inner children in slots < c)
-//   leaf child c   = entry (links[1] >> 2) + sum over leaf children in slots < c of their entry counts
-// with the per-slot entry count - 1 in two bits each: slots 0..2 in links[0] bits 0..5, slot 3 in links[1] bits 0..1 (a leaf has at most
-// four entries; 2^26 nodes, 2^26 entries).  links[1] bits 2..5: inner child c of this node carries an ORIENTED SLAB (flat_slab.h) in its
-// last 16 B; the traversal hands that bit down in the child link (bit 0 of an inner link), so a lane knows BEFORE it fetches a node whether to
-// load 48 or 64 B.  The last 16 B are that slab when the tree has implied links, else the explicit links child[4] (the kernels then read them
-// and no node has a slab); host code and the test oracle find the explicit links of every tree in flat_scene::child_links.
+// Everything a traversal step needs sits in the first 48 B (three 16-B loads per lane instead of four): the child links are implied by the
+// layout — the inner children of a node are consecutive nodes, the entries of its leaf children are consecutive leaf entries, both in slot
+// order — and spelled so that a link is ONE addition (round 3; the first form, a base and per-slot entry counts, cost the node step 45 VALU
+// instructions and a dozen exec-mask branches of prefix sums):
+//   links[0]  bits 0..25: first inner child's node index * 4 | slab flag of slot 0 (bit 0)     bits 26..29: t1     bits 30..31: t3 & 3
+//   links[1]  bits 0..1: t3 >> 2     bits 2..5: t2     bits 6..31: ~(first leaf entry of the node + 15), low 26 bits
+//   t_k of an inner child  = (inner children in slots < k) << 2 | slab flag of slot k      ->  link = inner base * 4 + t_k
+//   t_k of a leaf child    = 15 - (entries of the leaf children in slots < k)              ->  link = ~(leaf base + 15) + t_k = ~(its first entry)
+// (slot 0: t_0 = slab flag or 15, implied; a leaf has at most four entries; fewer than 2^24 nodes and 2^26 - 15 entries).  The slab flag says that the
+// child node carries an ORIENTED SLAB (flat_slab.h) in its last 16 B; the traversal hands that bit down in the child link (bit 0 of an inner link), so a
+// lane knows BEFORE it fetches a node whether to load 48 or 64 B.  The last 16 B are that slab when the tree has implied links, else the explicit links
+// child[4] (the kernels then read them and no node has a slab); host code and the test oracle find the explicit links of every tree in flat_scene::child_links.
 struct flat4_node {
     float origin[3];
     uint8_t e[3];          // biased float exponents of the per-axis quantisation step
@@ -51,15 +53,35 @@ struct flat4_node {
 };
 static_assert(sizeof(flat4_node) == 64, "quantised wide node is one 64-B fetch group");
 // the links a traversal step derives from the layout (what node_step_q4 computes): inner child = node index * 4 | slab flag, leaf child = ~first entry
+inline void flat4_link_nibbles(const uint32_t w0, const uint32_t w1, uint32_t t[4]) { t[0] = 0; t[1] = (w0 >> 26) & 15u; t[2] = (w1 >> 2) & 15u; t[3] = (w0 >> 30) | ((w1 & 3u) << 2); }
 inline void flat4_implied_links(const flat4_node& n, int32_t c[4]) {
-    const uint32_t w0 = n.links[0], w1 = n.links[1], leafm = n.mask >> 4, innerm = n.mask & ~leafm & 15u, sflags = (w1 >> 2) & 15u;
-    const uint32_t inner_base = w0 >> 6, leaf_base = w1 >> 6;
-    const uint32_t cnt[4] = { (w0 & 3u) + 1u, ((w0 >> 2) & 3u) + 1u, ((w0 >> 4) & 3u) + 1u, (w1 & 3u) + 1u };
-    uint32_t ni = 0, nl = 0;
+    const uint32_t w0 = n.links[0], w1 = n.links[1], leafm = n.mask >> 4;
+    const uint32_t ib4 = w0 & 0x03fffffcu, nlb15 = (w1 >> 6) | 0xfc000000u;
+    uint32_t t[4]; flat4_link_nibbles(w0, w1, t);
+    c[0] = (leafm & 1u) ? (int32_t)(nlb15 + 15u) : (int32_t)(w0 & 0x03ffffffu);
+    for (int k = 1; k < 4; k++) c[k] = (int32_t)((((leafm >> k) & 1u) ? nlb15 : ib4) + t[k]);
+}
+// the two link words of a node from its explicit links (child: node index * 4, ~first entry or 0x76543210), the entry count of every leaf child and the slab flags of the inner ones;
+// false when the node or entry numbers do not fit
+inline bool flat4_encode_links(const int32_t child[4], const uint32_t counts[4], uint32_t slab_flags, uint32_t links[2]) {
+    uint32_t inner_base4 = 0, leaf_base = 0; bool have_inner = false, have_leaf = false;
+    uint32_t t[4] = { 0, 0, 0, 0 }, ni = 0, nl = 0;
     for (int k = 0; k < 4; k++) {
-        if ((leafm >> k) & 1u) { c[k] = ~(int32_t)(leaf_base + nl); nl += cnt[k]; }
-        else { c[k] = (int32_t)(((inner_base + ni) << 2) | ((sflags >> k) & 1u)); if ((innerm >> k) & 1u) ni++; }
+        if (child[k] == 0x76543210) continue;
+        if (child[k] >= 0) {
+            if (!have_inner) { inner_base4 = (uint32_t)child[k]; have_inner = true; }
+            if ((uint32_t)child[k] != inner_base4 + 4u * ni) return false;        // inner children are consecutive nodes
+            t[k] = (ni << 2) | ((slab_flags >> k) & 1u); ni++;
+        } else {
+            if (!have_leaf) { leaf_base = (uint32_t)~child[k]; have_leaf = true; }
+            if ((uint32_t)~child[k] != leaf_base + nl || counts[k] < 1 || counts[k] > 4) return false;   // leaf children own consecutive entries
+            t[k] = 15u - nl; nl += counts[k];
+        }
     }
+    if (inner_base4 >= (1u << 26) || (inner_base4 & 3u) || (uint64_t)leaf_base + 15u >= (1ull << 26)) return false;
+    links[0] = inner_base4 | (child[0] >= 0 && child[0] != 0x76543210 ? (t[0] & 1u) : 0u) | (t[1] << 26) | ((t[3] & 3u) << 30);
+    links[1] = (t[3] >> 2) | (t[2] << 2) | ((~(leaf_base + 15u)) << 6);
+    return true;
 }
 
 // F4.  Plane-major so that a lane picks the near / far plane of all four children by ADDRESS (the sign of its ray direction

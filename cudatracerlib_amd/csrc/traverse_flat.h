@@ -286,16 +286,16 @@ __device__ __forceinline__ int node_step_q4(const node_words& W, int node, const
     const float inf = __builtin_huge_valf();
     float s_alpha = 0.0f, s_bn = -inf, s_bf = inf; uint32_t s_nw = 0u, s_fw = 0u;   // no slab: [-inf, inf] for every child
     if (compact) {
+        // implied links (flatten.h): link = base + nibble, no prefix sums and no branches — 20 VALU (the first spelling of the layout, counts per slot, took 45 and a dozen exec-mask branches)
         const uint32_t w0 = __float_as_uint(q2.z), w1 = __float_as_uint(q2.w);
-        const uint32_t leafm = meta >> 28, innerm = (meta >> 24) & ~leafm & 15u;
-        const uint32_t inner_base = w0 >> 6, leaf_base = w1 >> 6, sflags = w1 >> 2;
-        // entries of the leaf children in slots 0..2 (0 for an inner child), prefix sums = first entry of each leaf child
-        const uint32_t n0 = (leafm & 1u) ? (w0 & 3u) + 1u : 0u, n1 = (leafm & 2u) ? ((w0 >> 2) & 3u) + 1u : 0u, n2 = (leafm & 4u) ? ((w0 >> 4) & 3u) + 1u : 0u;
-        const uint32_t i1 = innerm & 1u, i2 = i1 + ((innerm >> 1) & 1u), i3 = i2 + ((innerm >> 2) & 1u);
-        c[0] = (leafm & 1u) ? ~(int)leaf_base : (int)((inner_base << 2) | (sflags & 1u));
-        c[1] = (leafm & 2u) ? ~(int)(leaf_base + n0) : (int)(((inner_base + i1) << 2) | ((sflags >> 1) & 1u));
-        c[2] = (leafm & 4u) ? ~(int)(leaf_base + n0 + n1) : (int)(((inner_base + i2) << 2) | ((sflags >> 2) & 1u));
-        c[3] = (leafm & 8u) ? ~(int)(leaf_base + n0 + n1 + n2) : (int)(((inner_base + i3) << 2) | ((sflags >> 3) & 1u));
+        const uint32_t ib4 = w0 & 0x03fffffcu, nlb15 = __builtin_amdgcn_alignbit(0xffffffffu, w1, 6);   // first inner child * 4; ~(first entry + 15)
+        const uint32_t dl = nlb15 - ib4;
+        const uint32_t t1 = __builtin_amdgcn_ubfe(w0, 26, 4), t2 = __builtin_amdgcn_ubfe(w1, 2, 4), t3 = __builtin_amdgcn_alignbit(w1, w0, 30) & 15u;
+        const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)meta, 28, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)meta, 29, 1), m2 = (uint32_t)__builtin_amdgcn_sbfe((int)meta, 30, 1), m3 = (uint32_t)((int)meta >> 31);
+        c[0] = (int)((m0 & (nlb15 + 15u)) | (~m0 & (w0 & 0x03ffffffu)));
+        c[1] = (int)(ib4 + t1 + (m1 & dl));
+        c[2] = (int)(ib4 + t2 + (m2 & dl));
+        c[3] = (int)(ib4 + t3 + (m3 & dl));
         if (node & 1) {
             const float4 q3 = W.q3;
             slab_ray SR;

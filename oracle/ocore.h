@@ -202,13 +202,12 @@ inline bool traceRayFlat(const Scene& S, V3 ori, V3 dir, float tmin_tri, float t
                 }
                 int32_t links[4];
                 if (F.compact) {
-                    const uint32_t w0 = w[10], w1 = w[11], leafm = meta >> 28, innerm = (meta >> 24) & ~leafm & 15u, sflags = (w1 >> 2) & 15u;
-                    const uint32_t cn[4] = { (w0 & 3u) + 1u, ((w0 >> 2) & 3u) + 1u, ((w0 >> 4) & 3u) + 1u, (w1 & 3u) + 1u };
-                    uint32_t ni = 0, nl = 0;
-                    for (int k = 0; k < 4; k++) {
-                        if ((leafm >> k) & 1u) { links[k] = ~(int32_t)((w1 >> 6) + nl); nl += cn[k]; }
-                        else { links[k] = (int32_t)((((w0 >> 6) + ni) << 2) | ((sflags >> k) & 1u)); if ((innerm >> k) & 1u) ni++; }
-                    }
+                    // flatten.h: link = base + nibble.  w0: first inner child * 4 | slab flag of slot 0, t1 in bits 26..29, t3 & 3 in bits 30..31; w1: t3 >> 2, t2 in bits 2..5, ~(first entry + 15) above
+                    const uint32_t w0 = w[10], w1 = w[11], leafm = meta >> 28;
+                    const uint32_t ib4 = w0 & 0x03fffffcu, nlb15 = (w1 >> 6) | 0xfc000000u;
+                    const uint32_t t[4] = { 0u, (w0 >> 26) & 15u, (w1 >> 2) & 15u, (w0 >> 30) | ((w1 & 3u) << 2) };
+                    links[0] = (leafm & 1u) ? (int32_t)(nlb15 + 15u) : (int32_t)(w0 & 0x03ffffffu);
+                    for (int k = 1; k < 4; k++) links[k] = (int32_t)((((leafm >> k) & 1u) ? nlb15 : ib4) + t[k]);
                 } else for (int k = 0; k < 4; k++) links[k] = (int32_t)w[12 + k];
                 for (int k = 0; k < 4; k++) {
                     const float tnx = std::fmaf((float)((nx >> (8 * k)) & 0xffu), ax, bx), tfx = std::fmaf((float)((fx >> (8 * k)) & 0xffu), ax, bx);

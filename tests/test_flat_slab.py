@@ -45,11 +45,11 @@ def decode_slabs(N):
 
 def slab_nodes(fb):
     """indices of the nodes that carry a slab: the children whose parent link says so (+ the root)"""
-    N = fb.nodes(); links = fb.child_links()
-    sflags = (N[:, 11] >> 2) & 15
+    N = fb.nodes(); links = fb.child_links(); imp = api.FlatBvh.implied_links(N)
+    exist = (N[:, 3] >> 24) & 15; leafm = N[:, 3] >> 28
     has = np.zeros(len(N), bool)
     for c in range(4):
-        sel = ((sflags >> c) & 1) == 1
+        sel = (((exist & ~leafm) >> c) & 1 == 1) & ((imp[:, c] & 1) == 1)      # inner children whose link carries the flag
         has[links[sel, c] // 4] = True
     has[0] = bool(fb.desc.root_slab)
     return has
@@ -94,7 +94,12 @@ def test_every_leaf_child_lies_inside_its_decoded_slab(name):
     W = world_vertices(d, L)
     origin = N[:, :3].view(np.float32).astype(np.float64)
     meta = N[:, 3]; exist = (meta >> 24) & 15; leafm = meta >> 28
-    cnt = np.stack([N[:, 10] & 3, (N[:, 10] >> 2) & 3, (N[:, 10] >> 4) & 3, N[:, 11] & 3], 1) + 1
+    cnt = np.zeros((len(N), 4), np.int64)                                                               # entries of every leaf child: up to the entry flagged last
+    for c in range(4):
+        idx = np.nonzero(((leafm >> c) & 1) == 1)[0]; e = ~links[idx, c]; k = np.ones(len(idx), np.int64)
+        for j in range(3):
+            more = (L[np.minimum(e + k - 1, len(L) - 1), 12] & 1) == 0; k = k + (more & (k == j + 1))
+        cnt[idx, c] = k
     checked = 0
     for c in range(4):
         is_leaf = has & (((leafm >> c) & 1) == 1)
@@ -152,7 +157,7 @@ def test_slabs_cut_the_leaf_entry_fetches(orc):
     tables = orc.sequence_tables(1)
     c1, c0 = {}, {}
     img1, rays1 = orc.render(d, 48, 48, n_passes=1, tables=tables, max_path_length=6, flat=fb.desc, counts=c1)
-    N = fb.nodes().copy(); N[:, 11] &= ~np.uint32(15 << 2)                          # no inner link carries the flag any more
+    N = api.FlatBvh.clear_slab_flags(fb.nodes().copy())                          # no inner link carries the flag any more
     plain = api.FlatBvhDesc.from_buffer_copy(fb.desc)
     plain.nodes = N.ctypes.data; plain.root_slab = 0
     img0, rays0 = orc.render(d, 48, 48, n_passes=1, tables=tables, max_path_length=6, flat=plain, counts=c0)

@@ -65,28 +65,30 @@ def check_implied_links(fb):
     assert N.shape[1] == 16
     meta = N[:, 3]; exist = (meta >> 24) & 15; leafm = meta >> 28; innerm = exist & ~leafm & 15
     assert (leafm & ~exist).max() == 0
-    w0, w1 = N[:, 10], N[:, 11]
-    inner_base, leaf_base, sflags = w0 >> 6, w1 >> 6, (w1 >> 2) & 15
     assert fb.desc.compact == 1
-    cnt = np.stack([w0 & 3, (w0 >> 2) & 3, (w0 >> 4) & 3, w1 & 3], 1) + 1
+    imp = api.FlatBvh.implied_links(N)
     child = fb.child_links()      # the explicit links (host side); a compact tree's last 16 B per node hold the oriented slab instead (flat_slab.h)
     has_slab = np.zeros(len(N), bool)
     n_leaf_before = np.zeros(len(N), np.int64); n_inner_before = np.zeros(len(N), np.int64)
+    inner_base = np.full(len(N), -1, np.int64); leaf_base = np.full(len(N), -1, np.int64)
     for c in range(4):
         is_leaf = ((leafm >> c) & 1) == 1; is_inner = ((innerm >> c) & 1) == 1
-        assert np.array_equal(child[is_leaf, c], ~(leaf_base[is_leaf].astype(np.int64) + n_leaf_before[is_leaf]).astype(np.int32))
-        assert np.array_equal(child[is_inner, c], ((inner_base[is_inner] + n_inner_before[is_inner]) * 4).astype(np.int32))
+        assert np.array_equal(imp[is_leaf, c], child[is_leaf, c])
+        assert np.array_equal(imp[is_inner, c] & ~3, child[is_inner, c]) and ((imp[is_inner, c] & 2) == 0).all()
         assert (child[~is_leaf & ~is_inner, c] == 0x76543210).all()
-        # the count of a leaf child = distance to the entry flagged last
-        first = (leaf_base + n_leaf_before)[is_leaf]; k = cnt[is_leaf, c]
-        assert (L[first + k - 1, 12] & 1).all()
-        for j in range(1, 4):
-            inside = k > j
-            assert not (L[(first + j - 1)[inside], 12] & 1).any()
+        # the layout behind the links: inner children are consecutive nodes, the entries of the leaf children consecutive entries, both in slot order
+        first_i = is_inner & (inner_base < 0); inner_base[first_i] = child[first_i, c] // 4
+        assert np.array_equal(child[is_inner, c] // 4, (inner_base + n_inner_before)[is_inner])
+        first_l = is_leaf & (leaf_base < 0); leaf_base[first_l] = ~child[first_l, c]
+        assert np.array_equal(~child[is_leaf, c], (leaf_base + n_leaf_before)[is_leaf])
+        first = (~child[is_leaf, c]).astype(np.int64); k = np.ones(len(first), np.int64)
+        for j in range(3):
+            more = (L[np.minimum(first + k - 1, len(L) - 1), 12] & 1) == 0; k = k + (more & (k == j + 1))
+        assert (L[first + k - 1, 12] & 1).all() and k.max(initial=1) <= 4
+        cnt_c = np.zeros(len(N), np.int64); cnt_c[is_leaf] = k
         # slab flag of an inner child: the bit the traversal hands down in the link
-        kids = (inner_base + n_inner_before)[is_inner]; has_slab[kids[((sflags[is_inner] >> c) & 1) == 1]] = True
-        assert (sflags[~is_inner] >> c & 1).max(initial=0) == 0
-        n_leaf_before += np.where(is_leaf, cnt[:, c], 0); n_inner_before += is_inner
+        has_slab[(child[is_inner, c] // 4)[(imp[is_inner, c] & 1) == 1]] = True
+        n_leaf_before += cnt_c; n_inner_before += is_inner
     has_slab[0] = bool(fb.desc.root_slab)
     assert has_slab.sum() == fb.desc.n_slab_nodes and (leafm[has_slab] != 0).all()      # only nodes with leaf children carry a slab
 
