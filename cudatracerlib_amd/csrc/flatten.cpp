@@ -156,7 +156,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     std::string key;
     if (!cache_dir().empty()) {
         content_hash H; const uint32_t version = 12;
-        H.add_value(version); H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
+        H.add_value(version); { const char* e = knob_env("CTL_FLAT_FORCE_EXPLICIT"); H.add_value(e ? atoi(e) : 0); } H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
         for (uint32_t k = 0; k < d.n_nodes; k++) { H.add_value(d.nodes[k].mesh_index); H.add(d.node_transforms[k].m, 64); }
@@ -346,6 +346,9 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
                 relink(n.child, 4, counts, &n.mask);
                 if (!flat4_encode_links(n.child, counts, 0u, n.links) || out.nodes.size() >= (1u << 24)) out.compact_links = false;   // slab flags: set below
             }
+            // The explicit-link form of the tree (no implied links, no slabs) is what a scene beyond 2^24 nodes or 2^26 entries gets; CTL_FLAT_FORCE_EXPLICIT=1 (knobs build only) builds it
+            // for any scene so that the tests can walk that path
+            if (const char* e = knob_env("CTL_FLAT_FORCE_EXPLICIT")) if (atoi(e) != 0) out.compact_links = false;
         } else for (auto& n : out.nodes_f4) relink(n.child, 4, nullptr, nullptr);
     }
     out.leaves.resize(entry_src.size());

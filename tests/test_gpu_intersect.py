@@ -178,3 +178,10 @@ def test_flattened_counts_against_the_oracle_on_the_same_arrays(gpu, orc, fmt):
     assert g["n_inst"] == 0 and o["n_inst"] == 0
     assert 0.98 * o["n_inner"] <= g["n_inner"] <= 1.35 * o["n_inner"], (g, o)
     assert 0.98 * o["n_tri"] <= g["n_tri"] <= 1.35 * o["n_tri"], (g, o)
+
+
+def test_flattened_tree_with_explicit_links(gpu, orc):
+    """the explicit-link form of the flattened tree (what a scene too large for the implied links gets; CTL_FLAT_FORCE_EXPLICIT=1 in the knobs build, child process):
+    the kernels read child[4] from the node's last 16 B — bit-exact against the oracle's traversal of the same arrays"""
+    from test_oracle_flat import run_explicit_links_child
+    run_explicit_links_child(True)

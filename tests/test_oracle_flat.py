@@ -204,3 +204,59 @@ def test_missing_children_have_inverted_boxes():
                 lo = (N[:, lo_w] >> (8 * c)) & 255; hi = (N[:, hi_w] >> (8 * c)) & 255
                 assert (lo[has] <= hi[has]).all()
                 assert (lo[~has] == 255).all() and (hi[~has] == 0).all()
+
+
+EXPLICIT_LINKS_CODE = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from cudatracerlib_amd import api, scenes
+import oracle
+sys.path.insert(0, %r)
+from test_oracle_flat import rays_for
+orc = oracle.Oracle()
+sc = scenes.synthetic_sm(32, 32, n_instances=60, subdiv=2)
+d = sc.desc
+fb = api.FlatBvh(d, api.FLAT_Q4)
+assert fb.desc.compact == 0 and fb.desc.n_slab_nodes == 0 and fb.desc.root_slab == 0
+N = fb.nodes()
+assert np.array_equal(N[:, 12:16].view(np.int32), fb.child_links())          # the last 16 B of every node are its explicit links
+rays = rays_for(d, 6000, 5)
+want = orc.intersect(d, rays)
+got = orc.intersect(d, rays, flat=fb.desc)
+same = ~((got["tri_idx"] != want["tri_idx"]) & (got["dist"] == want["dist"]))
+assert same.mean() > 0.999
+for k in ("tri_idx", "node_idx"):
+    assert np.array_equal(got[k][same], want[k][same]), k
+for k in ("dist", "u", "v"):
+    assert np.array_equal(got[k][same].view(np.uint32), want[k][same].view(np.uint32)), k
+if %r:
+    gpu = api
+    assert gpu.device_count() >= 1
+    scene = gpu.Scene(d, flatten=True)
+    for any_hit in (False, True):
+        g = gpu.intersect(scene, rays, any_hit=any_hit); w = orc.intersect(d, rays, any_hit=any_hit, flat=fb.desc)
+        if any_hit:
+            assert np.array_equal(g["tri_idx"] >= 0, w["tri_idx"] >= 0)
+        else:
+            for k in ("tri_idx", "node_idx"):
+                assert np.array_equal(g[k], w[k]), k
+            for k in ("dist", "u", "v"):
+                assert np.array_equal(g[k].view(np.uint32), w[k].view(np.uint32)), k
+print("EXPLICIT OK")
+'''
+
+
+def run_explicit_links_child(on_gpu):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CTL_FLAT_FORCE_EXPLICIT="1", CTL_AMD_LIB=os.path.join(root, "cudatracerlib_amd", "libctl_knobs.so"))
+    r = subprocess.run([sys.executable, "-c", EXPLICIT_LINKS_CODE % (root, os.path.join(root, "tests"), on_gpu)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "EXPLICIT OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_tree_with_explicit_links():
+    """The form a scene beyond 2^24 nodes or 2^26 - 15 leaf entries gets (flatten.h: no implied links, the last 16 B of a node are child[4], no slabs), built for a
+    small scene through CTL_FLAT_FORCE_EXPLICIT=1 (knobs build, child process): the oracle's traversal of it reports the two-level (t, u, v, triangle, node) bit for bit."""
+    run_explicit_links_child(False)
