@@ -237,7 +237,7 @@ class FlatBvh:
     @staticmethod
     def clear_slab_flags(N):
         """in place: no inner link hands a slab flag down any more"""
-        inner = ((N[:, 3] >> 24) & 15) & ~(N[:, 3] >> 28)      # bit 0 of a slot's nibble is the flag only for an inner child (a leaf child's nibble is 15 - entries before it)
+        inner = ((N[:, 3] >> 24) & 15) & ~(N[:, 3] >> 28)      # existing children without a leaf bit; bit 0 of a slot's nibble is the flag only for an inner child (a leaf child's nibble is 15 - entries before it)
         for k, (word, bit) in enumerate(((10, 0), (10, 26), (11, 2), (10, 30))):
             N[:, word] &= ~(((inner >> k) & 1).astype(np.uint32) << np.uint32(bit))
         return N

@@ -104,7 +104,13 @@ bool flat_links_valid(const flat_scene& F) {
                 if (((n.mask >> c) & 1) && !ok(k, F.nodes.size(), 4)) return false;
                 // the kernels follow the IMPLIED links (and the slab flag they carry) when the tree is compact: they must be the explicit ones
                 if (F.compact_links && ((n.mask >> c) & 1) && (imp[c] & ~(k >= 0 ? 1 : 0)) != k) return false;
-                if (!F.compact_links && n.child[c] != k) return false;
+                if (!F.compact_links && ((n.mask >> c) & 1) && n.child[c] != k) return false;
+                // a slot without a child repeats the link of one that exists (flatten_scene's last pass): a link the kernels may follow, so it is checked like the others
+                if (!((n.mask >> c) & 1)) {
+                    const int32_t mine = F.compact_links ? imp[c] : n.child[c]; bool found = false;
+                    for (int e = 0; e < 4; e++) if ((n.mask >> e) & 1) { const int32_t theirs = F.compact_links ? imp[e] : n.child[e]; if (mine == theirs || (mine >= 0 && theirs >= 0 && (mine & ~3) == (theirs & ~3))) found = true; }
+                    if (!found && (n.mask & 15)) return false;
+                }
             }
         }
     }
@@ -155,7 +161,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node format only
     std::string key;
     if (!cache_dir().empty()) {
-        content_hash H; const uint32_t version = 12;
+        content_hash H; const uint32_t version = 13;
         H.add_value(version); { const char* e = knob_env("CTL_FLAT_FORCE_EXPLICIT"); H.add_value(e ? atoi(e) : 0); } H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
@@ -472,6 +478,23 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
             }
             out.root_slab = has_slab[0] != 0;
             pt.lap("slabs");
+        }
+        // Slots without a child.  Their box is inverted, which the slab test rejects — unless the ray origin is so far from a small node (~2^16 node extents) that
+        // entry and exit plane round to the same distance on every axis; then the kernel follows the slot's link.  It must lead somewhere harmless: the link of a
+        // slot that exists (a second visit of a sibling finds nothing new).  Implied links: an empty slot's nibble is 0, which is the node's first inner child; a node
+        // without inner children gets the empty slot's LEAF bit set and nibble 15 = its first leaf entry (only the kernels and flat4_implied_links read a leaf bit
+        // without its exists bit; host code asks for both).  Explicit links: the slot's word repeats the first child's.
+        for (size_t i = 0; i < out.nodes.size(); i++) {
+            flat4_node& f = out.nodes[i];
+            const uint32_t exist = f.mask & 15u, leafm = (uint32_t)(f.mask >> 4) & exist;
+            if (exist == 15u || exist == 0u) continue;
+            if (out.compact_links) {
+                if ((exist & ~leafm) != 0u) continue;   // nibble 0 -> first inner child
+                for (int c = 1; c < 4; c++) if (!((exist >> c) & 1u)) {
+                    f.mask |= (uint8_t)(16u << c);
+                    if (c == 1) f.links[0] |= 15u << 26; else if (c == 2) f.links[1] |= 15u << 2; else { f.links[0] |= 3u << 30; f.links[1] |= 3u; }
+                }
+            } else for (int c = 1; c < 4; c++) if (!((exist >> c) & 1u)) f.child[c] = f.child[0];
         }
     }
     if (!key.empty()) {

@@ -43,7 +43,8 @@ enum flat_format : int {
 struct flat4_node {
     float origin[3];
     uint8_t e[3];          // biased float exponents of the per-axis quantisation step
-    uint8_t mask;          // bit c set <=> child c exists; bit 4 + c set <=> child c is a leaf.  A missing child also has an INVERTED box (lo = 255, hi = 0), so the kernel's slab test alone rejects it
+    uint8_t mask;          // bit c set <=> child c exists; bit 4 + c set (with bit c) <=> child c is a leaf.  A missing child has an INVERTED box (lo = 255, hi = 0), so the kernel's slab test alone rejects it,
+                           // and its link repeats a sibling's (flatten.cpp: a slot that round-off lets through must lead somewhere harmless) — which is why an empty slot of a node without inner children carries a leaf bit
     uint32_t qlo_x, qhi_x, qlo_y, qhi_y, qlo_z, qhi_z;   // byte c = child c
     uint32_t links[2];
     union {

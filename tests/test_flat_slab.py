@@ -46,7 +46,7 @@ def decode_slabs(N):
 def slab_nodes(fb):
     """indices of the nodes that carry a slab: the children whose parent link says so (+ the root)"""
     N = fb.nodes(); links = fb.child_links(); imp = api.FlatBvh.implied_links(N)
-    exist = (N[:, 3] >> 24) & 15; leafm = N[:, 3] >> 28
+    exist = (N[:, 3] >> 24) & 15; leafm = (N[:, 3] >> 28) & exist
     has = np.zeros(len(N), bool)
     for c in range(4):
         sel = (((exist & ~leafm) >> c) & 1 == 1) & ((imp[:, c] & 1) == 1)      # inner children whose link carries the flag
@@ -93,7 +93,7 @@ def test_every_leaf_child_lies_inside_its_decoded_slab(name):
     assert (np.abs(n[has]).max(1) == N_MAX).all() and (step[has] > 0).all()
     W = world_vertices(d, L)
     origin = N[:, :3].view(np.float32).astype(np.float64)
-    meta = N[:, 3]; exist = (meta >> 24) & 15; leafm = meta >> 28
+    meta = N[:, 3]; exist = (meta >> 24) & 15; leafm = (meta >> 28) & exist      # (an empty slot may carry a leaf bit: flatten.cpp)
     cnt = np.zeros((len(N), 4), np.int64)                                                               # entries of every leaf child: up to the entry flagged last
     for c in range(4):
         idx = np.nonzero(((leafm >> c) & 1) == 1)[0]; e = ~links[idx, c]; k = np.ones(len(idx), np.int64)

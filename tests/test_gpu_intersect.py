@@ -185,3 +185,56 @@ def test_flattened_tree_with_explicit_links(gpu, orc):
     the kernels read child[4] from the node's last 16 B — bit-exact against the oracle's traversal of the same arrays"""
     from test_oracle_flat import run_explicit_links_child
     run_explicit_links_child(True)
+
+
+def test_far_ray_origins_against_tiny_nodes(gpu, orc):
+    """millimetre-sized instances hit from 3 .. 3e4 units away.  From far enough the entry and exit planes of a small node round to the same distance and the 8-bit boxes
+    stop culling — including the inverted box of a slot WITHOUT a child, whose link the kernel then follows (flatten.cpp gives such a slot a sibling's link, so that
+    the walk ends).  Box culling in fp32 is only reliable while the ray origin is within ~1e5 triangle sizes — the reference's own two-level traversal and a flat one
+    then disagree on which triangles they look at (the oracle's two traversals: 0 rays of 8000 at 10 units, 9 at 100, 86 at 1000 on this scene) — so: from 3 units the
+    GPU equals the oracle's traversal of the same arrays; from everywhere the traversal ends, agrees on hit / miss for > 97 % of the rays, and every hit it reports is the
+    reference's evaluation of that triangle."""
+    from cudatracerlib_amd import api
+    V, F = scenes.icosphere(2)
+    Pb, Ib, Nb = scenes.unit_box()
+    meshes = [dict(V=V.astype(np.float32), F=F, N=None, material=("diffuse", (0.7, 0.7, 0.7))), dict(V=Pb, F=Ib, N=Nb, material=("diffuse", (0.2, 0.5, 0.7)))]
+    rs = np.random.RandomState(21)
+    nodes = []
+    for k in range(12):
+        xf = np.eye(4); xf[:3, :3] = scenes._rotation(rs) * (1e-3 * (1 + k % 3)); xf[:3, 3] = rs.uniform(-0.01, 0.01, size=3)
+        nodes.append((k % 2, xf.astype(np.float32)))
+    P, I, Nq = scenes._quad([[-5, 30, -5], [5, 30, -5], [5, 30, 5], [-5, 30, 5]], [0, -1, 0])
+    lights = [(len(nodes), (10.0, 10.0, 10.0))]
+    nodes.append((2, None)); meshes.append(dict(V=P, F=I, N=Nq, material=("diffuse", (0.5, 0.5, 0.5))))
+    sc = scenes.build_scene(dict(meshes=meshes, nodes=nodes, lights=lights, camera=scenes._camera((0, 0.05, -0.2), (0, 0, 0), 40.0, 32, 32)))
+    d = sc.desc
+    fb = api.FlatBvh(d, api.FLAT_Q4)
+    N = fb.nodes(); exist = (N[:, 3] >> 24) & 15
+    assert (exist != 15).mean() > 0.2                                               # the tree has slots without a child
+    targets = rs.uniform(-0.012, 0.012, size=(24000, 3))
+    dirs = rs.normal(size=targets.shape); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dist = np.repeat([3.0, 3e2, 3e3, 3e4], len(targets) // 4)[:, None]
+    rays = np.zeros((len(targets), 8), np.float32)
+    rays[:, :3] = targets - dist * dirs; rays[:, 4:7] = dirs; rays[:, 3] = d.ray_trace_eps; rays[:, 7] = np.float32(3.4e38)
+    scene = gpu.Scene(d, flatten=True)
+    got = gpu.intersect(scene, rays)
+    want = orc.intersect(d, rays, flat=fb.desc)
+    near = slice(0, len(targets) // 4)
+    assert (want["tri_idx"][near] >= 0).mean() > 0.2
+    for k in ("tri_idx", "node_idx"):
+        assert np.array_equal(got[k][near], want[k][near]), k
+    for k in ("dist", "u", "v"):
+        assert np.array_equal(got[k][near].view(np.uint32), want[k][near].view(np.uint32)), k
+    assert ((got["tri_idx"] >= 0) == (want["tri_idx"] >= 0)).mean() > 0.97
+    # every reported hit is the reference's evaluation of that triangle: the two-level oracle over an interval closed in around the reported t
+    hitm = got["tri_idx"] >= 0
+    probe = rays[hitm].copy()
+    probe[:, 7] = np.nextafter(np.nextafter(got["dist"][hitm], np.float32(np.inf)), np.float32(np.inf))
+    probe[:, 3] = np.nextafter(np.nextafter(got["dist"][hitm], np.float32(0)), np.float32(0))
+    again = orc.intersect(d, probe)
+    agree = (again["tri_idx"] == got["tri_idx"][hitm]) & (again["node_idx"] == got["node_idx"][hitm])
+    assert agree.mean() > 0.8                                                       # (from far away many triangles share one representable t, and the probe's own box tests lose some)
+    for k in ("dist", "u", "v"):
+        assert np.array_equal(again[k][agree].view(np.uint32), got[k][hitm][agree].view(np.uint32)), k
+    occ = gpu.intersect(scene, rays, any_hit=True)["tri_idx"] >= 0
+    assert (occ == (orc.intersect(d, rays, any_hit=True, flat=fb.desc)["tri_idx"] >= 0)).mean() > 0.97

@@ -63,8 +63,16 @@ def check_implied_links(fb):
     entries, per-slot entry counts) are the explicit child[] words, for every node of the tree"""
     N = fb.nodes(); L = fb.leaves()
     assert N.shape[1] == 16
-    meta = N[:, 3]; exist = (meta >> 24) & 15; leafm = meta >> 28; innerm = exist & ~leafm & 15
-    assert (leafm & ~exist).max() == 0
+    meta = N[:, 3]; exist = (meta >> 24) & 15; leafm = (meta >> 28) & exist; innerm = exist & ~leafm & 15
+    # a slot without a child: its link repeats a sibling's (flatten.cpp) — the first inner child, or, in a node of leaves only, the first leaf entry (leaf bit set without the exists bit)
+    imp0 = api.FlatBvh.implied_links(N); ch0 = fb.child_links()
+    for c in range(1, 4):
+        gone = ((exist >> c) & 1) == 0
+        all_leaves = gone & (innerm == 0)
+        assert (((meta[all_leaves] >> (28 + c)) & 1) == 1).all() and np.array_equal(imp0[all_leaves, c], ch0[all_leaves, 0])
+        some_inner = gone & (innerm != 0)
+        first_inner = np.array([ch0[i, np.nonzero((innerm[i] >> np.arange(4)) & 1)[0][0]] for i in np.nonzero(some_inner)[0]], np.int32).reshape(-1)
+        assert (((meta[some_inner] >> (28 + c)) & 1) == 0).all() and np.array_equal(imp0[some_inner, c] & ~3, first_inner)
     assert fb.desc.compact == 1
     imp = api.FlatBvh.implied_links(N)
     child = fb.child_links()      # the explicit links (host side); a compact tree's last 16 B per node hold the oriented slab instead (flat_slab.h)
@@ -219,7 +227,9 @@ d = sc.desc
 fb = api.FlatBvh(d, api.FLAT_Q4)
 assert fb.desc.compact == 0 and fb.desc.n_slab_nodes == 0 and fb.desc.root_slab == 0
 N = fb.nodes()
-assert np.array_equal(N[:, 12:16].view(np.int32), fb.child_links())          # the last 16 B of every node are its explicit links
+ch = fb.child_links(); stored = N[:, 12:16].view(np.int32); gone = ch == 0x76543210
+assert np.array_equal(stored[~gone], ch[~gone])                               # the last 16 B of every node are its explicit links ...
+assert np.array_equal(stored[gone], np.broadcast_to(ch[:, :1], ch.shape)[gone])   # ... and a slot without a child repeats the first child's (flatten.cpp)
 rays = rays_for(d, 6000, 5)
 want = orc.intersect(d, rays)
 got = orc.intersect(d, rays, flat=fb.desc)
