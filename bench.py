@@ -135,7 +135,7 @@ def calibrated_traffic(workload_key):
     return e
 
 
-KERNEL_BUILD = "r03-flat-q4-exact-pair-slab-q3early-nibble-links"   # changes when the traversal kernel or the flattened layout changes: a traffic profile of another build is not quoted
+KERNEL_BUILD = "r03-flat-q4-exact-pair-slab-q3early-nibble-links-subtree32"   # changes when the traversal kernel or the flattened layout changes: a traffic profile of another build is not quoted
 
 
 def self_launch(args, argv):

@@ -32,6 +32,8 @@
 
 namespace ctl {
 
+constexpr int kSlabSubtreeDefault = 32;                            // an inner child with at most this many triangles under it gets its own interval (0: leaf children only); measured in DESIGN.md §3
+constexpr int kSlabSubtreeMax = 64;
 constexpr int kSlabNMax = 31;                                   // largest |component| of the integer normal
 constexpr float kSlabRayPad = 31.0f * 1.9073486328125e-6f;     // kSlabNMax * 2^-19: 8 x the worst-case fp32 error of s + t r per unit of |o - origin|_1
 

@@ -161,8 +161,8 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node format only
     std::string key;
     if (!cache_dir().empty()) {
-        content_hash H; const uint32_t version = 13;
-        H.add_value(version); { const char* e = knob_env("CTL_FLAT_FORCE_EXPLICIT"); H.add_value(e ? atoi(e) : 0); } H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
+        content_hash H; const uint32_t version = 14;
+        H.add_value(version); { const char* e = knob_env("CTL_FLAT_SLAB_SUBTREE"); H.add_value(e ? atoi(e) : kSlabSubtreeDefault); } { const char* e = knob_env("CTL_FLAT_FORCE_EXPLICIT"); H.add_value(e ? atoi(e) : 0); } H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
         for (uint32_t k = 0; k < d.n_nodes; k++) { H.add_value(d.nodes[k].mesh_index); H.add(d.node_transforms[k].m, 64); }
@@ -386,26 +386,66 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
                 slack = woop_slack(l.v, M);
             };
             std::vector<uint8_t> has_slab(out.nodes.size(), 0);
+            // An INNER child whose whole subtree holds at most `sub_cap` triangles (a bottom node: the patch of surface under it is as flat as its triangles) gets a real interval too:
+            // a ray that crosses the patch's box but not the patch itself is turned away one level higher and never fetches the bottom node.  sub_tris: triangles under every node
+            // (children follow their parent in memory, so one backwards sweep does it).
+            static const int sub_cap = [] { const char* e = knob_env("CTL_FLAT_SLAB_SUBTREE"); const int v = e ? atoi(e) : kSlabSubtreeDefault; return v < 0 ? 0 : (v > kSlabSubtreeMax ? kSlabSubtreeMax : v); }();
+            std::vector<uint8_t> sub_tris(out.nodes.size(), 0);
+            for (size_t i = out.nodes.size(); i-- > 0;) {
+                uint32_t n = 0;
+                for (int c = 0; c < 4; c++) {
+                    const int32_t k = out.child_links[i * 4 + c];
+                    if (k == 0x76543210) continue;
+                    if (k >= 0) n += sub_tris[(size_t)k / 4];
+                    else for (uint32_t e = (uint32_t)~k;; e++) { n++; if (out.leaves[e].index & 1u) break; }
+                }
+                sub_tris[i] = (uint8_t)std::min(n, 255u);
+            }
             static const double useful_below = [] { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); return e ? atof(e) : 0.6; }();   // builder knob (part of the cache key)
             parallel_for(out.nodes.size(), [&](size_t i0, size_t i1) {
                 for (size_t i = i0; i < i1; i++) {
                     flat4_node& f = out.nodes[i];
                     const int32_t* ch = &out.child_links[i * 4];
                     f.slab_n = 0; f.slab_base = 0.0f; f.slab_lo = 0; f.slab_hi = 0xffffffffu;
-                    if (useful_below <= 0.0 || (f.mask >> 4) == 0) continue;
-                    // triangles of the leaf children
+                    if (useful_below <= 0.0) continue;
+                    // triangles of the leaf children and of the inner children with small subtrees; `tight` = the children that get an interval of their own
                     struct ctri { double w[3][3]; double slack; int c; };
-                    ctri T[16]; int nt = 0;
-                    for (int c = 0; c < 4; c++) if ((f.mask >> (4 + c)) & 1) for (uint32_t e = (uint32_t)~ch[c];; e++) { T[nt].c = c; world_tri(e, T[nt].w, T[nt].slack); nt++; if ((out.leaves[e].index & 1u) || nt == 16) break; }
+                    constexpr int kT = 4 * kSlabSubtreeMax; ctri T[kT]; int nt = 0; uint32_t tight = 0;
+                    for (int c = 0; c < 4; c++) {
+                        if (!((f.mask >> c) & 1)) continue;
+                        if ((f.mask >> (4 + c)) & 1) { tight |= 1u << c; for (uint32_t e = (uint32_t)~ch[c];; e++) { T[nt].c = c; world_tri(e, T[nt].w, T[nt].slack); nt++; if ((out.leaves[e].index & 1u) || nt == kT) break; } continue; }
+                        if (sub_cap <= 0 || sub_tris[(size_t)ch[c] / 4] > sub_cap) continue;
+                        const int nt_before = nt; bool complete = true;
+                        int32_t stack[64]; int sp = 0; stack[sp++] = ch[c];
+                        while (sp && complete) {
+                            const int32_t k = stack[--sp];
+                            if (k >= 0) { for (int q = 0; q < 4; q++) { const int32_t kk = out.child_links[(size_t)k / 4 * 4 + q]; if (kk == 0x76543210) continue; if (sp < 64) stack[sp++] = kk; else complete = false; } }
+                            else for (uint32_t e = (uint32_t)~k;; e++) { if (nt < kT) { T[nt].c = c; world_tri(e, T[nt].w, T[nt].slack); nt++; } else complete = false; if (out.leaves[e].index & 1u) break; }
+                        }
+                        if (complete) tight |= 1u << c; else nt = nt_before;   // an interval must cover EVERY triangle under the child, or the child keeps the whole node
+                    }
+                    if (!tight || nt == 0) continue;
                     double stepk[3], ext1 = 0, mag = 0;
                     for (int k = 0; k < 3; k++) { stepk[k] = std::ldexp(1.0, (int)f.e[k] - 127); ext1 += 255.0 * stepk[k]; mag = std::max(mag, std::fabs((double)f.origin[k]) + 255.0 * stepk[k]); }
                     // box extents of the children (decoded codes) for the usefulness measure
                     const uint32_t ql[3] = { f.qlo_x, f.qlo_y, f.qlo_z }, qh[3] = { f.qhi_x, f.qhi_y, f.qhi_z };
                     int best_n[3] = { 0, 0, 0 }; double best_cost = 1e300; double best_lo[4], best_hi[4];
-                    for (int cand = 0; cand < nt; cand++) {
-                        const double (*w)[3] = T[cand].w;
+                    // candidate directions: the triangles' own normals (at most 24 of them, evenly picked) and — for patches — the area-weighted mean normal of every child and of all
+                    double mean_n[5][3] = {};
+                    for (int t = 0; t < nt; t++) {
+                        const double (*w)[3] = T[t].w;
                         const double a[3] = { w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2] }, b[3] = { w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2] };
                         const double n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+                        for (int k = 0; k < 3; k++) { mean_n[T[t].c][k] += n[k]; mean_n[4][k] += n[k]; }
+                    }
+                    const int cand_step = std::max(1, nt / 24), n_tri_cand = (nt + cand_step - 1) / cand_step;
+                    for (int ci = 0; ci < n_tri_cand + (nt > 4 ? 5 : 0); ci++) {
+                        double n[3];
+                        if (ci < n_tri_cand) {
+                            const double (*w)[3] = T[ci * cand_step].w;
+                            const double a[3] = { w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2] }, b[3] = { w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2] };
+                            n[0] = a[1] * b[2] - a[2] * b[1]; n[1] = a[2] * b[0] - a[0] * b[2]; n[2] = a[0] * b[1] - a[1] * b[0];
+                        } else for (int k = 0; k < 3; k++) n[k] = mean_n[ci - n_tri_cand][k];
                         const double m = std::max(std::max(std::fabs(n[0]), std::fabs(n[1])), std::fabs(n[2]));
                         if (!(m > 0) || !std::isfinite(m)) continue;
                         int nq[3]; for (int k = 0; k < 3; k++) nq[k] = (int)std::lround(n[k] / m * (double)kSlabNMax);
@@ -417,7 +457,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
                             lo[T[t].c] = std::min(lo[T[t].c], D); hi[T[t].c] = std::max(hi[T[t].c], D);
                         }
                         double cost = 0; int nl = 0;
-                        for (int c = 0; c < 4; c++) if ((f.mask >> (4 + c)) & 1) {
+                        for (int c = 0; c < 4; c++) if ((tight >> c) & 1) {
                             double range = 0; for (int k = 0; k < 3; k++) range += std::fabs((double)nq[k]) * stepk[k] * (double)((int)((qh[k] >> (8 * c)) & 255u) - (int)((ql[k] >> (8 * c)) & 255u));
                             cost += range > 0 ? std::min(1.0, (hi[c] - lo[c]) / range) : 1.0; nl++;
                         }
@@ -432,8 +472,8 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
                     // D range the codes span: the leaf children's padded intervals — and, when the node has inner children too, the whole node (its
                     // quantisation grid's box), which their code 0 .. 255 must cover
                     double nlo = 1e300, nhi = -1e300;
-                    for (int c = 0; c < 4; c++) if ((f.mask >> (4 + c)) & 1) { nlo = std::min(nlo, best_lo[c] - pad[c]); nhi = std::max(nhi, best_hi[c] + pad[c]); }
-                    if ((f.mask & 15u) != (uint32_t)(f.mask >> 4)) {
+                    for (int c = 0; c < 4; c++) if ((tight >> c) & 1) { nlo = std::min(nlo, best_lo[c] - pad[c]); nhi = std::max(nhi, best_hi[c] + pad[c]); }
+                    if ((f.mask & 15u) != tight) {   // a child without an interval of its own spans the whole node
                         double pmax = 0; for (int c = 0; c < 4; c++) pmax = std::max(pmax, pad[c]);
                         double blo = 0, bhi = 0; for (int k = 0; k < 3; k++) { const double x = best_n[k] * 255.0 * stepk[k]; if (x < 0) blo += x; else bhi += x; }
                         nlo = std::min(nlo, blo - pmax); nhi = std::max(nhi, bhi + pmax);
@@ -449,7 +489,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
                     for (int c = 0; c < 4; c++) {
                         long lo, hi;
                         if (!((f.mask >> c) & 1)) { lo = 255; hi = 0; }
-                        else if (!((f.mask >> (4 + c)) & 1)) { lo = 0; hi = 255; }
+                        else if (!((tight >> c) & 1)) { lo = 0; hi = 255; }
                         else {
                             lo = (long)std::floor((best_lo[c] - pad[c] - (double)base) / step);
                             hi = (long)std::ceil((best_hi[c] + pad[c] - (double)base) / step);

@@ -43,6 +43,23 @@ def decode_slabs(N):
     return n, step, base, lo, hi
 
 
+def subtree_entries(links, L, link):
+    """leaf entries under a child link (explicit links: node index * 4, ~first entry)"""
+    out = []; stack = [int(link)]
+    while stack:
+        k = stack.pop()
+        if k >= 0:
+            stack.extend(int(x) for x in links[k // 4] if x != 0x76543210)
+        else:
+            e = ~k
+            while True:
+                out.append(e)
+                if L[e, 12] & 1:
+                    break
+                e += 1
+    return np.array(out, np.int64)
+
+
 def slab_nodes(fb):
     """indices of the nodes that carry a slab: the children whose parent link says so (+ the root)"""
     N = fb.nodes(); links = fb.child_links(); imp = api.FlatBvh.implied_links(N)
@@ -100,11 +117,20 @@ def test_every_leaf_child_lies_inside_its_decoded_slab(name):
         for j in range(3):
             more = (L[np.minimum(e + k - 1, len(L) - 1), 12] & 1) == 0; k = k + (more & (k == j + 1))
         cnt[idx, c] = k
-    checked = 0
+    checked = 0; tight_inner = 0
     for c in range(4):
         is_leaf = has & (((leafm >> c) & 1) == 1)
         is_inner = has & (((exist >> c) & 1) == 1) & ~is_leaf
-        assert (lo[is_inner, c] == 0).all() and (hi[is_inner, c] == 255).all()                            # an inner child: the whole node
+        # an inner child: the whole node, or — when at most kSlabSubtree triangles hang under it — an interval that holds every one of them (checked below like a leaf child's)
+        whole = (lo[:, c] == 0) & (hi[:, c] == 255)
+        for i in np.nonzero(is_inner & ~whole)[0]:
+            ents = subtree_entries(links, L, links[i, c]); assert 0 < len(ents) <= 64
+            D = np.einsum("i,nvi->nv", n[i].astype(np.float64), W[ents] - origin[i])
+            d0 = float(np.float32(base[i] + step[i] * np.float32(lo[i, c]))); d1 = float(np.float32(base[i] + step[i] * np.float32(hi[i, c])))
+            ext = np.ldexp(255.0, ((int(meta[i]) >> (8 * np.arange(3))) & 255).astype(np.int64) - 127)
+            room = np.abs(n[i]).sum() * 2.0 ** -20 * (np.abs(origin[i]) + ext).max()
+            assert D.min() - d0 >= room and d1 - D.max() >= room
+            tight_inner += 1
         gone = has & (((exist >> c) & 1) == 0)
         assert (lo[gone, c] == 255).all() and (hi[gone, c] == 0).all()
         idx = np.nonzero(is_leaf)[0]
@@ -121,7 +147,8 @@ def test_every_leaf_child_lies_inside_its_decoded_slab(name):
             room = np.abs(n[k]).sum(1) * 2.0 ** -20 * mag
             assert (D.min(1) - d0 >= room).all() and (d1 - D.max(1) >= room).all()
             checked += len(k)
-    assert checked == L[np.isin(np.arange(len(L)), [])].shape[0] + checked and checked > 0.9 * len(L) * has.sum() / max(1, ((leafm != 0)).sum())
+    assert checked == L[np.isin(np.arange(len(L)), [])].shape[0] + checked and checked > 0.9 * len(L) * (has & (leafm != 0)).sum() / max(1, ((leafm != 0)).sum())
+    assert tight_inner > 0.1 * ((leafm != 0) & has).sum()                                               # bottom nodes do get intervals in their parents
 
 
 @pytest.mark.parametrize("name", list(SCENES))
@@ -150,7 +177,7 @@ def test_slab_traversal_reports_the_two_level_hits_bit_for_bit(orc, name):
 
 def test_slabs_cut_the_leaf_entry_fetches(orc):
     """the point of the slabs: the rays of a render (bounce and shadow rays START on a surface, inside the boxes of the neighbouring triangles) fetch clearly fewer
-    leaf entries than with the boxes alone, visit the same nodes and render the same image — counted by zeroing the slab flags in a copy of the arrays
+    leaf entries than with the boxes alone, visit a few per cent fewer nodes and render the same image — counted by zeroing the slab flags in a copy of the arrays
     (the builder's own switch is a measurement knob)"""
     sc = scenes.synthetic_sm(48, 48, n_instances=400, subdiv=3); d = sc.desc      # the denser the scene the more there is to cull: 2000 instances of the bench scene -25 %, 400 here -12 %
     fb = api.FlatBvh(d, api.FLAT_Q4)
@@ -162,5 +189,5 @@ def test_slabs_cut_the_leaf_entry_fetches(orc):
     plain.nodes = N.ctypes.data; plain.root_slab = 0
     img0, rays0 = orc.render(d, 48, 48, n_passes=1, tables=tables, max_path_length=6, flat=plain, counts=c0)
     assert rays1 == rays0 and np.array_equal(img1, img0)
-    assert abs(c1["path_inner"] - c0["path_inner"]) < 0.01 * c0["path_inner"]      # (a slab also moves a child's entry distance, hence the visiting order)
+    assert 0.90 * c0["path_inner"] < c1["path_inner"] < 0.995 * c0["path_inner"], (c1, c0)      # fewer node visits too: the interval of an inner child with a small subtree keeps rays out of bottom nodes
     assert c1["path_tri"] < 0.92 * c0["path_tri"] and c1["occ_tri"] < 0.94 * c0["occ_tri"], (c1, c0)
