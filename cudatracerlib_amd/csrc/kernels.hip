@@ -65,11 +65,12 @@ __global__ __launch_bounds__(kBlock, ((LAYOUT && !ALPHA) ? CTL_INTERSECT_MIN_WAV
                                                        uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ,
                                                        unsigned long long* __restrict__ counts3) {
     __shared__ int lds_stack[(LAYOUT ? (kFlatLdsRows + 1) * kFlatStackInts : kLdsStack) * kBlock];   // flat: + one spare row that absorbs unused push slots
+    __shared__ uint16_t lds_dist[(LAYOUT && CTL_STACK_DIST >= 2) ? (kFlatLdsRows + 1) * kBlock : 1];
     __shared__ __attribute__((aligned(16))) float lds_top[LAYOUT ? kTopCacheFloats : 4];
     const uint32_t n = *n_ptr;
     trav_counts tc{ 0, 0, 0, 0, 0 };
     if (LAYOUT) fill_top_cache(S, lds_top);
-    if (LAYOUT) intersect_flat<ANY_HIT, COUNT, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, lds_top, tc);
+    if (LAYOUT) intersect_flat<ANY_HIT, COUNT, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, lds_top, tc, lds_dist);
     else intersect_persistent<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
     if (COUNT) {
         atomicAdd(&counts3[0], (unsigned long long)tc.n_inner); atomicAdd(&counts3[1], (unsigned long long)tc.n_tri); atomicAdd(&counts3[2], (unsigned long long)tc.n_inst);
@@ -86,13 +87,14 @@ __global__ __launch_bounds__(kBlock, ((LAYOUT && !ALPHA) ? CTL_INTERSECT_MIN_WAV
                                                             const float4* __restrict__ sro, const float4* __restrict__ srd, const uint32_t* __restrict__ sn_ptr,
                                                             uint32_t* __restrict__ swork, uint32_t* __restrict__ occ) {
     __shared__ int lds_stack[(LAYOUT ? (kFlatLdsRows + 1) * kFlatStackInts : kLdsStack) * kBlock];
+    __shared__ uint16_t lds_dist[(LAYOUT && CTL_STACK_DIST >= 2) ? (kFlatLdsRows + 1) * kBlock : 1];
     __shared__ __attribute__((aligned(16))) float lds_top[LAYOUT ? kTopCacheFloats : 4];
     const uint32_t n = *n_ptr, sn = *sn_ptr;
     trav_counts tc{ 0, 0, 0, 0, 0 };
     if (LAYOUT) {
         fill_top_cache(S, lds_top);
-        intersect_flat<false, false, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, nullptr, lds_stack, lds_top, tc);
-        intersect_flat<true, false, ALPHA, LAYOUT - 1>(S, sro, srd, sn, swork, nullptr, nullptr, occ, lds_stack, lds_top, tc);
+        intersect_flat<false, false, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, nullptr, lds_stack, lds_top, tc, lds_dist);
+        intersect_flat<true, false, ALPHA, LAYOUT - 1>(S, sro, srd, sn, swork, nullptr, nullptr, occ, lds_stack, lds_top, tc, lds_dist);
     } else {
         intersect_persistent<false, false, ALPHA>(S, ro, rd, n, work, hit, hit_node, nullptr, lds_stack, tc);
         intersect_persistent<true, false, ALPHA>(S, sro, srd, sn, swork, nullptr, nullptr, occ, lds_stack, tc);

@@ -89,30 +89,68 @@ __device__ int g_leaf_batch = 16;         // run the leaf phase once this many l
 #ifndef CTL_STACK_DIST
 #define CTL_STACK_DIST 0
 #endif
-#if CTL_STACK_DIST
+// CTL_STACK_DIST: 0 = links only (shipped); 1 = 8-byte LDS entries {link, entry distance}; 2 = the links as in 0 plus a second LDS array with the TOP 16 BITS of the entry distance
+// (truncation rounds a positive float down, so the stored distance never exceeds the true one and a cull stays conservative): 6 B per entry, kFlatLdsRows = 13 keeps seven workgroups per CU.
+struct stack_entry { int link; float dist; };
+constexpr int kStaleLink = 0x76543211;   // mode 3: "pop again" (neither an inner link — those lie below kSentinel — nor a leaf link nor kSentinel itself)
+#if CTL_STACK_DIST == 1
 typedef unsigned long long flat_stack_word;   // link in the low word, distance bits in the high word (a scalar type: it can live behind an address-space-qualified pointer)
 __device__ __forceinline__ flat_stack_word stack_word(int link, float dist) { return (unsigned long long)(uint32_t)link | ((unsigned long long)__float_as_uint(dist) << 32); }
-__device__ __forceinline__ bool stack_word_culled(const flat_stack_word& w, float ht) { return __uint_as_float((uint32_t)(w >> 32)) >= ht; }
-__device__ __forceinline__ int stack_word_link(const flat_stack_word& w) { return (int)(uint32_t)w; }
+__device__ __forceinline__ stack_entry stack_unpack(const flat_stack_word& w) { return stack_entry{ (int)(uint32_t)w, __uint_as_float((uint32_t)(w >> 32)) }; }
 #else
 typedef int flat_stack_word;
 __device__ __forceinline__ flat_stack_word stack_word(int link, float) { return link; }
-__device__ __forceinline__ bool stack_word_culled(const flat_stack_word&, float) { return false; }
-__device__ __forceinline__ int stack_word_link(const flat_stack_word& w) { return w; }
+__device__ __forceinline__ stack_entry stack_unpack(const flat_stack_word& w) { return stack_entry{ w, -__builtin_huge_valf() }; }
 #endif
-constexpr int kFlatStackInts = (int)(sizeof(flat_stack_word) / sizeof(int));   // ints of LDS per stack entry
+__device__ __forceinline__ bool stack_entry_culled(const stack_entry& e, float ht) { return CTL_STACK_DIST ? e.dist >= ht : false; }
+constexpr int kFlatStackInts = (int)(sizeof(flat_stack_word) / sizeof(int));   // ints of LDS per stack entry (link array)
 typedef __attribute__((address_space(3))) flat_stack_word flat_stack_lds_word;   // explicitly LDS: the pushes must compile to ds_write, not to generic flat stores
+typedef __attribute__((address_space(3))) uint16_t flat_stack_lds_dist;
 struct flat_stack {
     flat_stack_lds_word* lds;             // this lane's column, stride 256
     flat_stack_word ovf[kStackSize - kFlatLdsRows];
-    __device__ __forceinline__ flat_stack_word get(int i) const {
-        flat_stack_word w = lds[(i < kFlatLdsRows ? i : kFlatLdsRows) * 256];   // a ds_read whatever the depth (the spare row when the entry lives in scratch) ...
-        if (i >= kFlatLdsRows) w = ovf[i - kFlatLdsRows];                       // ... and the rare deep entry from scratch
-        return w;
+#if CTL_STACK_DIST >= 2
+    flat_stack_lds_dist* ldsd;            // this lane's column of the distance array, stride 256
+    uint16_t ovfd[kStackSize - kFlatLdsRows];
+#endif
+    __device__ __forceinline__ stack_entry get(int i, const bool wd = true) const {
+        const int row = i < kFlatLdsRows ? i : kFlatLdsRows;
+        flat_stack_word w = lds[row * 256];                                     // a ds_read whatever the depth (the spare row when the entry lives in scratch) ...
+#if CTL_STACK_DIST >= 2
+        uint32_t dh = 0xff80u; if (wd) dh = ldsd[row * 256];
+#endif
+        if (i >= kFlatLdsRows) {                                                // ... and the rare deep entry from scratch
+            w = ovf[i - kFlatLdsRows];
+#if CTL_STACK_DIST >= 2
+            if (wd) dh = ovfd[i - kFlatLdsRows];
+#endif
+        }
+        stack_entry e = stack_unpack(w);
+#if CTL_STACK_DIST >= 2
+        e.dist = __uint_as_float(dh << 16);
+#endif
+        return e;
     }
-    __device__ __forceinline__ void set(int i, flat_stack_word v) { if (i < kFlatLdsRows) lds[i * 256] = v; else ovf[i - kFlatLdsRows] = v; }
+    // store into LDS row `row` (the spare row kFlatLdsRows absorbs unused push slots)
+    __device__ __forceinline__ void put_row(int row, int link, float dist, const bool wd = true) {
+        lds[row * 256] = stack_word(link, dist);
+#if CTL_STACK_DIST >= 2
+        if (wd) ldsd[row * 256] = (uint16_t)(__float_as_uint(dist) >> 16);
+#endif
+    }
+    __device__ __forceinline__ void set(int i, int link, float dist, const bool wd = true) {
+        if (i < kFlatLdsRows) put_row(i, link, dist, wd);
+        else {
+            ovf[i - kFlatLdsRows] = stack_word(link, dist);
+#if CTL_STACK_DIST >= 2
+            if (wd) ovfd[i - kFlatLdsRows] = (uint16_t)(__float_as_uint(dist) >> 16);
+#endif
+        }
+    }
     // pop entries until one is worth visiting (the sentinel at the bottom carries -inf and always is)
-    __device__ __forceinline__ int pop(int& sp, float ht) const { flat_stack_word w; do { w = get(sp); sp--; } while (stack_word_culled(w, ht)); return stack_word_link(w); }
+    // mode 3: ONE pop; an entry that fell behind the hit comes back as kStaleLink and the lane pops again in the next iteration (no wave-wide loop of LDS round trips)
+    __device__ __forceinline__ int pop_once(int& sp, float ht, const bool wd = true) const { const stack_entry e = get(sp, wd); sp--; return (wd && stack_entry_culled(e, ht)) ? kStaleLink : e.link; }
+    __device__ __forceinline__ int pop(int& sp, float ht, const bool wd = true) const { stack_entry e; do { e = get(sp, wd); sp--; } while (wd && stack_entry_culled(e, ht)); return e.link; }
 };
 
 __device__ __forceinline__ float rcp_cull(float d) {   // slab tests only cull: the hardware reciprocal (1 ulp) of the guarded direction
@@ -348,14 +386,18 @@ __device__ __forceinline__ int node_step_f2(const float4* __restrict__ nodes, in
 // The whole intersect kernel body over the flattened structure: `n` rays (ro, rd) -> hit / hit_node (closest) and/or occ (any-hit flag).
 template <bool ANY_HIT, bool COUNT, bool ALPHA, int FMT>
 __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4* __restrict__ ro, const float4* __restrict__ rd, uint32_t n, uint32_t* __restrict__ work,
-                                               float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack_ints, const float* lds_top_floats, trav_counts& cnt) {
+                                               float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack_ints, const float* lds_top_floats, trav_counts& cnt, uint16_t* lds_dist = nullptr) {
     flat_stack_lds_word* lds_stack = (flat_stack_lds_word*)lds_stack_ints;
     lds_top_f4* lds_top = (lds_top_f4*)lds_top_floats;
     const uint32_t n_top = (FMT == kFmtQ4 && kTopCache) ? (uint32_t)S.flat_top_cached : 0u;
     const int lane = threadIdx.x & 63;
     const int refill_idle = g_refill_idle, leaf_batch = g_leaf_batch;
     const bool compact = S.flat_compact != 0;
+    constexpr bool kWithDist = CTL_STACK_DIST != 0 && !ANY_HIT;   // an any-hit ray ends at its first hit: no entry of its stack ever falls behind one
     flat_stack st; st.lds = lds_stack + threadIdx.x;
+#if CTL_STACK_DIST >= 2
+    st.ldsd = (flat_stack_lds_dist*)lds_dist + threadIdx.x;
+#endif
     bool has_ray = false;
     uint32_t ray_id = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, tmin = 0;
@@ -391,7 +433,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
                     R.idx = rcp_cull(dx); R.idy = rcp_cull(dy); R.idz = rcp_cull(dz);
                     R.oox = ox * R.idx; R.ooy = oy * R.idy; R.ooz = oz * R.idz;
                     ht = d.w;
-                    sp = 0; st.lds[0] = stack_word(kSentinel, -__builtin_huge_valf()); node = S.flat_root; pend = -1;
+                    sp = 0; st.put_row(0, kSentinel, -__builtin_huge_valf(), kWithDist); node = S.flat_root; pend = -1;
                 }
                 chunk_next += want < avail ? want : avail;
             }
@@ -399,8 +441,10 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
         if (__ballot(has_ray) == 0ull) { if (exhausted) break; continue; }
 
         // ---- a lane standing on a leaf with a free slot postpones it and goes on with the next stack entry
-        if (has_ray && node < 0 && pend < 0) {
-            pend = ~node; node = st.pop(sp, ht);
+        if (CTL_STACK_DIST == 3 && kWithDist) {
+            if (has_ray && ((node < 0 && pend < 0) || node == kStaleLink)) { if (node < 0) pend = ~node; node = st.pop_once(sp, ht, true); }
+        } else if (has_ray && node < 0 && pend < 0) {
+            pend = ~node; node = st.pop(sp, ht, kWithDist);
             if (CTL_PREFETCH_LEAF) pf_leaf = *(const uint32_t*)(S.flat_leaves + (size_t)(uint32_t)pend * 8);
         }
         const bool at_inner = has_ray && (unsigned)node < (unsigned)kSentinel;
@@ -429,7 +473,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
             if (FMT == kFmtQ4 && CTL_NODE_FETCH_QUAD) node_fetch_quad(nodes, node, at_inner, compact, W);
             if (at_inner) {
                 if (COUNT) { cnt.n_inner++; if (lane == (int)__builtin_ctzll(m_inner)) cnt.w_inner++; }
-                const flat_stack_word popped = st.get(sp);   // issued early: used when no child is entered
+                const stack_entry popped = st.get(sp, kWithDist);   // issued early: used when no child is entered
                 int c[4]; float dd[4]; int n_hit;
                 if (FMT == kFmtF4) n_hit = node_step_f4(nodes, node, R, tmin, ht, c, dd);
                 else if (FMT == kFmtQ4) {
@@ -448,23 +492,23 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
                     pend = ~c[0]; c[0] = c[1]; c[1] = c[2]; c[2] = c[3]; dd[0] = dd[1]; dd[1] = dd[2]; dd[2] = dd[3]; n_hit--;
                     if (CTL_PREFETCH_LEAF) pf_leaf = *(const uint32_t*)(S.flat_leaves + (size_t)(uint32_t)pend * 8);
                 }
-                node = n_hit ? c[0] : stack_word_link(popped);
+                node = n_hit ? c[0] : popped.link;
                 if (CTL_PREFETCH_NODE && (unsigned)node < (unsigned)kSentinel) pf_node = *(const uint32_t*)(nodes + (node & ~3));
                 const int top = sp + n_hit - 1;    // n_hit == 0: one entry popped
                 if (FMT == kFmtF2) {
-                    if (n_hit == 2) st.set(top, stack_word(c[1], dd[1]));
+                    if (n_hit == 2) st.set(top, c[1], dd[1], kWithDist);
                 } else if (top < kFlatLdsRows) {   // common case: unconditional LDS stores, unused ones into the spare row
-                    st.lds[(n_hit >= 2 ? top : kFlatLdsRows) * 256] = stack_word(c[1], dd[1]);
-                    st.lds[(n_hit >= 3 ? top - 1 : kFlatLdsRows) * 256] = stack_word(c[2], dd[2]);
-                    st.lds[(n_hit >= 4 ? top - 2 : kFlatLdsRows) * 256] = stack_word(c[3], dd[3]);
+                    st.put_row(n_hit >= 2 ? top : kFlatLdsRows, c[1], dd[1], kWithDist);
+                    st.put_row(n_hit >= 3 ? top - 1 : kFlatLdsRows, c[2], dd[2], kWithDist);
+                    st.put_row(n_hit >= 4 ? top - 2 : kFlatLdsRows, c[3], dd[3], kWithDist);
                 } else {
-                    if (n_hit >= 4) st.set(top - 2, stack_word(c[3], dd[3]));
-                    if (n_hit >= 3) st.set(top - 1, stack_word(c[2], dd[2]));
-                    if (n_hit >= 2) st.set(top, stack_word(c[1], dd[1]));
+                    if (n_hit >= 4) st.set(top - 2, c[3], dd[3], kWithDist);
+                    if (n_hit >= 3) st.set(top - 1, c[2], dd[2], kWithDist);
+                    if (n_hit >= 2) st.set(top, c[1], dd[1], kWithDist);
                 }
                 sp = top;
                 if (COUNT && sp > sp_max) sp_max = sp;
-                if (n_hit == 0 && stack_word_culled(popped, ht)) node = st.pop(sp, ht);   // the popped child lies behind the hit found since it was pushed: next one
+                if (kWithDist && n_hit == 0 && stack_entry_culled(popped, ht)) node = CTL_STACK_DIST == 3 ? kStaleLink : st.pop(sp, ht, kWithDist);   // the popped child lies behind the hit found since it was pushed: next one
             }
         }
         if (has_ray && !finished) finished = (node == kSentinel) && pend < 0;
