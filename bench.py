@@ -384,6 +384,7 @@ def main():
         hbm_meas = round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None
         roof = {"bound": "hbm", "kernel": "k_intersect<closest>" if not fused_launches else "k_intersect_pair (closest hits of bounce d + occlusion of bounce d-1 in one persistent launch)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(frac, 4), "traffic": traffic,
+                "frac_note": "achieved = ALGORITHMIC bytes (SURVEY 8d: 48 + 64 N_inner + 52 N_tri per ray) / launch time; it can pass 1 because L2 and the Infinity Cache serve about half of those records; hbm_frac_measured (PMC traffic / time / peak) is the HBM roofline fraction",
                 "hbm_frac_measured": hbm_meas, "saturated": bool(hbm_meas is not None and hbm_meas >= 0.8),   # saturated: the MEASURED HBM-side traffic reaches 80 % of peak; `frac` counts L2-served bytes too
                 "l2_hit_rate": cal.get("l2_hit_rate") if cal else None, "traffic_profile": cal.get("tag") if cal else None, "workload_key": wl_key, "kernel_build": KERNEL_BUILD,
                 "bytes_per_ray": round(bytes_per_launch / max(1.0, rays_per_launch), 1), "bytes_per_path_ray": round(per_ray_closest, 1), "bytes_per_shadow_ray": round(per_ray_any, 1),
