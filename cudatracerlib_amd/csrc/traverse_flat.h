@@ -89,6 +89,9 @@ __device__ int g_leaf_batch = 16;         // run the leaf phase once this many l
 #ifndef CTL_STACK_DIST
 #define CTL_STACK_DIST 0
 #endif
+#ifndef CTL_EXTRA_VALU
+#define CTL_EXTRA_VALU 0   // pairs of extra VALU instructions per node step (a measurement: what does the kernel's time do when its instruction count moves?)
+#endif
 // CTL_STACK_DIST: 0 = links only (shipped); 1 = 8-byte LDS entries {link, entry distance}; 2 = the links as in 0 plus a second LDS array with the TOP 16 BITS of the entry distance
 // (truncation rounds a positive float down, so the stored distance never exceeds the true one and a cull stays conservative): 6 B per entry, kFlatLdsRows = 13 keeps seven workgroups per CU.
 struct stack_entry { int link; float dist; };
@@ -365,6 +368,12 @@ __device__ __forceinline__ int node_step_q4(const node_words& W, int node, const
         dd[k] = (cmax >= cmin) ? cmin : inf;   // no "child exists" test: a missing child's box is inverted (flatten.cpp) and is never entered
     }
     CTL_CSWAP_PAIR(0, 1) CTL_CSWAP_PAIR(2, 3) CTL_CSWAP_PAIR(0, 2) CTL_CSWAP_PAIR(1, 3) CTL_CSWAP_PAIR(1, 2)
+#if CTL_EXTRA_VALU   // measurement: N more integer VALU instructions per node step, of the kind the link decode is made of (v_bfe / v_add / v_and on a value nothing else waits for)
+    { uint32_t x = meta;
+#pragma unroll
+      for (int e = 0; e < CTL_EXTRA_VALU; e++) asm volatile("v_bfe_u32 %0, %0, 1, 31\n\tv_add_u32 %0, %0, %1" : "+v"(x) : "v"(meta));
+      asm volatile("" :: "v"(x)); }
+#endif
     return dd[3] < inf ? 4 : (dd[2] < inf ? 3 : (dd[1] < inf ? 2 : (dd[0] < inf ? 1 : 0)));
 }
 
