@@ -6,9 +6,11 @@
 // both look at the winning triangle; the world-space tree only culls.  Rays that hit two triangles at exactly the same t may
 // report either (the visiting order differs), as between any two BVHs.
 //
-// Execution model (measured on MI355X, profiles/r02*, r03*): the kernel is bound by the NUMBER of records it gathers — per-lane L1 accesses (one
-// 16-B load of one lane = one L1 cycle: ~610 G lane-loads/s over the chip, tools/gather_probe.hip) and 128-B lines out of HBM (~58 G/s) — with
-// 15-20 % of its VALU issue slots unused (profiles/r02r_valu_headroom_ab.log).  So the design spends a little arithmetic to fetch less:
+// Execution model (measured on MI355X, profiles/r02*, r03*).  A node step ends in ONE wait for the slowest of the wave's ~54 active lanes, and with a sixth of the
+// node fetches going past the L2 practically every step waits for a memory-side line: an iteration is a memory round trip under load plus ~900 issue cycles, seven waves deep.  At
+// the end of round 3 the kernel sits at the knee between the two: 8 % fewer VALU instructions bought 1.7 %, 11 % more cost 2.6 %, 22 % more cost 16 % (CTL_EXTRA_VALU) — and taking
+// whole node visits away pays one for one.  Per-lane L1 accesses (one 16-B load of one lane = one L1 cycle, tools/gather_probe.hip) and HBM-side lines (0.46 of peak) are both below
+// their ceilings.  So the design spends arithmetic where it removes fetches or visits, and nowhere else:
 //  * lane refill as in traverse.h (a wave claims rays from a device cursor, idle lanes are refilled together);
 //  * node steps and leaf steps are separate wave-wide phases.  A lane that reaches a leaf POSTPONES it (one pending leaf per
 //    lane) and keeps descending the tree speculatively; the wave runs the leaf code only once enough lanes hold a pending leaf
