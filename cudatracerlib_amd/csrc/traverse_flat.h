@@ -402,6 +402,8 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
     lds_top_f4* lds_top = (lds_top_f4*)lds_top_floats;
     const uint32_t n_top = (FMT == kFmtQ4 && kTopCache) ? (uint32_t)S.flat_top_cached : 0u;
     const int lane = threadIdx.x & 63;
+    __shared__ unsigned int s_hist[COUNT ? kStackSize : 1];   // counting kernels: stack-depth histogram of this workgroup's rays, added to g_stack_hist at the end
+    if (COUNT) { for (int i = threadIdx.x; i < kStackSize; i += blockDim.x) s_hist[i] = 0u; __syncthreads(); }
     const int refill_idle = g_refill_idle, leaf_batch = g_leaf_batch;
     const bool compact = S.flat_compact != 0;
     constexpr bool kWithDist = CTL_STACK_DIST != 0 && !ANY_HIT;   // an any-hit ray ends at its first hit: no entry of its stack ever falls behind one
@@ -527,10 +529,11 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
             const uint32_t id = ray_id & 0x7fffffffu; const bool found = (ray_id >> 31) != 0u;
             if (ANY_HIT && occ) occ[id] = found ? 1u : 0u;
             if (hit && !found) { hit[id] = make_float4(ht, 0.0f, 0.0f, __int_as_float(-1)); hit_node[id] = -1; }   // a found hit wrote its record when it was accepted
-            if (COUNT) { atomicAdd(&g_stack_hist[sp_max < kStackSize ? sp_max : kStackSize - 1], 1ull); sp_max = 0; }
+            if (COUNT) { atomicAdd(&s_hist[sp_max < kStackSize ? sp_max : kStackSize - 1], 1u); sp_max = 0; }   // the workgroup's own histogram in LDS: one global atomic per ray on two dozen addresses made the counting kernels 15 x slower than the timed ones
             has_ray = false; node = kSentinel; pend = -1;
         }
     }
+    if (COUNT) { __syncthreads(); for (int i = threadIdx.x; i < kStackSize; i += blockDim.x) if (s_hist[i]) atomicAdd(&g_stack_hist[i], (unsigned long long)s_hist[i]); }
 }
 
 // Single-ray form for the megakernel plugin (one lane walks a whole path): same node steps, same entry test.  The stack's first kSingleLdsRows entries live in LDS
