@@ -93,4 +93,18 @@ __device__ __forceinline__ void add_sample(ctl_pixel_data* img, uint32_t W, uint
     atomicAdd(&r->rgb[0], L.x); atomicAdd(&r->rgb[1], L.y); atomicAdd(&r->rgb[2], L.z); atomicAdd(&r->weight_sum, 1.0f);
 }
 
+// AddSample of a finished path of pass `pass_b` of the batch whose own pixel is `pixel` (kernels.h pass_params::stage).  pX = pixel + jitter rounds into the NEXT pixel once in ~10^4
+// samples (1919 + 0.99999994f is 1920.0f) — as in the reference; such a sample is added atomically, it is not the only one its landing pixel gets in this pass.
+template <class PARAMS>
+__device__ __forceinline__ void add_sample_ordered(const PARAMS& P, ctl_pixel_data* img, uint32_t pixel, uint32_t pass_b, float sx, float sy, f3 L) {
+    if (!P.stage) { add_sample(img, P.width, P.height, sx, sy, L); return; }
+    L = f3(max2(0.0f, L.x), max2(0.0f, L.y), max2(0.0f, L.z));
+    const int x = (int)floorf(sx), y = (int)floorf(sy);
+    const bool bad = !(isfinite(L.x) && isfinite(L.y) && isfinite(L.z));
+    if (x < 0 || x >= (int)P.width || y < 0 || y >= (int)P.height || bad) return;
+    const uint32_t idx = (uint32_t)y * P.width + (uint32_t)x;
+    if (idx == pixel) P.stage[(size_t)pass_b * P.stage_stride + idx] = make_float4(L.x, L.y, L.z, 1.0f);
+    else { ctl_pixel_data* r = img + idx; atomicAdd(&r->rgb[0], L.x); atomicAdd(&r->rgb[1], L.y); atomicAdd(&r->rgb[2], L.z); atomicAdd(&r->weight_sum, 1.0f); }
+}
+
 } // namespace ctl

@@ -21,7 +21,7 @@ constexpr uint32_t kNoShadow = 0xffffffffu;
 struct final_soa {    // terminated paths that still wait for a shadow ray
     float4* rad;      // cl.rgb, shadow-ray index
     float4* dir;      // directF.rgb, -
-    float2* px;
+    float4* px;       // film sample position pX.xy, pixel index (bits), pass-in-batch (bits)
 };
 
 struct wave_queues {
@@ -56,7 +56,11 @@ struct pass_params {
     int wavefront_rules;                 // pathIterateKernel's own path rules (PathSemantics = Wavefront): selects the *_wf shade kernels
     int u16_bary;                        // hit barycentrics through the traversal result's 16-bit pair (U16Barycentrics)
     float* debug_out; uint32_t debug_x, debug_y;   // TracerBase::Debug (Kernel/Tracer.h:119-123): k_path_trace follows ONE path from the centre-less pixel position (x, y) and writes its radiance here
-    float* depth_buffer; uint32_t depth_w, depth_h; float depth_near, depth_far;   // IDepthTracer::setDepthBuffer (Kernel/Tracer.h:16-57), nullptr = none
+    float* depth_buffer; uint32_t depth_w, depth_h; float depth_near, depth_far;   // IDepthTracer::setDepthBuffer (Kernel/Tracer.h:16-57), nullptr = none    // Ordered accumulation.  Image::AddSample is four float atomics per finished path; a batch holds B passes of every pixel, so they collide on the same 28 bytes and
+    // cost 3 % of the whole job — and they add in whatever order the hardware serves them.  With `stage` set, a finished path stores its sample (rgb, weight 1) at
+    // stage[pass-in-batch][pixel] with one plain store (one path per pixel and pass: no two writers), and k_resolve_stage adds the batch to the frame pass by pass, in pass order — the order in which
+    // the reference's one-pass-at-a-time loop adds them.  nullptr: atomics (block samplers hand out 0 / 1 / 2 samples per pixel; the megakernel plugin).
+    float4* stage; size_t stage_stride;
 };
 
 struct launch_ctx { hipStream_t stream; int grid_blocks; bool alpha_test = false; };   // alpha_test: intersect kernels run Material::AlphaTest on candidate hits
@@ -82,6 +86,7 @@ void launch_shade_full(const launch_ctx& lc, const dev_scene& S, const wave_queu
 void launch_shade_basic_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_full_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_finalize(const launch_ctx& lc, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_resolve_stage(const launch_ctx& lc, float4* stage, size_t stride, uint32_t n_passes, ctl_pixel_data* image);   // frame += the staged samples of a batch, pass by pass; clears the stage
 int flat_top_cache_nodes();   // nodes at the head of the flattened node array that the traversal workgroups keep in LDS (traverse_flat.h kTopCache)
 void launch_accumulate_stats(const launch_ctx& lc, const wave_queues& Q, int max_depth);
 void launch_apply_pipeline(const launch_ctx& lc, const ctl_pixel_data* image, uint32_t n, float splat_scale, uint32_t* rgbcol_out);

@@ -108,11 +108,28 @@ __global__ __launch_bounds__(kBlock) void k_finalize(wave_queues Q, pass_params 
     const uint32_t n = Q.counts[depth * 4 + 2];
     const uint32_t* occ = Q.sh_occ[depth & 1];
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const float4 rad = Q.fin.rad[i], dir = Q.fin.dir[i]; const float2 px = Q.fin.px[i];
+        const float4 rad = Q.fin.rad[i], dir = Q.fin.dir[i], px = Q.fin.px[i];
         f3 cl(rad.x, rad.y, rad.z);
         if (!occ[__float_as_uint(rad.w)]) cl = cl + f3(dir.x, dir.y, dir.z);
-        add_sample(image, P.width, P.height, px.x, px.y, cl);
+        add_sample_ordered(P, image, __float_as_uint(px.z), __float_as_uint(px.w), px.x, px.y, cl);
     }
+}
+
+// frame += the staged samples of a batch (pass_params::stage), pass by pass in pass order; the stage is left cleared for the next batch.  One lane = one pixel; the n_passes
+// reads of a lane are n_passes coalesced streams.
+__global__ __launch_bounds__(256) void k_resolve_stage(float4* __restrict__ stage, size_t stride, uint32_t n_passes, ctl_pixel_data* __restrict__ image) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= stride) return;
+    ctl_pixel_data* r = image + i;
+    float a = r->rgb[0], b = r->rgb[1], c = r->rgb[2], w = r->weight_sum; bool any = false;
+    for (uint32_t p = 0; p < n_passes; p++) {
+        const float4 v = stage[(size_t)p * stride + i];
+        if (v.w != 0.0f) { a += v.x; b += v.y; c += v.z; w += v.w; any = true; stage[(size_t)p * stride + i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+    }
+    if (any) { r->rgb[0] = a; r->rgb[1] = b; r->rgb[2] = c; r->weight_sum = w; }
+}
+void launch_resolve_stage(const launch_ctx& lc, float4* stage, size_t stride, uint32_t n_passes, ctl_pixel_data* image) {
+    hipLaunchKernelGGL(k_resolve_stage, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, lc.stream, stage, stride, n_passes, image);
 }
 
 // rays of a pass = sum over bounces of (path rays + shadow rays)  (Kernel/TraceHelper.cu:176,745)

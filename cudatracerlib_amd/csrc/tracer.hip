@@ -558,6 +558,7 @@ WavefrontPathTracer::WavefrontPathTracer() {
     m_sParameters.addEnum("PathSemantics", 0, { "PathTrace", "Wavefront" });
     // build-specific: hit barycentrics through the 16-bit pair of the reference's traversal result (Kernel/TraceHelper.cu:722-731); off = full floats (single-ray traceRay)
     m_sParameters.addBool("U16Barycentrics", false);
+    m_sParameters.addBool("OrderedAccumulation", true);   // build-specific: finished paths are staged per (pass, pixel) and added to the frame in pass order (kernels.h pass_params::stage); false = four float atomics per path as Image::AddSample does
     int dev = 0; hipDeviceProp_t prop; CTL_HIP(hipGetDevice(&dev)); CTL_HIP(hipGetDeviceProperties(&prop, dev));
     grid_blocks = prop.multiProcessorCount * 8;   // 8 x 256-thread workgroups per CU = 32 waves/CU
 }
@@ -576,11 +577,11 @@ void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
         Q.sh_o[b] = new_f4(capacity); Q.sh_d[b] = new_f4(capacity); occ_[b].alloc(capacity); Q.sh_occ[b] = occ_[b].p;
     }
     Q.hit = new_f4(capacity); hit_node_.alloc(capacity); Q.hit_node = hit_node_.p;
-    Q.fin.rad = new_f4(capacity); Q.fin.dir = new_f4(capacity); px_[2].alloc(capacity); Q.fin.px = px_[2].p;
+    Q.fin.rad = new_f4(capacity); Q.fin.dir = new_f4(capacity); Q.fin.px = new_f4(capacity);
     stats_.alloc(14); Q.stats = stats_.p; CTL_HIP(hipMemset(stats_.p, 0, 14 * sizeof(unsigned long long)));
     Q.capacity = capacity;
     order_.alloc(capacity); Q.order = order_.p; mat_key_.alloc(capacity); Q.mat_key = mat_key_.p;
-    counts_.free(); work_.free(); mat_counts_.free();
+    counts_.free(); work_.free(); mat_counts_.free(); stage_.free();
 }
 
 // stats: [0] path rays, [1] shadow rays, [2..6] closest-hit traversal counts, [7..11] any-hit traversal counts
@@ -631,6 +632,13 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     P.block_counts = pass_block_counts_; P.max_block_count = pass_max_block_count_;
     P.wavefront_rules = m_sParameters.getValue("PathSemantics") == 1 ? 1 : 0; P.u16_bary = m_sParameters.getValue("U16Barycentrics") != 0 ? 1 : 0;
     P.depth_buffer = depth_buffer_; P.depth_w = depth_w_; P.depth_h = depth_h_; P.depth_near = m_pScene->near_depth; P.depth_far = m_pScene->far_depth;
+    // ordered accumulation (kernels.h pass_params::stage): one staged sample per (pass of the batch, pixel), added to the frame in pass order after the last bounce
+    P.stage = nullptr; P.stage_stride = (size_t)w * h;
+    if (m_sParameters.getValue("OrderedAccumulation") != 0 && !pass_block_counts_) {
+        const size_t need = P.stage_stride * n_batch;
+        if (stage_.n < need) { stage_.alloc(need); CTL_HIP(hipMemsetAsync(stage_.p, 0, need * sizeof(float4), stream)); }
+        P.stage = stage_.p;
+    }
     if (pass_block_counts_ && pass_paths_ > capacity) throw std::runtime_error("ray queue overflow: the block sampler asks for more samples in one pass than the queues hold (DoubleRayBuffer.h:86-89)");
     if (P.sort_materials) CTL_HIP(hipMemsetAsync(mat_counts_.p, 0, n_mat * sizeof(uint32_t), stream));
     CTL_HIP(hipMemsetAsync(counts_.p, 0, n_counts * sizeof(uint32_t), stream));
@@ -674,6 +682,7 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
         shadow_pass(maxPathLength);
         timer.begin(stream, 2); launch_finalize(lc, Q, P, maxPathLength, I->device()); timer.end(stream);
     }
+    if (P.stage) { timer.begin(stream, 2); launch_resolve_stage(lc, P.stage, P.stage_stride, n_batch, I->device()); timer.end(stream); }
     launch_accumulate_stats(lc, Q, maxPathLength);
 }
 

@@ -631,3 +631,39 @@ def test_debug_pixel_trace_single_ray_and_depth_buffer(gpu, orc):
         assert abs(depth[y, x] - want_z) < 0.05, (x, y, depth[y, x], want_z)      # (the pass's ray is jittered inside the pixel: same surface, nearly the same depth)
     with pytest.raises(gpu.CtlError):
         tr.setDepthBuffer(w, h)                                  # the megakernel PathTracer is not an IDepthTracer
+
+
+def test_ordered_accumulation_is_independent_of_the_batching(gpu, orc):
+    """OrderedAccumulation (default): a finished path stores its sample per (pass of the batch, pixel) and the batch is added to the frame pass by pass — in the order in which
+    Image::AddSample is called by the reference's one-pass-at-a-time loop — instead of four float atomics per path in whatever order the hardware serves them.  So the frame does
+    not depend on how the passes are batched (12 passes as 12 x 1, 3 x 4 and 1 x 12: bit-identical) nor on the run, and it equals the oracle's pass-by-pass sum to the bit wherever
+    the samples themselves do; with the atomics (OrderedAccumulation = false) the same samples arrive, their sum is equal only to round-off."""
+    w, h, n = 64, 64, 12
+    sc = scenes.cornell_box(w, h, glass_sphere=True)
+    scene = gpu.Scene(sc.desc, flatten=True)
+
+    def render(batch, ordered=True):
+        tr = gpu.WavefrontPathTracer(); p = tr.getParameters(); p.setValue("MaxPathLength", 5); p.setValue("PassBatch", batch); p.setValue("OrderedAccumulation", ordered)
+        tr.Resize(w, h); tr.InitializeScene(scene)
+        img = gpu.Image(w, h)
+        tr.DoPasses(img, n, new_trace=True)     # the tracer's own sampling-sequence generator: the same stream for every tracer
+        return img.getPixelData(), tr.stats().rays_total
+
+    base, rays = render(1)
+    assert (base[..., 6] == n).all()
+    for batch in (4, 12, 1):
+        got, r = render(batch)
+        assert r == rays and np.array_equal(got.view(np.uint32), base.view(np.uint32)), batch
+    atom, r = render(12, ordered=False)
+    assert r == rays and np.array_equal(atom[..., 6], base[..., 6])
+    assert np.allclose(atom[..., :3], base[..., :3], rtol=1e-5, atol=1e-6)
+    # the oracle adds pass after pass: with one pass per launch and the oracle's tables the frames agree to the bit in (almost) every pixel
+    tables = orc.sequence_tables(3)
+    want, _ = orc.render(sc.desc, w, h, n_passes=3, tables=tables, max_path_length=5, flat=None)
+    tr = gpu.WavefrontPathTracer(); tr.getParameters().setValue("MaxPathLength", 5)
+    tr.Resize(w, h); tr.InitializeScene(scene)
+    img = gpu.Image(w, h)
+    for k in range(3):
+        tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
+    got = img.getPixelData()
+    assert (got[..., :3].view(np.uint32) == want[..., :3].view(np.uint32)).all(axis=2).mean() > 0.98
