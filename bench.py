@@ -207,6 +207,7 @@ def main():
     ap.add_argument("--tracer-param", action="append", default=[], metavar="KEY=VALUE")
     ap.add_argument("--no-cache", action="store_true", help="do not use the compiled-geometry cache ($CTL_CACHE_DIR, default $TMPDIR/ctl_amd_cache)")
     ap.add_argument("--flatten", type=int, default=1, help="traverse one world-space BVH over all instanced triangles (64 B of HBM per triangle)")
+    ap.add_argument("--flat-format", default=None, choices=["q4", "q8"], help="node format of the flattened BVH (default: the library's)")
     ap.add_argument("--dump-frame", default=None, metavar="FILE.npy", help="rank 0 saves the reduced PixelData frame (h, w, 7) after the timed region (tests compare N-rank and 1-rank frames)")
     ap.add_argument("--launch-only", action="store_true", help="N-rank rendezvous plumbing only (no device): spawn, gloo group, id broadcast, reductions; prints n_gpus")
     args = ap.parse_args()
@@ -250,7 +251,7 @@ def main():
         dist.barrier()                      # rank 0 compiles and fills the cache first
     sc, scene_source = build_scene(args, rank, dist.barrier if (world > 1 and args.via_loader) else None)
     desc = sc.desc
-    scene = ctl.Scene(desc, flatten=bool(args.flatten))
+    scene = ctl.Scene(desc, flatten=bool(args.flatten), flat_format=args.flat_format)
     if world > 1 and rank == 0 and not args.no_cache:
         dist.barrier()
     t_build = time.perf_counter() - t_build
@@ -348,7 +349,7 @@ def main():
         cpu, oc = None, None
         if world == 1 and not args.no_cpu_baseline:
             from cudatracerlib_amd import api as _api
-            fb = _api.FlatBvh(desc, _api.FLAT_Q4) if args.flatten else None
+            fb = _api.FlatBvh(desc, _api.FLAT_FORMATS[args.flat_format or _api.DEFAULT_FLAT_FORMAT]) if args.flatten else None
             cpu, oc = cpu_baseline(desc, args, fb.desc if fb is not None else None)
         # algorithmic bytes per ray from the CPU restatement in counting mode over the same BVH; the GPU's own counters when the oracle leg is off
         if oc and oc.get("path_rays"):

@@ -184,8 +184,9 @@ def set_cache_dir(directory):
     _check(lib.ctl_set_cache_dir(None if directory is None else str(directory).encode()))
 
 
-FLAT_Q4, FLAT_F4, FLAT_F2 = 0, 1, 2          # CTL_FLAT_* node formats of the flattened BVH
-FLAT_FORMATS = {"q4": FLAT_Q4, "f4": FLAT_F4, "f2": FLAT_F2}
+FLAT_Q4, FLAT_F4, FLAT_F2, FLAT_Q8 = 0, 1, 2, 3          # CTL_FLAT_* node formats of the flattened BVH
+FLAT_FORMATS = {"q4": FLAT_Q4, "f4": FLAT_F4, "f2": FLAT_F2, "q8": FLAT_Q8}
+DEFAULT_FLAT_FORMAT = "q4"                                 # what Scene(desc, flatten=True) builds when no format is named (csrc/flatten.cpp default_flat_format)
 
 
 def flatten_probe(desc, format=FLAT_Q4):
@@ -215,8 +216,9 @@ class FlatBvh:
         return np.ctypeslib.as_array(C.cast(self.desc.nodes, C.POINTER(C.c_uint32)), shape=(n,)).reshape(self.desc.n_nodes, -1)
 
     def child_links(self):
-        """Q4: the explicit links, (n_nodes, 4) int32"""
-        return np.ctypeslib.as_array(C.cast(self.desc.child_links, C.POINTER(C.c_int32)), shape=(self.desc.n_nodes * 4,)).reshape(-1, 4)
+        """the explicit links: Q4 (n_nodes, 4) int32, Q8 (n_nodes, 8) in slot order"""
+        w = 8 if self.desc.format == FLAT_Q8 else 4
+        return np.ctypeslib.as_array(C.cast(self.desc.child_links, C.POINTER(C.c_int32)), shape=(self.desc.n_nodes * w,)).reshape(-1, w)
 
     def leaves(self):
         return np.ctypeslib.as_array(C.cast(self.desc.leaves, C.POINTER(C.c_uint32)), shape=(self.desc.n_leaves * 32,)).reshape(-1, 32)

@@ -5,7 +5,7 @@
 
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the tree.
 """
-import os, subprocess, sys, glob
+import hashlib, os, subprocess, sys, glob, tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -18,22 +18,37 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=o
 KNOBS_OUT = os.path.join(HERE, "libctl_knobs.so")   # the same library built -DCTL_MEASUREMENT_KNOBS (csrc/knobs.h): tools/exp.sh, tools/*probe*, the tests of builder options
 
 
-def stale(target=None):
+def _flag_key(defines=()):
+    """what besides the sources decides the binary: the -D set and $CTL_BUILD_EXTRA_FLAGS"""
+    return hashlib.sha256(("\0".join(sorted(defines)) + "\1" + os.environ.get("CTL_BUILD_EXTRA_FLAGS", "")).encode()).hexdigest()[:16]
+
+
+def _object_dir(out):
+    """the product's objects stay in-tree (build/, git- and gpurun-ignored); a variant's objects go under $TMPDIR — only its .so travels to the GPU box"""
+    if out is None:
+        return os.path.join(HERE, "build")
+    return os.path.join(os.environ.get("TMPDIR") or tempfile.gettempdir(), "ctl_build_" + os.path.splitext(os.path.basename(out))[0])
+
+
+def stale(target=None, defines=()):
     target = target or OUT
     if not os.path.exists(target):
         return True
+    key = os.path.join(_object_dir(None if target == OUT else target), "flags.key")
+    if not os.path.exists(key) or open(key).read().strip() != _flag_key(defines):
+        return True   # built with another -D / flag set (or by an older build.py): an A/B run must never compare a binary with itself
     t = os.path.getmtime(target)
-    deps = glob.glob(os.path.join(CSRC, "*")) + [os.path.join(HERE, "..", "include", "ctl_amd.h"), __file__]
+    deps = glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(CSRC, "experiments", "*")) + [os.path.join(HERE, "..", "include", "ctl_amd.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=True, out=None, defines=()):
     """out / defines: a variant build (tools/build_variant.sh) with extra -D flags into its own object directory"""
-    if not force and not stale(out):
+    if not force and not stale(out, defines):
         return out or OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    bdir = os.path.join(HERE, "build" if out is None else "build_" + os.path.splitext(os.path.basename(out))[0])
+    bdir = _object_dir(out)
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for s in SRCS:
@@ -51,6 +66,8 @@ def build(force=False, verbose=True, out=None, defines=()):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(os.path.join(bdir, "flags.key"), "w") as f:
+        f.write(_flag_key(defines) + "\n")
     return target
 
 

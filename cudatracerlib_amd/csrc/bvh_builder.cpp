@@ -348,6 +348,76 @@ struct dp_collapser {
 };
 } // namespace
 
+namespace {
+struct collapser8 {
+    const bvh_result& R; std::vector<wide8_node>& out; int max_depth = 0;
+    struct item { int code; aabb box; };
+    // children of BVH2 node `code2` opened greedily into at most eight items
+    int gather(int code2, item* it) const {
+        int n = 0;
+        const ctl_bvh_node& root = R.nodes[code2 / 4];
+        if (root.child0 != 0x76543210) it[n++] = { root.child0, node_child_box(root, 0) };
+        if (root.child1 != 0x76543210) it[n++] = { root.child1, node_child_box(root, 1) };
+        while (n < 8) {
+            int best = -1; float ba = -1.0f;
+            for (int i = 0; i < n; i++) if (it[i].code >= 0) { const float a = it[i].box.area(); if (a > ba) { ba = a; best = i; } }
+            if (best < 0) break;
+            const ctl_bvh_node& c = R.nodes[it[best].code / 4];
+            const bool has0 = c.child0 != 0x76543210, has1 = c.child1 != 0x76543210;
+            if (has0 && has1) { it[n++] = { c.child1, node_child_box(c, 1) }; it[best] = { c.child0, node_child_box(c, 0) }; }
+            else if (has0) it[best] = { c.child0, node_child_box(c, 0) };
+            else if (has1) it[best] = { c.child1, node_child_box(c, 1) };
+            else break;
+        }
+        return n;
+    }
+    // iterative (explicit stack): the wide tree of a degenerate scene can be as deep as the BVH2
+    void run(const aabb& root_box) {
+        struct todo { int code2, me, depth; };
+        std::vector<todo> stack;
+        out.emplace_back(); out[0].box = root_box;
+        stack.push_back({ 0, 0, 0 });
+        while (!stack.empty()) {
+            const todo t = stack.back(); stack.pop_back();
+            if (t.depth > max_depth) max_depth = t.depth;
+            item it[8]; const int n = gather(t.code2, it);
+            // octant-ordered slots: greedy matching on cost(child, slot) = sign(slot) . (centroid(child) - centroid(node))
+            float cen[3]; for (int k = 0; k < 3; k++) cen[k] = 0.5f * (out[t.me].box.lo[k] + out[t.me].box.hi[k]);
+            float cost[8][8];
+            for (int c = 0; c < n; c++) for (int s = 0; s < 8; s++) {
+                float v = 0; for (int k = 0; k < 3; k++) { const float d = 0.5f * (it[c].box.lo[k] + it[c].box.hi[k]) - cen[k]; v += ((s >> k) & 1) ? d : -d; }
+                cost[c][s] = v;
+            }
+            int slot_of[8]; bool cu[8] = {}, su[8] = {};
+            for (int r = 0; r < n; r++) {
+                int bc = -1, bs = -1; float bv = -3.402823466e+38f;
+                for (int c = 0; c < n; c++) if (!cu[c]) for (int s = 0; s < 8; s++) if (!su[s] && cost[c][s] > bv) { bv = cost[c][s]; bc = c; bs = s; }
+                cu[bc] = true; su[bs] = true; slot_of[bc] = bs;
+            }
+            wide8_node w; w.box = out[t.me].box;
+            for (int s = 0; s < 8; s++) { w.child[s] = 0x76543210; w.cbox[s].reset(); }
+            for (int c = 0; c < n; c++) {
+                const int s = slot_of[c];
+                w.cbox[s] = it[c].box;
+                if (it[c].code < 0) w.child[s] = it[c].code;
+                else { const int k = (int)out.size(); out.emplace_back(); out[k].box = it[c].box; w.child[s] = k; stack.push_back({ it[c].code, k, t.depth + 1 }); }
+            }
+            out[t.me] = w;
+        }
+    }
+};
+}  // namespace
+
+void collapse_bvh8(const bvh_result& R, std::vector<wide8_node>& out, int& max_depth) {
+    out.clear(); max_depth = 0;
+    if (R.nodes.empty()) return;
+    aabb box; box.reset();
+    box.grow(node_child_box(R.nodes[0], 0)); if (R.nodes[0].child1 != 0x76543210) box.grow(node_child_box(R.nodes[0], 1));
+    collapser8 C{ R, out };
+    C.run(box);
+    max_depth = C.max_depth;
+}
+
 void collapse_bvh4(bvh_result& R, std::vector<wide4_node>& out, int& max_depth, int mode, float node_cost, int max_leaf) {
     out.clear(); max_depth = 0;
     if (R.nodes.empty()) return;

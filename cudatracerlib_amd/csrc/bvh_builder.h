@@ -45,4 +45,9 @@ namespace ctl {
 // child >= 0: index into the wide-node array; child < 0: ~firstLeafEntry (entries of R.leaf_prims up to the next leaf_last flag); n = children used.
 struct wide4_node { aabb box; aabb cbox[4]; int child[4]; int n; };
 void collapse_bvh4(bvh_result& R, std::vector<wide4_node>& out, int& max_depth, int mode = 1, float node_cost = 0.75f, int max_leaf = 4);
+// 8-wide node for the Q8 format (flat8.h): greedy collapse (open the inner child with the largest surface area until eight slots are used), then the children are
+// placed into OCTANT-ORDERED slots: slot s stands for the sign vector (bit k set = "+" on axis k), and the children go to the slots that maximise
+// sum over children of  sign(s) . (child centroid - node centroid)  (greedy matching) — a ray then visits the slots in decreasing (s ^ octinv).  child[s] as in wide4_node, 0x76543210 = empty slot.
+struct wide8_node { aabb box; aabb cbox[8]; int child[8]; };
+void collapse_bvh8(const bvh_result& R, std::vector<wide8_node>& out, int& max_depth);
 } // namespace ctl

@@ -147,23 +147,23 @@ int ctl_traversal_stack_histogram(uint64_t* out, uint32_t n_bins, int reset) {
 // ---- scene
 int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc, false); CTL_CATCH }
 int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY
-    const uint32_t fmt = (flags >> 8) & 3u;   // 0: default, else CTL_FLAT_* + 1
+    const uint32_t fmt = (flags >> 8) & 7u;   // 0: default, else CTL_FLAT_* + 1
     *out = new ctl_scene(*desc, (flags & CTL_SCENE_FLATTEN) != 0, (int)fmt - 1);
 CTL_CATCH }
 void ctl_scene_destroy(ctl_scene* s) { delete s; }
 int ctl_set_cache_dir(const char* dir) { CTL_TRY set_cache_dir(dir); CTL_CATCH }
 int ctl_flatten_probe(const ctl_scene_desc* desc, uint32_t format, uint64_t* out4) {
-    CTL_REQUIRE(desc && out4 && format <= CTL_FLAT_F2, "null argument or bad format");
+    CTL_REQUIRE(desc && out4 && format <= CTL_FLAT_Q8, "null argument or bad format");
     CTL_TRY
         flat_scene F;
         if (!flatten_scene(*desc, F, (size_t)1 << 30, (int)format)) throw std::runtime_error("ctl_flatten_probe: nothing to flatten");
-        content_hash H; H.add_vector(F.nodes); H.add_vector(F.child_links); H.add_vector(F.nodes_f4); H.add_vector(F.nodes_f2); H.add_vector(F.leaves);
-        out4[0] = F.nodes.size() + F.nodes_f4.size() + F.nodes_f2.size(); out4[1] = F.leaves.size(); out4[2] = (uint64_t)F.max_depth;
+        content_hash H; H.add_vector(F.nodes); H.add_vector(F.child_links); H.add_vector(F.nodes_f4); H.add_vector(F.nodes_f2); H.add_vector(F.leaves); if (!F.nodes_q8.empty()) H.add_vector(F.nodes_q8);
+        out4[0] = F.nodes.size() + F.nodes_f4.size() + F.nodes_f2.size() + F.nodes_q8.size(); out4[1] = F.leaves.size(); out4[2] = (uint64_t)F.max_depth;
         out4[3] = std::strtoull(H.hex().substr(16).c_str(), nullptr, 16);
     CTL_CATCH
 }
 int ctl_flat_bvh_build(const ctl_scene_desc* desc, uint32_t format, ctl_flat_bvh** out) {
-    CTL_REQUIRE(desc && out && format <= CTL_FLAT_F2, "null argument or bad format");
+    CTL_REQUIRE(desc && out && format <= CTL_FLAT_Q8, "null argument or bad format");
     CTL_TRY
         std::unique_ptr<ctl_flat_bvh> h(new ctl_flat_bvh());
         if (!flatten_scene(*desc, h->f, (size_t)1 << 30, (int)format)) throw std::runtime_error("ctl_flat_bvh_build: nothing to flatten");
@@ -175,10 +175,11 @@ int ctl_flat_bvh_arrays(const ctl_flat_bvh* h, ctl_flat_bvh_desc* out) {
     const flat_scene& F = h->f;
     out->format = (uint32_t)F.format; out->max_depth = (uint32_t)F.max_depth;
     if (F.format == kFlatQ4) { out->nodes = F.nodes.data(); out->n_nodes = F.nodes.size(); out->node_bytes = 64; }
+    else if (F.format == kFlatQ8) { out->nodes = F.nodes_q8.data(); out->n_nodes = F.nodes_q8.size(); out->node_bytes = 128; }
     else if (F.format == kFlatF4) { out->nodes = F.nodes_f4.data(); out->n_nodes = F.nodes_f4.size(); out->node_bytes = 128; }
     else { out->nodes = F.nodes_f2.data(); out->n_nodes = F.nodes_f2.size(); out->node_bytes = 64; }
     out->leaves = F.leaves.data(); out->n_leaves = F.leaves.size();
-    out->child_links = F.format == kFlatQ4 ? F.child_links.data() : nullptr; out->compact = (F.format == kFlatQ4 && F.compact_links) ? 1u : 0u;
+    out->child_links = (F.format == kFlatQ4 || F.format == kFlatQ8) ? F.child_links.data() : nullptr; out->compact = ((F.format == kFlatQ4 && F.compact_links) || F.format == kFlatQ8) ? 1u : 0u;
     out->root_slab = F.root_slab ? 1u : 0u; out->n_slab_nodes = F.slab_nodes;
     return CTL_OK;
 }

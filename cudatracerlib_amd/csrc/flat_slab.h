@@ -41,6 +41,7 @@ struct slab_ray {        // what a node step needs of a node's slab for one ray
     float alpha;         // step / r
     float beta_n, beta_f;  // (base -+ pad - s) / r : entry / exit side
     uint32_t near_w, far_w;   // code words in entry / exit order
+    bool neg;                 // r < 0: entry side = the hi codes (8-wide nodes pick their two code words per side themselves)
 };
 
 CTL_SLAB_HD float slab_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -72,7 +73,7 @@ CTL_SLAB_HD void slab_setup(uint32_t nw, float base, uint32_t lo_w, uint32_t hi_
     R.alpha = step * rr;
     R.beta_n = (neg ? u + pad : u - pad) * rr;
     R.beta_f = (neg ? u - pad : u + pad) * rr;
-    R.near_w = neg ? hi_w : lo_w; R.far_w = neg ? lo_w : hi_w;
+    R.near_w = neg ? hi_w : lo_w; R.far_w = neg ? lo_w : hi_w; R.neg = neg;
 }
 // entry / exit distance of child k's slab
 CTL_SLAB_HD float slab_near(const slab_ray& R, int k) { return __builtin_fmaf((float)((R.near_w >> (8 * k)) & 0xffu), R.alpha, R.beta_n); }

@@ -114,11 +114,29 @@ bool flat_links_valid(const flat_scene& F) {
             }
         }
     }
+    else if (F.format == kFlatQ8) {
+        // every link the kernels derive (flat8.h) must land inside the arrays, and must be the explicit one host code sees
+        if (F.child_links.size() != F.nodes_q8.size() * 8 || F.nodes_q8.size() >= kFlat8MaxNodes) return false;
+        for (size_t i = 0; i < F.nodes_q8.size(); i++) {
+            const flat8_node& n = F.nodes_q8[i];
+            const uint32_t q0w = (uint32_t)n.e[0] | ((uint32_t)n.e[1] << 8) | ((uint32_t)n.e[2] << 16) | ((uint32_t)n.imask << 24);
+            const uint32_t im = flat8_inner_mask(q0w), lm = flat8_leaf_mask(q0w, n.base_b);
+            for (uint32_t s = 0; s < 8; s++) {
+                const int32_t k = F.child_links[i * 8 + s];
+                if ((im >> s) & 1u) { const uint32_t c = flat8_child_node(n.base_b, im, s); if (c >= F.nodes_q8.size() || k != (int32_t)c) return false; }
+                else if ((lm >> s) & 1u) { const uint32_t e = flat8_leaf_entry(n.leaf_base, lm, s); if (e >= nl || k != ~(int32_t)e || !(F.leaves[e].index & 1u)) return false; }
+                else if (k != (int32_t)kFlat8None) return false;
+            }
+            // an empty slot that round-off lets through is read as entry leaf_base + rank: one past the node's own entries at most, which must exist (the upload appends a closing entry)
+            if ((size_t)n.leaf_base + flat8_popc(lm) > nl) return false;
+        }
+    }
     else if (F.format == kFlatF4) { for (const auto& n : F.nodes_f4) for (int c = 0; c < 4; c++) if (!ok(n.child[c], F.nodes_f4.size(), 8)) return false; }
     else for (const auto& n : F.nodes_f2) if (!ok(n.child0, F.nodes_f2.size(), 4) || !ok(n.child1, F.nodes_f2.size(), 4)) return false;
     if (F.node_bytes() == 0) return false;
     return nl > 0 && (F.leaves[nl - 1].index & 1u);   // the last entry closes its leaf
 }
+struct slab_ctri { double w[3][3]; double slack; int c; };   // a triangle under child c of the node whose slab is being chosen
 float round_down(double x) { float f = (float)x; return ((double)f > x) ? std::nextafterf(f, -INFINITY) : f; }
 float round_up(double x) { float f = (float)x; return ((double)f < x) ? std::nextafterf(f, INFINITY) : f; }
 
@@ -129,14 +147,15 @@ int default_flat_format() {
         const char* e = knob_env("CTL_FLAT_FORMAT");
         if (e && (!std::strcmp(e, "f4") || !std::strcmp(e, "F4"))) return (int)kFlatF4;
         if (e && (!std::strcmp(e, "f2") || !std::strcmp(e, "F2"))) return (int)kFlatF2;
+        if (e && (!std::strcmp(e, "q8") || !std::strcmp(e, "Q8"))) return (int)kFlatQ8;
         return (int)kFlatQ4;
     }();
     return v;
 }
 
 bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangles, int format) {
-    out.nodes.clear(); out.nodes_f4.clear(); out.nodes_f2.clear(); out.leaves.clear(); out.compact_links = true;
-    out.format = (format == kFlatF4 || format == kFlatF2) ? format : kFlatQ4;
+    out.nodes.clear(); out.nodes_q8.clear(); out.nodes_f4.clear(); out.nodes_f2.clear(); out.leaves.clear(); out.compact_links = true;
+    out.format = (format == kFlatF4 || format == kFlatF2 || format == kFlatQ8) ? format : kFlatQ4;
     phase_timer pt;
     // leaf-entry range of every mesh (the woop stream is shared; a mesh ends where the next one starts)
     std::vector<std::pair<uint32_t, uint32_t>> starts;
@@ -161,7 +180,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node format only
     std::string key;
     if (!cache_dir().empty()) {
-        content_hash H; const uint32_t version = 14;
+        content_hash H; const uint32_t version = 15;
         H.add_value(version); { const char* e = knob_env("CTL_FLAT_SLAB_SUBTREE"); H.add_value(e ? atoi(e) : kSlabSubtreeDefault); } { const char* e = knob_env("CTL_FLAT_FORCE_EXPLICIT"); H.add_value(e ? atoi(e) : 0); } H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
@@ -169,12 +188,12 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
         key = H.hex();
         cache_reader rd("flat", key);
         int c_format = -1, c_depth = 0, c_compact = 0, c_root_slab = 0; uint64_t c_slab_nodes = 0;
-        if (rd.found() && rd.value(c_format) && rd.value(c_depth) && rd.value(c_compact) && rd.vector(out.nodes) && rd.vector(out.nodes_f4) && rd.vector(out.nodes_f2) && rd.vector(out.leaves) && rd.vector(out.child_links) && rd.value(c_root_slab) && rd.value(c_slab_nodes) && rd.verify() &&
+        if (rd.found() && rd.value(c_format) && rd.value(c_depth) && rd.value(c_compact) && rd.vector(out.nodes) && rd.vector(out.nodes_q8) && rd.vector(out.nodes_f4) && rd.vector(out.nodes_f2) && rd.vector(out.leaves) && rd.vector(out.child_links) && rd.value(c_root_slab) && rd.value(c_slab_nodes) && rd.verify() &&
             c_format == out.format && ((out.compact_links = c_compact != 0), flat_links_valid(out))) {
             out.max_depth = c_depth; out.root_slab = c_root_slab != 0; out.slab_nodes = (size_t)c_slab_nodes; pt.lap("cache hit");
             return true;
         }
-        out.nodes.clear(); out.nodes_f4.clear(); out.nodes_f2.clear(); out.leaves.clear(); out.child_links.clear(); out.compact_links = true;
+        out.nodes.clear(); out.nodes_q8.clear(); out.nodes_f4.clear(); out.nodes_f2.clear(); out.leaves.clear(); out.child_links.clear(); out.compact_links = true;
     }
     struct wtri { uint32_t tri, node, woop; };
     // object-space vertices of every mesh's triangles once (degenerate ones can never be hit and are dropped), then per node in parallel
@@ -218,7 +237,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     }, 1);
     pt.lap("world triangles");
     bvh_result R;
-    build_bvh(boxes, flat_max_leaf(), true, 60, R, flat_node_cost());
+    build_bvh(boxes, out.format == kFlatQ8 ? 1 : flat_max_leaf(), true, 60, R, flat_node_cost());   // Q8: every leaf slot is ONE entry (flat8.h)
     pt.lap("build BVH2");
     int wdepth = 0;
     if (out.format == kFlatF2) {
@@ -248,6 +267,72 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
             if (n.child1 == 0x76543210) { n.b[0] = n.b[2] = n.c[2] = big; n.b[1] = n.b[3] = n.c[3] = -big; }
             out.nodes_f2[i] = n;
         }
+    } else if (out.format == kFlatQ8) {
+        // collapse to 8-wide nodes with octant-ordered slots (bvh_builder.h), memory order as for the 4-wide tree: the top breadth-first, depth-first clusters below,
+        // the inner children of a node consecutive in slot order
+        std::vector<wide8_node> W;
+        collapse_bvh8(R, W, wdepth);
+        if (W.size() >= kFlat8MaxNodes) return flatten_scene(d, out, max_triangles, kFlatQ4);   // node indices are 24 bits: a tree beyond that is stored 4-wide (whose links turn explicit past its own limits)
+        {
+            std::vector<int> new_id(W.size(), -1), order; order.reserve(W.size());
+            std::vector<int> stack; new_id[0] = 0; order.push_back(0);
+            static const size_t bfs_top = [] { const char* e = knob_env("CTL_FLAT_BFS_TOP"); return e ? (size_t)atol(e) : (size_t)65536; }();
+            std::vector<int> frontier; frontier.push_back(0);
+            for (size_t head = 0; head < frontier.size() && order.size() < bfs_top; head++) {
+                const int me = frontier[head]; frontier[head] = -1;
+                for (int c = 0; c < 8; c++) if (W[me].child[c] >= 0 && W[me].child[c] != 0x76543210) { const int k = W[me].child[c]; new_id[k] = (int)order.size(); order.push_back(k); frontier.push_back(k); }
+            }
+            for (size_t i = frontier.size(); i-- > 0;) if (frontier[i] >= 0) stack.push_back(frontier[i]);
+            while (!stack.empty()) {
+                const int me = stack.back(); stack.pop_back();
+                int kids[8], nk = 0;
+                for (int c = 0; c < 8; c++) if (W[me].child[c] >= 0 && W[me].child[c] != 0x76543210) kids[nk++] = W[me].child[c];
+                for (int c = 0; c < nk; c++) { new_id[kids[c]] = (int)order.size(); order.push_back(kids[c]); }
+                for (int c = nk - 1; c >= 0; c--) stack.push_back(kids[c]);
+            }
+            std::vector<wide8_node> W2(W.size());
+            for (size_t i = 0; i < order.size(); i++) { W2[i] = W[order[i]]; for (int c = 0; c < 8; c++) if (W2[i].child[c] >= 0 && W2[i].child[c] != 0x76543210) W2[i].child[c] = new_id[W2[i].child[c]]; }
+            W.swap(W2);
+        }
+        out.nodes_q8.resize(W.size()); out.child_links.assign(W.size() * 8, (int32_t)kFlat8None);
+        parallel_for(W.size(), [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) {
+                const wide8_node& w = W[i]; flat8_node& f = out.nodes_q8[i];
+                std::memset(&f, 0, sizeof(f));
+                uint32_t* q[3][2] = { { f.qlo_x, f.qhi_x }, { f.qlo_y, f.qhi_y }, { f.qlo_z, f.qhi_z } };
+                uint32_t first_inner = 0; bool have_inner = false, consecutive = true; uint32_t ni = 0;
+                for (int c = 0; c < 8; c++) {
+                    const int k = w.child[c];
+                    if (k == 0x76543210) continue;
+                    out.child_links[i * 8 + c] = k;   // leaf links are rewritten below (entries in node order)
+                    if (k >= 0) { if (!have_inner) { first_inner = (uint32_t)k; have_inner = true; } if ((uint32_t)k != first_inner + ni) consecutive = false; ni++; f.imask |= (uint8_t)(1u << c); }
+                    else f.base_b |= 1u << (24 + c);   // B of a non-inner slot: a leaf
+                }
+                if (!consecutive) f.base_b = 0xffffffffu;   // cannot happen (memory order above); flat_links_valid refuses the tree
+                else f.base_b |= first_inner;
+                for (int k = 0; k < 3; k++) {
+                    f.origin[k] = w.box.lo[k];
+                    const double ext = (double)w.box.hi[k] - (double)w.box.lo[k];
+                    int e = 1;
+                    if (ext > 0) { int ex; std::frexp(ext / 255.0, &ex); e = ex + 127; if (e < 1) e = 1; if (e > 254) e = 254; }
+                    f.e[k] = (uint8_t)e;
+                    const double step = std::ldexp(1.0, e - 127);
+                    for (int c = 0; c < 8; c++) {
+                        long lo = 255, hi = 0;   // empty slot: inverted box, never entered
+                        if (w.child[c] != 0x76543210) {
+                            lo = (long)std::floor(((double)w.cbox[c].lo[k] - (double)f.origin[k]) / step);
+                            hi = (long)std::ceil(((double)w.cbox[c].hi[k] - (double)f.origin[k]) / step);
+                            // conservative under the device's fp32 evaluation origin + step * q (one rounding) too
+                            while (lo > 0 && (float)((double)f.origin[k] + step * (double)lo) > w.cbox[c].lo[k]) lo--;
+                            while (hi < 255 && (float)((double)f.origin[k] + step * (double)hi) < w.cbox[c].hi[k]) hi++;
+                            lo = std::min(255L, std::max(0L, lo)); hi = std::min(255L, std::max(0L, hi));
+                        }
+                        q[k][0][c >> 2] |= (uint32_t)lo << (8 * (c & 3)); q[k][1][c >> 2] |= (uint32_t)hi << (8 * (c & 3));
+                    }
+                }
+                f.slab_lo[0] = f.slab_lo[1] = 0u; f.slab_hi[0] = f.slab_hi[1] = 0xffffffffu;
+            }
+        });
     } else {
         // collapse to 4-wide nodes
         std::vector<wide4_node> W;
@@ -333,6 +418,20 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     // leaf entries.  Wide formats: in node order, the leaf children of a node one after the other in slot order (flat4_node's implied links).
     std::vector<uint32_t> entry_src;   // new entry -> position in R.leaf_prims
     if (out.format == kFlatF2) { entry_src.resize(R.leaf_prims.size()); for (size_t i = 0; i < entry_src.size(); i++) entry_src[i] = (uint32_t)i; }
+    else if (out.format == kFlatQ8) {
+        entry_src.reserve(R.leaf_prims.size());
+        for (size_t i = 0; i < out.nodes_q8.size(); i++) {
+            flat8_node& n = out.nodes_q8[i];
+            n.leaf_base = (uint32_t)entry_src.size();
+            for (int c = 0; c < 8; c++) {
+                int32_t& k = out.child_links[i * 8 + c];
+                if (k >= 0) continue;   // inner child, or kFlat8None (positive)
+                const uint32_t e = (uint32_t)~k;
+                if (!R.leaf_last[e]) return false;   // the BVH2 was built with one primitive per leaf
+                k = ~(int32_t)entry_src.size(); entry_src.push_back(e);
+            }
+        }
+    }
     else {
         entry_src.reserve(R.leaf_prims.size());
         auto relink = [&](int32_t* child, int n_children, uint32_t* counts, uint8_t* mask) {   // leaf children: entries appended in slot order, link = ~first new entry
@@ -372,138 +471,156 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     });
     pt.lap("leaf entries");
     out.max_depth = wdepth;
-    out.child_links.clear(); out.root_slab = false; out.slab_nodes = 0;
+    if (out.format != kFlatQ8) out.child_links.clear();
+    out.root_slab = false; out.slab_nodes = 0;
     if (out.format == kFlatQ4) {
         out.child_links.resize(out.nodes.size() * 4);
         for (size_t i = 0; i < out.nodes.size(); i++) std::memcpy(&out.child_links[i * 4], out.nodes[i].child, 16);
-        if (out.compact_links) {
-            // oriented slabs of the nodes that have leaf children (flat_slab.h).  World-space vertices in double from the object-space ones.
-            auto world_tri = [&](uint32_t entry, double w[3][3], double& slack) {
-                const size_t g = R.leaf_prims[entry_src[entry]]; const wtri& t = tris[g];
-                const ltri& l = mesh_local[d.nodes[t.node].mesh_index][g - node_first[t.node]];
-                const float* M = d.node_transforms[t.node].m;
-                for (int j = 0; j < 3; j++) for (int r = 0; r < 3; r++) w[j][r] = (double)M[r * 4] * l.v[j][0] + (double)M[r * 4 + 1] * l.v[j][1] + (double)M[r * 4 + 2] * l.v[j][2] + (double)M[r * 4 + 3];
-                slack = woop_slack(l.v, M);
-            };
-            std::vector<uint8_t> has_slab(out.nodes.size(), 0);
-            // An INNER child whose whole subtree holds at most `sub_cap` triangles (a bottom node: the patch of surface under it is as flat as its triangles) gets a real interval too:
-            // a ray that crosses the patch's box but not the patch itself is turned away one level higher and never fetches the bottom node.  sub_tris: triangles under every node
-            // (children follow their parent in memory, so one backwards sweep does it).
-            static const int sub_cap = [] { const char* e = knob_env("CTL_FLAT_SLAB_SUBTREE"); const int v = e ? atoi(e) : kSlabSubtreeDefault; return v < 0 ? 0 : (v > kSlabSubtreeMax ? kSlabSubtreeMax : v); }();
-            std::vector<uint8_t> sub_tris(out.nodes.size(), 0);
-            for (size_t i = out.nodes.size(); i-- > 0;) {
-                uint32_t n = 0;
-                for (int c = 0; c < 4; c++) {
-                    const int32_t k = out.child_links[i * 4 + c];
-                    if (k == 0x76543210) continue;
-                    if (k >= 0) n += sub_tris[(size_t)k / 4];
-                    else for (uint32_t e = (uint32_t)~k;; e++) { n++; if (out.leaves[e].index & 1u) break; }
-                }
-                sub_tris[i] = (uint8_t)std::min(n, 255u);
+    }
+    if ((out.format == kFlatQ4 && out.compact_links) || out.format == kFlatQ8) {
+        // oriented slabs of the nodes that have leaf children (flat_slab.h), for both wide formats: W = children per node, explicit links in out.child_links (W per node),
+        // a leaf = the entries from its first one up to the next `last` flag.  World-space vertices in double from the object-space ones.
+        const int W = out.format == kFlatQ8 ? 8 : 4;
+        const size_t n_nodes = out.format == kFlatQ8 ? out.nodes_q8.size() : out.nodes.size();
+        const uint32_t none = 0x76543210u;
+        auto world_tri = [&](uint32_t entry, double w[3][3], double& slack) {
+            const size_t g = R.leaf_prims[entry_src[entry]]; const wtri& t = tris[g];
+            const ltri& l = mesh_local[d.nodes[t.node].mesh_index][g - node_first[t.node]];
+            const float* M = d.node_transforms[t.node].m;
+            for (int j = 0; j < 3; j++) for (int r = 0; r < 3; r++) w[j][r] = (double)M[r * 4] * l.v[j][0] + (double)M[r * 4 + 1] * l.v[j][1] + (double)M[r * 4 + 2] * l.v[j][2] + (double)M[r * 4 + 3];
+            slack = woop_slack(l.v, M);
+        };
+        std::vector<uint8_t> has_slab(n_nodes, 0);
+        // An INNER child whose whole subtree holds at most `sub_cap` triangles (a bottom node: the patch of surface under it is as flat as its triangles) gets a real interval too:
+        // a ray that crosses the patch's box but not the patch itself is turned away one level higher and never fetches the bottom node.  sub_tris: triangles under every node
+        // (children follow their parent in memory, so one backwards sweep does it).
+        static const int sub_cap = [] { const char* e = knob_env("CTL_FLAT_SLAB_SUBTREE"); const int v = e ? atoi(e) : kSlabSubtreeDefault; return v < 0 ? 0 : (v > kSlabSubtreeMax ? kSlabSubtreeMax : v); }();
+        auto node_of = [&](int32_t k) { return out.format == kFlatQ8 ? (size_t)k : (size_t)k / 4; };   // explicit inner link -> node index
+        std::vector<uint8_t> sub_tris(n_nodes, 0);
+        for (size_t i = n_nodes; i-- > 0;) {
+            uint32_t n = 0;
+            for (int c = 0; c < W; c++) {
+                const int32_t k = out.child_links[i * W + c];
+                if ((uint32_t)k == none) continue;
+                if (k >= 0) n += sub_tris[node_of(k)];
+                else for (uint32_t e = (uint32_t)~k;; e++) { n++; if (out.leaves[e].index & 1u) break; }
             }
-            static const double useful_below = [] { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); return e ? atof(e) : 0.6; }();   // builder knob (part of the cache key)
+            sub_tris[i] = (uint8_t)std::min(n, 255u);
+        }
+        static const double useful_below = [] { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); return e ? atof(e) : 0.6; }();   // builder knob (part of the cache key)
+        struct slab_codes { uint32_t slab_n; float base; uint8_t lo[8], hi[8]; };
+        // the slab of one node: origin / exponents / child-box codes as stored, exist / leafm = per-slot masks, ch = its W explicit links.  false: the node carries none.
+        auto make_slab = [&](const float* origin, const uint8_t* ex, uint32_t exist, uint32_t leafm, const uint8_t ql[3][8], const uint8_t qh[3][8], const int32_t* ch, slab_codes& S) -> bool {
+            if (useful_below <= 0.0) return false;
+            // triangles of the leaf children and of the inner children with small subtrees; `tight` = the children that get an interval of their own
+            constexpr int kT = 8 * kSlabSubtreeMax; static thread_local std::vector<slab_ctri> T; if (T.size() < (size_t)kT) T.resize(kT);
+            int nt = 0; uint32_t tight = 0;
+            const int kTw = W * kSlabSubtreeMax;   // the 4-wide tree's own cap (its arrays held 4 x the subtree limit)
+            for (int c = 0; c < W; c++) {
+                if (!((exist >> c) & 1)) continue;
+                if ((leafm >> c) & 1) { tight |= 1u << c; for (uint32_t e = (uint32_t)~ch[c];; e++) { T[nt].c = c; world_tri(e, T[nt].w, T[nt].slack); nt++; if ((out.leaves[e].index & 1u) || nt == kTw) break; } continue; }
+                if (sub_cap <= 0 || sub_tris[node_of(ch[c])] > sub_cap) continue;
+                const int nt_before = nt; bool complete = true;
+                int32_t stack[128]; int sp = 0; stack[sp++] = ch[c];
+                while (sp && complete) {
+                    const int32_t k = stack[--sp];
+                    if (k >= 0) { for (int q = 0; q < W; q++) { const int32_t kk = out.child_links[node_of(k) * W + q]; if ((uint32_t)kk == none) continue; if (sp < (W == 4 ? 64 : 128)) stack[sp++] = kk; else complete = false; } }
+                    else for (uint32_t e = (uint32_t)~k;; e++) { if (nt < kTw) { T[nt].c = c; world_tri(e, T[nt].w, T[nt].slack); nt++; } else complete = false; if (out.leaves[e].index & 1u) break; }
+                }
+                if (complete) tight |= 1u << c; else nt = nt_before;   // an interval must cover EVERY triangle under the child, or the child keeps the whole node
+            }
+            if (!tight || nt == 0) return false;
+            double stepk[3], ext1 = 0, mag = 0;
+            for (int k = 0; k < 3; k++) { stepk[k] = std::ldexp(1.0, (int)ex[k] - 127); ext1 += 255.0 * stepk[k]; mag = std::max(mag, std::fabs((double)origin[k]) + 255.0 * stepk[k]); }
+            int best_n[3] = { 0, 0, 0 }; double best_cost = 1e300; double best_lo[8], best_hi[8];
+            // candidate directions: the triangles' own normals (at most 24 of them, evenly picked) and — for patches — the area-weighted mean normal of every child and of all
+            double mean_n[9][3] = {};
+            for (int t = 0; t < nt; t++) {
+                const double (*w)[3] = T[t].w;
+                const double a[3] = { w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2] }, b[3] = { w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2] };
+                const double n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+                for (int k = 0; k < 3; k++) { mean_n[T[t].c][k] += n[k]; mean_n[W][k] += n[k]; }
+            }
+            const int cand_step = std::max(1, nt / 24), n_tri_cand = (nt + cand_step - 1) / cand_step;
+            for (int ci = 0; ci < n_tri_cand + (nt > 4 ? W + 1 : 0); ci++) {
+                double n[3];
+                if (ci < n_tri_cand) {
+                    const double (*w)[3] = T[ci * cand_step].w;
+                    const double a[3] = { w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2] }, b[3] = { w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2] };
+                    n[0] = a[1] * b[2] - a[2] * b[1]; n[1] = a[2] * b[0] - a[0] * b[2]; n[2] = a[0] * b[1] - a[1] * b[0];
+                } else for (int k = 0; k < 3; k++) n[k] = mean_n[ci - n_tri_cand][k];
+                const double m = std::max(std::max(std::fabs(n[0]), std::fabs(n[1])), std::fabs(n[2]));
+                if (!(m > 0) || !std::isfinite(m)) continue;
+                int nq[3]; for (int k = 0; k < 3; k++) nq[k] = (int)std::lround(n[k] / m * (double)kSlabNMax);
+                bool dup = false; if (nq[0] == best_n[0] && nq[1] == best_n[1] && nq[2] == best_n[2]) dup = true;
+                if (dup) continue;
+                double lo[8], hi[8]; for (int c = 0; c < 8; c++) { lo[c] = 1e300; hi[c] = -1e300; }
+                for (int t = 0; t < nt; t++) for (int j = 0; j < 3; j++) {
+                    const double D = nq[0] * (T[t].w[j][0] - (double)origin[0]) + nq[1] * (T[t].w[j][1] - (double)origin[1]) + nq[2] * (T[t].w[j][2] - (double)origin[2]);
+                    lo[T[t].c] = std::min(lo[T[t].c], D); hi[T[t].c] = std::max(hi[T[t].c], D);
+                }
+                double cost = 0; int nl = 0;
+                for (int c = 0; c < W; c++) if ((tight >> c) & 1) {
+                    double range = 0; for (int k = 0; k < 3; k++) range += std::fabs((double)nq[k]) * stepk[k] * (double)((int)qh[k][c] - (int)ql[k][c]);
+                    cost += range > 0 ? std::min(1.0, (hi[c] - lo[c]) / range) : 1.0; nl++;
+                }
+                cost /= nl;
+                if (cost < best_cost) { best_cost = cost; for (int k = 0; k < 3; k++) best_n[k] = nq[k]; for (int c = 0; c < W; c++) { best_lo[c] = lo[c]; best_hi[c] = hi[c]; } }
+            }
+            if (!(best_cost < useful_below)) return false;
+            // static pad per child: round-off reach of the object-space test (2^-20 of the magnitudes involved) + the node-extent share of the kernel's evaluation error
+            const double n1 = std::fabs((double)best_n[0]) + std::fabs((double)best_n[1]) + std::fabs((double)best_n[2]);
+            double pad[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            for (int t = 0; t < nt; t++) pad[T[t].c] = std::max(pad[T[t].c], n1 * 9.5367431640625e-7 * (T[t].slack + mag) + (double)kSlabRayPad * ext1);   // 2^-20 of the magnitudes: ~8 x the fp32 round-off of the object-space test
+            // D range the codes span: the leaf children's padded intervals — and, when the node has inner children too, the whole node (its
+            // quantisation grid's box), which their code 0 .. 255 must cover
+            double nlo = 1e300, nhi = -1e300;
+            for (int c = 0; c < W; c++) if ((tight >> c) & 1) { nlo = std::min(nlo, best_lo[c] - pad[c]); nhi = std::max(nhi, best_hi[c] + pad[c]); }
+            if (exist != tight) {   // a child without an interval of its own spans the whole node
+                double pmax = 0; for (int c = 0; c < W; c++) pmax = std::max(pmax, pad[c]);
+                double blo = 0, bhi = 0; for (int k = 0; k < 3; k++) { const double x = best_n[k] * 255.0 * stepk[k]; if (x < 0) blo += x; else bhi += x; }
+                nlo = std::min(nlo, blo - pmax); nhi = std::max(nhi, bhi + pmax);
+            }
+            const float base = round_down(nlo);
+            // step: a float with 5 mantissa bits (the top 14 bits of its pattern share a word with the normal), rounded up; 254 steps span the range
+            float stepf = round_up((nhi - (double)base) / 254.0);
+            if (!(stepf > 0.0f) || !std::isfinite(stepf)) stepf = 1.17549435e-38f;
+            { uint32_t bits; std::memcpy(&bits, &stepf, 4); bits = (bits + 0x3ffffu) & 0xfffc0000u; std::memcpy(&stepf, &bits, 4); }
+            if (!std::isfinite(stepf) || stepf < 1.17549435e-38f) return false;
+            const double step = (double)stepf;
+            bool ok = true;
+            for (int c = 0; c < W; c++) {
+                long lo, hi;
+                if (!((exist >> c) & 1)) { lo = 255; hi = 0; }
+                else if (!((tight >> c) & 1)) { lo = 0; hi = 255; }
+                else {
+                    lo = (long)std::floor((best_lo[c] - pad[c] - (double)base) / step);
+                    hi = (long)std::ceil((best_hi[c] + pad[c] - (double)base) / step);
+                    // conservative under the fp32 evaluation base + step * code as well
+                    while (lo > 0 && (double)(float)((double)base + step * (double)lo) > best_lo[c] - pad[c]) lo--;
+                    while (hi < 255 && (double)(float)((double)base + step * (double)hi) < best_hi[c] + pad[c]) hi++;
+                    if (lo < 0 || hi > 255 || (double)base + step * (double)lo > best_lo[c] - pad[c] || (double)base + step * (double)hi < best_hi[c] + pad[c]) ok = false;
+                }
+                S.lo[c] = (uint8_t)(lo & 255); S.hi[c] = (uint8_t)(hi & 255);
+            }
+            if (!ok || (double)base + 255.0 * step < nhi) return false;
+            uint32_t sb; std::memcpy(&sb, &stepf, 4);
+            S.slab_n = ((uint32_t)best_n[0] & 63u) | (((uint32_t)best_n[1] & 63u) << 6) | (((uint32_t)best_n[2] & 63u) << 12) | sb;
+            S.base = base;
+            return true;
+        };
+        if (out.format == kFlatQ4) {
             parallel_for(out.nodes.size(), [&](size_t i0, size_t i1) {
                 for (size_t i = i0; i < i1; i++) {
                     flat4_node& f = out.nodes[i];
-                    const int32_t* ch = &out.child_links[i * 4];
                     f.slab_n = 0; f.slab_base = 0.0f; f.slab_lo = 0; f.slab_hi = 0xffffffffu;
-                    if (useful_below <= 0.0) continue;
-                    // triangles of the leaf children and of the inner children with small subtrees; `tight` = the children that get an interval of their own
-                    struct ctri { double w[3][3]; double slack; int c; };
-                    constexpr int kT = 4 * kSlabSubtreeMax; ctri T[kT]; int nt = 0; uint32_t tight = 0;
-                    for (int c = 0; c < 4; c++) {
-                        if (!((f.mask >> c) & 1)) continue;
-                        if ((f.mask >> (4 + c)) & 1) { tight |= 1u << c; for (uint32_t e = (uint32_t)~ch[c];; e++) { T[nt].c = c; world_tri(e, T[nt].w, T[nt].slack); nt++; if ((out.leaves[e].index & 1u) || nt == kT) break; } continue; }
-                        if (sub_cap <= 0 || sub_tris[(size_t)ch[c] / 4] > sub_cap) continue;
-                        const int nt_before = nt; bool complete = true;
-                        int32_t stack[64]; int sp = 0; stack[sp++] = ch[c];
-                        while (sp && complete) {
-                            const int32_t k = stack[--sp];
-                            if (k >= 0) { for (int q = 0; q < 4; q++) { const int32_t kk = out.child_links[(size_t)k / 4 * 4 + q]; if (kk == 0x76543210) continue; if (sp < 64) stack[sp++] = kk; else complete = false; } }
-                            else for (uint32_t e = (uint32_t)~k;; e++) { if (nt < kT) { T[nt].c = c; world_tri(e, T[nt].w, T[nt].slack); nt++; } else complete = false; if (out.leaves[e].index & 1u) break; }
-                        }
-                        if (complete) tight |= 1u << c; else nt = nt_before;   // an interval must cover EVERY triangle under the child, or the child keeps the whole node
-                    }
-                    if (!tight || nt == 0) continue;
-                    double stepk[3], ext1 = 0, mag = 0;
-                    for (int k = 0; k < 3; k++) { stepk[k] = std::ldexp(1.0, (int)f.e[k] - 127); ext1 += 255.0 * stepk[k]; mag = std::max(mag, std::fabs((double)f.origin[k]) + 255.0 * stepk[k]); }
-                    // box extents of the children (decoded codes) for the usefulness measure
-                    const uint32_t ql[3] = { f.qlo_x, f.qlo_y, f.qlo_z }, qh[3] = { f.qhi_x, f.qhi_y, f.qhi_z };
-                    int best_n[3] = { 0, 0, 0 }; double best_cost = 1e300; double best_lo[4], best_hi[4];
-                    // candidate directions: the triangles' own normals (at most 24 of them, evenly picked) and — for patches — the area-weighted mean normal of every child and of all
-                    double mean_n[5][3] = {};
-                    for (int t = 0; t < nt; t++) {
-                        const double (*w)[3] = T[t].w;
-                        const double a[3] = { w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2] }, b[3] = { w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2] };
-                        const double n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
-                        for (int k = 0; k < 3; k++) { mean_n[T[t].c][k] += n[k]; mean_n[4][k] += n[k]; }
-                    }
-                    const int cand_step = std::max(1, nt / 24), n_tri_cand = (nt + cand_step - 1) / cand_step;
-                    for (int ci = 0; ci < n_tri_cand + (nt > 4 ? 5 : 0); ci++) {
-                        double n[3];
-                        if (ci < n_tri_cand) {
-                            const double (*w)[3] = T[ci * cand_step].w;
-                            const double a[3] = { w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2] }, b[3] = { w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2] };
-                            n[0] = a[1] * b[2] - a[2] * b[1]; n[1] = a[2] * b[0] - a[0] * b[2]; n[2] = a[0] * b[1] - a[1] * b[0];
-                        } else for (int k = 0; k < 3; k++) n[k] = mean_n[ci - n_tri_cand][k];
-                        const double m = std::max(std::max(std::fabs(n[0]), std::fabs(n[1])), std::fabs(n[2]));
-                        if (!(m > 0) || !std::isfinite(m)) continue;
-                        int nq[3]; for (int k = 0; k < 3; k++) nq[k] = (int)std::lround(n[k] / m * (double)kSlabNMax);
-                        bool dup = false; if (nq[0] == best_n[0] && nq[1] == best_n[1] && nq[2] == best_n[2]) dup = true;
-                        if (dup) continue;
-                        double lo[4] = { 1e300, 1e300, 1e300, 1e300 }, hi[4] = { -1e300, -1e300, -1e300, -1e300 };
-                        for (int t = 0; t < nt; t++) for (int j = 0; j < 3; j++) {
-                            const double D = nq[0] * (T[t].w[j][0] - (double)f.origin[0]) + nq[1] * (T[t].w[j][1] - (double)f.origin[1]) + nq[2] * (T[t].w[j][2] - (double)f.origin[2]);
-                            lo[T[t].c] = std::min(lo[T[t].c], D); hi[T[t].c] = std::max(hi[T[t].c], D);
-                        }
-                        double cost = 0; int nl = 0;
-                        for (int c = 0; c < 4; c++) if ((tight >> c) & 1) {
-                            double range = 0; for (int k = 0; k < 3; k++) range += std::fabs((double)nq[k]) * stepk[k] * (double)((int)((qh[k] >> (8 * c)) & 255u) - (int)((ql[k] >> (8 * c)) & 255u));
-                            cost += range > 0 ? std::min(1.0, (hi[c] - lo[c]) / range) : 1.0; nl++;
-                        }
-                        cost /= nl;
-                        if (cost < best_cost) { best_cost = cost; for (int k = 0; k < 3; k++) best_n[k] = nq[k]; for (int c = 0; c < 4; c++) { best_lo[c] = lo[c]; best_hi[c] = hi[c]; } }
-                    }
-                    if (!(best_cost < useful_below)) continue;
-                    // static pad per child: round-off reach of the object-space test (2^-20 of the magnitudes involved) + the node-extent share of the kernel's evaluation error
-                    const double n1 = std::fabs((double)best_n[0]) + std::fabs((double)best_n[1]) + std::fabs((double)best_n[2]);
-                    double pad[4] = { 0, 0, 0, 0 };
-                    for (int t = 0; t < nt; t++) pad[T[t].c] = std::max(pad[T[t].c], n1 * 9.5367431640625e-7 * (T[t].slack + mag) + (double)kSlabRayPad * ext1);   // 2^-20 of the magnitudes: ~8 x the fp32 round-off of the object-space test
-                    // D range the codes span: the leaf children's padded intervals — and, when the node has inner children too, the whole node (its
-                    // quantisation grid's box), which their code 0 .. 255 must cover
-                    double nlo = 1e300, nhi = -1e300;
-                    for (int c = 0; c < 4; c++) if ((tight >> c) & 1) { nlo = std::min(nlo, best_lo[c] - pad[c]); nhi = std::max(nhi, best_hi[c] + pad[c]); }
-                    if ((f.mask & 15u) != tight) {   // a child without an interval of its own spans the whole node
-                        double pmax = 0; for (int c = 0; c < 4; c++) pmax = std::max(pmax, pad[c]);
-                        double blo = 0, bhi = 0; for (int k = 0; k < 3; k++) { const double x = best_n[k] * 255.0 * stepk[k]; if (x < 0) blo += x; else bhi += x; }
-                        nlo = std::min(nlo, blo - pmax); nhi = std::max(nhi, bhi + pmax);
-                    }
-                    const float base = round_down(nlo);
-                    // step: a float with 5 mantissa bits (the top 14 bits of its pattern share a word with the normal), rounded up; 254 steps span the range
-                    float stepf = round_up((nhi - (double)base) / 254.0);
-                    if (!(stepf > 0.0f) || !std::isfinite(stepf)) stepf = 1.17549435e-38f;
-                    { uint32_t bits; std::memcpy(&bits, &stepf, 4); bits = (bits + 0x3ffffu) & 0xfffc0000u; std::memcpy(&stepf, &bits, 4); }
-                    if (!std::isfinite(stepf) || stepf < 1.17549435e-38f) continue;
-                    const double step = (double)stepf;
-                    uint32_t lo_w = 0, hi_w = 0; bool ok = true;
-                    for (int c = 0; c < 4; c++) {
-                        long lo, hi;
-                        if (!((f.mask >> c) & 1)) { lo = 255; hi = 0; }
-                        else if (!((tight >> c) & 1)) { lo = 0; hi = 255; }
-                        else {
-                            lo = (long)std::floor((best_lo[c] - pad[c] - (double)base) / step);
-                            hi = (long)std::ceil((best_hi[c] + pad[c] - (double)base) / step);
-                            // conservative under the fp32 evaluation base + step * code as well
-                            while (lo > 0 && (double)(float)((double)base + step * (double)lo) > best_lo[c] - pad[c]) lo--;
-                            while (hi < 255 && (double)(float)((double)base + step * (double)hi) < best_hi[c] + pad[c]) hi++;
-                            if (lo < 0 || hi > 255 || (double)base + step * (double)lo > best_lo[c] - pad[c] || (double)base + step * (double)hi < best_hi[c] + pad[c]) ok = false;
-                        }
-                        lo_w |= (uint32_t)(lo & 255) << (8 * c); hi_w |= (uint32_t)(hi & 255) << (8 * c);
-                    }
-                    if (!ok || (double)base + 255.0 * step < nhi) continue;
-                    { uint32_t sb; std::memcpy(&sb, &stepf, 4);
-                      f.slab_n = ((uint32_t)best_n[0] & 63u) | (((uint32_t)best_n[1] & 63u) << 6) | (((uint32_t)best_n[2] & 63u) << 12) | sb; }
-                    f.slab_base = base; f.slab_lo = lo_w; f.slab_hi = hi_w;
+                    uint8_t ql[3][8] = {}, qh[3][8] = {};
+                    const uint32_t qlw[3] = { f.qlo_x, f.qlo_y, f.qlo_z }, qhw[3] = { f.qhi_x, f.qhi_y, f.qhi_z };
+                    for (int k = 0; k < 3; k++) for (int c = 0; c < 4; c++) { ql[k][c] = (uint8_t)(qlw[k] >> (8 * c)); qh[k][c] = (uint8_t)(qhw[k] >> (8 * c)); }
+                    slab_codes S;
+                    if (!make_slab(f.origin, f.e, f.mask & 15u, (uint32_t)(f.mask >> 4) & (f.mask & 15u), ql, qh, &out.child_links[i * 4], S)) continue;
+                    f.slab_n = S.slab_n; f.slab_base = S.base; f.slab_lo = 0; f.slab_hi = 0;
+                    for (int c = 0; c < 4; c++) { f.slab_lo |= (uint32_t)S.lo[c] << (8 * c); f.slab_hi |= (uint32_t)S.hi[c] << (8 * c); }
                     has_slab[i] = 1;
                 }
             });
@@ -517,8 +634,32 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
                 }
             }
             out.root_slab = has_slab[0] != 0;
-            pt.lap("slabs");
+        } else {
+            parallel_for(out.nodes_q8.size(), [&](size_t i0, size_t i1) {
+                for (size_t i = i0; i < i1; i++) {
+                    flat8_node& f = out.nodes_q8[i];
+                    uint8_t ql[3][8], qh[3][8];
+                    const uint32_t* qlw[3] = { f.qlo_x, f.qlo_y, f.qlo_z }; const uint32_t* qhw[3] = { f.qhi_x, f.qhi_y, f.qhi_z };
+                    for (int k = 0; k < 3; k++) for (int c = 0; c < 8; c++) { ql[k][c] = (uint8_t)(qlw[k][c >> 2] >> (8 * (c & 3))); qh[k][c] = (uint8_t)(qhw[k][c >> 2] >> (8 * (c & 3))); }
+                    const uint32_t leafm = (f.base_b >> 24) & ~(uint32_t)f.imask, exist = leafm | f.imask;
+                    slab_codes S;
+                    if (!make_slab(f.origin, f.e, exist, leafm, ql, qh, &out.child_links[i * 8], S)) continue;
+                    f.slab_n = S.slab_n; f.slab_base = S.base; f.slab_lo[0] = f.slab_lo[1] = f.slab_hi[0] = f.slab_hi[1] = 0;
+                    for (int c = 0; c < 8; c++) { f.slab_lo[c >> 2] |= (uint32_t)S.lo[c] << (8 * (c & 3)); f.slab_hi[c >> 2] |= (uint32_t)S.hi[c] << (8 * (c & 3)); }
+                    has_slab[i] = 1;
+                }
+            });
+            // B of an inner slot: the child node has leaf slots or a slab — a step on it loads q5 too, and a lane that holds a parked leaf group waits before it (flat8.h)
+            auto heavy = [&](size_t k) { const flat8_node& c = out.nodes_q8[k]; return has_slab[k] || ((c.base_b >> 24) & ~(uint32_t)c.imask) != 0u; };
+            for (size_t i = 0; i < out.nodes_q8.size(); i++) {
+                out.slab_nodes += has_slab[i];
+                for (int c = 0; c < 8; c++) { const int32_t k = out.child_links[i * 8 + c]; if (k >= 0 && (uint32_t)k != none && heavy((size_t)k)) out.nodes_q8[i].base_b |= 1u << (24 + c); }
+            }
+            out.root_slab = heavy(0);
         }
+        pt.lap("slabs");
+    }
+    if (out.format == kFlatQ4) {
         // Slots without a child.  Their box is inverted, which the slab test rejects — unless the ray origin is so far from a small node (~2^16 node extents) that
         // entry and exit plane round to the same distance on every axis; then the kernel follows the slot's link.  It must lead somewhere harmless: the link of a
         // slot that exists (a second visit of a sibling finds nothing new).  Implied links: an empty slot's nibble is 0, which is the node's first inner child; a node
@@ -539,7 +680,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     }
     if (!key.empty()) {
         cache_writer wr("flat", key);
-        if (wr.active()) { wr.value(out.format); wr.value(out.max_depth); { const int cl = out.compact_links ? 1 : 0; wr.value(cl); } wr.vector(out.nodes); wr.vector(out.nodes_f4); wr.vector(out.nodes_f2); wr.vector(out.leaves); wr.vector(out.child_links); { const int rs = out.root_slab ? 1 : 0; wr.value(rs); const uint64_t sn = out.slab_nodes; wr.value(sn); } wr.commit(); pt.lap("cache write"); }
+        if (wr.active()) { wr.value(out.format); wr.value(out.max_depth); { const int cl = out.compact_links ? 1 : 0; wr.value(cl); } wr.vector(out.nodes); wr.vector(out.nodes_q8); wr.vector(out.nodes_f4); wr.vector(out.nodes_f2); wr.vector(out.leaves); wr.vector(out.child_links); { const int rs = out.root_slab ? 1 : 0; wr.value(rs); const uint64_t sn = out.slab_nodes; wr.value(sn); } wr.commit(); pt.lap("cache write"); }
     }
     return true;
 }

@@ -7,6 +7,7 @@
 // which entries are looked at.
 #pragma once
 #include "../../include/ctl_amd.h"
+#include "flat8.h"
 #include <vector>
 #include <cstddef>
 
@@ -25,6 +26,7 @@ enum flat_format : int {
     kFlatQ4 = 0,   // 4-wide, 64 B, child boxes quantised to 8 bits against the node's own box
     kFlatF4 = 1,   // 4-wide, 128 B (one L2 line), fp32 child boxes stored plane-major
     kFlatF2 = 2,   // 2-wide, 64 B, fp32 child boxes: the reference's BVHNodeData layout (Engine/TriIntersectorData.h:42-117)
+    kFlatQ8 = 3,   // 8-wide, 128 B (one L2 line, 96 B used), 8-bit child boxes, one-triangle leaf slots, octant-ordered slots (flat8.h)
 };
 
 // Q4.  Child box c, axis k:  lo = origin[k] + 2^(e[k]-127) * qlo[k][c],  hi = origin[k] + 2^(e[k]-127) * qhi[k][c]  (conservative).
@@ -97,6 +99,7 @@ static_assert(sizeof(flat4f_node) == 128, "fp32 wide node is one 128-B L2 line")
 
 struct flat_scene {
     int format = kFlatQ4;
+    std::vector<flat8_node> nodes_q8;     // kFlatQ8; node 0 is the root
     std::vector<flat4_node> nodes;        // kFlatQ4; node 0 is the root
     std::vector<flat4f_node> nodes_f4;    // kFlatF4
     std::vector<ctl_bvh_node> nodes_f2;   // kFlatF2 (child >= 0: node index * 4)
@@ -106,8 +109,8 @@ struct flat_scene {
     std::vector<int32_t> child_links;     // Q4: 4 explicit links per node (as flat4_node::child), host side only
     bool root_slab = false;               // Q4: the root node itself carries a slab (single-node trees)
     size_t slab_nodes = 0;                // Q4: nodes that carry a slab
-    size_t node_bytes() const { return nodes.size() * sizeof(flat4_node) + nodes_f4.size() * sizeof(flat4f_node) + nodes_f2.size() * sizeof(ctl_bvh_node); }
-    int stack_need() const { return format == kFlatF2 ? max_depth + 2 : 3 * max_depth + 2; }   // traversal-stack entries a ray can need
+    size_t node_bytes() const { return nodes.size() * sizeof(flat4_node) + nodes_f4.size() * sizeof(flat4f_node) + nodes_f2.size() * sizeof(ctl_bvh_node) + nodes_q8.size() * sizeof(flat8_node); }
+    int stack_need() const { return (format == kFlatF2 || format == kFlatQ8) ? max_depth + 2 : 3 * max_depth + 2; }   // traversal-stack entries a ray can need (Q8: one sibling group per level)
 };
 
 // false when the scene has no triangles or more than `max_triangles` instanced triangles

@@ -5,6 +5,7 @@
 #include "kernels.h"
 #include "traverse.h"
 #include "traverse_flat.h"
+#include "traverse_flat8.h"
 #include "knobs.h"
 #include <stdexcept>
 #include "shading.h"
@@ -55,6 +56,8 @@ __global__ __launch_bounds__(kWideBlock) void k_raygen(dev_scene S, wave_queues 
 #ifndef CTL_INTERSECT_MIN_WAVES
 #define CTL_INTERSECT_MIN_WAVES 7   // waves per SIMD the register allocation of the FLATTENED traversal kernels leaves room for (72 VGPRs, no spills; the two-level kernels stay at 6: 24 KiB of LDS stack).  Measured with the slab build (profiles/r03_occupancy.log): 6 (80 VGPRs) 18.71 ms per fused launch, 7: 18.25, 8 (64 VGPRs, 11 spilled) 20.98; fewer resident workgroups (LDS padding): 5: 20.1, 4: 22.7, 3: 27.4
 #endif
+// ints of LDS a traversal workgroup keeps for its lanes' stacks
+constexpr int lds_stack_ints(int layout) { return (layout == 1 + kFmtQ8 ? (kQ8LdsRows + 1) * 2 : layout ? (kFlatLdsRows + 1) * kFlatStackInts : kLdsStack) * kBlock; }
 template <bool ANY_HIT, bool COUNT, int LAYOUT, bool ALPHA>   // LAYOUT: 0 two-level, 1 + flat_format for the flattened structure; ALPHA: alpha-test candidate hits
 #ifdef CTL_INTERSECT_EXACT_WAVES   // measurement builds: hold the traversal kernels to exactly this many waves per SIMD
 #define CTL_INTERSECT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(CTL_INTERSECT_EXACT_WAVES, CTL_INTERSECT_EXACT_WAVES)))
@@ -64,13 +67,13 @@ template <bool ANY_HIT, bool COUNT, int LAYOUT, bool ALPHA>   // LAYOUT: 0 two-l
 __global__ __launch_bounds__(kBlock, ((LAYOUT && !ALPHA) ? CTL_INTERSECT_MIN_WAVES : 6)) CTL_INTERSECT_WAVES_ATTR void k_intersect(dev_scene S, const float4* __restrict__ ro, const float4* __restrict__ rd, const uint32_t* __restrict__ n_ptr,
                                                        uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ,
                                                        unsigned long long* __restrict__ counts3) {
-    __shared__ int lds_stack[(LAYOUT ? (kFlatLdsRows + 1) * kFlatStackInts : kLdsStack) * kBlock];   // flat: + one spare row that absorbs unused push slots
+    __shared__ __attribute__((aligned(8))) int lds_stack[lds_stack_ints(LAYOUT)];   // flat: + one spare row that absorbs unused push slots
     __shared__ uint16_t lds_dist[(LAYOUT && CTL_STACK_DIST >= 2) ? (kFlatLdsRows + 1) * kBlock : 1];
     __shared__ __attribute__((aligned(16))) float lds_top[LAYOUT ? kTopCacheFloats : 4];
     const uint32_t n = *n_ptr;
     trav_counts tc{ 0, 0, 0, 0, 0 };
-    if (LAYOUT) fill_top_cache(S, lds_top);
-    if (LAYOUT) intersect_flat<ANY_HIT, COUNT, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, lds_top, tc, lds_dist);
+    if (LAYOUT == 1 + kFmtQ8) intersect_flat8<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, (unsigned long long*)lds_stack, tc);
+    else if (LAYOUT) { fill_top_cache(S, lds_top); intersect_flat<ANY_HIT, COUNT, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, lds_top, tc, lds_dist); }
     else intersect_persistent<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
     if (COUNT) {
         atomicAdd(&counts3[0], (unsigned long long)tc.n_inner); atomicAdd(&counts3[1], (unsigned long long)tc.n_tri); atomicAdd(&counts3[2], (unsigned long long)tc.n_inst);
@@ -86,12 +89,15 @@ __global__ __launch_bounds__(kBlock, ((LAYOUT && !ALPHA) ? CTL_INTERSECT_MIN_WAV
                                                             uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node,
                                                             const float4* __restrict__ sro, const float4* __restrict__ srd, const uint32_t* __restrict__ sn_ptr,
                                                             uint32_t* __restrict__ swork, uint32_t* __restrict__ occ) {
-    __shared__ int lds_stack[(LAYOUT ? (kFlatLdsRows + 1) * kFlatStackInts : kLdsStack) * kBlock];
+    __shared__ __attribute__((aligned(8))) int lds_stack[lds_stack_ints(LAYOUT)];
     __shared__ uint16_t lds_dist[(LAYOUT && CTL_STACK_DIST >= 2) ? (kFlatLdsRows + 1) * kBlock : 1];
     __shared__ __attribute__((aligned(16))) float lds_top[LAYOUT ? kTopCacheFloats : 4];
     const uint32_t n = *n_ptr, sn = *sn_ptr;
     trav_counts tc{ 0, 0, 0, 0, 0 };
-    if (LAYOUT) {
+    if (LAYOUT == 1 + kFmtQ8) {
+        intersect_flat8<false, false, ALPHA>(S, ro, rd, n, work, hit, hit_node, nullptr, (unsigned long long*)lds_stack, tc);
+        intersect_flat8<true, false, ALPHA>(S, sro, srd, sn, swork, nullptr, nullptr, occ, (unsigned long long*)lds_stack, tc);
+    } else if (LAYOUT) {
         fill_top_cache(S, lds_top);
         intersect_flat<false, false, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, nullptr, lds_stack, lds_top, tc, lds_dist);
         intersect_flat<true, false, ALPHA, LAYOUT - 1>(S, sro, srd, sn, swork, nullptr, nullptr, occ, lds_stack, lds_top, tc, lds_dist);
@@ -241,12 +247,14 @@ void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& 
         if (!S.flat_nodes) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 0, __VA_ARGS__);                                                         \
         else if (S.flat_format == kFmtF4) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 2, __VA_ARGS__);                                          \
         else if (S.flat_format == kFmtQ4) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 1, __VA_ARGS__);                                          \
+        else if (S.flat_format == kFmtQ8) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 4, __VA_ARGS__);                                          \
         else CTL_LAUNCH_INTERSECT_L(ANY, CNT, 3, __VA_ARGS__);                                                                       \
     } while (0)
 #else
 #define CTL_LAUNCH_INTERSECT(ANY, CNT, ...)                                                                                          \
     do {                                                                                                                             \
         if (!S.flat_nodes) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 0, __VA_ARGS__);                                                         \
+        else if (S.flat_format == kFmtQ8) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 4, __VA_ARGS__);                                          \
         else CTL_LAUNCH_INTERSECT_L(ANY, CNT, 1, __VA_ARGS__);                                                                       \
     } while (0)
 #endif
@@ -261,6 +269,9 @@ void launch_intersect_pair(const launch_ctx& lc, const dev_scene& S, const float
     if (!S.flat_nodes) {
         if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<0, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
         else hipLaunchKernelGGL((k_intersect_pair<0, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+    } else if (S.flat_format == kFmtQ8) {
+        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<4, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        else hipLaunchKernelGGL((k_intersect_pair<4, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
     } else {
         if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<1, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
         else hipLaunchKernelGGL((k_intersect_pair<1, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);

@@ -8,16 +8,22 @@
 #include "compaction.h"
 #include "tracer.h"
 #include "traverse_flat.h"
+#include "traverse_flat8.h"
 #include "mitsuba_loader.h"   // unsupported_error
 #include <climits>
 
 namespace ctl {
 
-// single-ray traversal of the flattened BVH (traverse_flat.h): closest hit, or any hit in (tmin, tmax)
+// single-ray traversal of the flattened BVH (traverse_flat8.h for the 8-wide format, traverse_flat.h for the 4-wide one): closest hit, or any hit in (tmin, tmax).
+// ONE LDS array serves both instantiations: a lane is never in a closest-hit and an any-hit search at the same time (20 KiB per 256-lane workgroup, not 40).
+__device__ __forceinline__ lds_int* single_stack_column() {
+    __shared__ int s_stack[kSingleLdsRows * 256];   // one column per lane of the 256-lane workgroup
+    return (lds_int*)s_stack + threadIdx.x;
+}
 template <bool ANY_HIT>
 __device__ __noinline__ bool trace_single(const dev_scene& S, f3 o, f3 d, float tmin, float tmax, float& ht, float& hu, float& hv, int& htri, int& hnode) {
-    __shared__ int s_stack[kSingleLdsRows * 256];   // one column per lane of the 256-lane workgroup (both instantiations: 2 x 20 KiB)
-    return trace_single_flat<ANY_HIT, true>(S, (lds_int*)s_stack + threadIdx.x, o, d, tmin, tmax, ht, hu, hv, htri, hnode);
+    if (S.flat_format == kFmtQ8) return trace_single_flat8<ANY_HIT, true>(S, single_stack_column(), o, d, tmin, tmax, ht, hu, hv, htri, hnode);
+    return trace_single_flat<ANY_HIT, true>(S, single_stack_column(), o, d, tmin, tmax, ht, hu, hv, htri, hnode);
 }
 
 // pathKernel2<DIRECT> + PathTrace<DIRECT> (Integrators/PathTracer.cu:182-194, 10-113), no participating media

@@ -278,11 +278,12 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
         // node format: Q4 (64-B 4-wide nodes with 8-bit child boxes) unless the caller or $CTL_FLAT_FORMAT asks for F4 / F2 (DESIGN.md §3 has the measurements)
         flat_scene F;
         if (flatten_scene(d, F, (size_t)1 << 30, flat_format < 0 ? default_flat_format() : flat_format)) {   // up to 2^30 instanced triangles (64 GiB of leaf entries)
-            if (F.stack_need() + 2 > kStackSize) throw std::runtime_error("ctl_scene_create: flattened BVH too deep for the traversal stack");
+            if (F.stack_need() + 2 > (F.format == kFlatQ8 ? kFlat8StackGroups : kStackSize)) throw std::runtime_error("ctl_scene_create: flattened BVH too deep for the traversal stack");
 #ifndef CTL_FLAT_EXPERIMENTS
-            if (F.format != kFlatQ4) throw unsupported_error("ctl_scene_create: the F4 / F2 node formats are measurement builds (-DCTL_FLAT_EXPERIMENTS)");
+            if (F.format != kFlatQ4 && F.format != kFlatQ8) throw unsupported_error("ctl_scene_create: the F4 / F2 node formats are measurement builds (-DCTL_FLAT_EXPERIMENTS)");
 #endif
             if (F.format == kFlatQ4) flat_nodes_.upload((const float4*)F.nodes.data(), F.nodes.size() * 4);
+            else if (F.format == kFlatQ8) flat_nodes_.upload((const float4*)F.nodes_q8.data(), F.nodes_q8.size() * 8);
             else if (F.format == kFlatF4) flat_nodes_.upload((const float4*)F.nodes_f4.data(), F.nodes_f4.size() * 8);
             else flat_nodes_.upload((const float4*)F.nodes_f2.data(), F.nodes_f2.size() * 4);
             for (const flat_leaf& L : F.leaves) if (L.node >= d.n_nodes) throw std::runtime_error("ctl_scene_create: flattened leaf entry out of range");
@@ -292,7 +293,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
             S.inst_w_one = 1; for (uint32_t k = 0; k < d.n_nodes; k++) if (d.node_inv_transforms[k].m[15] != 1.0f) S.inst_w_one = 0;
             CTL_HIP(hipDeviceSynchronize());
             S.flat_nodes = flat_nodes_.p; S.flat_leaves = flat_leaves_.p; S.flat_format = F.format; S.flat_compact = (F.format == kFlatQ4 && F.compact_links) ? 1 : 0;
-            S.flat_root = (S.flat_compact && F.root_slab) ? 1 : 0;   // bit 0 of an inner link: the node carries an oriented slab (flat_slab.h)
+            S.flat_root = ((S.flat_compact || F.format == kFlatQ8) && F.root_slab) ? 1 : 0;   // bit 0 of an inner link: the node carries an oriented slab (flat_slab.h); Q8 links are node index << 1 | that bit
             S.flat_top_cached = S.flat_compact ? (int)std::min<size_t>(F.nodes.size(), (size_t)flat_top_cache_nodes()) : 0;
         }
     }

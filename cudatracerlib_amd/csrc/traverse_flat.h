@@ -24,7 +24,7 @@
 
 namespace ctl {
 
-enum { kFmtQ4 = 0, kFmtF4 = 1, kFmtF2 = 2 };   // = flat_format (flatten.h)
+enum { kFmtQ4 = 0, kFmtF4 = 1, kFmtF2 = 2, kFmtQ8 = 3 };   // = flat_format (flatten.h); Q8 has its own kernel body (traverse_flat8.h)
 
 // Measured and NOT shipped (round 3, tools/ab_libs.sh r03e, same box): the first kTopCache nodes of the node array — the top of the tree, which flatten.cpp stores breadth-first:
 // 85 = four full levels — copied into LDS by every traversal workgroup (48 B each; a node with a slab goes the global way).  Counted by the oracle on the bench scene

@@ -321,7 +321,8 @@ int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out);
 enum { CTL_SCENE_FLATTEN = 1 };
 enum { CTL_FLAT_Q4 = 0,    /* 4-wide, 64-B nodes, 8-bit child boxes (default) */
        CTL_FLAT_F4 = 1,    /* 4-wide, 128-B nodes, fp32 child boxes           */
-       CTL_FLAT_F2 = 2 };  /* 2-wide, 64-B nodes in the reference's BVHNodeData layout */
+       CTL_FLAT_F2 = 2,    /* 2-wide, 64-B nodes in the reference's BVHNodeData layout */
+       CTL_FLAT_Q8 = 3 };  /* 8-wide, 128-B nodes, 8-bit child boxes, octant-ordered slots, one-triangle leaf slots (csrc/flat8.h) */
 #define CTL_SCENE_FLAT_FORMAT(f) ((((uint32_t)(f)) + 1u) << 8)
 int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out);
 void ctl_scene_destroy(ctl_scene* s);
@@ -340,9 +341,9 @@ typedef struct {
     uint32_t format, max_depth;      /* CTL_FLAT_*, depth of the stored tree                                      */
     const void* nodes; uint64_t n_nodes; uint32_t node_bytes;   /* node 0 is the root; child >= 0: node index * node_bytes / 16 */
     const void* leaves; uint64_t n_leaves;   /* 128 B each: object-space Woop rows a,b,c, {globalTri << 1 | last, node, 0, 0}, rows 0..2 of the node's inverse transform, {w33,0,0,0} */
-    const int32_t* child_links;      /* CTL_FLAT_Q4: 4 explicit links per node (>= 0: node index * 4, < 0: ~first leaf entry, 0x76543210: none), else NULL */
-    uint32_t compact;                /* CTL_FLAT_Q4: 1 = the kernels derive the links from the layout (flat4_node::links) and the nodes' last 16 B hold oriented slabs */
-    uint32_t root_slab;              /* CTL_FLAT_Q4: the root node carries a slab (bit 0 of the link a traversal starts with)            */
+    const int32_t* child_links;      /* CTL_FLAT_Q4: 4 explicit links per node (>= 0: node index * 4, < 0: ~first leaf entry, 0x76543210: none); CTL_FLAT_Q8: 8 per node, slot order (>= 0: node index); else NULL */
+    uint32_t compact;                /* CTL_FLAT_Q4: 1 = the kernels derive the links from the layout (flat4_node::links) and the nodes' last 16 B hold oriented slabs; CTL_FLAT_Q8: always 1 */
+    uint32_t root_slab;              /* the root node carries a slab (Q4: bit 0 of the link a traversal starts with; Q8: the root's q5 is loaded)            */
     uint64_t n_slab_nodes;           /* nodes that carry an oriented slab (flat_slab.h)                                                  */
 } ctl_flat_bvh_desc;
 int ctl_flat_bvh_build(const ctl_scene_desc* desc, uint32_t format, ctl_flat_bvh** out);

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include "omath.h"
 #include "../include/ctl_amd.h"   // boundary structs only (data layout contract)
+#include "../cudatracerlib_amd/csrc/flat8.h"   // layout + link decode of the product's 8-wide node (a data-layout contract as well: the mirror below restates the arithmetic)
 #include <vector>
 #include <stdexcept>
 
@@ -144,7 +145,98 @@ inline bool alphaSurvive(const Scene& S, uint32_t tri, uint32_t nodeIdx, float u
 inline bool g_slab_probe = false; inline std::atomic<uint64_t> g_slab_tests{ 0 }, g_slab_rejects{ 0 };
 // same switch: node visits by the node's position in the array (the top of the tree is stored breadth-first): bucket b counts visits of nodes with index < g_top_probe_limits[b]
 inline const uint32_t g_top_probe_limits[8] = { 85u, 256u, 341u, 512u, 1365u, 5461u, 65536u, 0xffffffffu }; inline std::atomic<uint64_t> g_top_probe[8];
+// The product's 8-wide node format (CTL_FLAT_Q8, cudatracerlib_amd/csrc/flat8.h): octant-ordered slots, one sibling group per level on the stack, the leaf slots a step hits
+// tested before its inner children are entered.  Same culling arithmetic as the 4-wide mirror below (8-bit boxes, the oriented slab as a fourth axis), restated.
+// $ORC_Q8_ORDER = dist (what-if): children nearest first by entry distance instead of by octant, to price the octant order.
+inline bool traceRayFlat8(const Scene& S, V3 ori, V3 dir, float tmin_tri, float tmax, bool any_hit, float node_tmin, Hit& res, TravCounts* cnt) {
+    const ctl_scene_desc& g = S.d; const ctl_flat_bvh_desc& F = *S.flat;
+    res.init(); res.dist = tmax;
+    if (!F.n_nodes || !F.n_leaves) return false;
+    static const bool by_dist = [] { const char* e = getenv("ORC_Q8_ORDER"); return e && !strcmp(e, "dist"); }();
+    const float ooeps = exp2f(-80.0f), inf = INFINITY;
+    const float idx = 1.0f / (fabsf(dir.x) > ooeps ? dir.x : copysign_bits(ooeps, dir.x)), idy = 1.0f / (fabsf(dir.y) > ooeps ? dir.y : copysign_bits(ooeps, dir.y)),
+                idz = 1.0f / (fabsf(dir.z) > ooeps ? dir.z : copysign_bits(ooeps, dir.z));
+    const float oox = ori.x * idx, ooy = ori.y * idy, ooz = ori.z * idz;
+    const int sx = idx < 0.0f, sy = idy < 0.0f, sz = idz < 0.0f;
+    const uint32_t octinv = (sx ? 0u : 1u) | (sy ? 0u : 2u) | (sz ? 0u : 4u);
+    const uint32_t* nodes = (const uint32_t*)F.nodes; const uint32_t* leaves = (const uint32_t*)F.leaves;
+    struct group { uint32_t base_b, imask, hits; };          // hits in visiting order (flat8_to_order): the highest set bit first
+    std::vector<group> stack((size_t)F.max_depth + 8); int sp = 0;
+    std::vector<std::pair<float, uint32_t>> dstack;          // by_dist: (entry distance, node link) singles
+    bool found = false;
+    uint32_t node = F.root_slab ? 1u : 0u;                   // link = node index << 1 | "load q5" (flat8.h B of an inner slot)
+    group cur{ 0, 0, 0 };
+    auto p2 = [](uint32_t e) { uint32_t b = e << 23; float f; std::memcpy(&f, &b, 4); return f; };
+    for (;;) {
+        if (cnt) cnt->n_inner++;
+        const uint32_t* w = nodes + (size_t)(node >> 1) * 32; const float* pf = (const float*)w;
+        const uint32_t q0w = w[3], base_b = w[4], leaf_base = w[5];
+        const uint32_t imask = ctl::flat8_inner_mask(q0w), lmask = ctl::flat8_leaf_mask(q0w, base_b);
+        const float ax = p2(q0w & 0xffu) * idx, ay = p2((q0w >> 8) & 0xffu) * idy, az = p2((q0w >> 16) & 0xffu) * idz;
+        const float bx = std::fmaf(pf[0], idx, -oox), by = std::fmaf(pf[1], idy, -ooy), bz = std::fmaf(pf[2], idz, -ooz);
+        const uint32_t* lox = w + 8, *loy = w + 10, *loz = w + 12, *hix = w + 14, *hiy = w + 16, *hiz = w + 18;
+        const uint32_t *nx = sx ? hix : lox, *fx = sx ? lox : hix, *ny = sy ? hiy : loy, *fy = sy ? loy : hiy, *nz = sz ? hiz : loz, *fz = sz ? loz : hiz;
+        float s_alpha = 0.0f, s_bn = -inf, s_bf = inf; const uint32_t zero2[2] = { 0u, 0u }; const uint32_t *s_nw = zero2, *s_fw = zero2;
+        if ((node & 1u) && w[6] != 0u) {   // the node's oriented slab (csrc/flat_slab.h), a fourth slab axis
+            const uint32_t nw = w[6];
+            auto s6 = [](uint32_t v) { return (float)((int)(v & 63u) - (int)((v & 32u) << 1)); };
+            uint32_t sb = nw & 0xfffc0000u; float step; std::memcpy(&step, &sb, 4);
+            const float snx = s6(nw), sny = s6(nw >> 6), snz = s6(nw >> 12), base = pf[7];
+            const float ex = ori.x - pf[0], ey = ori.y - pf[1], ez = ori.z - pf[2];
+            const float sdot = std::fmaf(snz, ez, std::fmaf(sny, ey, snx * ex)), rdot = std::fmaf(snz, dir.z, std::fmaf(sny, dir.y, snx * dir.x));
+            const float rr = 1.0f / (fabsf(rdot) > ooeps ? rdot : copysign_bits(ooeps, rdot));
+            const float pad = (fabsf(ex) + fabsf(ey) + fabsf(ez)) * (31.0f * 1.9073486328125e-6f), u = base - sdot;
+            const bool neg = rr < 0.0f;
+            s_alpha = step * rr; s_bn = (neg ? u + pad : u - pad) * rr; s_bf = (neg ? u - pad : u + pad) * rr;
+            s_nw = neg ? w + 22 : w + 20; s_fw = neg ? w + 20 : w + 22;
+        }
+        uint32_t hits = 0; float dd[8];
+        for (int k = 0; k < 8; k++) {
+            auto code = [&](const uint32_t* a) { return (float)((a[k >> 2] >> (8 * (k & 3))) & 0xffu); };
+            const float tnx = std::fmaf(code(nx), ax, bx), tfx = std::fmaf(code(fx), ax, bx), tny = std::fmaf(code(ny), ay, by), tfy = std::fmaf(code(fy), ay, by);
+            const float tnz = std::fmaf(code(nz), az, bz), tfz = std::fmaf(code(fz), az, bz);
+            const float tns = std::fmaf(code(s_nw), s_alpha, s_bn), tfs = std::fmaf(code(s_fw), s_alpha, s_bf);
+            const float cmin = fmax2(fmax2(fmax2(tnx, tny), fmax2(tnz, node_tmin)), tns), cmax = fmin2(fmin2(fmin2(tfx, tfy), fmin2(tfz, res.dist)), tfs);
+            dd[k] = cmin;
+            if (cmax >= cmin) hits |= 1u << k;
+        }
+        // leaf slots first, in visiting order
+        for (uint32_t lo = ctl::flat8_to_order(hits & lmask, octinv); lo;) {
+            const uint32_t bit = 31u - (uint32_t)__builtin_clz(lo); lo &= ~(1u << bit);
+            const uint32_t slot = bit ^ octinv, entry = ctl::flat8_leaf_entry(leaf_base, lmask, slot);
+            const uint32_t* e = leaves + (size_t)entry * 32;
+            const uint32_t index = e[12], nodeIdx = e[13];
+            if (cnt) cnt->n_tri++;
+            ctl_woop_tri wt; std::memcpy(&wt, e, 48);
+            M44 modl; std::memcpy(modl.d, g.node_inv_transforms[nodeIdx].m, 64);
+            const V3 d = transformDir(modl, dir), o = transformPoint(modl, ori);   // TraceHelper.cu:526-560 (per entry here; per instance there)
+            float t, u, v;
+            if (woopIntersect(wt, o, d, tmin_tri, res.dist, t, u, v) && (!S.alpha_test || alphaSurvive(S, index >> 1, nodeIdx, u, v))) {
+                res.node = nodeIdx; res.tri = index >> 1; res.u = u; res.v = v; res.dist = t; found = true;
+                if (any_hit) return true;
+            }
+        }
+        const uint32_t inner = hits & imask;
+        if (by_dist) {
+            std::pair<float, uint32_t> c[8]; int n = 0;
+            for (uint32_t s = 0; s < 8; s++) if ((inner >> s) & 1u) c[n++] = { dd[s], (ctl::flat8_child_node(base_b, imask, s) << 1) | ((base_b >> (24 + s)) & 1u) };
+            std::sort(c, c + n, [](const auto& a, const auto& b) { return a.first > b.first; });   // farthest first: the nearest is pushed last
+            for (int i = 0; i < n; i++) dstack.push_back(c[i]);
+            if (dstack.empty()) return found;
+            node = dstack.back().second; dstack.pop_back();
+            continue;
+        }
+        const uint32_t ordered = ctl::flat8_to_order(inner, octinv);
+        if (ordered) { if (cur.hits) stack[++sp] = cur; cur = group{ base_b, imask, ordered }; }
+        else if (!cur.hits) { if (sp == 0) return found; cur = stack[sp--]; }
+        const uint32_t bit = 31u - (uint32_t)__builtin_clz(cur.hits); cur.hits &= ~(1u << bit);
+        const uint32_t slot = bit ^ octinv;
+        node = (ctl::flat8_child_node(cur.base_b, cur.imask, slot) << 1) | ((cur.base_b >> (24 + slot)) & 1u);
+    }
+}
+
 inline bool traceRayFlat(const Scene& S, V3 ori, V3 dir, float tmin_tri, float tmax, bool any_hit, float node_tmin, Hit& res, TravCounts* cnt) {
+    if (S.flat->format == CTL_FLAT_Q8) return traceRayFlat8(S, ori, dir, tmin_tri, tmax, any_hit, node_tmin, res, cnt);
     const ctl_scene_desc& g = S.d; const ctl_flat_bvh_desc& F = *S.flat;
     res.init(); res.dist = tmax;
     if (!F.n_nodes || !F.n_leaves) return false;

@@ -1,5 +1,5 @@
 """N > 1 path on CPU: two processes over gloo run the host logic bench.py uses for multi-GPU — tile ownership, a
-per-rank full-size PixelData frame, ONE sum-reduce to rank 0 (cudatracerlib_amd/parallel.py).  The per-rank radiance
+per-rank full-size PixelData frame, ONE sum-reduce to rank 0 (tests/tile_shards.py).  The per-rank radiance
 comes from the oracle (the GPUs are not here); what is tested is that the shards partition the film and that the single
 collective reproduces the one-rank frame exactly."""
 import os
@@ -19,7 +19,8 @@ def _worker(rank, world, port, w, h, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle
-    from cudatracerlib_amd import scenes, parallel
+    from cudatracerlib_amd import scenes
+    import tile_shards as parallel
     sc = scenes.cornell_box(w, h)
     orc = oracle.Oracle()
     tables = orc.sequence_tables(1)
@@ -34,7 +35,7 @@ def _worker(rank, world, port, w, h, out_path):
 
 
 def test_tile_ownership_partitions_the_film():
-    from cudatracerlib_amd import parallel
+    import tile_shards as parallel
     for (w, h, world) in ((192, 128, 2), (1920, 1080, 8), (100, 70, 3)):
         own = parallel.tile_owner(w, h, world)
         assert own.shape == (h, w) and own.min() == 0 and own.max() == min(world, ((w + 63) // 64) * ((h + 63) // 64)) - 1

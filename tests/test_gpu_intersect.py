@@ -92,7 +92,7 @@ def check_flat(gpu, orc, desc, rays, any_hit, fmt):
     return got
 
 
-@pytest.mark.parametrize("fmt", ["q4"])   # f4 / f2 are measurement builds (-DCTL_FLAT_EXPERIMENTS)
+@pytest.mark.parametrize("fmt", ["q8", "q4"])   # f4 / f2 are measurement builds (-DCTL_FLAT_EXPERIMENTS)
 @pytest.mark.parametrize("any_hit", [False, True])
 def test_flattened_world_space_bvh(gpu, orc, any_hit, fmt):
     """CTL_SCENE_FLATTEN: one world-space BVH over all instanced triangles, every node format.  The tree only culls — each leaf entry is
@@ -161,7 +161,7 @@ def test_flattened_cornell_and_ragged(gpu, orc):
         assert np.array_equal(got["tri_idx"], want["tri_idx"]) and np.array_equal(got["dist"].view(np.uint32), want["dist"].view(np.uint32))
 
 
-@pytest.mark.parametrize("fmt", ["q4"])
+@pytest.mark.parametrize("fmt", ["q8", "q4"])
 def test_flattened_counts_against_the_oracle_on_the_same_arrays(gpu, orc, fmt):
     """N_inner / N_tri from the CPU restatement in counting mode with the SAME BVH.  The oracle walks the product's own
     flattened arrays depth-first; the kernel postpones leaves and descends speculatively, so it may visit somewhat more nodes, never fewer

@@ -19,13 +19,13 @@ def rays_for(desc, n, seed):
     return r
 
 
-@pytest.mark.parametrize("fmt", [api.FLAT_Q4, api.FLAT_F4, api.FLAT_F2])
+@pytest.mark.parametrize("fmt", [api.FLAT_Q8, api.FLAT_Q4, api.FLAT_F4, api.FLAT_F2])
 def test_flat_traversal_equals_two_level(orc, fmt):
     for sc, n in ((scenes.synthetic_sm(32, 32, n_instances=60, subdiv=2), 6000), (scenes.cornell_box(32, 32, glass_sphere=True), 4000)):
         d = sc.desc
         rays = rays_for(d, n, 5)
         fb = api.FlatBvh(d, fmt)
-        assert fb.desc.format == fmt and fb.desc.n_leaves > 0 and fb.desc.node_bytes == (128 if fmt == api.FLAT_F4 else 64)
+        assert fb.desc.format == fmt and fb.desc.n_leaves > 0 and fb.desc.node_bytes == (128 if fmt in (api.FLAT_F4, api.FLAT_Q8) else 64)
         want, c2 = orc.intersect(d, rays, count=True)
         got, cf = orc.intersect(d, rays, count=True, flat=fb.desc)
         ties = (got["tri_idx"] != want["tri_idx"]) & (got["dist"] == want["dist"])
@@ -104,6 +104,53 @@ def check_implied_links(fb):
 def test_implied_child_links_of_the_quantised_nodes(orc):
     for sc in (scenes.synthetic_sm(32, 32, n_instances=40, subdiv=2), scenes.cornell_box(32, 32, glass_sphere=True)):
         check_implied_links(api.FlatBvh(sc.desc, api.FLAT_Q4))
+
+
+def check_q8_layout(fb):
+    """flat8_node (csrc/flat8.h): the links a traversal step derives — inner child = first inner child + rank of the slot among the inner slots, leaf entry = first entry of
+    the node + rank among the leaf slots — are the explicit links; every leaf slot is ONE entry; empty slots carry inverted boxes; B of an inner slot = the child has leaf
+    slots or a slab; slots are octant-ordered (the child on the + side of an axis sits in a slot with that axis' bit set more often than not)"""
+    N = fb.nodes(); L = fb.leaves(); ch = fb.child_links()
+    assert N.shape[1] == 32 and ch.shape == (len(N), 8) and fb.desc.compact == 1
+    imask = N[:, 3] >> 24; B = N[:, 4] >> 24; base = N[:, 4] & 0xffffff; leaf_base = N[:, 5]
+    lmask = B & ~imask; heavy = B & imask
+    assert (L[:, 12] & 1).all()                                     # every entry closes its leaf
+    n_in = np.zeros(len(N), np.int64); n_lf = np.zeros(len(N), np.int64)
+    has_leaf = lmask != 0; has_slab = N[:, 6] != 0
+    for s in range(8):
+        inner = ((imask >> s) & 1) == 1; leaf = ((lmask >> s) & 1) == 1; empty = ~inner & ~leaf
+        assert np.array_equal(ch[inner, s], (base + n_in)[inner].astype(np.int32))
+        assert np.array_equal(~ch[leaf, s], (leaf_base + n_lf)[leaf].astype(np.int32))
+        assert (ch[empty, s] == 0x76543210).all()
+        byte = lambda w0: (N[:, w0 + (s >> 2)] >> (8 * (s & 3))) & 255
+        for lo, hi in ((8, 14), (10, 16), (12, 18)):
+            assert (byte(lo)[empty] == 255).all() and (byte(hi)[empty] == 0).all()
+            assert (byte(lo)[~empty] <= byte(hi)[~empty]).all()
+        kids = ch[inner, s]
+        assert np.array_equal(((heavy >> s) & 1)[inner] == 1, (has_leaf | has_slab)[kids])
+        n_in += inner; n_lf += leaf
+    assert n_lf.sum() == len(L) and bool(fb.desc.root_slab) == bool(has_leaf[0] or has_slab[0]) and has_slab.sum() == fb.desc.n_slab_nodes
+    # children start right behind their parents' blocks: node 0 is the root, every other node is someone's inner child exactly once
+    refs = np.sort(ch[(ch >= 0) & (ch != 0x76543210)]); assert np.array_equal(refs, np.arange(1, len(N)))
+    # octant order: centre of the child's box (codes) against the centre of the node's children, per axis
+    agree = tot = 0
+    for axis, (lo, hi) in enumerate(((8, 14), (10, 16), (12, 18))):
+        cen = np.zeros((len(N), 8)); ex = np.zeros((len(N), 8), bool)
+        for s in range(8):
+            cen[:, s] = ((N[:, lo + (s >> 2)] >> (8 * (s & 3))) & 255).astype(float) + ((N[:, hi + (s >> 2)] >> (8 * (s & 3))) & 255)
+            ex[:, s] = ((imask | lmask) >> s) & 1 == 1
+        mean = (cen * ex).sum(1) / np.maximum(ex.sum(1), 1)
+        for s in range(8):
+            side = cen[:, s] - mean; sel = ex[:, s] & (np.abs(side) > 16)
+            agree += ((side[sel] > 0) == bool((s >> axis) & 1)).sum(); tot += sel.sum()
+    assert agree > 0.8 * tot, (agree, tot)
+
+
+def test_layout_of_the_8_wide_nodes(orc):
+    for sc in (scenes.synthetic_sm(32, 32, n_instances=40, subdiv=2), scenes.cornell_box(32, 32, glass_sphere=True)):
+        fb = api.FlatBvh(sc.desc, api.FLAT_Q8)
+        assert fb.desc.format == api.FLAT_Q8
+        check_q8_layout(fb)
 
 
 def test_render_counts_in_flat_mode(orc):

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--width", type=int, default=480); ap.add_argument("--height", type=int, default=270)
     ap.add_argument("--instances", type=int, default=2000); ap.add_argument("--subdiv", type=int, default=4)
     ap.add_argument("--workload", default="synthetic-sm")
+    ap.add_argument("--format", default="q8", choices=sorted(api.FLAT_FORMATS))
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     a = ap.parse_args()
     if a.workload == "synthetic-sm":
@@ -27,7 +28,7 @@ def main():
         sc = scenes.synthetic_bathroom(a.width, a.height)
     else:
         sc = scenes.cornell_box(a.width, a.height, glass_sphere=True)
-    t0 = time.time(); fb = api.FlatBvh(sc.desc, api.FLAT_Q4); t_build = time.time() - t0
+    t0 = time.time(); fb = api.FlatBvh(sc.desc, api.FLAT_FORMATS[a.format]); t_build = time.time() - t0
     orc = oracle.Oracle()
     import ctypes as C
     orc.lib.orc_slab_probe.argtypes = [C.c_int, C.c_void_p]
