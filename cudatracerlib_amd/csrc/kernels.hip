@@ -4,8 +4,18 @@
 // (Integrators/PathTracer.cu:10-113) re-cut at its two trace points; see DESIGN.md "Kernels".
 #include "kernels.h"
 #include "traverse.h"
+#ifdef CTL_FLAT_EXPERIMENTS
+#include "experiments/traverse_flat_variants.h"   // round 2 / 3's variant arms (F4 / F2 node formats, quad fetch, top cache, stack distances, ...) instead of the product header; no 8-wide format in such a build
+#else
 #include "traverse_flat.h"
 #include "traverse_flat8.h"
+#endif
+#ifndef CTL_LEAF_QUEUE
+#define CTL_LEAF_QUEUE 0   // 1: the 4-wide flattened traversal runs its entry tests from a wave-wide queue (experiments/traverse_flat_wq.h: measured, 38-47 % slower)
+#endif
+#if CTL_LEAF_QUEUE
+#include "experiments/traverse_flat_wq.h"
+#endif
 #include "knobs.h"
 #include <stdexcept>
 #include "shading.h"
@@ -56,8 +66,32 @@ __global__ __launch_bounds__(kWideBlock) void k_raygen(dev_scene S, wave_queues 
 #ifndef CTL_INTERSECT_MIN_WAVES
 #define CTL_INTERSECT_MIN_WAVES 7   // waves per SIMD the register allocation of the FLATTENED traversal kernels leaves room for (72 VGPRs, no spills; the two-level kernels stay at 6: 24 KiB of LDS stack).  Measured with the slab build (profiles/r03_occupancy.log): 6 (80 VGPRs) 18.71 ms per fused launch, 7: 18.25, 8 (64 VGPRs, 11 spilled) 20.98; fewer resident workgroups (LDS padding): 5: 20.1, 4: 22.7, 3: 27.4
 #endif
-// ints of LDS a traversal workgroup keeps for its lanes' stacks
-constexpr int lds_stack_ints(int layout) { return (layout == 1 + kFmtQ8 ? (kQ8LdsRows + 1) * 2 : layout ? (kFlatLdsRows + 1) * kFlatStackInts : kLdsStack) * kBlock; }
+// ints of LDS a traversal workgroup keeps for its lanes' stacks, and the body for a flattened layout (LAYOUT = 1 + flat_format)
+#ifdef CTL_FLAT_EXPERIMENTS
+constexpr int lds_stack_ints(int layout) { return (layout ? (kFlatLdsRows + 1) * kFlatStackInts : kLdsStack) * kBlock; }
+template <bool ANY_HIT, bool COUNT, int LAYOUT, bool ALPHA>
+__device__ __forceinline__ void intersect_flat_layout(const dev_scene& S, const float4* __restrict__ ro, const float4* __restrict__ rd, uint32_t n, uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack, trav_counts& tc) {
+    __shared__ uint16_t lds_dist[CTL_STACK_DIST >= 2 ? (kFlatLdsRows + 1) * kBlock : 1];
+    __shared__ __attribute__((aligned(16))) float lds_top[kTopCacheFloats];
+    fill_top_cache(S, lds_top);
+    intersect_flat<ANY_HIT, COUNT, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, lds_top, tc, lds_dist);
+}
+#else
+#if CTL_LEAF_QUEUE
+constexpr int lds_stack_ints(int layout) { return layout == 1 + kFmtQ8 ? (kQ8LdsRows + 1) * 2 * kBlock : layout == 1 + kFmtQ4 ? kWqLdsInts : kLdsStack * kBlock; }
+#else
+constexpr int lds_stack_ints(int layout) { return layout == 1 + kFmtQ8 ? (kQ8LdsRows + 1) * 2 * kBlock : (layout ? kFlatLdsRows + 1 : kLdsStack) * kBlock; }
+#endif
+template <bool ANY_HIT, bool COUNT, int LAYOUT, bool ALPHA>
+__device__ __forceinline__ void intersect_flat_layout(const dev_scene& S, const float4* __restrict__ ro, const float4* __restrict__ rd, uint32_t n, uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ, int* lds_stack, trav_counts& tc) {
+    if (LAYOUT == 1 + kFmtQ8) intersect_flat8<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, (unsigned long long*)lds_stack, tc);
+#if CTL_LEAF_QUEUE
+    else intersect_flat_wq<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
+#else
+    else intersect_flat<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
+#endif
+}
+#endif
 template <bool ANY_HIT, bool COUNT, int LAYOUT, bool ALPHA>   // LAYOUT: 0 two-level, 1 + flat_format for the flattened structure; ALPHA: alpha-test candidate hits
 #ifdef CTL_INTERSECT_EXACT_WAVES   // measurement builds: hold the traversal kernels to exactly this many waves per SIMD
 #define CTL_INTERSECT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(CTL_INTERSECT_EXACT_WAVES, CTL_INTERSECT_EXACT_WAVES)))
@@ -68,12 +102,9 @@ __global__ __launch_bounds__(kBlock, ((LAYOUT && !ALPHA) ? CTL_INTERSECT_MIN_WAV
                                                        uint32_t* __restrict__ work, float4* __restrict__ hit, int* __restrict__ hit_node, uint32_t* __restrict__ occ,
                                                        unsigned long long* __restrict__ counts3) {
     __shared__ __attribute__((aligned(8))) int lds_stack[lds_stack_ints(LAYOUT)];   // flat: + one spare row that absorbs unused push slots
-    __shared__ uint16_t lds_dist[(LAYOUT && CTL_STACK_DIST >= 2) ? (kFlatLdsRows + 1) * kBlock : 1];
-    __shared__ __attribute__((aligned(16))) float lds_top[LAYOUT ? kTopCacheFloats : 4];
     const uint32_t n = *n_ptr;
     trav_counts tc{ 0, 0, 0, 0, 0 };
-    if (LAYOUT == 1 + kFmtQ8) intersect_flat8<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, (unsigned long long*)lds_stack, tc);
-    else if (LAYOUT) { fill_top_cache(S, lds_top); intersect_flat<ANY_HIT, COUNT, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, lds_top, tc, lds_dist); }
+    if (LAYOUT) intersect_flat_layout<ANY_HIT, COUNT, LAYOUT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
     else intersect_persistent<ANY_HIT, COUNT, ALPHA>(S, ro, rd, n, work, hit, hit_node, occ, lds_stack, tc);
     if (COUNT) {
         atomicAdd(&counts3[0], (unsigned long long)tc.n_inner); atomicAdd(&counts3[1], (unsigned long long)tc.n_tri); atomicAdd(&counts3[2], (unsigned long long)tc.n_inst);
@@ -90,17 +121,11 @@ __global__ __launch_bounds__(kBlock, ((LAYOUT && !ALPHA) ? CTL_INTERSECT_MIN_WAV
                                                             const float4* __restrict__ sro, const float4* __restrict__ srd, const uint32_t* __restrict__ sn_ptr,
                                                             uint32_t* __restrict__ swork, uint32_t* __restrict__ occ) {
     __shared__ __attribute__((aligned(8))) int lds_stack[lds_stack_ints(LAYOUT)];
-    __shared__ uint16_t lds_dist[(LAYOUT && CTL_STACK_DIST >= 2) ? (kFlatLdsRows + 1) * kBlock : 1];
-    __shared__ __attribute__((aligned(16))) float lds_top[LAYOUT ? kTopCacheFloats : 4];
     const uint32_t n = *n_ptr, sn = *sn_ptr;
     trav_counts tc{ 0, 0, 0, 0, 0 };
-    if (LAYOUT == 1 + kFmtQ8) {
-        intersect_flat8<false, false, ALPHA>(S, ro, rd, n, work, hit, hit_node, nullptr, (unsigned long long*)lds_stack, tc);
-        intersect_flat8<true, false, ALPHA>(S, sro, srd, sn, swork, nullptr, nullptr, occ, (unsigned long long*)lds_stack, tc);
-    } else if (LAYOUT) {
-        fill_top_cache(S, lds_top);
-        intersect_flat<false, false, ALPHA, LAYOUT - 1>(S, ro, rd, n, work, hit, hit_node, nullptr, lds_stack, lds_top, tc, lds_dist);
-        intersect_flat<true, false, ALPHA, LAYOUT - 1>(S, sro, srd, sn, swork, nullptr, nullptr, occ, lds_stack, lds_top, tc, lds_dist);
+    if (LAYOUT) {
+        intersect_flat_layout<false, false, LAYOUT, ALPHA>(S, ro, rd, n, work, hit, hit_node, nullptr, lds_stack, tc);
+        intersect_flat_layout<true, false, LAYOUT, ALPHA>(S, sro, srd, sn, swork, nullptr, nullptr, occ, lds_stack, tc);
     } else {
         intersect_persistent<false, false, ALPHA>(S, ro, rd, n, work, hit, hit_node, nullptr, lds_stack, tc);
         intersect_persistent<true, false, ALPHA>(S, sro, srd, sn, swork, nullptr, nullptr, occ, lds_stack, tc);
@@ -227,6 +252,10 @@ void apply_tuning_from_env() {
     if (const char* e = knob_env("CTL_LDS_PAD")) { int v = atoi(e); if (v >= 0 && v <= 140000) g_lds_pad = (unsigned)v; }
     if (const char* e = knob_env("CTL_REFILL_IDLE")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refill_idle), &v, sizeof(v)); }
     if (const char* e = knob_env("CTL_CHUNK_GUIDED")) { int v = atoi(e) != 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chunk_guided), &v, sizeof(v)); }
+#if CTL_LEAF_QUEUE
+    if (const char* e = knob_env("CTL_WQ_FLUSH")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wq_flush), &v, sizeof(v)); }
+    if (const char* e = knob_env("CTL_WQ_MIN_INNER")) { int v = atoi(e); if (v >= 0 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wq_min_inner), &v, sizeof(v)); }
+#endif
     if (const char* e = knob_env("CTL_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_leaf_batch), &v, sizeof(v)); }
 }
 
@@ -247,7 +276,6 @@ void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& 
         if (!S.flat_nodes) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 0, __VA_ARGS__);                                                         \
         else if (S.flat_format == kFmtF4) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 2, __VA_ARGS__);                                          \
         else if (S.flat_format == kFmtQ4) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 1, __VA_ARGS__);                                          \
-        else if (S.flat_format == kFmtQ8) CTL_LAUNCH_INTERSECT_L(ANY, CNT, 4, __VA_ARGS__);                                          \
         else CTL_LAUNCH_INTERSECT_L(ANY, CNT, 3, __VA_ARGS__);                                                                       \
     } while (0)
 #else
@@ -269,9 +297,11 @@ void launch_intersect_pair(const launch_ctx& lc, const dev_scene& S, const float
     if (!S.flat_nodes) {
         if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<0, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
         else hipLaunchKernelGGL((k_intersect_pair<0, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+#ifndef CTL_FLAT_EXPERIMENTS
     } else if (S.flat_format == kFmtQ8) {
         if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<4, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
         else hipLaunchKernelGGL((k_intersect_pair<4, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+#endif
     } else {
         if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<1, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
         else hipLaunchKernelGGL((k_intersect_pair<1, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);

@@ -7,8 +7,12 @@
 #include "shading.h"
 #include "compaction.h"
 #include "tracer.h"
+#ifdef CTL_FLAT_EXPERIMENTS
+#include "experiments/traverse_flat_variants.h"
+#else
 #include "traverse_flat.h"
 #include "traverse_flat8.h"
+#endif
 #include "mitsuba_loader.h"   // unsupported_error
 #include <climits>
 
@@ -22,7 +26,9 @@ __device__ __forceinline__ lds_int* single_stack_column() {
 }
 template <bool ANY_HIT>
 __device__ __noinline__ bool trace_single(const dev_scene& S, f3 o, f3 d, float tmin, float tmax, float& ht, float& hu, float& hv, int& htri, int& hnode) {
+#ifndef CTL_FLAT_EXPERIMENTS
     if (S.flat_format == kFmtQ8) return trace_single_flat8<ANY_HIT, true>(S, single_stack_column(), o, d, tmin, tmax, ht, hu, hv, htri, hnode);
+#endif
     return trace_single_flat<ANY_HIT, true>(S, single_stack_column(), o, d, tmin, tmax, ht, hu, hv, htri, hnode);
 }
 

@@ -281,6 +281,8 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
             if (F.stack_need() + 2 > (F.format == kFlatQ8 ? kFlat8StackGroups : kStackSize)) throw std::runtime_error("ctl_scene_create: flattened BVH too deep for the traversal stack");
 #ifndef CTL_FLAT_EXPERIMENTS
             if (F.format != kFlatQ4 && F.format != kFlatQ8) throw unsupported_error("ctl_scene_create: the F4 / F2 node formats are measurement builds (-DCTL_FLAT_EXPERIMENTS)");
+#else
+            if (F.format == kFlatQ8) throw unsupported_error("ctl_scene_create: a -DCTL_FLAT_EXPERIMENTS build has no kernel for the 8-wide node format");
 #endif
             if (F.format == kFlatQ4) flat_nodes_.upload((const float4*)F.nodes.data(), F.nodes.size() * 4);
             else if (F.format == kFlatQ8) flat_nodes_.upload((const float4*)F.nodes_q8.data(), F.nodes_q8.size() * 8);

@@ -1558,6 +1558,17 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
     return cl;
 }
 
+// KernelDynamicScene::sampleEmitterDirect (Engine/KernelDynamicScene.cu:98-117): the emitter choice re-uses (and re-scales) the sample's first coordinate.
+// `object` receives the chosen light when the sample is valid (dRec.object there).
+inline Spec sampleEmitterDirect(const Scene& S, DirectRec& dRec, V2 sample, const ctl_light** object = nullptr) {
+    dRec.pdf = 0; if (object) *object = nullptr;
+    float emPdf = 0.0f;
+    const ctl_light* emitter = sampleEmitter(S, emPdf, sample);
+    if (!emitter) return Spec(0.0f);
+    Spec value = lightSampleDirect(S, *emitter, dRec, sample);
+    if (dRec.pdf != 0) { dRec.pdf *= emPdf; value = sdiv(value, emPdf); if (object) *object = emitter; return value; }
+    return Spec(0.0f);
+}
 // ---- pathIterateKernel<NEXT_EVENT_EST> (Integrators/PseudoRealtime/WavefrontPathTracer.cu:51-164) followed along ONE path: the reference wavefront tracer's OWN
 // per-path rules, which differ from PathTrace<DIRECT> at equal parameters (the product's PathSemantics = Wavefront):
 //   * Russian roulette at pathDepth >= RRStartDepth, BEFORE the BSDF is sampled and whatever the last lobe was (:102-109);
@@ -1614,13 +1625,7 @@ inline Spec pathTraceWavefront(const Scene& S, bool NEE, V3 ro, V3 rd, Sampler& 
                 const V3 new_o = bRec.dg.P, new_d = bRec.dg.sys.toWorld(bRec.wo);
                 if (NEE && bsdfHasComponent(mat, ESmooth)) {
                     DirectRec dRec(bRec.dg.P, bRec.dg.sys.n);
-                    // KernelDynamicScene::sampleEmitterDirect (KernelDynamicScene.cu:98-117)
-                    V2 sample = rng.randomFloat2(); float emPdf = 0.0f; Spec value(0.0f);
-                    const ctl_light* emitter = sampleEmitter(S, emPdf, sample);
-                    if (emitter) {
-                        value = lightSampleDirect(S, *emitter, dRec, sample);
-                        if (dRec.pdf != 0) { dRec.pdf *= emPdf; value = sdiv(value, emPdf); } else value = Spec(0.0f);
-                    }
+                    const Spec value = sampleEmitterDirect(S, dRec, rng.randomFloat2());
                     if (!isZero(value)) {
                         bRec.typeMask = EAll & ~EDelta;
                         bRec.wo = bRec.dg.sys.toLocal(dRec.d);

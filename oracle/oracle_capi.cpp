@@ -237,6 +237,27 @@ void orc_light_sample_direct(const ctl_scene_desc* desc, uint32_t light, const f
     out[8] = d.p.x; out[9] = d.p.y; out[10] = d.p.z; out[11] = d.n.x; out[12] = d.n.y; out[13] = d.n.z;
 }
 
+// KernelDynamicScene::sampleEmitter for nq samples (2 floats each) over desc's light list: buffer slot of the chosen light, emPdf, the re-scaled sample.x;
+// pdf_emitter_out[i] = pdfEmitter(&lights[i]) for the first n_buf buffer slots (the reference indexes the CDF by BUFFER slot there, KernelDynamicScene.cu:42-46)
+void orc_emitter_select(const ctl_scene_desc* desc, int n_buf, int nq, const float* samples, int32_t* slot_out, float* pdf_out, float* resampled_out, float* pdf_emitter_out) {
+    Scene S; S.d = *desc;
+    for (int i = 0; i < nq; i++) {
+        V2 s{ samples[2 * i], samples[2 * i + 1] }; float emPdf = 0.0f;
+        const ctl_light* L = sampleEmitter(S, emPdf, s);
+        slot_out[i] = L ? (int32_t)(L - desc->lights) : -1; pdf_out[i] = emPdf; resampled_out[i] = s.x;
+    }
+    for (int i = 0; i < n_buf; i++) pdf_emitter_out[i] = pdfEmitter(S, desc->lights + i);
+}
+// KernelDynamicScene::sampleEmitterDirect: out = value(3), pdf, d(3), dist, p(3), n(3), buffer slot of dRec.object or -1
+void orc_sample_emitter_direct(const ctl_scene_desc* desc, const float* ref, const float* refN, float sx, float sy, float* out) {
+    Scene S; S.d = *desc;
+    DirectRec d(V3(ref[0], ref[1], ref[2]), V3(refN[0], refN[1], refN[2]));
+    const ctl_light* obj = nullptr;
+    Spec v = sampleEmitterDirect(S, d, V2{ sx, sy }, &obj);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = d.pdf; out[4] = d.d.x; out[5] = d.d.y; out[6] = d.d.z; out[7] = d.dist;
+    out[8] = d.p.x; out[9] = d.p.y; out[10] = d.p.z; out[11] = d.n.x; out[12] = d.n.y; out[13] = d.n.z; out[14] = obj ? (float)(obj - desc->lights) : -1.0f;
+}
+
 // Light::pdfDirect for a direction d seen from ref (solid-angle measure); p / n / dist describe the emitter point (area lights)
 float orc_light_pdf_direct(const ctl_scene_desc* desc, uint32_t light, const float* ref, const float* refN, const float* d, float dist, const float* n) {
     Scene S; S.d = *desc;

@@ -500,8 +500,49 @@ def gen_lights(r):
     np.savez_compressed(os.path.join(HERE, "lights.npz"), **out)
 
 
+def gen_emitters(r):
+    # ---- the reference's own emitter SELECTION: KernelDynamicScene::sampleEmitter / pdfEmitter / sampleEmitterDirect (Engine/KernelDynamicScene.cu:25-46, 98-117; `make ref`
+    # compiles those line ranges, oracle/ref_emitter_driver.cpp) over light lists given as (CDF, index list into a light buffer).  Case "deleted": the buffer holds one light
+    # more than the list (a deleted light in the middle), so list position and buffer slot differ — where pdfEmitter's indexing of the CDF by BUFFER slot shows.
+    r.ref_emitter_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    r.ref_sample_emitter_direct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rs = np.random.RandomState(20261006)
+    out = {}
+    def light_params(n_buf):
+        types = np.zeros(n_buf, np.int32); params = np.zeros((n_buf, 12), np.float32)
+        for i in range(n_buf):
+            t = (1, 4, 3)[i % 3]; types[i] = t
+            if t == 1: params[i, :6] = np.concatenate([rs.uniform(-5, 5, 3), rs.uniform(0.5, 40, 3)])
+            elif t == 4:
+                pp = rs.uniform(-5, 5, 3); cutoff = rs.uniform(20, 60)
+                params[i, :11] = np.concatenate([pp, pp + rs.normal(size=3) * 3, rs.uniform(0.5, 40, 3), [cutoff, cutoff * rs.uniform(0.3, 0.95)]])
+            else:
+                d = rs.normal(size=3); params[i, :7] = np.concatenate([d / np.linalg.norm(d), rs.uniform(0.5, 5, 3), [rs.uniform(3, 30)]])
+        return types, params
+    cases = {"one": (1, [0]), "three": (3, [0, 1, 2]), "seven": (7, list(range(7))), "sixteen": (16, list(range(16))), "deleted": (5, [0, 1, 3, 4]), "deleted_first": (4, [1, 2, 3])}
+    for name, (n_buf, idx) in cases.items():
+        n = len(idx)
+        w = rs.uniform(0.2, 3.0, n); cdf = (np.cumsum(w) / w.sum()).astype(np.float32); cdf[-1] = np.float32(1.0)
+        indices = np.array(idx, np.uint32)
+        nq = 192
+        smp = rs.rand(nq, 2).astype(np.float32)
+        edge = np.concatenate([[0.0, np.float32(0.99999994)], cdf[:-1], np.nextafter(cdf[:-1], np.float32(0)), np.nextafter(cdf[:-1], np.float32(2))]).astype(np.float32)
+        smp[:len(edge), 0] = edge[:nq]
+        slot = np.zeros(nq, np.int32); pdf = np.zeros(nq, np.float32); res = np.zeros(nq, np.float32); pe = np.zeros(16, np.float32)
+        assert r.ref_emitter_select(cdf.ctypes.data, indices.ctypes.data, n, n_buf, nq, smp.ctypes.data, slot.ctypes.data, pdf.ctypes.data, res.ctypes.data, pe.ctypes.data) == 0
+        types, params = light_params(n_buf)
+        q = np.zeros((nq, 8), np.float32); q[:, :3] = rs.uniform(-8, 8, size=(nq, 3)); nn = rs.normal(size=(nq, 3)); q[:, 3:6] = nn / np.linalg.norm(nn, axis=1, keepdims=True); q[:, 6:8] = smp
+        o15 = np.zeros((nq, 15), np.float32)
+        assert r.ref_sample_emitter_direct(cdf.ctypes.data, indices.ctypes.data, n, n_buf, types.ctypes.data, params.ctypes.data, nq, q.ctypes.data, o15.ctypes.data) == 0
+        for k, v in dict(cdf=cdf, indices=indices, n_buf=np.int32(n_buf), samples=smp, slot=slot, pdf=pdf, resampled=res, pdf_emitter=pe[:min(n_buf, 16)], types=types, params=params, q=q, direct=o15).items():
+            out["%s_%s" % (name, k)] = v
+    np.savez_compressed(os.path.join(HERE, "emitters.npz"), **out)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["lights"]:
+    if sys.argv[1:] == ["emitters"]:
+        gen_emitters(oracle.load_ref())
+    elif sys.argv[1:] == ["lights"]:
         gen_lights(oracle.load_ref())
     elif sys.argv[1:] == ["bsdf"]:
         gen_bsdf(oracle.load_ref())
@@ -518,4 +559,5 @@ if __name__ == "__main__":
         gen_math2(oracle.load_ref())
         gen_mipmap(oracle.load_ref())
         gen_bsdf(oracle.load_ref())
+        gen_emitters(oracle.load_ref())
         gen_lights(oracle.load_ref())
