@@ -135,7 +135,7 @@ def calibrated_traffic(workload_key):
     return e
 
 
-KERNEL_BUILD = "r03-flat-q4-exact-pair-slab-q3early-nibble-links-subtree32"   # changes when the traversal kernel or the flattened layout changes: a traffic profile of another build is not quoted
+KERNEL_BUILD = "r04-flat-q4-parked-leaves-clean-header"   # changes when the traversal kernel or the flattened layout changes: a traffic profile of another build is not quoted
 
 
 def self_launch(args, argv):
@@ -157,17 +157,40 @@ def self_launch(args, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CTL_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0 = procs[0].stdout.read().decode()      # rank 0 prints one line and then joins the final barrier, so this returns when the run is over (or rank 0 died)
-    rcs = []
-    deadline = time.time() + 120.0
-    for p in procs:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:       # a rank that hangs after rank 0 is gone: end exactly that process
-            p.kill(); rcs.append(p.wait())
-    for line in out0.splitlines():              # gloo's C++ side prints its connection banner on stdout: everything but the JSON line goes to stderr
+    # Watchdog.  ONE deadline for the whole job, counted from the spawn (not from rank 0's exit): a rank wedged in a rendezvous or a collective would otherwise hold the
+    # launcher until the caller's own kill, and nothing would say which rank it was.  Rank 0's stdout is drained by a thread so that a full pipe cannot block it.
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read().decode()), daemon=True); reader.start()
+    deadline = time.time() + float(args.launch_timeout)
+    rcs = [None] * n; verdict = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad and any(rc is None for rc in rcs):
+            # a rank died: the others would wait for it in the next barrier until their own time-outs — give them a moment to report, then end them
+            grace = time.time() + 20.0
+            while time.time() < grace and any(p.poll() is None for p in procs):
+                time.sleep(0.2)
+            verdict = "rank(s) %s failed (exit codes %s); still running and ended by the launcher: %s" % (bad, [rcs[r] for r in bad], [r for r, p in enumerate(procs) if p.poll() is None])
+        elif time.time() > deadline:
+            verdict = "no result within --launch-timeout %.0f s; rank(s) still running and ended by the launcher: %s (finished: %s)" % (
+                float(args.launch_timeout), [r for r, p in enumerate(procs) if p.poll() is None], {r: rc for r, rc in enumerate(rcs) if rc is not None})
+        if verdict:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                    # exactly the processes this launcher started
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(0.05)
+    reader.join(5.0)
+    for line in "".join(out0).splitlines():     # gloo's C++ side prints its connection banner on stdout: everything but the JSON line goes to stderr
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
+    if verdict:
+        raise SystemExit("bench.py --gpus %d: %s" % (n, verdict))
     if any(rcs):
         raise SystemExit("bench.py --gpus %d: rank exit codes %s" % (n, rcs))
 
@@ -176,6 +199,11 @@ def launch_only(rank, world, dist):
     """--launch-only: the rendezvous plumbing of an N-rank run without a device — gloo group, barrier, the 128-byte communicator id from rank 0 to everybody,
     the two scalar reductions — and one JSON line from rank 0.  What tests/test_bench_launcher.py runs on the CPU."""
     import torch
+    hook = os.environ.get("CTL_BENCH_TEST_RANK_FAULT", "")          # tests/test_bench_launcher.py: "hang:<rank>" / "die:<rank>" — what the launcher's watchdog is for
+    if hook == "hang:%d" % rank:
+        time.sleep(3600)
+    if hook == "die:%d" % rank:
+        os._exit(7)
     dist.barrier()
     ident = [bytes((7 * i + 1) & 255 for i in range(128)) if rank == 0 else None]    # stands for ncclGetUniqueId's 128 bytes
     dist.broadcast_object_list(ident, src=0)
@@ -209,6 +237,7 @@ def main():
     ap.add_argument("--flatten", type=int, default=1, help="traverse one world-space BVH over all instanced triangles (64 B of HBM per triangle)")
     ap.add_argument("--flat-format", default=None, choices=["q4", "q8"], help="node format of the flattened BVH (default: the library's)")
     ap.add_argument("--dump-frame", default=None, metavar="FILE.npy", help="rank 0 saves the reduced PixelData frame (h, w, 7) after the timed region (tests compare N-rank and 1-rank frames)")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("CTL_BENCH_LAUNCH_TIMEOUT", "1500")), help="N > 1: seconds from the spawn after which the launcher ends every rank and reports which ones were stuck")
     ap.add_argument("--launch-only", action="store_true", help="N-rank rendezvous plumbing only (no device): spawn, gloo group, id broadcast, reductions; prints n_gpus")
     args = ap.parse_args()
 
@@ -284,7 +313,10 @@ def main():
             try:
                 ident = [my_id if rank == 0 else None]
                 dist.broadcast_object_list(ident, src=0)
-                comm = ctl.Comm(ident[0], rank, world)
+                comm = ctl.Comm(ident[0], rank, world, timeout_ms=int(os.environ.get("CTL_BENCH_COMM_TIMEOUT_MS", "90000")))   # ncclCommInitRank with a deadline (comm.cpp)
+                scratch = ctl.Image(args.width, args.height)
+                comm.reduce_to(img, scratch if rank == 0 else None, 0)   # the FIRST ncclReduce of the communicator (connection set-up, a time-out of its own) runs here, outside the timed region
+                del scratch
                 reduce_kind = "ncclReduce in libctl_amd.so (ctl_image_reduce)"
             except Exception as e:   # never silently: the JSON line says which path ran
                 why = str(e)[:120]; comm = None
@@ -319,8 +351,13 @@ def main():
     sync()
     t0 = time.perf_counter()
     tr.DoPasses(img, args.steps, new_trace=(args.warmup == 0))
+    rank_ms = reduce_ms = None
     if world > 1:
-        reduce_frame()   # the single framebuffer exchange of the render: PixelData sums -> rank 0 over RCCL / xGMI
+        ctl.api._check(ctl.lib.ctl_device_synchronize())
+        rank_ms = (time.perf_counter() - t0) * 1e3      # this rank's own render of its shard
+        t_r = time.perf_counter()
+        reduce_frame()   # the single framebuffer exchange of the render: PixelData sums -> rank 0 over RCCL / xGMI (includes the wait for the slowest rank)
+        reduce_ms = (time.perf_counter() - t_r) * 1e3
     sync()
     elapsed = time.perf_counter() - t0
     st = tr.stats()
@@ -333,6 +370,7 @@ def main():
     if world > 1:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        per_rank = [None] * world; dist.all_gather_object(per_rank, {"rank_ms": round(rank_ms, 3), "reduce_ms": round(reduce_ms, 3), "rays": rays})
         r = torch.tensor([rays], dtype=torch.float64); dist.all_reduce(r, op=dist.ReduceOp.SUM); rays = float(r.item())
 
     out = None
@@ -378,15 +416,34 @@ def main():
             launches_dom = launches_closest
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         records_per_s = records_per_launch / (avg_launch_ms * 1e-3) if avg_launch_ms > 0 else 0.0
-        wl_key = "%s %dx%d depth %d" % (args.workload, args.width, args.height, args.depth) + ("" if args.workload != "synthetic-sm" else " %d inst subdiv %d" % (args.instances, args.subdiv)) + (" flat" if args.flatten else " two-level")
+        wl_key = "%s %dx%d depth %d" % (args.workload, args.width, args.height, args.depth) + ("" if args.workload != "synthetic-sm" else " %d inst subdiv %d" % (args.instances, args.subdiv)) + (" flat" if args.flatten else " two-level") + ((" " + args.flat_format) if (args.flatten and args.flat_format and args.flat_format != "q4") else "")
         cal = calibrated_traffic(wl_key)
         traffic = cal["bytes_per_ray"] * rays_per_launch if cal else None
-        frac = achieved / HBM_PEAK_GBS
-        hbm_meas = round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None
-        roof = {"bound": "hbm", "kernel": "k_intersect<closest>" if not fused_launches else "k_intersect_pair (closest hits of bounce d + occlusion of bounce d-1 in one persistent launch)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(frac, 4), "traffic": traffic,
-                "frac_note": "achieved = ALGORITHMIC bytes (SURVEY 8d: 48 + 64 N_inner + 52 N_tri per ray) / launch time; it can pass 1 because L2 and the Infinity Cache serve about half of those records; hbm_frac_measured (PMC traffic / time / peak) is the HBM roofline fraction",
-                "hbm_frac_measured": hbm_meas, "saturated": bool(hbm_meas is not None and hbm_meas >= 0.8),   # saturated: the MEASURED HBM-side traffic reaches 80 % of peak; `frac` counts L2-served bytes too
+        # The roofline fractions are fractions of PHYSICAL ceilings, all from the counters of the committed profile of THIS kernel build (profiles/<tag>_pmc_summary.csv ->
+        # profiles/roofline_traffic.json: per-ray HBM-side bytes, VALU instructions and lane-level vector loads) x the rays of this run's launches / this run's launch time:
+        #   hbm        (2 x FETCH_SIZE + WRITE_SIZE) / t / 8 TB/s          <- `frac`, `achieved`, `traffic`: the contract's HBM roofline, by MEASURED traffic
+        #   valu_issue SQ_INSTS_VALU / t / (1024 SIMDs x 2.4 GHz / 2)      a lower bound of the VALU pipes' busy time (2 cycles is the fastest a wave64 instruction issues)
+        #   l1_lookup  lane-level vector loads / t / 0.66 T/s               the scattered 16-B lane-loads the vector L1s sustain (tools/gather_probe.hip)
+        # `bound` names the largest.  SURVEY 8d's algorithmic figure (cache-blind: it charges HBM for every node visit, and passes 1) stays as algorithmic_*.
+        t_launch = avg_launch_ms * 1e-3
+        fractions = {}
+        if cal and t_launch > 0:
+            fractions["hbm"] = cal["bytes_per_ray"] * rays_per_launch / t_launch / (HBM_PEAK_GBS * 1e9)
+            if cal.get("valu_insts_per_ray"):
+                fractions["valu_issue"] = cal["valu_insts_per_ray"] * rays_per_launch / t_launch / (1024 * 2.4e9 / 2.0)
+            if cal.get("lane_loads_per_ray"):
+                fractions["l1_lookup"] = cal["lane_loads_per_ray"] * rays_per_launch / t_launch / 0.66e12
+        bound = max(fractions, key=fractions.get) if fractions else "unprofiled"
+        hbm_frac = fractions.get("hbm")
+        roof = {"bound": bound, "kernel": "k_intersect<closest>" if not fused_launches else "k_intersect_pair (closest hits of bounce d + occlusion of bounce d-1 in one persistent launch)",
+                "achieved": round(traffic / t_launch / 1e9, 2) if traffic and t_launch > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(hbm_frac, 4) if hbm_frac is not None else None, "traffic": traffic,
+                "fractions": {k: round(v, 4) for k, v in fractions.items()}, "bound_frac": round(fractions[bound], 4) if fractions else None,
+                "fractions_note": "each = per-ray counter quantity of the committed profile of this kernel build x this run's rays per launch / this run's launch time / ceiling (hbm 8 TB/s; valu_issue 1024 SIMDs x 2.4 GHz / 2 cycles, a lower bound; l1_lookup 0.66 T scattered lane-loads/s); frac = fractions.hbm",
+                "algorithmic_achieved": round(achieved, 2), "algorithmic_frac": round(achieved / HBM_PEAK_GBS, 4),
+                "algorithmic_note": "SURVEY 8d: (48 + 64 N_inner + 52 N_tri) B per ray x rays / launch time: cache-blind, L2 and the Infinity Cache serve over half of those records, so it can pass 1",
+                "saturated": bool(fractions and max(fractions.values()) >= 0.8),
+                "valu_lane_utilisation_profiled": cal.get("valu_lane_utilisation") if cal else None, "wait_any_frac_profiled": cal.get("wait_any_frac") if cal else None, "clock_ghz_profiled": cal.get("clock_ghz") if cal else None,
                 "l2_hit_rate": cal.get("l2_hit_rate") if cal else None, "traffic_profile": cal.get("tag") if cal else None, "workload_key": wl_key, "kernel_build": KERNEL_BUILD,
                 "bytes_per_ray": round(bytes_per_launch / max(1.0, rays_per_launch), 1), "bytes_per_path_ray": round(per_ray_closest, 1), "bytes_per_shadow_ray": round(per_ray_any, 1),
                 "per_ray": {k: round(v, 2) for k, v in per_ray.items()}, "per_shadow_ray": {k: round(v, 2) for k, v in any_visits.items()}, "per_ray_source": count_source, "per_shadow_ray_source": "GPU any-hit counting kernel",
@@ -397,7 +454,24 @@ def main():
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches_dom,
                 "separate_launches": {"closest_hit": {"rays": n_closest - fused_closest, "ms": round(k_ms_closest, 3), "launches": launches_closest},
                                       "any_hit": {"rays": n_any - fused_any, "ms": round(k_ms_any, 3)}},
+                "closest_rays_total": n_closest,
                 "ms_intersect": round(k_ms_closest + k_ms_fused + k_ms_any, 3), "ms_shade": round(st.ms_shade, 3), "ms_raygen": round(st.ms_raygen, 3)}
+        # the second kernel of the step: shading (k_shade_basic / k_shade_full), priced the same way per shaded path vertex (= closest-hit ray)
+        roof_shade = None
+        sh = cal.get("shade") if cal else None
+        if sh and sh.get("bytes_per_vertex") and st.ms_shade > 0:
+            t_sh = st.ms_shade * 1e-3
+            fs = {"hbm": sh["bytes_per_vertex"] * n_closest / t_sh / (HBM_PEAK_GBS * 1e9)}
+            if sh.get("valu_insts_per_vertex"):
+                fs["valu_issue"] = sh["valu_insts_per_vertex"] * n_closest / t_sh / (1024 * 2.4e9 / 2.0)
+            if sh.get("lane_loads_per_vertex"):
+                fs["l1_lookup"] = sh["lane_loads_per_vertex"] * n_closest / t_sh / 0.66e12
+            bs = max(fs, key=fs.get)
+            roof_shade = {"kernel": sh["kernel"], "bound": bs, "bound_frac": round(fs[bs], 4), "fractions": {k: round(v, 4) for k, v in fs.items()},
+                          "achieved": round(sh["bytes_per_vertex"] * n_closest / t_sh / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fs["hbm"], 4),
+                          "traffic_per_vertex": round(sh["bytes_per_vertex"], 1),
+                          "algorithmic_bytes_per_vertex": 104 + 16 + 20 + 136 + 32 + 48, "algorithmic_note": "SURVEY 8d shading list: path state 104 B + hit 16 + 4 read, <= 104 + 32 written, TriangleData 32 B, instance rows 48 B (+ material / light records, L2-resident)",
+                          "vertices": n_closest, "ms": round(st.ms_shade, 3), "valu_lane_utilisation_profiled": sh.get("valu_lane_utilisation")}
         out = {
             "metric": "Mrays/s at %dx%d, %d spp (steps), depth-%d; achieved HBM GB/s vs peak" % (args.width, args.height, args.steps, args.depth),
             "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -411,6 +485,13 @@ def main():
                        "rays_per_step": int(rays / args.steps), "scene_build_s": round(t_build, 2)},
             "roofline": roof,
         }
+        if roof_shade:
+            out["roofline_shade"] = roof_shade
+        if world > 1:
+            slow = max(range(world), key=lambda r: per_rank[r]["rank_ms"])
+            out["rank_ms"] = [q["rank_ms"] for q in per_rank]; out["reduce_ms"] = per_rank[0]["reduce_ms"]; out["reduce_ms_per_rank"] = [q["reduce_ms"] for q in per_rank]
+            out["slowest_rank"] = slow; out["rays_per_rank"] = [int(q["rays"]) for q in per_rank]
+            out["rank_ms_note"] = "rank_ms: a rank's own render of its tile shard (DoPasses + device sync); reduce_ms: the framebuffer reduce as the root saw it, including its wait for the slowest rank"
         if cpu:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

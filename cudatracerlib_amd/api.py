@@ -684,14 +684,21 @@ class Comm:
         _check(lib.ctl_comm_get_unique_id(buf))
         return bytes(buf)
 
-    def __init__(self, unique_id, rank, world):
+    def __init__(self, unique_id, rank, world, timeout_ms=0):
+        """timeout_ms: give ncclCommInitRank up after this long (0: $CTL_COMM_TIMEOUT_MS, else 120 s) — a rank that never arrives raises instead of hanging the job"""
         self._h = C.c_void_p()
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
-        _check(lib.ctl_comm_create(buf, C.c_int32(rank), C.c_int32(world), C.byref(self._h)))
+        _check(lib.ctl_comm_create_timeout(buf, C.c_int32(rank), C.c_int32(world), C.c_int32(timeout_ms), C.byref(self._h)))
 
     def reduce(self, image, root=0):
-        """sum of all ranks' PixelData frames into `root`'s image, in place, one ncclReduce; returns when it is complete"""
+        """sum of all ranks' PixelData frames into `root`'s image, in place, one ncclReduce; returns when it is complete.  ONE call per frame: a second one on an
+        image that already holds a reduced frame is refused (use reduce_to for a per-pass gather)"""
         _check(lib.ctl_image_reduce(image._h, self._h, C.c_int32(root)))
+
+    def reduce_to(self, src, dst, root=0):
+        """out of place (the per-pass gather of a progressive display): `dst` on the root = sum over the ranks of `src`; every rank's src stays its own cumulative frame.
+        dst may be None on the other ranks"""
+        _check(lib.ctl_image_reduce_to(src._h, dst._h if dst is not None else None, self._h, C.c_int32(root)))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -242,7 +242,16 @@ int ctl_comm_create(const uint8_t id128[128], int32_t rank, int32_t world, ctl_c
     CTL_TRY *out = new ctl_comm{ comm_create(id128, rank, world) }; CTL_CATCH
 }
 void ctl_comm_destroy(ctl_comm* c) { if (c) { comm_destroy(c->c); delete c; } }
-int ctl_image_reduce(ctl_image* img, ctl_comm* comm, int32_t root) { CTL_REQUIRE(img && comm, "null argument"); CTL_TRY comm_reduce_image(comm->c, &img->img, root); CTL_CATCH }
+int ctl_comm_create_timeout(const uint8_t id128[128], int32_t rank, int32_t world, int32_t timeout_ms, ctl_comm** out) {
+    CTL_REQUIRE(id128 && out, "null argument");
+    CTL_TRY *out = new ctl_comm{ comm_create(id128, rank, world, timeout_ms) }; CTL_CATCH
+}
+int ctl_image_reduce(ctl_image* img, ctl_comm* comm, int32_t root) { CTL_REQUIRE(img && comm, "null argument"); CTL_TRY comm_reduce_image(comm->c, &img->img, &img->img, root); CTL_CATCH }
+int ctl_image_reduce_to(ctl_image* src, ctl_image* dst, ctl_comm* comm, int32_t root) {
+    CTL_REQUIRE(src && comm, "null argument");
+    CTL_REQUIRE(dst != src, "ctl_image_reduce_to: source and destination must differ (ctl_image_reduce is the in-place form)");
+    CTL_TRY comm_reduce_image(comm->c, &src->img, dst ? &dst->img : nullptr, root); CTL_CATCH
+}
 void* ctl_image_device_ptr(ctl_image* img) { return img ? (void*)img->img.device() : nullptr; }
 int ctl_image_resolve_rgb(ctl_image* img, float splat_scale, float* host_rgb_out) { CTL_REQUIRE(img && host_rgb_out, "null argument"); CTL_TRY img->img.resolve_rgb(splat_scale, host_rgb_out); CTL_CATCH }
 

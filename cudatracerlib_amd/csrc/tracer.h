@@ -56,6 +56,8 @@ public:
     uint32_t getWidth() const { return w_; }
     uint32_t getHeight() const { return h_; }
     ctl_pixel_data* device() { return px_.p; }
+    bool holds_reduced_frame() const { return reduced_; }   // set on the root by an in-place ctl_image_reduce of more than one rank (comm.cpp), cleared by Clear() / write()
+    void mark_reduced(bool v) { reduced_ = v; }
     void read(ctl_pixel_data* host);
     void write(const ctl_pixel_data* host);
     void resolve_rgb(float splat_scale, float* host_rgb);
@@ -63,6 +65,7 @@ public:
     void apply_pipeline_ex(float splat_scale, const ctl_reconstruction_filter* filter, const ctl_tonemap* process, uint32_t* host_rgbcol);   // image_pipeline.hip
     void write_file(float splat_scale, const char* path);                          // Image::WriteDisplayImage (Engine/Image.cpp:67-75)
 private:
+    bool reduced_ = false;
     uint32_t w_, h_; dbuf<ctl_pixel_data> px_; dbuf<float> rgb_; dbuf<uint32_t> out_, filtered_; dbuf<int> lum_;   // filtered_: m_filteredColorsDevice (RGBE)
 };
 
@@ -236,8 +239,8 @@ void require_device();
 // comm.cpp: the framebuffer reduce of a multi-GPU render over RCCL (ctl_comm_* in include/ctl_amd.h)
 struct Comm;
 void comm_unique_id(unsigned char out[128]);
-Comm* comm_create(const unsigned char id[128], int rank, int world);
+Comm* comm_create(const unsigned char id[128], int rank, int world, int timeout_ms = 0);
 void comm_destroy(Comm* c);
-void comm_reduce_image(Comm* c, Image* img, int root);
+void comm_reduce_image(Comm* c, Image* src, Image* dst, int root);
 
 } // namespace ctl

@@ -337,9 +337,9 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
 
 // ------------------------------------------------------------------------------------------------ Image
 Image::Image(uint32_t w, uint32_t h) : w_(w), h_(h) { require_device(); px_.alloc((size_t)w * h); Clear(); }
-void Image::Clear() { CTL_HIP(hipMemset(px_.p, 0, px_.n * sizeof(ctl_pixel_data))); }
+void Image::Clear() { CTL_HIP(hipMemset(px_.p, 0, px_.n * sizeof(ctl_pixel_data))); reduced_ = false; }
 void Image::read(ctl_pixel_data* host) { CTL_HIP(hipDeviceSynchronize()); CTL_HIP(hipMemcpy(host, px_.p, px_.n * sizeof(ctl_pixel_data), hipMemcpyDeviceToHost)); }
-void Image::write(const ctl_pixel_data* host) { CTL_HIP(hipMemcpy(px_.p, host, px_.n * sizeof(ctl_pixel_data), hipMemcpyHostToDevice)); }
+void Image::write(const ctl_pixel_data* host) { CTL_HIP(hipMemcpy(px_.p, host, px_.n * sizeof(ctl_pixel_data), hipMemcpyHostToDevice)); reduced_ = false; }
 void Image::resolve_rgb(float splat_scale, float* host_rgb) {
     if (!rgb_.p) rgb_.alloc(px_.n * 3);
     CTL_HIP(hipDeviceSynchronize());

@@ -412,7 +412,16 @@ typedef struct ctl_comm ctl_comm;
 int ctl_comm_get_unique_id(uint8_t out128[128]);
 int ctl_comm_create(const uint8_t id128[128], int32_t rank, int32_t world, ctl_comm** out);
 void ctl_comm_destroy(ctl_comm* c);
+/* ctl_comm_create with a deadline: ncclCommInitRank is collective and waits for ever for a rank that never arrives; after timeout_ms (<= 0: $CTL_COMM_TIMEOUT_MS, else
+ * 120 000) the call fails with CTL_ERR_INVALID and a message naming the rank, so that the host can fall back or stop the job.  ctl_comm_create uses the default. */
+int ctl_comm_create_timeout(const uint8_t id128[128], int32_t rank, int32_t world, int32_t timeout_ms, ctl_comm** out);
+/* In place: the root's image becomes the sum over the ranks.  ONE call per render: a second call on an image that already holds a reduced frame is refused with
+ * CTL_ERR_INVALID (it would add the other ranks' cumulative tiles onto sums that contain them) until the image is cleared or rewritten. */
 int ctl_image_reduce(ctl_image* img, ctl_comm* comm, int32_t root);
+/* Out of place — the per-pass gather of a progressive display (the reference shows the frame after every DoPass, main.cpp:164-172): dst on the root receives the sum over the
+ * ranks of `src`; every rank's src (its own cumulative tile frame) is left as it is, so the call can be repeated after every pass.  dst may be NULL on the other ranks.
+ * K per-pass gathers end with the frame one end-of-render ctl_image_reduce gives, bit for bit (same ncclReduce over the same inputs). */
+int ctl_image_reduce_to(ctl_image* src, ctl_image* dst, ctl_comm* comm, int32_t root);
 
 /* ------------------------------------------------------------------- tracer */
 typedef struct ctl_tracer ctl_tracer;

@@ -48,3 +48,20 @@ def test_more_ranks_than_devices_is_refused():
         pytest.skip("box has two devices")
     p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert p.returncode != 0 and "HIP device" in p.stderr and p.stdout.strip() == ""
+
+
+def test_watchdog_ends_a_job_with_a_stuck_rank_and_names_it():
+    """a rank wedged before a rendezvous / inside a collective: the launcher's ONE deadline (counted from the spawn) ends every rank and says which were still running"""
+    import time
+    t = time.time()
+    p = _run(["--gpus", "3", "--launch-only", "--launch-timeout", "20"], {"CTL_BENCH_TEST_RANK_FAULT": "hang:1"}, timeout=120)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert "no result within --launch-timeout 20" in p.stderr and "still running" in p.stderr and "1" in p.stderr.split("still running")[1][:60]
+    assert time.time() - t < 90
+
+
+def test_watchdog_ends_the_others_when_a_rank_dies():
+    """a rank that exits early: the others would sit in the next barrier until gloo's own time-out; the launcher ends them and reports the exit code"""
+    p = _run(["--gpus", "2", "--launch-only", "--launch-timeout", "120"], {"CTL_BENCH_TEST_RANK_FAULT": "die:1"}, timeout=120)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert "rank(s) [1] failed" in p.stderr and "7" in p.stderr

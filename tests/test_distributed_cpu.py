@@ -64,3 +64,49 @@ def test_two_rank_gloo_reduce_reproduces_single_rank_frame(tmp_path):
     got, full = np.load(out)
     assert np.array_equal(got, full)   # x + 0 == x: bit-identical to the one-rank frame
     assert full[..., 6].sum() == w * h   # one sample per pixel per pass (a jittered sample may land in the neighbouring pixel)
+
+
+def _worker_progressive(rank, world, port, w, h, out_path):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from cudatracerlib_amd import scenes
+    import tile_shards as parallel
+    sc = scenes.cornell_box(w, h)
+    orc = oracle.Oracle()
+    tables = orc.sequence_tables(3)
+    mask = parallel.tile_mask(w, h, rank, world)[..., None]
+    shown = []
+    for k in range(1, 4):   # the rank's cumulative tile frame after pass k; the display frame is gathered after EVERY pass
+        full, _ = orc.render(sc.desc, w, h, n_passes=k, tables=tables[:k], max_path_length=3, threads=2)
+        mine = torch.from_numpy(np.ascontiguousarray((full * mask).reshape(-1)))
+        disp = parallel.reduce_framebuffer_to(mine, dst=0)
+        assert np.array_equal(mine.numpy().reshape(h, w, 7), full * mask)        # the source is untouched
+        if rank == 0:
+            shown.append(disp.numpy().reshape(h, w, 7).copy())
+    end = mine.clone(); parallel.reduce_framebuffer(end, dst=0)                 # ONE in-place reduce at the end of the render
+    if rank == 0:
+        np.save(out_path, np.stack(shown + [end.numpy().reshape(h, w, 7), full]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_per_pass_gathers_end_with_the_frame_of_one_final_reduce(tmp_path):
+    """progressive display (north_star: a gather of the framebuffer at the end of each pass): K out-of-place per-pass gathers (ctl_image_reduce_to's contract) show the
+    cumulative frame after every pass and end, bit for bit, with what ONE end-of-render in-place reduce gives — and with the one-rank frame"""
+    import torch.multiprocessing as mp
+    w, h = 192, 128
+    out = str(tmp_path / "prog.npy")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_progressive, args=(r, 2, port, w, h, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    s1, s2, s3, end, full = np.load(out)
+    assert np.array_equal(s3, end) and np.array_equal(end, full)
+    assert s1[..., 6].sum() == w * h and s2[..., 6].sum() == 2 * w * h and s3[..., 6].sum() == 3 * w * h

@@ -402,6 +402,37 @@ def test_native_framebuffer_reduce_single_rank(gpu):
     assert np.array_equal(img.getPixelData(), a)
     with pytest.raises(gpu.CtlError):
         comm.reduce(img, 3)
+    with pytest.raises(gpu.CtlError, match="already holds a reduced frame"):   # a second in-place reduce would double the other ranks' tiles: refused until the image is cleared / rewritten
+        comm.reduce(img, 0)
+    img.setPixelData(a); comm.reduce(img, 0)
+    del comm
+
+
+def test_per_pass_gather_out_of_place(gpu, orc):
+    """ctl_image_reduce_to (the per-pass gather of a progressive display; the reference shows the frame after every DoPass, main.cpp:164-172): after each of K passes the
+    rank's cumulative frame is gathered into a display image; the source stays untouched, the last gather equals one end-of-render in-place reduce bit for bit.
+    (One rank here — RCCL refuses two ranks on one device; tests/test_distributed_cpu.py runs the same contract with two ranks over gloo.)"""
+    sc = scenes.cornell_box(64, 64, glass_sphere=True)
+    scene = gpu.Scene(sc.desc, flatten=True)
+    tr = gpu.WavefrontPathTracer(); tr.getParameters().setValue("MaxPathLength", 4)
+    tr.Resize(64, 64); tr.InitializeScene(scene)
+    img, disp = gpu.Image(64, 64), gpu.Image(64, 64)
+    comm = gpu.Comm(gpu.Comm.unique_id(), 0, 1, timeout_ms=60000)
+    tables = orc.sequence_tables(3)
+    for k in range(3):
+        tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
+        before = img.getPixelData()
+        comm.reduce_to(img, disp, 0)
+        assert np.array_equal(img.getPixelData(), before) and np.array_equal(disp.getPixelData(), before)
+        assert before[..., 6].sum() == (k + 1) * 64 * 64
+    final = disp.getPixelData()
+    comm.reduce(img, 0)
+    assert np.array_equal(img.getPixelData(), final)
+    with pytest.raises(gpu.CtlError):
+        comm.reduce_to(img, img, 0)             # source and destination must differ
+    small = gpu.Image(32, 32)
+    with pytest.raises(gpu.CtlError):
+        comm.reduce_to(img, small, 0)
     del comm
 
 

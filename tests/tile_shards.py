@@ -37,3 +37,12 @@ def reduce_framebuffer(fb, dst=0):
         else:
             dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
     return fb
+
+
+def reduce_framebuffer_to(src, dst=0):
+    """out of place (the per-pass gather of a progressive display, ctl_image_reduce_to): returns the sum of the ranks' frames on rank `dst` (None elsewhere);
+    every rank's own cumulative frame `src` is left as it is, so the call can be repeated after every pass"""
+    import torch.distributed as dist
+    out = src.clone()
+    reduce_framebuffer(out, dst=dst)
+    return out if (not dist.is_initialized() or dist.get_rank() == dst) else None

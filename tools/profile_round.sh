@@ -17,6 +17,8 @@ pmc FETCH_SIZE FETCH_SIZE
 pmc WRITE_SIZE WRITE_SIZE
 pmc TCC TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum
 pmc SQ SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU
+pmc SQ2 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+pmc TCP TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 find "$OUT" -name '*.csv' -size +8M -delete
 find "$OUT" -name '*_agent_info.csv' -delete
 cat "$OUT/bench.json"
