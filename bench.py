@@ -48,6 +48,14 @@ def build_scene(args, rank=0, barrier=None):
         if barrier:
             barrier()
         return scenes.load_mitsuba(xml), "Mitsuba XML + .serialized meshes (scenes.export_mitsuba) through ctl_parse_mitsuba_scene"
+    if args.workload == "synthetic-sm-hard":   # ~8.5 M unique triangles (sliver terrain, alpha-masked cards, thin beams), textured materials, sun + area lights — always through the loader
+        nx, nz = (4096, 1024) if args.hard_scale == "full" else (1024, 256)
+        d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ctl_scene_sm_hard_%dx%d_%dx%d" % (nx, nz, args.width, args.height))
+        if rank == 0 and not os.path.exists(os.path.join(d, "scene.xml")):
+            scenes.write_sm_hard_mitsuba(d, args.width, args.height, nx=nx, nz=nz, cards=4000 if args.hard_scale == "full" else 1000, beams=3000 if args.hard_scale == "full" else 600)
+        if barrier:
+            barrier()
+        return scenes.load_mitsuba(os.path.join(d, "scene.xml"), args.width, args.height), "Mitsuba XML + .serialized meshes + PNG textures (scenes.write_sm_hard_mitsuba) through ctl_parse_mitsuba_scene"
     if args.workload == "synthetic-sm":
         return scenes.synthetic_sm(args.width, args.height, n_instances=args.instances, subdiv=args.subdiv), "builder API (cudatracerlib_amd/scenes.py)"
     if args.workload == "cornell-glass":      # BASELINE configs[1] (quote it with --width 1024 --height 1024)
@@ -229,6 +237,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--instances", type=int, default=2000)
     ap.add_argument("--subdiv", type=int, default=4)
+    ap.add_argument("--hard-scale", default="full", choices=["full", "small"], help="synthetic-sm-hard: 8.4 M (full) or 0.5 M (small) terrain triangles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scene", default=None, metavar="FILE.xml", help="render a Mitsuba-0.5 scene file (ParseMitsubaScene) instead of a built-in workload")
     ap.add_argument("--via-loader", action="store_true", help="write the synthetic workload as a Mitsuba scene and load it through ctl_parse_mitsuba_scene")
@@ -278,7 +287,7 @@ def main():
     t_build = time.perf_counter()
     if world > 1 and rank != 0 and not args.no_cache:
         dist.barrier()                      # rank 0 compiles and fills the cache first
-    sc, scene_source = build_scene(args, rank, dist.barrier if (world > 1 and args.via_loader) else None)
+    sc, scene_source = build_scene(args, rank, dist.barrier if (world > 1 and (args.via_loader or args.workload == "synthetic-sm-hard")) else None)
     desc = sc.desc
     scene = ctl.Scene(desc, flatten=bool(args.flatten), flat_format=args.flat_format)
     if world > 1 and rank == 0 and not args.no_cache:
@@ -416,7 +425,7 @@ def main():
             launches_dom = launches_closest
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         records_per_s = records_per_launch / (avg_launch_ms * 1e-3) if avg_launch_ms > 0 else 0.0
-        wl_key = "%s %dx%d depth %d" % (args.workload, args.width, args.height, args.depth) + ("" if args.workload != "synthetic-sm" else " %d inst subdiv %d" % (args.instances, args.subdiv)) + (" flat" if args.flatten else " two-level") + ((" " + args.flat_format) if (args.flatten and args.flat_format and args.flat_format != "q4") else "")
+        wl_key = "%s %dx%d depth %d" % (args.workload, args.width, args.height, args.depth) + ("" if args.workload != "synthetic-sm" else " %d inst subdiv %d" % (args.instances, args.subdiv)) + ((" " + args.hard_scale) if args.workload == "synthetic-sm-hard" else "") + (" flat" if args.flatten else " two-level") + ((" " + args.flat_format) if (args.flatten and args.flat_format and args.flat_format != "q4") else "")
         cal = calibrated_traffic(wl_key)
         traffic = cal["bytes_per_ray"] * rays_per_launch if cal else None
         # The roofline fractions are fractions of PHYSICAL ceilings, all from the counters of the committed profile of THIS kernel build (profiles/<tag>_pmc_summary.csv ->
@@ -478,7 +487,8 @@ def main():
             "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic-SM %dx%d, 1 spp/step, depth %d, NEE on, %d instances x icosphere(%d)/boxes, %d instanced triangles"
-                       % (args.width, args.height, args.depth, args.instances, args.subdiv, int(_instanced_tris(desc))) if args.workload == "synthetic-sm" else args.workload,
+                       % (args.width, args.height, args.depth, args.instances, args.subdiv, int(_instanced_tris(desc))) if args.workload == "synthetic-sm" else
+                       ("%s %dx%d depth %d, %d instanced triangles" % (args.workload, args.width, args.height, args.depth, int(_instanced_tris(desc)))),
                        "bvh": "flattened world-space BVH4 (64 B nodes with 8-bit quantised child boxes; 128 B leaf entries evaluated with the reference's object-space arithmetic)" if args.flatten else "two-level (scene BVH + instanced mesh BVHs)",
                        "scene_source": scene_source,
                        "parallelism": "image tiles 64x64 round-robin over %d GPU(s), 1 reduce of the framebuffer per render" % world, "framebuffer_reduce": reduce_kind,

@@ -797,6 +797,12 @@ class WavefrontPathTracer:
         if getattr(self, "_h", None):
             lib.ctl_tracer_destroy(self._h)
             self._h = None
+        self._free_depth()
+
+    def _free_depth(self):
+        d = getattr(self, "_depth", None)
+        if d is not None:
+            lib.ctl_device_free(d[0]); self._depth = None
 
     def getParameters(self):
         return _Parameters(self)
@@ -846,11 +852,17 @@ class WavefrontPathTracer:
 
     def setDepthBuffer(self, width, height):
         """IDepthTracer::setDepthBuffer: allocates width*height floats on the device and hands them to the tracer; read them back with getDepthBuffer()"""
+        lib.ctl_tracer_set_depth_buffer.argtypes = [C.c_void_p, C.c_void_p, u32, u32]
+        if getattr(self, "_depth", None) is not None:      # a buffer set before: the tracer lets go of it first, then it is freed
+            lib.ctl_tracer_set_depth_buffer(self._h, None, u32(0), u32(0)); self._free_depth()
         p = C.c_void_p()
         _check(lib.ctl_device_malloc(C.c_size_t(4 * width * height), C.byref(p)))
+        try:
+            _check(lib.ctl_tracer_set_depth_buffer(self._h, p, u32(width), u32(height)))
+        except Exception:
+            lib.ctl_device_free(p)                          # the tracer refused (the PathTracer plugin is no IDepthTracer): nothing keeps the allocation
+            raise
         self._depth = (p, width, height)
-        lib.ctl_tracer_set_depth_buffer.argtypes = [C.c_void_p, C.c_void_p, u32, u32]
-        _check(lib.ctl_tracer_set_depth_buffer(self._h, p, u32(width), u32(height)))
 
     def getDepthBuffer(self):
         p, w, h = self._depth

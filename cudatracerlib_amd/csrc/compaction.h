@@ -103,7 +103,9 @@ __device__ __forceinline__ void add_sample_ordered(const PARAMS& P, ctl_pixel_da
     const bool bad = !(isfinite(L.x) && isfinite(L.y) && isfinite(L.z));
     if (x < 0 || x >= (int)P.width || y < 0 || y >= (int)P.height || bad) return;
     const uint32_t idx = (uint32_t)y * P.width + (uint32_t)x;
-    if (idx == pixel) P.stage[(size_t)pass_b * P.stage_stride + idx] = make_float4(L.x, L.y, L.z, 1.0f);
+    // the stage holds THIS RANK'S pixels only (stage_stride = its 64 x 64 tiles x 4096): slot = local tile * 4096 + row-major position in the tile (k_resolve_stage, kernels.hip, inverts it)
+    const uint32_t tile = ((uint32_t)y >> 6) * ((P.width + 63u) >> 6) + ((uint32_t)x >> 6);
+    if (idx == pixel) P.stage[(size_t)pass_b * P.stage_stride + (size_t)(tile / P.tile_world) * 4096u + (((uint32_t)y & 63u) << 6) + ((uint32_t)x & 63u)] = make_float4(L.x, L.y, L.z, 1.0f);
     else { ctl_pixel_data* r = img + idx; atomicAdd(&r->rgb[0], L.x); atomicAdd(&r->rgb[1], L.y); atomicAdd(&r->rgb[2], L.z); atomicAdd(&r->weight_sum, 1.0f); }
 }
 

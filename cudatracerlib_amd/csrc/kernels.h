@@ -86,7 +86,7 @@ void launch_shade_full(const launch_ctx& lc, const dev_scene& S, const wave_queu
 void launch_shade_basic_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_full_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_finalize(const launch_ctx& lc, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
-void launch_resolve_stage(const launch_ctx& lc, float4* stage, size_t stride, uint32_t n_passes, ctl_pixel_data* image);   // frame += the staged samples of a batch, pass by pass; clears the stage
+void launch_resolve_stage(const launch_ctx& lc, float4* stage, size_t stride, uint32_t n_passes, ctl_pixel_data* image, uint32_t W, uint32_t H, uint32_t tile_rank, uint32_t tile_world);   // frame += the staged samples of a batch, pass by pass; clears the stage
 int flat_top_cache_nodes();   // nodes at the head of the flattened node array that the traversal workgroups keep in LDS (traverse_flat.h kTopCache)
 void launch_accumulate_stats(const launch_ctx& lc, const wave_queues& Q, int max_depth);
 void launch_apply_pipeline(const launch_ctx& lc, const ctl_pixel_data* image, uint32_t n, float splat_scale, uint32_t* rgbcol_out);

@@ -146,21 +146,24 @@ __global__ __launch_bounds__(kBlock) void k_finalize(wave_queues Q, pass_params 
     }
 }
 
-// frame += the staged samples of a batch (pass_params::stage), pass by pass in pass order; the stage is left cleared for the next batch.  One lane = one pixel; the n_passes
-// reads of a lane are n_passes coalesced streams.
-__global__ __launch_bounds__(256) void k_resolve_stage(float4* __restrict__ stage, size_t stride, uint32_t n_passes, ctl_pixel_data* __restrict__ image) {
+// frame += the staged samples of a batch (pass_params::stage), pass by pass in pass order; the stage is left cleared for the next batch.  One lane = one slot of the rank's
+// own tiles (compaction.h add_sample_ordered: local tile * 4096 + row-major position in the tile); the n_passes reads of a lane are n_passes coalesced streams.
+__global__ __launch_bounds__(256) void k_resolve_stage(float4* __restrict__ stage, size_t stride, uint32_t n_passes, ctl_pixel_data* __restrict__ image, uint32_t W, uint32_t H, uint32_t tile_rank, uint32_t tile_world) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= stride) return;
-    ctl_pixel_data* r = image + i;
+    const uint32_t tiles_x = (W + 63u) >> 6, tile = (uint32_t)(i >> 12) * tile_world + tile_rank, p = (uint32_t)i & 4095u;
+    const uint32_t x = (tile % tiles_x) * 64u + (p & 63u), y = (tile / tiles_x) * 64u + (p >> 6);
+    if (x >= W || y >= H) return;     // the clipped part of a border tile: nothing was staged there
+    ctl_pixel_data* r = image + ((size_t)y * W + x);
     float a = r->rgb[0], b = r->rgb[1], c = r->rgb[2], w = r->weight_sum; bool any = false;
-    for (uint32_t p = 0; p < n_passes; p++) {
-        const float4 v = stage[(size_t)p * stride + i];
-        if (v.w != 0.0f) { a += v.x; b += v.y; c += v.z; w += v.w; any = true; stage[(size_t)p * stride + i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+    for (uint32_t q = 0; q < n_passes; q++) {
+        const float4 v = stage[(size_t)q * stride + i];
+        if (v.w != 0.0f) { a += v.x; b += v.y; c += v.z; w += v.w; any = true; stage[(size_t)q * stride + i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
     }
     if (any) { r->rgb[0] = a; r->rgb[1] = b; r->rgb[2] = c; r->weight_sum = w; }
 }
-void launch_resolve_stage(const launch_ctx& lc, float4* stage, size_t stride, uint32_t n_passes, ctl_pixel_data* image) {
-    hipLaunchKernelGGL(k_resolve_stage, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, lc.stream, stage, stride, n_passes, image);
+void launch_resolve_stage(const launch_ctx& lc, float4* stage, size_t stride, uint32_t n_passes, ctl_pixel_data* image, uint32_t W, uint32_t H, uint32_t tile_rank, uint32_t tile_world) {
+    hipLaunchKernelGGL(k_resolve_stage, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, lc.stream, stage, stride, n_passes, image, W, H, tile_rank, tile_world);
 }
 
 // rays of a pass = sum over bounces of (path rays + shadow rays)  (Kernel/TraceHelper.cu:176,745)

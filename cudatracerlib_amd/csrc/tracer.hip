@@ -561,6 +561,7 @@ WavefrontPathTracer::WavefrontPathTracer() {
     m_sParameters.addEnum("PathSemantics", 0, { "PathTrace", "Wavefront" });
     // build-specific: hit barycentrics through the 16-bit pair of the reference's traversal result (Kernel/TraceHelper.cu:722-731); off = full floats (single-ray traceRay)
     m_sParameters.addBool("U16Barycentrics", false);
+    m_sParameters.addInterval("OrderedAccumulationMaxMB", 4096, 0, 1 << 20);   // build-specific: largest stage of the ordered accumulation (MB of HBM); a batch that needs more accumulates with atomics
     m_sParameters.addBool("OrderedAccumulation", true);   // build-specific: finished paths are staged per (pass, pixel) and added to the frame in pass order (kernels.h pass_params::stage); false = four float atomics per path as Image::AddSample does
     int dev = 0; hipDeviceProp_t prop; CTL_HIP(hipGetDevice(&dev)); CTL_HIP(hipGetDeviceProperties(&prop, dev));
     grid_blocks = prop.multiProcessorCount * 8;   // 8 x 256-thread workgroups per CU = 32 waves/CU
@@ -571,6 +572,9 @@ void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
     Tracer<true>::Resize(_w, _h);
     // DoubleRayBuffer(w*h, w*h) (WavefrontPathTracer.h:59) — here per rank: its tile shard's pixels
     n_local_pixels = shard_pixel_count(_w, _h, shard_rank, shard_world);
+    // a ray's slot number travels in 31 bits (bit 31 of the traversal kernels' ray word is the "hit found" flag, traverse_flat.h) and the batch position of a path in 8
+    if ((uint64_t)n_local_pixels * std::max(1u, alloc_batch_) >= (1ull << 31) || alloc_batch_ > 255u)
+        throw std::runtime_error("WavefrontPathTracer::Resize: " + std::to_string(n_local_pixels) + " pixels x " + std::to_string(alloc_batch_) + " passes per wavefront exceed the 2^31 ray slots (or 255 passes) of a batch: lower PassBatch");
     capacity = n_local_pixels * std::max(1u, alloc_batch_);   // grown by DoRender when a larger batch arrives
     f4_.clear();
     for (int b = 0; b < 2; b++) {
@@ -636,11 +640,19 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     P.wavefront_rules = m_sParameters.getValue("PathSemantics") == 1 ? 1 : 0; P.u16_bary = m_sParameters.getValue("U16Barycentrics") != 0 ? 1 : 0;
     P.depth_buffer = depth_buffer_; P.depth_w = depth_w_; P.depth_h = depth_h_; P.depth_near = m_pScene->near_depth; P.depth_far = m_pScene->far_depth;
     // ordered accumulation (kernels.h pass_params::stage): one staged sample per (pass of the batch, pixel), added to the frame in pass order after the last bounce
-    P.stage = nullptr; P.stage_stride = (size_t)w * h;
-    if (m_sParameters.getValue("OrderedAccumulation") != 0 && !pass_block_counts_) {
+    // The stage covers THIS RANK'S tiles only (n_local_pixels slots per pass of the batch, 16 B each: 663 MB for 20 passes of a whole 1080p frame, an eighth of that on a rank
+    // of eight).  It is an optimisation, not a requirement: past OrderedAccumulationMaxMB (default 4096) or when the allocation fails the paths fall back to Image::AddSample's
+    // four float atomics — same sums, hardware order.
+    P.stage = nullptr; P.stage_stride = (size_t)n_local_pixels;
+    if (m_sParameters.getValue("OrderedAccumulation") != 0 && !pass_block_counts_ && n_local_pixels != 0) {
         const size_t need = P.stage_stride * n_batch;
-        if (stage_.n < need) { stage_.alloc(need); CTL_HIP(hipMemsetAsync(stage_.p, 0, need * sizeof(float4), stream)); }
-        P.stage = stage_.p;
+        if (need * sizeof(float4) <= (size_t)m_sParameters.getValue("OrderedAccumulationMaxMB") << 20) {
+            if (stage_.n < need) {
+                try { stage_.alloc(need); CTL_HIP(hipMemsetAsync(stage_.p, 0, need * sizeof(float4), stream)); }
+                catch (const std::exception&) { stage_.free(); (void)hipGetLastError(); }
+            }
+            if (stage_.n >= need) P.stage = stage_.p;
+        }
     }
     if (pass_block_counts_ && pass_paths_ > capacity) throw std::runtime_error("ray queue overflow: the block sampler asks for more samples in one pass than the queues hold (DoubleRayBuffer.h:86-89)");
     if (P.sort_materials) CTL_HIP(hipMemsetAsync(mat_counts_.p, 0, n_mat * sizeof(uint32_t), stream));
@@ -685,7 +697,7 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
         shadow_pass(maxPathLength);
         timer.begin(stream, 2); launch_finalize(lc, Q, P, maxPathLength, I->device()); timer.end(stream);
     }
-    if (P.stage) { timer.begin(stream, 2); launch_resolve_stage(lc, P.stage, P.stage_stride, n_batch, I->device()); timer.end(stream); }
+    if (P.stage) { timer.begin(stream, 2); launch_resolve_stage(lc, P.stage, P.stage_stride, n_batch, I->device(), w, h, shard_rank, shard_world); timer.end(stream); }
     launch_accumulate_stats(lc, Q, maxPathLength);
 }
 

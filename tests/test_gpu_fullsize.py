@@ -216,8 +216,8 @@ def test_cornell_glass_at_full_size(gpu, orc):
             assert same_n.mean() >= 0.999
             g, wv = g[same_n][None], wv[same_n][None]
             ok = (np.abs(g - wv) <= 2e-3 * (1 + np.abs(wv))).all(axis=2)
-            assert ok.mean() >= 0.995, (y0, ok.mean())
-            assert abs(g.mean() - wv.mean()) <= 2e-3 * wv.mean(), (y0, g.mean(), wv.mean())
+            assert ok.mean() >= 0.998, (y0, ok.mean())                 # the bar of the other full-size frames (kernels and checker share their transcendental functions)
+            assert abs(g.mean() - wv.mean()) <= 1e-3 * wv.mean(), (y0, g.mean(), wv.mean())
     (two, rays_two), (flat, rays_flat) = frames
     assert rays_two == rays_flat and rays_two > 4 * w * h            # both layouts return the same hits, so the same paths
     assert np.array_equal(two[..., 6], flat[..., 6]) and np.allclose(two[..., :3], flat[..., :3], rtol=1e-5, atol=1e-5)
@@ -236,3 +236,49 @@ def test_cornell_glass_at_full_size(gpu, orc):
     assert abs(int(rm) - int(rays_flat)) <= 1e-3 * rays_flat
     close = np.isclose(mega[..., :3], flat[..., :3], rtol=1e-3, atol=1e-3).all(axis=2)
     assert close.mean() >= 0.995 and abs(mega[..., :3].mean() - flat[..., :3].mean()) <= 1e-3 * flat[..., :3].mean()
+
+
+def test_synthetic_sm_hard_at_full_size(gpu, orc):
+    """synthetic-sm-hard (scenes.write_sm_hard_mitsuba: 8.4 M UNIQUE sliver-terrain triangles in 32 meshes, 4000 alpha-masked foliage cards, 3000 thin beams, bitmap-textured
+    diffuse / plastic / rough-conductor materials, the `sun` emitter's spot lights + area lights) through the Mitsuba loader at 1920x1080, depth 8:
+      * bands of rows rendered by the oracle equal the same rows of the GPU frame, at the bar of the other full-size workloads;
+      * the 4-wide and the 8-wide flattened trees render the same frame and count the same rays (same hits, another tree);
+      * with the alpha test on (tracer parameter AlphaTest; the reference's wavefront kernel has none) a band equals the oracle's alpha-tested band."""
+    d0 = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ctl_scene_sm_hard_4096x1024_%dx%d" % (W, H))
+    gpu.api.set_cache_dir(os.environ.get("CTL_CACHE_DIR") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "ctl_amd_cache"))
+    sc = scenes.synthetic_sm_hard(d0, W, H)
+    d = sc.desc
+    assert d.n_tri_data > 8_400_000 and d.num_lights == 10
+    flat = gpu.Scene(d, flatten=True)
+    flat8 = gpu.Scene(d, flatten=True, flat_format="q8")
+    gpu.api.set_cache_dir(None)
+    tables = orc.sequence_tables(2)
+    bands = (400, 800)                                                # beams and cards against the far terrain; the near terrain
+    frames = {}
+    for name, scene, params in (("q4", flat, {}), ("q8", flat8, {}), ("alpha", flat, dict(AlphaTest=True))):
+        for depth in ((2, DEPTH) if name == "q4" else (DEPTH,)):
+            tr = gpu.WavefrontPathTracer(); p = tr.getParameters(); p.setValue("MaxPathLength", depth)
+            for k, v in params.items():
+                p.setValue(k, v)
+            tr.Resize(W, H); tr.InitializeScene(scene)
+            img = gpu.Image(W, H)
+            for k in range(2):
+                tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
+            got = img.getPixelData(); frames[name, depth] = (got, tr.stats().rays_total)
+            assert np.isfinite(got[..., :3]).all() and (got[..., :3] >= 0).all()
+            if name == "q8":
+                continue
+            for y0 in bands:
+                want = orc.render(d, W, H, n_passes=2, tables=tables, max_path_length=depth, rows=(y0, y0 + 8), threads=os.cpu_count() or 8, alpha_test=(name == "alpha"))[0]
+                g, w = got[y0 + 1:y0 + 7, :, :3], want[y0 + 1:y0 + 7, :, :3]
+                same_n = got[y0 + 1:y0 + 7, :, 6] == want[y0 + 1:y0 + 7, :, 6]
+                assert same_n.mean() >= 0.999
+                g, w = g[same_n][None], w[same_n][None]
+                ok = (np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2)
+                assert ok.mean() >= 0.998, (name, depth, y0, ok.mean())
+                assert abs(g.mean() - w.mean()) <= 1e-3 * w.mean(), (name, depth, y0, g.mean(), w.mean())
+    (a, ra), (b, rb) = frames["q4", DEPTH], frames["q8", DEPTH]
+    assert abs(int(ra) - int(rb)) <= 1e-4 * ra and np.array_equal(a[..., 6], b[..., 6])
+    close = np.isclose(a[..., :3], b[..., :3], rtol=1e-4, atol=1e-5).all(axis=2)
+    assert close.mean() >= 0.9995                                     # equal-t ties between the two trees' visiting orders aside
+    assert frames["alpha", DEPTH][1] != ra                            # the alpha test changes which rays exist
