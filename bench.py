@@ -389,7 +389,8 @@ def main():
         # traversal statistics of the SAME rays on the GPU (one extra, untimed batch in counting mode, as many passes per launch as the timed region had — a single
         # pass per launch is mostly ramp and drain and reports a lane utilisation the timed launches do not have): lane utilisation, visited nodes
         tr.setCounting(True)
-        tr.DoPasses(img, max(1, min(args.steps, 32)), new_trace=False)
+        counting_passes = max(1, min(args.steps, 32))
+        tr.DoPasses(img, counting_passes, new_trace=False)
         cs = tr.stats()
         tr.setCounting(False)
         gpu_counts = {"n_inner": cs.closest_counts.n_inner / max(1, cs.intersect_rays), "n_tri": cs.closest_counts.n_tri / max(1, cs.intersect_rays), "n_inst": cs.closest_counts.n_inst / max(1, cs.intersect_rays)}
@@ -463,7 +464,7 @@ def main():
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches_dom,
                 "separate_launches": {"closest_hit": {"rays": n_closest - fused_closest, "ms": round(k_ms_closest, 3), "launches": launches_closest},
                                       "any_hit": {"rays": n_any - fused_any, "ms": round(k_ms_any, 3)}},
-                "closest_rays_total": n_closest,
+                "closest_rays_total": n_closest, "counting_passes": counting_passes,   # (a profile of this command also sees the counting batch: its shade launches are the product's, its traversal launches the COUNT instantiations)
                 "ms_intersect": round(k_ms_closest + k_ms_fused + k_ms_any, 3), "ms_shade": round(st.ms_shade, 3), "ms_raygen": round(st.ms_raygen, 3)}
         # the second kernel of the step: shading (k_shade_basic / k_shade_full), priced the same way per shaded path vertex (= closest-hit ray)
         roof_shade = None

@@ -16,7 +16,15 @@ namespace ctl {
 
 // ---- transcendental functions: on the device the shared fp32 implementation of ctl_fmath.h (bit-identical to the oracle's -DORC_SHARED_MATH build), on the host libm —
 // host code only builds scene data (normal codec of TriangleData, light cosines), which is pinned on the reference's own glibc results (tests/golden)
-#if defined(__HIP_DEVICE_COMPILE__)
+#ifndef CTL_SHADE_PROBE
+#define CTL_SHADE_PROBE 0   // timing probes only (tools/shade_basic_probe.py; results are WRONG in such a build): 1 = the device library's fp32 sin / cos / ... instead of ctl_fmath.h; 2 = the normal codec without trigonometry
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && (CTL_SHADE_PROBE & 1)
+HD float m_sin(float x) { return __sinf(x); }  HD float m_cos(float x) { return __cosf(x); }  HD float m_tan(float x) { return __tanf(x); }
+HD void m_sincos(float x, float* s, float* c) { *s = __sinf(x); *c = __cosf(x); }
+HD float m_acos(float x) { return ::acosf(x); }  HD float m_atan(float x) { return ::atanf(x); }  HD float m_atan2(float y, float x) { return ::atan2f(y, x); }
+HD float m_exp(float x) { return __expf(x); }  HD float m_log(float x) { return __logf(x); }  HD float m_log2(float x) { return __log2f(x); }  HD float m_pow(float x, float y) { return __powf(x, y); }
+#elif defined(__HIP_DEVICE_COMPILE__)
 HD float m_sin(float x) { return fm::sin(x); }  HD float m_cos(float x) { return fm::cos(x); }  HD float m_tan(float x) { return fm::tan(x); }
 HD void m_sincos(float x, float* s, float* c) { fm::sincos(x, s, c); }
 HD float m_acos(float x) { return fm::acos(x); }  HD float m_atan(float x) { return fm::atan(x); }  HD float m_atan2(float y, float x) { return fm::atan2(y, x); }
@@ -204,7 +212,9 @@ HD f3 uchar2_to_normal(uint32_t v) {
     float theta = x == 63 ? PI_4 : (x == 127 ? PI_2 : (x == 191 ? 3 * PI_4 : float(x) * (1.0f / 255.0f) * kPi));
     float phi = y == 63 ? PI_2 : (y == 127 ? kPi : (y == 191 ? 3 * PI_2 : float(y) * (1.0f / 255.0f) * kPi * 2.0f));
     float sp, cp, st, ct;
-#ifdef __HIP_DEVICE_COMPILE__
+#if defined(__HIP_DEVICE_COMPILE__) && (CTL_SHADE_PROBE & 2)
+    sp = phi * 0.1f; cp = 1.0f - sp; st = theta * 0.2f; ct = 1.0f - st;
+#elif defined(__HIP_DEVICE_COMPILE__)
     m_sincos(phi, &sp, &cp); m_sincos(theta, &st, &ct);
 #else
     sp = m_sin(phi); cp = m_cos(phi); st = m_sin(theta); ct = m_cos(theta);

@@ -47,7 +47,7 @@ struct wq_stack {
 struct hit_candidate {
     float ht, hu, hv; int htri, hnode; bool any;
     __device__ __forceinline__ float dist() const { return ht; }
-    __device__ __forceinline__ void accept(float t, float u, float v, int tri, int nd) { ht = t; hu = u; hv = v; htri = tri; hnode = nd; any = true; }
+    __device__ __forceinline__ void accept(float t, float u, float v, int tri, int nd, uint32_t) { ht = t; hu = u; hv = v; htri = tri; hnode = nd; any = true; }
 };
 
 // One leaf entry for ANOTHER lane's ray, in two steps: the instance rows first (48 B), the ray taken into object space, only then the Woop rows (the same 128-B line, by then

@@ -49,6 +49,7 @@ struct pass_params {
     uint32_t n_local_pixels;             // pixels rendered by this rank
     int direct, max_path_length, rr_start_depth;
     int sort_materials;                  // shade in wave_queues::order
+    int key_from_traversal;              // Q.mat_key[i] = BSDF model + 1 of path i's hit (0 = miss), left there by the closest-hit traversal (dev_scene::hit_key_out)
     int block_sort;                      // full shade kernel: regroup the path slots of a workgroup by BSDF model (shade_kernel.inc)
     int sort_octants;                    // append the new rays of a workgroup grouped by direction octant (compaction.h)
     const unsigned char* block_counts;   // samples per 64x64 film block in this pass (a block sampler's decision), nullptr = one everywhere

@@ -273,6 +273,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
             throw std::runtime_error("ctl_scene_create: scene BVH depth " + std::to_string(top) + " + mesh BVH depth " + std::to_string(bottom) +
                                      " does not fit the traversal stack of " + std::to_string(kStackSize) + " entries (rebuild the meshes with CTL_BVH_BINNED, whose depth is bounded)");
     }
+    S.hit_key_out = nullptr; S.flat_leaf_keys = 0;
     S.flat_nodes = nullptr; S.flat_leaves = nullptr; S.flat_root = 0; S.flat_format = 0; S.flat_compact = 0; S.inst_w_one = 0; S.flat_top_cached = 0;
     if (flatten) {
         // node format: Q4 (64-B 4-wide nodes with 8-bit child boxes) unless the caller or $CTL_FLAT_FORMAT asks for F4 / F2 (DESIGN.md §3 has the measurements)
@@ -289,6 +290,19 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
             else if (F.format == kFlatF4) flat_nodes_.upload((const float4*)F.nodes_f4.data(), F.nodes_f4.size() * 8);
             else flat_nodes_.upload((const float4*)F.nodes_f2.data(), F.nodes_f2.size() * 4);
             for (const flat_leaf& L : F.leaves) if (L.node >= d.n_nodes) throw std::runtime_error("ctl_scene_create: flattened leaf entry out of range");
+            S.flat_leaf_keys = 0;
+#ifndef CTL_FLAT_EXPERIMENTS
+            // The DEVICE copy of the entries carries the BSDF model of each entry's material in bits 28..31 of its index word (the host arrays, the cache and the oracle's view stay
+            // as flatten.cpp made them): a closest-hit traversal leaves it per ray (dev_scene::hit_key_out) and the shade kernel regroups its lanes by it without the
+            // hit -> node -> triangle -> material chain of dependent loads that made the regrouping cost more than it won.
+            if (d.n_tri_data < (1u << 27) && d.n_materials) {
+                for (flat_leaf& L : F.leaves) {
+                    const uint32_t tri = L.index >> 1, mi = d.nodes[L.node].material_offset + ((d.tri_data[tri].nor_mat_extra[1] >> 16) & 0xffu);   // TriangleData::getMatIndex (TriangleData.h:40-44)
+                    L.index |= (mi < d.n_materials ? (d.materials[mi].bsdf_type & 15u) : 0u) << 28;
+                }
+                S.flat_leaf_keys = 1;
+            }
+#endif
             F.leaves.emplace_back(); std::memset(&F.leaves.back(), 0, sizeof(flat_leaf)); F.leaves.back().index = 1;   // one spare (closing) entry behind the last leaf
             flat_leaves_.upload((const float4*)F.leaves.data(), F.leaves.size() * 8);
             // every node transform affine with w == 1 exactly (what add_node produces): the kernels skip the load of w and the division by it
@@ -667,12 +681,16 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
         shadow_launches++;
     };
     const bool fuse = !counting && direct && m_sParameters.getValue("FuseTraversal") != 0;
+    // closest-hit traversals of a flattened scene leave the BSDF model of every hit in Q.mat_key (device_scene.h hit_key_out) for the shade kernel's regrouping; the counting
+    // kernels and the device-wide material sort (which writes its own keys there) do without
+    dev_scene Sk = S; Sk.hit_key_out = (S.flat_leaf_keys && S.shade_features == 0 && !counting && !P.sort_materials && P.block_sort) ? Q.mat_key : nullptr;   // (the full build keys its regrouping by model AND material index)
+    P.key_from_traversal = Sk.hit_key_out ? 1 : 0;
     for (int depth = 1; depth <= maxPathLength; depth++) {
         const int cur = (depth - 1) & 1;
         if (fuse && depth > 1) {   // path rays of this bounce + shadow rays of the previous one in one launch
             const int d = depth - 1;
             timer.begin(stream, 4);
-            launch_intersect_pair(lc, S, Q.path[cur].ray_o, Q.path[cur].ray_d, &Q.counts[(depth - 1) * 4 + 0], &Q.work[2 * depth], Q.hit, Q.hit_node,
+            launch_intersect_pair(lc, Sk, Q.path[cur].ray_o, Q.path[cur].ray_d, &Q.counts[(depth - 1) * 4 + 0], &Q.work[2 * depth], Q.hit, Q.hit_node,
                                   Q.sh_o[d & 1], Q.sh_d[d & 1], &Q.counts[d * 4 + 1], &Q.work[2 * d + 3], Q.sh_occ[d & 1]);
             timer.end(stream);
             fused_launches++;
@@ -684,7 +702,7 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
         }
         timer.begin(stream, 1);
         if (counting) launch_intersect_count(lc, S, Q.path[cur].ray_o, Q.path[cur].ray_d, &Q.counts[(depth - 1) * 4 + 0], &Q.work[2 * depth], Q.hit, Q.hit_node, nullptr, 0, Q.stats + 2);
-        else launch_intersect_closest(lc, S, Q.path[cur].ray_o, Q.path[cur].ray_d, &Q.counts[(depth - 1) * 4 + 0], &Q.work[2 * depth], Q.hit, Q.hit_node);
+        else launch_intersect_closest(lc, Sk, Q.path[cur].ray_o, Q.path[cur].ray_d, &Q.counts[(depth - 1) * 4 + 0], &Q.work[2 * depth], Q.hit, Q.hit_node);
         timer.end(stream);
         intersect_launches++;
         if (depth > 1 && direct) shadow_pass(depth - 1);

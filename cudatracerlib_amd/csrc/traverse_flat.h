@@ -58,14 +58,14 @@ __device__ __forceinline__ float rcp_cull(float d) {   // slab tests only cull: 
 struct hit_in_regs {
     float& ht; float& hu; float& hv; int& htri; int& hnode;
     __device__ __forceinline__ float dist() const { return ht; }
-    __device__ __forceinline__ void accept(float t, float u, float v, int tri, int nd) { ht = t; hu = u; hv = v; htri = tri; hnode = nd; }
+    __device__ __forceinline__ void accept(float t, float u, float v, int tri, int nd, uint32_t) { ht = t; hu = u; hv = v; htri = tri; hnode = nd; }
 };
 struct hit_in_memory {
-    float& ht; uint32_t& ray_word; float4* __restrict__ hit; int* __restrict__ hit_node;   // ray_word: ray index | found << 31
+    float& ht; uint32_t& ray_word; float4* __restrict__ hit; int* __restrict__ hit_node; unsigned char* __restrict__ key_out;   // ray_word: ray index | found << 31
     __device__ __forceinline__ float dist() const { return ht; }
-    __device__ __forceinline__ void accept(float t, float u, float v, int tri, int nd) {
+    __device__ __forceinline__ void accept(float t, float u, float v, int tri, int nd, uint32_t key) {
         ht = t;
-        if (hit) { const uint32_t id = ray_word & 0x7fffffffu; hit[id] = make_float4(t, u, v, __int_as_float(tri)); hit_node[id] = nd; }
+        if (hit) { const uint32_t id = ray_word & 0x7fffffffu; hit[id] = make_float4(t, u, v, __int_as_float(tri)); hit_node[id] = nd; if (key_out) key_out[id] = (unsigned char)(key + 1u); }
         ray_word |= 0x80000000u;
     }
 };
@@ -82,8 +82,9 @@ __device__ __forceinline__ bool flat_woop_test(const dev_scene& S, const float4 
             const float Oy = v22.w + o.x * v22.x + o.y * v22.y + o.z * v22.z;
             const float Dy = d.x * v22.x + d.y * v22.y + d.z * v22.z;
             const float v = Oy + t * Dy;
-            if (v >= 0.0f && u + v <= 1.0f && (!ALPHA || alpha_survives(S.tri_data, S.node_info, S.mats, S.images, (int)(index >> 1), nd, u, v))) {
-                sink.accept(t, u, v, (int)(index >> 1), nd);
+            const int tri = (int)((index & 0x0fffffffu) >> 1);   // bits 28..31: the BSDF model of the entry's material on the device copy (dev_scene::flat_leaf_keys), else 0
+            if (v >= 0.0f && u + v <= 1.0f && (!ALPHA || alpha_survives(S.tri_data, S.node_info, S.mats, S.images, tri, nd, u, v))) {
+                sink.accept(t, u, v, tri, nd, index >> 28);
                 return true;
             }
         }
@@ -210,7 +211,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, tmin = 0;
     ray_cull R{ 0, 0, 0, 0, 0, 0 };
     float ht = 0;                                 // distance of the closest hit so far; its record is in hit[] / hit_node[] already (hit_in_memory), bit 31 of ray_id says there is one
-    hit_in_memory sink{ ht, ray_id, hit, hit_node };
+    hit_in_memory sink{ ht, ray_id, hit, hit_node, ANY_HIT ? nullptr : S.hit_key_out };
     int sp = 0, node = kSentinel, pend = -1;      // pend: postponed leaf (its first entry in flat_leaves), -1 = none
     int sp_max = 0;                               // COUNT: deepest stack entry of the lane's current ray
     const float4* __restrict__ nodes = S.flat_nodes;
@@ -287,7 +288,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
         if (finished) {
             const uint32_t id = ray_id & 0x7fffffffu; const bool found = (ray_id >> 31) != 0u;
             if (ANY_HIT && occ) occ[id] = found ? 1u : 0u;
-            if (hit && !found) { hit[id] = make_float4(ht, 0.0f, 0.0f, __int_as_float(-1)); hit_node[id] = -1; }   // a found hit wrote its record when it was accepted
+            if (hit && !found) { hit[id] = make_float4(ht, 0.0f, 0.0f, __int_as_float(-1)); hit_node[id] = -1; if (!ANY_HIT && S.hit_key_out) S.hit_key_out[id] = 0; }   // a found hit wrote its record when it was accepted
             if (COUNT) { atomicAdd(&s_hist[sp_max < kStackSize ? sp_max : kStackSize - 1], 1u); sp_max = 0; }   // the workgroup's own histogram in LDS: one global atomic per ray on two dozen addresses made the counting kernels 15 x slower than the timed ones
             has_ray = false; node = kSentinel; pend = -1;
         }

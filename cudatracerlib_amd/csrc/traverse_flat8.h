@@ -115,7 +115,7 @@ __device__ __forceinline__ void intersect_flat8(const dev_scene& S, const float4
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, tmin = 0;
     ray_cull R{ 0, 0, 0, 0, 0, 0 };
     float ht = 0;                                 // distance of the closest hit so far; its record is in hit[] / hit_node[] already (hit_in_memory), bit 31 of ray_id says there is one
-    hit_in_memory sink{ ht, ray_id, hit, hit_node };
+    hit_in_memory sink{ ht, ray_id, hit, hit_node, ANY_HIT ? nullptr : S.hit_key_out };
     uint32_t node = kQ8None;                      // the node the lane visits next (index << 1 | B flag)
     q8_group grp{ 0u, 0u };                       // what is left of the sibling group `node` came from
     uint32_t p_base = 0u, p_mh = 0u;              // parked leaf group: first entry of its node, leaf mask | slots still to test (visiting order) << 8
@@ -196,7 +196,7 @@ __device__ __forceinline__ void intersect_flat8(const dev_scene& S, const float4
         if (finished) {
             const uint32_t id = ray_id & 0x7fffffffu; const bool found = (ray_id >> 31) != 0u;
             if (ANY_HIT && occ) occ[id] = found ? 1u : 0u;
-            if (hit && !found) { hit[id] = make_float4(ht, 0.0f, 0.0f, __int_as_float(-1)); hit_node[id] = -1; }   // a found hit wrote its record when it was accepted
+            if (hit && !found) { hit[id] = make_float4(ht, 0.0f, 0.0f, __int_as_float(-1)); hit_node[id] = -1; if (!ANY_HIT && S.hit_key_out) S.hit_key_out[id] = 0; }   // a found hit wrote its record when it was accepted
             if (COUNT) { atomicAdd(&s_hist[sp_max < kStackSize ? sp_max : kStackSize - 1], 1u); sp_max = 0; }
             has_ray = false; node = kQ8None; p_mh = 0u;
         }

@@ -127,7 +127,8 @@ def main():
         sk = [q for q in rows if q.startswith("k_shade")]
         if sk:
             q = max(sk, key=lambda q: rows[q].get("duration_ms", 0.0)); rs = rows[q]
-            verts = rf["closest_rays_total"] * (b["steps"] + b["warmup"]) / b["steps"] if rf.get("closest_rays_total") else None   # every closest-hit ray is one shaded vertex (or a miss that the shade kernel also handles)
+            # every closest-hit ray is one shaded vertex (or a miss that the shade kernel also handles); the profiled command shades the warm-up passes, the timed passes AND bench.py's counting batch
+            verts = rf["closest_rays_total"] * (b["steps"] + b["warmup"] + rf.get("counting_passes", 0)) / b["steps"] if rf.get("closest_rays_total") else None
             sh_hbm, sh_issue, sh_l1, sh_src, _ = fractions(rs)
             sl = rs.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * rs["SQ_INSTS_VALU"]) if rs.get("SQ_INSTS_VALU") else None
             entry["shade"] = {"kernel": q, "launches": rs.get("launches"), "duration_ms": rs.get("duration_ms"), "vertices_profiled": verts,
