@@ -143,7 +143,7 @@ def calibrated_traffic(workload_key):
     return e
 
 
-KERNEL_BUILD = "r04-flat-q4-parked-leaves-clean-header"   # changes when the traversal kernel or the flattened layout changes: a traffic profile of another build is not quoted
+KERNEL_BUILD = "r04-flat-q4-parked-leaves-hit-keys"   # changes when the traversal kernel or the flattened layout changes: a traffic profile of another build is not quoted
 
 
 def self_launch(args, argv):
