@@ -42,7 +42,7 @@ __device__ float phong_pdf(const ctl_material& M, const bsdf_rec& b) {   // BSDF
 
 __device__ f3 bsdf_more_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp) {
     switch (M.bsdf_type) {
-    case CTL_BSDF_THINDIELECTRIC: {   // BSDF_Simple.cu:330-371
+    case CTL_BSDF_THINDIELECTRIC: { if (!CTL_HAS_MODEL(CTL_BSDF_THINDIELECTRIC)) return f3(0.0f);   // BSDF_Simple.cu:330-371
         const bool sr = (b.type_mask & CTL_EDeltaReflection) != 0, st = (b.type_mask & CTL_ENull) != 0;
         float ct; float R = fresnel_dielectric_ext(fabsf(cos_theta(b.wi)), ct, M.f[0]); const float T = 1 - R;
         if (R < 1) R += T * T * R / (1 - R * R);
@@ -54,7 +54,7 @@ __device__ f3 bsdf_more_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f
         else if (st) { b.sampled_type = CTL_ENull; b.wo = -b.wi; pdf = 1.0f; return tex_eval(M.tex[0], b.dg) * (1 - R); }
         return f3(0.0f);
     }
-    case CTL_BSDF_ROUGHDIELECTRIC: {   // BSDF_Simple.cu:503-615
+    case CTL_BSDF_ROUGHDIELECTRIC: { if (!CTL_HAS_MODEL(CTL_BSDF_ROUGHDIELECTRIC)) return f3(0.0f);   // BSDF_Simple.cu:503-615
         const bool hr = (b.type_mask & CTL_EGlossyReflection) != 0, ht = (b.type_mask & CTL_EGlossyTransmission) != 0;
         bool sample_refl = hr;
         if (!hr && !ht) return f3(0.0f);
@@ -92,7 +92,7 @@ __device__ f3 bsdf_more_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f
         pdf *= fabsf(dwh_dwo);
         return weight;
     }
-    case CTL_BSDF_PLASTIC: {   // BSDF_Simple.cu:765-826
+    case CTL_BSDF_PLASTIC: { if (!CTL_HAS_MODEL(CTL_BSDF_PLASTIC)) return f3(0.0f);   // BSDF_Simple.cu:765-826
         const bool hs = (b.type_mask & CTL_EDeltaReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
         if ((!hd && !hs) || cos_theta(b.wi) <= 0) return f3(0.0f);
         float ct; const float Fi = fresnel_dielectric_ext(cos_theta(b.wi), ct, M.f[2]);
@@ -111,7 +111,7 @@ __device__ f3 bsdf_more_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f
         pdf = kInvPi * cos_theta(b.wo);
         return plastic_diffuse(M, b.dg) * (M.f[3] * (1 - Fi) * (1 - Fo));
     }
-    case CTL_BSDF_PHONG: {   // BSDF_Simple.cu:1059-1111
+    case CTL_BSDF_PHONG: { if (!CTL_HAS_MODEL(CTL_BSDF_PHONG)) return f3(0.0f);   // BSDF_Simple.cu:1059-1111
         const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
         if (!hs && !hd) return f3(0.0f);
         bool spec = hs; const float w = M.f[0];
@@ -135,7 +135,7 @@ __device__ f3 bsdf_more_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f
 
 __device__ f3 bsdf_more_f(const ctl_material& M, const bsdf_rec& b) {
     switch (M.bsdf_type) {
-    case CTL_BSDF_ROUGHDIELECTRIC: {   // BSDF_Simple.cu:436-501
+    case CTL_BSDF_ROUGHDIELECTRIC: { if (!CTL_HAS_MODEL(CTL_BSDF_ROUGHDIELECTRIC)) return f3(0.0f);   // BSDF_Simple.cu:436-501
         const float eta_ = M.f[0], inv_eta = M.f[1];
         const bool refl = cos_theta(b.wi) * cos_theta(b.wo) > 0;
         f3 H;
@@ -154,19 +154,19 @@ __device__ f3 bsdf_more_f(const ctl_material& M, const bsdf_rec& b) {
         const float factor = (cos_theta(b.wi) > 0 ? inv_eta : eta_);
         return tex_eval(M.tex[0], b.dg) * fabsf(value * factor * factor);
     }
-    case CTL_BSDF_PLASTIC: {   // BSDF_Simple.cu:828-858 — solid-angle measure: the diffuse lobe
+    case CTL_BSDF_PLASTIC: { if (!CTL_HAS_MODEL(CTL_BSDF_PLASTIC)) return f3(0.0f);   // BSDF_Simple.cu:828-858 — solid-angle measure: the diffuse lobe
         if (!(b.type_mask & CTL_EDiffuseReflection) || cos_theta(b.wo) <= 0 || cos_theta(b.wi) <= 0) return f3(0.0f);
         float ct; const float Fi = fresnel_dielectric_ext(cos_theta(b.wi), ct, M.f[2]), Fo = fresnel_dielectric_ext(cos_theta(b.wo), ct, M.f[2]);
         return plastic_diffuse(M, b.dg) * ((kInvPi * cos_theta(b.wo)) * M.f[3] * (1 - Fi) * (1 - Fo));
     }
-    case CTL_BSDF_PHONG: return phong_f(M, b);
+    case CTL_BSDF_PHONG: return CTL_HAS_MODEL(CTL_BSDF_PHONG) ? phong_f(M, b) : f3(0.0f);
     default: return bsdf_rough_f(M, b);
     }
 }
 
 __device__ float bsdf_more_pdf(const ctl_material& M, const bsdf_rec& b) {
     switch (M.bsdf_type) {
-    case CTL_BSDF_ROUGHDIELECTRIC: {   // BSDF_Simple.cu:373-434
+    case CTL_BSDF_ROUGHDIELECTRIC: { if (!CTL_HAS_MODEL(CTL_BSDF_ROUGHDIELECTRIC)) return 0.0f;   // BSDF_Simple.cu:373-434
         const float eta_ = M.f[0], inv_eta = M.f[1];
         const bool hr = (b.type_mask & CTL_EGlossyReflection) != 0, ht = (b.type_mask & CTL_EGlossyTransmission) != 0, refl = cos_theta(b.wi) * cos_theta(b.wo) > 0;
         f3 H; float dwh_dwo;
@@ -185,14 +185,14 @@ __device__ float bsdf_more_pdf(const ctl_material& M, const bsdf_rec& b) {
         if (ht && hr) { float ct; const float F = fresnel_dielectric_ext(dot(b.wi, H), ct, eta_); prob *= refl ? F : (1 - F); }
         return fabsf(prob * dwh_dwo);
     }
-    case CTL_BSDF_PLASTIC: {   // BSDF_Simple.cu:860-888
+    case CTL_BSDF_PLASTIC: { if (!CTL_HAS_MODEL(CTL_BSDF_PLASTIC)) return 0.0f;   // BSDF_Simple.cu:860-888
         const bool hs = (b.type_mask & CTL_EDeltaReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
         if (cos_theta(b.wo) <= 0 || cos_theta(b.wi) <= 0 || !hd) return 0.0f;
         float ps = hs ? 1.0f : 0.0f;
         if (hs) { float ct; const float Fi = fresnel_dielectric_ext(cos_theta(b.wi), ct, M.f[2]); ps = (Fi * M.f[4]) / (Fi * M.f[4] + (1 - Fi) * (1 - M.f[4])); }
         return (kInvPi * cos_theta(b.wo)) * (1 - ps);
     }
-    case CTL_BSDF_PHONG: return phong_pdf(M, b);
+    case CTL_BSDF_PHONG: return CTL_HAS_MODEL(CTL_BSDF_PHONG) ? phong_pdf(M, b) : 0.0f;
     default: return bsdf_rough_pdf(M, b);
     }
 }

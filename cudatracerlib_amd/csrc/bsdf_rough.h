@@ -226,14 +226,14 @@ __device__ float roughplastic_pdf(const ctl_material& M, const bsdf_rec& b) {   
     return result;
 }
 
-__device__ __noinline__ f3 bsdf_rough_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp) {
+__device__ CTL_ROUGH_OUTLINE f3 bsdf_rough_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp) {
     switch (M.bsdf_type) {
-    case CTL_BSDF_ROUGHDIFFUSE: {   // BSDF_Simple.h:42-49
+    case CTL_BSDF_ROUGHDIFFUSE: { if (!CTL_HAS_MODEL(CTL_BSDF_ROUGHDIFFUSE)) return f3(0.0f);   // BSDF_Simple.h:42-49
         b.wo = square_to_cosine_hemisphere(smp); b.eta = 1.0f; b.sampled_type = CTL_EGlossyReflection;
         pdf = kInvPi * cos_theta(b.wo);
         return sdiv(roughdiffuse_f(M, b), pdf);
     }
-    case CTL_BSDF_WARD: {   // BSDF_Simple.cu:1173-1230
+    case CTL_BSDF_WARD: { if (!CTL_HAS_MODEL(CTL_BSDF_WARD)) return f3(0.0f);   // BSDF_Simple.cu:1173-1230
         const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
         if (!hs && !hd) return f3(0.0f);
         bool spec = hs; const float ssw = M.f[0];
@@ -256,7 +256,7 @@ __device__ __noinline__ f3 bsdf_rough_sample(const ctl_material& M, bsdf_rec& b,
         if (pdf == 0) return f3(0.0f);
         return sdiv(ward_f(M, b), pdf);
     }
-    case CTL_BSDF_ROUGHPLASTIC: {   // BSDF_Simple.cu:890-946
+    case CTL_BSDF_ROUGHPLASTIC: { if (!CTL_HAS_MODEL(CTL_BSDF_ROUGHPLASTIC)) return f3(0.0f);   // BSDF_Simple.cu:890-946
         const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
         if (cos_theta(b.wi) <= 0 || (!hs && !hd)) return f3(0.0f);
         bool spec = hs;
@@ -279,21 +279,21 @@ __device__ __noinline__ f3 bsdf_rough_sample(const ctl_material& M, bsdf_rec& b,
     default: return f3(0.0f);
     }
 }
-__device__ __noinline__ f3 bsdf_rough_f(const ctl_material& M, const bsdf_rec& b) {
+__device__ CTL_ROUGH_OUTLINE f3 bsdf_rough_f(const ctl_material& M, const bsdf_rec& b) {
     switch (M.bsdf_type) {
-    case CTL_BSDF_ROUGHDIFFUSE: return roughdiffuse_f(M, b);
-    case CTL_BSDF_WARD: return ward_f(M, b);
-    case CTL_BSDF_ROUGHPLASTIC: return roughplastic_f(M, b);
+    case CTL_BSDF_ROUGHDIFFUSE: return CTL_HAS_MODEL(CTL_BSDF_ROUGHDIFFUSE) ? roughdiffuse_f(M, b) : f3(0.0f);
+    case CTL_BSDF_WARD: return CTL_HAS_MODEL(CTL_BSDF_WARD) ? ward_f(M, b) : f3(0.0f);
+    case CTL_BSDF_ROUGHPLASTIC: return CTL_HAS_MODEL(CTL_BSDF_ROUGHPLASTIC) ? roughplastic_f(M, b) : f3(0.0f);
     default: return f3(0.0f);
     }
 }
-__device__ __noinline__ float bsdf_rough_pdf(const ctl_material& M, const bsdf_rec& b) {
+__device__ CTL_ROUGH_OUTLINE float bsdf_rough_pdf(const ctl_material& M, const bsdf_rec& b) {
     switch (M.bsdf_type) {
     case CTL_BSDF_ROUGHDIFFUSE:   // BSDF_Simple.h:51-59
         if (!(b.type_mask & CTL_EGlossyReflection) || cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0) return 0.0f;
         return kInvPi * cos_theta(b.wo);
-    case CTL_BSDF_WARD: return ward_pdf(M, b);
-    case CTL_BSDF_ROUGHPLASTIC: return roughplastic_pdf(M, b);
+    case CTL_BSDF_WARD: return CTL_HAS_MODEL(CTL_BSDF_WARD) ? ward_pdf(M, b) : 0.0f;
+    case CTL_BSDF_ROUGHPLASTIC: return CTL_HAS_MODEL(CTL_BSDF_ROUGHPLASTIC) ? roughplastic_pdf(M, b) : 0.0f;
     default: return 0.0f;
     }
 }

@@ -35,7 +35,7 @@ struct dev_scene {
     int inst_w_one;              // every node's inverse transform has w33 == 1.0f exactly (x / 1 == x: the traversal skips the division)
     int flat_format;             // flat_format of flatten.h: 0 Q4 (64-B quantised 4-wide), 1 F4 (128-B fp32 4-wide), 2 F2 (64-B fp32 2-wide)
     int flat_leaf_keys;          // the device copy of the leaf entries carries the BSDF model of the entry's material (bsdf_type & 15) in bits 28..31 of its index word (tracer.hip; host arrays and the cache do not)
-    unsigned char* hit_key_out;  // per launch (the tracer's copy of this struct): where a closest-hit traversal leaves that model + 1 per ray (0 = miss), for the shade kernel's regrouping; else nullptr
+    unsigned char* hit_key_out;  // per launch (the tracer's copy of this struct): where a closest-hit traversal leaves that model (CTL_BSDF_*, all >= 1) per ray (0 = miss), for the shade kernel's regrouping; else nullptr
     int flat_top_cached;         // Q4 with implied links: the first this-many nodes of flat_nodes (the top of the tree, stored breadth-first) are kept in LDS by every traversal workgroup (traverse_flat.h kTopCache)
     const float4* inst_fwd;      // 3 x float4 per node: forward-transform rows 0..2 (fillDG)
     const uint4* tri_data;       // 2 x uint4 per triangle (TriangleData, 32 B)
@@ -54,6 +54,7 @@ struct dev_scene {
     uint32_t env_map_index;
     uint32_t alpha_maps;         // KernelDynamicScene::doAlphaMapping: some material carries an alpha map
     uint32_t shade_features;     // kShade* bits the scene needs (selects the shade-kernel build, kernels.hip launch_shade)
+    uint32_t shade_models;       // bit m = some material of the scene has the BSDF model CTL_BSDF_* == m (which model-class launches a depth needs, kernels.hip launch_shade)
     float eps;                   // m_rayTraceEps
     uint32_t light_indices[CTL_MAX_NUM_LIGHTS];
     float light_cdf[CTL_MAX_NUM_LIGHTS];

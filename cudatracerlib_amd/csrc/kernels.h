@@ -38,8 +38,14 @@ struct wave_queues {
     // a wave run one model's code instead of all of them
     uint32_t* order;           // [capacity] path slots in shading order
     unsigned char* mat_key;    // [capacity] BSDF model of the hit (0 = miss)
-    uint32_t* mat_counts;      // [depth * 32 + k]: k < 16 paths per model, 16 + k scatter cursors
+    uint32_t* mat_counts;      // [depth * 32 + k]: k < 16 paths per model, 16 + k scatter cursors, 24 + c vertices of model class c (k_class_partition)
+    // model-class shading (pass_params::model_classes): k_class_partition splits the slots of a depth into one list per model class, class_order[c][0 .. mat_counts[depth * 32 + 24 + c])
+    uint32_t* class_order[3];  // [capacity] each
 };
+// the model classes of shade_class_a/b/c.hip: which traversal keys (Q.mat_key: CTL_BSDF_* of the hit, 0 = miss) each launch shades
+#define CTL_CLASS_A_KEYS 0x00CBu   // miss, diffuse, dielectric, conductor, rough conductor (the models of the basic set)
+#define CTL_CLASS_B_KEYS 0x1F34u   // rough diffuse, thin dielectric, rough dielectric, plastic, rough plastic, Phong, Ward, Hanrahan-Krueger
+#define CTL_CLASS_C_KEYS 0xE000u   // coating, rough coating, blend (the nesting models)
 
 struct pass_params {
     const float* t1; const float2* t2;   // sampler tables of the first pass of this batch; pass b of the batch at + b * 4096*30
@@ -49,7 +55,8 @@ struct pass_params {
     uint32_t n_local_pixels;             // pixels rendered by this rank
     int direct, max_path_length, rr_start_depth;
     int sort_materials;                  // shade in wave_queues::order
-    int key_from_traversal;              // Q.mat_key[i] = BSDF model + 1 of path i's hit (0 = miss), left there by the closest-hit traversal (dev_scene::hit_key_out)
+    int key_from_traversal;              // Q.mat_key[i] = BSDF model (CTL_BSDF_*, all >= 1) of path i's hit (0 = miss), left there by the closest-hit traversal (dev_scene::hit_key_out)
+    int model_classes;                   // the full feature set shaded by one launch per model class present in the scene (shade_class_*.hip) instead of the one k_shade_full; needs key_from_traversal
     int block_sort;                      // full shade kernel: regroup the path slots of a workgroup by BSDF model (shade_kernel.inc)
     int sort_octants;                    // append the new rays of a workgroup grouped by direction octant (compaction.h)
     const unsigned char* block_counts;   // samples per 64x64 film block in this pass (a block sampler's decision), nullptr = one everywhere
@@ -84,6 +91,13 @@ void launch_shade(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q
 void read_stack_histogram(unsigned long long* h, bool reset);   // kernels.hip: rays of the counting traversals by deepest stack entry
 void launch_shade_basic(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_full(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_class_partition(const launch_ctx& lc, const wave_queues& Q, int depth);
+void launch_shade_class_a(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_shade_class_b(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_shade_class_c(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_shade_class_a_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_shade_class_b_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_shade_class_c_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_basic_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_full_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_finalize(const launch_ctx& lc, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);

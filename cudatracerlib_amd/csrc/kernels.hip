@@ -355,10 +355,69 @@ __global__ __launch_bounds__(kBlock) void k_mat_scatter(wave_queues Q, int depth
     }
 }
 
+// Model-class shading (shade_class_*.hip): split the vertices of a depth into one slot list per model class.  A workgroup takes windows of 16384 consecutive slots; inside a window the
+// slots of a class are ordered by model (Q.mat_key, the byte per ray the closest-hit traversal left) and go to the class's list as ONE contiguous chunk (one atomic per class
+// and window): a wave of a class launch is full, (mostly) of one model, and its 64 slots lie in one window of the queue (1 MB of path state per array) — the path-state reads stay as local as the in-kernel regrouping of
+// k_shade_full keeps them, without its barriers and without waves that idle because their slots belong to another class.
+#ifndef CTL_PART_PER_LANE
+#define CTL_PART_PER_LANE 16   // slots per lane of a partition workgroup = windows of 16384 slots (synthetic-bathroom shade ms per pass: 1024-slot windows 2.94, 2048: 2.77, 4096: 2.62, 8192: 2.59, 16384: 2.55, 32768: 2.53)
+#endif
+constexpr int kPartBlock = 1024, kPartPerLane = CTL_PART_PER_LANE;
+__device__ __forceinline__ uint32_t class_of_key(uint32_t k) { return ((CTL_CLASS_A_KEYS >> k) & 1u) ? 0u : (((CTL_CLASS_B_KEYS >> k) & 1u) ? 1u : 2u); }
+__global__ __launch_bounds__(kPartBlock) void k_class_partition(wave_queues Q, int depth) {
+    __shared__ uint32_t s_hist[16], s_start[16];
+    const uint32_t n = Q.counts[(depth - 1) * 4 + 0];
+    constexpr uint32_t kWin = kPartBlock * kPartPerLane;
+    for (uint32_t w0 = blockIdx.x * kWin; w0 < n; w0 += gridDim.x * kWin) {
+        if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t key[kPartPerLane], rank[kPartPerLane];
+#pragma unroll
+        for (int k = 0; k < kPartPerLane; k++) {
+            const uint32_t j = w0 + k * kPartBlock + threadIdx.x;
+            key[k] = j < n ? (uint32_t)Q.mat_key[j] & 15u : 16u;
+            // one LDS atomic per model present in the wave (ballot loop), not one per lane
+            rank[k] = 0;
+            unsigned long long todo = __ballot(key[k] < 16u);
+            while (todo) {
+                const uint32_t kk = (uint32_t)__shfl((int)key[k], (int)__builtin_ctzll(todo), 64);
+                const unsigned long long mine = __ballot(key[k] == kk);
+                uint32_t first = 0;
+                if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(mine)) first = atomicAdd(&s_hist[kk], (uint32_t)__popcll(mine));
+                first = (uint32_t)__shfl((int)first, (int)__builtin_ctzll(mine), 64);
+                if (key[k] == kk) rank[k] = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0));
+                todo &= ~mine;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {   // thread c: the chunk of class c in its list, the models of the class in key order inside it
+            uint32_t tot = 0;
+            for (uint32_t k = 0; k < 16; k++) if (class_of_key(k) == threadIdx.x) tot += s_hist[k];
+            uint32_t at = tot ? atomicAdd(&Q.mat_counts[depth * 32 + 24 + threadIdx.x], tot) : 0u;
+            for (uint32_t k = 0; k < 16; k++) if (class_of_key(k) == threadIdx.x) { s_start[k] = at; at += s_hist[k]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPartPerLane; k++)
+            if (key[k] < 16u) Q.class_order[class_of_key(key[k])][s_start[key[k]] + rank[k]] = w0 + k * kPartBlock + threadIdx.x;
+        __syncthreads();
+    }
+}
+void launch_class_partition(const launch_ctx& lc, const wave_queues& Q, int depth) {
+    hipLaunchKernelGGL(k_class_partition, dim3(lc.grid_blocks / 4), dim3(kPartBlock), 0, lc.stream, Q, depth);
+}
+
 // the shade kernel exists in feature-specialised builds (shade_basic.hip / shade_full.hip): a scene that uses only the basic
 // material / light / texture set runs the variant whose code does not carry the registers of the rest (dev_scene::shade_features)
 void launch_shade(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image) {
     if (S.shade_features == 0) { if (P.wavefront_rules) launch_shade_basic_wf(lc, S, Q, P, depth, image); else launch_shade_basic(lc, S, Q, P, depth, image); return; }
+    if (P.model_classes) {   // one launch per model class the scene has (class a also takes the misses): shade_class_*.hip
+        launch_class_partition(lc, Q, depth);
+        (P.wavefront_rules ? launch_shade_class_a_wf : launch_shade_class_a)(lc, S, Q, P, depth, image);
+        if (S.shade_models & CTL_CLASS_B_KEYS) (P.wavefront_rules ? launch_shade_class_b_wf : launch_shade_class_b)(lc, S, Q, P, depth, image);
+        if (S.shade_models & CTL_CLASS_C_KEYS) (P.wavefront_rules ? launch_shade_class_c_wf : launch_shade_class_c)(lc, S, Q, P, depth, image);
+        return;
+    }
     if (P.sort_materials) {
         hipLaunchKernelGGL(k_mat_count, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, S, Q, depth);
         hipLaunchKernelGGL(k_mat_scatter, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, Q, depth);

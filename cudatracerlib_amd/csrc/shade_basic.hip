@@ -14,7 +14,9 @@
 #ifndef CTL_BASIC_SORT_WINDOW
 #define CTL_BASIC_SORT_WINDOW 128   // round 4: lanes regroup by BSDF model inside windows of 128 slots, keyed by the byte the closest-hit traversal leaves per ray (dev_scene::hit_key_out): shade 1.52 -> 1.47 ms per
                                    // pass on synthetic-SM (256: 1.48; 512: 1.52 — a wider window packs the rough-conductor lanes better and scatters the path-state reads more; 0 = off: 1.52).  With the key
-                                   // derived in the kernel (hit -> node -> triangle -> material: four dependent loads) the regrouping LOST 11 % in round 2
+                                   // derived in the kernel (hit -> node -> triangle -> material: four dependent loads) the regrouping LOST 11 % in round 2.  The model-ordered slot lists of
+                                   // the class builds (k_class_partition, 16384-slot windows, 256-lane workgroups) lose here: 2.21 ms — this kernel is bound by its path-state streams, and a list
+                                   // turns them into gathers (profiles/r04_shade_experiments.log)
 #endif
 #define CTL_SHADE_SORT_WINDOW CTL_BASIC_SORT_WINDOW
 #define CTL_SHADE_KERNEL k_shade_basic

@@ -1,0 +1,26 @@
+// shade_class_b.hip — model-class build of the shade kernel: the single-layer models beyond the basic set — rough diffuse, thin dielectric, rough dielectric, plastic, rough plastic, Phong, Ward, Hanrahan-Krueger.
+// A scene that needs the full feature set AND has the traversal's key per ray (flattened BVH, dev_scene::flat_leaf_keys) is shaded by one launch per model class present in it
+// (kernels.hip launch_shade), each over the slot list k_class_partition made for the class, instead of one kernel over all slots that carries every model and regroups them
+// behind workgroup barriers: 256-lane workgroups, full waves of (mostly) one model, no wave that idles at a barrier while the slowest model of the workgroup finishes.
+#define CTL_SHADE_FEATURES (0x7F & ~16)
+#include "kernels.h"
+#define CTL_SHADE_KEYS CTL_CLASS_B_KEYS
+#define CTL_SHADE_CLASS 1
+#ifndef CTL_CLASS_B_BLOCK
+#define CTL_CLASS_B_BLOCK 256
+#endif
+#define CTL_SHADE_BLOCK CTL_CLASS_B_BLOCK
+#ifndef CTL_CLASS_B_WAVES
+#define CTL_CLASS_B_WAVES 4
+#endif
+#if CTL_CLASS_B_WAVES > 0
+#define CTL_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(CTL_CLASS_B_WAVES, CTL_CLASS_B_WAVES)))
+#endif
+#if defined(CTL_SHADE_WAVEFRONT_RULES) && CTL_SHADE_WAVEFRONT_RULES   // shade_class_b_wf.hip: pathIterateKernel's own path rules (PathSemantics = Wavefront)
+#define CTL_SHADE_KERNEL k_shade_class_b_wf
+#define CTL_SHADE_LAUNCH launch_shade_class_b_wf
+#else
+#define CTL_SHADE_KERNEL k_shade_class_b
+#define CTL_SHADE_LAUNCH launch_shade_class_b
+#endif
+#include "shade_kernel.inc"

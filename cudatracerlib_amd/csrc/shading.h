@@ -9,6 +9,18 @@
 #ifndef CTL_SHADE_FEATURES
 #define CTL_SHADE_FEATURES 0x7F
 #endif
+// BSDF models compiled into the dispatch switches of this translation unit: bit m = the model CTL_BSDF_* == m (bit 0 = the miss / environment branch of the shade kernel).
+// The model-class builds of the shade kernel (shade_class_*.hip) each carry one group of models; everything else carries all of them.
+#ifndef CTL_SHADE_MODELS
+#define CTL_SHADE_MODELS 0xFFFFu
+#endif
+#define CTL_HAS_MODEL(m) ((((unsigned)(CTL_SHADE_MODELS)) >> (m)) & 1u)
+// the rough and nesting model bodies stay out of line where a nesting model can call back into them (one copy instead of one per call site); a class build without nesting inlines them
+#if (CTL_SHADE_FEATURES & 16) || defined(CTL_CLASS_B_OUTLINE)
+#define CTL_ROUGH_OUTLINE __noinline__
+#else
+#define CTL_ROUGH_OUTLINE
+#endif
 
 namespace ctl {
 
@@ -423,7 +435,7 @@ namespace ctl {
 
 __device__ f3 bsdf_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp) {
     switch (M.bsdf_type) {
-    case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:7-36
+    case CTL_BSDF_DIFFUSE: { if (!CTL_HAS_MODEL(CTL_BSDF_DIFFUSE)) return f3(0.0f);   // BSDF_Simple.cu:7-36
         const uint32_t ct = M.combined_type;
         if (!(b.type_mask & ct) || (ct == CTL_EDiffuseReflection && cos_theta(b.wi) <= 0)) return f3(0.0f);
         b.sampled_type = ct;
@@ -439,7 +451,7 @@ __device__ f3 bsdf_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp
         pdf = fabsf(kInvPi * cos_theta(b.wo)) * sc;
         return tex_eval(M.tex[0], b.dg) * sc;
     }
-    case CTL_BSDF_DIELECTRIC: {   // BSDF_Simple.cu:174-224; no dispersion -> eta = B + C / 0.6 (Dispersion.h)
+    case CTL_BSDF_DIELECTRIC: { if (!CTL_HAS_MODEL(CTL_BSDF_DIELECTRIC)) return f3(0.0f);   // BSDF_Simple.cu:174-224; no dispersion -> eta = B + C / 0.6 (Dispersion.h)
         const bool sr = (b.type_mask & CTL_EDeltaReflection) != 0, st = (b.type_mask & CTL_EDeltaTransmission) != 0;
         float cosThetaT; const float eta = M.f[0] + M.f[1] / (600 / 1e3f), invEta = 1.0f / eta;
         const float F = fresnel_dielectric_ext(cos_theta(b.wi), cosThetaT, eta);
@@ -458,12 +470,12 @@ __device__ f3 bsdf_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp
         }
         return f3(0.0f);
     }
-    case CTL_BSDF_CONDUCTOR: {   // BSDF_Simple.cu:617-630
+    case CTL_BSDF_CONDUCTOR: { if (!CTL_HAS_MODEL(CTL_BSDF_CONDUCTOR)) return f3(0.0f);   // BSDF_Simple.cu:617-630
         if (!(b.type_mask & CTL_EDeltaReflection) || cos_theta(b.wi) <= 0) return f3(0.0f);
         b.sampled_type = CTL_EDeltaReflection; b.wo = reflect_local(b.wi); b.eta = 1.0f; pdf = 1;
         return tex_eval(M.tex[0], b.dg) * fresnel_conductor_exact(cos_theta(b.wi), f3(M.f[0], M.f[1], M.f[2]), f3(M.f[3], M.f[4], M.f[5]));
     }
-    case CTL_BSDF_ROUGHCONDUCTOR: {   // BSDF_Simple.cu:662-705
+    case CTL_BSDF_ROUGHCONDUCTOR: { if (!CTL_HAS_MODEL(CTL_BSDF_ROUGHCONDUCTOR)) return f3(0.0f);   // BSDF_Simple.cu:662-705
         if (cos_theta(b.wi) < 0 || !(b.type_mask & CTL_EGlossyReflection)) return f3(0.0f);
         const microfacet distr((int)M.u[0], avg3(tex_eval(M.tex[1], b.dg)), avg3(tex_eval(M.tex[2], b.dg)), M.u[1] != 0);
         const f3 m = distr.sample(b.wi, smp, pdf);
@@ -488,7 +500,7 @@ __device__ f3 bsdf_sample(const ctl_material& M, bsdf_rec& b, float& pdf, f2 smp
 // f() and pdf() for solid-angle measure (the only measure the path asks for: TraceAlgorithms.cu:55,61)
 __device__ f3 bsdf_f(const ctl_material& M, const bsdf_rec& b) {
     switch (M.bsdf_type) {
-    case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:38-56
+    case CTL_BSDF_DIFFUSE: { if (!CTL_HAS_MODEL(CTL_BSDF_DIFFUSE)) return f3(0.0f);   // BSDF_Simple.cu:38-56
         const uint32_t ct = M.combined_type;
         if (!(b.type_mask & ct)) return f3(0.0f);
         const bool vr = ct == CTL_EDiffuseReflection && cos_theta(b.wi) > 0 && cos_theta(b.wo) > 0;
@@ -498,7 +510,7 @@ __device__ f3 bsdf_f(const ctl_material& M, const bsdf_rec& b) {
         if (ct == (CTL_EDiffuseReflection | CTL_EDiffuseTransmission)) return s * 0.5f;
         return f3(0.0f);
     }
-    case CTL_BSDF_ROUGHCONDUCTOR: {   // BSDF_Simple.cu:707-740
+    case CTL_BSDF_ROUGHCONDUCTOR: { if (!CTL_HAS_MODEL(CTL_BSDF_ROUGHCONDUCTOR)) return f3(0.0f);   // BSDF_Simple.cu:707-740
         if (cos_theta(b.wi) < 0 || cos_theta(b.wo) < 0 || !(b.type_mask & CTL_EGlossyReflection)) return f3(0.0f);
         const f3 H = normalize(b.wo + b.wi);
         const microfacet distr((int)M.u[0], avg3(tex_eval(M.tex[1], b.dg)), avg3(tex_eval(M.tex[2], b.dg)), M.u[1] != 0);
@@ -519,7 +531,7 @@ __device__ f3 bsdf_f(const ctl_material& M, const bsdf_rec& b) {
 }
 __device__ float bsdf_pdf(const ctl_material& M, const bsdf_rec& b) {
     switch (M.bsdf_type) {
-    case CTL_BSDF_DIFFUSE: {   // BSDF_Simple.cu:58-75
+    case CTL_BSDF_DIFFUSE: { if (!CTL_HAS_MODEL(CTL_BSDF_DIFFUSE)) return 0.0f;   // BSDF_Simple.cu:58-75
         const uint32_t ct = M.combined_type;
         if (!(b.type_mask & ct)) return 0.0f;
         const bool vr = ct == CTL_EDiffuseReflection && cos_theta(b.wi) > 0 && cos_theta(b.wo) > 0;
@@ -529,7 +541,7 @@ __device__ float bsdf_pdf(const ctl_material& M, const bsdf_rec& b) {
         if (ct == (CTL_EDiffuseReflection | CTL_EDiffuseTransmission)) return f * 0.5f;
         return 0.0f;
     }
-    case CTL_BSDF_ROUGHCONDUCTOR: {   // BSDF_Simple.cu:742-763
+    case CTL_BSDF_ROUGHCONDUCTOR: { if (!CTL_HAS_MODEL(CTL_BSDF_ROUGHCONDUCTOR)) return 0.0f;   // BSDF_Simple.cu:742-763
         if (cos_theta(b.wi) < 0 || cos_theta(b.wo) < 0 || !(b.type_mask & CTL_EGlossyReflection)) return 0.0f;
         const f3 H = normalize(b.wo + b.wi);
         const microfacet distr((int)M.u[0], avg3(tex_eval(M.tex[1], b.dg)), avg3(tex_eval(M.tex[2], b.dg)), M.u[1] != 0);

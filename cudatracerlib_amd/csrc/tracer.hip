@@ -187,10 +187,11 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
     }
     mats_.upload(dmats.data(), dmats.size());
     // which shade-kernel build this scene needs (kernels.hip launch_shade)
-    S.shade_features = 0; S.alpha_maps = 0;
+    S.shade_features = 0; S.alpha_maps = 0; S.shade_models = 0;
     for (uint32_t i = 0; i < d.n_lights_buf; i++) if (d.lights[i].type != CTL_LIGHT_POINT && d.lights[i].type != CTL_LIGHT_DIFFUSE) S.shade_features |= kShadeMoreLights;
     for (uint32_t i = 0; i < d.n_materials; i++) {
         const uint32_t t = d.materials[i].bsdf_type;
+        S.shade_models |= 1u << (t & 15u);
         if (t == CTL_BSDF_THINDIELECTRIC || t == CTL_BSDF_ROUGHDIELECTRIC || t == CTL_BSDF_PLASTIC || t == CTL_BSDF_PHONG) S.shade_features |= kShadeMoreBsdfs;
         if (t == CTL_BSDF_ROUGHDIFFUSE || t == CTL_BSDF_WARD || t == CTL_BSDF_ROUGHPLASTIC) S.shade_features |= kShadeRoughBsdfs;
         if (t == CTL_BSDF_COATING || t == CTL_BSDF_ROUGHCOATING || t == CTL_BSDF_BLEND) S.shade_features |= kShadeNestingBsdfs | kShadeMoreBsdfs | kShadeRoughBsdfs;
@@ -561,6 +562,10 @@ WavefrontPathTracer::WavefrontPathTracer() {
     m_sParameters.addBool("SortMaterials", false);
     // build-specific: the full shade kernel regroups the paths of each workgroup by BSDF model before shading them (shade_kernel.inc)
     m_sParameters.addBool("BlockSort", true);
+    // build-specific: a scene that needs the full feature set is shaded by one launch per MODEL CLASS present in it (shade_class_a/b/c.hip: basic models + misses / the other single-layer
+    // models / the nesting models), each register-allocated for its own models, instead of the one kernel that carries all fifteen (k_shade_full: 104 spilled registers).  Needs the
+    // BSDF model per hit from the closest-hit traversal (flattened BVH).  false = k_shade_full
+    m_sParameters.addBool("ShadeByModelClass", true);
     // build-specific: the rays a shade workgroup emits are appended grouped by direction octant (compaction.h block_append3_keyed).
     // Off by default: measured on synthetic-SM the traversal kernels gain 1 % (6.10 -> 6.05 ms / pass) and the shade kernel pays 0.5 ms for it
     m_sParameters.addBool("SortOctants", false);
@@ -601,7 +606,8 @@ void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
     Q.fin.rad = new_f4(capacity); Q.fin.dir = new_f4(capacity); Q.fin.px = new_f4(capacity);
     stats_.alloc(14); Q.stats = stats_.p; CTL_HIP(hipMemset(stats_.p, 0, 14 * sizeof(unsigned long long)));
     Q.capacity = capacity;
-    order_.alloc(capacity); Q.order = order_.p; mat_key_.alloc(capacity); Q.mat_key = mat_key_.p;
+    order_.alloc((size_t)capacity * 3); Q.order = order_.p; for (int c = 0; c < 3; c++) Q.class_order[c] = order_.p + (size_t)c * capacity;   // SortMaterials uses the first third, the model-class lists one third each
+    mat_key_.alloc(capacity); Q.mat_key = mat_key_.p;
     counts_.free(); work_.free(); mat_counts_.free(); stage_.free();
 }
 
@@ -669,7 +675,7 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
         }
     }
     if (pass_block_counts_ && pass_paths_ > capacity) throw std::runtime_error("ray queue overflow: the block sampler asks for more samples in one pass than the queues hold (DoubleRayBuffer.h:86-89)");
-    if (P.sort_materials) CTL_HIP(hipMemsetAsync(mat_counts_.p, 0, n_mat * sizeof(uint32_t), stream));
+    CTL_HIP(hipMemsetAsync(mat_counts_.p, 0, n_mat * sizeof(uint32_t), stream));
     CTL_HIP(hipMemsetAsync(counts_.p, 0, n_counts * sizeof(uint32_t), stream));
     CTL_HIP(hipMemsetAsync(work_.p, 0, n_work * sizeof(uint32_t), stream));
     timer.begin(stream, 0); launch_raygen(lc, S, Q, P); timer.end(stream);
@@ -683,8 +689,10 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     const bool fuse = !counting && direct && m_sParameters.getValue("FuseTraversal") != 0;
     // closest-hit traversals of a flattened scene leave the BSDF model of every hit in Q.mat_key (device_scene.h hit_key_out) for the shade kernel's regrouping; the counting
     // kernels and the device-wide material sort (which writes its own keys there) do without
-    dev_scene Sk = S; Sk.hit_key_out = (S.flat_leaf_keys && S.shade_features == 0 && !counting && !P.sort_materials && P.block_sort) ? Q.mat_key : nullptr;   // (the full build keys its regrouping by model AND material index)
+    P.model_classes = (S.shade_features != 0 && m_sParameters.getValue("ShadeByModelClass") != 0) ? 1 : 0;
+    dev_scene Sk = S; Sk.hit_key_out = (S.flat_leaf_keys && (S.shade_features == 0 || P.model_classes) && !counting && !P.sort_materials && P.block_sort) ? Q.mat_key : nullptr;   // (k_shade_full keys its regrouping by model AND material index)
     P.key_from_traversal = Sk.hit_key_out ? 1 : 0;
+    if (!P.key_from_traversal) P.model_classes = 0;
     for (int depth = 1; depth <= maxPathLength; depth++) {
         const int cur = (depth - 1) & 1;
         if (fuse && depth > 1) {   // path rays of this bounce + shadow rays of the previous one in one launch

@@ -65,7 +65,7 @@ struct hit_in_memory {
     __device__ __forceinline__ float dist() const { return ht; }
     __device__ __forceinline__ void accept(float t, float u, float v, int tri, int nd, uint32_t key) {
         ht = t;
-        if (hit) { const uint32_t id = ray_word & 0x7fffffffu; hit[id] = make_float4(t, u, v, __int_as_float(tri)); hit_node[id] = nd; if (key_out) key_out[id] = (unsigned char)(key + 1u); }
+        if (hit) { const uint32_t id = ray_word & 0x7fffffffu; hit[id] = make_float4(t, u, v, __int_as_float(tri)); hit_node[id] = nd; if (key_out) key_out[id] = (unsigned char)key; }
         ray_word |= 0x80000000u;
     }
 };

@@ -400,11 +400,12 @@ def env_scene(width=96, height=64, rotate_env=False, point_filter=False, extra_l
     return sc
 
 
-def synthetic_bathroom(width=1920, height=1080, n_instances=300, subdiv=4, seed=17):
+def synthetic_bathroom(width=1920, height=1080, n_instances=300, subdiv=4, seed=17, material_set="all"):
     """"synthetic-bathroom": the seeded stand-in for BASELINE config 5 (Bitterli bathroom: rough plastic / rough conductor / rough
     dielectric surfaces under an environment emitter — the shading-divergence stress).  A tiled floor with a bitmap texture and a
     height map, walls of rough plastic, n_instances spheres / boxes cycling through nine BSDF models (Beckmann and GGX, visible-normal
-    sampling, rough glass, coated metal, Oren-Nayar), lit by a lat-long environment map through a window-less open top plus one area light."""
+    sampling, rough glass, coated metal, Oren-Nayar), lit by a lat-long environment map through a window-less open top plus one area light.
+    material_set (probes only, tools/shade_class_probe.py): "basic" / "single" swap every material for one of the shade kernel's model class a / class b (same geometry, lights and maps)."""
     from . import rough_tables
     rs = np.random.RandomState(seed)
     sc = api.DynamicScene()
@@ -414,10 +415,12 @@ def synthetic_bathroom(width=1920, height=1080, n_instances=300, subdiv=4, seed=
     tiles = sc.add_image(checker_image(), api.TEXEL_RGBCOL, api.WRAP_REPEAT, api.FILTER_BILINEAR)
     bumps = sc.add_image(api.float3_to_rgbcol(bump_image()), api.TEXEL_RGBCOL, api.WRAP_REPEAT, api.FILTER_BILINEAR)
     floor_mat = api.roughplastic(api.image_texture(tiles, scale=(0.8, 0.8, 0.8), uv_scale=(12.0, 12.0)), alpha=0.08, distribution=0)
+    if material_set == "basic":
+        floor_mat = api.diffuse(api.image_texture(tiles, scale=(0.8, 0.8, 0.8), uv_scale=(12.0, 12.0)))
     api.set_height_map(floor_mat, api.image_texture(bumps, scale=(0.02, 0.02, 0.02), uv_scale=(24.0, 24.0)))
     P, I, N = _quad([[-30, 0, -30], [-30, 0, 30], [30, 0, 30], [30, 0, -30]], [0, 1, 0])
     sc.CreateNode(sc.add_mesh(P, I, normals=N, uvs=np.array([[0, 0], [0, 1], [1, 1], [1, 0]], np.float32), materials=[floor_mat]))
-    wall = api.roughplastic((0.75, 0.74, 0.7), alpha=0.2, distribution=1)
+    wall = api.roughplastic((0.75, 0.74, 0.7), alpha=0.2, distribution=1) if material_set != "basic" else api.diffuse((0.75, 0.74, 0.7))
     m = _MeshAcc()
     for p, n in (([[-30, 0, 30], [-30, 25, 30], [30, 25, 30], [30, 0, 30]], [0, 0, -1]), ([[-30, 0, -30], [-30, 25, -30], [-30, 25, 30], [-30, 0, 30]], [1, 0, 0]),
                  ([[30, 0, 30], [30, 25, 30], [30, 25, -30], [30, 0, -30]], [-1, 0, 0])):
@@ -431,6 +434,10 @@ def synthetic_bathroom(width=1920, height=1080, n_instances=300, subdiv=4, seed=
             api.roughconductor(alpha=0.1, distribution=0, sample_visible=True), api.roughconductor(alpha=0.25, alpha_v=0.05, distribution=1, sample_visible=True, eta=(0.14, 0.37, 1.44), k=(3.98, 2.38, 1.6)),
             api.roughdielectric(alpha=0.08, int_ior=1.5, ext_ior=1.0, distribution=1, sample_visible=True), api.roughdielectric(alpha=0.2, int_ior=1.33, ext_ior=1.0, distribution=0, sample_visible=True),
             api.dielectric(int_ior=1.5, ext_ior=1.0), api.coating(i0, n0, int_ior=1.5, ext_ior=1.0, thickness=1.0, sigma_a=(0.2, 0.5, 0.9)), api.roughdiffuse((0.6, 0.6, 0.55), alpha=0.4)]
+    if material_set == "basic":      # class a only: diffuse / rough conductor / smooth glass / mirror
+        mats = [api.diffuse((0.7, 0.2, 0.15)), api.diffuse((0.2, 0.3, 0.7)), mats[2], mats[3], api.dielectric(int_ior=1.5, ext_ior=1.0), api.conductor(), mats[6], api.roughconductor(alpha=0.15, distribution=1), api.diffuse((0.6, 0.6, 0.55))]
+    elif material_set == "single":   # class b only: rough plastic / rough dielectric / rough diffuse / plastic
+        mats = [mats[0], mats[1], api.plastic((0.5, 0.5, 0.2)), mats[0], mats[4], mats[5], mats[1], mats[8], mats[8]]
     V, F = icosphere(subdiv)
     spheres = [sc.add_mesh(V, F, normals=V, materials=[mm]) for mm in mats]
     Pb, Ib, Nb = unit_box()

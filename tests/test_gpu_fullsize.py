@@ -178,7 +178,7 @@ def test_bathroom_workload_at_full_size(gpu, orc):
             assert abs(g.mean() - w.mean()) <= mean_tol * w.mean(), (depth, y0, g.mean(), w.mean())
     base, rays = render(gpu, gpu.WavefrontPathTracer, flat, tables)
     assert rays > 4 * W * H
-    for params in (dict(BlockSort=False), dict(SortMaterials=True)):
+    for params in (dict(BlockSort=False), dict(SortMaterials=True), dict(ShadeByModelClass=False)):
         other, rays_o = render(gpu, gpu.WavefrontPathTracer, flat, tables, **params)
         assert rays_o == rays
         assert np.array_equal(other[..., 6], base[..., 6])

@@ -118,13 +118,13 @@ def test_synthetic_bathroom_workload(gpu, orc):
 
 
 def test_queue_ordering_options_do_not_change_the_image(gpu, orc):
-    """FuseTraversal (path rays of a bounce and shadow rays of the previous one in one persistent launch, or in two), BlockSort (each workgroup of the full shade kernel regroups its paths by BSDF model), SortMaterials (shade in BSDF-model order) and SortOctants (append new rays grouped by direction octant) only reorder work:
+    """FuseTraversal (path rays of a bounce and shadow rays of the previous one in one persistent launch, or in two), BlockSort (each workgroup of the full shade kernel regroups its paths by BSDF model), ShadeByModelClass (one shade launch per model class of the scene, or the one kernel with every model), SortMaterials (shade in BSDF-model order) and SortOctants (append new rays grouped by direction octant) only reorder work:
     same frame (up to the order of the float atomics) and same ray count as the default order"""
     sc = scenes.synthetic_bathroom(96, 54, n_instances=60, subdiv=2)
     scene = gpu.Scene(sc.desc, flatten=True)
     tables = orc.sequence_tables(3)
     out = []
-    for params in (dict(), dict(SortMaterials=True), dict(SortOctants=True), dict(SortMaterials=True, SortOctants=True), dict(BlockSort=False), dict(BlockSort=False, SortMaterials=True), dict(FuseTraversal=False)):
+    for params in (dict(), dict(SortMaterials=True), dict(SortOctants=True), dict(SortMaterials=True, SortOctants=True), dict(BlockSort=False), dict(BlockSort=False, SortMaterials=True), dict(FuseTraversal=False), dict(ShadeByModelClass=False), dict(ShadeByModelClass=False, BlockSort=False)):
         tr = gpu.WavefrontPathTracer(); p = tr.getParameters(); p.setValue("MaxPathLength", 6)
         for k, v in params.items():
             p.setValue(k, v)
