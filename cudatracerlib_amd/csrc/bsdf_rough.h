@@ -18,7 +18,7 @@ __device__ __forceinline__ bool spline_weights(float p, uint32_t size, float* w,
     if (knot + 2 < size) { w[3] += 0.5f * d1; w[1] -= 0.5f * d1; } else { w[2] += d1; w[1] -= d1; }
     return true;
 }
-__device__ float eval_cubic_interp_2d(float px, float py, const float* __restrict__ values, uint32_t sx, uint32_t sy) {
+__device__ CTL_ROUGH_BODY float eval_cubic_interp_2d(float px, float py, const float* __restrict__ values, uint32_t sx, uint32_t sy) {
     float wx[4], wy[4]; uint32_t kx, ky;
     if (!spline_weights(px, sx, wx, kx) || !spline_weights(py, sy, wy, ky)) return 0.0f;
     float result = 0.0f;
@@ -30,7 +30,7 @@ __device__ float eval_cubic_interp_2d(float px, float py, const float* __restric
         }
     return result;
 }
-__device__ float eval_cubic_interp_3d(float px, float py, float pz, const float* __restrict__ values, uint32_t sx, uint32_t sy, uint32_t sz) {
+__device__ CTL_ROUGH_BODY float eval_cubic_interp_3d(float px, float py, float pz, const float* __restrict__ values, uint32_t sx, uint32_t sy, uint32_t sz) {
     float wx[4], wy[4], wz[4]; uint32_t kx, ky, kz;
     if (!spline_weights(px, sx, wx, kx) || !spline_weights(py, sy, wy, ky) || !spline_weights(pz, sz, wz, kz)) return 0.0f;
     float result = 0.0f;
@@ -46,7 +46,7 @@ __device__ float eval_cubic_interp_3d(float px, float py, float pz, const float*
     return result;
 }
 // RoughTransmittanceManager::Evaluate / EvaluateDiffuse for the table of slot `type`
-__device__ float rough_transmittance(const diff_geom& dg, uint32_t type, float cosTheta, float alpha, float eta) {
+__device__ CTL_ROUGH_BODY float rough_transmittance(const diff_geom& dg, uint32_t type, float cosTheta, float alpha, float eta) {
     const ctl_rough_transmittance& T = dg.rough_transmittance[type];
     const float warpedCosTheta = m_pow(fabsf(cosTheta), 0.25f);
     if (cosTheta < 0) { cosTheta = -cosTheta; eta = 1.0f / eta; }
@@ -58,7 +58,7 @@ __device__ float rough_transmittance(const diff_geom& dg, uint32_t type, float c
     const float result = eval_cubic_interp_3d(warpedCosTheta, warpedAlpha, warpedEta, data, T.theta_samples, T.alpha_samples, T.eta_samples);
     return min2(1.0f, max2(0.0f, result));
 }
-__device__ float rough_transmittance_diffuse(const diff_geom& dg, uint32_t type, float alpha, float eta) {
+__device__ CTL_ROUGH_BODY float rough_transmittance_diffuse(const diff_geom& dg, uint32_t type, float alpha, float eta) {
     const ctl_rough_transmittance& T = dg.rough_transmittance[type];
     const float* data = T.diff_trans;
     if (eta < 1) { data += (size_t)T.eta_samples * T.alpha_samples; eta = 1.0f / eta; }
@@ -74,7 +74,7 @@ __device__ __forceinline__ float cos_phi(f3 v) { const float st = sin_theta(v); 
 __device__ __forceinline__ float safe_acosf(float v) { return m_acos(min2(1.0f, max2(-1.0f, v))); }
 __device__ __forceinline__ float safe_sqrtf(float v) { return sqrtf(max2(0.0f, v)); }
 
-__device__ f3 roughdiffuse_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:82-172
+__device__ CTL_ROUGH_BODY f3 roughdiffuse_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:82-172
     if (!(b.type_mask & CTL_EGlossyReflection) || cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0) return f3(0.0f);
     const float conversionFactor = 1 / sqrtf((float)2);
     const float sigma = avg3(tex_eval(M.tex[1], b.dg)) * conversionFactor;
@@ -104,7 +104,7 @@ __device__ f3 roughdiffuse_f(const ctl_material& M, const bsdf_rec& b) {   // BS
     return (snglScat + dblScat) * (kInvPi * cos_theta(b.wo));
 }
 
-__device__ f3 ward_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:1232-1276
+__device__ CTL_ROUGH_BODY f3 ward_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:1232-1276
     if (cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0) return f3(0.0f);
     const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
     f3 result(0.0f);
@@ -125,7 +125,7 @@ __device__ f3 ward_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simpl
     if (hd) result = result + tex_eval(M.tex[0], b.dg) * kInvPi;
     return result * cos_theta(b.wo);
 }
-__device__ float ward_pdf(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:1278-1313
+__device__ CTL_ROUGH_BODY float ward_pdf(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:1278-1313
     if (cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0) return 0.0f;
     const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
     float diffuseProb = 0.0f, specProb = 0.0f; const float ssw = M.f[0];
@@ -184,7 +184,7 @@ __device__ __forceinline__ float roughplastic_prob_specular(const ctl_material& 
     const float ps = 1 - (M.reserved_[0] ? roughplastic_T(M, b, cos_theta(b.wi), distr.aU) : rough_transmittance_wi(b, M.u[2], cos_theta(b.wi), distr.aU, M.f[0]));
     return (ps * M.f[2]) / (ps * M.f[2] + (1 - ps) * (1 - M.f[2]));
 }
-__device__ f3 roughplastic_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:948-1005
+__device__ CTL_ROUGH_BODY f3 roughplastic_f(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:948-1005
     const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
     if (cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0 || (!hs && !hd)) return f3(0.0f);
     const microfacet distr = roughplastic_distr(M, b.dg);
@@ -208,7 +208,7 @@ __device__ f3 roughplastic_f(const ctl_material& M, const bsdf_rec& b) {   // BS
     }
     return result;
 }
-__device__ float roughplastic_pdf(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:1007-1057
+__device__ CTL_ROUGH_BODY float roughplastic_pdf(const ctl_material& M, const bsdf_rec& b) {   // BSDF_Simple.cu:1007-1057
     const bool hs = (b.type_mask & CTL_EGlossyReflection) != 0, hd = (b.type_mask & CTL_EDiffuseReflection) != 0;
     if (cos_theta(b.wi) <= 0 || cos_theta(b.wo) <= 0 || (!hs && !hd)) return 0.0f;
     const microfacet distr = roughplastic_distr(M, b.dg);

@@ -24,6 +24,22 @@ HD float m_sin(float x) { return __sinf(x); }  HD float m_cos(float x) { return 
 HD void m_sincos(float x, float* s, float* c) { *s = __sinf(x); *c = __cosf(x); }
 HD float m_acos(float x) { return ::acosf(x); }  HD float m_atan(float x) { return ::atanf(x); }  HD float m_atan2(float y, float x) { return ::atan2f(y, x); }
 HD float m_exp(float x) { return __expf(x); }  HD float m_log(float x) { return __logf(x); }  HD float m_log2(float x) { return __log2f(x); }  HD float m_pow(float x, float y) { return __powf(x, y); }
+#elif defined(__HIP_DEVICE_COMPILE__) && defined(CTL_FMATH_OUTLINE)
+// one out-of-line copy of each function per code object instead of one inlined per call site: ctl_fmath.h is 39 % of the code of a model-class shade kernel (293 KB against a 64-KB
+// instruction cache); arguments and results travel in registers
+namespace fm_ol {
+struct sc { float s, c; };
+static __device__ __noinline__ float sin_(float x) { return fm::sin(x); }    static __device__ __noinline__ float cos_(float x) { return fm::cos(x); }
+static __device__ __noinline__ float tan_(float x) { return fm::tan(x); }    static __device__ __noinline__ sc sincos_(float x) { sc r; fm::sincos(x, &r.s, &r.c); return r; }
+static __device__ __noinline__ float acos_(float x) { return fm::acos(x); }  static __device__ __noinline__ float atan_(float x) { return fm::atan(x); }
+static __device__ __noinline__ float atan2_(float y, float x) { return fm::atan2(y, x); }
+static __device__ __noinline__ float exp_(float x) { return fm::exp(x); }    static __device__ __noinline__ float log_(float x) { return fm::log(x); }
+static __device__ __noinline__ float log2_(float x) { return fm::log2(x); }  static __device__ __noinline__ float pow_(float x, float y) { return fm::pow(x, y); }
+}
+HD float m_sin(float x) { return fm_ol::sin_(x); }  HD float m_cos(float x) { return fm_ol::cos_(x); }  HD float m_tan(float x) { return fm_ol::tan_(x); }
+HD void m_sincos(float x, float* s, float* c) { const fm_ol::sc r = fm_ol::sincos_(x); *s = r.s; *c = r.c; }
+HD float m_acos(float x) { return fm_ol::acos_(x); }  HD float m_atan(float x) { return fm_ol::atan_(x); }  HD float m_atan2(float y, float x) { return fm_ol::atan2_(y, x); }
+HD float m_exp(float x) { return fm_ol::exp_(x); }  HD float m_log(float x) { return fm_ol::log_(x); }  HD float m_log2(float x) { return fm_ol::log2_(x); }  HD float m_pow(float x, float y) { return fm_ol::pow_(x, y); }
 #elif defined(__HIP_DEVICE_COMPILE__)
 HD float m_sin(float x) { return fm::sin(x); }  HD float m_cos(float x) { return fm::cos(x); }  HD float m_tan(float x) { return fm::tan(x); }
 HD void m_sincos(float x, float* s, float* c) { fm::sincos(x, s, c); }

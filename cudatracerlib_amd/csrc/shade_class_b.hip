@@ -3,9 +3,11 @@
 // (kernels.hip launch_shade), each over the slot list k_class_partition made for the class, instead of one kernel over all slots that carries every model and regroups them
 // behind workgroup barriers: 256-lane workgroups, full waves of (mostly) one model, no wave that idles at a barrier while the slowest model of the workgroup finishes.
 #define CTL_SHADE_FEATURES (0x7F & ~16)
+#define CTL_FMATH_OUTLINE   // ctl_math.h: one out-of-line copy of each transcendental function instead of one per call site (class b: 293 -> 159 KB of code against a 64-KB instruction cache)
 #include "kernels.h"
 #define CTL_SHADE_KEYS CTL_CLASS_B_KEYS
 #define CTL_SHADE_CLASS 1
+#define CTL_LIGHT_INLINE   // shading.h: no out-of-line emitter function takes the scene by reference — out of line they cost a private copy of the dev_scene argument (496 B of scratch per lane, read back with vector loads): synthetic-bathroom shade 2.52 -> 2.26 ms per pass
 #ifndef CTL_CLASS_B_BLOCK
 #define CTL_CLASS_B_BLOCK 256
 #endif

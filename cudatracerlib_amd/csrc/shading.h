@@ -16,6 +16,20 @@
 #endif
 #define CTL_HAS_MODEL(m) ((((unsigned)(CTL_SHADE_MODELS)) >> (m)) & 1u)
 // the rough and nesting model bodies stay out of line where a nesting model can call back into them (one copy instead of one per call site); a class build without nesting inlines them
+// emitter functions that take the scene by reference: out of line they force a private copy of the kernel's dev_scene argument (496 B of scratch per lane); CTL_LIGHT_INLINE builds inline them
+#ifdef CTL_LIGHT_INLINE
+#define CTL_LIGHT_OUTLINE __forceinline__
+#define CTL_LIGHT_MAYBE __forceinline__
+#else
+#define CTL_LIGHT_OUTLINE __noinline__
+#define CTL_LIGHT_MAYBE
+#endif
+// the bodies of the rough models (called from sample, f and pdf): CTL_ROUGH_INLINE builds force them inline, so that no call takes the BSDF record by reference and it can live in registers
+#ifdef CTL_ROUGH_INLINE
+#define CTL_ROUGH_BODY __forceinline__
+#else
+#define CTL_ROUGH_BODY
+#endif
 #if (CTL_SHADE_FEATURES & 16) || defined(CTL_CLASS_B_OUTLINE)
 #define CTL_ROUGH_OUTLINE __noinline__
 #else
@@ -652,7 +666,7 @@ __device__ float env_pdf_direction(const dev_scene& S, const ctl_light& L, f3 d)
         * L.normalization / fmaxf(fabsf(sinTheta), 0.000001f);
 }
 // InfiniteLight::evalEnvironment (SceneTypes/Light.cu:488-501)
-__device__ f3 env_eval(const dev_scene& S, const ctl_light& L, f3 dir) {
+__device__ CTL_LIGHT_MAYBE f3 env_eval(const dev_scene& S, const ctl_light& L, f3 dir) {
     const f3 v = xform_dir_transpose(L.to_world, dir);
     const f2 uv{ m_atan2(v.x, -v.z) * kInvTwoPi, m_acos(fminf(1.0f, fmaxf(-1.0f, v.y))) * kInvPi };
     return mip_triangle(S.images[L.env_image], uv) * f3(L.env_scale[0], L.env_scale[1], L.env_scale[2]);
@@ -678,7 +692,7 @@ __device__ __forceinline__ bool barycentric(f3 p, f3 a, f3 b, f3 c, float& u, fl
     u = 1.0f - v - w;
     return 0 <= v && v <= 1 && 0 <= u && u <= 1 && 0 <= w && w <= 1;
 }
-__device__ __noinline__ f2 shape_get_position_uv(const dev_scene& S, const ctl_light& L, f3 pos) {   // ShapeSet::getPosition: first triangle of the set that holds the point
+__device__ CTL_LIGHT_OUTLINE f2 shape_get_position_uv(const dev_scene& S, const ctl_light& L, f3 pos) {   // ShapeSet::getPosition: first triangle of the set that holds the point
     const ctl_shape_tri* tris = (const ctl_shape_tri*)(S.anim + L.triangles_index);
     for (uint32_t i = 0; i < L.count; i++) {
         const ctl_shape_tri& sn = tris[i]; f2 b;
@@ -686,7 +700,7 @@ __device__ __noinline__ f2 shape_get_position_uv(const dev_scene& S, const ctl_l
     }
     return f2{ 0.0f, 0.0f };
 }
-__device__ __noinline__ f3 light_radiance_tex(const dev_scene& S, const ctl_light& L, f2 uv) {   // m_rad_texture.Evaluate(dg), dg = {P, bary, uv}
+__device__ CTL_LIGHT_OUTLINE f3 light_radiance_tex(const dev_scene& S, const ctl_light& L, f2 uv) {   // m_rad_texture.Evaluate(dg), dg = {P, bary, uv}
     diff_geom dg; dg.uv = uv; dg.images = S.images;
 #ifdef CTL_TEX_PARTIALS
     dg.has_uv_partials = false;
@@ -696,7 +710,7 @@ __device__ __noinline__ f3 light_radiance_tex(const dev_scene& S, const ctl_ligh
 #endif
 // DiffuseLight / PointLight / SpotLight / DistantLight / InfiniteLight ::sampleDirect (SceneTypes/Light.cu:83-137, 13-31, 287-301, 224-245, 350-366)
 // with ShapeSet::SamplePosition (Engine/ShapeSet.cu:51-69)
-__device__ f3 light_sample_direct(const dev_scene& S, const ctl_light& L, direct_rec& r, f2 smp) {
+__device__ CTL_LIGHT_MAYBE f3 light_sample_direct(const dev_scene& S, const ctl_light& L, direct_rec& r, f2 smp) {
     if (L.type == CTL_LIGHT_POINT) {
         r.p = f3(L.position[0], L.position[1], L.position[2]);
         const f3 dir = r.p - r.ref;
