@@ -30,6 +30,10 @@ int flat_max_leaf() { static const int v = [] { const char* e = knob_env("CTL_FL
 // k_intersect spends ~277 lane-slots on a node step and ~365 on a leaf-entry step at its measured lane utilisation
 int flat_collapse_mode() { static const int v = [] { const char* e = knob_env("CTL_FLAT_COLLAPSE"); return e ? atoi(e) : 0; }(); return v; }
 float flat_collapse_node_cost() { static const float v = [] { const char* e = knob_env("CTL_FLAT_COLLAPSE_NODE_COST"); const float x = e ? (float)atof(e) : 0.0f; return x > 0.0f ? x : 0.75f; }(); return v; }
+// early split clipping (flatten_scene): longest side a triangle reference may have, in medians of the scene's triangle boxes (0 = off); $CTL_FLAT_SPLIT
+float flat_split_ratio() { static const float v = [] { const char* e = knob_env("CTL_FLAT_SPLIT"); const float x = e ? (float)atof(e) : -1.0f; return x >= 0.0f ? x : 4.0f; }(); return v; }   // with the gain rule below, on the GPU (profiles/r04_split_clipping.log): 4: synthetic-sm-hard 3381 Mrays/s (no clipping: 1383), 8: 3316, 16: 3203; synthetic-SM and -bathroom unchanged
+// ... and a split is kept only where the two parts' boxes have less than this fraction of the part's box surface (1 = always); $CTL_FLAT_SPLIT_GAIN
+float flat_split_gain() { static const float v = [] { const char* e = knob_env("CTL_FLAT_SPLIT_GAIN"); const float x = e ? (float)atof(e) : -1.0f; return x > 0.0f ? x : 0.65f; }(); return v; }   // 0.6 .. 0.7 equal; 0.8 .. 1.0 also split axis-aligned floors and walls: synthetic-SM - 7 %, synthetic-sm-hard 2800 .. 2960
 float flat_node_cost() { static const float v = [] { const char* e = knob_env("CTL_FLAT_NODE_COST"); const float x = e ? (float)atof(e) : 0.0f; return x > 0.0f ? x : 0.5f; }(); return v; }
 
 // 4x4 inverse in double (cofactor expansion)
@@ -180,8 +184,8 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node format only
     std::string key;
     if (!cache_dir().empty()) {
-        content_hash H; const uint32_t version = 15;
-        H.add_value(version); { const char* e = knob_env("CTL_FLAT_SLAB_SUBTREE"); H.add_value(e ? atoi(e) : kSlabSubtreeDefault); } { const char* e = knob_env("CTL_FLAT_FORCE_EXPLICIT"); H.add_value(e ? atoi(e) : 0); } H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
+        content_hash H; const uint32_t version = 16;
+        H.add_value(version); { const char* e = knob_env("CTL_FLAT_SLAB_SUBTREE"); H.add_value(e ? atoi(e) : kSlabSubtreeDefault); } { const char* e = knob_env("CTL_FLAT_FORCE_EXPLICIT"); H.add_value(e ? atoi(e) : 0); } H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(flat_split_ratio()); H.add_value(flat_split_gain()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
         for (uint32_t k = 0; k < d.n_nodes; k++) { H.add_value(d.nodes[k].mesh_index); H.add(d.node_transforms[k].m, 64); }
@@ -195,7 +199,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
         }
         out.nodes.clear(); out.nodes_q8.clear(); out.nodes_f4.clear(); out.nodes_f2.clear(); out.leaves.clear(); out.child_links.clear(); out.compact_links = true;
     }
-    struct wtri { uint32_t tri, node, woop; };
+    struct wtri { uint32_t tri, node, woop, local; };   // local: index into mesh_local[mesh of node] (a triangle split below is referenced by several entries)
     // object-space vertices of every mesh's triangles once (degenerate ones can never be hit and are dropped), then per node in parallel
     struct ltri { double v[3][3]; uint32_t tri, woop; };
     std::vector<std::vector<ltri>> mesh_local(d.n_meshes);
@@ -214,7 +218,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
             const float* M = d.node_transforms[k].m;
             size_t o = node_first[k];
             for (const ltri& l : mesh_local[N.mesh_index]) {
-                wtri& t = tris[o]; t.tri = km.tri_offset + l.tri; t.node = (uint32_t)k; t.woop = l.woop;
+                wtri& t = tris[o]; t.tri = km.tri_offset + l.tri; t.node = (uint32_t)k; t.woop = l.woop; t.local = (uint32_t)(o - node_first[k]);
                 aabb& b = boxes[o]; b.reset(); o++;
                 for (int j = 0; j < 3; j++) {
                     for (int r = 0; r < 3; r++) {
@@ -236,6 +240,87 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
         }
     }, 1);
     pt.lap("world triangles");
+    // Early split clipping: a triangle much larger than its neighbours (a floor under two thousand instances, a beam across a hall of small triangles) would otherwise sit in a leaf
+    // near the root whose box every ray crosses.  Such a triangle is entered as several REFERENCES — the same entry, each with the box of the part of the triangle inside one cell of a
+    // recursive spatial-median subdivision of its box (exact polygon clipping in double, rounded outwards, padded like the whole triangle) — until no reference is longer than
+    // flat_split_ratio() x the MEDIAN length of the scene's triangle boxes: the scene's own scale, so a beam through fine geometry ends up in finer pieces than a floor under coarse
+    // one.  The total is held to + 30 % references by doubling that length.  The traversal tests the whole triangle wherever a reference leads it (same hit, same bits; a second
+    // encounter of the closest hit does not pass t < t_hit).  Measured with the oracle's counting traversal (tools/bvh_quality_probe.py): DESIGN.md §3.
+    if (flat_split_ratio() > 0.0f) {
+        const size_t n0 = boxes.size(), budget = n0 * 3 / 10 + 64;
+        auto longest = [](const aabb& b) { return std::max(std::max(b.hi[0] - b.lo[0], b.hi[1] - b.lo[1]), b.hi[2] - b.lo[2]); };
+        std::vector<float> ext(n0);
+        for (size_t g = 0; g < n0; g++) ext[g] = longest(boxes[g]);
+        std::nth_element(ext.begin(), ext.begin() + n0 / 2, ext.end());
+        const double median = ext[n0 / 2];
+        struct piece { aabb box; uint32_t src; };
+        std::vector<piece> extra; std::vector<aabb> first;   // first[i]: the box that replaces boxes[big[i]]
+        std::vector<uint32_t> big;
+        for (double lmax = std::max(median * flat_split_ratio(), 1e-30);; lmax *= 2.0) {
+            extra.clear(); first.clear(); big.clear();
+            bool over = false;
+            for (size_t g = 0; g < n0 && !over; g++) {
+                const aabb& b = boxes[g];
+                if (longest(b) <= lmax) continue;
+                const wtri& t = tris[g]; const ltri& l = mesh_local[d.nodes[t.node].mesh_index][t.local]; const float* M = d.node_transforms[t.node].m;
+                double w[3][3];
+                for (int j = 0; j < 3; j++) for (int r = 0; r < 3; r++) w[j][r] = (double)M[r * 4] * l.v[j][0] + (double)M[r * 4 + 1] * l.v[j][1] + (double)M[r * 4 + 2] * l.v[j][2] + (double)M[r * 4 + 3];
+                const float off = (float)woop_slack(l.v, M);
+                struct poly { double p[9][3]; int n; double lo[3], hi[3]; };
+                std::vector<poly> todo(1), done;
+                poly& P0 = todo[0]; P0.n = 3;
+                for (int j = 0; j < 3; j++) for (int r = 0; r < 3; r++) P0.p[j][r] = w[j][r];
+                for (int r = 0; r < 3; r++) { P0.lo[r] = std::min(std::min(w[0][r], w[1][r]), w[2][r]); P0.hi[r] = std::max(std::max(w[0][r], w[1][r]), w[2][r]); }
+                while (!todo.empty()) {
+                    poly P = todo.back(); todo.pop_back();
+                    int ax = 0; for (int r = 1; r < 3; r++) if (P.hi[r] - P.lo[r] > P.hi[ax] - P.lo[ax]) ax = r;
+                    if (P.hi[ax] - P.lo[ax] <= lmax || P.n > 7 || done.size() + todo.size() >= 16384) { done.push_back(P); continue; }
+                    const double mid = 0.5 * (P.lo[ax] + P.hi[ax]);
+                    const size_t todo_before = todo.size();
+                    for (int side_k = 0; side_k < 2; side_k++) {   // Sutherland-Hodgman against x[ax] <= mid / >= mid
+                        poly Q; Q.n = 0;
+                        for (int i = 0; i < P.n; i++) {
+                            const double* a = P.p[i]; const double* c = P.p[(i + 1) % P.n];
+                            const bool ia = side_k ? a[ax] >= mid : a[ax] <= mid, ic = side_k ? c[ax] >= mid : c[ax] <= mid;
+                            if (ia) { for (int r = 0; r < 3; r++) Q.p[Q.n][r] = a[r]; Q.n++; }
+                            if (ia != ic) { const double u = (mid - a[ax]) / (c[ax] - a[ax]); for (int r = 0; r < 3; r++) Q.p[Q.n][r] = r == ax ? mid : a[r] + u * (c[r] - a[r]); Q.n++; }
+                        }
+                        if (Q.n < 3) continue;
+                        for (int r = 0; r < 3; r++) { Q.lo[r] = Q.hi[r] = Q.p[0][r]; for (int i = 1; i < Q.n; i++) { Q.lo[r] = std::min(Q.lo[r], Q.p[i][r]); Q.hi[r] = std::max(Q.hi[r], Q.p[i][r]); } }
+                        // the interpolated corners carry round-off of the order of the triangle's size: keep a part's box inside the parent part's box, and widen it by that round-off
+                        for (int r = 0; r < 3; r++) { const double e = 4e-16 * (std::fabs(P.lo[r]) + std::fabs(P.hi[r]) + (P.hi[r] - P.lo[r])); Q.lo[r] = std::max(P.lo[r], Q.lo[r] - e); Q.hi[r] = std::min(P.hi[r], Q.hi[r] + e); }
+                        todo.push_back(Q);
+                    }
+                    // keep the split only where it removes empty space: the two parts' boxes together must have less than flat_split_gain() x the surface of the part's box.  Halving a
+                    // beam that crosses its box diagonally quarters each box (sum 0.5); halving an axis-aligned rectangle of a floor removes nothing (sum 1.0) and only adds references
+                    if (todo.size() == todo_before + 2) {
+                        auto half_area = [](const poly& B) { const double x = B.hi[0] - B.lo[0], y = B.hi[1] - B.lo[1], z = B.hi[2] - B.lo[2]; return x * y + y * z + z * x; };
+                        if (half_area(todo[todo_before]) + half_area(todo[todo_before + 1]) >= flat_split_gain() * half_area(P)) { todo.resize(todo_before); done.push_back(P); }
+                    } else if (todo.size() == todo_before + 1) { todo.resize(todo_before); done.push_back(P); }   // everything on one side of the plane (a sliver): no split
+                    else if (todo.size() == todo_before) done.push_back(P);
+                }
+                if (done.size() < 2) continue;
+                big.push_back((uint32_t)g);
+                for (size_t i = 0; i < done.size(); i++) {
+                    aabb pb;
+                    for (int r = 0; r < 3; r++) {
+                        pb.lo[r] = round_down(done[i].lo[r]); pb.hi[r] = round_up(done[i].hi[r]);
+                        const float mag = std::max(std::max(std::max(std::fabs(b.lo[r]), std::fabs(b.hi[r])), b.hi[r] - b.lo[r]), off);   // the WHOLE triangle's padding: the test that accepts a hit is the whole triangle's
+                        const float e = mag * 9.5367431640625e-7f + 1e-30f;
+                        pb.lo[r] = std::max(b.lo[r], pb.lo[r] - e); pb.hi[r] = std::min(b.hi[r], pb.hi[r] + e);
+                    }
+                    if (i == 0) first.push_back(pb); else extra.push_back(piece{ pb, (uint32_t)g });
+                }
+                if (extra.size() > budget) over = true;
+            }
+            if (!over) break;
+        }
+        for (size_t i = 0; i < big.size(); i++) boxes[big[i]] = first[i];
+        tris.reserve(n0 + extra.size()); boxes.reserve(n0 + extra.size());
+        for (const piece& e : extra) { tris.push_back(tris[e.src]); boxes.push_back(e.box); }
+        out.split_refs = extra.size();
+        pt.lap("split large triangles");
+    }
     bvh_result R;
     build_bvh(boxes, out.format == kFlatQ8 ? 1 : flat_max_leaf(), true, 60, R, flat_node_cost());   // Q8: every leaf slot is ONE entry (flat8.h)
     pt.lap("build BVH2");
@@ -485,7 +570,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
         const uint32_t none = 0x76543210u;
         auto world_tri = [&](uint32_t entry, double w[3][3], double& slack) {
             const size_t g = R.leaf_prims[entry_src[entry]]; const wtri& t = tris[g];
-            const ltri& l = mesh_local[d.nodes[t.node].mesh_index][g - node_first[t.node]];
+            const ltri& l = mesh_local[d.nodes[t.node].mesh_index][t.local];
             const float* M = d.node_transforms[t.node].m;
             for (int j = 0; j < 3; j++) for (int r = 0; r < 3; r++) w[j][r] = (double)M[r * 4] * l.v[j][0] + (double)M[r * 4 + 1] * l.v[j][1] + (double)M[r * 4 + 2] * l.v[j][2] + (double)M[r * 4 + 3];
             slack = woop_slack(l.v, M);

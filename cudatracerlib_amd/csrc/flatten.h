@@ -109,6 +109,7 @@ struct flat_scene {
     std::vector<int32_t> child_links;     // Q4: 4 explicit links per node (as flat4_node::child), host side only
     bool root_slab = false;               // Q4: the root node itself carries a slab (single-node trees)
     size_t slab_nodes = 0;                // Q4: nodes that carry a slab
+    size_t split_refs = 0;                // references added by early split clipping (flatten.cpp; a triangle with k references has k leaf entries)
     size_t node_bytes() const { return nodes.size() * sizeof(flat4_node) + nodes_f4.size() * sizeof(flat4f_node) + nodes_f2.size() * sizeof(ctl_bvh_node) + nodes_q8.size() * sizeof(flat8_node); }
     int stack_need() const { return (format == kFlatF2 || format == kFlatQ8) ? max_depth + 2 : 3 * max_depth + 2; }   // traversal-stack entries a ray can need (Q8: one sibling group per level)
 };

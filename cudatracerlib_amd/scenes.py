@@ -461,6 +461,33 @@ def synthetic_bathroom(width=1920, height=1080, n_instances=300, subdiv=4, seed=
     return sc
 
 
+def beams_over_spheres(width=64, height=64, n_instances=40, n_beams=24, seed=5):
+    """A floor, `n_instances` small icospheres and `n_beams` long thin quads that cross the room diagonally: triangles hundreds of times longer than their neighbours, whose boxes are
+    mostly empty — what early split clipping (csrc/flatten.cpp) enters as several references."""
+    rs = np.random.RandomState(seed)
+    sc = api.DynamicScene()
+    P, I, N = _quad([[-12, 0, -12], [-12, 0, 12], [12, 0, 12], [12, 0, -12]], [0, 1, 0])
+    sc.CreateNode(sc.add_mesh(P, I, normals=N, materials=[api.diffuse((0.6, 0.6, 0.6))]))
+    V, F = icosphere(2)
+    ball = sc.add_mesh(V, F, normals=V, materials=[api.diffuse((0.7, 0.3, 0.2))])
+    for _ in range(n_instances):
+        xf = np.eye(4); xf[:3, :3] *= rs.uniform(0.2, 0.5); xf[:3, 3] = [rs.uniform(-10, 10), rs.uniform(0.5, 6), rs.uniform(-10, 10)]
+        sc.CreateNode(ball, xf.astype(np.float32))
+    m = _MeshAcc()
+    for _ in range(n_beams):
+        a = np.array([rs.uniform(-11, -6), rs.uniform(0.3, 7), rs.uniform(-11, 11)]); b = np.array([rs.uniform(6, 11), rs.uniform(0.3, 7), rs.uniform(-11, 11)])
+        side = np.cross(b - a, rs.normal(size=3)); side *= 0.04 / np.linalg.norm(side)
+        q = [a - side, a + side, b + side, b - side]
+        Pq, Iq, Nq = _quad(q, _quad_normal(q, [0, 20, 0]))
+        m.add(Pq, Iq, Nq, 0)
+    Pb, Ib, Nb, _ = m.arrays()
+    sc.CreateNode(sc.add_mesh(Pb, Ib, normals=Nb, materials=[api.diffuse((0.3, 0.3, 0.35), two_sided=True)]))
+    sc.CreatePointLight((0, 9, 0), (60, 60, 60))
+    sc.setCamera((0, 4, -11.5), (0, 2, 0), (0, 1, 0), 60.0, width, height)
+    sc.UpdateScene()
+    return sc
+
+
 def bump_image(n=64, seed=3):
     """Smooth procedural height field, (n, n, 3) floats in [0, 1] (also the source of the tangent-space normal map below)."""
     y, x = np.mgrid[0:n, 0:n].astype(np.float32) / n

@@ -101,6 +101,20 @@ def test_flattened_world_space_bvh(gpu, orc, any_hit, fmt):
     check_flat(gpu, orc, sc.desc, camera_and_random_rays(sc.desc, 30000, 7, any_tmax=any_hit), any_hit, fmt)
 
 
+@pytest.mark.parametrize("fmt", ["q8", "q4"])
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_flattened_bvh_with_split_references(gpu, orc, any_hit, fmt):
+    """a scene whose long diagonal beams the flattened BVH enters as several references each (early split clipping, csrc/flatten.cpp; tests/test_oracle_flat.py pins the structure):
+    the kernels report the two-level traversal's hits bit for bit — a triangle met twice is accepted once"""
+    from cudatracerlib_amd import api
+    sc = scenes.beams_over_spheres()
+    fb = api.FlatBvh(sc.desc, api.FLAT_FORMATS[fmt])
+    assert fb.desc.n_leaves > 2 + 40 * 320 + 48 + 100
+    got = check_flat(gpu, orc, sc.desc, camera_and_random_rays(sc.desc, 30000, 7, any_tmax=any_hit), any_hit, fmt)
+    if not any_hit:
+        assert (got["node_idx"] == sc.desc.n_nodes - 1).sum() > 300      # rays that end on a beam
+
+
 def test_flattened_rays_through_vertices_and_edges(gpu, orc):
     """rays aimed exactly at mesh vertices, edge midpoints and centroids.  At a vertex several triangles are hit at t values one unit in the last
     place apart, and WHICH of them a traversal reports depends on the last bit of its box tests — between the reference's own two-level traversal
@@ -147,7 +161,10 @@ def test_flattened_rays_through_vertices_and_edges(gpu, orc):
     for k in ("dist", "u", "v"):
         assert np.array_equal(again[k][agree].view(np.uint32), got[k][hitm][agree].view(np.uint32)), k
     occ = gpu.intersect(scene, rays, any_hit=True)["tri_idx"] >= 0
-    assert np.array_equal(occ, orc.intersect(d, rays, any_hit=True)["tri_idx"] >= 0)
+    assert np.array_equal(occ, orc.intersect(d, rays, any_hit=True, flat=fb.desc)["tri_idx"] >= 0)    # the oracle's any-hit traversal of the SAME arrays: equal
+    # the reference's own two-level traversal: equal but for rays ALONG an edge that two triangles share (the diagonal of the floor quad — its midpoint is a target once per reference of
+    # the floor triangles): the flat traversal reports the far floor triangle there, the two-level one passes between the two (2 of 20595 rays, with or without split clipping)
+    assert (occ != (orc.intersect(d, rays, any_hit=True)["tri_idx"] >= 0)).mean() < 5e-4
 
 
 def test_flattened_cornell_and_ragged(gpu, orc):

@@ -41,6 +41,47 @@ def test_flat_traversal_equals_two_level(orc, fmt):
         assert np.array_equal(occ_f, occ_2)
 
 
+@pytest.mark.parametrize("fmt", [api.FLAT_Q4, api.FLAT_Q8])
+def test_early_split_clipping_keeps_every_hit(orc, fmt):
+    """a scene with beams — thin triangles that cross the room diagonally, hundreds of times longer than the sphere triangles around them: the flattened BVH enters each as SEVERAL
+    references (csrc/flatten.cpp: the same leaf entry under the boxes of the parts of the triangle), every (triangle, instance) pair is still there, and a traversal of it reports the
+    hits of the reference's two-level traversal bit for bit — aimed rays along the beams and at their parts' seams included"""
+    sc = scenes.beams_over_spheres()
+    d = sc.desc
+    fb = api.FlatBvh(d, fmt)
+    L = fb.leaves()
+    pairs = np.stack([L[:, 12] >> 1, L[:, 13]], axis=1)
+    uniq, cnt = np.unique(pairs, axis=0, return_counts=True)
+    n_tris = 2 + 40 * 320 + 48
+    assert len(uniq) == n_tris and fb.desc.n_leaves > n_tris + 100 and cnt.max() >= 8          # the beams have many references ...
+    beam_node = d.n_nodes - 1
+    assert set(uniq[cnt > 1][:, 1].tolist()) <= {beam_node, 0}                                   # ... the spheres' triangles one each
+    rays = rays_for(d, 6000, 11)
+    # rays aimed at points ON the beams (uniformly along them: the seams of the parts are hit at random offsets) from random origins
+    rs = np.random.RandomState(3)
+    P = d.view("tri_data", np.uint32, d.n_tri_data, 8)   # (only used for the count; the targets come from the entries' Woop rows, as in tests/test_gpu_intersect.py)
+    E = L[L[:, 13] == beam_node]
+    R = E[:, :12].view(np.float32).astype(np.float64).reshape(-1, 3, 4)
+    M = np.zeros((len(E), 4, 4)); M[:, 0] = R[:, 1]; M[:, 1] = R[:, 2]; M[:, 2] = R[:, 0]; M[:, 2, 3] *= -1; M[:, 3, 3] = 1
+    Mi = np.linalg.inv(M)
+    v2 = Mi[:, :3, 3]; v0 = v2 + Mi[:, :3, 0]; v1 = v2 + Mi[:, :3, 1]
+    k = rs.randint(0, len(E), size=4000); a, b = rs.uniform(size=(2, 4000, 1)); flip = (a + b) > 1; a = np.where(flip, 1 - a, a); b = np.where(flip, 1 - b, b)
+    target = v2[k] + a * (v0[k] - v2[k]) + b * (v1[k] - v2[k])           # (the beam node's transform is the identity)
+    o = rs.uniform(-11, 11, size=(4000, 3)); o[:, 1] = rs.uniform(0.2, 8, size=4000)
+    dirs = target - o; dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    aimed = np.zeros((4000, 8), np.float32); aimed[:, :3] = o; aimed[:, 4:7] = dirs; aimed[:, 3] = d.ray_trace_eps; aimed[:, 7] = np.float32(3.4e38)
+    rays = np.concatenate([rays, aimed])
+    want = orc.intersect(d, rays); got = orc.intersect(d, rays, flat=fb.desc)
+    ties = (got["tri_idx"] != want["tri_idx"]) & (got["dist"] == want["dist"])
+    same = ~ties
+    assert ties.sum() <= 10 and (want["node_idx"] == beam_node).sum() > 1500
+    for k2 in ("tri_idx", "node_idx"):
+        assert np.array_equal(got[k2][same], want[k2][same]), k2
+    for k2 in ("dist", "u", "v"):
+        assert np.array_equal(got[k2][same].view(np.uint32), want[k2][same].view(np.uint32)), k2
+    assert np.array_equal(orc.intersect(d, rays, any_hit=True, flat=fb.desc)["tri_idx"] >= 0, orc.intersect(d, rays, any_hit=True)["tri_idx"] >= 0)
+
+
 def test_leaf_entries_carry_the_meshes_own_woop_rows_and_the_inverse_transform(orc):
     """a flattened leaf entry (128 B) = the object-space Woop rows of its triangle, bit for bit, (globalTri << 1 | last, node), and a copy of
     rows 0..2 and element (3,3) of that node's inverse transform"""

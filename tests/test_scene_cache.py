@@ -86,7 +86,8 @@ def test_changed_input_misses_and_damaged_file_is_ignored(cache_dir):
 
 
 def test_flattened_bvh_is_well_formed(cache_dir):
-    """every instanced triangle appears exactly once among the leaf entries (no spatial splits in this builder)"""
+    """every instanced triangle appears among the leaf entries — once, or, where early split clipping (flatten.cpp) entered a large triangle as several references, once per reference
+    (the axis-aligned walls of the box are not clipped: halving them removes no empty space; tests/test_oracle_flat.py has a scene with beams)"""
     sc = scenes.cornell_box(32, 32, glass_sphere=True)
     d = sc.desc
     r = api.flatten_probe(d)
@@ -95,4 +96,8 @@ def test_flattened_bvh_is_well_formed(cache_dir):
     tri_off = np.sort(meshes[:, 0]); counts = np.diff(np.append(tri_off, d.n_tri_data))
     per_mesh = dict(zip(tri_off.tolist(), counts.tolist()))
     want = sum(per_mesh[int(meshes[int(n[0]), 0])] for n in nodes)
-    assert r["leaves"] == want and r["nodes"] >= 1 and 1 <= r["depth"] <= 31
+    assert r["leaves"] >= want and r["nodes"] >= 1 and 1 <= r["depth"] <= 31
+    fb = api.FlatBvh(d)
+    L = fb.leaves()
+    uniq = np.unique(np.stack([L[:, 12] >> 1, L[:, 13]], axis=1), axis=0)     # words 12, 13 of an entry: {triangle << 1 | last, node}
+    assert len(uniq) == want                                     # every (triangle, instance) pair is there

@@ -26,6 +26,11 @@ def main():
         sc = scenes.synthetic_sm(a.width, a.height, n_instances=a.instances, subdiv=a.subdiv)
     elif a.workload == "synthetic-bathroom":
         sc = scenes.synthetic_bathroom(a.width, a.height)
+    elif a.workload == "synthetic-sm-hard":   # through the loader, as bench.py builds it (full size: 8.4 M terrain triangles)
+        d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ctl_scene_sm_hard_probe_%dx%d" % (a.width, a.height))
+        if not os.path.exists(os.path.join(d, "scene.xml")):
+            scenes.write_sm_hard_mitsuba(d, a.width, a.height)
+        sc = scenes.load_mitsuba(os.path.join(d, "scene.xml"), a.width, a.height)
     else:
         sc = scenes.cornell_box(a.width, a.height, glass_sphere=True)
     t0 = time.time(); fb = api.FlatBvh(sc.desc, api.FLAT_FORMATS[a.format]); t_build = time.time() - t0
