@@ -256,7 +256,9 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
         struct piece { aabb box; uint32_t src; };
         std::vector<piece> extra; std::vector<aabb> first;   // first[i]: the box that replaces boxes[big[i]]
         std::vector<uint32_t> big;
-        for (double lmax = std::max(median * flat_split_ratio(), 1e-30);; lmax *= 2.0) {
+        double side = 0.0;   // longest side of the scene: references are never made shorter than 1 / 4096 of it (a scene whose median triangle is a point)
+        { aabb sb; sb.reset(); for (const aabb& b : boxes) for (int r = 0; r < 3; r++) { sb.lo[r] = std::min(sb.lo[r], b.lo[r]); sb.hi[r] = std::max(sb.hi[r], b.hi[r]); } side = longest(sb); }
+        for (double lmax = std::max(std::max(median * flat_split_ratio(), side / 4096.0), 1e-30);; lmax *= 2.0) {
             extra.clear(); first.clear(); big.clear();
             bool over = false;
             for (size_t g = 0; g < n0 && !over; g++) {

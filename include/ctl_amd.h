@@ -317,7 +317,9 @@ int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out);
 /* flags: CTL_SCENE_FLATTEN = additionally build ONE world-space BVH over all instanced triangles (128 B of HBM per instanced
  * triangle) and traverse that.  The flattened tree only culls: every leaf entry is evaluated with the reference's instance
  * transform + object-space Woop arithmetic (Kernel/TraceHelper.cu:526-560,646-682), so t,u,v,triangle,node equal the two-level
- * traversal bit for bit.  CTL_SCENE_FLAT_FORMAT(f) picks the node format (measurement; default Q4). */
+ * traversal bit for bit.  A triangle much longer than its neighbours is entered under several leaf entries (early split
+ * clipping, DESIGN.md §3: the same 128 B under the boxes of its parts; a hit is the whole triangle's), so the tree may hold more entries
+ * than the scene has instanced triangles.  CTL_SCENE_FLAT_FORMAT(f) picks the node format (measurement; default Q4). */
 enum { CTL_SCENE_FLATTEN = 1 };
 enum { CTL_FLAT_Q4 = 0,    /* 4-wide, 64-B nodes, 8-bit child boxes (default) */
        CTL_FLAT_F4 = 1,    /* 4-wide, 128-B nodes, fp32 child boxes           */
