@@ -212,7 +212,7 @@ private:
     wave_queues Q{};
     uint32_t capacity = 0, n_local_pixels = 0, alloc_batch_ = 1;
     float* depth_buffer_ = nullptr; unsigned int depth_w_ = 0, depth_h_ = 0;
-    std::vector<std::unique_ptr<dbuf<float4>>> f4_; dbuf<float2> px_[2]; dbuf<float4> stage_; dbuf<int> hit_node_; dbuf<uint32_t> occ_[2], counts_, work_, order_, mat_counts_; dbuf<unsigned char> mat_key_; dbuf<unsigned long long> stats_;
+    std::vector<std::unique_ptr<dbuf<float4>>> f4_; dbuf<float2> px_[2]; dbuf<float4> stage_; dbuf<int> hit_node_; dbuf<uint32_t> occ_[2], counts_, work_, order_, class_order_, mat_counts_; dbuf<unsigned char> mat_key_; dbuf<unsigned long long> stats_;
     int grid_blocks = 0;
     float4* new_f4(size_t n);
 };

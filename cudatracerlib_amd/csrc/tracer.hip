@@ -606,7 +606,7 @@ void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
     Q.fin.rad = new_f4(capacity); Q.fin.dir = new_f4(capacity); Q.fin.px = new_f4(capacity);
     stats_.alloc(14); Q.stats = stats_.p; CTL_HIP(hipMemset(stats_.p, 0, 14 * sizeof(unsigned long long)));
     Q.capacity = capacity;
-    order_.alloc((size_t)capacity * 3); Q.order = order_.p; for (int c = 0; c < 3; c++) Q.class_order[c] = order_.p + (size_t)c * capacity;   // SortMaterials uses the first third, the model-class lists one third each
+    order_.alloc(capacity); Q.order = order_.p; class_order_.free(); for (int c = 0; c < 3; c++) Q.class_order[c] = nullptr;   // the model-class lists (12 B per slot) are allocated by the first render that shades by class
     mat_key_.alloc(capacity); Q.mat_key = mat_key_.p;
     counts_.free(); work_.free(); mat_counts_.free(); stage_.free();
 }
@@ -693,6 +693,7 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     dev_scene Sk = S; Sk.hit_key_out = (S.flat_leaf_keys && (S.shade_features == 0 || P.model_classes) && !counting && !P.sort_materials && P.block_sort) ? Q.mat_key : nullptr;   // (k_shade_full keys its regrouping by model AND material index)
     P.key_from_traversal = Sk.hit_key_out ? 1 : 0;
     if (!P.key_from_traversal) P.model_classes = 0;
+    if (P.model_classes && !class_order_.p) { class_order_.alloc((size_t)capacity * 3); for (int c = 0; c < 3; c++) Q.class_order[c] = class_order_.p + (size_t)c * capacity; }
     for (int depth = 1; depth <= maxPathLength; depth++) {
         const int cur = (depth - 1) & 1;
         if (fuse && depth > 1) {   // path rays of this bounce + shadow rays of the previous one in one launch
