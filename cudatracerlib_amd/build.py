@@ -10,7 +10,7 @@ import hashlib, os, subprocess, sys, glob, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libctl_amd.so")
-SRCS = ["kernels.hip", "shade_basic.hip", "shade_full.hip", "shade_class_a.hip", "shade_class_b.hip", "shade_class_c.hip", "shade_class_a_wf.hip", "shade_class_b_wf.hip", "shade_class_c_wf.hip", "shade_basic_wf.hip", "shade_full_wf.hip", "megakernel.hip", "image_pipeline.hip", "block_sampler.hip", "tracer.hip", "capi.hip", "scene_builder.cpp", "bvh_builder.cpp", "sbvh_builder.cpp", "flatten.cpp", "mitsuba_loader.cpp", "image_io.cpp", "jpeg_decode.cpp", "mesh_io.cpp", "scene_cache.cpp", "comm.cpp"]
+SRCS = ["kernels.hip", "shade_basic.hip", "shade_full.hip", "shade_class_a.hip", "shade_class_b.hip", "shade_class_c.hip", "shade_class_p.hip", "shade_class_g.hip", "shade_class_g_wf.hip", "shade_class_p_wf.hip", "shade_class_a_wf.hip", "shade_class_b_wf.hip", "shade_class_c_wf.hip", "shade_basic_wf.hip", "shade_full_wf.hip", "megakernel.hip", "image_pipeline.hip", "block_sampler.hip", "tracer.hip", "capi.hip", "scene_builder.cpp", "bvh_builder.cpp", "sbvh_builder.cpp", "flatten.cpp", "mitsuba_loader.cpp", "image_io.cpp", "jpeg_decode.cpp", "mesh_io.cpp", "scene_cache.cpp", "comm.cpp"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-pthread"]
 

@@ -40,11 +40,13 @@ struct wave_queues {
     unsigned char* mat_key;    // [capacity] BSDF model of the hit (0 = miss)
     uint32_t* mat_counts;      // [depth * 32 + k]: k < 16 paths per model, 16 + k scatter cursors, 24 + c vertices of model class c (k_class_partition)
     // model-class shading (pass_params::model_classes): k_class_partition splits the slots of a depth into one list per model class, class_order[c][0 .. mat_counts[depth * 32 + 24 + c])
-    uint32_t* class_order[3];  // [capacity] each
+    uint32_t* class_order[5];  // [capacity] each: classes a, b, c, p, g
 };
-// the model classes of shade_class_a/b/c.hip: which traversal keys (Q.mat_key: CTL_BSDF_* of the hit, 0 = miss) each launch shades
-#define CTL_CLASS_A_KEYS 0x00CBu   // miss, diffuse, dielectric, conductor, rough conductor (the models of the basic set)
-#define CTL_CLASS_B_KEYS 0x1F34u   // rough diffuse, thin dielectric, rough dielectric, plastic, rough plastic, Phong, Ward, Hanrahan-Krueger
+// the model classes of shade_class_a/b/c/p.hip: which traversal keys (Q.mat_key: CTL_BSDF_* of the hit, 0 = miss) each launch shades
+#define CTL_CLASS_A_KEYS 0x004Bu   // miss, diffuse, dielectric, conductor
+#define CTL_CLASS_G_KEYS 0x0080u   // rough conductor alone (the heaviest model of the basic set: with it class a spills 59 registers, without 15)
+#define CTL_CLASS_B_KEYS 0x1D34u   // rough diffuse, thin dielectric, rough dielectric, plastic, Phong, Ward, Hanrahan-Krueger
+#define CTL_CLASS_P_KEYS 0x0200u   // rough plastic alone: the commonest model of interiors and the heaviest single-layer one — by itself its BSDF record stays in registers (144 B of scratch; together with class b's models: 400 B)
 #define CTL_CLASS_C_KEYS 0xE000u   // coating, rough coating, blend (the nesting models)
 
 struct pass_params {
@@ -95,6 +97,10 @@ void launch_class_partition(const launch_ctx& lc, const wave_queues& Q, int dept
 void launch_shade_class_a(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_class_b(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_class_c(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_shade_class_g(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_shade_class_g_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_shade_class_p(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
+void launch_shade_class_p_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_class_a_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_class_b_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);
 void launch_shade_class_c_wf(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q, const pass_params& P, int depth, ctl_pixel_data* image);

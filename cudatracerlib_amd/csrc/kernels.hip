@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kBlock) void k_mat_scatter(wave_queues Q, int depth
 #define CTL_PART_PER_LANE 16   // slots per lane of a partition workgroup = windows of 16384 slots (synthetic-bathroom shade ms per pass: 1024-slot windows 2.94, 2048: 2.77, 4096: 2.62, 8192: 2.59, 16384: 2.55, 32768: 2.53)
 #endif
 constexpr int kPartBlock = 1024, kPartPerLane = CTL_PART_PER_LANE;
-__device__ __forceinline__ uint32_t class_of_key(uint32_t k) { return ((CTL_CLASS_A_KEYS >> k) & 1u) ? 0u : (((CTL_CLASS_B_KEYS >> k) & 1u) ? 1u : 2u); }
+__device__ __forceinline__ uint32_t class_of_key(uint32_t k) { return ((CTL_CLASS_A_KEYS >> k) & 1u) ? 0u : (((CTL_CLASS_B_KEYS >> k) & 1u) ? 1u : (((CTL_CLASS_P_KEYS >> k) & 1u) ? 3u : (((CTL_CLASS_G_KEYS >> k) & 1u) ? 4u : 2u))); }
 __global__ __launch_bounds__(kPartBlock) void k_class_partition(wave_queues Q, int depth) {
     __shared__ uint32_t s_hist[16], s_start[16];
     const uint32_t n = Q.counts[(depth - 1) * 4 + 0];
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kPartBlock) void k_class_partition(wave_queues Q, i
             }
         }
         __syncthreads();
-        if (threadIdx.x < 3) {   // thread c: the chunk of class c in its list, the models of the class in key order inside it
+        if (threadIdx.x < 5) {   // thread c: the chunk of class c in its list, the models of the class in key order inside it
             uint32_t tot = 0;
             for (uint32_t k = 0; k < 16; k++) if (class_of_key(k) == threadIdx.x) tot += s_hist[k];
             uint32_t at = tot ? atomicAdd(&Q.mat_counts[depth * 32 + 24 + threadIdx.x], tot) : 0u;
@@ -415,6 +415,8 @@ void launch_shade(const launch_ctx& lc, const dev_scene& S, const wave_queues& Q
         launch_class_partition(lc, Q, depth);
         (P.wavefront_rules ? launch_shade_class_a_wf : launch_shade_class_a)(lc, S, Q, P, depth, image);
         if (S.shade_models & CTL_CLASS_B_KEYS) (P.wavefront_rules ? launch_shade_class_b_wf : launch_shade_class_b)(lc, S, Q, P, depth, image);
+        if (S.shade_models & CTL_CLASS_G_KEYS) (P.wavefront_rules ? launch_shade_class_g_wf : launch_shade_class_g)(lc, S, Q, P, depth, image);
+        if (S.shade_models & CTL_CLASS_P_KEYS) (P.wavefront_rules ? launch_shade_class_p_wf : launch_shade_class_p)(lc, S, Q, P, depth, image);
         if (S.shade_models & CTL_CLASS_C_KEYS) (P.wavefront_rules ? launch_shade_class_c_wf : launch_shade_class_c)(lc, S, Q, P, depth, image);
         return;
     }

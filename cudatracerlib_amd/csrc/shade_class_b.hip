@@ -1,4 +1,4 @@
-// shade_class_b.hip — model-class build of the shade kernel: the single-layer models beyond the basic set — rough diffuse, thin dielectric, rough dielectric, plastic, rough plastic, Phong, Ward, Hanrahan-Krueger.
+// shade_class_b.hip — model-class build of the shade kernel: the single-layer models beyond the basic set — rough diffuse, thin dielectric, rough dielectric, plastic, Phong, Ward, Hanrahan-Krueger (rough plastic has class p, shade_class_p.hip).
 // A scene that needs the full feature set AND has the traversal's key per ray (flattened BVH, dev_scene::flat_leaf_keys) is shaded by one launch per model class present in it
 // (kernels.hip launch_shade), each over the slot list k_class_partition made for the class, instead of one kernel over all slots that carries every model and regroups them
 // behind workgroup barriers: 256-lane workgroups, full waves of (mostly) one model, no wave that idles at a barrier while the slowest model of the workgroup finishes.

@@ -1,28 +1,28 @@
-// shade_class_a.hip — model-class build of the shade kernel: misses (environment emitter), diffuse, dielectric, conductor — with every texture / light / surface-map feature (rough conductor has class g, shade_class_g.hip).
+// shade_class_g.hip — model-class build of the shade kernel: rough conductor alone (kernels.h CTL_CLASS_G_KEYS), with every texture / light / surface-map feature.
 // A scene that needs the full feature set AND has the traversal's key per ray (flattened BVH, dev_scene::flat_leaf_keys) is shaded by one launch per model class present in it
 // (kernels.hip launch_shade), each over the slot list k_class_partition made for the class, instead of one kernel over all slots that carries every model and regroups them
 // behind workgroup barriers: 256-lane workgroups, full waves of (mostly) one model, no wave that idles at a barrier while the slowest model of the workgroup finishes.
 #define CTL_SHADE_FEATURES (0x7F & ~(1 | 2 | 16))
 #define CTL_FMATH_OUTLINE   // ctl_math.h: one out-of-line copy of each transcendental function instead of one per call site (class b: 293 -> 159 KB of code against a 64-KB instruction cache)
 #include "kernels.h"
-#define CTL_SHADE_KEYS CTL_CLASS_A_KEYS
-#define CTL_SHADE_CLASS 0
+#define CTL_SHADE_KEYS CTL_CLASS_G_KEYS
+#define CTL_SHADE_CLASS 4
 #define CTL_LIGHT_INLINE   // shading.h: no out-of-line emitter function takes the scene by reference — out of line they cost a private copy of the dev_scene argument (496 B of scratch per lane, read back with vector loads): synthetic-bathroom shade 2.52 -> 2.26 ms per pass
-#ifndef CTL_CLASS_A_BLOCK
-#define CTL_CLASS_A_BLOCK 256
+#ifndef CTL_CLASS_G_BLOCK
+#define CTL_CLASS_G_BLOCK 256
 #endif
-#define CTL_SHADE_BLOCK CTL_CLASS_A_BLOCK
-#ifndef CTL_CLASS_A_WAVES
-#define CTL_CLASS_A_WAVES 4
+#define CTL_SHADE_BLOCK CTL_CLASS_G_BLOCK
+#ifndef CTL_CLASS_G_WAVES
+#define CTL_CLASS_G_WAVES 4
 #endif
-#if CTL_CLASS_A_WAVES > 0
-#define CTL_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(CTL_CLASS_A_WAVES, CTL_CLASS_A_WAVES)))
+#if CTL_CLASS_G_WAVES > 0
+#define CTL_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(CTL_CLASS_G_WAVES, CTL_CLASS_G_WAVES)))
 #endif
-#if defined(CTL_SHADE_WAVEFRONT_RULES) && CTL_SHADE_WAVEFRONT_RULES   // shade_class_a_wf.hip: pathIterateKernel's own path rules (PathSemantics = Wavefront)
-#define CTL_SHADE_KERNEL k_shade_class_a_wf
-#define CTL_SHADE_LAUNCH launch_shade_class_a_wf
+#if defined(CTL_SHADE_WAVEFRONT_RULES) && CTL_SHADE_WAVEFRONT_RULES   // shade_class_g_wf.hip: pathIterateKernel's own path rules (PathSemantics = Wavefront)
+#define CTL_SHADE_KERNEL k_shade_class_g_wf
+#define CTL_SHADE_LAUNCH launch_shade_class_g_wf
 #else
-#define CTL_SHADE_KERNEL k_shade_class_a
-#define CTL_SHADE_LAUNCH launch_shade_class_a
+#define CTL_SHADE_KERNEL k_shade_class_g
+#define CTL_SHADE_LAUNCH launch_shade_class_g
 #endif
 #include "shade_kernel.inc"

@@ -562,8 +562,8 @@ WavefrontPathTracer::WavefrontPathTracer() {
     m_sParameters.addBool("SortMaterials", false);
     // build-specific: the full shade kernel regroups the paths of each workgroup by BSDF model before shading them (shade_kernel.inc)
     m_sParameters.addBool("BlockSort", true);
-    // build-specific: a scene that needs the full feature set is shaded by one launch per MODEL CLASS present in it (shade_class_a/b/c.hip: basic models + misses / the other single-layer
-    // models / the nesting models), each register-allocated for its own models, instead of the one kernel that carries all fifteen (k_shade_full: 104 spilled registers).  Needs the
+    // build-specific: a scene that needs the full feature set is shaded by one launch per MODEL CLASS present in it (shade_class_a/b/p/c.hip: basic models + misses / the other single-layer
+    // models / rough plastic / the nesting models), each register-allocated for its own models, instead of the one kernel that carries all fifteen (k_shade_full: 104 spilled registers).  Needs the
     // BSDF model per hit from the closest-hit traversal (flattened BVH).  false = k_shade_full
     m_sParameters.addBool("ShadeByModelClass", true);
     // build-specific: the rays a shade workgroup emits are appended grouped by direction octant (compaction.h block_append3_keyed).
@@ -606,7 +606,7 @@ void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
     Q.fin.rad = new_f4(capacity); Q.fin.dir = new_f4(capacity); Q.fin.px = new_f4(capacity);
     stats_.alloc(14); Q.stats = stats_.p; CTL_HIP(hipMemset(stats_.p, 0, 14 * sizeof(unsigned long long)));
     Q.capacity = capacity;
-    order_.alloc(capacity); Q.order = order_.p; class_order_.free(); for (int c = 0; c < 3; c++) Q.class_order[c] = nullptr;   // the model-class lists (12 B per slot) are allocated by the first render that shades by class
+    order_.alloc(capacity); Q.order = order_.p; class_order_.free(); for (int c = 0; c < 5; c++) Q.class_order[c] = nullptr;   // the model-class lists (20 B per slot) are allocated by the first render that shades by class
     mat_key_.alloc(capacity); Q.mat_key = mat_key_.p;
     counts_.free(); work_.free(); mat_counts_.free(); stage_.free();
 }
@@ -693,7 +693,7 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     dev_scene Sk = S; Sk.hit_key_out = (S.flat_leaf_keys && (S.shade_features == 0 || P.model_classes) && !counting && !P.sort_materials && P.block_sort) ? Q.mat_key : nullptr;   // (k_shade_full keys its regrouping by model AND material index)
     P.key_from_traversal = Sk.hit_key_out ? 1 : 0;
     if (!P.key_from_traversal) P.model_classes = 0;
-    if (P.model_classes && !class_order_.p) { class_order_.alloc((size_t)capacity * 3); for (int c = 0; c < 3; c++) Q.class_order[c] = class_order_.p + (size_t)c * capacity; }
+    if (P.model_classes && !class_order_.p) { class_order_.alloc((size_t)capacity * 5); for (int c = 0; c < 5; c++) Q.class_order[c] = class_order_.p + (size_t)c * capacity; }
     for (int depth = 1; depth <= maxPathLength; depth++) {
         const int cur = (depth - 1) & 1;
         if (fuse && depth > 1) {   // path rays of this bounce + shadow rays of the previous one in one launch
