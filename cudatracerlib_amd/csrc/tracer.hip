@@ -303,6 +303,13 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
                 }
                 S.flat_leaf_keys = 1;
             }
+            // ... and, in a scene with alpha maps, bit 31 of the node word says that THIS entry's material has one: the alpha-testing traversal kernels (AlphaTest) test those
+            // entries only, and the wavefront kernel collects their candidates for a phase of its own (flat_woop_test, intersect_flat)
+            if (S.alpha_maps && d.n_materials)
+                for (flat_leaf& L : F.leaves) {
+                    const uint32_t tri = (S.flat_leaf_keys ? (L.index & 0x0fffffffu) : L.index) >> 1, mi = d.nodes[L.node].material_offset + ((d.tri_data[tri].nor_mat_extra[1] >> 16) & 0xffu);
+                    if (mi >= d.n_materials || d.materials[mi].alpha_state != CTL_ALPHA_DISABLED) L.node |= 0x80000000u;
+                }
 #endif
             F.leaves.emplace_back(); std::memset(&F.leaves.back(), 0, sizeof(flat_leaf)); F.leaves.back().index = 1;   // one spare (closing) entry behind the last leaf
             flat_leaves_.upload((const float4*)F.leaves.data(), F.leaves.size() * 8);

@@ -69,8 +69,12 @@ struct hit_in_memory {
         ray_word |= 0x80000000u;
     }
 };
+// A geometric hit whose alpha test is still to be done (wavefront kernel with ALPHA: the evaluation — texture address, texel decode, a few hundred instructions — is run for all
+// lanes that hold one at the same time, intersect_flat's alpha phase, instead of for one or two lanes at a time inside the entry phase).
+struct alpha_cand { float t, u, v; int tri, node; uint32_t key; };
 template <bool ALPHA, class SINK>
-__device__ __forceinline__ bool flat_woop_test(const dev_scene& S, const float4 v00, const float4 v11, const float4 v22, uint32_t index, int nd, const f3 o, const f3 d, float tmin, SINK& sink) {
+__device__ __forceinline__ bool flat_woop_test(const dev_scene& S, const float4 v00, const float4 v11, const float4 v22, uint32_t index, int nd, const f3 o, const f3 d, float tmin, SINK& sink,
+                                               alpha_cand* cand = nullptr, bool* deferred = nullptr) {
     const float Oz = v00.w - o.x * v00.x - o.y * v00.y - o.z * v00.z;
     const float invDz = 1.0f / (d.x * v00.x + d.y * v00.y + d.z * v00.z);
     const float t = Oz * invDz;
@@ -83,8 +87,14 @@ __device__ __forceinline__ bool flat_woop_test(const dev_scene& S, const float4 
             const float Dy = d.x * v22.x + d.y * v22.y + d.z * v22.z;
             const float v = Oy + t * Dy;
             const int tri = (int)((index & 0x0fffffffu) >> 1);   // bits 28..31: the BSDF model of the entry's material on the device copy (dev_scene::flat_leaf_keys), else 0
-            if (v >= 0.0f && u + v <= 1.0f && (!ALPHA || alpha_survives(S.tri_data, S.node_info, S.mats, S.images, tri, nd, u, v))) {
-                sink.accept(t, u, v, tri, nd, index >> 28);
+            // nd: bit 31 on the device copy = the entry's material has an alpha map (tracer.hip; scenes with alpha maps only): only those entries are alpha-tested
+            const int node = nd & 0x7fffffff;
+            if (v >= 0.0f && u + v <= 1.0f) {
+                if (ALPHA && nd < 0) {
+                    if (cand) { cand->t = t; cand->u = u; cand->v = v; cand->tri = tri; cand->node = node; cand->key = index >> 28; *deferred = true; return false; }
+                    if (!alpha_survives(S.tri_data, S.node_info, S.mats, S.images, tri, node, u, v)) return false;
+                }
+                sink.accept(t, u, v, tri, node, index >> 28);
                 return true;
             }
         }
@@ -102,21 +112,22 @@ __device__ __forceinline__ void flat_leaf_load(const dev_scene& S, uint32_t e, l
 }
 template <bool ANY_HIT, bool ALPHA, class SINK>
 __device__ __forceinline__ int flat_leaf_eval(const dev_scene& S, uint32_t e, const leaf_words& L, float orgx, float orgy, float orgz, float dirx, float diry, float dirz, float tmin,
-                                              SINK& sink, bool& got) {
+                                              SINK& sink, bool& got, alpha_cand* cand = nullptr, bool* deferred = nullptr) {
     m34 m; m.r[0][0] = L.r0.x; m.r[0][1] = L.r0.y; m.r[0][2] = L.r0.z; m.r[0][3] = L.r0.w; m.r[1][0] = L.r1.x; m.r[1][1] = L.r1.y; m.r[1][2] = L.r1.z; m.r[1][3] = L.r1.w;
     m.r[2][0] = L.r2.x; m.r[2][1] = L.r2.y; m.r[2][2] = L.r2.z; m.r[2][3] = L.r2.w;
     const f3 d = xform_dir(m, f3(dirx, diry, dirz));
     f3 o = xform_point(m, f3(orgx, orgy, orgz));
     if (!S.inst_w_one) o = f3(o.x / L.w33, o.y / L.w33, o.z / L.w33);
-    if (flat_woop_test<ALPHA>(S, L.v00, L.v11, L.v22, L.iw.x, (int)L.iw.y, o, d, tmin, sink)) { got = true; if (ANY_HIT) return -1; }
+    if (flat_woop_test<ALPHA>(S, L.v00, L.v11, L.v22, L.iw.x, (int)L.iw.y, o, d, tmin, sink, cand, deferred)) { got = true; if (ANY_HIT) return -1; }
     return (L.iw.x & 1u) ? -1 : (int)(e + 1);
 }
 // One leaf entry (flat_leaf, 128 B) against the world-space ray: the ray through the node's inverse transform (TraceHelper.cu:526-560; the rows
 // travel with the entry), then the Woop test.  Returns the next entry of the leaf, or -1 when this was its last one.
 template <bool ANY_HIT, bool ALPHA, class SINK>
-__device__ __forceinline__ int flat_leaf_test(const dev_scene& S, uint32_t e, float orgx, float orgy, float orgz, float dirx, float diry, float dirz, float tmin, SINK& sink, bool& got) {
+__device__ __forceinline__ int flat_leaf_test(const dev_scene& S, uint32_t e, float orgx, float orgy, float orgz, float dirx, float diry, float dirz, float tmin, SINK& sink, bool& got,
+                                              alpha_cand* cand = nullptr, bool* deferred = nullptr) {
     leaf_words L; flat_leaf_load(S, e, L);
-    return flat_leaf_eval<ANY_HIT, ALPHA>(S, e, L, orgx, orgy, orgz, dirx, diry, dirz, tmin, sink, got);
+    return flat_leaf_eval<ANY_HIT, ALPHA>(S, e, L, orgx, orgy, orgz, dirx, diry, dirz, tmin, sink, got, cand, deferred);
 }
 
 // culling-only min / max: the hardware instructions as they are (a NaN operand loses, as with fmaxf / fminf)
@@ -213,6 +224,11 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
     float ht = 0;                                 // distance of the closest hit so far; its record is in hit[] / hit_node[] already (hit_in_memory), bit 31 of ray_id says there is one
     hit_in_memory sink{ ht, ray_id, hit, hit_node, ANY_HIT ? nullptr : S.hit_key_out };
     int sp = 0, node = kSentinel, pend = -1;      // pend: postponed leaf (its first entry in flat_leaves), -1 = none
+    alpha_cand cand{ 0, 0, 0, 0, 0, 0 }; bool has_cand = false;   // ALPHA builds: a geometric hit that waits for its alpha test (alpha phase below)
+#ifndef CTL_ALPHA_BATCH
+#define CTL_ALPHA_BATCH 12
+#endif
+    constexpr int kAlphaBatch = CTL_ALPHA_BATCH;
     int sp_max = 0;                               // COUNT: deepest stack entry of the lane's current ray
     const float4* __restrict__ nodes = S.flat_nodes;
     uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = (n == 0);
@@ -248,17 +264,29 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
         if (__ballot(has_ray) == 0ull) { if (exhausted) break; continue; }
 
         // ---- a lane standing on a leaf with a free slot postpones it and goes on with the next stack entry
-        if (has_ray && node < 0 && pend < 0) { pend = ~node; node = st.get(sp); sp--; }
-        const bool at_inner = has_ray && (unsigned)node < (unsigned)kSentinel;
-        const bool at_leaf = has_ray && pend >= 0;
+        if (has_ray && !has_cand && node < 0 && pend < 0) { pend = ~node; node = st.get(sp); sp--; }
+        const bool at_inner = has_ray && !has_cand && (unsigned)node < (unsigned)kSentinel;
+        const bool at_leaf = has_ray && !has_cand && pend >= 0;
         const unsigned long long m_inner = __ballot(at_inner), m_leaf = __ballot(at_leaf);
+        const unsigned long long m_cand = ALPHA ? __ballot(has_cand) : 0ull;
         bool finished = false;
-        if (m_leaf != 0ull && (__popcll(m_leaf) >= leaf_batch || m_inner == 0ull)) {
+        if (ALPHA && m_cand != 0ull && (__popcll(m_cand) >= kAlphaBatch || (m_inner == 0ull && m_leaf == 0ull))) {
+            // ---- alpha phase (ALPHA builds): every lane that holds a geometric hit of an alpha-mapped material evaluates Material::AlphaTest for it now, together; a lane with a
+            // candidate has stood still since it found it (the entries behind it are tested against the hit distance this decides)
+            if (has_cand) {
+                has_cand = false;
+                if (alpha_survives(S.tri_data, S.node_info, S.mats, S.images, cand.tri, cand.node, cand.u, cand.v)) {
+                    sink.accept(cand.t, cand.u, cand.v, cand.tri, cand.node, cand.key);
+                    if (ANY_HIT) finished = true;
+                }
+            }
+        } else if (m_leaf != 0ull && (__popcll(m_leaf) >= leaf_batch || m_inner == 0ull)) {
             // ---- leaf phase: every lane that holds a leaf tests its next entry
             if (at_leaf) {
                 if (COUNT) { cnt.n_tri++; if (lane == (int)__builtin_ctzll(m_leaf)) cnt.w_tri++; }
                 bool got = false;
-                pend = flat_leaf_test<ANY_HIT, ALPHA>(S, (uint32_t)pend, ox, oy, oz, dx, dy, dz, tmin, sink, got);
+                if (ALPHA) pend = flat_leaf_test<ANY_HIT, ALPHA>(S, (uint32_t)pend, ox, oy, oz, dx, dy, dz, tmin, sink, got, &cand, &has_cand);
+                else pend = flat_leaf_test<ANY_HIT, ALPHA>(S, (uint32_t)pend, ox, oy, oz, dx, dy, dz, tmin, sink, got);
                 if (ANY_HIT && got) finished = true;
             }
         } else {
@@ -284,7 +312,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
                 if (COUNT && sp > sp_max) sp_max = sp;
             }
         }
-        if (has_ray && !finished) finished = (node == kSentinel) && pend < 0;
+        if (has_ray && !finished) finished = (node == kSentinel) && pend < 0 && !has_cand;
         if (finished) {
             const uint32_t id = ray_id & 0x7fffffffu; const bool found = (ray_id >> 31) != 0u;
             if (ANY_HIT && occ) occ[id] = found ? 1u : 0u;
