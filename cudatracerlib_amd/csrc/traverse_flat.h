@@ -225,10 +225,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
     hit_in_memory sink{ ht, ray_id, hit, hit_node, ANY_HIT ? nullptr : S.hit_key_out };
     int sp = 0, node = kSentinel, pend = -1;      // pend: postponed leaf (its first entry in flat_leaves), -1 = none
     alpha_cand cand{ 0, 0, 0, 0, 0, 0 }; bool has_cand = false;   // ALPHA builds: a geometric hit that waits for its alpha test (alpha phase below)
-#ifndef CTL_ALPHA_BATCH
-#define CTL_ALPHA_BATCH 12
-#endif
-    constexpr int kAlphaBatch = CTL_ALPHA_BATCH;
+    constexpr int kAlphaBatch = 12;   // lanes with a candidate that start an alpha phase (4 / 8 / 12 / 20 / 32: 12.07 / 10.93 / 10.59 / 10.66 / 11.94 ms of traversal per pass on synthetic-sm-hard with AlphaTest)
     int sp_max = 0;                               // COUNT: deepest stack entry of the lane's current ray
     const float4* __restrict__ nodes = S.flat_nodes;
     uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = (n == 0);
