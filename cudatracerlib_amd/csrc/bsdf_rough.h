@@ -153,7 +153,18 @@ __device__ __forceinline__ float rough_transmittance_1d(const float* __restrict_
     return min2(1.0f, max2(0.0f, result));
 }
 __device__ __forceinline__ float roughplastic_T(const ctl_material& M, const bsdf_rec& b, float cosTheta, float alpha) {   // cosTheta > 0 on every roughplastic path
-    if (M.reserved_[0]) return rough_transmittance_1d(b.dg.rt_reduced + (M.reserved_[0] - 1), M.reserved_[1], cosTheta);
+    if (M.reserved_[0]) {
+#if CTL_SHADE_FEATURES & 2
+        // sample, f and pdf of a vertex (and the NEE evaluation behind them) ask for T(cos wi) five times: memoised like the 3-D lookups, keyed by the table's offset
+        const uint32_t key = M.reserved_[0] | 0x80000000u;
+        if (b.rt_cos == cosTheta && b.rt_type == key) return b.rt_val;
+        const float v = rough_transmittance_1d(b.dg.rt_reduced + (M.reserved_[0] - 1), M.reserved_[1], cosTheta);
+        if (cosTheta == cos_theta(b.wi)) { b.rt_cos = cosTheta; b.rt_type = key; b.rt_val = v; }   // only the incident direction recurs
+        return v;
+#else
+        return rough_transmittance_1d(b.dg.rt_reduced + (M.reserved_[0] - 1), M.reserved_[1], cosTheta);
+#endif
+    }
     return rough_transmittance(b.dg, M.u[2], cosTheta, alpha, M.f[0]);
 }
 __device__ __forceinline__ float rough_transmittance_wi(const bsdf_rec& b, uint32_t type, float cosTheta, float alpha, float eta) {

@@ -153,6 +153,7 @@ CTL_FM_HD float pow(float x, float y) {
         for (int k = 1; k < n; k++) r *= ax;
         return sign * (float)(y < 0 ? 1.0 / r : r);
     }
+    if (y == 0.25f) return (float)__builtin_sqrt(__builtin_sqrt(ax));   // the warp of the rough-transmittance tables (x >= 0 here): two correctly rounded double roots instead of log + exp
     const double t = (double)y * log_d(ax);
     if (t > 100.0) return sign * finf();
     if (t < -120.0) return sign * 0.0f;
