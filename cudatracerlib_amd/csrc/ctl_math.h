@@ -237,5 +237,20 @@ HD f3 uchar2_to_normal(uint32_t v) {
 #endif
     return f3(st * cp, st * sp, ct);
 }
+// The same from a table: both angles come from bytes, so there are 256 values of (sin, cos) each — lut[x] for theta, lut[256 + y] for phi, filled on the host with the very
+// function the device path above calls (normal_codec_lut, bit-identical by ctl_fmath.h's contract).  Six double-precision sincos per shaded vertex become six 8-byte loads.
+HD f3 uchar2_to_normal_lut(uint32_t v, const float2* __restrict__ lut) {
+    const float2 t = lut[(v >> 8) & 0xff], p = lut[256 + (v & 0xff)];   // {sin, cos}
+    return f3(t.x * p.y, t.x * p.x, t.y);
+}
+inline void normal_codec_lut(float* out /* 512 x {sin, cos} */) {
+    const float PI_4 = kPi / 4.0f, PI_2 = kPi / 2.0f;
+    for (uint32_t x = 0; x < 256; x++) {
+        const float theta = x == 63 ? PI_4 : (x == 127 ? PI_2 : (x == 191 ? 3 * PI_4 : float(x) * (1.0f / 255.0f) * kPi));
+        const float phi = x == 63 ? PI_2 : (x == 127 ? kPi : (x == 191 ? 3 * PI_2 : float(x) * (1.0f / 255.0f) * kPi * 2.0f));
+        fm::sincos(theta, &out[2 * x], &out[2 * x + 1]);
+        fm::sincos(phi, &out[2 * (256 + x)], &out[2 * (256 + x) + 1]);
+    }
+}
 
 } // namespace ctl

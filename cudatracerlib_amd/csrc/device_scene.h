@@ -38,6 +38,7 @@ struct dev_scene {
     unsigned char* hit_key_out;  // per launch (the tracer's copy of this struct): where a closest-hit traversal leaves that model (CTL_BSDF_*, all >= 1) per ray (0 = miss), for the shade kernel's regrouping; else nullptr
     int flat_top_cached;         // Q4 with implied links: the first this-many nodes of flat_nodes (the top of the tree, stored breadth-first) are kept in LDS by every traversal workgroup (traverse_flat.h kTopCache)
     const float4* inst_fwd;      // 3 x float4 per node: forward-transform rows 0..2 (fillDG)
+    const float2* normal_lut;    // 512 x {sin, cos}: the 8+8-bit normal codec's angles (ctl_math.h uchar2_to_normal_lut)
     const uint4* tri_data;       // 2 x uint4 per triangle (TriangleData, 32 B)
     const uint4* node_info;      // per node {material_offset, light0, light1, n_lights}
     const ctl_material* mats;

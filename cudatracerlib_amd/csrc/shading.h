@@ -145,7 +145,7 @@ __device__ __forceinline__ void fill_dg(const dev_scene& S, float u, float v, in
     const float4 f0 = S.inst_fwd[node * 3], f1 = S.inst_fwd[node * 3 + 1], f2_ = S.inst_fwd[node * 3 + 2];
     m34 l2w; l2w.r[0][0] = f0.x; l2w.r[0][1] = f0.y; l2w.r[0][2] = f0.z; l2w.r[0][3] = f0.w; l2w.r[1][0] = f1.x; l2w.r[1][1] = f1.y; l2w.r[1][2] = f1.z; l2w.r[1][3] = f1.w;
     l2w.r[2][0] = f2_.x; l2w.r[2][1] = f2_.y; l2w.r[2][2] = f2_.z; l2w.r[2][3] = f2_.w;
-    const f3 na = uchar2_to_normal(ta.x & 0xffff), nb = uchar2_to_normal(ta.x >> 16), nc = uchar2_to_normal(ta.y & 0xffff);
+    const f3 na = uchar2_to_normal_lut(ta.x & 0xffff, S.normal_lut), nb = uchar2_to_normal_lut(ta.x >> 16, S.normal_lut), nc = uchar2_to_normal_lut(ta.y & 0xffff, S.normal_lut);   // = uchar2_to_normal, from the scene's 4-KB table
     const float w = 1.0f - u - v;
     const f3 n = normalize(u * na + v * nb + w * nc);
     const f3 dpdu(half_to_float((uint16_t)ta.z), half_to_float((uint16_t)(ta.z >> 16)), half_to_float((uint16_t)ta.w));

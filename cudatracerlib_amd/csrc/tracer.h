@@ -43,7 +43,7 @@ public:
     float box_min[3] = { 0, 0, 0 }, box_max[3] = { 0, 0, 0 };   // KernelDynamicScene::m_sBox
     float near_depth = 0, far_depth = 0;                        // SensorBase::m_fNearFarDepths of the scene's camera (DeviceDepthImage::NormalizeDepthD3D)
 private:
-    dbuf<float4> top_nodes_, bot_nodes_, leaf_tris_, inst_, inst_fwd_, flat_nodes_, flat_leaves_;
+    dbuf<float4> top_nodes_, bot_nodes_, leaf_tris_, inst_, inst_fwd_, flat_nodes_, flat_leaves_; dbuf<float2> normal_lut_;
     dbuf<uint4> tri_data_, node_info_;
     dbuf<ctl_material> mats_; dbuf<ctl_light> lights_; dbuf<unsigned char> anim_; dbuf<uint32_t> texels_; dbuf<ctl_mipmap> images_; dbuf<dev_mip_levels> mip_levels_; dbuf<float> mip_lut_; dbuf<float> rt_data_, rt_reduced_; dbuf<ctl_rough_transmittance> rt_;
 };

@@ -72,6 +72,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
         ninfo[k] = make_uint4(N.material_offset, N.lights[0], N.lights[1], N.n_lights);
     }
     inst_.upload(inst.data(), inst.size()); inst_fwd_.upload(fwd.data(), fwd.size()); node_info_.upload(ninfo.data(), ninfo.size());
+    { std::vector<float> lut(1024); normal_codec_lut(lut.data()); normal_lut_.upload((const float2*)lut.data(), 512); }
     static_assert(sizeof(ctl_triangle_data) == 32, "TriangleData is 32 B");
     static_assert(sizeof(ctl_material) == 384 && sizeof(ctl_texture) == 48, "material descriptor layout (include/ctl_amd.h)");
     tri_data_.upload((const uint4*)d.tri_data, (size_t)d.n_tri_data * 2);
@@ -322,7 +323,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
         }
     }
     CTL_HIP(hipDeviceSynchronize());
-    S.top_nodes = top_nodes_.p; S.bot_nodes = bot_nodes_.p; S.leaf_tris = leaf_tris_.p; S.inst = inst_.p; S.inst_fwd = inst_fwd_.p;
+    S.top_nodes = top_nodes_.p; S.bot_nodes = bot_nodes_.p; S.leaf_tris = leaf_tris_.p; S.inst = inst_.p; S.inst_fwd = inst_fwd_.p; S.normal_lut = normal_lut_.p;
     S.tri_data = tri_data_.p; S.node_info = node_info_.p; S.mats = mats_.p; S.lights = lights_.p; S.anim = anim_.p;
     S.start_node = d.scene_start_node; S.n_nodes = d.n_nodes; S.num_lights = d.num_lights; S.env_map_index = d.env_map_index; S.eps = d.ray_trace_eps;
     for (int i = 0; i < CTL_MAX_NUM_LIGHTS; i++) { S.light_indices[i] = d.light_indices[i]; S.light_cdf[i] = d.light_cdf[i]; }
