@@ -305,9 +305,12 @@ def main():
     tr.reservePasses(args.steps)      # queue memory for the batch size the timed call will use: allocated here, not inside the timed region
     img = ctl.Image(args.width, args.height)
 
-    comm, reduce_kind = None, "none (1 GPU)"
+    comm, reduce_kind, exchange = None, "none (1 GPU)", None
     if world > 1:
         import torch
+
+        def agree(flag):   # every rank takes the same path: MIN over the ranks of "it worked here" (gloo)
+            t = torch.tensor([1 if flag else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN); return int(t.item()) == 1
         # (1) every rank proves that RCCL loads in its process (ncclGetUniqueId is local) BEFORE anybody enters the collective ncclCommInitRank:
         #     a rank that cannot load the library must not leave the others waiting inside it
         why = ""
@@ -317,26 +320,56 @@ def main():
             my_id = ctl.Comm.unique_id()
         except Exception as e:
             why = str(e)[:120]; my_id = None
-        ok = torch.tensor([1 if my_id is not None else 0]); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
+        if agree(my_id is not None):
             try:
                 ident = [my_id if rank == 0 else None]
                 dist.broadcast_object_list(ident, src=0)
                 comm = ctl.Comm(ident[0], rank, world, timeout_ms=int(os.environ.get("CTL_BENCH_COMM_TIMEOUT_MS", "90000")))   # ncclCommInitRank with a deadline (comm.cpp)
-                scratch = ctl.Image(args.width, args.height)
-                comm.reduce_to(img, scratch if rank == 0 else None, 0)   # the FIRST ncclReduce of the communicator (connection set-up, a time-out of its own) runs here, outside the timed region
-                del scratch
-                reduce_kind = "ncclReduce in libctl_amd.so (ctl_image_reduce)"
             except Exception as e:   # never silently: the JSON line says which path ran
                 why = str(e)[:120]; comm = None
-            ok = torch.tensor([1 if comm is not None else 0]); dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks take the same path
-            if int(ok.item()) == 0:
+            if not agree(comm is not None):
                 comm = None
+        # (2) BOTH exchanges run once here, outside the timed region (the FIRST collective of a communicator sets its connections up and has a time-out of its own):
+        #     north_star's gather of the ranks' own tiles first; the whole-frame reduce is the agreed fallback.  A collective that timed out has aborted the communicator
+        #     (comm.cpp wait_done), so the fallback of a failed gather is tried on a fresh one.
+        if comm is not None:
+            scratch = ctl.Image(args.width, args.height)
+            for kind in ("gather", "reduce"):
+                ok_here = True
+                try:
+                    if kind == "gather" and os.environ.get("CTL_BENCH_NO_GATHER") == "1":
+                        raise RuntimeError("CTL_BENCH_NO_GATHER=1")
+                    (comm.gather_to if kind == "gather" else comm.reduce_to)(img, scratch if rank == 0 else None, 0)
+                except Exception as e:
+                    why = "%s: %s" % (kind, str(e)[:120]); ok_here = False
+                if agree(ok_here):
+                    exchange = kind
+                    break
+                if kind == "gather":      # a fresh communicator for the fallback (the old one may be aborted on some ranks)
+                    try:
+                        comm = None
+                        ident = [ctl.Comm.unique_id() if rank == 0 else None]
+                        dist.broadcast_object_list(ident, src=0)
+                        comm = ctl.Comm(ident[0], rank, world, timeout_ms=int(os.environ.get("CTL_BENCH_COMM_TIMEOUT_MS", "90000")))
+                    except Exception as e:
+                        why = str(e)[:120]; comm = None
+                    if not agree(comm is not None):
+                        comm = None
+                        break
+            del scratch
+            if exchange is None:
+                comm = None
+            elif exchange == "gather":
+                reduce_kind = "ncclGather of each rank's own tiles in libctl_amd.so (ctl_image_gather, %d B per rank)" % img.packedTileBytes(world)
+            else:
+                whys = [None] * world; dist.all_gather_object(whys, why)
+                reduce_kind = "ncclReduce of the whole frames in libctl_amd.so (ctl_image_reduce; the gather failed: %s)" % next((x for x in whys if x), "on another rank")
         if comm is None:
             whys = [None] * world; dist.all_gather_object(whys, why)
             why = next((x for x in whys if x), "another rank failed")
-            print("bench.py: native RCCL reduce unavailable (%s); falling back to torch.distributed" % why, file=sys.stderr, flush=True)
-            reduce_kind = "torch.distributed gloo all-reduce through host memory (native RCCL unavailable: %s)" % why
+            print("bench.py: native RCCL exchange unavailable (%s); falling back to torch.distributed" % why, file=sys.stderr, flush=True)
+            exchange = "gloo-gather"
+            reduce_kind = "torch.distributed gloo gather of each rank's own tiles through host memory (ctl_image_pack_tiles / _unpack_tiles; native RCCL unavailable: %s)" % why
 
     def sync():
         ctl.api._check(ctl.lib.ctl_device_synchronize())
@@ -347,13 +380,17 @@ def main():
             dist.barrier()
 
     def reduce_frame():
-        if comm is not None:
+        if exchange == "gather":
+            comm.gather(img, 0)
+        elif exchange == "reduce":
             comm.reduce(img, 0)
-        else:
+        else:   # the same packed tiles, moved by gloo through host memory
             import torch
-            fb = torch.from_numpy(img.getPixelData()); dist.all_reduce(fb, op=dist.ReduceOp.SUM)
+            mine = torch.from_numpy(img.packTiles(rank, world))
+            bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, bufs, dst=0)
             if rank == 0:
-                img.setPixelData(fb.numpy())
+                img.unpackTiles(world, torch.stack(bufs).numpy())
 
     if args.warmup > 0:
         tr.DoPasses(img, args.warmup, new_trace=True)
@@ -492,7 +529,7 @@ def main():
                        ("%s %dx%d depth %d, %d instanced triangles" % (args.workload, args.width, args.height, args.depth, int(_instanced_tris(desc)))),
                        "bvh": "flattened world-space BVH4 (64 B nodes with 8-bit quantised child boxes; 128 B leaf entries evaluated with the reference's object-space arithmetic; triangles much longer than their neighbours entered as several references)" if args.flatten else "two-level (scene BVH + instanced mesh BVHs)",
                        "scene_source": scene_source,
-                       "parallelism": "image tiles 64x64 round-robin over %d GPU(s), 1 reduce of the framebuffer per render" % world, "framebuffer_reduce": reduce_kind,
+                       "parallelism": "image tiles 64x64 round-robin over %d GPU(s), 1 gather of the framebuffer per render" % world, "framebuffer_reduce": reduce_kind,
                        "rays_per_step": int(rays / args.steps), "scene_build_s": round(t_build, 2)},
             "roofline": roof,
         }

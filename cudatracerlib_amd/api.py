@@ -700,6 +700,14 @@ class Comm:
         dst may be None on the other ranks"""
         _check(lib.ctl_image_reduce_to(src._h, dst._h if dst is not None else None, self._h, C.c_int32(root)))
 
+    def gather(self, image, root=0):
+        """north_star's exchange: every rank's own tiles + halo (ceil(tiles / world) x 65 x 65 x 28 B) to `root`'s image, in place, one ncclGather; ONE call per render"""
+        _check(lib.ctl_image_gather(image._h, self._h, C.c_int32(root)))
+
+    def gather_to(self, src, dst, root=0):
+        """out of place (repeatable: the per-pass progressive gather): `dst` on the root = every rank's own tiles of its `src`; dst may be None on the other ranks"""
+        _check(lib.ctl_image_gather_to(src._h, dst._h if dst is not None else None, self._h, C.c_int32(root)))
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib.ctl_comm_destroy(self._h)
@@ -719,43 +727,24 @@ class Image:
             lib.ctl_image_destroy(self._h)
             self._h = None
 
-    def Clear(self):
-        _check(lib.ctl_image_clear(self._h))
+    def packedTileBytes(self, world):
+        """bytes of one rank's packed tiles (ctl_image_packed_tile_bytes)"""
+        n = C.c_uint64()
+        _check(lib.ctl_image_packed_tile_bytes(u32(self.width), u32(self.height), u32(world), C.byref(n)))
+        return n.value
 
-    def getPixelData(self):
-        """(h, w, 7) float32: rgb[3], rgbSplat[3], weightSum."""
-        a = np.zeros((self.height, self.width, 7), np.float32)
-        _check(lib.ctl_image_read_pixels(self._h, a.ctypes.data_as(C.c_void_p)))
-        return a
+    def packTiles(self, rank, world):
+        """the tiles t % world == rank of this image with their one-pixel halo as (slots, 65 * 65, 7) float32 — what ctl_image_gather sends (ctl_image_pack_tiles)"""
+        out = np.empty(self.packedTileBytes(world) // 4, np.float32)
+        _check(lib.ctl_image_pack_tiles(self._h, u32(rank), u32(world), out.ctypes.data_as(C.c_void_p)))
+        return out.reshape(-1, 65 * 65, 7)
 
-    def setPixelData(self, a):
-        a = np.ascontiguousarray(a, dtype=np.float32).reshape(self.height, self.width, 7)
-        _check(lib.ctl_image_write_pixels(self._h, a.ctypes.data_as(C.c_void_p)))
-
-    def device_ptr(self):
-        return lib.ctl_image_device_ptr(self._h)
-
-    def applyImagePipeline(self, splat_scale=0.0, filter=None, process=None):
-        """applyImagePipeline(tracer, img, filter, process) (Kernel/ImagePipeline/ImagePipeline.cu:54-84): (h, w, 4) uint8 display image.
-        filter = ctl_reconstruction_filter (see box_filter ... triangle_filter) or None; process = ctl_tonemap (see tonemap) or None."""
-        a = np.zeros((self.height, self.width), np.uint32)
-        if filter is None and process is None:
-            _check(lib.ctl_image_apply_pipeline(self._h, f32(splat_scale), a.ctypes.data_as(C.c_void_p)))
-        else:
-            _check(lib.ctl_image_apply_pipeline_ex(self._h, f32(splat_scale), None if filter is None else C.byref(filter),
-                                                   None if process is None else C.byref(process), a.ctypes.data_as(C.c_void_p)))
-        return a.view(np.uint8).reshape(self.height, self.width, 4)
-
-    def WriteDisplayImage(self, path, splat_scale=0.0):
-        """Image::WriteDisplayImage: .png (display image), .hdr / .pfm (linear)."""
-        _check(lib.ctl_image_write_file(self._h, f32(splat_scale), path.encode()))
-
-    def getRGB(self, splat_scale=0.0):
-        """copySamplesToOutput (Kernel/ImagePipeline/ImagePipeline.cu:14-30) up to linear RGB."""
-        a = np.zeros((self.height, self.width, 3), np.float32)
-        _check(lib.ctl_image_resolve_rgb(self._h, f32(splat_scale), a.ctypes.data_as(C.c_void_p)))
-        return a
-
+    def unpackTiles(self, world, packed_all_ranks):
+        """write the packed tiles of ALL ranks (rank-major) into this image: tiles copied, then halos added (ctl_image_unpack_tiles)"""
+        a = np.ascontiguousarray(packed_all_ranks, np.float32)
+        if a.nbytes != self.packedTileBytes(world) * world:
+            raise ValueError("unpackTiles: %d bytes, expected %d" % (a.nbytes, self.packedTileBytes(world) * world))
+        _check(lib.ctl_image_unpack_tiles(self._h, u32(world), a.ctypes.data_as(C.c_void_p)))
 
 class _Parameters:
     def __init__(self, tracer):

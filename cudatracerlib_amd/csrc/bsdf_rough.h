@@ -2,49 +2,13 @@
 // rough-transmittance tables (Engine/RoughTransmittance.cu:55-119) and their cubic spline lookup (Math/Spline.cu:223-453).
 // Included by bsdf_more.h; expression order follows the reference (no FMA contraction), see DESIGN.md §4.
 #pragma once
+#include "spline.h"
 
 namespace ctl {
 
-// one dimension of Spline::evalCubicInterp{2D,3D}: knots on [0,1], extrapolate = false
-__device__ __forceinline__ bool spline_weights(float p, uint32_t size, float* w, uint32_t& knot) {
-    if (!(p >= 0.0f && p <= 1.0f)) return false;
-    float t = ((p - 0.0f) * (size - 1)) / (1.0f - 0.0f);
-    knot = min((uint32_t)t, size - 2);
-    t = t - (float)knot;
-    const float t2 = t * t, t3 = t2 * t;
-    w[0] = 0.0f; w[1] = 2 * t3 - 3 * t2 + 1; w[2] = -2 * t3 + 3 * t2; w[3] = 0.0f;
-    const float d0 = t3 - 2 * t2 + t, d1 = t3 - t2;
-    if (knot > 0) { w[2] += 0.5f * d0; w[0] -= 0.5f * d0; } else { w[2] += d0; w[1] -= d0; }
-    if (knot + 2 < size) { w[3] += 0.5f * d1; w[1] -= 0.5f * d1; } else { w[2] += d1; w[1] -= d1; }
-    return true;
-}
-__device__ CTL_ROUGH_BODY float eval_cubic_interp_2d(float px, float py, const float* __restrict__ values, uint32_t sx, uint32_t sy) {
-    float wx[4], wy[4]; uint32_t kx, ky;
-    if (!spline_weights(px, sx, wx, kx) || !spline_weights(py, sy, wy, ky)) return 0.0f;
-    float result = 0.0f;
-    for (int y = -1; y <= 2; ++y)
-        for (int x = -1; x <= 2; ++x) {
-            const float wxy = wx[x + 1] * wy[y + 1];
-            if (wxy == 0) continue;
-            result += values[(size_t)(ky + y) * sx + kx + x] * wxy;
-        }
-    return result;
-}
-__device__ CTL_ROUGH_BODY float eval_cubic_interp_3d(float px, float py, float pz, const float* __restrict__ values, uint32_t sx, uint32_t sy, uint32_t sz) {
-    float wx[4], wy[4], wz[4]; uint32_t kx, ky, kz;
-    if (!spline_weights(px, sx, wx, kx) || !spline_weights(py, sy, wy, ky) || !spline_weights(pz, sz, wz, kz)) return 0.0f;
-    float result = 0.0f;
-    for (int z = -1; z <= 2; ++z)
-        for (int y = -1; y <= 2; ++y) {
-            const float wyz = wy[y + 1] * wz[z + 1];
-            for (int x = -1; x <= 2; ++x) {
-                const float wxyz = wx[x + 1] * wyz;
-                if (wxyz == 0) continue;
-                result += values[((size_t)(kz + z) * sy + (ky + y)) * sx + kx + x] * wxyz;
-            }
-        }
-    return result;
-}
+// Spline::evalCubicInterp2D / 3D over [0,1]^n: spline.h (one statement for the kernels, the host-side table reduction and the test against the reference's Spline.cu)
+__device__ CTL_ROUGH_BODY float eval_cubic_interp_2d(float px, float py, const float* __restrict__ values, uint32_t sx, uint32_t sy) { return spline_eval_2d(px, py, values, sx, sy); }
+__device__ CTL_ROUGH_BODY float eval_cubic_interp_3d(float px, float py, float pz, const float* __restrict__ values, uint32_t sx, uint32_t sy, uint32_t sz) { return spline_eval_3d(px, py, pz, values, sx, sy, sz); }
 // RoughTransmittanceManager::Evaluate / EvaluateDiffuse for the table of slot `type`
 __device__ CTL_ROUGH_BODY float rough_transmittance(const diff_geom& dg, uint32_t type, float cosTheta, float alpha, float eta) {
     const ctl_rough_transmittance& T = dg.rough_transmittance[type];
@@ -146,11 +110,7 @@ __device__ CTL_ROUGH_BODY float ward_pdf(const ctl_material& M, const bsdf_rec& 
 
 // Rough plastic with a constant roughness: the table was reduced to 1-D in cos(theta) at scene upload (tracer.hip), M.reserved_ = {offset + 1, samples}
 __device__ __forceinline__ float rough_transmittance_1d(const float* __restrict__ table, uint32_t size, float cosTheta) {
-    float w[4]; uint32_t knot;
-    if (!spline_weights(m_pow(fabsf(cosTheta), 0.25f), size, w, knot)) return 0.0f;
-    float result = 0.0f;
-    for (int x = -1; x <= 2; ++x) { if (w[x + 1] == 0) continue; result += table[knot + x] * w[x + 1]; }
-    return min2(1.0f, max2(0.0f, result));
+    return min2(1.0f, max2(0.0f, spline_eval_1d(m_pow(fabsf(cosTheta), 0.25f), table, size)));
 }
 __device__ __forceinline__ float roughplastic_T(const ctl_material& M, const bsdf_rec& b, float cosTheta, float alpha) {   // cosTheta > 0 on every roughplastic path
     if (M.reserved_[0]) {

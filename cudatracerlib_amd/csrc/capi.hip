@@ -252,6 +252,17 @@ int ctl_image_reduce_to(ctl_image* src, ctl_image* dst, ctl_comm* comm, int32_t 
     CTL_REQUIRE(dst != src, "ctl_image_reduce_to: source and destination must differ (ctl_image_reduce is the in-place form)");
     CTL_TRY comm_reduce_image(comm->c, &src->img, dst ? &dst->img : nullptr, root); CTL_CATCH
 }
+int ctl_image_gather(ctl_image* img, ctl_comm* comm, int32_t root) { CTL_REQUIRE(img && comm, "null argument"); CTL_TRY comm_gather_image(comm->c, &img->img, &img->img, root); CTL_CATCH }
+int ctl_image_gather_to(ctl_image* src, ctl_image* dst, ctl_comm* comm, int32_t root) {
+    CTL_REQUIRE(src && comm, "null argument");
+    CTL_REQUIRE(dst != src, "ctl_image_gather_to: source and destination must differ (ctl_image_gather is the in-place form)");
+    CTL_TRY comm_gather_image(comm->c, &src->img, dst ? &dst->img : nullptr, root); CTL_CATCH
+}
+int ctl_image_packed_tile_bytes(uint32_t width, uint32_t height, uint32_t world, uint64_t* out_bytes) {
+    CTL_REQUIRE(out_bytes && width && height, "bad argument"); CTL_TRY *out_bytes = image_packed_tile_bytes(width, height, world); CTL_CATCH
+}
+int ctl_image_pack_tiles(ctl_image* img, uint32_t rank, uint32_t world, void* host_out) { CTL_REQUIRE(img && host_out, "null argument"); CTL_TRY image_pack_tiles(&img->img, rank, world, host_out); CTL_CATCH }
+int ctl_image_unpack_tiles(ctl_image* img, uint32_t world, const void* host_in_all_ranks) { CTL_REQUIRE(img && host_in_all_ranks, "null argument"); CTL_TRY image_unpack_tiles(&img->img, world, host_in_all_ranks); CTL_CATCH }
 void* ctl_image_device_ptr(ctl_image* img) { return img ? (void*)img->img.device() : nullptr; }
 int ctl_image_resolve_rgb(ctl_image* img, float splat_scale, float* host_rgb_out) { CTL_REQUIRE(img && host_rgb_out, "null argument"); CTL_TRY img->img.resolve_rgb(splat_scale, host_rgb_out); CTL_CATCH }
 

@@ -158,7 +158,7 @@ int default_flat_format() {
 }
 
 bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangles, int format) {
-    out.nodes.clear(); out.nodes_q8.clear(); out.nodes_f4.clear(); out.nodes_f2.clear(); out.leaves.clear(); out.compact_links = true;
+    out.nodes.clear(); out.nodes_q8.clear(); out.nodes_f4.clear(); out.nodes_f2.clear(); out.leaves.clear(); out.compact_links = true; out.split_refs = 0;
     out.format = (format == kFlatF4 || format == kFlatF2 || format == kFlatQ8) ? format : kFlatQ4;
     phase_timer pt;
     // leaf-entry range of every mesh (the woop stream is shared; a mesh ends where the next one starts)
@@ -184,17 +184,17 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     // flattened-BVH cache (scene_cache.h): the result depends on the leaf streams, the instance list and the node format only
     std::string key;
     if (!cache_dir().empty()) {
-        content_hash H; const uint32_t version = 16;
+        content_hash H; const uint32_t version = 17;
         H.add_value(version); { const char* e = knob_env("CTL_FLAT_SLAB_SUBTREE"); H.add_value(e ? atoi(e) : kSlabSubtreeDefault); } { const char* e = knob_env("CTL_FLAT_FORCE_EXPLICIT"); H.add_value(e ? atoi(e) : 0); } H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(flat_split_ratio()); H.add_value(flat_split_gain()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
         for (uint32_t k = 0; k < d.n_nodes; k++) { H.add_value(d.nodes[k].mesh_index); H.add(d.node_transforms[k].m, 64); }
         key = H.hex();
         cache_reader rd("flat", key);
-        int c_format = -1, c_depth = 0, c_compact = 0, c_root_slab = 0; uint64_t c_slab_nodes = 0;
-        if (rd.found() && rd.value(c_format) && rd.value(c_depth) && rd.value(c_compact) && rd.vector(out.nodes) && rd.vector(out.nodes_q8) && rd.vector(out.nodes_f4) && rd.vector(out.nodes_f2) && rd.vector(out.leaves) && rd.vector(out.child_links) && rd.value(c_root_slab) && rd.value(c_slab_nodes) && rd.verify() &&
+        int c_format = -1, c_depth = 0, c_compact = 0, c_root_slab = 0; uint64_t c_slab_nodes = 0, c_split_refs = 0;
+        if (rd.found() && rd.value(c_format) && rd.value(c_depth) && rd.value(c_compact) && rd.vector(out.nodes) && rd.vector(out.nodes_q8) && rd.vector(out.nodes_f4) && rd.vector(out.nodes_f2) && rd.vector(out.leaves) && rd.vector(out.child_links) && rd.value(c_root_slab) && rd.value(c_slab_nodes) && rd.value(c_split_refs) && rd.verify() &&
             c_format == out.format && ((out.compact_links = c_compact != 0), flat_links_valid(out))) {
-            out.max_depth = c_depth; out.root_slab = c_root_slab != 0; out.slab_nodes = (size_t)c_slab_nodes; pt.lap("cache hit");
+            out.max_depth = c_depth; out.root_slab = c_root_slab != 0; out.slab_nodes = (size_t)c_slab_nodes; out.split_refs = (size_t)c_split_refs; pt.lap("cache hit");
             return true;
         }
         out.nodes.clear(); out.nodes_q8.clear(); out.nodes_f4.clear(); out.nodes_f2.clear(); out.leaves.clear(); out.child_links.clear(); out.compact_links = true;
@@ -514,7 +514,9 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
                 int32_t& k = out.child_links[i * 8 + c];
                 if (k >= 0) continue;   // inner child, or kFlat8None (positive)
                 const uint32_t e = (uint32_t)~k;
-                if (!R.leaf_last[e]) return false;   // the BVH2 was built with one primitive per leaf
+                // the BVH2 was built with one primitive per leaf; coincident boxes (duplicate triangles, split references with identical boxes) can still share a leaf once
+                // the builder's depth limit is reached: such a scene takes the 4-wide format, whose leaves hold any number of entries (as a tree beyond 2^24 nodes does)
+                if (!R.leaf_last[e]) return flatten_scene(d, out, max_triangles, kFlatQ4);
                 k = ~(int32_t)entry_src.size(); entry_src.push_back(e);
             }
         }
@@ -767,7 +769,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     }
     if (!key.empty()) {
         cache_writer wr("flat", key);
-        if (wr.active()) { wr.value(out.format); wr.value(out.max_depth); { const int cl = out.compact_links ? 1 : 0; wr.value(cl); } wr.vector(out.nodes); wr.vector(out.nodes_q8); wr.vector(out.nodes_f4); wr.vector(out.nodes_f2); wr.vector(out.leaves); wr.vector(out.child_links); { const int rs = out.root_slab ? 1 : 0; wr.value(rs); const uint64_t sn = out.slab_nodes; wr.value(sn); } wr.commit(); pt.lap("cache write"); }
+        if (wr.active()) { wr.value(out.format); wr.value(out.max_depth); { const int cl = out.compact_links ? 1 : 0; wr.value(cl); } wr.vector(out.nodes); wr.vector(out.nodes_q8); wr.vector(out.nodes_f4); wr.vector(out.nodes_f2); wr.vector(out.leaves); wr.vector(out.child_links); { const int rs = out.root_slab ? 1 : 0; wr.value(rs); const uint64_t sn = out.slab_nodes; wr.value(sn); const uint64_t sr = out.split_refs; wr.value(sr); } wr.commit(); pt.lap("cache write"); }
     }
     return true;
 }

@@ -56,7 +56,7 @@ public:
     uint32_t getWidth() const { return w_; }
     uint32_t getHeight() const { return h_; }
     ctl_pixel_data* device() { return px_.p; }
-    bool holds_reduced_frame() const { return reduced_; }   // set on the root by an in-place ctl_image_reduce of more than one rank (comm.cpp), cleared by Clear() / write()
+    bool holds_reduced_frame() const { return reduced_; }   // set on every rank by an in-place ctl_image_reduce / ctl_image_gather of more than one rank (comm.cpp), cleared by Clear() / write()
     void mark_reduced(bool v) { reduced_ = v; }
     void read(ctl_pixel_data* host);
     void write(const ctl_pixel_data* host);
@@ -203,12 +203,13 @@ public:
     WavefrontPathTracer();
     void Resize(unsigned int w, unsigned int h) override;
     void setDepthBuffer(float* device_data, unsigned int dw, unsigned int dh) override { depth_buffer_ = device_data; depth_w_ = dw; depth_h_ = dh; }   // WavefrontPathTracer : IDepthTracer (WavefrontPathTracer.h:24)
-    void reservePasses(unsigned int n) override { const unsigned int b = std::min(passBatch(), std::max(1u, n)); if (w != 0xffffffffu && (uint64_t)n_local_pixels * b > capacity) { alloc_batch_ = b; Resize(w, h); } ensureTableRing(b); }
+    void reservePasses(unsigned int n) override { const unsigned int b = std::min(passBatch(), std::max(1u, n)); growBatch(b, "reservePasses"); ensureTableRing(b); }
 protected:
     void DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) override;
     void takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) override;
     unsigned int passBatch() const override;
 private:
+    void growBatch(unsigned int b, const char* who);   // queues for b passes per wavefront; validated before anything changes
     wave_queues Q{};
     uint32_t capacity = 0, n_local_pixels = 0, alloc_batch_ = 1;
     float* depth_buffer_ = nullptr; unsigned int depth_w_ = 0, depth_h_ = 0;
@@ -242,5 +243,10 @@ void comm_unique_id(unsigned char out[128]);
 Comm* comm_create(const unsigned char id[128], int rank, int world, int timeout_ms = 0);
 void comm_destroy(Comm* c);
 void comm_reduce_image(Comm* c, Image* src, Image* dst, int root);
+void comm_gather_image(Comm* c, Image* src, Image* dst, int root);
+size_t comm_gather_bytes(Comm* c, uint32_t W, uint32_t H);
+size_t image_packed_tile_bytes(uint32_t W, uint32_t H, uint32_t world);
+void image_pack_tiles(Image* img, uint32_t rank, uint32_t world, void* host_out);
+void image_unpack_tiles(Image* img, uint32_t world, const void* host_in_all_ranks);
 
 } // namespace ctl

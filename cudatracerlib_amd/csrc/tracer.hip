@@ -6,6 +6,7 @@
 #include "flatten.h"
 #include "image_io.h"
 #include "mitsuba_loader.h"   // unsupported_error
+#include "spline.h"
 #include <algorithm>
 #include <thread>
 #include <cctype>
@@ -144,6 +145,27 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
     // (Math/Spline.cu:223-453 via RoughTransmittance.cu:55-119), summed alpha / eta first instead of last: equal up to fp32 rounding.
     S.rt_reduced = nullptr;
     if (d.rough_transmittance) {
+        std::vector<float> pool; size_t off_t[3] = {}, off_d[3] = {};
+        for (int i = 0; i < 3; i++) {
+            const ctl_rough_transmittance& t = d.rough_transmittance[i];
+            if (!t.trans || !t.diff_trans) continue;
+            const size_t nt = (size_t)2 * t.eta_samples * t.alpha_samples * t.theta_samples, nd = (size_t)2 * t.eta_samples * t.alpha_samples;
+            off_t[i] = pool.size(); pool.insert(pool.end(), t.trans, t.trans + nt);
+            off_d[i] = pool.size(); pool.insert(pool.end(), t.diff_trans, t.diff_trans + nd);
+        }
+        if (!pool.empty()) {
+            rt_data_.upload(pool.data(), pool.size());
+            ctl_rough_transmittance tab[3];
+            for (int i = 0; i < 3; i++) { tab[i] = d.rough_transmittance[i]; const bool ok = tab[i].trans && tab[i].diff_trans; tab[i].trans = ok ? rt_data_.p + off_t[i] : nullptr; tab[i].diff_trans = ok ? rt_data_.p + off_d[i] : nullptr; }
+            rt_.upload(tab, 3);
+            S.rough_transmittance = rt_.p;
+        }
+    }
+    // Rough plastics with a CONSTANT roughness texture look the transmittance table up at fixed (alpha, eta): reduce the 3-D cubic interpolation
+    // (64 taps per lookup, three to five lookups per shaded vertex) to a 1-D table in cos(theta) once, here.  Same spline weights
+    // (Math/Spline.cu:223-453 via RoughTransmittance.cu:55-119), summed alpha / eta first instead of last: equal up to fp32 rounding.
+    S.rt_reduced = nullptr;
+    if (d.rough_transmittance) {
         auto weights = [](float p, uint32_t size, float* w, uint32_t& knot) {   // = spline_weights (bsdf_rough.h)
             if (!(p >= 0.0f && p <= 1.0f)) return false;
             float t = ((p - 0.0f) * (size - 1)) / (1.0f - 0.0f);
@@ -167,20 +189,10 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
             if (eta < 1) { data += (size_t)T.eta_samples * T.alpha_samples * T.theta_samples; ddata += (size_t)T.eta_samples * T.alpha_samples; eta = 1.0f / eta; }
             if (eta < T.eta_min) eta = T.eta_min;
             const float wa = std::pow((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f), we = std::pow((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
-            float wy[4], wz[4]; uint32_t ky, kz;
-            const bool ok = weights(wa, T.alpha_samples, wy, ky) && weights(we, T.eta_samples, wz, kz);
             m.reserved_[0] = (uint32_t)pool.size() + 1; m.reserved_[1] = T.theta_samples;
-            for (uint32_t x = 0; x < T.theta_samples; x++) {
-                float v = 0.0f;
-                if (ok) for (int z = -1; z <= 2; ++z) for (int y = -1; y <= 2; ++y) {
-                    const float wyz = wy[y + 1] * wz[z + 1];
-                    if (wyz == 0) continue;
-                    v += data[((size_t)(kz + z) * T.alpha_samples + (ky + y)) * T.theta_samples + x] * wyz;
-                }
-                pool.push_back(v);
-            }
-            float dv = 0.0f;
-            if (ok) for (int z = -1; z <= 2; ++z) for (int y = -1; y <= 2; ++y) { const float w = wy[y + 1] * wz[z + 1]; if (w == 0) continue; dv += ddata[(size_t)(kz + z) * T.alpha_samples + (ky + y)] * w; }
+            pool.resize(pool.size() + T.theta_samples);
+            spline_reduce_3d_to_1d(wa, we, data, T.theta_samples, T.alpha_samples, T.eta_samples, pool.data() + pool.size() - T.theta_samples);
+            const float dv = spline_eval_2d(wa, we, ddata, T.alpha_samples, T.eta_samples);
             pool.push_back(std::min(1.0f, std::max(0.0f, dv)));   // RoughTransmittanceManager::EvaluateDiffuse clamps
         }
         if (!pool.empty()) { rt_reduced_.upload(pool.data(), pool.size()); S.rt_reduced = rt_reduced_.p; }
@@ -300,7 +312,9 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
             if (d.n_tri_data < (1u << 27) && d.n_materials) {
                 for (flat_leaf& L : F.leaves) {
                     const uint32_t tri = L.index >> 1, mi = d.nodes[L.node].material_offset + ((d.tri_data[tri].nor_mat_extra[1] >> 16) & 0xffu);   // TriangleData::getMatIndex (TriangleData.h:40-44)
-                    L.index |= (mi < d.n_materials ? (d.materials[mi].bsdf_type & 15u) : 0u) << 28;
+                    // key 0 is the miss key: a hit whose material does not exist would be partitioned as a hit and shaded from a record outside the scene's materials
+                    if (mi >= d.n_materials) throw std::runtime_error("ctl_scene_create: triangle " + std::to_string(tri) + " of node " + std::to_string(L.node) + " names material " + std::to_string(mi) + " of " + std::to_string(d.n_materials));
+                    L.index |= (d.materials[mi].bsdf_type & 15u) << 28;
                 }
                 S.flat_leaf_keys = 1;
             }
@@ -595,13 +609,24 @@ WavefrontPathTracer::WavefrontPathTracer() {
 }
 float4* WavefrontPathTracer::new_f4(size_t n) { f4_.emplace_back(new dbuf<float4>()); f4_.back()->alloc(n); return f4_.back()->p; }
 
+// a ray's slot number travels in 31 bits (bit 31 of the traversal kernels' ray word is the "hit found" flag, traverse_flat.h) and the batch position of a path in 8.
+// Checked BEFORE any state changes (Resize, DoRender, reservePasses): a refused size or batch leaves the tracer as it was.
+static void check_batch(uint64_t n_local, unsigned int batch, const char* who) {
+    if (n_local * std::max(1u, batch) >= (1ull << 31) || batch > 255u)
+        throw std::runtime_error(std::string("WavefrontPathTracer::") + who + ": " + std::to_string(n_local) + " pixels x " + std::to_string(batch) + " passes per wavefront exceed the 2^31 ray slots (or 255 passes) of a batch: lower PassBatch");
+}
+void WavefrontPathTracer::growBatch(unsigned int b, const char* who) {
+    if (w == 0xffffffffu || (uint64_t)n_local_pixels * b <= capacity) return;
+    check_batch(n_local_pixels, b, who);
+    alloc_batch_ = b; Resize(w, h);
+}
 void WavefrontPathTracer::Resize(unsigned int _w, unsigned int _h) {
+    const uint64_t new_local = shard_pixel_count(_w, _h, shard_rank, shard_world);
+    check_batch(new_local, 1, "Resize");
+    if (new_local * alloc_batch_ >= (1ull << 31)) alloc_batch_ = 1;   // a batch reserved for a smaller frame / shard: the queues grow again with the next render's batch
     Tracer<true>::Resize(_w, _h);
     // DoubleRayBuffer(w*h, w*h) (WavefrontPathTracer.h:59) — here per rank: its tile shard's pixels
     n_local_pixels = shard_pixel_count(_w, _h, shard_rank, shard_world);
-    // a ray's slot number travels in 31 bits (bit 31 of the traversal kernels' ray word is the "hit found" flag, traverse_flat.h) and the batch position of a path in 8
-    if ((uint64_t)n_local_pixels * std::max(1u, alloc_batch_) >= (1ull << 31) || alloc_batch_ > 255u)
-        throw std::runtime_error("WavefrontPathTracer::Resize: " + std::to_string(n_local_pixels) + " pixels x " + std::to_string(alloc_batch_) + " passes per wavefront exceed the 2^31 ray slots (or 255 passes) of a batch: lower PassBatch");
     capacity = n_local_pixels * std::max(1u, alloc_batch_);   // grown by DoRender when a larger batch arrives
     f4_.clear();
     for (int b = 0; b < 2; b++) {
@@ -647,7 +672,7 @@ unsigned int WavefrontPathTracer::passBatch() const {
 }
 
 void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_t2p, unsigned int n_batch) {
-    if ((uint64_t)n_local_pixels * n_batch > capacity) { alloc_batch_ = n_batch; Resize(w, h); }   // the queues grow to the largest batch asked for
+    growBatch(n_batch, "DoRender");   // the queues grow to the largest batch asked for
     const int maxPathLength = m_sParameters.getValue("MaxPathLength"), rrStart = m_sParameters.getValue("RRStartDepth");
     const bool direct = m_sParameters.getValue("Direct") != 0;
     const size_t n_counts = (size_t)(maxPathLength + 2) * 4, n_work = (size_t)2 * (maxPathLength + 2);

@@ -406,9 +406,9 @@ int ctl_image_write_file(ctl_image* img, float splat_scale, const char* path);
 
 /* ---------------------------------------------------------------- multi-GPU */
 /* The one exchange step of a multi-GPU render (the reference is single-device): rank r renders the 64x64 image tiles t with
- * t % world == r (ctl_tracer_set_tile_shard) into a cleared full-size Image; ctl_image_reduce sums the PixelData frames of all ranks into
- * `root`'s image with ONE ncclReduce over RCCL / xGMI — the tiles are disjoint, so the sum is the gather.  One rank per process and GPU:
- * call ctl_set_device first.  ctl_comm_get_unique_id on one rank, hand the 128 bytes to the others by any means (MPI_Bcast, a file,
+ * t % world == r (ctl_tracer_set_tile_shard) into a cleared full-size Image.  ctl_image_gather brings every rank's own tiles to `root`'s image
+ * with ONE ncclGather over RCCL / xGMI; ctl_image_reduce (the fallback) sums the whole PixelData frames with ONE ncclReduce — the tiles are
+ * disjoint, so the sum is the gather, at 8x the bytes.  One rank per process and GPU: call ctl_set_device first.  ctl_comm_get_unique_id on one rank, hand the 128 bytes to the others by any means (MPI_Bcast, a file,
  * torch.distributed), then ctl_comm_create on every rank (collective).  RCCL is loaded on first use. */
 typedef struct ctl_comm ctl_comm;
 int ctl_comm_get_unique_id(uint8_t out128[128]);
@@ -417,13 +417,30 @@ void ctl_comm_destroy(ctl_comm* c);
 /* ctl_comm_create with a deadline: ncclCommInitRank is collective and waits for ever for a rank that never arrives; after timeout_ms (<= 0: $CTL_COMM_TIMEOUT_MS, else
  * 120 000) the call fails with CTL_ERR_INVALID and a message naming the rank, so that the host can fall back or stop the job.  ctl_comm_create uses the default. */
 int ctl_comm_create_timeout(const uint8_t id128[128], int32_t rank, int32_t world, int32_t timeout_ms, ctl_comm** out);
-/* In place: the root's image becomes the sum over the ranks.  ONE call per render: a second call on an image that already holds a reduced frame is refused with
- * CTL_ERR_INVALID (it would add the other ranks' cumulative tiles onto sums that contain them) until the image is cleared or rewritten. */
+/* In place: the root's image becomes the sum over the ranks.  ONE call per render: with more than one rank a second call on an image that already went through an in-place
+ * exchange is refused with CTL_ERR_INVALID on EVERY rank, before any of them enters the collective (it would add the other ranks' cumulative tiles onto sums that contain
+ * them), until the image is cleared or rewritten. */
 int ctl_image_reduce(ctl_image* img, ctl_comm* comm, int32_t root);
 /* Out of place — the per-pass gather of a progressive display (the reference shows the frame after every DoPass, main.cpp:164-172): dst on the root receives the sum over the
  * ranks of `src`; every rank's src (its own cumulative tile frame) is left as it is, so the call can be repeated after every pass.  dst may be NULL on the other ranks.
  * K per-pass gathers end with the frame one end-of-render ctl_image_reduce gives, bit for bit (same ncclReduce over the same inputs). */
 int ctl_image_reduce_to(ctl_image* src, ctl_image* dst, ctl_comm* comm, int32_t root);
+/* The gather of BASELINE's north_star.  Every rank packs the tiles it owns into ceil(tiles / world) slots of 65 x 65 x 28 B: [slot k = tile k * world + rank][row-major
+ * pixel][7 floats]; rows / columns 0..63 are the tile, row 64 / column 64 its HALO — the frame's pixels just right of and below the tile where they belong to another rank
+ * (a sample's film position pixel + jitter rounds into the next pixel once in ~10^4 samples, as Image::AddSample's floor does in the reference, and at a tile edge that
+ * pixel is another rank's: the rank accumulated it in its own full-size frame).  The clipped part of a border tile and a missing last slot are zero.  7.6 MB per rank at
+ * 1920x1080 / 8 against the reduce's 58 MB.  ONE ncclGather moves the slots to the root; a streaming kernel there copies every tile into the frame, a second one adds the
+ * halos.  Result: weights equal to the reduce's / the one-rank frame's exactly, colours to float rounding in the ~10^-5 of pixels that received a halo sample (bit-equal
+ * elsewhere).  _to writes all of `dst` (root only; NULL elsewhere), leaves every rank's `src` alone and can be repeated — the per-pass progressive exchange; the in-place
+ * form is ONE call per render like ctl_image_reduce (refused on every rank on a repeat).  Same deadline as the reduce: after the communicator's time-out the communicator
+ * is aborted (ncclCommAbort), the call fails with CTL_ERR_INVALID and every later call on that communicator is refused. */
+int ctl_image_gather(ctl_image* img, ctl_comm* comm, int32_t root);
+int ctl_image_gather_to(ctl_image* src, ctl_image* dst, ctl_comm* comm, int32_t root);
+/* The same packed slots for a host that moves them itself (MPI_Gather, a socket; bench.py's gloo fallback): bytes of one rank's buffer; D2H of `rank`'s slots of img;
+ * H2D of ALL ranks' buffers, rank-major (MPI_Gather's receive buffer), into img on the root: every tile is copied, then every halo added. */
+int ctl_image_packed_tile_bytes(uint32_t width, uint32_t height, uint32_t world, uint64_t* out_bytes);
+int ctl_image_pack_tiles(ctl_image* img, uint32_t rank, uint32_t world, void* host_out);
+int ctl_image_unpack_tiles(ctl_image* img, uint32_t world, const void* host_in_all_ranks);
 
 /* ------------------------------------------------------------------- tracer */
 typedef struct ctl_tracer ctl_tracer;

@@ -65,6 +65,8 @@ def load(shared_math=False):
     o.orc_bsdf_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_void_p]
     o.orc_light_sample_direct.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
     o.orc_rough_transmittance_eval.restype = f32; o.orc_rough_transmittance_eval.argtypes = [u32, f32, f32, f32]
+    o.orc_spline_eval_2d.restype = f32; o.orc_spline_eval_2d.argtypes = [f32, f32, C.c_void_p, u32, u32]
+    o.orc_spline_eval_3d.restype = f32; o.orc_spline_eval_3d.argtypes = [f32, f32, f32, C.c_void_p, u32, u32, u32]
     o.orc_rough_transmittance_eval_diffuse.restype = f32; o.orc_rough_transmittance_eval_diffuse.argtypes = [u32, f32, f32]
     o.orc_set_probe_rough_transmittance.argtypes = [C.c_void_p]
     o.orc_set_probe_materials.argtypes = [C.c_void_p]

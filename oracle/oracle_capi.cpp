@@ -196,6 +196,9 @@ void orc_set_probe_rough_transmittance(const ctl_rough_transmittance* t3) { g_pr
 static const ctl_material* g_probe_mats = nullptr;   // material array the nested indices of coating / roughcoating / blend refer to
 void orc_set_probe_materials(const ctl_material* m) { g_probe_mats = m; }
 float orc_rough_transmittance_eval(uint32_t slot, float cosTheta, float alpha, float eta) { DG dg; dg.rough_transmittance = g_probe_rt; return roughTransmittance(dg, slot, cosTheta, alpha, eta); }
+// the spline restatement alone (obsdf3.h evalCubicInterp2D / 3D), held against the reference's Math/Spline.cu through tests/golden/spline.npz
+float orc_spline_eval_2d(float px, float py, const float* values, uint32_t sx, uint32_t sy) { return evalCubicInterp2D(px, py, values, sx, sy); }
+float orc_spline_eval_3d(float px, float py, float pz, const float* values, uint32_t sx, uint32_t sy, uint32_t sz) { return evalCubicInterp3D(px, py, pz, values, sx, sy, sz); }
 float orc_rough_transmittance_eval_diffuse(uint32_t slot, float alpha, float eta) { DG dg; dg.rough_transmittance = g_probe_rt; return roughTransmittanceDiffuse(dg, slot, alpha, eta); }
 // local-frame probe: dg is an identity frame at the origin with uv = (u,v).  out = f(3), pdf, wo(3), sampledType, eta
 void orc_bsdf_sample(const ctl_material* M, const float* wi, float sx, float sy, float* out) {

@@ -471,6 +471,54 @@ def gen_bsdf(r):
     np.savez_compressed(os.path.join(HERE, "bsdf.npz"), **out)
 
 
+def spline_cases():
+    """inputs of spline.npz: tables of 2..32 knots per axis, query points inside, exactly on knots, at 0 and 1, just outside [0, 1] and NaN (own random stream)"""
+    rs = np.random.RandomState(20260941)
+
+    def points(n, sizes):
+        p = rs.uniform(0, 1, size=(n, len(sizes))).astype(np.float32)
+        for a, s in enumerate(sizes):
+            k = rs.randint(0, s, size=n // 4).astype(np.float32) / np.float32(s - 1)       # exactly on knots (as fp32 allows)
+            p[: n // 4, a] = k
+        p[n // 4] = 0; p[n // 4 + 1] = 1; p[n // 4 + 2, 0] = np.nextafter(np.float32(1), np.float32(2)); p[n // 4 + 3, -1] = np.nextafter(np.float32(0), np.float32(-1))
+        p[n // 4 + 4, 0] = np.nan; p[n // 4 + 5] = np.nextafter(np.float32(1), np.float32(0)); p[n // 4 + 6, 0] = -0.0
+        return p
+    cases = []
+    for dim in (1, 2, 3):
+        for _ in range(24 if dim < 3 else 16):
+            sizes = [int(x) for x in rs.randint(2, 33, size=dim)]
+            if _ == 0: sizes = [2] * dim
+            if _ == 1: sizes = [3] * dim
+            vals = (rs.uniform(0, 1, size=int(np.prod(sizes))) ** 2).astype(np.float32)      # transmittance-like: in [0, 1]
+            if _ % 5 == 2: vals = rs.normal(size=vals.size).astype(np.float32) * np.float32(100)
+            cases.append((dim, sizes, vals, points(48, sizes)))
+    return cases
+
+
+def gen_spline(r):
+    """Spline::evalCubicInterp1D / 2D / 3D (Math/Spline.cu:6-44, 223-296, 376-453) of the reference build: min = 0, max = 1 per axis and extrapolate = false — the way
+    RoughTransmittance calls it — plus, for the 1-D and 2-D functions, a shifted knot range with extrapolation on (pins the driver's argument order)"""
+    r.ref_spline_eval_1d.restype = C.c_float; r.ref_spline_eval_1d.argtypes = [f32, C.c_void_p, C.c_uint32, f32, f32, C.c_int]
+    r.ref_spline_eval_2d.restype = C.c_float; r.ref_spline_eval_2d.argtypes = [C.c_void_p] * 5 + [C.c_int]
+    r.ref_spline_eval_3d.restype = C.c_float; r.ref_spline_eval_3d.argtypes = [C.c_void_p] * 5 + [C.c_int]
+    out = {}
+    for i, (dim, sizes, vals, pts) in enumerate(spline_cases()):
+        sz = np.array(sizes, np.uint32); lo = np.zeros(dim, np.float32); hi = np.ones(dim, np.float32)
+        res = np.zeros(len(pts), np.float32); res_x = np.zeros(len(pts), np.float32)
+        lo2 = np.full(dim, -1.5, np.float32); hi2 = np.full(dim, 2.25, np.float32)
+        for j, q in enumerate(pts):
+            q = np.ascontiguousarray(q, np.float32); q2 = (np.nan_to_num(q, nan=0.5) * np.float32(5) - np.float32(2)).astype(np.float32)   # (a NaN with extrapolation on reads outside the table in the reference)
+            if dim == 1:
+                res[j] = r.ref_spline_eval_1d(f32(q[0]), vals.ctypes.data, int(sz[0]), f32(0), f32(1), 0)
+                res_x[j] = r.ref_spline_eval_1d(f32(q2[0]), vals.ctypes.data, int(sz[0]), f32(lo2[0]), f32(hi2[0]), 1)
+            else:
+                fn = r.ref_spline_eval_2d if dim == 2 else r.ref_spline_eval_3d
+                res[j] = fn(q.ctypes.data, vals.ctypes.data, sz.ctypes.data, lo.ctypes.data, hi.ctypes.data, 0)
+                res_x[j] = fn(q2.ctypes.data, vals.ctypes.data, sz.ctypes.data, lo2.ctypes.data, hi2.ctypes.data, 1)
+        out["c%02d_size" % i] = sz; out["c%02d_values" % i] = vals; out["c%02d_points" % i] = pts; out["c%02d_result" % i] = res; out["c%02d_result_shifted_extrapolated" % i] = res_x
+    np.savez_compressed(os.path.join(HERE, "spline.npz"), n_cases=np.int32(len(spline_cases())), **out)
+
+
 def gen_lights(r):
     # ---- the reference's own PointLight / SpotLight / DistantLight (SceneTypes/Light.cu, compiled by `make ref` without its two g_SceneData functions; oracle/ref_light_driver.cpp):
     # constructed by the reference from primary parameters, sampleDirect from random reference points
@@ -544,13 +592,17 @@ if __name__ == "__main__":
         gen_emitters(oracle.load_ref())
     elif sys.argv[1:] == ["lights"]:
         gen_lights(oracle.load_ref())
+        gen_spline(oracle.load_ref())
     elif sys.argv[1:] == ["bsdf"]:
         gen_bsdf(oracle.load_ref())
         gen_lights(oracle.load_ref())
+        gen_spline(oracle.load_ref())
     elif sys.argv[1:] == ["mipmap"]:
         gen_mipmap(oracle.load_ref())
     elif sys.argv[1:] == ["math2"]:
         gen_math2(oracle.load_ref())
+    elif sys.argv[1:] == ["spline"]:
+        gen_spline(oracle.load_ref())
     elif sys.argv[1:] == ["traceray"]:      # only this fixture (the others stay byte-identical)
         gen_traceray(oracle.load_ref())
     else:
@@ -561,3 +613,4 @@ if __name__ == "__main__":
         gen_bsdf(oracle.load_ref())
         gen_emitters(oracle.load_ref())
         gen_lights(oracle.load_ref())
+        gen_spline(oracle.load_ref())

@@ -31,6 +31,12 @@ def test_three_ranks():
     assert out["n_gpus"] == 3 and out["ranks_joined"] == 3
 
 
+def test_eight_ranks():
+    """the world size of BASELINE config 4 (8 x MI355X): eight processes rendezvous, get the communicator id and reduce their scalars"""
+    out = json.loads(_run(["--gpus", "8", "--launch-only"], timeout=400).stdout)
+    assert out["n_gpus"] == 8 and out["ranks_joined"] == 8 and out["max_over_ranks"] == 8.0 and out["id_broadcast_ok"]
+
+
 def test_one_gpu_runs_in_process():
     out = json.loads(_run(["--gpus", "1", "--launch-only"]).stdout)
     assert out["n_gpus"] == 1 and not out["self_launched"]      # N = 1 is today's single-process code path, no launcher in between

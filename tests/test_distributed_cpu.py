@@ -110,3 +110,79 @@ def test_per_pass_gathers_end_with_the_frame_of_one_final_reduce(tmp_path):
     s1, s2, s3, end, full = np.load(out)
     assert np.array_equal(s3, end) and np.array_equal(end, full)
     assert s1[..., 6].sum() == w * h and s2[..., 6].sum() == 2 * w * h and s3[..., 6].sum() == 3 * w * h
+
+
+def _spilled_frames(w, h, world, seed=11):
+    """what the ranks of a render hold: `full` = the one-rank frame; per rank its own tiles of it, where a few samples of pixels on a tile's right / bottom edge were
+    accumulated one pixel further — in ANOTHER rank's tile (pixel + jitter rounds up, compaction.h add_sample_ordered) — integer-valued so that every sum is exact"""
+    import tile_shards as parallel
+    rs = np.random.RandomState(seed)
+    own = parallel.tile_owner(w, h, world)
+    base = rs.randint(0, 50, size=(h, w, 7)).astype(np.float32)
+    frames = [np.where((own == r)[..., None], base, np.float32(0)) for r in range(world)]
+    full = base.copy()
+    n_spill = 0
+    for y in range(h):
+        for x in range(w):
+            for (dx, dy) in ((1, 0), (0, 1), (1, 1)):
+                xx, yy = x + dx, y + dy
+                if xx < w and yy < h and own[yy, xx] != own[y, x] and rs.uniform() < 0.25:
+                    v = rs.randint(1, 9, size=7).astype(np.float32)
+                    frames[own[y, x]][yy, xx] += v; full[yy, xx] += v; n_spill += 1
+    assert n_spill > 20
+    return full, frames
+
+
+def _worker_gather(rank, world, port, w, h, out_path):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import tile_shards as parallel
+    full, frames = _spilled_frames(w, h, world)                                               # the same on every rank (seeded)
+    mine = frames[rank]
+    before = mine.copy()
+    got = parallel.gather_framebuffer(mine, dst=0)                                            # ONE gather of ceil(tiles / world) packed slots per rank
+    assert np.array_equal(mine, before)                                                       # the source is untouched: the call serves the per-pass exchange too
+    red = torch.from_numpy(mine.reshape(-1).copy()); parallel.reduce_framebuffer(red, dst=0)  # the fallback: one sum-reduce of the whole frames
+    again = parallel.gather_framebuffer(mine, dst=0)                                          # out of place: repeatable
+    if rank == 0:
+        np.save(out_path, np.stack([got, red.numpy().reshape(h, w, 7), full, again]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 192, 160), (3, 320, 100), (3, 1920 // 4, 1080 // 4)])
+def test_gather_of_packed_tiles_equals_the_reduce(tmp_path, world, w, h):
+    """north_star's exchange — a gather of the framebuffer — on 2 and 3 ranks over gloo: uneven tile counts (9 tiles / 2 ranks, 10 tiles / 3 ranks: the last slot of
+    some ranks is padding), clipped border tiles, and samples a rank accumulated one pixel inside ANOTHER rank's tile (they travel in the slot's halo and are added on the
+    root); the gathered frame == the reduced frame == the one-rank frame, bit for bit (integer-valued data: every sum is exact); a repeat gives the same frame"""
+    import torch.multiprocessing as mp
+    import tile_shards as parallel
+    nt = ((w + 63) // 64) * ((h + 63) // 64)
+    assert nt % world != 0 or h % 64 != 0
+    out = str(tmp_path / "g.npy")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_gather, args=(r, world, port, w, h, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got, red, full, again = np.load(out)
+    assert np.array_equal(got, full) and np.array_equal(red, full) and np.array_equal(again, full)
+    assert parallel.packed_slots(w, h, world) * world >= nt
+
+
+def test_pack_unpack_round_trip_and_sizes():
+    import tile_shards as parallel
+    assert parallel.packed_slots(1920, 1080, 8) * 65 * 65 * 28 == 7571200          # 7.6 MB per rank at the benchmark size (DESIGN §7), against 58 MB for the reduce
+    for (w, h, world) in ((100, 70, 3), (64, 64, 1), (130, 65, 4), (192, 128, 8), (200, 150, 2)):
+        full, frames = _spilled_frames(w, h, world, seed=w) if world > 1 and (w > 64 or h > 64) else (np.random.RandomState(1).randint(0, 9, size=(h, w, 7)).astype(np.float32), None)
+        if frames is None:
+            frames = [full]
+        packed = np.stack([parallel.pack_tiles(frames[r], r, world) for r in range(world)])
+        assert packed.shape == (world, parallel.packed_slots(w, h, world), 65 * 65, 7)
+        out = parallel.unpack_tiles(np.full_like(full, -1), world, packed)
+        assert np.array_equal(out, full)

@@ -101,6 +101,21 @@ def test_batching_and_sharding_do_not_change_the_frame(gpu, workload):
     assert sum(p[1] for p in parts) == rays_one
     assert np.array_equal(s[..., 6], one[..., 6])
     assert np.allclose(s[..., :3], one[..., :3], rtol=1e-5, atol=1e-5)
+    # ... and what ONE gather of their packed tiles (ctl_image_gather: 64 slots of 65 x 65 pixels per rank, the halo carrying the samples a rank accumulated one pixel inside
+    # another rank's tile) gives the root: each shard frame through the device pack kernel, all eight buffers through the device unpack — the frame of the sum (= of the
+    # reduce).  Weights exactly; colours bit for bit except where a halo sample was added (another order of the same additions).
+    import tile_shards
+    img = gpu.Image(W, H); packed = []
+    for r in range(8):
+        img.setPixelData(parts[r][0]); packed.append(img.packTiles(r, 8))
+        own = tile_shards.tile_mask(W, H, r, 8)
+        assert (parts[r][0][..., 6][~own] != 0).sum() < 200                # the spill into other ranks' tiles exists and is rare (~1e-5 of the samples)
+    assert packed[0].nbytes == 7571200
+    img.setPixelData(parts[0][0]); img.unpackTiles(8, np.stack(packed))
+    g = img.getPixelData()
+    assert np.array_equal(g[..., 6], s[..., 6])
+    assert np.allclose(g[..., :3], s[..., :3], rtol=1e-6, atol=1e-6) and (g[..., :3] == s[..., :3]).all(axis=2).mean() > 0.9999
+    assert sum((parts[r][0][..., 6][~tile_shards.tile_mask(W, H, r, 8)] != 0).sum() for r in range(8)) > 0   # (the halo path was exercised)
     share = np.array([p[1] for p in parts], np.float64) / rays_one
     assert share.min() > 0.09 and share.max() < 0.16                  # round-robin tiles balance the ranks (ideal 0.125)
 

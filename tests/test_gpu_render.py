@@ -402,10 +402,55 @@ def test_native_framebuffer_reduce_single_rank(gpu):
     assert np.array_equal(img.getPixelData(), a)
     with pytest.raises(gpu.CtlError):
         comm.reduce(img, 3)
-    with pytest.raises(gpu.CtlError, match="already holds a reduced frame"):   # a second in-place reduce would double the other ranks' tiles: refused until the image is cleared / rewritten
-        comm.reduce(img, 0)
-    img.setPixelData(a); comm.reduce(img, 0)
+    comm.reduce(img, 0)     # one rank: the sum is the frame itself, a repeat is harmless (with more ranks a second in-place reduce is refused on every rank, comm.cpp)
+    assert np.array_equal(img.getPixelData(), a)
     del comm
+
+
+def test_native_framebuffer_gather(gpu):
+    """ctl_image_gather / _gather_to / ctl_image_pack_tiles / _unpack_tiles (csrc/comm.cpp), north_star's "single RCCL gather of the framebuffer": (1) a communicator of
+    one rank: pack -> ncclGather -> unpack gives the frame back bit for bit, in place and out of place, at a size with clipped border tiles; (2) the device pack / unpack
+    kernels against their numpy statement (tests/tile_shards.py) for every rank of 2-, 3- and 8-rank shards of frames in which samples were accumulated one pixel inside
+    ANOTHER rank's tile (the halo of a slot; corner pixels that lie in the halo of several of a rank's tiles travel once); (3) the root's unpack of all ranks' buffers ->
+    the one-rank frame, bit for bit (integer-valued data).  (ncclGather with world > 1 needs > 1 GPU.)"""
+    import tile_shards
+    from test_distributed_cpu import _spilled_frames
+    w, h = 200, 150      # 4 x 3 tiles, right and bottom tiles clipped
+    a = np.random.RandomState(3).uniform(-1, 4, size=(h, w, 7)).astype(np.float32)
+    img, dst = gpu.Image(w, h), gpu.Image(w, h)
+    img.setPixelData(a)
+    comm = gpu.Comm(gpu.Comm.unique_id(), 0, 1, timeout_ms=60000)
+    comm.gather(img, 0); comm.gather(img, 0)                # one rank: nothing to count twice
+    assert np.array_equal(img.getPixelData(), a)
+    comm.gather_to(img, dst, 0); comm.gather_to(img, dst, 0)
+    assert np.array_equal(dst.getPixelData(), a) and np.array_equal(img.getPixelData(), a)
+    comm.reduce(img, 0)                                     # the fallback gives the same frame
+    assert np.array_equal(img.getPixelData(), a)
+    with pytest.raises(gpu.CtlError):
+        comm.gather(img, 2)
+    with pytest.raises(gpu.CtlError):
+        comm.gather_to(img, img, 0)
+    with pytest.raises(gpu.CtlError):
+        comm.gather_to(img, gpu.Image(64, 64), 0)
+    del comm
+    for world in (2, 3, 8):
+        full, frames = _spilled_frames(w, h, world, seed=world)
+        assert img.packedTileBytes(world) == tile_shards.packed_slots(w, h, world) * 65 * 65 * 28
+        packed = []
+        for r in range(world):
+            img.setPixelData(frames[r])
+            p = img.packTiles(r, world)
+            assert np.array_equal(p, tile_shards.pack_tiles(frames[r], r, world)), (world, r)
+            packed.append(p)
+        out = gpu.Image(w, h); out.setPixelData(frames[0])                       # the root unpacks into its own frame (the in-place form) ...
+        out.unpackTiles(world, np.stack(packed))
+        assert np.array_equal(out.getPixelData(), full), world
+        out.setPixelData(np.full_like(full, -7)); out.unpackTiles(world, np.stack(packed))   # ... or into any other image
+        assert np.array_equal(out.getPixelData(), full)
+    with pytest.raises(gpu.CtlError):
+        img.packTiles(3, 3)
+    with pytest.raises(ValueError):
+        out.unpackTiles(3, np.zeros(5, np.float32))
 
 
 def test_per_pass_gather_out_of_place(gpu, orc):
