@@ -143,7 +143,25 @@ def calibrated_traffic(workload_key):
     return e
 
 
-KERNEL_BUILD = "r04-flat-q4-parked-leaves-hit-keys"   # changes when the traversal kernel or the flattened layout changes: a traffic profile of another build is not quoted
+def source_hash(names):
+    """what ties a committed counter profile to the binary: sha256 over the named files of cudatracerlib_amd/csrc (name + content), first 12 hex digits"""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        h.update(n.encode() + b"\0")
+        with open(os.path.join(ROOT, "cudatracerlib_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+        h.update(b"\1")
+    return h.hexdigest()[:12]
+
+
+# the traversal kernel and the tree it walks / the shade kernels: an edit to any of these files without a re-profile (tools/profile_round.sh -> tools/summarize_profile.py ->
+# profiles/roofline_traffic.json) turns the roofline's counter-side numbers into "unprofiled" instead of quoting another binary's counters (tests/test_profile_hash.py)
+TRAVERSAL_SOURCES = ["traverse_flat.h", "flat_slab.h", "flatten.cpp", "flatten.h", "traverse.h", "kernels.hip"]
+SHADE_SOURCES = ["shade_kernel.inc", "shading.h", "bsdf_complex.h", "bsdf_more.h", "bsdf_rough.h", "spline.h", "material_factory.h", "mipmap.h", "ctl_math.h", "ctl_fmath.h", "compaction.h", "kernels.h",
+                 "shade_basic.hip", "shade_full.hip", "shade_class_a.hip", "shade_class_b.hip", "shade_class_c.hip", "shade_class_g.hip", "shade_class_p.hip"]
+KERNEL_BUILD = "trav-" + source_hash(TRAVERSAL_SOURCES)
+SHADE_BUILD = "shade-" + source_hash(SHADE_SOURCES)
 
 
 def self_launch(args, argv):
@@ -506,6 +524,8 @@ def main():
         # the second kernel of the step: shading (k_shade_basic / k_shade_full), priced the same way per shaded path vertex (= closest-hit ray)
         roof_shade = None
         sh = cal.get("shade") if cal else None
+        if sh and sh.get("kernel_build") != SHADE_BUILD:
+            sh = None           # the profile is of other shade sources
         if sh and sh.get("bytes_per_vertex") and st.ms_shade > 0:
             t_sh = st.ms_shade * 1e-3
             fs = {"hbm": sh["bytes_per_vertex"] * n_closest / t_sh / (HBM_PEAK_GBS * 1e9)}
@@ -518,7 +538,10 @@ def main():
                           "achieved": round(sh["bytes_per_vertex"] * n_closest / t_sh / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fs["hbm"], 4),
                           "traffic_per_vertex": round(sh["bytes_per_vertex"], 1),
                           "algorithmic_bytes_per_vertex": 104 + 16 + 20 + 136 + 32 + 48, "algorithmic_note": "SURVEY 8d shading list: path state 104 B + hit 16 + 4 read, <= 104 + 32 written, TriangleData 32 B, instance rows 48 B (+ material / light records, L2-resident)",
-                          "vertices": n_closest, "ms": round(st.ms_shade, 3), "valu_lane_utilisation_profiled": sh.get("valu_lane_utilisation")}
+                          "vertices": n_closest, "ms": round(st.ms_shade, 3), "valu_lane_utilisation_profiled": sh.get("valu_lane_utilisation"), "kernel_build": SHADE_BUILD}
+        elif st.ms_shade > 0:
+            roof_shade = {"bound": "unprofiled", "kernel_build": SHADE_BUILD, "vertices": n_closest, "ms": round(st.ms_shade, 3),
+                          "note": "no counter profile of this workload with these shade sources in profiles/roofline_traffic.json (tools/profile_round.sh writes one)"}
         out = {
             "metric": "Mrays/s at %dx%d, %d spp (steps), depth-%d; achieved HBM GB/s vs peak" % (args.width, args.height, args.steps, args.depth),
             "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -746,6 +746,43 @@ class Image:
             raise ValueError("unpackTiles: %d bytes, expected %d" % (a.nbytes, self.packedTileBytes(world) * world))
         _check(lib.ctl_image_unpack_tiles(self._h, u32(world), a.ctypes.data_as(C.c_void_p)))
 
+    def Clear(self):
+        _check(lib.ctl_image_clear(self._h))
+
+    def getPixelData(self):
+        """(h, w, 7) float32: rgb[3], rgbSplat[3], weightSum."""
+        a = np.zeros((self.height, self.width, 7), np.float32)
+        _check(lib.ctl_image_read_pixels(self._h, a.ctypes.data_as(C.c_void_p)))
+        return a
+
+    def setPixelData(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(self.height, self.width, 7)
+        _check(lib.ctl_image_write_pixels(self._h, a.ctypes.data_as(C.c_void_p)))
+
+    def device_ptr(self):
+        return lib.ctl_image_device_ptr(self._h)
+
+    def applyImagePipeline(self, splat_scale=0.0, filter=None, process=None):
+        """applyImagePipeline(tracer, img, filter, process) (Kernel/ImagePipeline/ImagePipeline.cu:54-84): (h, w, 4) uint8 display image.
+        filter = ctl_reconstruction_filter (see box_filter ... triangle_filter) or None; process = ctl_tonemap (see tonemap) or None."""
+        a = np.zeros((self.height, self.width), np.uint32)
+        if filter is None and process is None:
+            _check(lib.ctl_image_apply_pipeline(self._h, f32(splat_scale), a.ctypes.data_as(C.c_void_p)))
+        else:
+            _check(lib.ctl_image_apply_pipeline_ex(self._h, f32(splat_scale), None if filter is None else C.byref(filter),
+                                                   None if process is None else C.byref(process), a.ctypes.data_as(C.c_void_p)))
+        return a.view(np.uint8).reshape(self.height, self.width, 4)
+
+    def WriteDisplayImage(self, path, splat_scale=0.0):
+        """Image::WriteDisplayImage: .png (display image), .hdr / .pfm (linear)."""
+        _check(lib.ctl_image_write_file(self._h, f32(splat_scale), path.encode()))
+
+    def getRGB(self, splat_scale=0.0):
+        """copySamplesToOutput (Kernel/ImagePipeline/ImagePipeline.cu:14-30) up to linear RGB."""
+        a = np.zeros((self.height, self.width, 3), np.float32)
+        _check(lib.ctl_image_resolve_rgb(self._h, f32(splat_scale), a.ctypes.data_as(C.c_void_p)))
+        return a
+
 class _Parameters:
     def __init__(self, tracer):
         self._t = tracer

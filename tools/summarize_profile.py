@@ -135,7 +135,8 @@ def main():
                               "bytes_per_vertex": ((2 * rs.get("FETCH_SIZE", 0.0) + rs.get("WRITE_SIZE", 0.0)) * 1024 / verts) if verts else None,
                               "valu_insts_per_vertex": (rs.get("SQ_INSTS_VALU", 0.0) / verts) if verts else None,
                               "lane_loads_per_vertex": ((rs.get("TCP_TOTAL_CACHE_ACCESSES_sum") or rs.get("SQ_INSTS_VMEM_RD", 0.0) * 64.0 * (sl or 0.0)) / verts) if verts else None,
-                              "valu_lane_utilisation": round(sl, 4) if sl else None, "profile_fractions": {"hbm": sh_hbm, "valu_issue_min": sh_issue, "l1_lookup": sh_l1}}
+                              "valu_lane_utilisation": round(sl, 4) if sl else None, "profile_fractions": {"hbm": sh_hbm, "valu_issue_min": sh_issue, "l1_lookup": sh_l1},
+                              "kernel_build": (b.get("roofline_shade") or {}).get("kernel_build")}   # bench.py SHADE_BUILD of the profiled run: hash of the shade sources
         t["workloads"][rf["workload_key"]] = entry
         json.dump(t, open(tpath, "w"), indent=1)
     # the contract's cross-check: rocprofv3's own durations of the dominant kernel's TIMED launches (the last `launches` dispatches of the kernel-trace run:
