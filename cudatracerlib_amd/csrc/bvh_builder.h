@@ -30,7 +30,10 @@ struct bvh_result {
 // prim_boxes: one box per primitive.  max_leaf: 8 for meshes (BVHBuilderHelper.cpp:119), 1 for the scene BVH
 // (BVHRebuilder.cpp:380-383).  wrap_single_leaf: emit the (leaf, 0x76543210) root node the reference emits for a
 // one-leaf mesh (SplitBVHBuilder.cpp:176-189).  max_depth_limit bounds the traversal stack.
-void build_bvh(const std::vector<aabb>& prim_boxes, int max_leaf, bool wrap_single_leaf, int max_depth_limit, bvh_result& out, float node_cost = 1.0f);
+// reinsertion_passes > 0: that many passes of insertion-based re-optimisation over the finished tree (bvh_builder.cpp reinserter), each over the largest
+// `reinsertion_fraction` of the nodes; a result deeper than max_depth_limit is discarded.
+void build_bvh(const std::vector<aabb>& prim_boxes, int max_leaf, bool wrap_single_leaf, int max_depth_limit, bvh_result& out, float node_cost = 1.0f,
+               int reinsertion_passes = 0, float reinsertion_fraction = 1.0f);
 
 // The reference's mesh build restated (sbvh_builder.cpp): SplitBVHBuilder with spatial splits over the triangles
 // (positions[3 * n_vert], indices[3 * n_tri] or nullptr for a soup).  leaf_prims may name a triangle more than once.

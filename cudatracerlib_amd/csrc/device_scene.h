@@ -53,6 +53,7 @@ struct dev_scene {
     uint32_t n_nodes;
     uint32_t num_lights;
     uint32_t env_map_index;
+    uint32_t n_lights_buf, n_anim_bytes, n_materials_probe;   // sizes of lights[] and the anim blob (shade kernels keep small ones in LDS, shade_kernel.inc)
     uint32_t alpha_maps;         // KernelDynamicScene::doAlphaMapping: some material carries an alpha map
     uint32_t shade_features;     // kShade* bits the scene needs (selects the shade-kernel build, kernels.hip launch_shade)
     uint32_t shade_models;       // bit m = some material of the scene has the BSDF model CTL_BSDF_* == m (which model-class launches a depth needs, kernels.hip launch_shade)

@@ -34,6 +34,10 @@ float flat_collapse_node_cost() { static const float v = [] { const char* e = kn
 float flat_split_ratio() { static const float v = [] { const char* e = knob_env("CTL_FLAT_SPLIT"); const float x = e ? (float)atof(e) : -1.0f; return x >= 0.0f ? x : 4.0f; }(); return v; }   // with the gain rule below, on the GPU (profiles/r04_split_clipping.log): 4: synthetic-sm-hard 3381 Mrays/s (no clipping: 1383), 8: 3316, 16: 3203; synthetic-SM and -bathroom unchanged
 // ... and a split is kept only where the two parts' boxes have less than this fraction of the part's box surface (1 = always); $CTL_FLAT_SPLIT_GAIN
 float flat_split_gain() { static const float v = [] { const char* e = knob_env("CTL_FLAT_SPLIT_GAIN"); const float x = e ? (float)atof(e) : -1.0f; return x > 0.0f ? x : 0.65f; }(); return v; }   // 0.6 .. 0.7 equal; 0.8 .. 1.0 also split axis-aligned floors and walls: synthetic-SM - 7 %, synthetic-sm-hard 2800 .. 2960
+// insertion-based re-optimisation of the BVH2 before the collapse (bvh_builder.cpp reinserter): passes, and the share of the nodes (largest first) a pass visits
+int flat_reinsert_passes() { static const int v = [] { const char* e = knob_env("CTL_FLAT_REINSERT"); const int x = e ? atoi(e) : -1; return x >= 0 && x <= 64 ? x : 16; }(); return v; }
+float flat_reinsert_fraction() { static const float v = [] { const char* e = knob_env("CTL_FLAT_REINSERT_FRACTION"); const float x = e ? (float)atof(e) : 0.0f; return x > 0.0f && x <= 1.0f ? x : 0.03f; }(); return v; }
+int flat_slot_order() { static const int v = [] { const char* e = knob_env("CTL_FLAT_SLOT_ORDER"); const int x = e ? atoi(e) : -1; return x >= 0 && x <= 2 ? x : 0; }(); return v; }
 float flat_node_cost() { static const float v = [] { const char* e = knob_env("CTL_FLAT_NODE_COST"); const float x = e ? (float)atof(e) : 0.0f; return x > 0.0f ? x : 0.5f; }(); return v; }
 
 // 4x4 inverse in double (cofactor expansion)
@@ -185,7 +189,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
     std::string key;
     if (!cache_dir().empty()) {
         content_hash H; const uint32_t version = 17;
-        H.add_value(version); { const char* e = knob_env("CTL_FLAT_SLAB_SUBTREE"); H.add_value(e ? atoi(e) : kSlabSubtreeDefault); } { const char* e = knob_env("CTL_FLAT_FORCE_EXPLICIT"); H.add_value(e ? atoi(e) : 0); } H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(flat_split_ratio()); H.add_value(flat_split_gain()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
+        H.add_value(version); { const char* e = knob_env("CTL_FLAT_SLAB_SUBTREE"); H.add_value(e ? atoi(e) : kSlabSubtreeDefault); } { const char* e = knob_env("CTL_FLAT_FORCE_EXPLICIT"); H.add_value(e ? atoi(e) : 0); } H.add_value(flat_collapse_mode()); { const char* e = knob_env("CTL_FLAT_SLAB_USEFUL"); H.add_value(e ? atof(e) : 0.6); } H.add_value(flat_collapse_node_cost()); { const char* e = knob_env("CTL_FLAT_BFS_TOP"); H.add_value(e ? atol(e) : 65536L); } H.add_value((int)sizeof(flat_leaf)); H.add_value(flat_max_leaf()); H.add_value(flat_node_cost()); H.add_value(flat_split_ratio()); H.add_value(flat_split_gain()); H.add_value(flat_reinsert_passes()); H.add_value(flat_reinsert_fraction()); H.add_value(flat_slot_order()); H.add_value(out.format); H.add_value(d.n_meshes); H.add_value(d.n_nodes); H.add_value(d.n_woop);
         H.add(d.woop, (size_t)d.n_woop * sizeof(ctl_woop_tri)); H.add(d.woop_index, (size_t)d.n_woop * sizeof(ctl_woop_index));
         H.add(d.meshes, (size_t)d.n_meshes * sizeof(ctl_kernel_mesh));
         for (uint32_t k = 0; k < d.n_nodes; k++) { H.add_value(d.nodes[k].mesh_index); H.add(d.node_transforms[k].m, 64); }
@@ -324,7 +328,7 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
         pt.lap("split large triangles");
     }
     bvh_result R;
-    build_bvh(boxes, out.format == kFlatQ8 ? 1 : flat_max_leaf(), true, 60, R, flat_node_cost());   // Q8: every leaf slot is ONE entry (flat8.h)
+    build_bvh(boxes, out.format == kFlatQ8 ? 1 : flat_max_leaf(), true, 60, R, flat_node_cost(), flat_reinsert_passes(), flat_reinsert_fraction());   // Q8: every leaf slot is ONE entry (flat8.h)
     pt.lap("build BVH2");
     int wdepth = 0;
     if (out.format == kFlatF2) {
@@ -424,6 +428,16 @@ bool flatten_scene(const ctl_scene_desc& d, flat_scene& out, size_t max_triangle
         // collapse to 4-wide nodes
         std::vector<wide4_node> W;
         collapse_bvh4(R, W, wdepth, flat_collapse_mode(), flat_collapse_node_cost(), std::min(flat_max_leaf(), 4));
+        if (const int so = flat_slot_order()) {
+            // Slot order.  The closest-hit traversal orders the entered children by distance; the any-hit traversal (shadow rays) takes them in SLOT order, so the slot order is its
+            // visiting order: 1 = largest box first (the child a random ray most likely meets), 2 = smallest first (measurement), 0 = as the collapse left them
+            for (wide4_node& w : W) {
+                int idx[4] = { 0, 1, 2, 3 };
+                std::stable_sort(idx, idx + w.n, [&](int a, int b) { const float x = w.cbox[a].area(), y = w.cbox[b].area(); return so == 1 ? x > y : x < y; });
+                wide4_node t = w;
+                for (int k = 0; k < w.n; k++) { w.cbox[k] = t.cbox[idx[k]]; w.child[k] = t.child[idx[k]]; }
+            }
+        }
         {   // memory order: the inner children of a node sit next to each other, subtrees stay clustered: a ray that enters a node
             // usually enters one or two of its children next, and neighbouring lines share DRAM pages / L2 sets
             std::vector<int> new_id(W.size(), -1), order; order.reserve(W.size());

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, CTL_MEGA_WAVES) void k_path_trace(dev_scene S,
             const uint32_t nli = mat.node_light_index;
             if (nli != 0xffffffffu) {
                 const uint32_t li2 = nli == 0 ? ninfo.y : ninfo.z;
-                const ctl_light& light = S.lights[li2];
+                const ctl_light& light = scene_lights(S)[li2];
                 float misWeight = 1.0f;
                 if (!(!P.direct || depth == 1 || specularBounce)) misWeight = power_heuristic(brdf_scattering_pdf, light_pdf_direct(light, r_d, last_nor, b.dg.n, t) * pdf_emitter(S, li2));
                 cl = cl + misWeight * cf * light_eval(S, light, b.dg.P, b.dg.sys.n, -r_d);
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, CTL_MEGA_WAVES) void k_path_trace(dev_scene S,
                 float lpdf; const int li2 = sample_emitter(S, lpdf, sl.x);
                 if (li2 >= 0) {
                     direct_rec dr; dr.ref = b.dg.P; dr.refN = b.dg.sys.n;
-                    const f3 value = light_sample_direct(S, S.lights[li2], dr, rng.next2());
+                    const f3 value = light_sample_direct(S, scene_lights(S)[li2], dr, rng.next2());
                     if (!is_zero(value)) {
                         bsdf_rec b2 = b; b2.wo = b.dg.sys.to_local(dr.d); b2.type_mask = kEAll & ~kEDelta;
                         const f3 bsdfVal = bsdf_f_top(mat, b2);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, CTL_MEGA_WAVES) void k_path_trace(dev_scene S,
             }
         }
         if (!had_hit && S.env_map_index != 0xffffffffu) {   // PathTracer.cu:99-111
-            const ctl_light& light = S.lights[S.env_map_index];
+            const ctl_light& light = scene_lights(S)[S.env_map_index];
             float misWeight = 1.0f;
             if (!(!P.direct || depth == 1 || specularBounce)) misWeight = power_heuristic(brdf_scattering_pdf, env_pdf_direct(S, light, r_d) * pdf_emitter(S, S.env_map_index));
             cl = cl + misWeight * cf * env_eval(S, light, r_d);
@@ -154,7 +154,7 @@ __device__ f3 estimate_direct_all(const dev_scene& S, const ctl_material& mat, c
     f3 L(0.0f);
     for (uint32_t i = 0; i < S.num_lights; i++) {
         direct_rec dr; dr.ref = b.dg.P; dr.refN = b.dg.sys.n;
-        const f3 value = light_sample_direct(S, S.lights[S.light_indices[i]], dr, rng.next2());
+        const f3 value = light_sample_direct(S, scene_lights(S)[S.light_indices[i]], dr, rng.next2());
         if (is_zero(value)) continue;
         bsdf_rec b2 = b; b2.wo = b.dg.sys.to_local(dr.d); b2.type_mask = kEAll & ~kEDelta;
         const f3 bsdfVal = bsdf_f_top(mat, b2);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_path_trace_regularization(dev_scene S, 
             if (mat.two_sided && b.wi.z < 0) { b.dg.n = -b.dg.n; b.dg.sys.n = -b.dg.sys.n; b.wi.z *= -1.0f; }
             if (depth == 1) compute_partials(b.dg, r_ox, r_dx, r_oy, r_dy);
             const uint32_t nli = mat.node_light_index;
-            if (nli != 0xffffffffu && (!P.direct || depth == 1 || specularBounce)) cl = cl + cf * light_eval(S, S.lights[nli == 0 ? ninfo.y : ninfo.z], b.dg.P, b.dg.sys.n, -r_d);
+            if (nli != 0xffffffffu && (!P.direct || depth == 1 || specularBounce)) cl = cl + cf * light_eval(S, scene_lights(S)[nli == 0 ? ninfo.y : ninfo.z], b.dg.P, b.dg.sys.n, -r_d);
             float pdf_unused;
             const f3 f = bsdf_sample_top(mat, b, pdf_unused, rng.next2());
             if (P.direct) {
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_path_trace_regularization(dev_scene S, 
                         uint32_t slot = 0; while (slot < S.num_lights && S.light_indices[slot] != (uint32_t)li2) slot++;   // sampleEmitter rescales the sample it consumed (KernelDynamicScene.cu:25-40)
                         const float fU = S.light_cdf[slot], fL = slot > 0 ? S.light_cdf[slot - 1] : 0.0f;
                         sample.x = (sample.x - fL) / (fU - fL);
-                        const ctl_light& l = S.lights[li2];
+                        const ctl_light& l = scene_lights(S)[li2];
                         f3 lp; const f3 l_s = sdiv(light_sample_position(l, sample, lp), emPdf);
                         const float lDist = length(lp - b.dg.P);
                         const f3 lDir = (lp - b.dg.P) / lDist;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_path_trace_regularization(dev_scene S, 
             had_hit = false;
         }
         if (S.env_map_index != 0xffffffffu) {   // PathTracer.cu:168-171, as written: the last ray's environment radiance is added whether it escaped or not
-            const ctl_light& env = S.lights[S.env_map_index];
+            const ctl_light& env = scene_lights(S)[S.env_map_index];
             if (!had_hit && depth == 0) cl = cf * env_eval_differential(S, env, r_d, r_dx, r_dy);
             else cl = cl + cf * env_eval(S, env, r_d);
         }

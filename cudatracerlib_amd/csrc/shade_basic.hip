@@ -21,4 +21,7 @@
 #define CTL_SHADE_SORT_WINDOW CTL_BASIC_SORT_WINDOW
 #define CTL_SHADE_KERNEL k_shade_basic
 #define CTL_SHADE_LAUNCH launch_shade_basic
+#ifndef CTL_SHADE_LDS_TABLES
+#define CTL_SHADE_LDS_TABLES 12   // KB of LDS for the emitter records + anim blob (shading.h scene_lights / scene_anim; + 4 KB for the normal table): synthetic-SM shade 1.447 -> 1.356 ms per pass
+#endif
 #include "shade_kernel.inc"

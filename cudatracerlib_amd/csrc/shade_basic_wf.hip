@@ -19,4 +19,7 @@
 #define CTL_SHADE_SORT_WINDOW CTL_BASIC_SORT_WINDOW
 #define CTL_SHADE_KERNEL k_shade_basic_wf
 #define CTL_SHADE_LAUNCH launch_shade_basic_wf
+#ifndef CTL_SHADE_LDS_TABLES
+#define CTL_SHADE_LDS_TABLES 12   // as shade_basic.hip
+#endif
 #include "shade_kernel.inc"

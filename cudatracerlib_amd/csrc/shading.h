@@ -139,13 +139,43 @@ struct diff_geom {
     bool has_uv_partials; float dudx, dudy, dvdx, dvdy; const dev_mip_levels* mip_levels; const float* mip_weight_lut;
 #endif
 };   // images: g_SceneData.m_sTexData; tables of RoughTransmittanceManager (both uniform)
+// The scene's small tables — emitter records, the anim blob (area lights' triangle CDFs and shape triangles, the environment map's row weights), the normal codec's sin / cos
+// table — are read through these.  A shade kernel built with CTL_SHADE_LDS_TABLES = K keeps them in LDS when records + blob fit K KB (staged once per workgroup by
+// scene_tables_to_lds at kernel start); next-event estimation walks them one after the other (sampled emitter -> its record -> its CDF -> the chosen triangle), each step a
+// dependent load.  The struct itself is never copied: a private copy of dev_scene, whose light_cdf / light_indices are indexed per lane, would live in scratch.
+#ifndef CTL_SHADE_LDS_TABLES
+#define CTL_SHADE_LDS_TABLES 0
+#endif
+#if CTL_SHADE_LDS_TABLES
+constexpr uint32_t kLdsTabBytes = CTL_SHADE_LDS_TABLES * 1024u;
+__device__ __forceinline__ unsigned char* scene_lds_tab() { __shared__ __attribute__((aligned(16))) unsigned char tab[kLdsTabBytes + 4096u]; return tab; }
+__device__ __forceinline__ uint32_t scene_lds_light_bytes(const dev_scene& S) { return (S.n_lights_buf * (uint32_t)sizeof(ctl_light) + 15u) & ~15u; }
+__device__ __forceinline__ bool scene_lds_fits(const dev_scene& S) { return scene_lds_light_bytes(S) + ((S.n_anim_bytes + 15u) & ~15u) <= kLdsTabBytes; }
+__device__ __forceinline__ const ctl_light* scene_lights(const dev_scene& S) { return scene_lds_fits(S) ? (const ctl_light*)scene_lds_tab() : S.lights; }
+__device__ __forceinline__ const unsigned char* scene_anim(const dev_scene& S) { return scene_lds_fits(S) ? scene_lds_tab() + scene_lds_light_bytes(S) : S.anim; }
+__device__ __forceinline__ const float2* scene_normal_lut(const dev_scene&) { return (const float2*)(scene_lds_tab() + kLdsTabBytes); }
+template <uint32_t BLOCK> __device__ __forceinline__ void scene_tables_to_lds(const dev_scene& S) {
+    unsigned char* tab = scene_lds_tab();
+    for (uint32_t k = threadIdx.x; k < 4096u / 16u; k += BLOCK) ((uint4*)(tab + kLdsTabBytes))[k] = ((const uint4*)S.normal_lut)[k];
+    if (scene_lds_fits(S)) {
+        const uint32_t lw = S.n_lights_buf * (uint32_t)(sizeof(ctl_light) / 4u), lb = scene_lds_light_bytes(S), aw = (S.n_anim_bytes + 3u) / 4u;   // (device allocations are padded: the blob's last word may reach 3 bytes past it)
+        for (uint32_t k = threadIdx.x; k < lw; k += BLOCK) ((uint32_t*)tab)[k] = ((const uint32_t*)S.lights)[k];
+        for (uint32_t k = threadIdx.x; k < aw; k += BLOCK) ((uint32_t*)(tab + lb))[k] = ((const uint32_t*)S.anim)[k];
+    }
+    __syncthreads();
+}
+#else
+__device__ __forceinline__ const ctl_light* scene_lights(const dev_scene& S) { return S.lights; }
+__device__ __forceinline__ const unsigned char* scene_anim(const dev_scene& S) { return S.anim; }
+__device__ __forceinline__ const float2* scene_normal_lut(const dev_scene& S) { return S.normal_lut; }
+#endif
 __device__ __forceinline__ void fill_dg(const dev_scene& S, float u, float v, int tri, int node, diff_geom& dg) {
     const uint4 ta = S.tri_data[tri * 2], tb = S.tri_data[tri * 2 + 1];   // {nme.x, nme.y, dpd.x, dpd.y} {dpd.z, uv0, uv1, uv2}
     dg.images = S.images; dg.rough_transmittance = S.rough_transmittance; dg.mats = S.mats; dg.rt_reduced = S.rt_reduced;
     const float4 f0 = S.inst_fwd[node * 3], f1 = S.inst_fwd[node * 3 + 1], f2_ = S.inst_fwd[node * 3 + 2];
     m34 l2w; l2w.r[0][0] = f0.x; l2w.r[0][1] = f0.y; l2w.r[0][2] = f0.z; l2w.r[0][3] = f0.w; l2w.r[1][0] = f1.x; l2w.r[1][1] = f1.y; l2w.r[1][2] = f1.z; l2w.r[1][3] = f1.w;
     l2w.r[2][0] = f2_.x; l2w.r[2][1] = f2_.y; l2w.r[2][2] = f2_.z; l2w.r[2][3] = f2_.w;
-    const f3 na = uchar2_to_normal_lut(ta.x & 0xffff, S.normal_lut), nb = uchar2_to_normal_lut(ta.x >> 16, S.normal_lut), nc = uchar2_to_normal_lut(ta.y & 0xffff, S.normal_lut);   // = uchar2_to_normal, from the scene's 4-KB table
+    const f3 na = uchar2_to_normal_lut(ta.x & 0xffff, scene_normal_lut(S)), nb = uchar2_to_normal_lut(ta.x >> 16, scene_normal_lut(S)), nc = uchar2_to_normal_lut(ta.y & 0xffff, scene_normal_lut(S));   // = uchar2_to_normal, from the scene's 4-KB table
     const float w = 1.0f - u - v;
     const f3 n = normalize(u * na + v * nb + w * nc);
     const f3 dpdu(half_to_float((uint16_t)ta.z), half_to_float((uint16_t)(ta.z >> 16)), half_to_float((uint16_t)ta.w));
@@ -628,7 +658,7 @@ __device__ __forceinline__ float interval_to_tent(float sample) {   // Math/Warp
 // InfiniteLight::internalSampleDirection (SceneTypes/Light.cu:420-463)
 __device__ void env_sample_direction(const dev_scene& S, const ctl_light& L, f2 sample, f3& d, f3& value, float& pdf) {
     const ctl_mipmap& map = S.images[L.env_image];
-    const float* cdfRows = (const float*)(S.anim + L.cdf_rows_index), *cdfCols = (const float*)(S.anim + L.cdf_cols_index), *rowWeights = (const float*)(S.anim + L.row_weights_index);
+    const float* cdfRows = (const float*)(scene_anim(S) + L.cdf_rows_index), *cdfCols = (const float*)(scene_anim(S) + L.cdf_cols_index), *rowWeights = (const float*)(scene_anim(S) + L.row_weights_index);
     const float sizeX = (float)map.width, sizeY = (float)map.height;
     float qpdf;
     const uint32_t row = sample_reuse(cdfRows, (uint32_t)sizeY, sample.y, qpdf);
@@ -653,7 +683,7 @@ __device__ __forceinline__ f3 xform_dir_transpose(const float* m, f3 d) {   // O
 // InfiniteLight::internalPdfDirection (SceneTypes/Light.cu:465-486)
 __device__ float env_pdf_direction(const dev_scene& S, const ctl_light& L, f3 d) {
     const ctl_mipmap& map = S.images[L.env_image];
-    const float* rowWeights = (const float*)(S.anim + L.row_weights_index);
+    const float* rowWeights = (const float*)(scene_anim(S) + L.row_weights_index);
     const float sizeX = (float)map.width, sizeY = (float)map.height;
     const f2 uv{ m_atan2(d.x, -d.z) * kInvTwoPi, m_acos(fminf(1.0f, fmaxf(-1.0f, d.y))) * kInvPi };
     const float u = uv.x * sizeX - 0.5f, v = uv.y * sizeY - 0.5f;
@@ -693,7 +723,7 @@ __device__ __forceinline__ bool barycentric(f3 p, f3 a, f3 b, f3 c, float& u, fl
     return 0 <= v && v <= 1 && 0 <= u && u <= 1 && 0 <= w && w <= 1;
 }
 __device__ CTL_LIGHT_OUTLINE f2 shape_get_position_uv(const dev_scene& S, const ctl_light& L, f3 pos) {   // ShapeSet::getPosition: first triangle of the set that holds the point
-    const ctl_shape_tri* tris = (const ctl_shape_tri*)(S.anim + L.triangles_index);
+    const ctl_shape_tri* tris = (const ctl_shape_tri*)(scene_anim(S) + L.triangles_index);
     for (uint32_t i = 0; i < L.count; i++) {
         const ctl_shape_tri& sn = tris[i]; f2 b;
         if (barycentric(pos, f3(sn.p[0][0], sn.p[0][1], sn.p[0][2]), f3(sn.p[1][0], sn.p[1][1], sn.p[1][2]), f3(sn.p[2][0], sn.p[2][1], sn.p[2][2]), b.x, b.y)) return shape_tri_uv(S, sn, b);
@@ -751,8 +781,8 @@ __device__ CTL_LIGHT_MAYBE f3 light_sample_direct(const dev_scene& S, const ctl_
         return sdiv(value, pdf);
     }
 #endif
-    const float* cdf = (const float*)(S.anim + L.area_dist_index);
-    const ctl_shape_tri* tris = (const ctl_shape_tri*)(S.anim + L.triangles_index);
+    const float* cdf = (const float*)(scene_anim(S) + L.area_dist_index);
+    const ctl_shape_tri* tris = (const ctl_shape_tri*)(scene_anim(S) + L.triangles_index);
     float pdfTri, sc = 1;
 #if CTL_SHADE_FEATURES & 8
     f2 uv{ 0.0f, 0.0f };
@@ -819,26 +849,29 @@ __device__ __forceinline__ f3 light_eval(const dev_scene& S, const ctl_light& L,
 #endif
     return f3(L.radiance[0], L.radiance[1], L.radiance[2]);
 }
-// KernelDynamicScene::sampleEmitter / pdfEmitter (Engine/KernelDynamicScene.cu:25-46)
+// KernelDynamicScene::sampleEmitter / pdfEmitter (Engine/KernelDynamicScene.cu:25-46).  (Walking all num_lights entries with a uniform index — scalar loads from the
+// argument segment instead of a per-lane dependent walk — measured no gain: 1.447 against 1.437 ms per pass, profiles/r05_shade_experiments.log.)
+struct emitter_choice { uint32_t light; float fL, fU; };
+__device__ __forceinline__ emitter_choice choose_emitter(const dev_scene& S, float sx) {
+    const uint32_t n = S.num_lights;
+    uint32_t idx = 0;
+    while (idx < n && !(sx < S.light_cdf[idx])) idx++;   // upper_bound
+    if (idx >= n) idx = n - 1;
+    return emitter_choice{ S.light_indices[idx], idx > 0 ? S.light_cdf[idx - 1] : 0.0f, S.light_cdf[idx] };
+}
 __device__ __forceinline__ int sample_emitter(const dev_scene& S, float& emPdf, float sx) {
     if (S.num_lights == 0) return -1;
-    uint32_t idx = 0;
-    while (idx < S.num_lights && !(sx < S.light_cdf[idx])) idx++;   // upper_bound
-    if (idx >= S.num_lights) idx = S.num_lights - 1;
-    const float fU = S.light_cdf[idx], fL = idx > 0 ? S.light_cdf[idx - 1] : 0.0f;
-    emPdf = fU - fL;
-    return (int)S.light_indices[idx];
+    const emitter_choice c = choose_emitter(S, sx);
+    emPdf = c.fU - c.fL;
+    return (int)c.light;
 }
 // the same choice, re-using the sample: sample.x = (sample.x - fL) / (fU - fL) (KernelDynamicScene.cu:36) — what sampleEmitterDirect hands on to the light
 __device__ __forceinline__ int sample_emitter_reuse(const dev_scene& S, float& emPdf, float& sx) {
     if (S.num_lights == 0) return -1;
-    uint32_t idx = 0;
-    while (idx < S.num_lights && !(sx < S.light_cdf[idx])) idx++;
-    if (idx >= S.num_lights) idx = S.num_lights - 1;
-    const float fU = S.light_cdf[idx], fL = idx > 0 ? S.light_cdf[idx - 1] : 0.0f;
-    sx = (sx - fL) / (fU - fL);
-    emPdf = fU - fL;
-    return (int)S.light_indices[idx];
+    const emitter_choice c = choose_emitter(S, sx);
+    sx = (sx - c.fL) / (c.fU - c.fL);
+    emPdf = c.fU - c.fL;
+    return (int)c.light;
 }
 __device__ __forceinline__ float pdf_emitter(const dev_scene& S, uint32_t light) { return S.light_cdf[light] - (light == 0 ? 0.0f : S.light_cdf[light - 1]); }
 

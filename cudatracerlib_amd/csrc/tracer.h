@@ -203,13 +203,14 @@ public:
     WavefrontPathTracer();
     void Resize(unsigned int w, unsigned int h) override;
     void setDepthBuffer(float* device_data, unsigned int dw, unsigned int dh) override { depth_buffer_ = device_data; depth_w_ = dw; depth_h_ = dh; }   // WavefrontPathTracer : IDepthTracer (WavefrontPathTracer.h:24)
-    void reservePasses(unsigned int n) override { const unsigned int b = std::min(passBatch(), std::max(1u, n)); growBatch(b, "reservePasses"); ensureTableRing(b); }
+    void reservePasses(unsigned int n) override { const unsigned int b = std::min(passBatch(), std::max(1u, n)); growBatch(b, "reservePasses"); ensureTableRing(b); if (w != 0xffffffffu) (void)ensureStage(b); }
 protected:
     void DoRender(Image* I, const float* d_t1, const float* d_t2, unsigned int n_batch) override;
     void takeRayCounts(uint64_t& path_rays, uint64_t& shadow_rays_) override;
     unsigned int passBatch() const override;
 private:
-    void growBatch(unsigned int b, const char* who);   // queues for b passes per wavefront; validated before anything changes
+    void growBatch(unsigned int b, const char* who);
+    float4* ensureStage(unsigned int b);   // queues for b passes per wavefront; validated before anything changes
     wave_queues Q{};
     uint32_t capacity = 0, n_local_pixels = 0, alloc_batch_ = 1;
     float* depth_buffer_ = nullptr; unsigned int depth_w_ = 0, depth_h_ = 0;

@@ -338,7 +338,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
     }
     CTL_HIP(hipDeviceSynchronize());
     S.top_nodes = top_nodes_.p; S.bot_nodes = bot_nodes_.p; S.leaf_tris = leaf_tris_.p; S.inst = inst_.p; S.inst_fwd = inst_fwd_.p; S.normal_lut = normal_lut_.p;
-    S.tri_data = tri_data_.p; S.node_info = node_info_.p; S.mats = mats_.p; S.lights = lights_.p; S.anim = anim_.p;
+    S.tri_data = tri_data_.p; S.node_info = node_info_.p; S.mats = mats_.p; S.lights = lights_.p; S.anim = anim_.p; S.n_lights_buf = d.n_lights_buf; S.n_anim_bytes = (uint32_t)d.n_anim_bytes; S.n_materials_probe = std::max(1u, d.n_materials);
     S.start_node = d.scene_start_node; S.n_nodes = d.n_nodes; S.num_lights = d.num_lights; S.env_map_index = d.env_map_index; S.eps = d.ray_trace_eps;
     for (int i = 0; i < CTL_MAX_NUM_LIGHTS; i++) { S.light_indices[i] = d.light_indices[i]; S.light_cdf[i] = d.light_cdf[i]; }
     // PerspectiveSensor / ThinLensSensor / OrthographicSensor / TelecentricSensor ::Update (SceneTypes/Sensor.cu:76-96, :226-246, :408-427, :515-535)
@@ -615,6 +615,18 @@ static void check_batch(uint64_t n_local, unsigned int batch, const char* who) {
     if (n_local * std::max(1u, batch) >= (1ull << 31) || batch > 255u)
         throw std::runtime_error(std::string("WavefrontPathTracer::") + who + ": " + std::to_string(n_local) + " pixels x " + std::to_string(batch) + " passes per wavefront exceed the 2^31 ray slots (or 255 passes) of a batch: lower PassBatch");
 }
+// the stage of the ordered accumulation for a batch of b passes, or nullptr (parameter off, over OrderedAccumulationMaxMB, allocation failed).  Also called by reservePasses:
+// the allocation (663 MB for 20 passes of a 1080p frame) then happens before the render, not inside its first call.
+float4* WavefrontPathTracer::ensureStage(unsigned int b) {
+    if (m_sParameters.getValue("OrderedAccumulation") == 0 || n_local_pixels == 0) return nullptr;
+    const size_t need = (size_t)n_local_pixels * b;
+    if (need * sizeof(float4) > (size_t)m_sParameters.getValue("OrderedAccumulationMaxMB") << 20) return nullptr;
+    if (stage_.n < need) {
+        try { stage_.alloc(need); CTL_HIP(hipMemsetAsync(stage_.p, 0, need * sizeof(float4), stream)); }
+        catch (const std::exception&) { stage_.free(); (void)hipGetLastError(); }
+    }
+    return stage_.n >= need ? stage_.p : nullptr;
+}
 void WavefrontPathTracer::growBatch(unsigned int b, const char* who) {
     if (w == 0xffffffffu || (uint64_t)n_local_pixels * b <= capacity) return;
     check_batch(n_local_pixels, b, who);
@@ -697,16 +709,7 @@ void WavefrontPathTracer::DoRender(Image* I, const float* d_t1p, const float* d_
     // of eight).  It is an optimisation, not a requirement: past OrderedAccumulationMaxMB (default 4096) or when the allocation fails the paths fall back to Image::AddSample's
     // four float atomics — same sums, hardware order.
     P.stage = nullptr; P.stage_stride = (size_t)n_local_pixels;
-    if (m_sParameters.getValue("OrderedAccumulation") != 0 && !pass_block_counts_ && n_local_pixels != 0) {
-        const size_t need = P.stage_stride * n_batch;
-        if (need * sizeof(float4) <= (size_t)m_sParameters.getValue("OrderedAccumulationMaxMB") << 20) {
-            if (stage_.n < need) {
-                try { stage_.alloc(need); CTL_HIP(hipMemsetAsync(stage_.p, 0, need * sizeof(float4), stream)); }
-                catch (const std::exception&) { stage_.free(); (void)hipGetLastError(); }
-            }
-            if (stage_.n >= need) P.stage = stage_.p;
-        }
-    }
+    if (!pass_block_counts_) P.stage = ensureStage(n_batch);
     if (pass_block_counts_ && pass_paths_ > capacity) throw std::runtime_error("ray queue overflow: the block sampler asks for more samples in one pass than the queues hold (DoubleRayBuffer.h:86-89)");
     CTL_HIP(hipMemsetAsync(mat_counts_.p, 0, n_mat * sizeof(uint32_t), stream));
     CTL_HIP(hipMemsetAsync(counts_.p, 0, n_counts * sizeof(uint32_t), stream));

@@ -158,6 +158,7 @@ __device__ __forceinline__ void node_fetch_own(const float4* __restrict__ nodes,
     if (!compact || (node & 1)) W.q3 = p[3];
 }
 
+template <bool ORDERED = true>
 __device__ __forceinline__ int node_step_q4(const node_words& W, int node, const ray_cull& R, float ox, float oy, float oz, float dx, float dy, float dz,
                                             float tmin, float ht, int c[4], float dd[4], bool compact) {
     const float4 q0 = W.q0, q1 = W.q1, q2 = W.q2;
@@ -200,6 +201,14 @@ __device__ __forceinline__ int node_step_q4(const node_words& W, int node, const
         const float cmin = max3_raw(max3_raw(tnx, tny, tnz), tns, tmin);
         const float cmax = min3_raw(min3_raw(tfx, tfy, tfz), tfs, ht);
         dd[k] = (cmax >= cmin) ? cmin : inf;   // no "child exists" test: a missing child's box is inverted (flatten.cpp) and is never entered
+    }
+    if (!ORDERED) {
+        // any-hit traversal (round 5, profiles/r05_traversal_probes.log): the entered children in SLOT order, no ordering network — 6 selects instead of 5 compare-and-swaps
+        const bool e0 = dd[0] < inf, e1 = dd[1] < inf, e2 = dd[2] < inf, e3 = dd[3] < inf;
+        const int f23 = e2 ? c[2] : c[3], f123 = e1 ? c[1] : f23;
+        const int o0 = e0 ? c[0] : f123, o1 = e0 ? f123 : (e1 ? f23 : c[3]), o2 = (e0 && e1) ? f23 : c[3];
+        c[0] = o0; c[1] = o1; c[2] = o2;
+        return (int)e0 + (int)e1 + (int)e2 + (int)e3;
     }
     CTL_CSWAP_PAIR(0, 1) CTL_CSWAP_PAIR(2, 3) CTL_CSWAP_PAIR(0, 2) CTL_CSWAP_PAIR(1, 3) CTL_CSWAP_PAIR(1, 2)
     return dd[3] < inf ? 4 : (dd[2] < inf ? 3 : (dd[1] < inf ? 2 : (dd[0] < inf ? 1 : 0)));
@@ -293,7 +302,12 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
                 node_words W; node_fetch_own(nodes, node, compact, W);
                 const int popped = st.get(sp);   // issued early: used when no child is entered
                 int c[4]; float dd[4];
-                const int n_hit = node_step_q4(W, node, R, ox, oy, oz, dx, dy, dz, tmin, ht, c, dd, compact);
+#ifdef CTL_ANYHIT_ORDERED   // measurement builds: the any-hit traversal with the closest-hit one's ordering network (the A side of profiles/r05_traversal_probes.log)
+                const int n_hit = node_step_q4<true>(W, node, R, ox, oy, oz, dx, dy, dz, tmin, ht, c, dd, compact);
+#else
+                // shadow rays take the entered children in SLOT order: any hit ends the ray, the nearest-first order buys nothing (it visited 8 % MORE nodes) and costs 5 compare-and-swaps
+                const int n_hit = node_step_q4<!ANY_HIT>(W, node, R, ox, oy, oz, dx, dy, dz, tmin, ht, c, dd, compact);
+#endif
                 node = n_hit ? c[0] : popped;
                 const int top = sp + n_hit - 1;    // n_hit == 0: one entry popped
                 if (top < kFlatLdsRows) {          // common case: unconditional LDS stores, unused ones into the spare row
