@@ -30,7 +30,7 @@ constexpr int kFlatLdsRows = 19;          // stack entries per lane in LDS (+ 1 
 constexpr int kFlatStackInts = 1;
 constexpr int kTopCache = 0, kTopCacheFloats = 12;   // (experiment builds keep the top of the tree in LDS)
 __device__ unsigned long long g_stack_hist[kStackSize];   // counting kernels only: rays by the deepest traversal-stack entry they used (ctl_traversal_stack_histogram)
-__device__ int g_leaf_batch = 16;         // run the leaf phase once this many lanes hold a pending leaf entry (knob CTL_LEAF_BATCH): 8: 2253, 12: 2299, 16: 2315, 20: 2311, 24: 2288, 32: 2216 Mrays/s (profiles/r03_threshold_ab.log)
+__device__ int g_leaf_batch = 20;         // run the leaf phase once this many lanes hold a pending leaf entry (knob CTL_LEAF_BATCH; round 5, on the re-optimised tree: synthetic-SM 12: 3118, 16: 3137, 20: 3143, 24: 3123, 32: 3072 Mrays/s; synthetic-sm-hard 4232 / 4275 / 4382 / 4384 / 4311 — one value serves both, no per-scene choice needed; earlier trees: 8: 2253, 12: 2299, 16: 2315, 20: 2311, 24: 2288, 32: 2216 Mrays/s (profiles/r03_threshold_ab.log)
 
 typedef __attribute__((address_space(3))) int flat_stack_lds_word;   // explicitly LDS: the pushes must compile to ds_write, not to generic flat stores
 struct flat_stack {

@@ -91,16 +91,17 @@ def main():
                "synthetic-SM via loader": brief(bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--via-loader"])),
                "synthetic-sm-hard": brief(bench(["--steps", "20", "--warmup", "5", "--workload", "synthetic-sm-hard"])),
                "synthetic-sm-hard AlphaTest": brief(bench(["--steps", "20", "--warmup", "5", "--workload", "synthetic-sm-hard", "--no-cpu-baseline", "--tracer-param", "AlphaTest=true"]))}
-    R["C5"] = {"synthetic-bathroom": brief(bench(["--steps", "20", "--warmup", "5", "--workload", "synthetic-bathroom"]))}
+    R["C5"] = {"synthetic-bathroom": brief(bench(["--steps", "20", "--warmup", "5", "--workload", "synthetic-bathroom"])),
+               "synthetic-bathroom 128 spp (config 5's own step count)": brief(bench(["--steps", "128", "--warmup", "5", "--workload", "synthetic-bathroom", "--no-cpu-baseline"]))}
     R["C4"] = {"status": "no multi-GPU node was available to this round's gpurun calls (1-GPU boxes): not measured on hardware",
                "fields_bench_writes": ["value", "rank_ms[]", "reduce_ms", "reduce_ms_per_rank[]", "slowest_rank", "rays_per_rank[]", "config.framebuffer_reduce"],
-               "emulated_on_one_gpu": "tools/shard_time_probe.py (one rank of N rendering its tile shard): DESIGN.md section 7"}
+               "emulated_on_one_gpu": "tools/shard_time_probe.py (one rank of N rendering its tile shard at 20 / 64 / 256 passes) and the 8-process rehearsal on one device (CTL_BENCH_SHARE_GPU=1 bench.py --gpus 8: the gathered frame equals the one-rank frame): DESIGN.md section 7, profiles/r05x_shard_time_probe.txt, profiles/r05x_bench_8ranks_shared_gpu.json, profiles/r05x_frames_8_vs_1.txt"}
     json.dump(R, open(os.path.join(out_dir, "results.json"), "w"), indent=1)
     print(json.dumps(R)[:3000])
 
 
 def render(R):
-    L = ["# RESULTS — round 4 (`profiles/results_%s.json`, written by `tools/results_round.py` on one MI355X box)" % R["tag"], "",
+    L = ["# RESULTS — round %s (`profiles/results_%s.json`, written by `tools/results_round.py` on one MI355X box)" % (R["tag"][1:3].lstrip("0"), R["tag"]), "",
          "Per-config records of BASELINE.md §2.  Every GPU number is a 1-GPU run of this tree's `bench.py` / tracer; every CPU number is the oracle (kind `port`) on the box's host CPUs (%s visible; the container's cgroup quota is in each `cpu` record)." % R["host_cpus"], ""]
     for key in ("C1", "C2"):
         c = R[key]; im = c["image"]

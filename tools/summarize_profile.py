@@ -126,9 +126,20 @@ def main():
         # the shade kernel of the same run (bench.py roofline_shade): per shaded path vertex = per ray of the closest-hit traversal
         sk = [q for q in rows if q.startswith("k_shade")]
         if sk:
-            q = max(sk, key=lambda q: rows[q].get("duration_ms", 0.0)); rs = rows[q]
-            # every closest-hit ray is one shaded vertex (or a miss that the shade kernel also handles); the profiled command shades the warm-up passes, the timed passes AND bench.py's counting batch
-            verts = rf["closest_rays_total"] * (b["steps"] + b["warmup"] + rf.get("counting_passes", 0)) / b["steps"] if rf.get("closest_rays_total") else None
+            cls = [q for q in sk if q.startswith("k_shade_class")]
+            if cls:
+                # full feature set: the product shades by model class (one launch per class and depth); bench.py's counting batch runs k_shade_full instead (no traversal keys while
+                # counting) and is left out.  The class launches together ARE the shade stage: their counters and durations are summed, per vertex of the warm-up + timed passes.
+                rs = {}
+                for q2 in cls:
+                    for k2, v2 in rows[q2].items():
+                        if isinstance(v2, (int, float)): rs[k2] = rs.get(k2, 0.0) + v2
+                q = "k_shade_class_* (" + " + ".join(sorted(c.replace("k_shade_class_", "") for c in cls)) + ")"
+                verts = rf["closest_rays_total"] * (b["steps"] + b["warmup"]) / b["steps"] if rf.get("closest_rays_total") else None
+            else:
+                q = max(sk, key=lambda q: rows[q].get("duration_ms", 0.0)); rs = rows[q]
+                # every closest-hit ray is one shaded vertex (or a miss that the shade kernel also handles); the profiled command shades the warm-up passes, the timed passes AND bench.py's counting batch
+                verts = rf["closest_rays_total"] * (b["steps"] + b["warmup"] + rf.get("counting_passes", 0)) / b["steps"] if rf.get("closest_rays_total") else None
             sh_hbm, sh_issue, sh_l1, sh_src, _ = fractions(rs)
             sl = rs.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * rs["SQ_INSTS_VALU"]) if rs.get("SQ_INSTS_VALU") else None
             entry["shade"] = {"kernel": q, "launches": rs.get("launches"), "duration_ms": rs.get("duration_ms"), "vertices_profiled": verts,
