@@ -550,7 +550,7 @@ def main():
             "config": {"workload": "synthetic-SM %dx%d, 1 spp/step, depth %d, NEE on, %d instances x icosphere(%d)/boxes, %d instanced triangles"
                        % (args.width, args.height, args.depth, args.instances, args.subdiv, int(_instanced_tris(desc))) if args.workload == "synthetic-sm" else
                        ("%s %dx%d depth %d, %d instanced triangles" % (args.workload, args.width, args.height, args.depth, int(_instanced_tris(desc)))),
-                       "bvh": "flattened world-space BVH4 (64 B nodes with 8-bit quantised child boxes; 128 B leaf entries evaluated with the reference's object-space arithmetic; triangles much longer than their neighbours entered as several references)" if args.flatten else "two-level (scene BVH + instanced mesh BVHs)",
+                       "bvh": "flattened world-space BVH4 (64 B nodes with 8-bit quantised child boxes; 128 B leaf entries evaluated with the reference's object-space arithmetic; triangles much longer than their neighbours entered as several references; BVH2 re-optimised by reinsertion before the collapse)" if args.flatten else "two-level (scene BVH + instanced mesh BVHs)",
                        "scene_source": scene_source,
                        "parallelism": "image tiles 64x64 round-robin over %d GPU(s), 1 gather of the framebuffer per render" % world, "framebuffer_reduce": reduce_kind,
                        "rays_per_step": int(rays / args.steps), "scene_build_s": round(t_build, 2)},

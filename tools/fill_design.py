@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""Fill the @TOKEN@ placeholders of DESIGN.new.md from the round's final GPU run (gpurun_out/<tag>/ + profiles/<tag>_*): python tools/fill_design.py r05x > DESIGN.md"""
+"""Fill the @TOKEN@ placeholders of tools/design_template.md from the round's final GPU run (gpurun_out/<tag>/ + profiles/<tag>_*): python tools/fill_design.py r05x > DESIGN.md"""
 import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1]
+tag = sys.argv[1]                                   # profile tag (profiles/<tag>_pmc_summary.csv, plugin compare, shard probe)
 G = os.path.join(ROOT, "gpurun_out", tag)
+G2 = os.path.join(ROOT, "gpurun_out", sys.argv[2]) if len(sys.argv) > 2 else G    # bench lines that quote the committed profile, where they exist
 
 
 def line(name):
-    return json.loads(open(os.path.join(G, name)).read().strip().splitlines()[-1])
+    p = os.path.join(G2, name)
+    return json.loads(open(p if os.path.exists(p) else os.path.join(G, name)).read().strip().splitlines()[-1])
 
 
 def brief(j):
@@ -51,7 +53,7 @@ for l in open(os.path.join(G, "shard_time_probe.txt")):
 for p in ("20", "64", "256"):
     one, eight = float(T["S%s_1" % p]), float(T["S%s_8" % p])
     T["S%s_X" % p] = "%.2f" % (one / eight); T["S%s_XG" % p] = "%.2f" % (one / (eight + 0.3))
-s = open(os.path.join(ROOT, "DESIGN.new.md")).read()
+s = open(os.path.join(ROOT, "tools", "design_template.md")).read()
 missing = sorted(set(re.findall(r"@([A-Z0-9_]+)@", s)) - set(T))
 if missing: print("missing tokens:", missing, file=sys.stderr)
 print(re.sub(r"@([A-Z0-9_]+)@", lambda m: T.get(m.group(1), m.group(0)), s), end="")
