@@ -1,10 +1,10 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see omath.h header).
 // obsdf3.h — roughdiffuse, ward, roughplastic (SceneTypes/BSDF_Simple.cu) with the rough-transmittance tables
 // (Engine/RoughTransmittance.cu) and the cubic spline interpolation they use (Math/Spline.cu).  Included by ocore.h after
-// BRec / Microfacet / texEval are defined.  Pinned on the reference's own code: the BSDF functions against BSDF_Simple.cu (tests/golden/bsdf.npz), the spline against
-// Math/Spline.cu (tests/golden/spline.npz, both compiled by `make -C oracle ref`).  UNPINNED: the 20-line warp of RoughTransmittance::Evaluate / EvaluateDiffuse
-// (RoughTransmittance.cu:55-119 — the file's host half needs the .dat tables and FileStream plumbing; restated below by reading) and the tables themselves —
-// Mitsuba's data/microfacet/*.dat are not part of the reference tree; cudatracerlib_amd/rough_tables.py re-derives them.
+// BRec / Microfacet / texEval are defined.  Pinned on the reference's own code, bit for bit: roughdiffuse / ward against BSDF_Simple.cu (tests/golden/bsdf.npz); the spline against
+// Math/Spline.cu (spline.npz); the table lookups against RoughTransmittance::Evaluate / EvaluateDiffuse + the manager's lookup by type, and roughplastic's sample / f / pdf against
+// BSDF_Simple.cu:890-1057 run through them (bsdf_rough.npz) — all compiled by `make -C oracle ref`.  Outside: the CONTENT of Mitsuba's data/microfacet/*.dat tables (not part of
+// the reference tree; cudatracerlib_amd/rough_tables.py re-derives them).
 #pragma once
 
 namespace orc {

@@ -3,7 +3,8 @@
 // roughdielectric, conductor, roughconductor, plastic, phong, ward) and SceneTypes/BSDF_Complex.cu (coating, blend), compiled by `make ref`:
 // BSDF_Complex.cu as it lies; BSDF_Simple.cu through a build-time copy under oracle/_ref/gen/ (git-ignored) that drops line 2, the unused
 // `#include <Base/CudaRandom.h>` (curand_kernel.h does not exist in this image; nothing in the file uses it).  This file contains no reference source.
-// roughplastic and roughcoating are NOT driven: they evaluate RoughTransmittanceManager -> Math/Spline.cu, which only nvcc compiles (its ::min / ::max).
+// roughplastic and roughcoating (round 5): their f / sample evaluate RoughTransmittanceManager -> Math/Spline.cu; both now build (oracle/Makefile: Spline.cu behind one `using` line,
+// RoughTransmittance.cu:55-123,140-158 extracted) and the manager's three tables are installed through ref_rough_manager_set (ref_rough_driver.cpp) before a query.
 //
 // A query builds the reference's BSDF object from the product's flat ctl_material (include/ctl_amd.h) the way INTEGRATION.md's converter maps them back,
 // lets the reference's constructor / Update() derive what it derives (fdrInt, invEta2, sampling weights, ...), and calls sample / f / pdf in a frame whose
@@ -36,6 +37,7 @@ static BSDFFirst simple_of(const ctl_material& M) {
     case CTL_BSDF_ROUGHCONDUCTOR: { roughconductor d((MicrofacetDistribution::EType)M.u[0], spec3(M.f), spec3(M.f + 3), tex_of(M.tex[1]), tex_of(M.tex[2]), tex_of(M.tex[0])); d.m_sampleVisible = M.u[1] != 0; b.SetData(d); break; }
     case CTL_BSDF_PLASTIC: { plastic d(M.f[2], tex_of(M.tex[0]), tex_of(M.tex[1]), M.u[0] != 0); b.SetData(d); break; }
     case CTL_BSDF_PHONG: { phong d(tex_of(M.tex[0]), tex_of(M.tex[1]), tex_of(M.tex[2])); b.SetData(d); break; }
+    case CTL_BSDF_ROUGHPLASTIC: { Texture a = tex_of(M.tex[2]), d0 = tex_of(M.tex[0]), s0 = tex_of(M.tex[1]); roughplastic d((MicrofacetDistribution::EType)M.u[2], M.f[0], a, d0, s0, M.u[0] != 0); b.SetData(d); break; }
     case CTL_BSDF_WARD: { ward d((ward::EModelVariant)M.u[0], tex_of(M.tex[0]), tex_of(M.tex[1]), tex_of(M.tex[2]), tex_of(M.tex[3])); b.SetData(d); break; }
     default: throw std::runtime_error("ref_bsdf_driver: model not driven");
     }
@@ -77,6 +79,9 @@ int ref_bsdf_query(const ctl_material* mats, uint32_t idx, int mode, uint32_t ty
         if (M.bsdf_type == CTL_BSDF_COATING) {
             coating c(simple_of(mats[M.u[2]]), M.f[0], M.f[2], tex_of(M.tex[0]), tex_of(M.tex[1]));
             run(c, mode, typeMask, n, q, out);
+        } else if (M.bsdf_type == CTL_BSDF_ROUGHCOATING) {
+            roughcoating c((MicrofacetDistribution::EType)M.u[0], simple_of(mats[M.u[2]]), M.f[0], M.f[2], tex_of(M.tex[0]), tex_of(M.tex[2]), tex_of(M.tex[1]));
+            run(c, mode, typeMask, n, q, out);
         } else if (M.bsdf_type == CTL_BSDF_BLEND) {
             blend b(simple_of(mats[M.u[2]]), simple_of(mats[M.u[3]]), tex_of(M.tex[0]));
             run(b, mode, typeMask, n, q, out);
@@ -93,10 +98,12 @@ int ref_bsdf_derived(const ctl_material* mats, uint32_t idx, float* out5) {
         const ctl_material& M = mats[idx];
         std::memset(out5, 0, 20);
         if (M.bsdf_type == CTL_BSDF_COATING) { coating c(simple_of(mats[M.u[2]]), M.f[0], M.f[2], tex_of(M.tex[0]), tex_of(M.tex[1])); out5[0] = (float)c.m_combinedType; out5[4] = c.m_specularSamplingWeight; out5[3] = c.m_invEta; return 0; }
+        if (M.bsdf_type == CTL_BSDF_ROUGHCOATING) { roughcoating c((MicrofacetDistribution::EType)M.u[0], simple_of(mats[M.u[2]]), M.f[0], M.f[2], tex_of(M.tex[0]), tex_of(M.tex[2]), tex_of(M.tex[1])); out5[0] = (float)c.m_combinedType; out5[4] = c.m_specularSamplingWeight; out5[3] = c.m_invEta; out5[1] = c.m_sampleVisible ? 1.0f : 0.0f; return 0; }
         if (M.bsdf_type == CTL_BSDF_BLEND) { blend b(simple_of(mats[M.u[2]]), simple_of(mats[M.u[3]]), tex_of(M.tex[0])); out5[0] = (float)b.m_combinedType; return 0; }
         const BSDFFirst b = simple_of(M);
         out5[0] = (float)b.getType();
         if (M.bsdf_type == CTL_BSDF_PLASTIC) { const plastic* p = b.As<plastic>(); out5[1] = p->m_fdrInt; out5[2] = p->m_fdrExt; out5[3] = p->m_invEta2; out5[4] = p->m_specularSamplingWeight; }
+        if (M.bsdf_type == CTL_BSDF_ROUGHPLASTIC) { const roughplastic* p = b.As<roughplastic>(); out5[1] = p->m_sampleVisible ? 1.0f : 0.0f; out5[3] = p->m_invEta2; out5[4] = p->m_specularSamplingWeight; }
         if (M.bsdf_type == CTL_BSDF_PHONG) out5[4] = b.As<phong>()->m_specularSamplingWeight;
         if (M.bsdf_type == CTL_BSDF_WARD) out5[4] = b.As<ward>()->m_specularSamplingWeight;
         return 0;

@@ -471,6 +471,75 @@ def gen_bsdf(r):
     np.savez_compressed(os.path.join(HERE, "bsdf.npz"), **out)
 
 
+def rough_cases():
+    """materials of bsdf_rough.npz (the LAST one is queried) and the three transmittance tables (slot 0 / 1 / 2 = beckmann.dat / phong.dat / ggx.dat, RoughTransmittance.cu:126-128;
+    looked up by the distribution TYPE 0 Beckmann / 1 GGX / 2 Phong, :140-158)"""
+    from cudatracerlib_amd import api, rough_tables
+    tables = [rough_tables.make_table(slot, n_eta=4, n_alpha=5, n_theta=8, quad=16) for slot in (0, 1, 2)]
+    chk = api.checker_texture((0.05, 0.05, 0.05), (0.35, 0.35, 0.35), uv_scale=(3.0, 2.0), uv_offset=(0.25, 0.5))      # a roughness that varies over the surface: the 3-D lookup
+    d = api.diffuse((0.6, 0.7, 0.8)); rc = api.roughconductor(alpha=0.2, distribution=1, sample_visible=True)
+    cases = {
+        "roughplastic_beck": [api.roughplastic((0.2, 0.5, 0.25), alpha=0.15, distribution=0)],
+        "roughplastic_ggx_nonlinear": [api.roughplastic((0.6, 0.25, 0.2), alpha=0.3, int_ior=1.6, distribution=1, nonlinear=True)],
+        "roughplastic_phong_tinted": [api.roughplastic((0.3, 0.3, 0.6), alpha=0.25, int_ior=1.33, ext_ior=1.0, distribution=2, specular_reflectance=(0.9, 0.8, 0.7))],
+        "roughplastic_checker_alpha": [api.roughplastic((0.5, 0.5, 0.5), alpha=chk, distribution=1)],
+        "roughcoating_diffuse": [d, api.roughcoating(0, d, alpha=0.2, int_ior=1.5, ext_ior=1.0, thickness=1.0, sigma_a=(0.1, 0.4, 0.9), distribution=0)],
+        "roughcoating_roughconductor_ggx": [rc, api.roughcoating(0, rc, alpha=0.1, int_ior=1.33, ext_ior=1.0, thickness=0.5, sigma_a=0.0, distribution=1, specular_reflectance=(0.9, 0.9, 1.0))],
+    }
+    return cases, tables
+
+
+def gen_bsdf_rough(r):
+    """roughplastic (SceneTypes/BSDF_Simple.cu:890-1057) and roughcoating (BSDF_Complex.cu) of the reference build, through RoughTransmittanceManager -> RoughTransmittance::Evaluate /
+    EvaluateDiffuse (Engine/RoughTransmittance.cu:55-121, 140-158) -> Math/Spline.cu, over three synthetic tables; plus the two lookups by themselves (cos theta < 0, eta < 1,
+    eta below the table, alpha at and beyond the table's ends).  Same query scheme as gen_bsdf."""
+    from cudatracerlib_amd import api
+    r.ref_bsdf_query.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    r.ref_bsdf_derived.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    r.ref_rough_manager_set.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, f32, f32, f32, f32]
+    r.ref_rough_transmittance_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, f32, f32, f32, f32, C.c_int, C.c_void_p, C.c_void_p]
+    r.ref_rough_manager_eval.restype = C.c_float; r.ref_rough_manager_eval.argtypes = [C.c_int, f32, f32, f32]
+    cases, tables = rough_cases()
+    out = {}; keep = []
+    for slot, (tr, df, er, ar) in enumerate(tables):
+        tr = np.ascontiguousarray(tr, np.float32); df = np.ascontiguousarray(df, np.float32); keep += [tr, df]
+        assert r.ref_rough_manager_set(slot, tr.ctypes.data, df.ctypes.data, tr.shape[0] // 2, tr.shape[1], tr.shape[2], f32(er[0]), f32(er[1]), f32(ar[0]), f32(ar[1])) == 0
+        out["table%d_trans" % slot] = tr; out["table%d_diff" % slot] = df; out["table%d_ranges" % slot] = np.array([er[0], er[1], ar[0], ar[1]], np.float32)
+    rs = np.random.RandomState(20261011)
+    # the lookups alone: {cos theta, alpha, eta}
+    nq = 256
+    q = np.stack([rs.uniform(-1, 1, nq), rs.uniform(tables[0][3][0], tables[0][3][1], nq), rs.choice([1.49, 1 / 1.49, 1.6, 1.05, 1.0001, 2.4, 1 / 1.33], nq)], axis=1).astype(np.float32)
+    q[0] = [1, tables[0][3][0], 1.5]; q[1] = [0, tables[0][3][1], 1.5]; q[2] = [0.5, tables[0][3][1] * 1.5, 1.5]; q[3] = [-0.3, 0.1, 1.5]; q[4] = [0.7, tables[0][3][0] * 0.5, 1.5]
+    for slot, (tr, df, er, ar) in enumerate(tables):
+        res = np.zeros((nq, 2), np.float32)
+        assert r.ref_rough_transmittance_eval(out["table%d_trans" % slot].ctypes.data, out["table%d_diff" % slot].ctypes.data, tr.shape[0] // 2, tr.shape[1], tr.shape[2],
+                                               f32(er[0]), f32(er[1]), f32(ar[0]), f32(ar[1]), nq, q.ctypes.data, res.ctypes.data) == 0
+        out["lookup%d" % slot] = res
+    out["lookup_q"] = q
+    out["manager_by_type"] = np.array([[r.ref_rough_manager_eval(t, float(q[i, 0]), float(q[i, 1]), float(q[i, 2])) for i in range(16)] for t in range(3)], np.float32)   # type t reads slot t
+    n = 192
+    for name, mats in cases.items():
+        arr = (api.ctl_material * len(mats))(*mats); idx = len(mats) - 1
+        wi = rs.normal(size=(n, 3)); wi /= np.linalg.norm(wi, axis=1, keepdims=True); wi[:, 2] = np.abs(wi[:, 2])
+        wi[:4] = [[0, 0, 1], [0.6, 0, 0.8], [0.999, 0, 0.0447101778], [-0.6, 0.64, 0.48]]; wi[4] = [0.6, 0, -0.8]
+        q1 = np.zeros((n, 8), np.float32); q1[:, :3] = wi; q1[:, 3:5] = rs.rand(n, 2); q1[:, 6:8] = rs.uniform(-1, 2, size=(n, 2))
+        smp = np.zeros((n, 9), np.float32)
+        assert r.ref_bsdf_query(C.addressof(arr), idx, 0, 0x1ff, n, q1.ctypes.data, smp.ctypes.data) == 0, name
+        q2 = q1.copy(); wo = np.roll(smp[:, 4:7], 1, axis=0).copy()
+        bad = ~(np.linalg.norm(wo, axis=1) > 0.5); alt = rs.normal(size=(n, 3)); alt /= np.linalg.norm(alt, axis=1, keepdims=True); wo[bad] = alt[bad]
+        own = smp[:, 4:7].copy(); kp = (np.arange(n) % 3 == 0) & (np.linalg.norm(own, axis=1) > 0.5); wo[kp] = own[kp]
+        q2[:, 3:6] = wo
+        out[name + "_materials"] = np.frombuffer(bytes(arr), np.uint8).copy(); out[name + "_sample_q"] = q1; out[name + "_sample"] = smp; out[name + "_eval_q"] = q2
+        for mask in (0x1ff, 0x2 | 0x4, 0x8 | 0x10):
+            for mode in (1, 2):
+                ev = np.zeros((n, 9), np.float32)
+                assert r.ref_bsdf_query(C.addressof(arr), idx, mode, mask, n, q2.ctypes.data, ev.ctypes.data) == 0
+                out["%s_eval_mode%d_mask%x" % (name, mode, mask)] = ev[:, :4].copy()
+        d5 = np.zeros(5, np.float32); assert r.ref_bsdf_derived(C.addressof(arr), idx, d5.ctypes.data) == 0
+        out[name + "_derived"] = d5
+    np.savez_compressed(os.path.join(HERE, "bsdf_rough.npz"), **out)
+
+
 def spline_cases():
     """inputs of spline.npz: tables of 2..32 knots per axis, query points inside, exactly on knots, at 0 and 1, just outside [0, 1] and NaN (own random stream)"""
     rs = np.random.RandomState(20260941)
@@ -593,16 +662,21 @@ if __name__ == "__main__":
     elif sys.argv[1:] == ["lights"]:
         gen_lights(oracle.load_ref())
         gen_spline(oracle.load_ref())
+        gen_bsdf_rough(oracle.load_ref())
     elif sys.argv[1:] == ["bsdf"]:
         gen_bsdf(oracle.load_ref())
         gen_lights(oracle.load_ref())
         gen_spline(oracle.load_ref())
+        gen_bsdf_rough(oracle.load_ref())
     elif sys.argv[1:] == ["mipmap"]:
         gen_mipmap(oracle.load_ref())
     elif sys.argv[1:] == ["math2"]:
         gen_math2(oracle.load_ref())
+    elif sys.argv[1:] == ["bsdf_rough"]:
+        gen_bsdf_rough(oracle.load_ref())
     elif sys.argv[1:] == ["spline"]:
         gen_spline(oracle.load_ref())
+        gen_bsdf_rough(oracle.load_ref())
     elif sys.argv[1:] == ["traceray"]:      # only this fixture (the others stay byte-identical)
         gen_traceray(oracle.load_ref())
     else:
@@ -614,3 +688,4 @@ if __name__ == "__main__":
         gen_emitters(oracle.load_ref())
         gen_lights(oracle.load_ref())
         gen_spline(oracle.load_ref())
+        gen_bsdf_rough(oracle.load_ref())
