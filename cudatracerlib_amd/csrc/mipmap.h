@@ -168,8 +168,10 @@ __device__ __noinline__ bool alpha_survives(const uint4* __restrict__ tri_data, 
     const ctl_material& mat = mats[node_info[node].x + ((ta.y >> 16) & 0xff)];
     const uint32_t st = mat.alpha_state;
     if (st == CTL_ALPHA_DISABLED) return true;
-    const f2 a{ half_to_float((uint16_t)tb.y), half_to_float((uint16_t)(tb.y >> 16)) }, b{ half_to_float((uint16_t)tb.z), half_to_float((uint16_t)(tb.z >> 16)) },
-        c{ half_to_float((uint16_t)tb.w), half_to_float((uint16_t)(tb.w >> 16)) };
+    // tri->getUVSetData(0, a, b, c) (Kernel/TraceHelper.cu:149 -> Engine/TriangleData.cu:25-32): u from the HIGH half of each word, v from the low one — the other way round than
+    // fillDG: the reference looks the alpha map up with the surface's u and v exchanged (the same function is pinned on its own code through ShapeSet, tests/golden/scene_lights.npz)
+    const f2 a{ half_to_float((uint16_t)(tb.y >> 16)), half_to_float((uint16_t)tb.y) }, b{ half_to_float((uint16_t)(tb.z >> 16)), half_to_float((uint16_t)tb.z) },
+        c{ half_to_float((uint16_t)(tb.w >> 16)), half_to_float((uint16_t)tb.w) };
     const float w = 1 - u - v;
     const f2 uv{ u * a.x + v * b.x + w * c.x, u * a.y + v * b.y + w * c.y };
     const ctl_texture& refl = mat.tex[0];

@@ -708,8 +708,10 @@ __device__ __forceinline__ float env_pdf_direct(const dev_scene& S, const ctl_li
 __device__ __forceinline__ bool light_needs_uv(const ctl_light& L) { return L.rad_texture.type == CTL_TEX_CHECKER || L.rad_texture.type == CTL_TEX_IMAGE; }
 __device__ __forceinline__ f2 shape_tri_uv(const dev_scene& S, const ctl_shape_tri& sn, f2 bary) {   // getUV: TriangleData::getUVSetData(0, a, b, c)
     const uint4 tb = S.tri_data[sn.t_dat * 2 + 1];
-    const f2 a{ half_to_float((uint16_t)tb.y), half_to_float((uint16_t)(tb.y >> 16)) }, b{ half_to_float((uint16_t)tb.z), half_to_float((uint16_t)(tb.z >> 16)) },
-        c{ half_to_float((uint16_t)tb.w), half_to_float((uint16_t)(tb.w >> 16)) };
+    // getUVSetData takes u from the HIGH half of each word and v from the low one (Engine/TriangleData.cu:27) — the other way round than fillDG: the reference looks an
+    // area light's radiance texture up with the surface's u and v exchanged (pinned on its own code: tests/golden/scene_lights.npz), and so does this
+    const f2 a{ half_to_float((uint16_t)(tb.y >> 16)), half_to_float((uint16_t)tb.y) }, b{ half_to_float((uint16_t)(tb.z >> 16)), half_to_float((uint16_t)tb.z) },
+        c{ half_to_float((uint16_t)(tb.w >> 16)), half_to_float((uint16_t)tb.w) };
     const float u = bary.x, v = bary.y, w = 1 - u - v;
     return f2{ u * a.x + v * b.x + w * c.x, u * a.y + v * b.y + w * c.y };
 }

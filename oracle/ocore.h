@@ -738,7 +738,9 @@ inline bool alphaSurvive(const Scene& S, uint32_t tri, uint32_t nodeIdx, float u
     const ctl_material& mat = S.d.materials[triMatIndex(T, S.d.nodes[nodeIdx].material_offset)];
     if (mat.alpha_state == CTL_ALPHA_DISABLED) return true;
     auto h = [&](uint32_t bits) { return halfToFloat((uint16_t)bits, S.half_host_quirk); };
-    V2 a{ h(T.uv[0]), h(T.uv[0] >> 16) }, b{ h(T.uv[1]), h(T.uv[1] >> 16) }, c{ h(T.uv[2]), h(T.uv[2] >> 16) };   // getUVSetData(0, a, b, c)
+    // tri->getUVSetData(0, a, b, c) (Kernel/TraceHelper.cu:149): u from the HIGH half of each word, v from the low one — see shapeTriUV below: the alpha map, too, is looked
+    // up with the surface's u and v exchanged
+    V2 a{ h(T.uv[0] >> 16), h(T.uv[0]) }, b{ h(T.uv[1] >> 16), h(T.uv[1]) }, c{ h(T.uv[2] >> 16), h(T.uv[2]) };
     V2 uv{ u * a.x + v * b.x + (1 - u - v) * c.x, u * a.y + v * b.y + (1 - u - v) * c.y };
     return materialAlphaTest(mat, uv, S.d.images);
 }
@@ -868,7 +870,10 @@ inline void shapeSamplePosition(const Scene& S, const ctl_light& L, DirectRec& p
 inline V2 shapeTriUV(const Scene& S, const ctl_shape_tri& sn, V2 bary) {
     const ctl_triangle_data& T = S.d.tri_data[sn.t_dat];
     auto h = [&](uint32_t bits) { return halfToFloat((uint16_t)bits, S.half_host_quirk); };
-    V2 a{ h(T.uv[0]), h(T.uv[0] >> 16) }, b{ h(T.uv[1]), h(T.uv[1] >> 16) }, c{ h(T.uv[2]), h(T.uv[2] >> 16) };
+    // TriangleData::getUVSetData(0, a, b, c) (Engine/TriangleData.cu:25-32) takes u from the HIGH half of each word and v from the low one — the other way round than fillDG
+    // (:91-97) reads them and than the constructor packs them: an area light's radiance texture (and an alpha map, alphaSurvive above) is looked up with the surface's u and v
+    // exchanged.  The reference's own behaviour, pinned on its own code by tests/golden/scene_lights.npz (the checker panel); reproduced here and in csrc/shading.h / mipmap.h.
+    V2 a{ h(T.uv[0] >> 16), h(T.uv[0]) }, b{ h(T.uv[1] >> 16), h(T.uv[1]) }, c{ h(T.uv[2] >> 16), h(T.uv[2]) };
     float u = bary.x, v = bary.y, w = 1 - u - v;
     return V2{ u * a.x + v * b.x + w * c.x, u * a.y + v * b.y + w * c.y };
 }

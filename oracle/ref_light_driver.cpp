@@ -3,7 +3,7 @@
 // reference's constructors from their primary parameters, and their sampleDirect; DiffuseLight::pdfDirect / eval with a constant radiance.  `make ref` compiles
 // Light.cu through a build-time copy under oracle/_ref/gen/ (git-ignored) without line 6 (`#include <Kernel/TraceHelper.h>`, which pulls in curand_kernel.h) and
 // without lines 420-479 (InfiniteLight::internalSampleDirection / internalPdfDirection: they read the scene's global g_SceneData declared in that header).
-// Area-light SAMPLING goes through ShapeSet (Engine/ShapeSet.cu), which needs the same global, and is not driven.  This file contains no reference source.
+// Area-light and environment-map SAMPLING go through that global: ref_scene_light_driver.cpp (round 5).  This file contains no reference source.
 #include <SceneTypes/Light.h>
 #include <cstdint>
 #include <cstring>

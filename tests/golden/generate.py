@@ -540,6 +540,55 @@ def gen_bsdf_rough(r):
     np.savez_compressed(os.path.join(HERE, "bsdf_rough.npz"), **out)
 
 
+def scene_light_cases():
+    """scenes whose area / environment emitters the reference build samples through the product's own scene description (name -> DynamicScene)"""
+    from cudatracerlib_amd import scenes
+    return {"cornell": scenes.cornell_box(64, 64), "panel_checker": scenes.area_lights_scene(kind="checker"), "panel_orthogonal": scenes.area_lights_scene(kind="orthogonal"),
+            "env": scenes.env_scene(), "env_rotated": scenes.env_scene(rotate_env=True), "bathroom": scenes.synthetic_bathroom(64, 64, n_instances=12, subdiv=1),
+            "sm": scenes.synthetic_sm(64, 64, n_instances=20, subdiv=1)}
+
+
+def scene_light_digest(d):
+    """what the reference's outputs depend on: the lights, the anim blob, TriangleData and the images' level-0 texels of the description"""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(C.string_at(d.lights, d.n_lights_buf * C.sizeof(type(d.lights.contents)))); h.update(C.string_at(d.anim, d.n_anim_bytes)); h.update(C.string_at(d.tri_data, d.n_tri_data * 32))
+    for i in range(d.n_images):
+        m = d.images[i]; h.update(C.string_at(m.texels, m.width * m.height * 4)); h.update(bytes([m.texel_type, m.wrap_mode, m.filter_mode]))
+    return h.hexdigest()
+
+
+def gen_scene_lights(r):
+    """DiffuseLight::sampleDirect / pdfDirect through ShapeSet::SamplePosition (Engine/ShapeSet.cu:24-105) and InfiniteLight::sampleDirect / pdfDirect through
+    internalSampleDirection / internalPdfDirection (SceneTypes/Light.cu:420-479) of the reference build, over scenes compiled by the product's host code (oracle/ref_scene_light_driver.cpp)"""
+    r.ref_scene_light_sample_direct.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    r.ref_scene_light_pdf_direct.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    rs = np.random.RandomState(20261019)
+    out = {}
+    for name, sc in scene_light_cases().items():
+        d = sc.desc
+        out[name + "_digest"] = np.frombuffer(scene_light_digest(d).encode(), np.uint8).copy()
+        lo, hi = np.array(d.box_min[:], np.float32), np.array(d.box_max[:], np.float32)
+        for li in range(d.n_lights_buf):
+            if d.lights[li].type not in (2, 5):
+                continue
+            n = 256
+            q = np.zeros((n, 8), np.float32)
+            q[:, :3] = lo + (hi - lo) * rs.uniform(0.02, 0.98, size=(n, 3)); nrm = rs.normal(size=(n, 3)); q[:, 3:6] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+            q[:, 6:8] = rs.rand(n, 2); q[0, 6:8] = [0, 0]; q[1, 6:8] = [0.99999994, 0.99999994]; q[2, 6:8] = [0.5, 0.5]; q[3, 6:8] = [0, 0.99999994]
+            res = np.zeros((n, 14), np.float32)
+            assert r.ref_scene_light_sample_direct(C.addressof(d), li, n, q.ctypes.data, res.ctypes.data) == 0, (name, li)
+            # pdfDirect for the sampled directions, and for directions that miss the emitter / random ones
+            q2 = np.zeros((n, 14), np.float32); q2[:, :6] = q[:, :6]; q2[:, 6:9] = res[:, 4:7]; q2[:, 9] = res[:, 7]; q2[:, 10:13] = res[:, 11:14]
+            bad = ~(np.linalg.norm(q2[:, 6:9], axis=1) > 0.5); alt = rs.normal(size=(n, 3)); alt /= np.linalg.norm(alt, axis=1, keepdims=True)
+            q2[bad, 6:9] = alt[bad]; q2[bad, 9] = 1.0; q2[bad, 10:13] = -alt[bad]
+            swap = np.arange(n) % 4 == 0; q2[swap, 6:9] = alt[swap]       # every fourth: an unrelated direction (environment: any direction has a density)
+            pdf = np.zeros(n, np.float32)
+            assert r.ref_scene_light_pdf_direct(C.addressof(d), li, n, q2.ctypes.data, pdf.ctypes.data) == 0
+            out["%s_light%d_q" % (name, li)] = q; out["%s_light%d_sample" % (name, li)] = res; out["%s_light%d_pdf_q" % (name, li)] = q2; out["%s_light%d_pdf" % (name, li)] = pdf
+    np.savez_compressed(os.path.join(HERE, "scene_lights.npz"), **out)
+
+
 def spline_cases():
     """inputs of spline.npz: tables of 2..32 knots per axis, query points inside, exactly on knots, at 0 and 1, just outside [0, 1] and NaN (own random stream)"""
     rs = np.random.RandomState(20260941)
@@ -663,20 +712,26 @@ if __name__ == "__main__":
         gen_lights(oracle.load_ref())
         gen_spline(oracle.load_ref())
         gen_bsdf_rough(oracle.load_ref())
+        gen_scene_lights(oracle.load_ref())
     elif sys.argv[1:] == ["bsdf"]:
         gen_bsdf(oracle.load_ref())
         gen_lights(oracle.load_ref())
         gen_spline(oracle.load_ref())
         gen_bsdf_rough(oracle.load_ref())
+        gen_scene_lights(oracle.load_ref())
     elif sys.argv[1:] == ["mipmap"]:
         gen_mipmap(oracle.load_ref())
     elif sys.argv[1:] == ["math2"]:
         gen_math2(oracle.load_ref())
+    elif sys.argv[1:] == ["scene_lights"]:
+        gen_scene_lights(oracle.load_ref())
     elif sys.argv[1:] == ["bsdf_rough"]:
         gen_bsdf_rough(oracle.load_ref())
+        gen_scene_lights(oracle.load_ref())
     elif sys.argv[1:] == ["spline"]:
         gen_spline(oracle.load_ref())
         gen_bsdf_rough(oracle.load_ref())
+        gen_scene_lights(oracle.load_ref())
     elif sys.argv[1:] == ["traceray"]:      # only this fixture (the others stay byte-identical)
         gen_traceray(oracle.load_ref())
     else:
@@ -689,3 +744,4 @@ if __name__ == "__main__":
         gen_lights(oracle.load_ref())
         gen_spline(oracle.load_ref())
         gen_bsdf_rough(oracle.load_ref())
+        gen_scene_lights(oracle.load_ref())

@@ -177,7 +177,7 @@ def _panel(kind):
 def test_textured_area_light_samples_its_texture(lib):
     """DiffuseLight with a radiance texture that needs uv (Light.cu:50-53, :83-134): sampleDirect returns texture(uv of the sampled point) / pdf with
     the solid-angle pdf of a constant light, and the uv is the sampled triangle's getUVSetData(0) interpolated with the sampled barycentrics — the
-    panel's uv are its x / z extent mapped to [0, 1]^2, so the checker cell can be read off the sampled position."""
+    panel's uv are its x / z extent mapped to [0, 1]^2, so the checker cell can be read off the sampled position (with u and v exchanged, as getUVSetData delivers them)."""
     sc, d, li = _panel("checker")
     L = d.lights[li]
     assert L.rad_texture.type == 3 and not L.orthogonal
@@ -190,6 +190,8 @@ def test_textured_area_light_samples_its_texture(lib):
         p, n, dist, pdf = o[8:11], o[11:14], o[7], o[3]
         assert pdf == pytest.approx(dist * dist / (abs(np.dot(o[4:7], n)) * L.sum_area), rel=1e-4)
         u, v = (p[0] + 2.5) / 5.0, (p[2] + 2.0) / 4.0            # the panel's uv layout (scenes.area_lights_scene); stored as halves
+        u, v = v, u                                              # getUVSetData reads the halves the other way round than fillDG (TriangleData.cu:27 against :94): the reference looks the
+        #                                                          light's texture up at (v, u) — pinned on its own code by tests/golden/scene_lights.npz
         cu, cv = u * 3.0 * 2, v * 2.0 * 2
         if min(abs(cu - round(cu)), abs(cv - round(cv))) < 0.02:
             continue                                             # too close to a cell border for half-precision uv

@@ -120,6 +120,7 @@ def test_trace_ray_alpha_test_lets_rays_through_the_holes(orc):
     alpha = orc.intersect(d, rays, alpha_test=True)
     assert np.allclose(plain["dist"], 6.0, atol=1e-4)              # every ray stops at the card without the test
     u, v = (xs.ravel() + 3) / 6, (ys.ravel() - 0.2) / 4
+    u, v = v, u      # the alpha test interpolates getUVSetData's pairs (TraceHelper.cu:149), which come out (v, u) (TriangleData.cu:27 against fillDG's :94): the reference's own exchange
     solid = ((np.floor(u * 4 * 2).astype(int) % 2) * 2 - 1) * ((np.floor(v * 3 * 2).astype(int) % 2) * 2 - 1) == 1   # CheckerboardTexture (Texture.h:136-146)
     edge = (np.abs(u * 8 - np.round(u * 8)) < 1e-3) | (np.abs(v * 6 - np.round(v * 6)) < 1e-3)
     ok = ~edge
