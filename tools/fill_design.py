@@ -17,7 +17,7 @@ def brief(j):
     return j["value"], j["ms_per_step"], r["ms_intersect"] / j["steps"], r["ms_shade"] / j["steps"], r["per_ray"], r
 
 
-T = {}
+T = {"TAG": tag}
 fin = line("bench_final.json"); v, ms, tr, sh, pr, r = brief(fin)
 T["SM20"] = "%.0f" % v; T["SM20_MS"] = "%.2f (%.2f + %.2f)" % (ms, tr, sh); T["VIS_INNER"] = "%.1f" % pr["n_inner"]; T["VIS_TRI"] = "%.1f" % pr["n_tri"]
 T["TRAV_MS"] = "%.2f" % tr; T["TRAV_SHARE"] = "%.0f" % (100 * tr / ms); T["SHADE_MS"] = "%.2f" % sh
