@@ -743,3 +743,41 @@ def test_ordered_accumulation_is_independent_of_the_batching(gpu, orc):
         tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
     got = img.getPixelData()
     assert (got[..., :3].view(np.uint32) == want[..., :3].view(np.uint32)).all(axis=2).mean() > 0.98
+
+
+def test_refused_batch_leaves_the_tracer_usable(gpu):
+    """A batch beyond the 2^31 ray slots of a wavefront is refused BEFORE anything changes (advisor r4: the check used to run after Resize had stored the new size and batch, and every
+    later Resize threw again): 4096 x 4096 pixels x 128 passes = 2^31 slots is refused by DoPasses; the same tracer then renders with a smaller batch, and resizes."""
+    sc = scenes.cornell_box(64, 64)
+    scene = gpu.Scene(sc.desc, flatten=True)
+    tr = gpu.WavefrontPathTracer(); p = tr.getParameters(); p.setValue("MaxPathLength", 2); p.setValue("PassBatch", 128)
+    tr.Resize(4096, 4096); tr.InitializeScene(scene)
+    img = gpu.Image(4096, 4096)
+    with pytest.raises(gpu.CtlError, match="2\\^31 ray slots"):
+        tr.DoPasses(img, 128, new_trace=True)
+    with pytest.raises(gpu.CtlError, match="2\\^31 ray slots"):
+        tr.reservePasses(128)
+    p.setValue("PassBatch", 2)
+    tr.DoPasses(img, 2, new_trace=True)
+    assert tr.stats().passes_done == 2 and tr.stats().rays_total > 2 * 4096 * 4096
+    tr.Resize(64, 64)
+    small = gpu.Image(64, 64); tr.DoPasses(small, 2, new_trace=True)
+    assert small.getPixelData()[..., 6].sum() == 2 * 64 * 64
+
+
+def test_material_index_out_of_range_is_refused(gpu):
+    """a triangle that names a material the scene does not have: ctl_scene_create refuses the flattened scene (advisor r4: its traversal key would have been the MISS key and the vertex
+    would have been shaded from a record outside the material array)"""
+    import ctypes as C
+    sc = scenes.cornell_box(64, 64)
+    d = sc.desc
+    n = d.n_tri_data
+    copy = np.frombuffer(C.string_at(d.tri_data, n * 32), np.uint32).copy().reshape(n, 8)
+    copy[3, 1] = (int(copy[3, 1]) & 0xff00ffff) | (200 << 16)                              # TriangleData::getMatIndex: bits 16..23 of the second word
+    old = d.tri_data
+    d.tri_data = copy.ctypes.data
+    try:
+        with pytest.raises(gpu.CtlError, match="names material"):
+            gpu.Scene(d, flatten=True)
+    finally:
+        d.tri_data = old
