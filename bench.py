@@ -277,7 +277,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     share_gpu = os.environ.get("CTL_BENCH_SHARE_GPU") == "1"
-    if world > 1:
+    # CTL_BENCH_COMM_WORLD1=1: the N-rank code path with ONE rank (gloo group of one, communicator of one, gather / reduce warm-up, the exchange inside the timed region): every line of
+    # the RCCL branch runs on a 1-GPU box against the real librccl.so, so that an 8-GPU node is not the first place where that Python executes (tests/test_gpu_render.py)
+    multi = world > 1 or os.environ.get("CTL_BENCH_COMM_WORLD1") == "1"
+    if multi and world == 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); free_port = sk.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(free_port)); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if multi:
         # torch.distributed (gloo, CPU tensors) is plumbing only: the barrier, the broadcast of the RCCL unique id and two scalar reductions.  The framebuffer —
         # the one data-path collective — goes through the library's own ncclReduce (ctl_image_reduce, csrc/comm.cpp).
         # CTL_BENCH_SHARE_GPU=1 is a test hook for a 1-GPU box: every rank on device 0 (RCCL refuses two ranks on one device, so the reduce falls back to gloo).
@@ -303,12 +311,12 @@ def main():
     if not args.no_cache:
         ctl.api.set_cache_dir(os.environ.get("CTL_CACHE_DIR") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "ctl_amd_cache"))
     t_build = time.perf_counter()
-    if world > 1 and rank != 0 and not args.no_cache:
+    if multi and rank != 0 and not args.no_cache:
         dist.barrier()                      # rank 0 compiles and fills the cache first
-    sc, scene_source = build_scene(args, rank, dist.barrier if (world > 1 and (args.via_loader or args.workload == "synthetic-sm-hard")) else None)
+    sc, scene_source = build_scene(args, rank, dist.barrier if (multi and (args.via_loader or args.workload == "synthetic-sm-hard")) else None)
     desc = sc.desc
     scene = ctl.Scene(desc, flatten=bool(args.flatten), flat_format=args.flat_format)
-    if world > 1 and rank == 0 and not args.no_cache:
+    if multi and rank == 0 and not args.no_cache:
         dist.barrier()
     t_build = time.perf_counter() - t_build
     tr = ctl.WavefrontPathTracer()
@@ -324,7 +332,7 @@ def main():
     img = ctl.Image(args.width, args.height)
 
     comm, reduce_kind, exchange = None, "none (1 GPU)", None
-    if world > 1:
+    if multi:
         import torch
 
         def agree(flag):   # every rank takes the same path: MIN over the ranks of "it worked here" (gloo)
@@ -391,7 +399,7 @@ def main():
 
     def sync():
         ctl.api._check(ctl.lib.ctl_device_synchronize())
-        if world > 1:
+        if multi:
             import torch
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
@@ -416,7 +424,7 @@ def main():
     t0 = time.perf_counter()
     tr.DoPasses(img, args.steps, new_trace=(args.warmup == 0))
     rank_ms = reduce_ms = None
-    if world > 1:
+    if multi:
         ctl.api._check(ctl.lib.ctl_device_synchronize())
         rank_ms = (time.perf_counter() - t0) * 1e3      # this rank's own render of its shard
         t_r = time.perf_counter()
@@ -431,7 +439,7 @@ def main():
     launches_closest = int(st.intersect_launches)
     # FuseTraversal (default): bounce d's path rays and bounce d-1's shadow rays share one persistent launch; those launches are the dominant kernel then
     fused_launches, fused_any, fused_closest, k_ms_fused = int(st.fused_launches), int(st.fused_shadow_rays), int(st.fused_closest_rays), st.ms_fused
-    if world > 1:
+    if multi:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
         per_rank = [None] * world; dist.all_gather_object(per_rank, {"rank_ms": round(rank_ms, 3), "reduce_ms": round(reduce_ms, 3), "rays": rays})
@@ -558,7 +566,7 @@ def main():
         }
         if roof_shade:
             out["roofline_shade"] = roof_shade
-        if world > 1:
+        if multi:
             slow = max(range(world), key=lambda r: per_rank[r]["rank_ms"])
             out["rank_ms"] = [q["rank_ms"] for q in per_rank]; out["reduce_ms"] = per_rank[0]["reduce_ms"]; out["reduce_ms_per_rank"] = [q["reduce_ms"] for q in per_rank]
             out["slowest_rank"] = slow; out["rays_per_rank"] = [int(q["rays"]) for q in per_rank]
@@ -566,7 +574,7 @@ def main():
         if cpu:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return out

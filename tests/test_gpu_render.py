@@ -781,3 +781,26 @@ def test_material_index_out_of_range_is_refused(gpu):
             gpu.Scene(d, flatten=True)
     finally:
         d.tri_data = old
+
+
+@pytest.mark.gpu
+def test_bench_rccl_branch_runs_with_one_rank(gpu, tmp_path):
+    """bench.py's N-rank code path — gloo group, communicator with a deadline, the gather AND the reduce warmed up before the timed region, the agreed choice, the exchange inside
+    the timed region, the per-rank fields — executed with ONE rank against the real librccl.so (CTL_BENCH_COMM_WORLD1=1), so that an 8-GPU node is not the first place where it
+    runs: the native gather is chosen; with CTL_BENCH_NO_GATHER=1 the reduce on a fresh communicator is; both frames equal the plain one-rank frame bit for bit."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "192", "--instances", "60", "--subdiv", "2", "--no-cpu-baseline", "--no-cache"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CTL_BENCH_SHARE_GPU")}
+    frames, lines = [], []
+    for extra in ({}, {"CTL_BENCH_COMM_WORLD1": "1"}, {"CTL_BENCH_COMM_WORLD1": "1", "CTL_BENCH_NO_GATHER": "1"}):
+        f = str(tmp_path / ("frame%d.npy" % len(frames)))
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dump-frame", f] + common, env=dict(env, **extra), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        js = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(js) == 1
+        lines.append(json.loads(js[0])); frames.append(np.load(f))
+    assert "ncclGather" in lines[1]["config"]["framebuffer_reduce"] and "reduce_ms" in lines[1] and len(lines[1]["rank_ms"]) == 1
+    assert "ncclReduce" in lines[2]["config"]["framebuffer_reduce"] and "CTL_BENCH_NO_GATHER" in lines[2]["config"]["framebuffer_reduce"]
+    assert lines[0]["n_gpus"] == lines[1]["n_gpus"] == 1 and "rank_ms" not in lines[0]
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)) and np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
