@@ -268,6 +268,12 @@ float orc_light_pdf_direct(const ctl_scene_desc* desc, uint32_t light, const flo
     r.d = V3(d[0], d[1], d[2]); r.dist = dist; r.n = V3(n[0], n[1], n[2]); r.measure = ESolidAngle;
     return lightPdfDirect(S, desc->lights[light], r);
 }
+// DiffuseLight::eval(p, Frame(n), d) (SceneTypes/Light.cu:67-81)
+void orc_light_eval(const ctl_scene_desc* desc, uint32_t light, const float* p, const float* n, const float* d, float* out) {
+    Scene S; S.d = *desc;
+    Spec v = lightEval(S, desc->lights[light], V3(p[0], p[1], p[2]), Frame(V3(n[0], n[1], n[2])), V3(d[0], d[1], d[2]));
+    out[0] = v.x; out[1] = v.y; out[2] = v.z;
+}
 // InfiniteLight::evalEnvironment for a world direction
 void orc_env_eval(const ctl_scene_desc* desc, const float* dir, float* out) {
     Scene S; S.d = *desc;

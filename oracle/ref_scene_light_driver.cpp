@@ -5,7 +5,8 @@
 // it in Kernel/TraceHelper.h (which also pulls curand_kernel.h in — not in this image) and defines it in Kernel/TraceHelper.cu.  `make ref` therefore builds ONE
 // generated translation unit (oracle/_ref/gen/scene_lights.cpp, git-ignored) out of the reference's own lines: TraceHelper.h:15 (the host declaration) and :24 (the
 // `g_SceneData` macro), TraceHelper.cu:27 (the definition), ShapeSet.cu:24-105, Light.cu:420-479 — behind the reference's own headers and the `using std::min; using
-// std::max;` preface; no declaration is written by hand.  With it, Light.cu's DiffuseLight::sampleDirect / pdfDirect / eval and InfiniteLight::sampleDirect / pdfDirect —
+// std::max;` preface; no declaration is written by hand.  The same unit carries SceneTypes/Texture.cu:6-43 — ImageTexture::Evaluate / Average / getTexture, the file's whole body,
+// which reads the same global — so that image textures (BSDF parameters, area-light radiance) run the reference's own code too.  With it, Light.cu's DiffuseLight::sampleDirect / pdfDirect / eval and InfiniteLight::sampleDirect / pdfDirect —
 // compiled all along by the copy of Light.cu without those lines — become callable.
 // A query points the global at the product's own scene description (ctl_scene_desc: the anim blob with the lights' triangle CDFs / ShapeSet::triData records /
 // environment-map tables, the TriangleData array, level 0 of the images) and rebuilds the reference's light object from the product's flat ctl_light the way
@@ -42,6 +43,11 @@ void bind_scene(const ctl_scene_desc* d) {
     }
     S.m_sTexData.Data = g_maps.data(); S.m_sTexData.UsedCount = S.m_sTexData.Length = d->n_images;
 }
+ImageTexture image_of(const ctl_texture& t) {   // ImageTexture (SceneTypes/Texture.h:159-183): value = m_scale, uv_scale / uv_offset = the diagonal TextureMapping2D, image = tex_idx
+    ImageTexture it(TextureMapping2D(t.uv_scale[0], t.uv_scale[1], t.uv_offset[0], t.uv_offset[1]), std::string(), spec3(t.value));
+    it.tex_idx = t.image;
+    return it;
+}
 DiffuseLight area_of(const ctl_light& L) {
     shape_layout sl{ L.area_dist_index, (L.count + 1) * 4u, L.triangles_index, L.count * (unsigned)sizeof(ctl_shape_tri), L.sum_area, L.count };
     ShapeSet s; std::memcpy((void*)&s, &sl, sizeof sl);
@@ -49,7 +55,7 @@ DiffuseLight area_of(const ctl_light& L) {
     if (L.rad_texture.type == CTL_TEX_CHECKER) {
         const ctl_texture& t = L.rad_texture;
         CheckerboardTexture c(spec3(t.value), spec3(t.value1), TextureMapping2D(t.uv_scale[0], t.uv_scale[1], t.uv_offset[0], t.uv_offset[1])); d.m_rad_texture.SetData(c);
-    }
+    } else if (L.rad_texture.type == CTL_TEX_IMAGE) { ImageTexture it = image_of(L.rad_texture); d.m_rad_texture.SetData(it); }
     d.m_bOrthogonal = L.orthogonal != 0;
     return d;
 }
@@ -95,6 +101,28 @@ int ref_scene_light_sample_direct(const ctl_scene_desc* desc, uint32_t light, in
     if (L.type == CTL_LIGHT_DIFFUSE) { const DiffuseLight d = area_of(L); sample_direct(d, n, q, out); return 0; }
     if (L.type == CTL_LIGHT_INFINITE) { const InfiniteLight e = env_of(desc, L); sample_direct(e, n, q, out); return 0; }
     return -1;
+}
+// ImageTexture::Evaluate(uv) / Average() (SceneTypes/Texture.cu:6-13, 32-38) over the scene's images.  q: 2 floats per query; out: 3 floats per query, then 3 for Average()
+int ref_scene_image_texture_eval(const ctl_scene_desc* desc, const ctl_texture* t, int n, const float* q, float* out) {
+    if (t->type != CTL_TEX_IMAGE) return -1;
+    bind_scene(desc); const ImageTexture it = image_of(*t);
+    for (int i = 0; i <= n; i++) {
+        const Spectrum s = i < n ? it.Evaluate(Vec2f(q[2 * i], q[2 * i + 1])) : it.Average();
+        float r, g, b; s.toLinearRGB(r, g, b); out[3 * i] = r; out[3 * i + 1] = g; out[3 * i + 2] = b;
+    }
+    return 0;
+}
+// DiffuseLight::eval(p, frame with normal n, d) — with a radiance texture it finds the triangle again through ShapeSet::getPosition.  q: 9 floats = p(3), n(3), d(3); out: 3 per query
+int ref_scene_light_eval(const ctl_scene_desc* desc, uint32_t light, int n, const float* q, float* out) {
+    bind_scene(desc); const ctl_light& L = desc->lights[light];
+    if (L.type != CTL_LIGHT_DIFFUSE) return -1;
+    const DiffuseLight d = area_of(L);
+    for (int i = 0; i < n; i++) {
+        const float* a = q + 9 * i;
+        const Spectrum s = d.eval(Vec3f(a[0], a[1], a[2]), Frame(NormalizedT<Vec3f>(a[3], a[4], a[5])), NormalizedT<Vec3f>(a[6], a[7], a[8]));
+        float r, g, b; s.toLinearRGB(r, g, b); out[3 * i] = r; out[3 * i + 1] = g; out[3 * i + 2] = b;
+    }
+    return 0;
 }
 // pdfDirect (solid-angle measure) for a direction d seen from ref that meets the emitter at distance dist with emitter normal n
 int ref_scene_light_pdf_direct(const ctl_scene_desc* desc, uint32_t light, int n, const float* q, float* out) {

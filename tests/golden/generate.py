@@ -544,6 +544,7 @@ def scene_light_cases():
     """scenes whose area / environment emitters the reference build samples through the product's own scene description (name -> DynamicScene)"""
     from cudatracerlib_amd import scenes
     return {"cornell": scenes.cornell_box(64, 64), "panel_checker": scenes.area_lights_scene(kind="checker"), "panel_orthogonal": scenes.area_lights_scene(kind="orthogonal"),
+            "panel_image": scenes.area_lights_scene(kind="image"), "panel_orthogonal_image": scenes.area_lights_scene(kind="orthogonal_image"),
             "env": scenes.env_scene(), "env_rotated": scenes.env_scene(rotate_env=True), "bathroom": scenes.synthetic_bathroom(64, 64, n_instances=12, subdiv=1),
             "sm": scenes.synthetic_sm(64, 64, n_instances=20, subdiv=1)}
 
@@ -563,6 +564,8 @@ def gen_scene_lights(r):
     internalSampleDirection / internalPdfDirection (SceneTypes/Light.cu:420-479) of the reference build, over scenes compiled by the product's host code (oracle/ref_scene_light_driver.cpp)"""
     r.ref_scene_light_sample_direct.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
     r.ref_scene_light_pdf_direct.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    r.ref_scene_light_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    r.ref_scene_image_texture_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     rs = np.random.RandomState(20261019)
     out = {}
     for name, sc in scene_light_cases().items():
@@ -586,6 +589,26 @@ def gen_scene_lights(r):
             pdf = np.zeros(n, np.float32)
             assert r.ref_scene_light_pdf_direct(C.addressof(d), li, n, q2.ctypes.data, pdf.ctypes.data) == 0
             out["%s_light%d_q" % (name, li)] = q; out["%s_light%d_sample" % (name, li)] = res; out["%s_light%d_pdf_q" % (name, li)] = q2; out["%s_light%d_pdf" % (name, li)] = pdf
+            if d.lights[li].type == 2:      # DiffuseLight::eval at the sampled emitter points, seen from the reference points (and from behind: every fourth)
+                live = res[:, 3] > 0
+                q3 = np.zeros((int(live.sum()), 9), np.float32); q3[:, :3] = res[live, 8:11]; q3[:, 3:6] = res[live, 11:14]; q3[:, 6:9] = -res[live, 4:7]
+                q3[::4, 6:9] *= -1
+                ev = np.zeros((len(q3), 3), np.float32)
+                if len(q3):
+                    assert r.ref_scene_light_eval(C.addressof(d), li, len(q3), q3.ctypes.data, ev.ctypes.data) == 0
+                out["%s_light%d_eval_q" % (name, li)] = q3; out["%s_light%d_eval" % (name, li)] = ev
+        # ImageTexture::Evaluate(uv) / Average() for every image texture among the scene's materials and lights (SceneTypes/Texture.cu:6-13, 32-38)
+        texs = []
+        for mi in range(d.n_materials):
+            texs += [(("mat%d_tex%d" % (mi, k)), d.materials[mi].tex[k]) for k in range(4) if d.materials[mi].tex[k].type == 4]
+            if d.materials[mi].map_kind != 0 and d.materials[mi].map_tex.type == 4: texs.append(("mat%d_map" % mi, d.materials[mi].map_tex))
+            if d.materials[mi].alpha_state != 0 and d.materials[mi].alpha_tex.type == 4: texs.append(("mat%d_alpha" % mi, d.materials[mi].alpha_tex))
+        texs += [("light%d_rad" % li, d.lights[li].rad_texture) for li in range(d.n_lights_buf) if d.lights[li].type == 2 and d.lights[li].rad_texture.type == 4]
+        for tn, t in texs:
+            uvq = rs.uniform(-1.5, 2.5, size=(192, 2)).astype(np.float32); uvq[0] = [0, 0]; uvq[1] = [1, 1]; uvq[2] = [0.5, 0.5]; uvq[3] = [-0.25, 1.75]
+            tv = np.zeros((193, 3), np.float32)
+            assert r.ref_scene_image_texture_eval(C.addressof(d), C.byref(t), 192, uvq.ctypes.data, tv.ctypes.data) == 0, (name, tn)
+            out["%s_%s_uv" % (name, tn)] = uvq; out["%s_%s_value" % (name, tn)] = tv
     np.savez_compressed(os.path.join(HERE, "scene_lights.npz"), **out)
 
 
