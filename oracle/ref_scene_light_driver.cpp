@@ -92,6 +92,8 @@ template <class LT> void pdf_direct(const LT& light, int n, const float* q, floa
 }
 }  // namespace
 
+void ref_bind_scene(const ctl_scene_desc* d) { bind_scene(d); }   // for ref_material_driver.cpp: the same binding of g_SceneData
+
 extern "C" {
 
 // sampleDirect of light `light` of the scene (area or environment light).  q: 8 floats per query = {ref(3), refN(3), sample(2)}; out: 14 floats per query

@@ -612,6 +612,83 @@ def gen_scene_lights(r):
     np.savez_compressed(os.path.join(HERE, "scene_lights.npz"), **out)
 
 
+def material_map_cases():
+    """scenes whose materials carry normal / height / alpha maps (name -> DynamicScene), and hand-made materials without a scene (name -> ctl_material)"""
+    from cudatracerlib_amd import scenes, api
+    sc = {"maps_normal_luminance": scenes.maps_scene(32, 24, "normal", "luminance"), "maps_height_alpha": scenes.maps_scene(32, 24, "height", "alpha"),
+          "maps_none_color": scenes.maps_scene(32, 24, None, "color"), "bathroom": scenes.synthetic_bathroom(64, 64, n_instances=12, subdiv=1)}
+    hand = {"normal_constant": api.set_normal_map(api.diffuse(), (0.8, 0.4, 0.9)), "normal_flat": api.set_normal_map(api.diffuse(), (0.5, 0.5, 1.0)),
+            "normal_checker": api.set_normal_map(api.diffuse(), api.checker_texture((0.6, 0.5, 0.9), (0.4, 0.55, 0.8), uv_scale=(3.0, 2.0))),
+            "height_constant": api.set_height_map(api.diffuse(), 0.7), "plain": api.diffuse(),
+            "alpha_checker_luminance": api.set_alpha_map(api.diffuse(), api.checker_texture(1.0, 0.0, uv_scale=(2.0, 5.0)), api.ALPHA_MAP_LUMINANCE, 0.5),
+            "alpha_constant_color": api.set_alpha_map(api.diffuse(), (0.2, 0.4, 0.6), api.ALPHA_MAP_COLOR, 0.15, (0.3, 0.3, 0.6)),
+            "alpha_checker_color": api.set_alpha_map(api.diffuse(), api.checker_texture((0.9, 0.1, 0.1), (0.1, 0.1, 0.9), uv_scale=(3.0, 3.0)), api.ALPHA_MAP_COLOR, 0.25, (1.0, 0.0, 0.0)),
+            "alpha_reflectance_luminance_bright": api.set_alpha_map(api.diffuse((0.9, 0.9, 0.9)), 0.0, api.ALPHA_REFLECTANCE_LUMINANCE, 0.5),
+            "alpha_reflectance_luminance_dark": api.set_alpha_map(api.diffuse((0.1, 0.1, 0.1)), 1.0, api.ALPHA_REFLECTANCE_LUMINANCE, 0.5),
+            "alpha_reflectance_checker_color": api.set_alpha_map(api.diffuse(api.checker_texture((0.8, 0.2, 0.2), (0.2, 0.2, 0.8), uv_scale=(2.0, 2.0))), 0.0, api.ALPHA_REFLECTANCE_COLOR, 0.3, (0.8, 0.2, 0.2)),
+            "alpha_mode_on_constant": api.set_alpha_map(api.diffuse(), 0.0, api.ALPHA_MAP_ALPHA, 0.5)}
+    return sc, hand
+
+
+def material_map_queries(rs, n):
+    """n shading points for Material::SampleNormalMap: uv, an orthonormal shading frame, a geometric normal near it (every eighth: on the other side), dpdu / dpdv near the tangents"""
+    q = np.zeros((n, 20), np.float32)
+    q[:, :2] = rs.uniform(-0.5, 2.5, size=(n, 2)); q[0, :2] = [0, 0]; q[1, :2] = [1, 1]; q[2, :2] = [0.5, 0.5]
+    for i in range(n):
+        f, _ = np.linalg.qr(rs.normal(size=(3, 3)))
+        if np.linalg.det(f) < 0:
+            f[:, 2] = -f[:, 2]
+        s, t, nn = f[:, 0], f[:, 1], f[:, 2]
+        if i < 4:
+            s, t, nn = np.array([1.0, 0, 0]), np.array([0, 0, -1.0]), np.array([0, 1.0, 0])
+        g = nn + 0.2 * rs.normal(size=3); g /= np.linalg.norm(g)
+        if i % 8 == 7:
+            g = -g
+        q[i, 2:5], q[i, 5:8], q[i, 8:11], q[i, 11:14] = s, t, nn, g
+        q[i, 14:17] = s * rs.uniform(0.2, 5) + 0.1 * rs.normal(size=3); q[i, 17:20] = t * rs.uniform(0.2, 5) + 0.1 * rs.normal(size=3)
+    return q
+
+
+def material_map_digest(d):
+    """what the reference's outputs depend on: the materials and the images' level-0 texels of the description"""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(C.string_at(d.materials, d.n_materials * C.sizeof(type(d.materials.contents))))
+    for i in range(d.n_images):
+        m = d.images[i]; h.update(C.string_at(m.texels, m.width * m.height * 4)); h.update(bytes([m.texel_type, m.wrap_mode, m.filter_mode]))
+    return h.hexdigest()
+
+
+def gen_material_maps(r):
+    """Material::SampleNormalMap / AlphaTest of the reference build (Engine/Material.cu, compiled whole; oracle/ref_material_driver.cpp) over the product's materials"""
+    r.ref_material_sample_normal_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    r.ref_material_alpha_test.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rs = np.random.RandomState(20261101)
+    out = {}
+    scs, hand = material_map_cases()
+
+    def run(key, desc_addr, mat):
+        if mat.map_kind != 0 or key.endswith("plain"):
+            q = material_map_queries(rs, 256); res = np.zeros((256, 10), np.float32)
+            assert r.ref_material_sample_normal_map(desc_addr, C.byref(mat), 256, q.ctypes.data, res.ctypes.data) == 0
+            out[key + "_frame_q"] = q; out[key + "_frame"] = res
+        if mat.alpha_state != 0 or key.endswith("plain"):
+            q = rs.uniform(-0.5, 2.5, size=(1024, 4)).astype(np.float32); q[:, :2] = rs.dirichlet([1, 1, 1], size=1024)[:, :2]
+            q[0, 2:] = [0, 0]; q[1, 2:] = [1, 1]; q[2, 2:] = [0.5, 0.5]; q[3, 2:] = [0.25, 0.75]
+            res = np.zeros(1024, np.int32)
+            assert r.ref_material_alpha_test(desc_addr, C.byref(mat), 1024, q.ctypes.data, res.ctypes.data) == 0
+            out[key + "_alpha_q"] = q; out[key + "_alpha"] = res
+    for name, sc in scs.items():
+        d = sc.desc
+        out[name + "_digest"] = np.frombuffer(material_map_digest(d).encode(), np.uint8).copy()
+        for mi in range(d.n_materials):
+            run("%s_mat%d" % (name, mi), C.addressof(d), d.materials[mi])
+    for name, m in hand.items():
+        out["hand_" + name + "_bytes"] = np.frombuffer(C.string_at(C.addressof(m), C.sizeof(m)), np.uint8).copy()
+        run("hand_" + name, None, m)
+    np.savez_compressed(os.path.join(HERE, "material_maps.npz"), **out)
+
+
 def spline_cases():
     """inputs of spline.npz: tables of 2..32 knots per axis, query points inside, exactly on knots, at 0 and 1, just outside [0, 1] and NaN (own random stream)"""
     rs = np.random.RandomState(20260941)
@@ -755,6 +832,8 @@ if __name__ == "__main__":
         gen_spline(oracle.load_ref())
         gen_bsdf_rough(oracle.load_ref())
         gen_scene_lights(oracle.load_ref())
+    elif sys.argv[1:] == ["material_maps"]:
+        gen_material_maps(oracle.load_ref())
     elif sys.argv[1:] == ["traceray"]:      # only this fixture (the others stay byte-identical)
         gen_traceray(oracle.load_ref())
     else:
@@ -768,3 +847,4 @@ if __name__ == "__main__":
         gen_spline(oracle.load_ref())
         gen_bsdf_rough(oracle.load_ref())
         gen_scene_lights(oracle.load_ref())
+        gen_material_maps(oracle.load_ref())

@@ -1,8 +1,8 @@
 """Material maps of the oracle: Material::SampleNormalMap (normal / height map, Engine/Material.cu:96-138), Material::AlphaTest
 (:141-190) and the alpha test inside single-ray traversal (Kernel/TraceHelper.cu:135-153).
 
-Material.cu needs Texture / KernelMIPMap / g_SceneData, so it is not part of oracle/_ref; the restatement is pinned by closed
-forms: a flat normal-map texel leaves the frame alone, a tilted one gives toWorld(c - 0.5); a height ramp gives the analytic
+Since round 5 Engine/Material.cu itself is part of oracle/_ref and tests/test_oracle_golden.py holds the restatement on it bit for bit
+(tests/golden/material_maps.npz); the closed forms here say what the functions MEAN: a flat normal-map texel leaves the frame alone, a tilted one gives toWorld(c - 0.5); a height ramp gives the analytic
 normal of the displaced plane; the alpha tests are threshold functions of hand-made textures; rays through the holes of an
 alpha-mapped card reach the wall behind it.
 """
