@@ -392,7 +392,9 @@ def fresnel_diffuse_reflectance(eta):
 
 
 def material_update(m):
-    """BSDF::Update(): the derived fields (fdrInt / fdrExt, invEta2, sampling weights) from the primary ones, by the library (ctl_material_update)"""
+    """BSDF::Update(): the derived fields (fdrInt / fdrExt, invEta2, sampling weights) from the primary ones, by the library (ctl_material_update).  A weight that comes
+    from the average of an IMAGE texture is final only after DynamicScene.UpdateScene (ctl_builder_finalize), when the bitmap is there — as in the reference, whose
+    UpdateMaterialsPhase2 runs Update() after the textures are loaded (Engine/DynamicScene.cpp:74-89)."""
     _check(lib.ctl_material_update(C.byref(m)))
     return m
 
@@ -400,7 +402,7 @@ def material_update(m):
 def plastic(diffuse_reflectance=(0.5, 0.5, 0.5), int_ior=1.49, ext_ior=1.000277, specular_reflectance=1.0, nonlinear=False):
     """plastic(eta, diffuse, specular) — BSDF_Simple.h:234-270 incl. Update(): fdrInt/fdrExt, invEta2, specularSamplingWeight."""
     m = _material(8, E["DeltaReflection"] | E["DiffuseReflection"])
-    m.tex[0], m.tex[1] = _const_tex(diffuse_reflectance), _const_tex(specular_reflectance)
+    m.tex[0], m.tex[1] = _as_tex(diffuse_reflectance), _as_tex(specular_reflectance)
     m.f[2] = float(np.float32(np.float32(int_ior) / np.float32(ext_ior)))
     m.u[0] = 1 if nonlinear else 0
     return material_update(m)
@@ -409,7 +411,7 @@ def plastic(diffuse_reflectance=(0.5, 0.5, 0.5), int_ior=1.49, ext_ior=1.000277,
 def phong(diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(0.2, 0.2, 0.2), exponent=30.0):
     """phong(diffuse, specular, exponent) — BSDF_Simple.h:313-340; specularSamplingWeight = sAvg / (dAvg + sAvg)."""
     m = _material(10, E["GlossyReflection"] | E["DiffuseReflection"])
-    m.tex[0], m.tex[1], m.tex[2] = _const_tex(diffuse_reflectance), _const_tex(specular_reflectance), _const_tex(exponent)
+    m.tex[0], m.tex[1], m.tex[2] = _as_tex(diffuse_reflectance), _as_tex(specular_reflectance), _as_tex(exponent)
     return material_update(m)
 
 

@@ -7,6 +7,7 @@
 #include "mitsuba_loader.h"
 #include "flatten.h"
 #include "material_factory.h"
+#include "material_textures.h"
 #include "image_io.h"
 #include <memory>
 #include "scene_cache.h"
@@ -103,7 +104,9 @@ int ctl_builder_set_camera_lookat(ctl_builder* b, const float pos[3], const floa
 int ctl_builder_set_camera(ctl_builder* b, const ctl_sensor* sensor) { CTL_REQUIRE(b && sensor, "null argument"); CTL_TRY b->b.set_camera(*sensor); CTL_CATCH }
 int ctl_builder_finalize(ctl_builder* b, ctl_scene_desc* out) { CTL_REQUIRE(b && out, "null argument"); CTL_TRY b->b.finalize(*out); CTL_CATCH }
 
-int ctl_material_update(ctl_material* m) { CTL_REQUIRE(m, "null argument"); CTL_REQUIRE(material_update(*m), "unknown bsdf_type"); return CTL_OK; }
+int ctl_material_update(ctl_material* m) {   // (a weight from an IMAGE texture's average is final after ctl_builder_finalize, material_textures.h)
+    CTL_REQUIRE(m, "null argument"); CTL_REQUIRE(material_update(*m), "unknown bsdf_type"); material_update_textures(*m, image_set()); return CTL_OK;
+}
 float ctl_fresnel_diffuse_reflectance(float eta) { return fresnel_diffuse_reflectance(eta); }
 // ---- the shared transcendental functions (ctl_fmath.h), evaluated on the host or by a kernel: the parity tests hold the two bit-identical
 __global__ void k_shared_math(int which, int n, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out) {

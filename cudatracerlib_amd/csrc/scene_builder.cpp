@@ -3,6 +3,7 @@
 // KernelDynamicScene arrays (Engine/KernelDynamicScene.h:28-109) as a ctl_scene_desc.
 #include "scene_builder.h"
 #include "scene_cache.h"
+#include "material_textures.h"
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -537,6 +538,11 @@ void scene_builder::finalize(ctl_scene_desc& out) {
     for (int i = 0; i < 3; i++) { out.box_min[i] = scene.lo[i]; out.box_max[i] = scene.hi[i]; }
     for (size_t i = 0; i < images.size(); i++) images[i].texels = image_texels[i].data();
     out.images = images.data(); out.n_images = (uint32_t)images.size();
+    {   // BSDF::Update() now that every image is there (MaterialStream::UpdateMaterialsPhase2 after LoadTextures, Engine/DynamicScene.cpp:74-89): the sampling weights that come
+        // from the average of an IMAGE texture were made with the bitmap counted as white (material_textures.h)
+        image_set I; I.images = images.data(); I.n = (uint32_t)images.size();
+        for (auto& m : mats) material_update_textures(m, I);
+    }
     for (int i = 0; i < 3; i++) { rt[i].trans = rt_trans[i].empty() ? nullptr : rt_trans[i].data(); rt[i].diff_trans = rt_diff[i].empty() ? nullptr : rt_diff[i].data(); }
     out.rough_transmittance = have_rt ? rt : nullptr;
     {   // the light that depends on the scene box: InfiniteLight::Update (SceneTypes/Light.h:318-325)

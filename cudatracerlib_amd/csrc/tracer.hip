@@ -7,6 +7,7 @@
 #include "image_io.h"
 #include "mitsuba_loader.h"   // unsupported_error
 #include "spline.h"
+#include "mip_pyramid.h"
 #include <algorithm>
 #include <thread>
 #include <cctype>
@@ -87,29 +88,12 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
         std::vector<uint32_t> pool;
         std::vector<size_t> off(d.n_images);
         std::vector<dev_mip_levels> lv(std::max<uint32_t>(1, d.n_images));
-        auto decode = [](uint32_t v, uint32_t type, float c[3]) {
-            const uint32_t x = v & 0xff, y = (v >> 8) & 0xff, z = (v >> 16) & 0xff, w = v >> 24;
-            if (type == CTL_TEXEL_RGBE) { if (!w) { c[0] = c[1] = c[2] = 0; return; } const float e = std::ldexp(1.0f, (int)w - (128 + 8)); c[0] = x * e; c[1] = y * e; c[2] = z * e; }
-            else { c[0] = float(x) / 255.0f; c[1] = float(y) / 255.0f; c[2] = float(z) / 255.0f; }
-        };
+        static_assert(sizeof(mip_level_table) == sizeof(dev_mip_levels), "one layout");
         for (uint32_t i = 0; i < d.n_images; i++) {
             const ctl_mipmap& m = d.images[i];
             if (!m.texels || !m.width || !m.height) throw std::runtime_error("ctl_scene_create: empty image");
-            off[i] = pool.size(); pool.insert(pool.end(), m.texels, m.texels + (size_t)m.width * m.height);
-            dev_mip_levels& L = lv[i]; std::memset(&L, 0, sizeof(L)); L.levels = 1;
-            for (uint32_t mn = std::min(m.width, m.height); (mn >>= 1) && L.levels < 16;) L.levels++;
-            uint32_t o = m.width * m.height, pw = m.width; size_t prev = off[i];
-            for (uint32_t l = 1, j = m.width / 2, k = m.height / 2; l < L.levels; l++, j >>= 1, k >>= 1) {
-                L.offsets[l - 1] = o; pool.resize(off[i] + o + (size_t)j * k);
-                for (uint32_t t = 0; t < k; t++) for (uint32_t x = 0; x < j; x++) {
-                    float a[3], b[3], c[3], e[3];
-                    decode(pool[prev + (size_t)(2 * t) * pw + 2 * x], m.texel_type, a); decode(pool[prev + (size_t)(2 * t) * pw + 2 * x + 1], m.texel_type, b);
-                    decode(pool[prev + (size_t)(2 * t + 1) * pw + 2 * x], m.texel_type, c); decode(pool[prev + (size_t)(2 * t + 1) * pw + 2 * x + 1], m.texel_type, e);
-                    float v[3]; for (int q = 0; q < 3; q++) { float s2 = a[q] + b[q]; s2 = s2 + c[q]; s2 = s2 + e[q]; v[q] = 0.25f * s2; }
-                    pool[off[i] + o + (size_t)t * j + x] = m.texel_type == CTL_TEXEL_RGBE ? float3_to_rgbe(v[0], v[1], v[2]) : float3_to_rgbcol(v[0], v[1], v[2]);
-                }
-                prev = off[i] + o; pw = j; o += j * k;
-            }
+            mip_level_table L; off[i] = mip_pyramid_append(m, pool, L);   // mip_pyramid.h
+            std::memcpy(&lv[i], &L, sizeof(L));
         }
         if (!pool.empty()) texels_.upload(pool.data(), pool.size()); else texels_.alloc(4);
         std::vector<ctl_mipmap> tab(d.n_images);

@@ -930,3 +930,104 @@ def synthetic_sm_hard(directory, width=1920, height=1080, **kw):
     if not os.path.exists(xml):
         write_sm_hard_mitsuba(directory, width, height, **kw)
     return load_mitsuba(xml, width, height)
+
+
+def fuzz_scene(seed, width=48, height=32):
+    """A seeded RANDOM scene for the parity fuzz tests (tests/test_gpu_fuzz.py, tests/test_oracle_fuzz.py): a floor (bitmap, checker or plain) and up to two walls, 8-20 instances
+    of spheres / boxes under random affine transforms — rotation x non-uniform scale, one in four MIRRORED (negative determinant), one in five sheared —, materials drawn from all
+    fourteen BSDF models with random parameters (both microfacet distributions, visible-normal sampling on and off, anisotropy, nested models under coatings and blends, textures
+    in every slot that takes one, a normal or height map now and then), and one to three emitters of the five kinds (area with constant / checker radiance, point, spot,
+    distant, environment map plain or rotated).  Everything comes from RandomState(seed): the same seed is the same scene on every box."""
+    from . import rough_tables
+    rs = np.random.RandomState(1000 + seed)
+    sc = api.DynamicScene()
+    for slot in (0, 1):
+        tr, df, er, ar = rough_tables.make_table(slot, n_eta=4, n_alpha=4, n_theta=8, quad=12)
+        sc.setRoughTransmittance(slot, tr, df, er, ar)
+    tiles = sc.add_image(checker_image(), api.TEXEL_RGBCOL, api.WRAP_REPEAT, api.FILTER_BILINEAR if seed % 2 else api.FILTER_POINT)
+    bumps = sc.add_image(api.float3_to_rgbcol(bump_image(32, seed=seed)), api.TEXEL_RGBCOL, api.WRAP_REPEAT, api.FILTER_BILINEAR)
+    nmap = sc.add_image(api.float3_to_rgbcol(normal_image(32)), api.TEXEL_RGBCOL, api.WRAP_REPEAT, api.FILTER_BILINEAR)
+
+    def colour(lo=0.05, hi=0.9):
+        return tuple(float(x) for x in rs.uniform(lo, hi, size=3))
+
+    def texture():
+        k = rs.randint(4)
+        if k == 0:
+            return api.image_texture(tiles, scale=colour(0.4, 1.0), uv_scale=(float(rs.choice([1.0, 2.0, 5.0])),) * 2)
+        if k == 1:
+            return api.checker_texture(colour(), colour(), uv_scale=(float(rs.choice([2.0, 4.0])), float(rs.choice([2.0, 3.0]))))
+        return colour()
+
+    def simple(kind=None):
+        kind = rs.randint(11) if kind is None else kind
+        a = float(rs.uniform(0.03, 0.5)); dist = int(rs.randint(2)); vis = bool(rs.randint(2))
+        if kind == 0: return api.diffuse(texture(), two_sided=bool(rs.randint(2)))
+        if kind == 1: return api.roughdiffuse(texture(), alpha=a, use_fast_approx=bool(rs.randint(2)))
+        if kind == 2: return api.dielectric(int_ior=float(rs.uniform(1.2, 1.8)), ext_ior=1.0)
+        if kind == 3: return api.thindielectric(int_ior=float(rs.uniform(1.2, 1.8)), ext_ior=1.0)
+        if kind == 4: return api.roughdielectric(alpha=a, int_ior=float(rs.uniform(1.2, 1.8)), ext_ior=1.0, distribution=dist, sample_visible=vis, alpha_v=(float(rs.uniform(0.03, 0.5)) if rs.randint(3) == 0 else None))
+        if kind == 5: return api.conductor(eta=colour(0.1, 1.5), k=colour(1.5, 4.0))
+        if kind == 6: return api.roughconductor(alpha=a, eta=colour(0.1, 1.5), k=colour(1.5, 4.0), distribution=dist, sample_visible=vis, alpha_v=(float(rs.uniform(0.03, 0.5)) if rs.randint(3) == 0 else None))
+        if kind == 7: return api.plastic(texture(), int_ior=float(rs.uniform(1.3, 1.7)), ext_ior=1.0, nonlinear=bool(rs.randint(2)))
+        if kind == 8: return api.roughplastic(texture(), alpha=a, int_ior=float(rs.uniform(1.3, 1.7)), ext_ior=1.0, distribution=dist, nonlinear=bool(rs.randint(2)))
+        if kind == 9: return api.phong(colour(0.1, 0.6), colour(0.05, 0.35), exponent=float(rs.uniform(5, 120)))
+        return api.ward(colour(0.1, 0.6), colour(0.05, 0.35), alpha_u=float(rs.uniform(0.05, 0.4)), alpha_v=float(rs.uniform(0.05, 0.4)), variant=int(rs.randint(3)))
+
+    def material():
+        k = rs.randint(14)
+        if k < 11:
+            m = simple(k)
+        elif k == 11:
+            n = simple(int(rs.choice([0, 6, 9]))); m = api.coating(sc.add_material(n), n, int_ior=1.5, ext_ior=1.0, thickness=float(rs.uniform(0.2, 2.0)), sigma_a=colour(0.0, 1.0))
+        elif k == 12:
+            n = simple(int(rs.choice([0, 6, 1]))); m = api.roughcoating(sc.add_material(n), n, alpha=float(rs.uniform(0.05, 0.3)), int_ior=1.5, ext_ior=1.0, thickness=float(rs.uniform(0.2, 2.0)), sigma_a=colour(0.0, 1.0), distribution=int(rs.randint(2)))
+        else:
+            n0, n1 = simple(int(rs.choice([0, 7, 9]))), simple(int(rs.choice([5, 6, 10]))); m = api.blend(sc.add_material(n0), n0, sc.add_material(n1), n1, weight=float(rs.uniform(0.2, 0.8)))
+        r = rs.randint(8)
+        if r == 0 and k not in (2, 3): api.set_normal_map(m, api.image_texture(nmap, uv_scale=(3.0, 3.0)))
+        elif r == 1 and k not in (2, 3): api.set_height_map(m, api.image_texture(bumps, scale=(0.05, 0.05, 0.05), uv_scale=(2.0, 2.0)))
+        return m
+
+    P, I, N = _quad([[-10, 0, -10], [-10, 0, 10], [10, 0, 10], [10, 0, -10]], [0, 1, 0])
+    sc.CreateNode(sc.add_mesh(P, I, normals=N, uvs=np.array([[0, 0], [0, 4], [4, 4], [4, 0]], np.float32), materials=[simple(int(rs.choice([0, 1, 7, 8])))]))
+    for p, n in ((([-10, 0, -10], [10, 0, -10], [10, 9, -10], [-10, 9, -10]), [0, 0, 1]), (([-10, 0, 10], [-10, 0, -10], [-10, 9, -10], [-10, 9, 10]), [1, 0, 0]))[:rs.randint(3)]:
+        Pq, Iq, Nq = _quad([list(x) for x in p], n)
+        sc.CreateNode(sc.add_mesh(Pq, Iq, normals=Nq, uvs=np.array([[0, 0], [2, 0], [2, 1], [0, 1]], np.float32), materials=[simple(int(rs.choice([0, 1, 9])))]))
+    V, F = icosphere(2)
+    uv_s = np.stack([np.arctan2(V[:, 2], V[:, 0]) / (2 * np.pi) + 0.5, np.arccos(np.clip(V[:, 1], -1, 1)) / np.pi], axis=1).astype(np.float32)
+    Pb, Ib, Nb = unit_box()
+    uv_b = (Pb[:, [0, 2]] * 0.5 + 0.5).astype(np.float32)
+    for i in range(rs.randint(8, 21)):
+        m = material()
+        mesh = sc.add_mesh(V, F, normals=V, uvs=uv_s, materials=[m]) if rs.randint(3) else sc.add_mesh(Pb, Ib, normals=Nb, uvs=uv_b, materials=[m])
+        A = _rotation(rs) @ np.diag(rs.uniform(0.5, 1.6, size=3))
+        if rs.randint(4) == 0: A = A @ np.diag([1.0, 1.0, -1.0])           # mirrored instance
+        if rs.randint(5) == 0: A = A @ np.array([[1, 0.4, 0], [0, 1, 0], [0, 0.3, 1.0]])   # sheared instance
+        xf = np.eye(4); xf[:3, :3] = A; xf[:3, 3] = [rs.uniform(-7, 7), rs.uniform(0.8, 4.5), rs.uniform(-7, 6)]
+        sc.CreateNode(mesh, xf.astype(np.float32))
+    kinds = list(rs.choice(5, size=rs.randint(1, 4), replace=False))
+    for k in kinds:
+        if k == 0:
+            P, I, N = _quad([[-2.5, 8.9, -2], [2.5, 8.9, -2], [2.5, 8.9, 2], [-2.5, 8.9, 2]], [0, -1, 0])
+            lm = sc.add_mesh(P, I, normals=N, uvs=np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32), materials=[api.diffuse((0.5, 0.5, 0.5))])
+            rt = api.checker_texture((1.0, 0.9, 0.8), (0.2, 0.3, 0.9), uv_scale=(3.0, 2.0)) if rs.randint(2) else None
+            sc.CreateLight(sc.CreateNode(lm), 0, tuple(float(x) for x in rs.uniform(10, 40, size=3)), rad_texture=rt)
+        elif k == 1:
+            sc.CreatePointLight((float(rs.uniform(-5, 5)), float(rs.uniform(3, 8)), float(rs.uniform(-5, 5))), tuple(float(x) for x in rs.uniform(30, 120, size=3)))
+        elif k == 2:
+            sc.CreateSpotLight((float(rs.uniform(-6, 6)), 8.0, float(rs.uniform(-3, 8))), (float(rs.uniform(-2, 2)), 0.0, float(rs.uniform(-2, 2))), tuple(float(x) for x in rs.uniform(200, 500, size=3)),
+                               cutoff_angle=float(rs.uniform(15, 40)), beam_width=float(rs.uniform(5, 14)))
+        elif k == 3:
+            d = rs.normal(size=3); d[1] = abs(d[1]) + 0.5; d /= np.linalg.norm(d)
+            sc.CreateDistantLight(tuple(float(x) for x in d), tuple(float(x) for x in rs.uniform(0.8, 2.5, size=3)), scene_radius=1.0)
+        else:
+            env = sc.add_image(procedural_envmap(), api.TEXEL_RGBE, api.WRAP_REPEAT, api.FILTER_BILINEAR)
+            T = None
+            if rs.randint(2):
+                a = float(rs.uniform(0, 6.28)); c, s = np.cos(a), np.sin(a)
+                T = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], np.float32)
+            sc.setEnvironementMap(env, (1.0, 1.0, 1.0), T)
+    sc.setCamera((float(rs.uniform(-3, 3)), float(rs.uniform(3, 7)), float(rs.uniform(11, 15))), (0.0, 2.0, 0.0), (0, 1, 0), float(rs.uniform(40, 65)), width, height)
+    sc.UpdateScene()
+    return sc
