@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--tracer-param", action="append", default=[], metavar="KEY=VALUE")
     ap.add_argument("--no-cache", action="store_true", help="do not use the compiled-geometry cache ($CTL_CACHE_DIR, default $TMPDIR/ctl_amd_cache)")
     ap.add_argument("--flatten", type=int, default=1, help="traverse one world-space BVH over all instanced triangles (64 B of HBM per triangle)")
+    ap.add_argument("--reduced-rough-transmittance", action="store_true", help="CTL_SCENE_REDUCED_ROUGH_TRANSMITTANCE: rough plastic through the per-material 1-D reduction of the transmittance table (faster; equal to the reference's lookup up to fp32 rounding only)")
     ap.add_argument("--flat-format", default=None, choices=["q4", "q8"], help="node format of the flattened BVH (default: the library's)")
     ap.add_argument("--dump-frame", default=None, metavar="FILE.npy", help="rank 0 saves the reduced PixelData frame (h, w, 7) after the timed region (tests compare N-rank and 1-rank frames)")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("CTL_BENCH_LAUNCH_TIMEOUT", "1500")), help="N > 1: seconds from the spawn after which the launcher ends every rank and reports which ones were stuck")
@@ -315,7 +316,7 @@ def main():
         dist.barrier()                      # rank 0 compiles and fills the cache first
     sc, scene_source = build_scene(args, rank, dist.barrier if (multi and (args.via_loader or args.workload == "synthetic-sm-hard")) else None)
     desc = sc.desc
-    scene = ctl.Scene(desc, flatten=bool(args.flatten), flat_format=args.flat_format)
+    scene = ctl.Scene(desc, flatten=bool(args.flatten), flat_format=args.flat_format, reduced_rough_transmittance=args.reduced_rough_transmittance)
     if multi and rank == 0 and not args.no_cache:
         dist.barrier()
     t_build = time.perf_counter() - t_build
@@ -560,6 +561,7 @@ def main():
                        ("%s %dx%d depth %d, %d instanced triangles" % (args.workload, args.width, args.height, args.depth, int(_instanced_tris(desc)))),
                        "bvh": "flattened world-space BVH4 (64 B nodes with 8-bit quantised child boxes; 128 B leaf entries evaluated with the reference's object-space arithmetic; triangles much longer than their neighbours entered as several references; BVH2 re-optimised by reinsertion before the collapse)" if args.flatten else "two-level (scene BVH + instanced mesh BVHs)",
                        "scene_source": scene_source,
+                       "rough_transmittance": "per-material 1-D reduction (CTL_SCENE_REDUCED_ROUGH_TRANSMITTANCE: equal to the reference's lookup up to fp32 rounding)" if args.reduced_rough_transmittance else "the reference's 3-D lookup on every call (bit-equal frames)",
                        "parallelism": "image tiles 64x64 round-robin over %d GPU(s), 1 gather of the framebuffer per render" % world, "framebuffer_reduce": reduce_kind,
                        "rays_per_step": int(rays / args.steps), "scene_build_s": round(t_build, 2)},
             "roofline": roof,

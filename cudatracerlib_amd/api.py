@@ -631,11 +631,12 @@ class DynamicScene:
 class Scene:
     """The scene resident in HBM (UpdateKernel, Kernel/TraceHelper.cu:182-217)."""
 
-    def __init__(self, desc, flatten=False, flat_format=None):
-        """flat_format: None = the library default (Q4, or $CTL_FLAT_FORMAT), else FLAT_Q4 / FLAT_F4 / FLAT_F2 or one of the strings q4 / f4 / f2"""
+    def __init__(self, desc, flatten=False, flat_format=None, reduced_rough_transmittance=False):
+        """flat_format: None = the library default (Q4, or $CTL_FLAT_FORMAT), else FLAT_Q4 / FLAT_F4 / FLAT_F2 or one of the strings q4 / f4 / f2.
+        reduced_rough_transmittance: CTL_SCENE_REDUCED_ROUGH_TRANSMITTANCE (faster rough plastic, equal to the reference's lookup up to rounding only)"""
         self._h = C.c_void_p()
         self._keepalive = desc
-        flags = 1 if flatten else 0
+        flags = (1 if flatten else 0) | (2 if reduced_rough_transmittance else 0)
         if flat_format is not None:
             flags |= (FLAT_FORMATS.get(flat_format, flat_format) + 1) << 8
         _check(lib.ctl_scene_create_ex(C.byref(desc), u32(flags), C.byref(self._h)))

@@ -19,7 +19,7 @@
 using namespace ctl;
 
 struct ctl_builder { scene_builder b; };
-struct ctl_scene { Scene s; ctl_scene(const ctl_scene_desc& d, bool flatten, int fmt = -1) : s(d, flatten, fmt) {} };
+struct ctl_scene { Scene s; ctl_scene(const ctl_scene_desc& d, bool flatten, int fmt = -1, bool reduced_rt = false) : s(d, flatten, fmt, reduced_rt) {} };
 struct ctl_flat_bvh { flat_scene f; };
 struct ctl_image { Image img; ctl_image(uint32_t w, uint32_t h) : img(w, h) {} };
 struct ctl_tracer { std::unique_ptr<TracerBase> t; };
@@ -151,7 +151,7 @@ int ctl_traversal_stack_histogram(uint64_t* out, uint32_t n_bins, int reset) {
 int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY *out = new ctl_scene(*desc, false); CTL_CATCH }
 int ctl_scene_create_ex(const ctl_scene_desc* desc, uint32_t flags, ctl_scene** out) { CTL_REQUIRE(desc && out, "null argument"); CTL_TRY
     const uint32_t fmt = (flags >> 8) & 7u;   // 0: default, else CTL_FLAT_* + 1
-    *out = new ctl_scene(*desc, (flags & CTL_SCENE_FLATTEN) != 0, (int)fmt - 1);
+    *out = new ctl_scene(*desc, (flags & CTL_SCENE_FLATTEN) != 0, (int)fmt - 1, (flags & CTL_SCENE_REDUCED_ROUGH_TRANSMITTANCE) != 0);
 CTL_CATCH }
 void ctl_scene_destroy(ctl_scene* s) { delete s; }
 int ctl_set_cache_dir(const char* dir) { CTL_TRY set_cache_dir(dir); CTL_CATCH }

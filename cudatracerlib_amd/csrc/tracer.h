@@ -36,7 +36,7 @@ class Scene {
 public:
     // flatten: also build the single-level world-space BVH (flatten.cpp) and make the intersect kernels use it
     // flat_format: flat_format of flatten.h, or -1 for the default (Q4 / $CTL_FLAT_FORMAT)
-    explicit Scene(const ctl_scene_desc& d, bool flatten = false, int flat_format = -1);
+    explicit Scene(const ctl_scene_desc& d, bool flatten = false, int flat_format = -1, bool reduced_rough_transmittance = false);
     bool flattened() const { return S.flat_nodes != nullptr; }
     dev_scene S{};
     uint32_t n_nodes = 0;

@@ -24,7 +24,7 @@ int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 
 void require_device() { if (device_count() <= 0) throw hip_error("no HIP device: the MI355X path tracer has no CPU fallback"); apply_tuning_from_env(); }
 
 // ------------------------------------------------------------------------------------------------ Scene
-Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
+Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format, bool reduced_rough_transmittance) {
     for (int k = 0; k < 3; k++) { box_min[k] = d.box_min[k]; box_max[k] = d.box_max[k]; }
     near_depth = d.camera.near_depth; far_depth = d.camera.far_depth;
     require_device();
@@ -124,9 +124,6 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
             S.rough_transmittance = rt_.p;
         }
     }
-    // Rough plastics with a CONSTANT roughness texture look the transmittance table up at fixed (alpha, eta): reduce the 3-D cubic interpolation
-    // (64 taps per lookup, three to five lookups per shaded vertex) to a 1-D table in cos(theta) once, here.  Same spline weights
-    // (Math/Spline.cu:223-453 via RoughTransmittance.cu:55-119), summed alpha / eta first instead of last: equal up to fp32 rounding.
     S.rt_reduced = nullptr;
     if (d.rough_transmittance) {
         std::vector<float> pool; size_t off_t[3] = {}, off_d[3] = {};
@@ -148,8 +145,13 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format) {
     // Rough plastics with a CONSTANT roughness texture look the transmittance table up at fixed (alpha, eta): reduce the 3-D cubic interpolation
     // (64 taps per lookup, three to five lookups per shaded vertex) to a 1-D table in cos(theta) once, here.  Same spline weights
     // (Math/Spline.cu:223-453 via RoughTransmittance.cu:55-119), summed alpha / eta first instead of last: equal up to fp32 rounding.
+    // CTL_SCENE_REDUCED_ROUGH_TRANSMITTANCE (opt-in): rough plastics with a CONSTANT roughness texture look the transmittance table up at fixed (alpha, eta); the 3-D cubic
+    // interpolation (64 taps per lookup, three lookups per shaded vertex) is reduced to a 1-D table in cos(theta) once, here.  Same spline weights (Math/Spline.cu:223-453 via
+    // RoughTransmittance.cu:55-119), summed alpha / eta first instead of last: equal up to fp32 rounding — which is NOT equal: the last bits move the rescaled lobe sample, and
+    // a texture boundary under the next hit turns that into another colour (profiles/r05_fuzz.log: up to 0.13 % of the pixels of a textured scene beyond the tolerance, 5 % of
+    // the bathroom miniature's pixels equal to the bit, against 100 % with the reference's own lookup).  Default: the 3-D lookup on every call, the reference's arithmetic.
     S.rt_reduced = nullptr;
-    if (d.rough_transmittance) {
+    if (d.rough_transmittance && reduced_rough_transmittance) {
         auto weights = [](float p, uint32_t size, float* w, uint32_t& knot) {   // = spline_weights (bsdf_rough.h)
             if (!(p >= 0.0f && p <= 1.0f)) return false;
             float t = ((p - 0.0f) * (size - 1)) / (1.0f - 0.0f);

@@ -1509,6 +1509,9 @@ inline void computePartials(DG& dg, V3 rox, V3 rxd, V3 roy, V3 ryd) {
 struct RayDiff { V3 ox, dx, oy, dy; };   // the sensor's x / y differential rays (sampleRayDifferential)
 // diff non-null = the megakernel integrator's first-hit texture filtering
 // (PathTracer.cu:60-61), null = no partials (what the wavefront tracer does)
+// debugging aid of the parity fuzz (tools/fuzz_diag.py): when set for this thread, pathTrace appends one record of 20 floats per vertex —
+// depth, triangle, node, material index, BSDF model, light index (-1), f.rgb, pdf, sampled type, cf.rgb and cl.rgb AFTER the vertex, hit distance, u, v
+inline std::vector<float>*& pathLog() { static thread_local std::vector<float>* p = nullptr; return p; }
 inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, int maxPathLength, int rrStartDepth, uint64_t* rays, const RayDiff* diff = nullptr, bool omitLastNEE = false) {
     Spec cl(0.0f), cf(1.0f);
     int depth = 0; bool specularBounce = false;
@@ -1541,6 +1544,11 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
             specularBounce = (bRec.sampledType & EDelta) != 0;
             cf = cf * f;
             ro = bRec.dg.P; rd = bRec.dg.sys.toWorld(bRec.wo);   // BSDFSamplingRecord::getOutgoing (Samples.cu)
+            if (pathLog()) {
+                const float rec[20] = { (float)depth, (float)r2.tri, (float)r2.node, (float)(&mat - S.d.materials), (float)mat.bsdf_type, li == UINT32_MAX ? -1.0f : (float)li, f.x, f.y, f.z,
+                                        brdf_scattering_pdf, (float)bRec.sampledType, cf.x, cf.y, cf.z, cl.x, cl.y, cl.z, r2.dist, r2.u, r2.v };
+                pathLog()->insert(pathLog()->end(), rec, rec + 20);
+            }
         }
         if (!r2.hasHit()) break;
         if (depth > rrStartDepth && !specularBounce) {
@@ -1755,7 +1763,8 @@ inline Spec pathTraceRegularization(const Scene& S, bool DIRECT, V3 ro, V3 rd, c
 
 // Engine/Image.cu:22-44 (host branch)
 inline void addSample(ctl_pixel_data* img, int W, int H, float sx, float sy, Spec L) {
-    L = V3(fmax2(L.x, 0.0f), fmax2(L.y, 0.0f), fmax2(L.z, 0.0f));   // Spectrum::clampNegative
+    L = V3(fmax2(0.0f, L.x), fmax2(0.0f, L.y), fmax2(0.0f, L.z));   // Spectrum::clampNegative (Spectrum.h:241-244): max(0, s) = (0 > s) ? 0 : s — a NaN stays a NaN and the sample is dropped below
+                                                                     // (the operands the other way round would turn it into 0 and count the sample: found by the parity fuzz, round 5)
     int x = floor2int(sx), y = floor2int(sy);
     bool bad = std::isnan(L.x) || std::isnan(L.y) || std::isnan(L.z) || std::isinf(L.x) || std::isinf(L.y) || std::isinf(L.z);
     if (x < 0 || x >= W || y < 0 || y >= H || bad) return;

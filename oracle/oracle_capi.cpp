@@ -392,6 +392,25 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
     return total.load();
 }
 
+// debugging aid (tools/fuzz_diag.py): the path of ONE sample of orc_render — pixel (x, y), one pair of sampler tables — vertex by vertex (ocore.h pathLog: 20 floats per vertex);
+// returns the number of floats written, rgb = the sample's radiance
+int orc_path_log(const ctl_scene_desc* desc, uint32_t W, uint32_t H, const float* t1, const float* t2, uint32_t x, uint32_t y, int direct, int maxPathLength, int rrStart, float* out, int cap, float* rgb) {
+    (void)H;
+    Scene S; S.d = *desc; S.flat = g_flat;
+    PerspectiveSensor sensor; sensor.update(desc->camera);
+    Sampler rng(t1, t2, y * W + x);
+    V2 j = rng.randomFloat2(); V2 pX{ (float)x + j.x, (float)y + j.y }; V2 ap = rng.randomFloat2();
+    V3 o, d; sensor.sampleRay(pX, ap, o, d);
+    std::vector<float> log; pathLog() = &log;
+    uint64_t rays = 0;
+    const Spec col = pathTrace(S, direct != 0, o, d, rng, maxPathLength, rrStart, &rays);
+    pathLog() = nullptr;
+    rgb[0] = col.x; rgb[1] = col.y; rgb[2] = col.z;
+    const int n = (int)std::min<size_t>(log.size(), (size_t)cap);
+    std::memcpy(out, log.data(), sizeof(float) * n);
+    return n;
+}
+
 // the transcendental functions this build of the oracle runs its path with (omath.h msin ..: glibc's, or the product's shared ones with -DORC_SHARED_MATH):
 // which = 0 sin, 1 cos, 2 tan, 3 acos, 4 atan, 5 atan2(x, y), 6 exp, 7 log, 8 log2, 9 pow(x, y)
 void orc_math_eval(int which, int n, const float* x, const float* y, float* out) {

@@ -1,7 +1,6 @@
 """Parity fuzz: seeded RANDOM scenes (cudatracerlib_amd.scenes.fuzz_scene — materials drawn from all fourteen BSDF models with random parameters and textures, nested models
 under coatings and blends, normal / height maps, mirrored and sheared instances, one to three emitters of the five kinds) rendered by the HIP wavefront path tracer and by
-the oracle's PathTrace<DIRECT> on the same sampler tables, at the bar of tests/test_gpu_render.py (99.95 % of pixels within 2e-3 (1 + ref), image means to 1e-3, weights
-equal) — two-level and flattened BVH.  The hand-made scenes of the other tests each exercise what they were written for; these exercise combinations nobody chose."""
+the oracle's PathTrace<DIRECT> on the same sampler tables, at the bar of tests/test_gpu_render.py (every pixel within 2e-3 (1 + ref), 98 % equal to the bit, image means to 1e-3) — two-level and flattened BVH.  The hand-made scenes of the other tests each exercise what they were written for; these exercise combinations nobody chose."""
 import numpy as np
 import pytest
 from cudatracerlib_amd import scenes
@@ -30,14 +29,16 @@ def test_fuzz_scene_gpu_equals_oracle(gpu, orc, seed):
     want, _ = orc.render(d, W, H, n_passes=PASSES, tables=tables, max_path_length=DEPTH, rr_start=RR)
     for flatten in (False, True):
         got = _render(gpu, gpu.Scene(d, flatten=flatten), tables)
-        assert np.array_equal(got[..., 6], want[..., 6]), ("weightSum", seed, flatten)
         g, w = got[..., :3], want[..., :3]
         assert np.isfinite(g).all()
-        ok = (np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2)
-        # 1536 pixels: 99.95 % allows none; the bar is "at most one pixel off" so that a single tie between two equidistant surfaces (BVHs differ) does not fail a seed
-        assert (~ok).sum() <= 1, (seed, flatten, int((~ok).sum()), np.argwhere(~ok)[:4].tolist(), g[~ok][:2].tolist(), w[~ok][:2].tolist())
-        assert abs(g.mean() - w.mean()) <= 1e-3 * max(w.mean(), 1e-6), (seed, flatten, float(g.mean()), float(w.mean()))
-        # bit-equal pixels: the bar of tests/test_gpu_render.py where the device runs the checker's arithmetic; rough plastic / rough coating look their transmittance up in
-        # the per-material 1-D reduction of the table (equal up to fp32 rounding), so scenes that hold one are held to the tolerance only
-        if not any(d.materials[i].bsdf_type in (9, 14) for i in range(d.n_materials)):
-            assert (g == w).all(axis=2).mean() >= 0.9, (seed, flatten, float((g == w).all(axis=2).mean()))
+        # Samples the reference DROPS (Image::AddSample returns on a NaN radiance, Engine/Image.cu:25-28): a BSDF evaluated outside its domain — a one-sided rough coating seen from
+        # behind has no side check before its microfacet sample (BSDF_Complex.cu:159-223), a zero-pdf vertex that hits an emitter makes 0 / 0 of its MIS weight — poisons the whole
+        # sample.  The kernels stop a path whose throughput became exactly zero (no contribution can follow), so where the reference's path went on and met such a NaN LATER they keep
+        # the radiance collected so far and count the sample: pixels whose weights differ are that case, bounded here and left out of the colour comparison.
+        same_w = got[..., 6] == want[..., 6]
+        assert (~same_w).mean() <= 0.01 and (got[..., 6] >= want[..., 6]).all(), ("weightSum", seed, flatten, float((~same_w).mean()))
+        ok = (np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2) | ~same_w
+        assert (~ok).sum() == 0, (seed, flatten, int((~ok).sum()), np.argwhere(~ok)[:4].tolist(), g[~ok][:2].tolist(), w[~ok][:2].tolist())
+        assert abs(g[same_w].mean() - w[same_w].mean()) <= 1e-3 * max(w[same_w].mean(), 1e-6), (seed, flatten)
+        # every model runs the checker's arithmetic on the device (rough plastic / rough coating included: the reference's 3-D transmittance lookup): bit-equal frames
+        assert (g == w).all(axis=2)[same_w].mean() >= 0.98, (seed, flatten, float((g == w).all(axis=2)[same_w].mean()))
