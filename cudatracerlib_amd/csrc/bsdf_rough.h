@@ -108,21 +108,48 @@ __device__ CTL_ROUGH_BODY float ward_pdf(const ctl_material& M, const bsdf_rec& 
     return 0.0f;
 }
 
-// Rough plastic with a constant roughness: the table was reduced to 1-D in cos(theta) at scene upload (tracer.hip), M.reserved_ = {offset + 1, samples}
+// Rough plastic with a constant roughness looks the table up at a fixed (alpha, eta): what depends on those two alone is made once per material at scene upload
+// (tracer.hip), M.reserved_ = {offset + 1 into dev_scene::rt_reduced, theta samples | kRtRows}.
+//  * kRtRows (the default): the SIXTEEN ROWS of the table the 3-D interpolation reads for this (alpha, eta) and their sixteen weight products wy * wz, followed by the constant
+//    the 2-D diffuse lookup returns: {wyz[16], rows[16][samples], diffuse}.  rough_transmittance_rows runs the sum of spline_eval_3d over them — the same 64 products and 64
+//    additions in the same order, the same skipped zero weights — so the value is the reference's to the bit; what is saved are the two pow() of the warp, two sets of spline
+//    weights and the strided addressing of every lookup.
+//  * without kRtRows (CTL_SCENE_REDUCED_ROUGH_TRANSMITTANCE): the rows summed over alpha / eta beforehand, {table[samples], diffuse}: four taps, equal up to rounding only.
+constexpr uint32_t kRtRows = 0x80000000u;
 __device__ __forceinline__ float rough_transmittance_1d(const float* __restrict__ table, uint32_t size, float cosTheta) {
     return min2(1.0f, max2(0.0f, spline_eval_1d(m_pow(fabsf(cosTheta), 0.25f), table, size)));
 }
+__device__ CTL_ROUGH_BODY float rough_transmittance_rows(const float* __restrict__ blk, uint32_t sx, float cosTheta) {   // = rough_transmittance for cosTheta >= 0 at the material's (alpha, eta)
+    float wx[4]; uint32_t kx;
+    if (!spline_weights(m_pow(fabsf(cosTheta), 0.25f), sx, wx, kx)) return 0.0f;
+    const float* __restrict__ rows = blk + 16;
+    float result = 0.0f;
+    for (int zy = 0; zy < 16; ++zy) {
+        const float wyz = blk[zy];
+        for (int x = -1; x <= 2; ++x) {
+            const float wxyz = wx[x + 1] * wyz;
+            if (wxyz == 0) continue;
+            result += rows[zy * (int)sx + (int)kx + x] * wxyz;
+        }
+    }
+    return min2(1.0f, max2(0.0f, result));
+}
+__device__ __forceinline__ float roughplastic_diffuse_T(const ctl_material& M, const bsdf_rec& b) {   // the material's constant EvaluateDiffuse(alpha, eta), behind its table
+    const uint32_t n = M.reserved_[1] & ~kRtRows;
+    return b.dg.rt_reduced[M.reserved_[0] - 1 + ((M.reserved_[1] & kRtRows) ? 16u + 16u * n : n)];
+}
 __device__ __forceinline__ float roughplastic_T(const ctl_material& M, const bsdf_rec& b, float cosTheta, float alpha) {   // cosTheta > 0 on every roughplastic path
     if (M.reserved_[0]) {
+        const float* __restrict__ blk = b.dg.rt_reduced + (M.reserved_[0] - 1); const uint32_t n = M.reserved_[1] & ~kRtRows; const bool rows = (M.reserved_[1] & kRtRows) != 0;
 #if CTL_SHADE_FEATURES & 2
         // sample, f and pdf of a vertex (and the NEE evaluation behind them) ask for T(cos wi) five times: memoised like the 3-D lookups, keyed by the table's offset
         const uint32_t key = M.reserved_[0] | 0x80000000u;
         if (b.rt_cos == cosTheta && b.rt_type == key) return b.rt_val;
-        const float v = rough_transmittance_1d(b.dg.rt_reduced + (M.reserved_[0] - 1), M.reserved_[1], cosTheta);
+        const float v = rows ? rough_transmittance_rows(blk, n, cosTheta) : rough_transmittance_1d(blk, n, cosTheta);
         if (cosTheta == cos_theta(b.wi)) { b.rt_cos = cosTheta; b.rt_type = key; b.rt_val = v; }   // only the incident direction recurs
         return v;
 #else
-        return rough_transmittance_1d(b.dg.rt_reduced + (M.reserved_[0] - 1), M.reserved_[1], cosTheta);
+        return rows ? rough_transmittance_rows(blk, n, cosTheta) : rough_transmittance_1d(blk, n, cosTheta);
 #endif
     }
     return rough_transmittance(b.dg, M.u[2], cosTheta, alpha, M.f[0]);
@@ -172,7 +199,7 @@ __device__ CTL_ROUGH_BODY f3 roughplastic_f(const ctl_material& M, const bsdf_re
         f3 diff = tex_eval(M.tex[0], b.dg);
         const float T12 = M.reserved_[0] ? roughplastic_T(M, b, cos_theta(b.wi), distr.aU) : rough_transmittance_wi(b, M.u[2], cos_theta(b.wi), distr.aU, M.f[0]);
         const float T21 = roughplastic_T(M, b, cos_theta(b.wo), distr.aU);
-        const float Fdr = 1 - (M.reserved_[0] ? b.dg.rt_reduced[M.reserved_[0] - 1 + M.reserved_[1]] : rough_transmittance_diffuse_memo(b, M.u[2], distr.aU, M.f[0]));
+        const float Fdr = 1 - (M.reserved_[0] ? roughplastic_diffuse_T(M, b) : rough_transmittance_diffuse_memo(b, M.u[2], distr.aU, M.f[0]));
         if (M.u[0]) diff = diff / (f3(1.0f) - diff * Fdr);
         else diff = sdiv(diff, 1 - Fdr);
         result = result + diff * (kInvPi * cos_theta(b.wo) * T12 * T21 * M.f[1]);

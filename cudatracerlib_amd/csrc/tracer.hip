@@ -8,6 +8,7 @@
 #include "mitsuba_loader.h"   // unsupported_error
 #include "spline.h"
 #include "mip_pyramid.h"
+#include "ctl_fmath.h"
 #include <algorithm>
 #include <thread>
 #include <cctype>
@@ -145,41 +146,51 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format, bool reduce
     // Rough plastics with a CONSTANT roughness texture look the transmittance table up at fixed (alpha, eta): reduce the 3-D cubic interpolation
     // (64 taps per lookup, three to five lookups per shaded vertex) to a 1-D table in cos(theta) once, here.  Same spline weights
     // (Math/Spline.cu:223-453 via RoughTransmittance.cu:55-119), summed alpha / eta first instead of last: equal up to fp32 rounding.
-    // CTL_SCENE_REDUCED_ROUGH_TRANSMITTANCE (opt-in): rough plastics with a CONSTANT roughness texture look the transmittance table up at fixed (alpha, eta); the 3-D cubic
-    // interpolation (64 taps per lookup, three lookups per shaded vertex) is reduced to a 1-D table in cos(theta) once, here.  Same spline weights (Math/Spline.cu:223-453 via
-    // RoughTransmittance.cu:55-119), summed alpha / eta first instead of last: equal up to fp32 rounding — which is NOT equal: the last bits move the rescaled lobe sample, and
-    // a texture boundary under the next hit turns that into another colour (profiles/r05_fuzz.log: up to 0.13 % of the pixels of a textured scene beyond the tolerance, 5 % of
-    // the bathroom miniature's pixels equal to the bit, against 100 % with the reference's own lookup).  Default: the 3-D lookup on every call, the reference's arithmetic.
+    // Rough plastics with a CONSTANT roughness texture look RoughTransmittanceManager's table up at a fixed (alpha, eta) (RoughTransmittance.cu:55-88 -> Math/Spline.cu:376-453).
+    // What depends on those two alone is made here, once per material (bsdf_rough.h roughplastic_T):
+    //  * default — the sixteen rows the 3-D interpolation reads for this (alpha, eta) and the sixteen products wy * wz of its weights; the device runs the reference's own sum
+    //    over them: the same value to the bit, without the warp's two pow(), two sets of spline weights and the strided addressing per lookup;
+    //  * CTL_SCENE_REDUCED_ROUGH_TRANSMITTANCE (opt-in) — the rows summed over alpha / eta beforehand (a 1-D table, 4 taps instead of 64): equal up to fp32 rounding, which is NOT
+    //    equal: the last bits move the rescaled lobe sample, and a texture boundary under the next hit turns that into another colour (profiles/r05_fuzz.log: up to 0.13 % of a
+    //    textured scene's pixels beyond the tolerance, 5 % of the bathroom miniature's pixels equal to the bit against 100 %).
+    // The arithmetic is the device's: ctl_fmath.h's pow (the kernels' m_pow), fp32, no contraction.
     S.rt_reduced = nullptr;
-    if (d.rough_transmittance && reduced_rough_transmittance) {
-        auto weights = [](float p, uint32_t size, float* w, uint32_t& knot) {   // = spline_weights (bsdf_rough.h)
-            if (!(p >= 0.0f && p <= 1.0f)) return false;
-            float t = ((p - 0.0f) * (size - 1)) / (1.0f - 0.0f);
-            knot = std::min((uint32_t)t, size - 2); t = t - (float)knot;
-            const float t2 = t * t, t3 = t2 * t;
-            w[0] = 0.0f; w[1] = 2 * t3 - 3 * t2 + 1; w[2] = -2 * t3 + 3 * t2; w[3] = 0.0f;
-            const float d0 = t3 - 2 * t2 + t, d1 = t3 - t2;
-            if (knot > 0) { w[2] += 0.5f * d0; w[0] -= 0.5f * d0; } else { w[2] += d0; w[1] -= d0; }
-            if (knot + 2 < size) { w[3] += 0.5f * d1; w[1] -= 0.5f * d1; } else { w[2] += d1; w[1] -= d1; }
-            return true;
-        };
+    if (d.rough_transmittance) {
         std::vector<float> pool;
         for (auto& m : dmats) {
             if (m.bsdf_type != CTL_BSDF_ROUGHPLASTIC || m.tex[2].type != CTL_TEX_CONSTANT || m.u[2] > CTL_MF_PHONG) continue;
             const ctl_rough_transmittance& T = d.rough_transmittance[m.u[2]];
             if (!T.trans || !T.diff_trans || T.theta_samples < 2 || T.alpha_samples < 2 || T.eta_samples < 2) continue;
             float r = m.tex[2].value[0]; r += m.tex[2].value[1]; r += m.tex[2].value[2];
-            const float alpha = std::max(r * (1.0f / 3), 1e-4f);   // avg3 + the MicrofacetDistribution constructor's clamp
+            const float avg = r * (1.0f / 3), alpha = avg > 1e-4f ? avg : 1e-4f;   // avg3 (shading.h) + the MicrofacetDistribution constructor's max(alpha, 1e-4f)
             float eta = m.f[0];
             const float* data = T.trans; const float* ddata = T.diff_trans;
             if (eta < 1) { data += (size_t)T.eta_samples * T.alpha_samples * T.theta_samples; ddata += (size_t)T.eta_samples * T.alpha_samples; eta = 1.0f / eta; }
             if (eta < T.eta_min) eta = T.eta_min;
-            const float wa = std::pow((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f), we = std::pow((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
-            m.reserved_[0] = (uint32_t)pool.size() + 1; m.reserved_[1] = T.theta_samples;
-            pool.resize(pool.size() + T.theta_samples);
-            spline_reduce_3d_to_1d(wa, we, data, T.theta_samples, T.alpha_samples, T.eta_samples, pool.data() + pool.size() - T.theta_samples);
+            const float wa = fm::pow((alpha - T.alpha_min) / (T.alpha_max - T.alpha_min), 0.25f), we = fm::pow((eta - T.eta_min) / (T.eta_max - T.eta_min), 0.25f);
             const float dv = spline_eval_2d(wa, we, ddata, T.alpha_samples, T.eta_samples);
-            pool.push_back(std::min(1.0f, std::max(0.0f, dv)));   // RoughTransmittanceManager::EvaluateDiffuse clamps
+            const float diffuse = std::min(1.0f, std::max(0.0f, dv));   // RoughTransmittanceManager::EvaluateDiffuse clamps
+            const uint32_t sx = T.theta_samples;
+            if (reduced_rough_transmittance) {
+                m.reserved_[0] = (uint32_t)pool.size() + 1; m.reserved_[1] = sx;
+                pool.resize(pool.size() + sx);
+                spline_reduce_3d_to_1d(wa, we, data, sx, T.alpha_samples, T.eta_samples, pool.data() + pool.size() - sx);
+                pool.push_back(diffuse);
+                continue;
+            }
+            if (std::getenv("CTL_RT_ROWS") && std::atoi(std::getenv("CTL_RT_ROWS")) == 0) continue;   // MEASUREMENT: every lookup through the generic 3-D function (profiles/r05_fuzz.log)
+            float wy[4], wz[4]; uint32_t ky, kz;
+            if (!spline_weights(wa, T.alpha_samples, wy, ky) || !spline_weights(we, T.eta_samples, wz, kz)) continue;   // outside the table: the device's generic lookup returns its 0
+            m.reserved_[0] = (uint32_t)pool.size() + 1; m.reserved_[1] = sx | 0x80000000u;   // kRtRows (bsdf_rough.h)
+            const size_t base = pool.size();
+            pool.resize(base + 16 + (size_t)16 * sx + 1, 0.0f);
+            for (int z = -1, zy = 0; z <= 2; ++z) for (int y = -1; y <= 2; ++y, ++zy) {
+                const float wyz = wy[y + 1] * wz[z + 1];      // spline_eval_3d's own product
+                pool[base + zy] = wyz;
+                // a row whose weight is zero is never read (spline_eval_3d skips a zero product); at the table's border it would lie outside
+                if (wyz != 0) std::memcpy(&pool[base + 16 + (size_t)zy * sx], data + ((size_t)(kz + z) * T.alpha_samples + (ky + y)) * sx, sizeof(float) * sx);
+            }
+            pool[base + 16 + (size_t)16 * sx] = diffuse;
         }
         if (!pool.empty()) { rt_reduced_.upload(pool.data(), pool.size()); S.rt_reduced = rt_reduced_.p; }
         else for (auto& m : dmats) m.reserved_[0] = 0;

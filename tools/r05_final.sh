@@ -13,6 +13,7 @@ python bench.py > $OUT/bench_64spp.json 2>$OUT/e1
 python bench.py --steps 20 --warmup 5 > $OUT/bench_final.json 2>$OUT/e0
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload synthetic-bathroom > $OUT/bench_bathroom.json 2>$OUT/e2
 python bench.py --steps 128 --warmup 5 --no-cpu-baseline --workload synthetic-bathroom > $OUT/bench_bathroom_128spp.json 2>$OUT/e2b
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload synthetic-bathroom --reduced-rough-transmittance > $OUT/bench_bathroom_reduced.json 2>$OUT/e2c
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload cornell-glass --width 1024 --height 1024 > $OUT/bench_cornell.json 2>$OUT/e3
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --via-loader > $OUT/bench_loader.json 2>$OUT/e4
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --tracer-param PathSemantics=1 > $OUT/bench_wavefront_rules.json 2>$OUT/e5
@@ -29,5 +30,5 @@ a, b = np.load("$OUT/frame1.npy"), np.load("$OUT/frame8.npy")
 print("8-rank frame (gather of packed tiles, 8 processes on one device) vs 1-rank frame, 1920x1080, 25 passes: weights equal", np.array_equal(a[..., 6], b[..., 6]), "| rgb bit-equal fraction of pixels", float((a[..., :3] == b[..., :3]).all(-1).mean()), "| max abs diff", float(np.abs(a - b).max()), "| max rel diff", float((np.abs(a - b) / (1 + np.abs(a))).max()))
 PY
 rm -f $OUT/frame1.npy $OUT/frame8.npy; cat $OUT/frames_8_vs_1.txt
-for f in final 64spp bathroom bathroom_128spp cornell loader wavefront_rules sm_hard q8 2ranks_shared_gpu 8ranks_shared_gpu; do echo "$f $(python tools/bench_brief.py < $OUT/bench_$f.json | cut -c1-150)"; done
+for f in final 64spp bathroom bathroom_128spp bathroom_reduced cornell loader wavefront_rules sm_hard q8 2ranks_shared_gpu 8ranks_shared_gpu; do echo "$f $(python tools/bench_brief.py < $OUT/bench_$f.json | cut -c1-150)"; done
 tail -3 $OUT/plugin_compare.txt; cat $OUT/shard_time_probe.txt

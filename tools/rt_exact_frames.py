@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bit-equal pixel fractions GPU vs oracle (shared-math build) of scenes with rough plastic: the bathroom miniature and fuzz seeds (run with CTL_RT_REDUCTION=1 / 0)"""
+"""bit-equal pixel fractions GPU vs oracle (shared-math build) of scenes with rough plastic: the bathroom miniature and fuzz seeds (RT_MODE = rows / generic / reduced, tools/r05_rt_exact_probe.sh)"""
 import os, sys, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,7 @@ for name, sc, W, H in cases:
     tables = orc.sequence_tables(P)
     want, _ = orc.render(d, W, H, n_passes=P, tables=tables, max_path_length=8, rr_start=5)
     tr = gpu.WavefrontPathTracer(); tr.getParameters().setValue("MaxPathLength", 8)
-    tr.Resize(W, H); tr.InitializeScene(gpu.Scene(d, flatten=True)); img = gpu.Image(W, H)
+    tr.Resize(W, H); tr.InitializeScene(gpu.Scene(d, flatten=True, reduced_rough_transmittance=os.environ.get("RT_MODE") == "reduced")); img = gpu.Image(W, H)
     for k in range(P):
         tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
     got = img.getPixelData(); g, w = got[..., :3], want[..., :3]
