@@ -37,6 +37,8 @@ for key, f in (("HARD", "bench_sm_hard.json"), ("BATH", "bench_bathroom.json")):
     T[key + "_ROOF"] = ("%s: hbm %.2f, valu_issue %.2f, l1_lookup %.2f" % (r.get("bound"), fr.get("hbm", 0), fr.get("valu_issue", 0), fr.get("l1_lookup", 0))) if fr else str(r.get("bound"))
     if key == "BATH": T["BATH_SHADE"] = "%.2f" % sh
 T["BATH128"] = "%.0f" % line("bench_bathroom_128spp.json")["value"]
+try: T["BATHRED"] = "%.0f" % line("bench_bathroom_reduced.json")["value"]
+except Exception: T["BATHRED"] = "?"
 # SQ_WAIT_ANY of the shade kernel from the pmc summary
 for row in csv.DictReader(open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.csv"))):
     k = row.get("kernel") or list(row.values())[0]
