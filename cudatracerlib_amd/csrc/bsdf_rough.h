@@ -122,15 +122,17 @@ __device__ __forceinline__ float rough_transmittance_1d(const float* __restrict_
 __device__ CTL_ROUGH_BODY float rough_transmittance_rows(const float* __restrict__ blk, uint32_t sx, float cosTheta) {   // = rough_transmittance for cosTheta >= 0 at the material's (alpha, eta)
     float wx[4]; uint32_t kx;
     if (!spline_weights(m_pow(fabsf(cosTheta), 0.25f), sx, wx, kx)) return 0.0f;
-    const float* __restrict__ rows = blk + 16;
+    // spline_eval_3d skips a tap whose weight product is zero; here every tap is added.  The same value: the sum starts at +0 and, in round-to-nearest, can only ever be +0 or
+    // non-zero (+0 + -0 = +0, x + -x = +0), so adding a zero product never changes it; the table is finite, the taps beside a border knot (weight 0) read the neighbouring
+    // row's end, inside the block.  Without the data-dependent branch the 64 loads issue together instead of one behind the other.
+    const float* __restrict__ rows = blk + 16 + ((int)kx - 1);
     float result = 0.0f;
+#pragma unroll
     for (int zy = 0; zy < 16; ++zy) {
         const float wyz = blk[zy];
-        for (int x = -1; x <= 2; ++x) {
-            const float wxyz = wx[x + 1] * wyz;
-            if (wxyz == 0) continue;
-            result += rows[zy * (int)sx + (int)kx + x] * wxyz;
-        }
+        const float* __restrict__ r = rows + zy * (int)sx;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) result += r[x] * (wx[x] * wyz);
     }
     return min2(1.0f, max2(0.0f, result));
 }
