@@ -149,7 +149,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format, bool reduce
     // Rough plastics with a CONSTANT roughness texture look RoughTransmittanceManager's table up at a fixed (alpha, eta) (RoughTransmittance.cu:55-88 -> Math/Spline.cu:376-453).
     // What depends on those two alone is made here, once per material (bsdf_rough.h roughplastic_T):
     //  * default — the sixteen rows the 3-D interpolation reads for this (alpha, eta) and the sixteen products wy * wz of its weights; the device runs the reference's own sum
-    //    over them: the same value to the bit, without the warp's two pow(), two sets of spline weights and the strided addressing per lookup;
+    //    over them: the same value to the bit, without the warp's two pow(), two sets of spline weights, the strided addressing and the per-tap branch of every lookup;
     //  * CTL_SCENE_REDUCED_ROUGH_TRANSMITTANCE (opt-in) — the rows summed over alpha / eta beforehand (a 1-D table, 4 taps instead of 64): equal up to fp32 rounding, which is NOT
     //    equal: the last bits move the rescaled lobe sample, and a texture boundary under the next hit turns that into another colour (profiles/r05_fuzz.log: up to 0.13 % of a
     //    textured scene's pixels beyond the tolerance, 5 % of the bathroom miniature's pixels equal to the bit against 100 %).

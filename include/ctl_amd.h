@@ -322,7 +322,7 @@ int ctl_scene_create(const ctl_scene_desc* desc, ctl_scene** out);
  * than the scene has instanced triangles.  CTL_SCENE_FLAT_FORMAT(f) picks the node format (measurement; default Q4). */
 enum { CTL_SCENE_FLATTEN = 1,
        /* opt-in: a rough plastic with a constant roughness looks RoughTransmittanceManager's table up through a per-material 1-D reduction (4 taps instead of 64; synthetic-bathroom
-        * + 15 % rays/s).  Equal to the reference's 3-D lookup (Engine/RoughTransmittance.cu:55-88) up to fp32 rounding only: frames stay within the per-pixel tolerance in most
+        * + 3 % rays/s).  Equal to the reference's 3-D lookup (Engine/RoughTransmittance.cu:55-88) up to fp32 rounding only: frames stay within the per-pixel tolerance in most
         * scenes but are no longer equal to the bit, and textured scenes can exceed it at texture boundaries.  Without the flag every lookup is the reference's own arithmetic. */
        CTL_SCENE_REDUCED_ROUGH_TRANSMITTANCE = 2 };
 enum { CTL_FLAT_Q4 = 0,    /* 4-wide, 64-B nodes, 8-bit child boxes (default) */
