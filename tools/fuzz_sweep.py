@@ -11,15 +11,21 @@ import oracle
 
 W, H, PASSES, DEPTH, RR = 96, 64, 4, 8, 5
 first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (100, 300)
+MODE = sys.argv[3] if len(sys.argv) > 3 else "default"      # default | wavefront (PathSemantics = Wavefront, +u16 on odd seeds) | plugin (the megakernel PathTracer: first-hit ray differentials)
 orc = oracle.Oracle(shared_math=True)
 worst = []; n_bad = 0
 for seed in range(first, last):
     sc = scenes.fuzz_scene(seed, W, H); d = sc.desc
     tables = orc.sequence_tables(PASSES)
-    want, want_rays = orc.render(d, W, H, n_passes=PASSES, tables=tables, max_path_length=DEPTH, rr_start=RR)
-    for flatten in (False, True):
+    kw = {}
+    if MODE == "wavefront": kw = dict(wavefront_rules=True, u16_barycentrics=bool(seed & 1))
+    elif MODE == "plugin": kw = dict(partials=True)
+    want, want_rays = orc.render(d, W, H, n_passes=PASSES, tables=tables, max_path_length=DEPTH, rr_start=RR, **kw)
+    for flatten in ((True,) if MODE == "plugin" else (False, True)):
         scene = gpu.Scene(d, flatten=flatten)
-        tr = gpu.WavefrontPathTracer(); p = tr.getParameters(); p.setValue("MaxPathLength", DEPTH); p.setValue("RRStartDepth", RR)
+        tr = gpu.PathTracer() if MODE == "plugin" else gpu.WavefrontPathTracer()
+        p = tr.getParameters(); p.setValue("MaxPathLength", DEPTH); p.setValue("RRStartDepth", RR)
+        if MODE == "wavefront": p.setValue("PathSemantics", "Wavefront"); p.setValue("U16Barycentrics", bool(seed & 1))
         tr.Resize(W, H); tr.InitializeScene(scene); img = gpu.Image(W, H)
         for k in range(PASSES):
             tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
@@ -40,4 +46,4 @@ for seed in range(first, last):
             rec["where"] = [[int(x), int(y)] for x, y in zip(xs[:4], ys[:4])]; rec["gpu"] = g[off][:2].tolist(); rec["cpu"] = w[off][:2].tolist()
             print(json.dumps(rec), flush=True)
 worst.sort(reverse=True)
-print(json.dumps({"seeds": [first, last], "renders": len(worst), "not_clean": n_bad, "worst_off_pixels": worst[:5]}), flush=True)
+print(json.dumps({"mode": MODE, "seeds": [first, last], "renders": len(worst), "not_clean": n_bad, "worst_off_pixels": worst[:5]}), flush=True)
