@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, CTL_MEGA_WAVES) void k_path_trace(dev_scene S,
             float misWeight = 1.0f;
             if (!(!P.direct || depth == 1 || specularBounce)) misWeight = power_heuristic(brdf_scattering_pdf, env_pdf_direct(S, light, r_d) * pdf_emitter(S, S.env_map_index));
             cl = cl + misWeight * cf * env_eval(S, light, r_d);
-        }
+        } else if (!had_hit) cl = cl + cf * f3(0.0f);   // EvalEnvironment == Spectrum(0) without a map, added all the same: a NaN / infinite throughput poisons the sample (oracle/ocore.h pathTrace)
         if (P.debug_out) { P.debug_out[0] = cl.x; P.debug_out[1] = cl.y; P.debug_out[2] = cl.z; }
         else add_sample(image, P.width, P.height, pX.x, pX.y, cl);
     }
@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void k_path_trace_regularization(dev_scene S, 
             const ctl_light& env = scene_lights(S)[S.env_map_index];
             if (!had_hit && depth == 0) cl = cf * env_eval_differential(S, env, r_d, r_dx, r_dy);
             else cl = cl + cf * env_eval(S, env, r_d);
-        }
+        } else if (!had_hit && depth == 0) cl = cf * f3(0.0f);
+        else cl = cl + cf * f3(0.0f);
         add_sample(image, P.width, P.height, pX.x, pX.y, cl);
     }
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);

@@ -39,11 +39,29 @@ __device__ __forceinline__ f3 mip_texel(const ctl_mipmap& M, f2 uv) {
     const int x = clampi((int)l.x, 0, (int)M.width - 1), y = clampi((int)l.y, 0, (int)M.height - 1);
     return texel_decode(M.texels[(size_t)y * M.width + x], M.texel_type);
 }
+// The four texels of a bilinear lookup (and of evalGradient): addresses first, then the four loads together, then the decoding — the values and the order of the arithmetic are
+// mip_texel's; one trip to memory instead of four behind each other (a texel that wraps to "outside" reads texel 0 and counts as black, like mip_texel's early return).
+__device__ __forceinline__ bool mip_texel_index(const ctl_mipmap& M, f2 uv, uint32_t& idx) {
+    f2 l; idx = 0u;
+    if (!wrap_coordinates(uv, f2{ (float)M.width, (float)M.height }, M.wrap_mode, l)) return false;
+    const int x = clampi((int)l.x, 0, (int)M.width - 1), y = clampi((int)l.y, 0, (int)M.height - 1);
+    idx = (uint32_t)y * M.width + (uint32_t)x;
+    return true;
+}
+__device__ __forceinline__ void mip_texels4(const ctl_mipmap& M, f2 a, f2 b, f2 c, f2 d, f3& ta, f3& tb, f3& tc, f3& td) {
+    uint32_t ia, ib, ic, id;
+    const bool va = mip_texel_index(M, a, ia), vb = mip_texel_index(M, b, ib), vc = mip_texel_index(M, c, ic), vd = mip_texel_index(M, d, id);
+    const uint32_t* __restrict__ t = M.texels;
+    const uint32_t wa = t[ia], wb = t[ib], wc = t[ic], wd = t[id];
+    const uint32_t type = M.texel_type;
+    ta = va ? texel_decode(wa, type) : f3(0.0f); tb = vb ? texel_decode(wb, type) : f3(0.0f); tc = vc ? texel_decode(wc, type) : f3(0.0f); td = vd ? texel_decode(wd, type) : f3(0.0f);
+}
 __device__ __forceinline__ f3 mip_triangle(const ctl_mipmap& M, f2 uv) {
     const f2 sz{ (float)M.width, (float)M.height }, is{ 1.0f / sz.x, 1.0f / sz.y };
     const float ds = fracf_(uv.x * sz.x), dt = fracf_(uv.y * sz.y);
-    return ((1.f - ds) * (1.f - dt)) * mip_texel(M, uv) + ((1.f - ds) * dt) * mip_texel(M, f2{ uv.x + 0, uv.y + is.y }) +
-           (ds * (1.f - dt)) * mip_texel(M, f2{ uv.x + is.x, uv.y + 0 }) + (ds * dt) * mip_texel(M, f2{ uv.x + is.x, uv.y + is.y });
+    f3 t00, t01, t10, t11;
+    mip_texels4(M, uv, f2{ uv.x + 0, uv.y + is.y }, f2{ uv.x + is.x, uv.y + 0 }, f2{ uv.x + is.x, uv.y + is.y }, t00, t01, t10, t11);
+    return ((1.f - ds) * (1.f - dt)) * t00 + ((1.f - ds) * dt) * t01 + (ds * (1.f - dt)) * t10 + (ds * dt) * t11;
 }
 __device__ __forceinline__ f3 mip_fetch(const ctl_mipmap& M, int x, int y) {
     x = clampi(x, 0, (int)M.width - 1); y = clampi(y, 0, (int)M.height - 1);
@@ -64,10 +82,9 @@ __device__ __forceinline__ void mip_eval_gradient(const ctl_mipmap& M, f2 uv, f3
     const float u = uv.x * dim.x - 0.5f, v = uv.y * dim.y - 0.5f;
     const int xPos = (int)u, yPos = (int)v;
     const float dx = u - xPos, dy = v - yPos;
-    const f3 p00 = mip_texel(M, f2{ (float)xPos / dim.x, (float)yPos / dim.y });
-    const f3 p10 = mip_texel(M, f2{ ((float)xPos + 1) / dim.x, (float)yPos / dim.y });
-    const f3 p01 = mip_texel(M, f2{ (float)xPos / dim.x, ((float)yPos + 1) / dim.y });
-    const f3 p11 = mip_texel(M, f2{ ((float)xPos + 1) / dim.x, ((float)yPos + 1) / dim.y });
+    f3 p00, p10, p01, p11;
+    mip_texels4(M, f2{ (float)xPos / dim.x, (float)yPos / dim.y }, f2{ ((float)xPos + 1) / dim.x, (float)yPos / dim.y }, f2{ (float)xPos / dim.x, ((float)yPos + 1) / dim.y },
+                f2{ ((float)xPos + 1) / dim.x, ((float)yPos + 1) / dim.y }, p00, p10, p01, p11);
     const f3 tmp = p01 + p10 - p11;
     g0 = (p10 + p00 * (dy - 1) - tmp * dy) * dim.x;
     g1 = (p01 + p00 * (dx - 1) - tmp * dx) * dim.y;

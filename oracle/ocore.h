@@ -1567,6 +1567,10 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
             misWeight = powerHeuristic(1, brdf_scattering_pdf, 1, direct_pdf);
         }
         cl = cl + misWeight * cf * envEval(S, *light, rd);
+    } else if (!r2.hasHit()) {
+        // without an environment map the line is still executed: cl += 1 * cf * Spectrum(0) (EvalEnvironment, KernelDynamicScene.cu:54-60) — nothing for a finite throughput, a NaN
+        // for a NaN / infinite one: the escaped path of a BSDF evaluated outside its domain poisons its sample, and Image::AddSample drops it (found reading for the round-5 fuzz)
+        cl = cl + 1.0f * cf * Spec(0.0f);
     }
     return cl;
 }
@@ -1666,7 +1670,7 @@ inline Spec pathTraceWavefront(const Scene& S, bool NEE, V3 ro, V3 rd, Sampler& 
                     misWeight = powerHeuristic(1, bsdf_pdf, 1, direct_pdf);
                 }
                 L = L + misWeight * throughput * envEval(S, *light, rd);
-            }
+            } else L = L + 1.0f * throughput * Spec(0.0f);   // EvalEnvironment == Spectrum(0) without a map (:156 is executed all the same): a NaN / infinite throughput poisons the sample
         }
         if (path_terminated) break;   // I.AddSample (:159-162)
     }
@@ -1757,7 +1761,8 @@ inline Spec pathTraceRegularization(const Scene& S, bool DIRECT, V3 ro, V3 rd, c
         const ctl_light& env = S.d.lights[S.d.env_map_index];
         if (!r2.hasHit() && depth == 0) cl = cf * (S.pyramids ? envEvalDifferential(S, env, rd, diff.dx, diff.dy) : envEval(S, env, rd));
         else cl = cl + cf * envEval(S, env, rd);
-    } else if (!r2.hasHit() && depth == 0) cl = Spec(0.0f);
+    } else if (!r2.hasHit() && depth == 0) cl = cf * Spec(0.0f);   // EvalEnvironment == Spectrum(0) without a map
+    else cl = cl + cf * Spec(0.0f);
     return cl;
 }
 
