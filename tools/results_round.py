@@ -124,12 +124,12 @@ def render(R):
         return rows + [""]
     L += table("C3  San Miguel stand-ins, 1920x1080, depth 8, 20 spp per run unless said (assets absent on every box: SURVEY §8d)", R["C3"])
     L += table("C5  Bathroom stand-in, 1920x1080, depth 8", R["C5"])
-    red = os.path.join(ROOT, "profiles", "r05i_bench_bathroom_reduced.json")
+    red = os.path.join(ROOT, "profiles", "r05k_bench_bathroom_reduced.json")
     if R["tag"].startswith("r05") and os.path.exists(red):   # the opt-in scene flag, one bench line of the same build and box series (tools/r05_results.sh)
         b = json.loads(open(red).read().strip().splitlines()[-1])
         L[-1:] = ["Rough plastic runs the reference's own 3-D transmittance lookup (frames equal the CPU path's to the bit; DESIGN.md §4).  With the opt-in scene flag "
                   "`CTL_SCENE_REDUCED_ROUGH_TRANSMITTANCE` (a per-material 1-D reduction of the table, the behaviour of rounds 2-4: within the per-pixel tolerance in most scenes, not equal to the bit): "
-                  "**%.1f Mrays/s**, %.3f ms per step (`profiles/r05i_bench_bathroom_reduced.json`)." % (b["value"], b["ms_per_step"]), ""]
+                  "**%.1f Mrays/s**, %.3f ms per step (`profiles/r05k_bench_bathroom_reduced.json`)." % (b["value"], b["ms_per_step"]), ""]
     L += ["## C4  8 x MI355X", "", R["C4"]["status"] + ".  `bench.py --gpus N` writes: " + ", ".join("`%s`" % f for f in R["C4"]["fields_bench_writes"]) + ".  " + R["C4"]["emulated_on_one_gpu"] + ".", ""]
     open(os.path.join(ROOT, "RESULTS.md"), "w").write("\n".join(L) + "\n")
     print("\n".join(L))
