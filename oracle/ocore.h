@@ -1509,8 +1509,8 @@ inline void computePartials(DG& dg, V3 rox, V3 rxd, V3 roy, V3 ryd) {
 struct RayDiff { V3 ox, dx, oy, dy; };   // the sensor's x / y differential rays (sampleRayDifferential)
 // diff non-null = the megakernel integrator's first-hit texture filtering
 // (PathTracer.cu:60-61), null = no partials (what the wavefront tracer does)
-// debugging aid of the parity fuzz (tools/fuzz_diag.py): when set for this thread, pathTrace appends one record of 20 floats per vertex —
-// depth, triangle, node, material index, BSDF model, light index (-1), f.rgb, pdf, sampled type, cf.rgb and cl.rgb AFTER the vertex, hit distance, u, v
+// debugging aid of the parity fuzz (tools/fuzz_diag.py): when set for this thread, pathTrace appends one record of 26 floats per vertex —
+// depth, triangle, node, material index, BSDF model, light index (-1), f.rgb, pdf, sampled type, cf.rgb and cl.rgb AFTER the vertex, hit distance, u, v, the ray that found the vertex (origin, direction)
 inline std::vector<float>*& pathLog() { static thread_local std::vector<float>* p = nullptr; return p; }
 inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, int maxPathLength, int rrStartDepth, uint64_t* rays, const RayDiff* diff = nullptr, bool omitLastNEE = false) {
     Spec cl(0.0f), cf(1.0f);
@@ -1520,6 +1520,7 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
     while (depth++ < maxPathLength) {
         r2 = traceRayClosest(S, ro, rd);
         if (rays) (*rays)++;
+        const V3 log_o = ro, log_d = rd;
         if (r2.hasHit()) {
             getBsdfSample(S, r2, ro, rd, bRec);
             if (depth == 1 && diff && S.pyramids) { bRec.dg.pyramids = S.pyramids; computePartials(bRec.dg, diff->ox, diff->dx, diff->oy, diff->dy); }
@@ -1545,9 +1546,9 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
             cf = cf * f;
             ro = bRec.dg.P; rd = bRec.dg.sys.toWorld(bRec.wo);   // BSDFSamplingRecord::getOutgoing (Samples.cu)
             if (pathLog()) {
-                const float rec[20] = { (float)depth, (float)r2.tri, (float)r2.node, (float)(&mat - S.d.materials), (float)mat.bsdf_type, li == UINT32_MAX ? -1.0f : (float)li, f.x, f.y, f.z,
-                                        brdf_scattering_pdf, (float)bRec.sampledType, cf.x, cf.y, cf.z, cl.x, cl.y, cl.z, r2.dist, r2.u, r2.v };
-                pathLog()->insert(pathLog()->end(), rec, rec + 20);
+                const float rec[26] = { (float)depth, (float)r2.tri, (float)r2.node, (float)(&mat - S.d.materials), (float)mat.bsdf_type, li == UINT32_MAX ? -1.0f : (float)li, f.x, f.y, f.z,
+                                        brdf_scattering_pdf, (float)bRec.sampledType, cf.x, cf.y, cf.z, cl.x, cl.y, cl.z, r2.dist, r2.u, r2.v, log_o.x, log_o.y, log_o.z, log_d.x, log_d.y, log_d.z };
+                pathLog()->insert(pathLog()->end(), rec, rec + 26);
             }
         }
         if (!r2.hasHit()) break;

@@ -392,7 +392,7 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
     return total.load();
 }
 
-// debugging aid (tools/fuzz_diag.py): the path of ONE sample of orc_render — pixel (x, y), one pair of sampler tables — vertex by vertex (ocore.h pathLog: 20 floats per vertex);
+// debugging aid (tools/fuzz_diag.py): the path of ONE sample of orc_render — pixel (x, y), one pair of sampler tables — vertex by vertex (ocore.h pathLog: 26 floats per vertex);
 // returns the number of floats written, rgb = the sample's radiance
 int orc_path_log(const ctl_scene_desc* desc, uint32_t W, uint32_t H, const float* t1, const float* t2, uint32_t x, uint32_t y, int direct, int maxPathLength, int rrStart, float* out, int cap, float* rgb) {
     (void)H;
