@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What the rough-plastic class of synthetic-bathroom waits for: shade ms per pass with parts of the floor's material taken away at scene level; library
-variants (CTL_AMD_LIB) move the reduced transmittance tables into LDS.  Usage: python tools/r05_bathroom_probe.py"""
+variants (CTL_AMD_LIB) move the reduced transmittance tables into LDS.  Usage: python tools/archive/r05_bathroom_probe.py"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

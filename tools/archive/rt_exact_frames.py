@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bit-equal pixel fractions GPU vs oracle (shared-math build) of scenes with rough plastic: the bathroom miniature and fuzz seeds (RT_MODE = rows / generic / reduced, tools/r05_rt_exact_probe.sh)"""
+"""bit-equal pixel fractions GPU vs oracle (shared-math build) of scenes with rough plastic: the bathroom miniature and fuzz seeds (RT_MODE = rows / generic / reduced, tools/archive/r05_rt_exact_probe.sh)"""
 import os, sys, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

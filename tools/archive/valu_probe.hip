@@ -1,7 +1,7 @@
 // valu_probe.hip — issue rate of the VALU / SALU instructions the traversal kernel is made of, per SIMD, on gfx950.
 // Each wave runs `iters` rounds of 16 independent instructions of one kind (inline asm, so the compiler cannot fold or pack them);
 // 8 waves per SIMD (2048 blocks of 256 threads on 256 CUs).  Prints cycles per wave-instruction per SIMD at the 2.4 GHz nominal clock
-// and from s_memtime (shader clock).   build: hipcc -O3 --offload-arch=gfx950 tools/valu_probe.hip -o gpurun_out/valu_probe
+// and from s_memtime (shader clock).   build: hipcc -O3 --offload-arch=gfx950 tools/archive/valu_probe.hip -o gpurun_out/valu_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,4 +1,4 @@
-// valu_probe3.hip — issue cost of the instructions the traversal kernel's node step is made of, per SIMD, on gfx950 — the round-2 probe (tools/valu_probe.hip) redone without its
+// valu_probe3.hip — issue cost of the instructions the traversal kernel's node step is made of, per SIMD, on gfx950 — the round-2 probe (tools/archive/valu_probe.hip) redone without its
 // two artefacts: (1) its v_cndmask_b32 read VCC that nothing in the kernel had written (22.7 "cycles"), (2) its SALU kernels
 // ended their loop after a round (0.01): s_and_b64 writes SCC, which the loop's own compare-and-branch uses.  Here every mask is written inside the measured asm, SALU operands are compiler-allocated, every launch is checked, and each kind is measured with
 // 1, 2, 4 and 8 waves per SIMD so that latency (1 wave) and issue rate (8 waves) can be told apart.
