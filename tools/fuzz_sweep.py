@@ -11,20 +11,41 @@ import oracle
 
 W, H, PASSES, DEPTH, RR = 96, 64, 4, 8, 5
 first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (100, 300)
-MODE = sys.argv[3] if len(sys.argv) > 3 else "default"      # default | wavefront (PathSemantics = Wavefront, +u16 on odd seeds) | plugin (the megakernel PathTracer: first-hit ray differentials)
+MODE = sys.argv[3] if len(sys.argv) > 3 else "default"      # default | wavefront (PathSemantics = Wavefront, +u16 on odd seeds) | plugin (the megakernel PathTracer: first-hit ray differentials) | sensors (thin lens / orthographic / telecentric / spherical by seed) | alpha (alpha maps on a third of the materials, AlphaTest = true) | nodirect (Direct = false, depth 5, RRStartDepth 2)
 orc = oracle.Oracle(shared_math=True)
 worst = []; n_bad = 0
 for seed in range(first, last):
     sc = scenes.fuzz_scene(seed, W, H); d = sc.desc
+    if MODE == "sensors":
+        cam = gpu.api.ctl_sensor.from_buffer_copy(d.camera)
+        kind = seed % 4
+        cam.type = (3, 4, 5, 1)[kind]
+        cam.aperture_radius, cam.focus_distance = (0.2, 12.0) if kind == 0 else (0.05, 8.0)
+        cam.screen_scale[:] = [6.0, 6.0]
+        if kind in (1, 2): cam.near_depth, cam.far_depth = 1e-5, 1e5
+        sc.setSensor(cam); sc.UpdateScene(); d = sc.desc
+    if MODE == "alpha":
+        rs = np.random.RandomState(seed)
+        for i in range(d.n_materials):
+            if rs.randint(3) == 0 and d.materials[i].bsdf_type not in (3, 4, 5):
+                m = d.materials[i]
+                k = rs.randint(3)
+                t = gpu.api.checker_texture(1.0, 0.0, uv_scale=(float(rs.choice([2.0, 4.0, 7.0])), float(rs.choice([2.0, 3.0])))) if k < 2 else gpu.api.checker_texture((0.9, 0.1, 0.1), (0.1, 0.1, 0.9), uv_scale=(3.0, 3.0))
+                m.alpha_state = 1 if k < 2 else 3; m.alpha_test_scalar = 0.5 if k < 2 else 0.25; m.alpha_test_color[:] = [1.0, 0.0, 0.0]; m.alpha_tex = t
     tables = orc.sequence_tables(PASSES)
     kw = {}
     if MODE == "wavefront": kw = dict(wavefront_rules=True, u16_barycentrics=bool(seed & 1))
     elif MODE == "plugin": kw = dict(partials=True)
-    want, want_rays = orc.render(d, W, H, n_passes=PASSES, tables=tables, max_path_length=DEPTH, rr_start=RR, **kw)
+    elif MODE == "alpha": kw = dict(alpha_test=True)
+    elif MODE == "nodirect": kw = dict(direct=False)
+    depth_, rr_ = (5, 2) if MODE == "nodirect" else (DEPTH, RR)
+    want, want_rays = orc.render(d, W, H, n_passes=PASSES, tables=tables, max_path_length=depth_, rr_start=rr_, **kw)
     for flatten in ((True,) if MODE == "plugin" else (False, True)):
         scene = gpu.Scene(d, flatten=flatten)
         tr = gpu.PathTracer() if MODE == "plugin" else gpu.WavefrontPathTracer()
-        p = tr.getParameters(); p.setValue("MaxPathLength", DEPTH); p.setValue("RRStartDepth", RR)
+        p = tr.getParameters(); p.setValue("MaxPathLength", depth_); p.setValue("RRStartDepth", rr_)
+        if MODE == "alpha": p.setValue("AlphaTest", True)
+        if MODE == "nodirect": p.setValue("Direct", False)
         if MODE == "wavefront": p.setValue("PathSemantics", "Wavefront"); p.setValue("U16Barycentrics", bool(seed & 1))
         tr.Resize(W, H); tr.InitializeScene(scene); img = gpu.Image(W, H)
         for k in range(PASSES):
