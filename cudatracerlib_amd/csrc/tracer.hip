@@ -9,6 +9,7 @@
 #include "spline.h"
 #include "mip_pyramid.h"
 #include "ctl_fmath.h"
+#include "knobs.h"
 #include <algorithm>
 #include <thread>
 #include <cctype>
@@ -178,7 +179,7 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format, bool reduce
                 pool.push_back(diffuse);
                 continue;
             }
-            if (std::getenv("CTL_RT_ROWS") && std::atoi(std::getenv("CTL_RT_ROWS")) == 0) continue;   // MEASUREMENT: every lookup through the generic 3-D function (profiles/r05_fuzz.log)
+            if (const char* e = knob_env("CTL_RT_ROWS")) { if (std::atoi(e) == 0) continue; }   // measurement build only (knobs.h): every lookup through the generic 3-D function (profiles/r05_fuzz.log)
             float wy[4], wz[4]; uint32_t ky, kz;
             if (!spline_weights(wa, T.alpha_samples, wy, ky) || !spline_weights(we, T.eta_samples, wz, kz)) continue;   // outside the table: the device's generic lookup returns its 0
             m.reserved_[0] = (uint32_t)pool.size() + 1; m.reserved_[1] = sx | 0x80000000u;   // kRtRows (bsdf_rough.h)
