@@ -11,14 +11,20 @@
 
 namespace ctl {
 
-struct image_set { const ctl_mipmap* images = nullptr; uint32_t n = 0; };
+struct image_set {
+    const ctl_mipmap* images = nullptr; uint32_t n = 0;
+    float (*cache)[4] = nullptr;   // optional, n entries {r, g, b, valid}: an image's average is made once however many materials use it (a pyramid of a 4096² bitmap is 22 M texels)
+};
 
 inline void tex_average(const ctl_texture& t, float out[3], const image_set& I) {
     for (int q = 0; q < 3; q++) out[q] = t.value[q];
     if (t.type == CTL_TEX_CHECKER) { for (int q = 0; q < 3; q++) out[q] = (t.value[q] + t.value1[q]) * 0.5f; }
     else if (t.type == CTL_TEX_IMAGE && I.images) {
         float a[3] = { 0.0f, 0.0f, 0.0f };                 // tex_idx == 0xffffffff: Spectrum(0) (Texture.cu:33-34)
-        if (t.image < I.n) mip_image_average(I.images[t.image], a);
+        if (t.image < I.n) {
+            if (I.cache && I.cache[t.image][3] != 0.0f) { a[0] = I.cache[t.image][0]; a[1] = I.cache[t.image][1]; a[2] = I.cache[t.image][2]; }
+            else { mip_image_average(I.images[t.image], a); if (I.cache) { I.cache[t.image][0] = a[0]; I.cache[t.image][1] = a[1]; I.cache[t.image][2] = a[2]; I.cache[t.image][3] = 1.0f; } }
+        }
         for (int q = 0; q < 3; q++) out[q] = a[q] * t.value[q];
     }
 }

@@ -541,6 +541,7 @@ void scene_builder::finalize(ctl_scene_desc& out) {
     {   // BSDF::Update() now that every image is there (MaterialStream::UpdateMaterialsPhase2 after LoadTextures, Engine/DynamicScene.cpp:74-89): the sampling weights that come
         // from the average of an IMAGE texture were made with the bitmap counted as white (material_textures.h)
         image_set I; I.images = images.data(); I.n = (uint32_t)images.size();
+        std::vector<float> avg_cache(4 * images.size() + 4, 0.0f); I.cache = reinterpret_cast<float (*)[4]>(avg_cache.data());
         for (auto& m : mats) material_update_textures(m, I);
     }
     for (int i = 0; i < 3; i++) { rt[i].trans = rt_trans[i].empty() ? nullptr : rt_trans[i].data(); rt[i].diff_trans = rt_diff[i].empty() ? nullptr : rt_diff[i].data(); }
