@@ -192,6 +192,11 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format, bool reduce
                 if (wyz != 0) std::memcpy(&pool[base + 16 + (size_t)zy * sx], data + ((size_t)(kz + z) * T.alpha_samples + (ky + y)) * sx, sizeof(float) * sx);
             }
             pool[base + 16 + (size_t)16 * sx] = diffuse;
+            // the device adds every tap where spline_eval_3d skips a zero weight: the same value only over FINITE entries (0 x inf is NaN) — a table that holds anything else
+            // keeps the generic lookup
+            bool finite = true;
+            for (size_t q = base; q < pool.size(); q++) finite = finite && std::isfinite(pool[q]);
+            if (!finite) { pool.resize(base); m.reserved_[0] = m.reserved_[1] = 0; }
         }
         if (!pool.empty()) { rt_reduced_.upload(pool.data(), pool.size()); S.rt_reduced = rt_reduced_.p; }
         else for (auto& m : dmats) m.reserved_[0] = 0;
