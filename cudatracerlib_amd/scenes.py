@@ -1031,3 +1031,28 @@ def fuzz_scene(seed, width=48, height=32):
     sc.setCamera((float(rs.uniform(-3, 3)), float(rs.uniform(3, 7)), float(rs.uniform(11, 15))), (0.0, 2.0, 0.0), (0, 1, 0), float(rs.uniform(40, 65)), width, height)
     sc.UpdateScene()
     return sc
+
+
+def coating_from_behind(width=32, height=24, env=True):
+    """A one-sided rough coating seen from BEHIND under an environment map: the reference's roughcoating::sample has no side check before its microfacet sample
+    (SceneTypes/BSDF_Complex.cu:159-223) and returns NaN there when the specular lobe is chosen; the sample's radiance becomes NaN and Image::AddSample drops it (Engine/Image.cu:25-28) — the
+    panel's pixels receive fewer samples than passes.  tests/test_oracle_fuzz.py and tests/test_gpu_fuzz.py hold oracle and kernels to that."""
+    from . import rough_tables
+    sc = api.DynamicScene()
+    for slot in (0, 1):
+        tr, df, er, ar = rough_tables.make_table(slot, n_eta=4, n_alpha=4, n_theta=8, quad=12)
+        sc.setRoughTransmittance(slot, tr, df, er, ar)
+    inner = api.diffuse((0.6, 0.3, 0.2))
+    m = api.roughcoating(sc.add_material(inner), inner, alpha=0.2, int_ior=1.5, ext_ior=1.0, thickness=1.0, sigma_a=(0.1, 0.2, 0.3), distribution=0)
+    P, I, N = _quad([[-2, -2, 0], [2, -2, 0], [2, 2, 0], [-2, 2, 0]], [0, 0, -1])      # faces -z; the camera sits at +z
+    sc.CreateNode(sc.add_mesh(P, I, normals=N, uvs=np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32), materials=[m]))
+    P, I, N = _quad([[-8, -3, -8], [-8, -3, 8], [8, -3, 8], [8, -3, -8]], [0, 1, 0])
+    sc.CreateNode(sc.add_mesh(P, I, normals=N, materials=[api.diffuse((0.5, 0.5, 0.5))]))
+    if env:
+        e = sc.add_image(procedural_envmap(), api.TEXEL_RGBE, api.WRAP_REPEAT, api.FILTER_BILINEAR)
+        sc.setEnvironementMap(e, (1.0, 1.0, 1.0), None)
+    else:
+        sc.CreatePointLight((0, 4, 6), (60, 60, 60))
+    sc.setCamera((0, 0, 9), (0, 0, 0), (0, 1, 0), 40.0, width, height)
+    sc.UpdateScene()
+    return sc

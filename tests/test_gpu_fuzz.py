@@ -76,3 +76,25 @@ def test_fuzz_scene_intersect_equals_oracle(gpu, orc, seed):
             assert np.array_equal(got[k][same].view(np.uint32), want[k][same].view(np.uint32)), (seed, flatten, k)
         assert np.array_equal(gpu.intersect(scene, occ_rays, any_hit=True)["tri_idx"] >= 0, want_occ), (seed, flatten, "occlusion")
     assert (want["tri_idx"] >= 0).mean() > 0.2
+
+
+@pytest.mark.parametrize("env", [True, False])
+def test_nan_samples_are_dropped_by_the_kernels_too(gpu, orc, env):
+    """scenes.coating_from_behind (tests/test_oracle_fuzz.py has the why): the panel's samples are NaN and dropped — same weights, same frame, wavefront plugin under both rule
+    sets and the megakernel plugin"""
+    sc = scenes.coating_from_behind(32, 24, env=env)
+    d = sc.desc
+    tables = orc.sequence_tables(3)
+    for mode in ("default", "wavefront", "plugin"):
+        kw = dict(wavefront_rules=True) if mode == "wavefront" else (dict(partials=True) if mode == "plugin" else {})
+        want, _ = orc.render(d, 32, 24, n_passes=3, tables=tables, max_path_length=6, rr_start=4, **kw)
+        tr = gpu.PathTracer() if mode == "plugin" else gpu.WavefrontPathTracer()
+        p = tr.getParameters(); p.setValue("MaxPathLength", 6); p.setValue("RRStartDepth", 4)
+        if mode == "wavefront": p.setValue("PathSemantics", "Wavefront")
+        tr.Resize(32, 24); tr.InitializeScene(gpu.Scene(d, flatten=True)); img = gpu.Image(32, 24)
+        for k in range(3):
+            tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
+        got = img.getPixelData()
+        assert np.array_equal(got[..., 6], want[..., 6]), (mode, env)
+        assert 3 * 64 - got[8:16, 12:20, 6].sum() >= 3, (mode, env)      # some of the panel's samples are NaN and dropped
+        assert (np.abs(got[..., :3] - want[..., :3]) <= 2e-3 * (1 + np.abs(want[..., :3]))).all(), (mode, env)

@@ -39,3 +39,17 @@ def test_fuzz_scene_renders_and_flattens(orc, seed):
         assert np.array_equal(got[k][same], want[k][same]), k
     for k in ("dist", "u", "v"):
         assert np.array_equal(got[k][same].view(np.uint32), want[k][same].view(np.uint32)), k
+
+
+@pytest.mark.parametrize("env", [True, False])
+def test_nan_samples_are_dropped_like_the_reference_drops_them(orc, env):
+    """scenes.coating_from_behind: a primary hit on the panel evaluates a rough coating outside its domain: NaN from its sample when the specular lobe is chosen, as in the reference; the throughput is NaN,
+    the continuation ray leaves the scene, and `cl += misWeight * cf * EvalEnvironment(r)` (PathTracer.cu:99-111) — executed with or without a map — makes the radiance NaN:
+    Image::AddSample's clampNegative keeps the NaN (max(0, NaN) = (0 > NaN) ? 0 : NaN, Math/MathFunc.h:96) and the sample is not counted (Engine/Image.cu:25-28).
+    Both lines were restated wrongly until round 5's parity fuzz (NaN clamped to 0 and counted; no term without a map)."""
+    sc = scenes.coating_from_behind(32, 24, env=env)
+    img, rays = orc.render(sc.desc, 32, 24, n_passes=3, tables=orc.sequence_tables(3), max_path_length=6)
+    assert np.isfinite(img).all()
+    centre = img[8:16, 12:20, 6]
+    assert (centre <= 3).all() and 3 * centre.size - centre.sum() >= 5      # the panel: the samples that chose the specular lobe (NaN) are dropped, the nested lobe's are counted
+    assert img[-3:, :, 6].mean() > 2.9 and img[-3:, :, :3].mean() > 0        # the floor below it: (nearly) every sample counted — a path that bounces into the panel's back is dropped too
