@@ -191,6 +191,8 @@ def test_bathroom_workload_at_full_size(gpu, orc):
             ok = (np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2)
             assert ok.mean() >= frac, (depth, y0, ok.mean())
             assert abs(g.mean() - w.mean()) <= mean_tol * w.mean(), (depth, y0, g.mean(), w.mean())
+            # round 5: rough plastic runs the reference's own transmittance lookup on the device — the bands are equal to the BIT (rounds 2-4: the tolerance only)
+            assert (g == w).all(axis=2).mean() >= 0.97, (depth, y0, float((g == w).all(axis=2).mean()))
     base, rays = render(gpu, gpu.WavefrontPathTracer, flat, tables)
     assert rays > 4 * W * H
     for params in (dict(BlockSort=False), dict(SortMaterials=True), dict(ShadeByModelClass=False)):
