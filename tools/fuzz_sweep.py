@@ -11,7 +11,7 @@ import oracle
 
 W, H, PASSES, DEPTH, RR = 96, 64, 4, 8, 5
 first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (100, 300)
-MODE = sys.argv[3] if len(sys.argv) > 3 else "default"      # default | wavefront (PathSemantics = Wavefront, +u16 on odd seeds) | plugin (the megakernel PathTracer: first-hit ray differentials) | sensors (thin lens / orthographic / telecentric / spherical by seed) | alpha (alpha maps on a third of the materials, AlphaTest = true) | nodirect (Direct = false, depth 5, RRStartDepth 2)
+MODE = sys.argv[3] if len(sys.argv) > 3 else "default"      # default | wavefront (PathSemantics = Wavefront, +u16 on odd seeds) | plugin (the megakernel PathTracer: first-hit ray differentials) | sensors (thin lens / orthographic / telecentric / spherical by seed) | alpha (alpha maps on a third of the materials, AlphaTest = true) | nodirect (Direct = false, depth 5, RRStartDepth 2) | wild (textured roughness / exponents / specular colours, two-sidedness, texture offsets varied in place)
 orc = oracle.Oracle(shared_math=True)
 worst = []; n_bad = 0
 for seed in range(first, last):
@@ -32,6 +32,22 @@ for seed in range(first, last):
                 k = rs.randint(3)
                 t = gpu.api.checker_texture(1.0, 0.0, uv_scale=(float(rs.choice([2.0, 4.0, 7.0])), float(rs.choice([2.0, 3.0])))) if k < 2 else gpu.api.checker_texture((0.9, 0.1, 0.1), (0.1, 0.1, 0.9), uv_scale=(3.0, 3.0))
                 m.alpha_state = 1 if k < 2 else 3; m.alpha_test_scalar = 0.5 if k < 2 else 0.25; m.alpha_test_color[:] = [1.0, 0.0, 0.0]; m.alpha_tex = t
+    if MODE == "wild":      # parameters the scene generator leaves constant, varied in place (both sides read the same records): textured roughness / exponents / specular colours, two-sidedness, texture offsets
+        rs = np.random.RandomState(7000 + seed)
+        def chk(a, b):
+            return gpu.api.checker_texture(a, b, uv_scale=(float(rs.choice([1.0, 3.0, 6.0])), float(rs.choice([2.0, 5.0]))), uv_offset=(float(rs.uniform(0, 1)), float(rs.uniform(0, 1))))
+        slots = {7: (1, 2), 5: (2, 3), 9: (2,), 14: (2,), 2: (1,), 11: (2, 3)}
+        for i in range(d.n_materials):
+            m = d.materials[i]; t = m.bsdf_type
+            if t in slots and rs.randint(2):
+                for k in slots[t]:
+                    a0, a1 = float(rs.uniform(0.03, 0.5)), float(rs.uniform(0.03, 0.5))
+                    m.tex[k] = chk((a0, a0, a0), (a1, a1, a1))
+            if t == 10 and rs.randint(2): e0, e1 = float(rs.uniform(3, 150)), float(rs.uniform(3, 150)); m.tex[2] = chk((e0, e0, e0), (e1, e1, e1))
+            if t in (6, 7) and rs.randint(2): m.tex[0] = chk(tuple(rs.uniform(0.3, 1.0, 3)), tuple(rs.uniform(0.3, 1.0, 3)))
+            if t not in (3, 4, 5) and rs.randint(3) == 0: m.two_sided = 1
+            for k in range(4):
+                if m.tex[k].type in (3, 4) and rs.randint(2): m.tex[k].uv_offset[:] = [float(rs.uniform(-1, 1)), float(rs.uniform(-1, 1))]
     tables = orc.sequence_tables(PASSES)
     kw = {}
     if MODE == "wavefront": kw = dict(wavefront_rules=True, u16_barycentrics=bool(seed & 1))
