@@ -25,7 +25,7 @@ def gpu_pass(scene, tab, depth):
 
 for seed in [int(a) for a in sys.argv[1:]]:
     sc = scenes.fuzz_scene(seed, W, H); d = sc.desc
-    scene = gpu.Scene(d, flatten=True); scene2 = gpu.Scene(d, flatten=False); fb = gpu.api.FlatBvh(d, gpu.api.FLAT_Q4)
+    scene = gpu.Scene(d, flatten=os.environ.get("FLAT", "1") == "1"); scene2 = gpu.Scene(d, flatten=False); fb = gpu.api.FlatBvh(d, gpu.api.FLAT_Q4)
     tables = orc.sequence_tables(PASSES)
     found = []
     for k in range(PASSES):
@@ -56,5 +56,5 @@ for seed in [int(a) for a in sys.argv[1:]]:
                 r[0], r[1], r[2], r[3], MODEL.get(int(r[4]), "?"), extra, m.map_kind, m.tex[0].type, r[5], np.round(r[6:9], 5).tolist(), r[9], int(r[10]), np.round(r[11:14], 5).tolist(), np.round(r[14:17], 5).tolist(), r[17], r[18], r[19]))
             # the same ray through ctl_intersect (both layouts) and the oracle's two traversals
             ray = np.zeros((1, 8), np.float32); ray[0, :3] = r[20:23]; ray[0, 3] = d.ray_trace_eps; ray[0, 4:7] = r[23:26]; ray[0, 7] = np.float32(3.402823466e+38)
-            hits = {"gpu flat": gpu.intersect(scene, ray), "gpu two-level": gpu.intersect(scene2, ray), "oracle two-level": orc.intersect(d, ray), "oracle flat": orc.intersect(d, ray, flat=fb.desc)}
+            hits = {"gpu (the rendering layout)": gpu.intersect(scene, ray), "gpu two-level": gpu.intersect(scene2, ray), "oracle two-level": orc.intersect(d, ray), "oracle flat": orc.intersect(d, ray, flat=fb.desc)}
             print("      ray o %s d %s | %s" % (r[20:23].tolist(), r[23:26].tolist(), " | ".join("%s: tri %d node %d t %.9g u %.6f v %.6f" % (k, h["tri_idx"][0], h["node_idx"][0], h["dist"][0], h["u"][0], h["v"][0]) for k, h in hits.items())))
