@@ -143,23 +143,58 @@ def calibrated_traffic(workload_key):
     return e
 
 
+def strip_comments(text):
+    """C++ source without // and /* */ comments, trailing blanks and empty lines (string and character literals left alone): what source_hash hashes, so that an edit
+    to a COMMENT is not another binary and does not throw a committed counter profile away"""
+    out = []; i = 0; n = len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i); i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2); i = n if j < 0 else j + 2; out.append(" ")
+        else:
+            out.append(c); i += 1
+    return "\n".join(l.rstrip() for l in "".join(out).split("\n") if l.strip())
+
+
 def source_hash(names):
-    """what ties a committed counter profile to the binary: sha256 over the named files of cudatracerlib_amd/csrc (name + content), first 12 hex digits"""
+    """what ties a committed counter profile to the binary: sha256 over the named files of cudatracerlib_amd/csrc (name + content without comments) and over the compiler flags
+    of cudatracerlib_amd/build.py, first 12 hex digits"""
     import hashlib
     h = hashlib.sha256()
     for n in names:
         h.update(n.encode() + b"\0")
         with open(os.path.join(ROOT, "cudatracerlib_amd", "csrc", n), "rb") as f:
-            h.update(f.read())
+            h.update(strip_comments(f.read().decode("utf-8", "replace")).encode())
         h.update(b"\1")
+    h.update(("\0".join(build_flags()) + "\2").encode())
     return h.hexdigest()[:12]
 
 
-# the traversal kernel and the tree it walks / the shade kernels: an edit to any of these files without a re-profile (tools/profile_round.sh -> tools/summarize_profile.py ->
-# profiles/roofline_traffic.json) turns the roofline's counter-side numbers into "unprofiled" instead of quoting another binary's counters (tests/test_profile_hash.py)
-TRAVERSAL_SOURCES = ["traverse_flat.h", "flat_slab.h", "flatten.cpp", "flatten.h", "traverse.h", "kernels.hip"]
-SHADE_SOURCES = ["shade_kernel.inc", "shading.h", "bsdf_complex.h", "bsdf_more.h", "bsdf_rough.h", "spline.h", "material_factory.h", "mipmap.h", "ctl_math.h", "ctl_fmath.h", "compaction.h", "kernels.h",
-                 "shade_basic.hip", "shade_full.hip", "shade_class_a.hip", "shade_class_b.hip", "shade_class_c.hip", "shade_class_g.hip", "shade_class_p.hip"]
+def build_flags():
+    """FLAGS of cudatracerlib_amd/build.py, read from the file itself: importing the package here would load libctl_amd.so (and its HIP runtime) at bench.py's import time, before
+    the ranks of an N-rank run have chosen their device and before torch brings its own — the ranks then saw no device (found by the 2-rank GPU test)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ctl_build_flags", os.path.join(ROOT, "cudatracerlib_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return list(m.FLAGS)
+
+
+# Every file that decides what the profiled kernels DO: the kernel and its headers, the builders of the tree it walks (the flattener AND the BVH2 builder with its
+# re-optimisation pass), the host code that lays the device scene out (tracer.hip: leaf keys, rough-transmittance rows), the structs both sides share, the measurement knobs,
+# every build stub of the shade source.  An edit to the CODE of any of them (comments do not count) without a re-profile (tools/profile_round.sh -> tools/summarize_profile.py ->
+# profiles/roofline_traffic.json) turns the roofline's counter-side numbers into "unprofiled" instead of quoting another binary's counters (tests/test_profile_hash.py).
+_COMMON_SOURCES = ["tracer.hip", "tracer.h", "device_scene.h", "kernels.h", "knobs.h", "ctl_math.h", "compaction.h"]
+TRAVERSAL_SOURCES = ["traverse_flat.h", "flat_slab.h", "flatten.cpp", "flatten.h", "bvh_builder.cpp", "bvh_builder.h", "traverse.h", "traverse_flat8.h", "flat8.h", "kernels.hip"] + _COMMON_SOURCES
+SHADE_SOURCES = ["shade_kernel.inc", "shading.h", "bsdf_complex.h", "bsdf_more.h", "bsdf_rough.h", "spline.h", "material_factory.h", "material_textures.h", "mipmap.h", "mip_pyramid.h", "ctl_fmath.h",
+                 "shade_basic.hip", "shade_full.hip", "shade_class_a.hip", "shade_class_b.hip", "shade_class_c.hip", "shade_class_g.hip", "shade_class_p.hip",
+                 "shade_basic_wf.hip", "shade_full_wf.hip", "shade_class_a_wf.hip", "shade_class_b_wf.hip", "shade_class_c_wf.hip", "shade_class_g_wf.hip", "shade_class_p_wf.hip"] + _COMMON_SOURCES
 KERNEL_BUILD = "trav-" + source_hash(TRAVERSAL_SOURCES)
 SHADE_BUILD = "shade-" + source_hash(SHADE_SOURCES)
 

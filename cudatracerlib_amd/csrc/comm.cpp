@@ -150,8 +150,14 @@ struct Comm {
     ncclComm_t comm = nullptr; int rank = 0, world = 1; hipStream_t stream = nullptr; hipEvent_t done = nullptr;
     int timeout_ms = 0;        // of every collective on this communicator (ctl_comm_create_timeout's argument)
     bool dead = false;         // a collective timed out and the communicator was aborted: every later call is refused, the destructor does not enter ncclCommDestroy
+    bool stuck = false;        // ... and the abort was not available or failed: a collective may still be reading / writing send / recv and sits on `stream` — those three are LEAKED, never freed or synchronised
     dbuf<float> send, recv;    // packed tiles of this rank / of every rank (root only), kept between gathers
-    ~Comm() { if (comm && !dead) (void)rccl().CommDestroy(comm); if (done) (void)hipEventDestroy(done); if (stream) (void)hipStreamDestroy(stream); }
+    ~Comm() {
+        if (comm && !dead) (void)rccl().CommDestroy(comm);
+        if (stuck) { send.p = nullptr; send.n = 0; recv.p = nullptr; recv.n = 0; return; }   // hipFree / hipStreamDestroy / hipEventDestroy would wait for the stuck collective
+        if (done) (void)hipEventDestroy(done);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
 // how long a collective call may take before it is given up (ms; ctl_comm_create_timeout's argument, else $CTL_COMM_TIMEOUT_MS, else 120 s).  A rank that never arrives makes
 // ncclCommInitRank / ncclReduce / ncclGather wait for ever: the caller gets an error it can act on (bench.py falls back to torch.distributed on every rank) instead of a hung job.
@@ -210,9 +216,12 @@ static void wait_done(Comm* c, const char* what) {
         const auto now = std::chrono::steady_clock::now();
         if (now > deadline) {
             c->dead = true;
-            if (rccl().CommAbort) (void)rccl().CommAbort(c->comm);    // ends the kernel of the collective; the stream drains
-            (void)hipStreamSynchronize(c->stream);
-            throw std::runtime_error(std::string(what) + " did not complete within " + std::to_string(c->timeout_ms) + " ms; the communicator was aborted (create a new one, or fall back)");
+            // ncclCommAbort ends the kernel of the collective and the stream drains: only THEN is it safe to wait for the stream.  Without the symbol (the dlsym is optional) or
+            // when the abort fails, waiting would block for ever on the very collective the deadline is for: throw at once and leak the buffers it may still touch (Comm::stuck)
+            const bool aborted = rccl().CommAbort && rccl().CommAbort(c->comm) == ncclSuccess;
+            if (aborted) (void)hipStreamSynchronize(c->stream); else c->stuck = true;
+            throw std::runtime_error(std::string(what) + " did not complete within " + std::to_string(c->timeout_ms) + " ms; " +
+                                     (aborted ? "the communicator was aborted" : "the communicator could not be aborted (its buffers and stream are left to the stuck collective)") + " (create a new one, or fall back)");
         }
         if (now - start > std::chrono::milliseconds(5)) std::this_thread::sleep_for(std::chrono::microseconds(50));   // spin for the first 5 ms (an exchange takes < 1), then poll
     }

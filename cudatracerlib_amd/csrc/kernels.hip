@@ -248,6 +248,14 @@ void read_stack_histogram(unsigned long long* h, bool reset) {
     if (reset) { unsigned long long z[kStackSize] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stack_hist), z, sizeof(z)) != hipSuccess) throw std::runtime_error("clearing the stack histogram failed"); }
 }
 static unsigned g_lds_pad = 0;   // extra dynamic LDS per traversal workgroup: holds the kernels to fewer resident workgroups per CU (occupancy experiment)
+// Grid of a traversal launch: exactly the workgroups that are resident together — per CU the waves per SIMD of the kernel's __launch_bounds__ (a 256-lane workgroup is one wave
+// on each of the four SIMDs), or what the CU's 160 KB of LDS hold if that is fewer.  The waves' first ray claims are static (traverse.h ray_claims): a workgroup that had to
+// wait for a place would keep its share of the rays waiting with it.  (lc.grid_blocks = 8 workgroups per CU.)
+static int traversal_blocks(const launch_ctx& lc, int layout, bool alpha) {
+    const int cus = lc.grid_blocks / 8, by_regs = (layout && !alpha) ? CTL_INTERSECT_MIN_WAVES : 6;
+    const int by_lds = (int)((160u * 1024u) / ((unsigned)sizeof(int) * (unsigned)lds_stack_ints(layout) + g_lds_pad));
+    return cus * (by_regs < by_lds ? by_regs : by_lds);
+}
 void apply_tuning_from_env() {
     static bool done = false;
     if (done) return;
@@ -268,8 +276,8 @@ void launch_raygen(const launch_ctx& lc, const dev_scene& S, const wave_queues& 
 }
 #define CTL_LAUNCH_INTERSECT_L(ANY, CNT, L, ...)                                                                                     \
     do {                                                                                                                             \
-        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect<ANY, CNT, L, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((k_intersect<ANY, CNT, L, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, __VA_ARGS__);     \
+        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect<ANY, CNT, L, true>), dim3(traversal_blocks(lc, L, true)), dim3(kBlock), g_lds_pad, lc.stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((k_intersect<ANY, CNT, L, false>), dim3(traversal_blocks(lc, L, false)), dim3(kBlock), g_lds_pad, lc.stream, __VA_ARGS__);     \
     } while (0)
 // The product traverses Q4 nodes.  The F4 / F2 node formats are measured experiments (0.69x and 0.66x of Q4's rays/s); their kernels are
 // compiled only with -DCTL_FLAT_EXPERIMENTS, and a scene asking for them is refused otherwise (tracer.hip).
@@ -298,16 +306,16 @@ void launch_intersect_any(const launch_ctx& lc, const dev_scene& S, const float4
 void launch_intersect_pair(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node,
                            const float4* sro, const float4* srd, const uint32_t* sn_ptr, uint32_t* swork, uint32_t* occ) {
     if (!S.flat_nodes) {
-        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<0, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
-        else hipLaunchKernelGGL((k_intersect_pair<0, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<0, true>), dim3(traversal_blocks(lc, 0, true)), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        else hipLaunchKernelGGL((k_intersect_pair<0, false>), dim3(traversal_blocks(lc, 0, false)), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
 #ifndef CTL_FLAT_EXPERIMENTS
     } else if (S.flat_format == kFmtQ8) {
-        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<4, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
-        else hipLaunchKernelGGL((k_intersect_pair<4, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<4, true>), dim3(traversal_blocks(lc, 4, true)), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        else hipLaunchKernelGGL((k_intersect_pair<4, false>), dim3(traversal_blocks(lc, 4, false)), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
 #endif
     } else {
-        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<1, true>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
-        else hipLaunchKernelGGL((k_intersect_pair<1, false>), dim3(lc.grid_blocks), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        if (lc.alpha_test) hipLaunchKernelGGL((k_intersect_pair<1, true>), dim3(traversal_blocks(lc, 1, true)), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
+        else hipLaunchKernelGGL((k_intersect_pair<1, false>), dim3(traversal_blocks(lc, 1, false)), dim3(kBlock), g_lds_pad, lc.stream, S, ro, rd, n_ptr, work, hit, hit_node, sro, srd, sn_ptr, swork, occ);
     }
 }
 void launch_intersect_count(const launch_ctx& lc, const dev_scene& S, const float4* ro, const float4* rd, const uint32_t* n_ptr, uint32_t* work, float4* hit, int* hit_node,

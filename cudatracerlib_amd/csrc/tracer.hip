@@ -126,27 +126,6 @@ Scene::Scene(const ctl_scene_desc& d, bool flatten, int flat_format, bool reduce
             S.rough_transmittance = rt_.p;
         }
     }
-    S.rt_reduced = nullptr;
-    if (d.rough_transmittance) {
-        std::vector<float> pool; size_t off_t[3] = {}, off_d[3] = {};
-        for (int i = 0; i < 3; i++) {
-            const ctl_rough_transmittance& t = d.rough_transmittance[i];
-            if (!t.trans || !t.diff_trans) continue;
-            const size_t nt = (size_t)2 * t.eta_samples * t.alpha_samples * t.theta_samples, nd = (size_t)2 * t.eta_samples * t.alpha_samples;
-            off_t[i] = pool.size(); pool.insert(pool.end(), t.trans, t.trans + nt);
-            off_d[i] = pool.size(); pool.insert(pool.end(), t.diff_trans, t.diff_trans + nd);
-        }
-        if (!pool.empty()) {
-            rt_data_.upload(pool.data(), pool.size());
-            ctl_rough_transmittance tab[3];
-            for (int i = 0; i < 3; i++) { tab[i] = d.rough_transmittance[i]; const bool ok = tab[i].trans && tab[i].diff_trans; tab[i].trans = ok ? rt_data_.p + off_t[i] : nullptr; tab[i].diff_trans = ok ? rt_data_.p + off_d[i] : nullptr; }
-            rt_.upload(tab, 3);
-            S.rough_transmittance = rt_.p;
-        }
-    }
-    // Rough plastics with a CONSTANT roughness texture look the transmittance table up at fixed (alpha, eta): reduce the 3-D cubic interpolation
-    // (64 taps per lookup, three to five lookups per shaded vertex) to a 1-D table in cos(theta) once, here.  Same spline weights
-    // (Math/Spline.cu:223-453 via RoughTransmittance.cu:55-119), summed alpha / eta first instead of last: equal up to fp32 rounding.
     // Rough plastics with a CONSTANT roughness texture look RoughTransmittanceManager's table up at a fixed (alpha, eta) (RoughTransmittance.cu:55-88 -> Math/Spline.cu:376-453).
     // What depends on those two alone is made here, once per material (bsdf_rough.h roughplastic_T):
     //  * default — the sixteen rows the 3-D interpolation reads for this (alpha, eta) and the sixteen products wy * wz of its weights; the device runs the reference's own sum

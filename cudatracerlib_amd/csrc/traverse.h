@@ -37,6 +37,40 @@ __device__ __forceinline__ uint32_t guided_chunk(uint32_t n, uint32_t last_base)
     return c < 64u ? 64u : (c > kChunk ? kChunk : c);
 }
 
+// A wave's claims from the launch's ray cursor.  The FIRST claim is static — wave w takes rays [w c0, (w + 1) c0), c0 = the guided claim for the whole queue — and only what
+// lies beyond the waves' static shares goes through the cursor (which counts from 0 there).  Round 6: one address serves ~88 atomics per microsecond, a launch has 8192 (7168)
+// waves, and every wave used to open with one claim and end with one that found the cursor past the end — two bursts of ~90 us per queue whatever its size, four per fused
+// launch: the 0.33 ms a near-empty traversal launch took.  A queue of fewer rays than the static shares cover now needs no atomic at all.  (The grid holds exactly the
+// workgroups that are resident together, kernels.hip traversal_blocks: a workgroup that started late would sit on its static share.)
+#ifndef CTL_STATIC_FIRST_CLAIM
+#define CTL_STATIC_FIRST_CLAIM 1
+#endif
+struct ray_claims {
+    uint32_t next, end, static_total; bool exhausted;
+    __device__ __forceinline__ void init(uint32_t n) {
+#if CTL_STATIC_FIRST_CLAIM
+        const uint32_t waves = gridDim.x * (blockDim.x >> 6), wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), c0 = guided_chunk(n, 0u);
+        const uint64_t all = (uint64_t)waves * c0, mine = (uint64_t)wave * c0;
+        static_total = all < n ? (uint32_t)all : n;
+        next = mine < n ? (uint32_t)mine : n; end = mine + c0 < n ? (uint32_t)(mine + c0) : n;
+        exhausted = next >= end && static_total >= n;   // no static share (the queue is shorter than that) and then nothing behind the shares either
+#else
+        static_total = 0u; next = end = 0u; exhausted = n == 0u;
+#endif
+    }
+    // the next range once [next, end) is used up; false (and exhausted) when there is none.  Wave-uniform; lane 0 does the atomic.
+    __device__ __forceinline__ bool refill(uint32_t n, uint32_t* __restrict__ work, int lane) {
+        if (static_total >= n) { exhausted = true; next = end = n; return false; }
+        const uint32_t claim = guided_chunk(n, end);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(work, claim);
+        base = static_total + (uint32_t)__shfl((int)base, 0, 64);
+        if (base >= n || base < static_total) { exhausted = true; next = end = n; return false; }   // (< static_total: the cursor ran past 2^32 - static_total, i.e. far past the end)
+        next = base; end = base + claim < n && base + claim > base ? base + claim : n;
+        return true;
+    }
+};
+
 __device__ __forceinline__ float rcp_guarded(float d) {   // TraceHelper.cu:417-420: 1/(|d| > 2^-80 ? d : copysign(2^-80, d))
     const float ooeps = 8.271806125530277e-25f;   // exp2(-80)
     return 1.0f / (fabsf(d) > ooeps ? d : copysign_bits(ooeps, d));
@@ -86,7 +120,8 @@ __device__ __forceinline__ void intersect_persistent(const dev_scene& S, const f
     const float4* __restrict__ nodes = S.top_nodes;
     int sp = 0, node = kSentinel, sp_enter = 0, cur_inst = -1; uint32_t leaf_base = 0, tri_base = 0; bool bottom = false;
     // ---- per-wave ray chunk (uniform)
-    uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = (n == 0) || S.n_nodes == 0;
+    ray_claims rc; rc.init(n); if (S.n_nodes == 0) rc.exhausted = true;
+    uint32_t& chunk_next = rc.next; uint32_t& chunk_end = rc.end; bool& exhausted = rc.exhausted;
     if (S.n_nodes == 0) {   // empty scene: every ray misses (TraceHelper.cu:442-443)
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
             if (ANY_HIT && occ) occ[i] = 0u;
@@ -99,14 +134,7 @@ __device__ __forceinline__ void intersect_persistent(const dev_scene& S, const f
         // ---- refill idle lanes
         const unsigned long long idle = __ballot(!has_ray);
         if (idle != 0ull && !exhausted && (__popcll(idle) >= refill_idle || idle == ~0ull)) {
-            if (chunk_next >= chunk_end) {
-                const uint32_t claim = guided_chunk(n, chunk_end);
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work, claim);
-                base = __shfl(base, 0, 64);
-                chunk_next = base; chunk_end = base + claim < n ? base + claim : n;
-                if (base >= n) { exhausted = true; chunk_next = chunk_end = n; }
-            }
+            if (chunk_next >= chunk_end) rc.refill(n, work, lane);
             if (!exhausted) {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
                 const uint32_t avail = chunk_end - chunk_next, want = (uint32_t)__popcll(idle);

@@ -26,7 +26,12 @@ namespace ctl {
 
 enum { kFmtQ4 = 0, kFmtF4 = 1, kFmtF2 = 2, kFmtQ8 = 3 };   // = flat_format (flatten.h); Q8 has its own kernel body (traverse_flat8.h), F4 / F2 are experiment builds
 
-constexpr int kFlatLdsRows = 19;          // stack entries per lane in LDS (+ 1 spare row: 20 KiB per 256-lane workgroup, seven workgroups per CU); deeper entries live in scratch (0.015 % of the bench rays, profiles/r03a_stack_histogram.log)
+#ifndef CTL_FLAT_LDS_ROWS
+#define CTL_FLAT_LDS_ROWS 23   // round 6: 23 rows + 1 spare = 24 KiB per 256-lane workgroup, SIX workgroups per CU (rounds 3-5: 19 rows, 20 KiB, seven).  Held to six by LDS padding the round-5 kernel
+                               // ran 0.75 % faster, to five 0.8 % slower, to four 10 % (profiles/r06_lanes.log item 1); with the rows put to use: synthetic-SM 3123 / 3130 -> 3181 / 3170 Mrays/s,
+                               // one rank of eight 19.86 -> 19.06 ms per 20 passes; 80 VGPRs (6 waves by registers too) the same (profiles/r06_traversal.log)
+#endif
+constexpr int kFlatLdsRows = CTL_FLAT_LDS_ROWS;          // stack entries per lane in LDS (+ 1 spare row); deeper entries live in scratch (19 rows: 0.015 % of the bench rays, profiles/r03a_stack_histogram.log)
 constexpr int kFlatStackInts = 1;
 constexpr int kTopCache = 0, kTopCacheFloats = 12;   // (experiment builds keep the top of the tree in LDS)
 __device__ unsigned long long g_stack_hist[kStackSize];   // counting kernels only: rays by the deepest traversal-stack entry they used (ctl_traversal_stack_histogram)
@@ -237,20 +242,14 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
     constexpr int kAlphaBatch = 12;   // lanes with a candidate that start an alpha phase (4 / 8 / 12 / 20 / 32: 12.07 / 10.93 / 10.59 / 10.66 / 11.94 ms of traversal per pass on synthetic-sm-hard with AlphaTest)
     int sp_max = 0;                               // COUNT: deepest stack entry of the lane's current ray
     const float4* __restrict__ nodes = S.flat_nodes;
-    uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = (n == 0);
+    ray_claims rc; rc.init(n);   // traverse.h: the first claim is static, the rest goes through the cursor
+    uint32_t& chunk_next = rc.next; uint32_t& chunk_end = rc.end; bool& exhausted = rc.exhausted;
 
     for (;;) {
         // ---- refill idle lanes
         const unsigned long long idle = __ballot(!has_ray);
         if (idle != 0ull && !exhausted && (__popcll(idle) >= refill_idle || idle == ~0ull)) {
-            if (chunk_next >= chunk_end) {
-                const uint32_t claim = guided_chunk(n, chunk_end);
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work, claim);
-                base = __shfl(base, 0, 64);
-                chunk_next = base; chunk_end = base + claim < n ? base + claim : n;
-                if (base >= n) { exhausted = true; chunk_next = chunk_end = n; }
-            }
+            if (chunk_next >= chunk_end) rc.refill(n, work, lane);
             if (!exhausted) {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
                 const uint32_t avail = chunk_end - chunk_next, want = (uint32_t)__popcll(idle);

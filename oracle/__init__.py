@@ -76,6 +76,7 @@ def load(shared_math=False):
     o.orc_env_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     o.orc_texture_eval.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
     o.orc_set_block_counts.argtypes = [C.c_void_p, u32]
+    o.orc_set_zero_stop_image.argtypes = [C.c_void_p]; o.orc_set_zero_stop_image.restype = None
     o.orc_sample_normal_map.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p, C.c_void_p]
     o.orc_alpha_test.argtypes = [C.c_void_p, C.c_void_p, f32, f32]
     o.orc_triangle_data_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_int, C.c_void_p]
@@ -149,7 +150,7 @@ class Oracle:
         return hits
 
     def render(self, desc, width, height, n_passes=1, tables=None, direct=True, max_path_length=8, rr_start=5, threads=8, rows=None, half_host_quirk=False, alpha_test=False, block_counts=None,
-               flat=None, counts=None, partials=False, regularization=False, wavefront_rules=False, u16_barycentrics=False, omit_last_nee=False):
+               flat=None, counts=None, partials=False, regularization=False, wavefront_rules=False, u16_barycentrics=False, omit_last_nee=False, zero_stop=None):
         """pathKernel2<DIRECT,false> over all pixels (Integrators/PathTracer.cu:182-194). tables = list of (t1, t2) per pass or None.
         alpha_test: traceRay<USE_ALPHA> when the scene has alpha maps (what the reference's single-ray path does; its wavefront
         intersectKernel has no alpha test).
@@ -159,6 +160,8 @@ class Oracle:
         partials: first-hit ray differentials + filtered (trilinear / EWA) texture lookups, as the megakernel PathTracer does (PathTracer.cu:60-61).
         flat: a ctl_flat_bvh_desc -> every ray walks the product's flattened BVH (same hits, other visiting order).
         counts: a dict that receives the traversal statistics of this render (path_rays, path_inner, path_tri, path_inst, occ_rays, ...).
+        zero_stop: a float32 array (h, w, 7), added to: the samples the reference drops as NaN / infinite AFTER the path's throughput had become exactly zero, each as the
+            radiance collected up to that vertex (what the product's kernels, which end such a path at once, count) — kernels' frame == returned frame + zero_stop.
         Returns (pixel_data (h, w, 7), rays)."""
         img = np.zeros((height, width, 7), np.float32)
         y0, y1 = (0, height) if rows is None else rows
@@ -173,6 +176,9 @@ class Oracle:
             bc = np.ascontiguousarray(block_counts, np.uint8).ravel()
             self.lib.orc_set_block_counts(bc.ctypes.data, (width + 63) // 64)
         self.lib.orc_set_flat_bvh(C.addressof(flat) if flat is not None else None)
+        if zero_stop is not None:
+            assert zero_stop.dtype == np.float32 and zero_stop.shape == (height, width, 7) and zero_stop.flags["C_CONTIGUOUS"]
+            self.lib.orc_set_zero_stop_image(zero_stop.ctypes.data)
         if counts is not None:
             self.lib.orc_render_counting(1)
         try:
@@ -180,6 +186,7 @@ class Oracle:
                                        img.ctypes.data, threads, y0, y1, (1 if half_host_quirk else 0) | (2 if alpha_test else 0) | (4 if partials else 0) | (8 if regularization else 0) | (16 if wavefront_rules else 0) | (32 if u16_barycentrics else 0) | (64 if omit_last_nee else 0))
         finally:
             self.lib.orc_set_flat_bvh(None)
+            self.lib.orc_set_zero_stop_image(None)
             if counts is not None:
                 c8 = (u64 * 8)()
                 self.lib.orc_render_counts(c8)

@@ -1512,11 +1512,18 @@ struct RayDiff { V3 ox, dx, oy, dy; };   // the sensor's x / y differential rays
 // debugging aid of the parity fuzz (tools/fuzz_diag.py): when set for this thread, pathTrace appends one record of 26 floats per vertex —
 // depth, triangle, node, material index, BSDF model, light index (-1), f.rgb, pdf, sampled type, cf.rgb and cl.rgb AFTER the vertex, hit distance, u, v, the ray that found the vertex (origin, direction)
 inline std::vector<float>*& pathLog() { static thread_local std::vector<float>* p = nullptr; return p; }
+// What the PRODUCT's kernels add for a path whose throughput became exactly zero (a test's aid, not the reference): they stop such a path at once (it cannot contribute
+// any more; shade_kernel.inc, megakernel.hip) and count the radiance collected so far, where the reference traces it on — and DROPS the whole sample when the dead path later
+// meets a NaN (Image::AddSample).  The path functions note the radiance at the first zero throughput here; orc_render adds it to a side image when the sample is then dropped
+// (orc_set_zero_stop_image), so that a test can hold the kernels' frame to `oracle frame + side image` pixel by pixel instead of masking the pixels whose weights differ.
+struct ZeroStop { bool have = false; bool pending = false; Spec cl; };
+inline ZeroStop& zeroStop() { static thread_local ZeroStop z; return z; }
 inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, int maxPathLength, int rrStartDepth, uint64_t* rays, const RayDiff* diff = nullptr, bool omitLastNEE = false) {
     Spec cl(0.0f), cf(1.0f);
     int depth = 0; bool specularBounce = false;
     BRec bRec; Hit r2; r2.init();
     float brdf_scattering_pdf = 0; V3 last_nor;
+    zeroStop() = ZeroStop();
     while (depth++ < maxPathLength) {
         r2 = traceRayClosest(S, ro, rd);
         if (rays) (*rays)++;
@@ -1544,6 +1551,7 @@ inline Spec pathTrace(const Scene& S, bool DIRECT, V3 ro, V3 rd, Sampler& rnd, i
             if (DIRECT && bsdfHasComponent(mat, ESmooth) && !(omitLastNEE && depth == maxPathLength)) cl = cl + cf * uniformSampleOneLight(S, bRec, mat, rnd, rays);
             specularBounce = (bRec.sampledType & EDelta) != 0;
             cf = cf * f;
+            if (!zeroStop().have && isZero(cf)) { zeroStop().have = true; zeroStop().cl = cl; }   // where the kernels end the path (next-event estimation of this vertex included, as theirs is)
             ro = bRec.dg.P; rd = bRec.dg.sys.toWorld(bRec.wo);   // BSDFSamplingRecord::getOutgoing (Samples.cu)
             if (pathLog()) {
                 const float rec[26] = { (float)depth, (float)r2.tri, (float)r2.node, (float)(&mat - S.d.materials), (float)mat.bsdf_type, li == UINT32_MAX ? -1.0f : (float)li, f.x, f.y, f.z,
@@ -1602,6 +1610,7 @@ inline Spec pathTraceWavefront(const Scene& S, bool NEE, V3 ro, V3 rd, Sampler& 
     Spec L(0.0f), throughput(1.0f), directF(0.0f);
     bool specular_bounce = true, have_shadow = false; float bsdf_pdf = 0.0f, dDist = 0.0f; uint16_t prev_normal = 0; V3 sh_o, sh_d;
     BRec bRec;
+    zeroStop() = ZeroStop();
     for (int pathDepth = 0; pathDepth < maxPathDepth; pathDepth++) {
         Hit res = traceRayClosest(S, ro, rd);
         if (rays) (*rays)++;
@@ -1615,6 +1624,7 @@ inline Spec pathTraceWavefront(const Scene& S, bool NEE, V3 ro, V3 rd, Sampler& 
             if (sh.dist >= dDist * (1 - S.d.ray_trace_eps)) L = L + directF;
             have_shadow = false; directF = Spec(0.0f);
         }
+        if (zeroStop().pending) { zeroStop().pending = false; zeroStop().have = true; zeroStop().cl = L; }   // the kernels' sample of a path that died at the previous vertex: its last shadow ray resolved
         bool path_terminated = (pathDepth + 1 == maxPathDepth);
         if (res.hasHit()) {
             getBsdfSample(S, res, ro, rd, bRec);
@@ -1657,6 +1667,7 @@ inline Spec pathTraceWavefront(const Scene& S, bool NEE, V3 ro, V3 rd, Sampler& 
                 }
                 prev_normal = normalToUchar2(bRec.dg.sys.n);
                 throughput = throughput * f;
+                if (!zeroStop().have && !zeroStop().pending && isZero(throughput)) zeroStop().pending = true;   // the kernels end the path here (shade_kernel.inc: alive = !is_zero(cf))
                 ro = new_o; rd = new_d;
             } else path_terminated = true;
         } else {   // :143-157
@@ -1713,6 +1724,7 @@ inline Spec pathTraceRegularization(const Scene& S, bool DIRECT, V3 ro, V3 rd, c
     Spec cl(0.0f), cf(1.0f);
     int depth = 0; bool specularBounce = false;
     BRec bRec;
+    zeroStop() = ZeroStop();   // (k_path_trace_regularization makes no zero-throughput cut)
     for (;;) {   // while (traceRay(r, &r2) && depth++ < maxPathLength)
         r2 = traceRayClosest(S, ro, rd);
         if (rays) (*rays)++;

@@ -305,6 +305,11 @@ int orc_alpha_test(const ctl_scene_desc* desc, const ctl_material* mat, float u,
 // samples per 64x64 block for the following orc_render calls (a block sampler's decision for one pass); NULL = one sample everywhere
 static const uint8_t* g_block_counts = nullptr; static uint32_t g_blocks_x = 0;
 void orc_set_block_counts(const uint8_t* counts, uint32_t blocks_x) { g_block_counts = counts; g_blocks_x = blocks_x; }
+// side image of the following orc_render calls (same size as the frame; NULL = none): the samples the reference DROPS as NaN / infinite although the path's throughput had
+// become exactly zero before — for each, the radiance collected up to that vertex (ocore.h ZeroStop), added as Image::AddSample would.  The product's kernels end a
+// zero-throughput path at once and count that radiance: their frame = the oracle's frame + this image, weights included (tests/test_gpu_fuzz.py).
+static ctl_pixel_data* g_zero_stop_img = nullptr;
+void orc_set_zero_stop_image(ctl_pixel_data* img) { g_zero_stop_img = img; }
 // counting mode of orc_render: traversal statistics of every ray the following renders trace.  out8 = {path rays, n_inner, n_tri, n_inst,
 // occlusion rays, n_inner, n_tri, n_inst}; orc_render_counts(NULL) switches counting off, a non-NULL call reads and resets the totals.
 static bool g_count_render = false; static uint64_t g_render_counts[8] = {};
@@ -377,6 +382,11 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
                     else
                     col = pathTrace(S, direct != 0, o, d, rng, maxPathLength, rrStart, &rays, partials ? &diff : nullptr, omitLastNEE);   // imp == 1 (Sensor.cu:127)
                     addSample(img, (int)W, (int)H, pX.x, pX.y, col);
+                    if (g_zero_stop_img && zeroStop().have) {
+                        const Spec c = V3(fmax2(0.0f, col.x), fmax2(0.0f, col.y), fmax2(0.0f, col.z));
+                        const bool dropped = std::isnan(c.x) || std::isnan(c.y) || std::isnan(c.z) || std::isinf(c.x) || std::isinf(c.y) || std::isinf(c.z);
+                        if (dropped) addSample(g_zero_stop_img, (int)W, (int)H, pX.x, pX.y, zeroStop().cl);
+                    }
                 }
             }
             if (pass + 1 < n_passes) barrier();

@@ -23,8 +23,11 @@ def _render(gpu, scene, tables, mode, seed):
     return img.getPixelData()
 
 
+ZERO_STOP_SEEDS = (102, 146)   # scenes of profiles/r05_fuzz.log whose one-sided coatings are seen from behind: the reference drops samples there that the kernels' zero-throughput cut keeps
+
+
 @pytest.mark.parametrize("mode", ["default", "wavefront", "plugin"])
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(12)) + list(ZERO_STOP_SEEDS))
 def test_fuzz_scene_gpu_equals_oracle(gpu, orc, seed, mode):
     """mode: default = the wavefront plugin with PathTrace<DIRECT>'s rules; wavefront = pathIterateKernel's own rules (PathSemantics = Wavefront; 16-bit barycentrics on odd seeds)
     against the oracle's pathTraceWavefront; plugin = the megakernel PathTracer with first-hit ray differentials against the oracle with partials"""
@@ -32,22 +35,29 @@ def test_fuzz_scene_gpu_equals_oracle(gpu, orc, seed, mode):
     d = sc.desc
     tables = orc.sequence_tables(PASSES)
     kw = dict(wavefront_rules=True, u16_barycentrics=bool(seed & 1)) if mode == "wavefront" else (dict(partials=True) if mode == "plugin" else {})
-    want, _ = orc.render(d, W, H, n_passes=PASSES, tables=tables, max_path_length=DEPTH, rr_start=RR, **kw)
+    # Samples the reference DROPS (Image::AddSample returns on a NaN radiance, Engine/Image.cu:25-28): a BSDF evaluated outside its domain — a one-sided rough coating seen from
+    # behind has no side check before its microfacet sample (BSDF_Complex.cu:159-223), a zero-pdf vertex that hits an emitter makes 0 / 0 of its MIS weight — poisons the whole
+    # sample.  The kernels stop a path whose throughput became exactly zero (no contribution can follow), so where the reference's path went on and met such a NaN LATER they keep
+    # the radiance collected so far and count the sample.  The oracle says which samples those are and what the kernels' rule makes of each (zero_stop: the radiance at the
+    # first zero throughput of every sample it then drops, added as AddSample would): the kernels' frame must equal `oracle frame + zero_stop` in EVERY pixel — weights exactly,
+    # colours at the bar of the other tests.  (Round 5 masked the pixels whose weights differ; a weight that differs for any OTHER reason now fails.)
+    zero_stop = np.zeros((H, W, 7), np.float32)
+    want, _ = orc.render(d, W, H, n_passes=PASSES, tables=tables, max_path_length=DEPTH, rr_start=RR, zero_stop=zero_stop, **kw)
+    assert (zero_stop[..., 6] > 0).mean() <= 0.05, ("zero-throughput drops", seed, float((zero_stop[..., 6] > 0).mean()))
+    if seed in ZERO_STOP_SEEDS: assert zero_stop[..., 6].sum() > 0, seed   # (the case is exercised, not only allowed; seeds 3, 5, 7, 8 have a few such samples as well)
+    untouched = zero_stop[..., 6] == 0
+    want = want + zero_stop
     for flatten in ((True,) if mode == "plugin" else (False, True)):
         got = _render(gpu, gpu.Scene(d, flatten=flatten), tables, mode, seed)
         g, w = got[..., :3], want[..., :3]
         assert np.isfinite(g).all()
-        # Samples the reference DROPS (Image::AddSample returns on a NaN radiance, Engine/Image.cu:25-28): a BSDF evaluated outside its domain — a one-sided rough coating seen from
-        # behind has no side check before its microfacet sample (BSDF_Complex.cu:159-223), a zero-pdf vertex that hits an emitter makes 0 / 0 of its MIS weight — poisons the whole
-        # sample.  The kernels stop a path whose throughput became exactly zero (no contribution can follow), so where the reference's path went on and met such a NaN LATER they keep
-        # the radiance collected so far and count the sample: pixels whose weights differ are that case, bounded here and left out of the colour comparison.
-        same_w = got[..., 6] == want[..., 6]
-        assert (~same_w).mean() <= 0.01 and (got[..., 6] >= want[..., 6]).all(), ("weightSum", seed, flatten, float((~same_w).mean()))
-        ok = (np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2) | ~same_w
+        assert np.array_equal(got[..., 6], want[..., 6]), ("weightSum", seed, flatten, np.argwhere(got[..., 6] != want[..., 6])[:4].tolist())
+        ok = (np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2)
         assert (~ok).sum() == 0, (seed, flatten, int((~ok).sum()), np.argwhere(~ok)[:4].tolist(), g[~ok][:2].tolist(), w[~ok][:2].tolist())
-        assert abs(g[same_w].mean() - w[same_w].mean()) <= 1e-3 * max(w[same_w].mean(), 1e-6), (seed, flatten)
+        assert abs(g.mean() - w.mean()) <= 1e-3 * max(w.mean(), 1e-6), (seed, flatten)
         # every model runs the checker's arithmetic on the device (rough plastic / rough coating included: the reference's 3-D transmittance lookup): bit-equal frames
-        assert (g == w).all(axis=2)[same_w].mean() >= 0.97, (seed, flatten, float((g == w).all(axis=2)[same_w].mean()))
+        # (a pixel that received a zero-stop sample adds it in another order than the kernels' pass order: left out of THIS bar only)
+        assert (g == w).all(axis=2)[untouched].mean() >= 0.97, (seed, flatten, float((g == w).all(axis=2)[untouched].mean()))
 
 
 @pytest.mark.parametrize("seed", list(range(12)))

@@ -53,3 +53,23 @@ def test_nan_samples_are_dropped_like_the_reference_drops_them(orc, env):
     centre = img[8:16, 12:20, 6]
     assert (centre <= 3).all() and 3 * centre.size - centre.sum() >= 5      # the panel: the samples that chose the specular lobe (NaN) are dropped, the nested lobe's are counted
     assert img[-3:, :, 6].mean() > 2.9 and img[-3:, :, :3].mean() > 0        # the floor below it: (nearly) every sample counted — a path that bounces into the panel's back is dropped too
+
+
+@pytest.mark.parametrize("seed", [0, 3, 146])
+def test_zero_stop_side_image(orc, seed):
+    """orc.render(zero_stop=...): the samples the reference drops as NaN AFTER the path's throughput had become exactly zero, each as the radiance collected up to that vertex —
+    what the product's kernels (which end such a path at once) count; tests/test_gpu_fuzz.py holds their frames to `frame + zero_stop`.  Here: the side image is empty for a
+    scene whose materials are evaluated inside their domain, holds a few samples for the scenes with one-sided coatings seen from behind, never more than the frame dropped,
+    and leaves the frame itself untouched."""
+    W, H, P = 48, 32, 3
+    sc = scenes.fuzz_scene(seed, W, H)
+    tables = orc.sequence_tables(P)
+    plain, rays = orc.render(sc.desc, W, H, n_passes=P, tables=tables, max_path_length=6, rr_start=4)
+    for kw in ({}, dict(wavefront_rules=True), dict(partials=True)):
+        zs = np.zeros((H, W, 7), np.float32)
+        img, _ = orc.render(sc.desc, W, H, n_passes=P, tables=tables, max_path_length=6, rr_start=4, zero_stop=zs, **kw)
+        if not kw: assert np.array_equal(img, plain)
+        assert np.isfinite(zs).all() and (zs[..., :3] >= 0).all()
+        dropped = P - img[..., 6]
+        assert (zs[..., 6] <= dropped).all()
+        assert (zs[..., 6].sum() > 0) == (seed != 0), (seed, kw, float(zs[..., 6].sum()))

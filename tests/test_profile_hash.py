@@ -15,17 +15,47 @@ def _bench():
     return m
 
 
-def test_hash_follows_the_sources(tmp_path):
+def test_hash_follows_the_sources(tmp_path, monkeypatch):
     b = _bench()
     assert b.KERNEL_BUILD == "trav-" + b.source_hash(b.TRAVERSAL_SOURCES) and len(b.KERNEL_BUILD) == 17
     for n in b.TRAVERSAL_SOURCES + b.SHADE_SOURCES:
         assert os.path.exists(os.path.join(ROOT, "cudatracerlib_amd", "csrc", n)), n
-    assert "flatten.cpp" in b.TRAVERSAL_SOURCES and "traverse_flat.h" in b.TRAVERSAL_SOURCES and "shade_kernel.inc" in b.SHADE_SOURCES
-    # one byte more in one file: another hash
-    import hashlib
-    h0 = b.source_hash(["flatten.cpp"])
-    h = hashlib.sha256(); h.update(b"flatten.cpp\0"); h.update(open(os.path.join(ROOT, "cudatracerlib_amd", "csrc", "flatten.cpp"), "rb").read() + b" "); h.update(b"\1")
-    assert h.hexdigest()[:12] != h0
+    # the files whose edits change what the profiled kernels do (advisor, round 5): the BVH2 builder with its re-optimisation pass, the host code that lays the device scene out,
+    # the shared structs, every *_wf build stub
+    for n in ("flatten.cpp", "traverse_flat.h", "bvh_builder.cpp", "tracer.hip", "device_scene.h", "flat8.h", "knobs.h"):
+        assert n in b.TRAVERSAL_SOURCES, n
+    for n in ("shade_kernel.inc", "tracer.hip", "device_scene.h", "shade_basic_wf.hip", "shade_class_p_wf.hip"):
+        assert n in b.SHADE_SOURCES, n
+    # a copy of the sources in a scratch tree: one more statement in one file is another hash, one more COMMENT is not, another compiler flag is
+    import shutil
+    src = os.path.join(ROOT, "cudatracerlib_amd", "csrc"); dst = tmp_path / "cudatracerlib_amd" / "csrc"; dst.mkdir(parents=True)
+    for n in set(b.TRAVERSAL_SOURCES): shutil.copy(os.path.join(src, n), dst / n)
+    shutil.copy(os.path.join(ROOT, "cudatracerlib_amd", "build.py"), tmp_path / "cudatracerlib_amd" / "build.py")
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    h0 = b.source_hash(b.TRAVERSAL_SOURCES)
+    assert "trav-" + h0 == b.KERNEL_BUILD
+    f = dst / "bvh_builder.cpp"; text = f.read_text()
+    f.write_text(text + "\n// a remark\n/* another */\n")
+    assert b.source_hash(b.TRAVERSAL_SOURCES) == h0
+    f.write_text(text + "\nstatic int one_more_statement = 1;\n")
+    assert b.source_hash(b.TRAVERSAL_SOURCES) != h0
+    f.write_text(text)
+    flags = b.build_flags()
+    assert "--offload-arch=gfx950" in flags and "-ffp-contract=off" in flags
+    monkeypatch.setattr(b, "build_flags", lambda: flags + ["-O2"])
+    assert b.source_hash(b.TRAVERSAL_SOURCES) != h0
+    # bench.py itself must not load the package (libctl_amd.so and its HIP runtime) at import time: see build_flags
+    import subprocess, sys
+    code = ("import importlib.util, sys; s = importlib.util.spec_from_file_location('b', %r); m = importlib.util.module_from_spec(s); s.loader.exec_module(m); "
+            "assert 'cudatracerlib_amd' not in sys.modules and 'torch' not in sys.modules; print(m.KERNEL_BUILD)") % os.path.join(ROOT, "bench.py")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == _bench().KERNEL_BUILD, out.stderr[-500:]
+
+
+def test_comment_stripping_leaves_literals_alone():
+    b = _bench()
+    t = b.strip_comments('int a = 1; // c\nconst char* s = "http://x"; /* b */ int b;\n\n   \nchar c = \'"\'; // "q\n')
+    assert t == 'int a = 1;\nconst char* s = "http://x";   int b;\nchar c = \'"\';'
 
 
 def test_committed_profile_is_of_this_tree():
