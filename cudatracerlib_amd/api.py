@@ -758,6 +758,11 @@ class Image:
         _check(lib.ctl_image_read_pixels(self._h, a.ctypes.data_as(C.c_void_p)))
         return a
 
+    def addSamples(self, samples):
+        """Image::AddSample (Engine/Image.cu:22-44) for samples (n, 5) = sx, sy, r, g, b"""
+        a = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1, 5)
+        _check(lib.ctl_image_add_samples(self._h, u32(len(a)), a.ctypes.data_as(C.c_void_p)))
+
     def setPixelData(self, a):
         a = np.ascontiguousarray(a, dtype=np.float32).reshape(self.height, self.width, 7)
         _check(lib.ctl_image_write_pixels(self._h, a.ctypes.data_as(C.c_void_p)))

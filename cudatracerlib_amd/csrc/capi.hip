@@ -237,6 +237,7 @@ void ctl_image_destroy(ctl_image* img) { delete img; }
 int ctl_image_clear(ctl_image* img) { CTL_REQUIRE(img, "null image"); CTL_TRY img->img.Clear(); CTL_CATCH }
 int ctl_image_read_pixels(ctl_image* img, ctl_pixel_data* host_out) { CTL_REQUIRE(img && host_out, "null argument"); CTL_TRY img->img.read(host_out); CTL_CATCH }
 int ctl_image_write_pixels(ctl_image* img, const ctl_pixel_data* host_in) { CTL_REQUIRE(img && host_in, "null argument"); CTL_TRY img->img.write(host_in); CTL_CATCH }
+int ctl_image_add_samples(ctl_image* img, uint32_t n, const float* host_samples5) { CTL_REQUIRE(img && (host_samples5 || !n), "null argument"); CTL_TRY img->img.add_samples(n, host_samples5); CTL_CATCH }
 // ---- multi-GPU: the one collective (comm.cpp)
 struct ctl_comm { Comm* c; };
 int ctl_comm_get_unique_id(uint8_t out128[128]) { CTL_REQUIRE(out128, "null argument"); CTL_TRY comm_unique_id(out128); CTL_CATCH }

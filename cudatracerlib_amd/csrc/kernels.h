@@ -112,6 +112,7 @@ int flat_top_cache_nodes();   // nodes at the head of the flattened node array t
 void launch_accumulate_stats(const launch_ctx& lc, const wave_queues& Q, int max_depth);
 void launch_apply_pipeline(const launch_ctx& lc, const ctl_pixel_data* image, uint32_t n, float splat_scale, uint32_t* rgbcol_out);
 void launch_resolve_rgb(const launch_ctx& lc, const ctl_pixel_data* image, uint32_t n, float splat_scale, float* rgb_out);
+void launch_add_samples(const launch_ctx& lc, ctl_pixel_data* image, uint32_t W, uint32_t H, uint32_t n, const float* samples5);   // Image::AddSample for n samples {sx, sy, r, g, b}
 
 // local pixel index -> film pixel for a tile shard (64x64 tiles, 8x8 micro-tiles inside = one wave)
 __host__ __device__ inline uint32_t shard_pixel_count(uint32_t W, uint32_t H, uint32_t rank, uint32_t world) {

@@ -242,6 +242,14 @@ __global__ __launch_bounds__(kBlock) void k_apply_pipeline(const ctl_pixel_data*
     }
 }
 
+// Image::AddSample (Engine/Image.cu:22-44) for a list of samples: compaction.h add_sample, the function the shade kernels deposit finished paths with when no stage is set
+__global__ __launch_bounds__(kBlock) void k_add_samples(ctl_pixel_data* __restrict__ image, uint32_t W, uint32_t H, uint32_t n, const float* __restrict__ s) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) add_sample(image, W, H, s[5 * i], s[5 * i + 1], f3(s[5 * i + 2], s[5 * i + 3], s[5 * i + 4]));
+}
+void launch_add_samples(const launch_ctx& lc, ctl_pixel_data* image, uint32_t W, uint32_t H, uint32_t n, const float* samples5) {
+    hipLaunchKernelGGL(k_add_samples, dim3(lc.grid_blocks), dim3(kBlock), 0, lc.stream, image, W, H, n, samples5);
+}
+
 // the counting kernels' stack-depth histogram (traverse_flat.h g_stack_hist lives in this translation unit)
 void read_stack_histogram(unsigned long long* h, bool reset) {
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stack_hist), sizeof(unsigned long long) * kStackSize) != hipSuccess) throw std::runtime_error("reading the stack histogram failed");

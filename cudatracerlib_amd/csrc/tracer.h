@@ -60,6 +60,7 @@ public:
     void mark_reduced(bool v) { reduced_ = v; }
     void read(ctl_pixel_data* host);
     void write(const ctl_pixel_data* host);
+    void add_samples(uint32_t n, const float* host_samples5);   // Image::AddSample (Engine/Image.cu:22-44) for n host samples {sx, sy, r, g, b}
     void resolve_rgb(float splat_scale, float* host_rgb);
     void apply_pipeline(float splat_scale, uint32_t* host_rgbcol);                 // applyImagePipeline without filter / post-process
     void apply_pipeline_ex(float splat_scale, const ctl_reconstruction_filter* filter, const ctl_tonemap* process, uint32_t* host_rgbcol);   // image_pipeline.hip

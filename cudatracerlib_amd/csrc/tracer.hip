@@ -359,6 +359,15 @@ Image::Image(uint32_t w, uint32_t h) : w_(w), h_(h) { require_device(); px_.allo
 void Image::Clear() { CTL_HIP(hipMemset(px_.p, 0, px_.n * sizeof(ctl_pixel_data))); reduced_ = false; }
 void Image::read(ctl_pixel_data* host) { CTL_HIP(hipDeviceSynchronize()); CTL_HIP(hipMemcpy(host, px_.p, px_.n * sizeof(ctl_pixel_data), hipMemcpyDeviceToHost)); }
 void Image::write(const ctl_pixel_data* host) { CTL_HIP(hipMemcpy(px_.p, host, px_.n * sizeof(ctl_pixel_data), hipMemcpyHostToDevice)); reduced_ = false; }
+void Image::add_samples(uint32_t n, const float* host_samples5) {
+    if (!n) return;
+    dbuf<float> tmp; tmp.alloc((size_t)n * 5);
+    CTL_HIP(hipDeviceSynchronize());   // the frame is complete (a tracer renders on its own stream)
+    CTL_HIP(hipMemcpy(tmp.p, host_samples5, (size_t)n * 5 * sizeof(float), hipMemcpyHostToDevice));
+    launch_ctx lc{ nullptr, 1024 };
+    launch_add_samples(lc, px_.p, w_, h_, n, tmp.p);
+    CTL_HIP(hipDeviceSynchronize());
+}
 void Image::resolve_rgb(float splat_scale, float* host_rgb) {
     if (!rgb_.p) rgb_.alloc(px_.n * 3);
     CTL_HIP(hipDeviceSynchronize());

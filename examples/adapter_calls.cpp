@@ -6,6 +6,7 @@
 #include "ctl_amd.h"
 
 #include <cfloat>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -110,8 +111,13 @@ int main() {
         void* depth = nullptr; check(ctl_device_malloc(128 * 96 * sizeof(float), &depth)); tracer.setDepthBuffer((float*)depth, 128, 96); tracer.DoRender(pixels.data());
         tracer.setDepthBuffer(nullptr, 0, 0); check(ctl_device_free(depth));
         ctl_hit hit; const float o[3] = { 0, 1, 0 }, dir[3] = { 0, -1, 0 }; const bool found = TraceSingleRayAMD(tracer.scene(), o, dir, 1e-4f, hit);
-        std::printf("{\"weight_sum_after_2_passes\": %.0f, \"luminance_sum\": %.4f, \"display_equals_frame\": %s, \"rays_last_pass\": %llu, \"hit\": %s, \"hit_dist\": %.6f}\n",
-                    weight, lum, same ? "true" : "false", (unsigned long long)tracer.getRaysInLastPass(), found ? "true" : "false", found ? hit.dist : -1.0f);
+        // Image::AddSample from the host side (a plugin that deposits its own radiance): three samples into the display image — one lands, one is NaN and one lies outside the film (both dropped)
+        const float smp[15] = { 5.5f, 7.25f, 1.0f, 2.0f, 3.0f,   6.5f, 7.5f, 1.0f, NAN, 0.0f,   -0.5f, 3.0f, 1.0f, 1.0f, 1.0f };
+        check(ctl_image_clear(display)); check(ctl_image_add_samples(display, 3, smp)); check(ctl_image_read_pixels(display, shown.data()));
+        double added = 0; for (const ctl_pixel_data& p : shown) added += p.weight_sum;
+        const bool landed = shown[7 * 128 + 5].weight_sum == 1.0f && shown[7 * 128 + 5].rgb[1] == 2.0f;
+        std::printf("{\"weight_sum_after_2_passes\": %.0f, \"luminance_sum\": %.4f, \"display_equals_frame\": %s, \"rays_last_pass\": %llu, \"hit\": %s, \"hit_dist\": %.6f, \"add_samples_kept\": %.0f, \"add_sample_landed\": %s}\n",
+                    weight, lum, same ? "true" : "false", (unsigned long long)tracer.getRaysInLastPass(), found ? "true" : "false", found ? hit.dist : -1.0f, added, landed ? "true" : "false");
         ctl_image_destroy(display); ctl_builder_destroy(b);
     } catch (const std::exception& e) { std::fprintf(stderr, "adapter_calls: %s\n", e.what()); return 1; }
     return 0;

@@ -387,6 +387,10 @@ void ctl_image_destroy(ctl_image* img);
 int ctl_image_clear(ctl_image* img);                                        /* Image::Clear                    */
 int ctl_image_read_pixels(ctl_image* img, ctl_pixel_data* host_out);        /* D2H of the PixelData array      */
 int ctl_image_write_pixels(ctl_image* img, const ctl_pixel_data* host_in);
+/* Image::AddSample (Engine/Image.h:56, Image.cu:22-44) for `n` samples {sx, sy, r, g, b} in host memory: negatives clamped, a NaN / infinite radiance or a position outside the
+ * film dropped, the pixel floor(sx), floor(sy) receives rgb += L, weightSum += 1 (float atomics, as the reference's device branch).  What a plugin that does not use the
+ * tracer's own accumulation calls to deposit its radiance. */
+int ctl_image_add_samples(ctl_image* img, uint32_t n, const float* host_samples5);
 void* ctl_image_device_ptr(ctl_image* img);                                 /* PixelData* in HBM (RCCL gather) */
 /* copySamplesToOutput (Kernel/ImagePipeline/ImagePipeline.cu:14-30): rgb/weight + splat*scale -> linear RGB float */
 int ctl_image_resolve_rgb(ctl_image* img, float splat_scale, float* host_rgb_out);

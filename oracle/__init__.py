@@ -77,6 +77,7 @@ def load(shared_math=False):
     o.orc_texture_eval.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p]
     o.orc_set_block_counts.argtypes = [C.c_void_p, u32]
     o.orc_set_zero_stop_image.argtypes = [C.c_void_p]; o.orc_set_zero_stop_image.restype = None
+    o.orc_image_add_samples.argtypes = [C.c_void_p, u32, u32, C.c_int, C.c_void_p]; o.orc_image_add_samples.restype = None
     o.orc_sample_normal_map.argtypes = [C.c_void_p, C.c_void_p, f32, f32, C.c_void_p, C.c_void_p]
     o.orc_alpha_test.argtypes = [C.c_void_p, C.c_void_p, f32, f32]
     o.orc_triangle_data_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32, C.c_int, C.c_void_p]

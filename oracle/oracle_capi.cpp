@@ -402,6 +402,12 @@ uint64_t orc_render(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t
     return total.load();
 }
 
+// Image::AddSample (Engine/Image.cu:22-44) over a list of samples, in order: pixels = W x H PixelData, samples = n x {sx, sy, r, g, b} (tests/golden/image.npz holds the
+// reference's own function's result for such lists)
+void orc_image_add_samples(ctl_pixel_data* pixels, uint32_t W, uint32_t H, int n, const float* samples) {
+    for (int i = 0; i < n; i++) addSample(pixels, (int)W, (int)H, samples[5 * i], samples[5 * i + 1], Spec(samples[5 * i + 2], samples[5 * i + 3], samples[5 * i + 4]));
+}
+
 // debugging aid (tools/fuzz_diag.py): the path of ONE sample of orc_render — pixel (x, y), one pair of sampler tables — vertex by vertex (ocore.h pathLog: 26 floats per vertex);
 // returns the number of floats written, rgb = the sample's radiance
 int orc_path_log(const ctl_scene_desc* desc, uint32_t W, uint32_t H, const float* t1, const float* t2, uint32_t x, uint32_t y, int direct, int maxPathLength, int rrStart, float* out, int cap, float* rgb) {

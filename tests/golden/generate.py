@@ -805,8 +805,38 @@ def gen_emitters(r):
     np.savez_compressed(os.path.join(HERE, "emitters.npz"), **out)
 
 
+def image_samples():
+    """inputs of image.npz: samples {sx, sy, r, g, b} for a 16 x 12 frame — positions inside, on pixel borders, one ulp below an integer (rounds into the next pixel when the
+    jitter is added in float), outside on every side, -0.0, NaN, infinite; radiance positive, negative (clampNegative), -0.0, NaN in one channel, +-inf, huge (own random stream)"""
+    rs = np.random.RandomState(20261001)
+    W, H, n = 16, 12, 6000
+    s = np.zeros((n, 5), np.float32)
+    s[:, 0] = rs.uniform(-1.5, W + 1.5, n); s[:, 1] = rs.uniform(-1.5, H + 1.5, n)
+    s[:, 2:] = rs.uniform(0, 4, (n, 3)) ** 2
+    k = rs.randint(0, n, 900); s[k[:300], 0] = np.floor(s[k[:300], 0]); s[k[300:600], 1] = np.floor(s[k[300:600], 1])
+    s[k[600:750], 0] = np.nextafter(np.floor(s[k[600:750], 0]).astype(np.float32), np.float32(-1e9)); s[k[750:900], 1] = np.nextafter(np.ceil(s[k[750:900], 1]).astype(np.float32), np.float32(-1e9))
+    special_pos = np.array([-0.0, np.nan, np.inf, -np.inf, W, H, W - 2.0 ** -20, -2.0 ** -30, 0.0, 3.4e38, -3.4e38, 2147483648.0, -2147483904.0], np.float32)
+    k = rs.randint(0, n, 400); s[k[:200], 0] = special_pos[rs.randint(0, len(special_pos), 200)]; s[k[200:], 1] = special_pos[rs.randint(0, len(special_pos), 200)]
+    special_col = np.array([-0.0, -1.0, -1e-30, np.nan, np.inf, -np.inf, 1e36, 1e-45, 0.0], np.float32)
+    k = rs.randint(0, n, 1500); s[k, 2 + rs.randint(0, 3, 1500)] = special_col[rs.randint(0, len(special_col), 1500)]
+    return W, H, s
+
+
+def gen_image(r):
+    """Image::AddSample (Engine/Image.cu:22-44) run by the reference's own code (oracle/ref_image_driver.cpp) over image_samples(), in order"""
+    W, H, s = image_samples()
+    r.ref_image_add_samples.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]; r.ref_image_add_samples.restype = C.c_int
+    px = np.zeros((H, W, 7), np.float32)
+    assert r.ref_image_add_samples(px.ctypes.data, W, H, len(s), s.ctypes.data) == 0
+    with np.errstate(invalid="ignore"):
+        assert np.isfinite(px).all() and 0.5 * len(s) < px[..., 6].sum() < len(s) and (px[..., 3:6] == 0).all()
+    np.savez_compressed(os.path.join(HERE, "image.npz"), width=np.int32(W), height=np.int32(H), samples=s, pixels=px)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["emitters"]:
+    if sys.argv[1:] == ["image"]:
+        gen_image(oracle.load_ref())
+    elif sys.argv[1:] == ["emitters"]:
         gen_emitters(oracle.load_ref())
     elif sys.argv[1:] == ["lights"]:
         gen_lights(oracle.load_ref())
@@ -848,3 +878,4 @@ if __name__ == "__main__":
         gen_bsdf_rough(oracle.load_ref())
         gen_scene_lights(oracle.load_ref())
         gen_material_maps(oracle.load_ref())
+        gen_image(oracle.load_ref())

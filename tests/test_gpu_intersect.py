@@ -255,3 +255,27 @@ def test_far_ray_origins_against_tiny_nodes(gpu, orc):
         assert np.array_equal(again[k][agree].view(np.uint32), got[k][hitm][agree].view(np.uint32)), k
     occ = gpu.intersect(scene, rays, any_hit=True)["tri_idx"] >= 0
     assert (occ == (orc.intersect(d, rays, any_hit=True, flat=fb.desc)["tri_idx"] >= 0)).mean() > 0.97
+
+
+@pytest.mark.parametrize("flatten", [True, False])
+def test_ray_claims_across_the_static_shares(gpu, flatten):
+    """The waves' ray claims (traverse.h ray_claims, round 6): a wave's first claim is static, only the rays behind the static shares go through the launch's cursor.  Queue
+    lengths on every side of that boundary — fewer rays than waves, exactly the static shares (one resident wave x 64 rays each), one ray more, several dynamic claims, a last
+    partial wave — give, ray for ray, what the same rays give in launches of 4096 (where every ray lies in a static share and no atomic is issued at all): every ray is traced
+    exactly once and lands in its own slot, closest hit and occlusion.  (The 4096-ray launches themselves are held to the oracle by the other tests of this file.)"""
+    sc = scenes.synthetic_sm(64, 64, n_instances=40, subdiv=2)
+    d = sc.desc
+    scene = gpu.Scene(d, flatten=flatten)
+    waves = 256 * 6 * 4          # resident traversal waves on an MI355X (kernels.hip traversal_blocks): 256 CUs x six workgroups (either layout) x four waves
+    rays = camera_and_random_rays(d, waves * 64 * 3 + 77, 11)
+    occ = camera_and_random_rays(d, waves * 64 * 3 + 77, 12, any_tmax=True)
+    ref = {k: np.concatenate([gpu.intersect(scene, rays[i:i + 4096])[k] for i in range(0, len(rays), 4096)]) for k in ("dist", "u", "v", "tri_idx", "node_idx")}
+    ref_occ = np.concatenate([gpu.intersect(scene, occ[i:i + 4096], any_hit=True)["tri_idx"] >= 0 for i in range(0, len(occ), 4096)])
+    assert (ref["tri_idx"] >= 0).mean() > 0.3 and 0.1 < ref_occ.mean() < 0.95
+    for n in (1, 63, 64, 65, 4097, waves * 64 - 1, waves * 64, waves * 64 + 1, waves * 64 + 64 * 37 + 5, len(rays)):
+        got = gpu.intersect(scene, rays[:n])
+        for k in ("tri_idx", "node_idx"):
+            assert np.array_equal(got[k], ref[k][:n]), (n, k)
+        for k in ("dist", "u", "v"):
+            assert np.array_equal(got[k].view(np.uint32), ref[k][:n].view(np.uint32)), (n, k)
+        assert np.array_equal(gpu.intersect(scene, occ[:n], any_hit=True)["tri_idx"] >= 0, ref_occ[:n]), (n, "occlusion")

@@ -765,6 +765,27 @@ def test_ordered_accumulation_is_independent_of_the_batching(gpu, orc):
     assert (got[..., :3].view(np.uint32) == want[..., :3].view(np.uint32)).all(axis=2).mean() > 0.98
 
 
+def test_image_add_samples_equals_the_references_own_add_sample(gpu):
+    """ctl_image_add_samples = Image::AddSample (Engine/Image.cu:22-44) on the device — compaction.h add_sample, the function the shade kernels deposit finished paths with — over
+    the samples of tests/golden/image.npz, whose expected frame was made by the reference's own code: which samples are dropped (outside the film after floor, NaN / infinite
+    radiance after clampNegative) and where the others land is equal one for one (weightSum exact); the sums are float atomics in hardware order, equal to round-off.
+    NaN / infinite POSITIONS are left out: (int)floorf of those is the host's conversion in the fixture and the GPU's here (the reference's own host and CUDA branches differ
+    the same way); a film position is pixel + jitter, never one of them."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "image.npz"))
+    W, H, s = int(g["width"]), int(g["height"]), g["samples"]
+    s = s[np.isfinite(s[:, :2]).all(axis=1) & (np.abs(s[:, :2]) < 1e9).all(axis=1)]
+    assert len(s) > 5000
+    # the fixture's frame without the left-out samples: they were all dropped by the reference (NaN / infinite / beyond-int positions land outside the film)
+    want = g["pixels"]
+    img = gpu.Image(W, H)
+    img.addSamples(s)
+    got = img.getPixelData()
+    assert np.array_equal(got[..., 6], want[..., 6])
+    assert np.allclose(got[..., :3], want[..., :3], rtol=2e-6, atol=0) and (got[..., 3:6] == 0).all()
+    img.addSamples(s[:100])
+    assert got[..., 6].sum() < img.getPixelData()[..., 6].sum() <= got[..., 6].sum() + 100
+
+
 def test_refused_batch_leaves_the_tracer_usable(gpu):
     """A batch beyond the 2^31 ray slots of a wavefront is refused BEFORE anything changes (advisor r4: the check used to run after Resize had stored the new size and batch, and every
     later Resize threw again): 4096 x 4096 pixels x 128 passes = 2^31 slots is refused by DoPasses; the same tracer then renders with a smaller batch, and resizes."""

@@ -87,3 +87,4 @@ def test_adapter_calls_run(gpu, tmp_path):
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["weight_sum_after_2_passes"] == 2 * 128 * 96 and out["display_equals_frame"] is True and out["luminance_sum"] > 0
     assert out["hit"] is True and abs(out["hit_dist"] - 1.0) < 1e-5 and out["rays_last_pass"] > 0
+    assert out["add_samples_kept"] == 1 and out["add_sample_landed"] is True      # ctl_image_add_samples = Image::AddSample: the NaN sample and the one outside the film are dropped

@@ -5,6 +5,6 @@ TAG=${1:-r06c}; WL=${2:-synthetic-sm}; OUT=gpurun_out/$TAG; mkdir -p $OUT; expor
 while read -r lib lanes envs; do
   [ -z "$lib" ] && continue
   echo "== $WL lib $lib lanes $lanes $envs" | tee -a $OUT/summary.txt
-  env CTL_AMD_LIB=$L/libctl_$lib.so $envs timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload $WL --tracer-param PipelineLanes=$lanes > $OUT/last.json 2> $OUT/last.err
+  env CTL_AMD_LIB=$L/libctl_$lib.so $envs timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload $WL  > $OUT/last.json 2> $OUT/last.err
   python tools/bench_brief.py < $OUT/last.json | tee -a $OUT/summary.txt; tail -2 $OUT/last.err; cat $OUT/last.json >> $OUT/runs.jsonl
 done

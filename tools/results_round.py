@@ -95,7 +95,7 @@ def main():
                "synthetic-bathroom 128 spp (config 5's own step count)": brief(bench(["--steps", "128", "--warmup", "5", "--workload", "synthetic-bathroom", "--no-cpu-baseline"]))}
     R["C4"] = {"status": "no multi-GPU node was available to this round's gpurun calls (1-GPU boxes): not measured on hardware",
                "fields_bench_writes": ["value", "rank_ms[]", "reduce_ms", "reduce_ms_per_rank[]", "slowest_rank", "rays_per_rank[]", "config.framebuffer_reduce"],
-               "emulated_on_one_gpu": "tools/shard_time_probe.py (one rank of N rendering its tile shard at 20 / 64 / 256 passes) and the 8-process rehearsal on one device (CTL_BENCH_SHARE_GPU=1 bench.py --gpus 8: the gathered frame equals the one-rank frame): DESIGN.md section 7, profiles/r05x_shard_time_probe.txt, profiles/r05x_bench_8ranks_shared_gpu.json, profiles/r05x_frames_8_vs_1.txt"}
+               "emulated_on_one_gpu": "tools/shard_time_probe.py (one rank of N rendering its tile shard at 20 / 64 / 256 passes) and the 8-process rehearsal on one device (CTL_BENCH_SHARE_GPU=1 bench.py --gpus 8: the gathered frame equals the one-rank frame): DESIGN.md section 7, profiles/r06b_shard_time_probe.txt, profiles/r06b_bench_8ranks_shared_gpu.json, profiles/r06b_frames_8_vs_1.txt"}
     json.dump(R, open(os.path.join(out_dir, "results.json"), "w"), indent=1)
     print(json.dumps(R)[:3000])
 
@@ -124,12 +124,14 @@ def render(R):
         return rows + [""]
     L += table("C3  San Miguel stand-ins, 1920x1080, depth 8, 20 spp per run unless said (assets absent on every box: SURVEY §8d)", R["C3"])
     L += table("C5  Bathroom stand-in, 1920x1080, depth 8", R["C5"])
-    red = os.path.join(ROOT, "profiles", "r05k_bench_bathroom_reduced.json")
-    if R["tag"].startswith("r05") and os.path.exists(red):   # the opt-in scene flag, one bench line of the same build and box series (tools/r05_results.sh)
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", R["tag"][:3] + "*_bench_bathroom_reduced.json")))   # the opt-in scene flag, one bench line of the same round's build and box series (tools/r0N_results.sh)
+    red = cands[-1] if cands else ""
+    if red:
         b = json.loads(open(red).read().strip().splitlines()[-1])
         L[-1:] = ["Rough plastic runs the reference's own 3-D transmittance lookup (frames equal the CPU path's to the bit; DESIGN.md §4).  With the opt-in scene flag "
                   "`CTL_SCENE_REDUCED_ROUGH_TRANSMITTANCE` (a per-material 1-D reduction of the table, the behaviour of rounds 2-4: within the per-pixel tolerance in most scenes, not equal to the bit): "
-                  "**%.1f Mrays/s**, %.3f ms per step (`profiles/r05k_bench_bathroom_reduced.json`)." % (b["value"], b["ms_per_step"]), ""]
+                  "**%.1f Mrays/s**, %.3f ms per step (`profiles/%s`)." % (b["value"], b["ms_per_step"], os.path.basename(red)), ""]
     L += ["## C4  8 x MI355X", "", R["C4"]["status"] + ".  `bench.py --gpus N` writes: " + ", ".join("`%s`" % f for f in R["C4"]["fields_bench_writes"]) + ".  " + R["C4"]["emulated_on_one_gpu"] + ".", ""]
     open(os.path.join(ROOT, "RESULTS.md"), "w").write("\n".join(L) + "\n")
     print("\n".join(L))
