@@ -24,7 +24,12 @@ T["TRAV_MS"] = "%.2f" % tr; T["TRAV_SHARE"] = "%.0f" % (100 * tr / ms); T["SHADE
 fr = r.get("fractions", {})
 T["SM_ROOF"] = "%s: hbm %.2f, valu_issue (2 cycles / instr) %.2f, l1_lookup %.2f" % (r.get("bound"), fr.get("hbm", 0), fr.get("valu_issue", 0), fr.get("l1_lookup", 0))
 T["TRAV_HBM"] = "%.2f" % fr.get("hbm", 0); T["TRAV_L1"] = "%.2f" % fr.get("l1_lookup", 0); T["TRAV_L2"] = "%.2f" % (r.get("l2_hit_rate") or 0)
+T["B_PATH"] = "%.0f" % r.get("bytes_per_path_ray", 0); T["B_SHADOW"] = "%.0f" % r.get("bytes_per_shadow_ray", 0); T["B_RAY"] = "%.0f" % r.get("bytes_per_ray", 0)
+T["RAYS_LAUNCH"] = "%.1f" % (r.get("rays_per_launch", 0) / 1e6); T["ALG_GB"] = "%.1f" % (r.get("bytes_per_ray", 0) * r.get("rays_per_launch", 0) / 1e9)
+T["TRAFFIC_GB"] = "%.1f" % ((r.get("traffic") or 0) / 1e9); T["TRAFFIC_RATIO"] = "%.2f" % ((r.get("traffic") or 0) / max(1.0, r.get("bytes_per_ray", 0) * r.get("rays_per_launch", 0)))
+T["LAUNCH_MS"] = "%.2f" % r.get("avg_launch_ms", 0)
 rs = fin.get("roofline_shade", {})
+T["SH_ALG"] = "%.0f" % (rs.get("algorithmic_bytes_per_vertex") or 0); T["SH_TRAFFIC"] = "%.0f" % (rs.get("traffic_per_vertex") or 0); T["SH_VERT"] = "%.2f" % ((rs.get("vertices") or 0) / fin["steps"] / 1e6)
 T["SHADE_HBM"] = "%.2f" % (rs.get("fractions", {}).get("hbm", 0))
 cpu = fin.get("cpu_baseline", {})
 T["CPU"] = "%.2f Mrays/s" % cpu.get("value", 0); T["CPU_CORES"] = str(cpu.get("cores")); T["CPU_X"] = "%.0f" % (v / cpu["value"]) if cpu.get("value") else "?"
