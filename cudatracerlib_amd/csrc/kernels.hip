@@ -276,6 +276,9 @@ void apply_tuning_from_env() {
     if (const char* e = knob_env("CTL_WQ_MIN_INNER")) { int v = atoi(e); if (v >= 0 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wq_min_inner), &v, sizeof(v)); }
 #endif
     if (const char* e = knob_env("CTL_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_leaf_batch), &v, sizeof(v)); }
+#if !CTL_LEAF_QUEUE && !defined(CTL_FLAT_EXPERIMENTS)
+    if (const char* e = knob_env("CTL_LEAF_BATCH_ANY")) { int v = atoi(e); if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_leaf_batch_any), &v, sizeof(v)); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ launch wrappers

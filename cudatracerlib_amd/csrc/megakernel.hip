@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256, CTL_MEGA_WAVES) void k_path_trace(dev_scene S,
             }
             const f3 f = bsdf_sample_top(mat, b, brdf_scattering_pdf, rng.next2());
             last_nor = b.dg.sys.n;
+            if (P.direct && (mat.combined_type & kESmooth)) cl = cl + cf * f3(0.0f);   // `cl += cf * UniformSampleOneLight(...)` with a zero estimate (PathTracer.cu:81-82): + 0, or NaN for a NaN / infinite throughput (shade_kernel.inc has the why)
             if (P.direct && (mat.combined_type & kESmooth) && S.num_lights) {   // UniformSampleOneLight + EstimateDirect (TraceAlgorithms.cu:44-101)
                 const f2 sl = rng.next2();
                 float lpdf; const int li2 = sample_emitter(S, lpdf, sl.x);

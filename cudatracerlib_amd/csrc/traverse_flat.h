@@ -37,6 +37,7 @@ constexpr int kTopCache = 0, kTopCacheFloats = 12;   // (experiment builds keep 
 __device__ unsigned long long g_stack_hist[kStackSize];   // counting kernels only: rays by the deepest traversal-stack entry they used (ctl_traversal_stack_histogram)
 __device__ int g_leaf_batch = 20;         // run the leaf phase once this many lanes hold a pending leaf entry (knob CTL_LEAF_BATCH; round 5, on the re-optimised tree: synthetic-SM 12: 3118, 16: 3137, 20: 3143, 24: 3123, 32: 3072 Mrays/s; synthetic-sm-hard 4232 / 4275 / 4382 / 4384 / 4311 — one value serves both, no per-scene choice needed; earlier trees: 8: 2253, 12: 2299, 16: 2315, 20: 2311, 24: 2288, 32: 2216 Mrays/s (profiles/r03_threshold_ab.log)
 
+__device__ int g_leaf_batch_any = 20;     // the same threshold for the any-hit traversal (knob CTL_LEAF_BATCH_ANY; round 6 sweep: profiles/r06_traversal.log)
 typedef __attribute__((address_space(3))) int flat_stack_lds_word;   // explicitly LDS: the pushes must compile to ds_write, not to generic flat stores
 struct flat_stack {
     flat_stack_lds_word* lds;             // this lane's column, stride 256
@@ -228,7 +229,7 @@ __device__ __forceinline__ void intersect_flat(const dev_scene& S, const float4*
     const int lane = threadIdx.x & 63;
     __shared__ unsigned int s_hist[COUNT ? kStackSize : 1];   // counting kernels: stack-depth histogram of this workgroup's rays, added to g_stack_hist at the end
     if (COUNT) { for (int i = threadIdx.x; i < kStackSize; i += blockDim.x) s_hist[i] = 0u; __syncthreads(); }
-    const int refill_idle = g_refill_idle, leaf_batch = g_leaf_batch;
+    const int refill_idle = g_refill_idle, leaf_batch = ANY_HIT ? g_leaf_batch_any : g_leaf_batch;
     const bool compact = S.flat_compact != 0;
     flat_stack st; st.lds = (flat_stack_lds_word*)lds_stack_ints + threadIdx.x;
     bool has_ray = false;

@@ -108,3 +108,26 @@ def test_nan_samples_are_dropped_by_the_kernels_too(gpu, orc, env):
         assert np.array_equal(got[..., 6], want[..., 6]), (mode, env)
         assert 3 * 64 - got[8:16, 12:20, 6].sum() >= 3, (mode, env)      # some of the panel's samples are NaN and dropped
         assert (np.abs(got[..., :3] - want[..., :3]) <= 2e-3 * (1 + np.abs(want[..., :3]))).all(), (mode, env)
+
+
+@pytest.mark.parametrize("mode", ["default", "plugin"])
+def test_nan_throughput_poisons_the_sample_through_a_zero_light_estimate(gpu, orc, mode):
+    """`cl += cf * UniformSampleOneLight(...)` (PathTracer.cu:81-82) is executed whatever the estimate is: an occluded light sample returns Spectrum(0), and NaN x 0 is NaN — a path
+    whose throughput became NaN (a Phong lobe evaluated outside its domain) poisons its sample at the next smooth vertex even when that vertex's shadow ray is occluded, and
+    Image::AddSample drops it.  The kernels defer the estimate behind the shadow ray and used to add nothing for an occluded one: they COUNTED such a sample (one pixel in 2700
+    renders of round 6's strict fuzz sweep: seed 392 at the sweep's size, pass 0, pixel (14, 48)).  Now `cl += cf * 0` is added where the reference adds it."""
+    W2, H2, D2, RR2 = 96, 64, 8, 5
+    sc = scenes.fuzz_scene(392, W2, H2)
+    d = sc.desc
+    tables = orc.sequence_tables(1)
+    zs = np.zeros((H2, W2, 7), np.float32)
+    want, _ = orc.render(d, W2, H2, n_passes=1, tables=tables, max_path_length=D2, rr_start=RR2, zero_stop=zs, **(dict(partials=True) if mode == "plugin" else {}))
+    assert want[48, 14, 6] == 0 and zs[48, 14, 6] == 0          # the reference drops this sample, and not because its throughput had died
+    want = want + zs
+    tr = gpu.PathTracer() if mode == "plugin" else gpu.WavefrontPathTracer()
+    p = tr.getParameters(); p.setValue("MaxPathLength", D2); p.setValue("RRStartDepth", RR2)
+    tr.Resize(W2, H2); tr.InitializeScene(gpu.Scene(d, flatten=True)); img = gpu.Image(W2, H2)
+    tr.setSamplerTables(*tables[0]); tr.DoPass(img, new_trace=True)
+    got = img.getPixelData()
+    assert np.array_equal(got[..., 6], want[..., 6]), np.argwhere(got[..., 6] != want[..., 6])[:4].tolist()
+    assert (np.abs(got[..., :3] - want[..., :3]) <= 2e-3 * (1 + np.abs(want[..., :3]))).all()

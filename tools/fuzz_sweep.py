@@ -13,7 +13,7 @@ W, H, PASSES, DEPTH, RR = 96, 64, 4, 8, 5
 first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (100, 300)
 MODE = sys.argv[3] if len(sys.argv) > 3 else "default"      # default | wavefront (PathSemantics = Wavefront, +u16 on odd seeds) | plugin (the megakernel PathTracer: first-hit ray differentials) | sensors (thin lens / orthographic / telecentric / spherical by seed) | alpha (alpha maps on a third of the materials, AlphaTest = true) | nodirect (Direct = false, depth 5, RRStartDepth 2) | wild (textured roughness / exponents / specular colours, two-sidedness, texture offsets varied in place)
 orc = oracle.Oracle(shared_math=True)
-worst = []; n_bad = 0
+worst = []; n_bad = 0; zs_all = []
 for seed in range(first, last):
     sc = scenes.fuzz_scene(seed, W, H); d = sc.desc
     if MODE == "sensors":
@@ -55,7 +55,12 @@ for seed in range(first, last):
     elif MODE == "alpha": kw = dict(alpha_test=True)
     elif MODE == "nodirect": kw = dict(direct=False)
     depth_, rr_ = (5, 2) if MODE == "nodirect" else (DEPTH, RR)
-    want, want_rays = orc.render(d, W, H, n_passes=PASSES, tables=tables, max_path_length=depth_, rr_start=rr_, **kw)
+    # round 6: the oracle also returns the samples the reference drops after a path's throughput died, as the radiance the kernels' zero-throughput cut counts (zero_stop):
+    # the kernels' frame is held to frame + zero_stop in EVERY pixel, weights exactly (rounds 5's sweeps masked the pixels whose weights differ)
+    zero_stop = np.zeros((H, W, 7), np.float32)
+    want, want_rays = orc.render(d, W, H, n_passes=PASSES, tables=tables, max_path_length=depth_, rr_start=rr_, zero_stop=zero_stop, **kw)
+    n_zero_stop = int(zero_stop[..., 6].sum()); untouched = zero_stop[..., 6] == 0
+    want = want + zero_stop
     for flatten in ((True,) if MODE == "plugin" else (False, True)):
         scene = gpu.Scene(d, flatten=flatten)
         tr = gpu.PathTracer() if MODE == "plugin" else gpu.WavefrontPathTracer()
@@ -68,19 +73,20 @@ for seed in range(first, last):
             tr.setSamplerTables(*tables[k]); tr.DoPass(img, new_trace=(k == 0))
         got = img.getPixelData()
         g, w = got[..., :3], want[..., :3]
-        same_w = got[..., 6] == want[..., 6]      # pixels whose weights differ: a sample the reference dropped as NaN after a zero-throughput vertex (tests/test_gpu_fuzz.py)
-        bad_w = bool((~same_w).mean() > 0.01 or (got[..., 6] < want[..., 6]).any())
-        off = ~(np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2) & same_w
-        exact = float((g == w).all(axis=2)[same_w].mean())
-        rel = abs(float(g[same_w].mean()) - float(w[same_w].mean())) / max(float(w[same_w].mean()), 1e-9)
+        same_w = got[..., 6] == want[..., 6]      # every pixel's weight must equal the oracle's + its zero-stop samples
+        bad_w = bool((~same_w).any())
+        off = ~(np.abs(g - w) <= 2e-3 * (1 + np.abs(w))).all(axis=2)
+        exact = float((g == w).all(axis=2)[untouched].mean())
+        rel = abs(float(g.mean()) - float(w.mean())) / max(float(w.mean()), 1e-9)
         fin = bool(np.isfinite(g).all())
-        rec = {"seed": seed, "flat": flatten, "off_pixels": int(off.sum()), "exact": round(exact, 4), "mean_rel": rel, "weights_differ_pixels": int((~same_w).sum()), "weights_bad": bad_w, "finite": fin,
+        rec = {"seed": seed, "flat": flatten, "off_pixels": int(off.sum()), "exact": round(exact, 4), "mean_rel": rel, "weights_differ_pixels": int((~same_w).sum()), "weights_bad": bad_w, "zero_stop_samples": n_zero_stop, "finite": fin,
                "models": sorted(set(d.materials[i].bsdf_type for i in range(d.n_materials)))}
-        worst.append((int(off.sum()), rel, seed, flatten))
+        worst.append((int(off.sum()), rel, seed, flatten)); zs_all.append(n_zero_stop)
         if off.sum() > 0 or rel > 1e-3 or bad_w or not fin or exact < 0.98:
             n_bad += 1
             ys, xs = np.nonzero(off)
             rec["where"] = [[int(x), int(y)] for x, y in zip(xs[:4], ys[:4])]; rec["gpu"] = g[off][:2].tolist(); rec["cpu"] = w[off][:2].tolist()
             print(json.dumps(rec), flush=True)
 worst.sort(reverse=True)
+print(json.dumps({"zero_stop_samples_total": int(sum(zs_all)), "renders_with_zero_stop": int(sum(1 for z in zs_all if z))}), flush=True)
 print(json.dumps({"mode": MODE, "seeds": [first, last], "renders": len(worst), "not_clean": n_bad, "worst_off_pixels": worst[:5]}), flush=True)
