@@ -57,7 +57,7 @@ def test_fuzz_scene_gpu_equals_oracle(gpu, orc, seed, mode):
         assert abs(g.mean() - w.mean()) <= 1e-3 * max(w.mean(), 1e-6), (seed, flatten)
         # every model runs the checker's arithmetic on the device (rough plastic / rough coating included: the reference's 3-D transmittance lookup): bit-equal frames
         # (a pixel that received a zero-stop sample adds it in another order than the kernels' pass order: left out of THIS bar only)
-        assert (g == w).all(axis=2)[untouched].mean() >= 0.97, (seed, flatten, float((g == w).all(axis=2)[untouched].mean()))
+        assert (g == w).all(axis=2)[untouched].mean() >= 0.99, (seed, flatten, float((g == w).all(axis=2)[untouched].mean()))   # (0.97 until round 6: pathIterateKernel's rules added emission as (w cf) Le where the reference's wavefront kernel has (w Le) cf — one ulp in 1-3 % of the pixels)
 
 
 @pytest.mark.parametrize("seed", list(range(12)))

@@ -1,0 +1,24 @@
+"""round 6: where do the frames of pathIterateKernel's rules with 16-bit barycentrics stop being bit-equal to the oracle's?  seed, then per path length: pixels not bit-equal / beyond tolerance"""
+import sys, numpy as np
+sys.path.insert(0, '/root/repo')
+import cudatracerlib_amd as gpu
+from cudatracerlib_amd import scenes
+import oracle
+W, H, RR = 96, 64, 5
+orc = oracle.Oracle(shared_math=True)
+for seed in [int(a) for a in sys.argv[1:]]:
+    sc = scenes.fuzz_scene(seed, W, H); d = sc.desc
+    tables = orc.sequence_tables(1)
+    scene = gpu.Scene(d, flatten=True)
+    for u16 in (False, True):
+        for L in (1, 2, 3, 4, 6, 8):
+            want, _ = orc.render(d, W, H, n_passes=1, tables=tables, max_path_length=L, rr_start=RR, wavefront_rules=True, u16_barycentrics=u16)
+            tr = gpu.WavefrontPathTracer(); p = tr.getParameters(); p.setValue("MaxPathLength", L); p.setValue("RRStartDepth", RR); p.setValue("PathSemantics", "Wavefront"); p.setValue("U16Barycentrics", u16)
+            tr.Resize(W, H); tr.InitializeScene(scene); img = gpu.Image(W, H); tr.setSamplerTables(*tables[0]); tr.DoPass(img, new_trace=True)
+            got = img.getPixelData()
+            ne = (got[..., :3] != want[..., :3]).any(axis=2)
+            rel = np.abs(got[..., :3] - want[..., :3]) / (1 + np.abs(want[..., :3]))
+            ys, xs = np.nonzero(ne)
+            print("seed %d u16 %d len %d: not bit-equal %d, beyond 2e-3: %d, max rel %.3g, first %s" % (seed, u16, L, int(ne.sum()), int((rel > 2e-3).any(axis=2).sum()), float(rel.max()), [(int(x), int(y)) for x, y in zip(xs[:3], ys[:3])]), flush=True)
+            if ne.any() and L == 1:
+                y, x = ys[0], xs[0]; print("   gpu", got[y, x].tolist(), "cpu", want[y, x].tolist())

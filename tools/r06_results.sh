@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: the bench lines of the shipped build WITH its committed counter profile (profiles/roofline_traffic.json carries this tree's source hash), and RESULTS.md's records
-TAG=${1:-r06m}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+TAG=${1:-r06n}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 python bench.py > $OUT/bench_64spp.json 2>$OUT/e1
 python bench.py --steps 20 --warmup 5 > $OUT/bench_final.json 2>$OUT/e0
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload synthetic-bathroom > $OUT/bench_bathroom.json 2>$OUT/e2

@@ -95,7 +95,7 @@ def main():
                "synthetic-bathroom 128 spp (config 5's own step count)": brief(bench(["--steps", "128", "--warmup", "5", "--workload", "synthetic-bathroom", "--no-cpu-baseline"]))}
     R["C4"] = {"status": "no multi-GPU node was available to this round's gpurun calls (1-GPU boxes): not measured on hardware.  In particular the default exchange of an N-rank run — ONE ncclGather of each rank's own tiles (ctl_image_gather) — and its fallback ncclReduce have only ever run with ONE rank against the real librccl.so (CTL_BENCH_COMM_WORLD1=1) and, with 2 / 3 / 8 ranks, through the gloo path that moves the same packed tiles: the multi-rank collective itself, its time-out and its fall-back on a fresh communicator are unverified on hardware (bench.py warms both exchanges up before the timed region, all ranks agree on the one that worked, CTL_BENCH_NO_GATHER=1 keeps the reduce)",
                "fields_bench_writes": ["value", "rank_ms[]", "reduce_ms", "reduce_ms_per_rank[]", "slowest_rank", "rays_per_rank[]", "config.framebuffer_reduce"],
-               "emulated_on_one_gpu": "tools/shard_time_probe.py (one rank of N rendering its tile shard at 20 / 64 / 256 passes) and the 8-process rehearsal on one device (CTL_BENCH_SHARE_GPU=1 bench.py --gpus 8: the gathered frame equals the one-rank frame): DESIGN.md section 7, profiles/r06d_shard_time_probe.txt, profiles/r06d_bench_8ranks_shared_gpu.json, profiles/r06d_frames_8_vs_1.txt"}
+               "emulated_on_one_gpu": "tools/shard_time_probe.py (one rank of N rendering its tile shard at 20 / 64 / 256 passes) and the 8-process rehearsal on one device (CTL_BENCH_SHARE_GPU=1 bench.py --gpus 8: the gathered frame equals the one-rank frame): DESIGN.md section 7, profiles/r06e_shard_time_probe.txt, profiles/r06e_bench_8ranks_shared_gpu.json, profiles/r06e_frames_8_vs_1.txt"}
     json.dump(R, open(os.path.join(out_dir, "results.json"), "w"), indent=1)
     print(json.dumps(R)[:3000])
 
