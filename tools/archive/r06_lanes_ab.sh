@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6: pipeline lanes A/B on one box — bench.py (driver style) under the settings of the heredoc / file: "<library variant> <lanes> [ENV=value ...]"
-# tools/r06_lanes_ab.sh <tag> [workload] < settings
+# tools/archive/r06_lanes_ab.sh <tag> [workload] < settings
 TAG=${1:-r06c}; WL=${2:-synthetic-sm}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; L=$PWD/cudatracerlib_amd
 while read -r lib lanes envs; do
   [ -z "$lib" ] && continue
