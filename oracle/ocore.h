@@ -64,7 +64,7 @@ struct Hit {   // Kernel/TraceResult.h:18-35
     bool hasHit() const { return tri != UINT32_MAX; }
     void init() { dist = FLT_MAX; tri = UINT32_MAX; node = UINT32_MAX; u = v = 0; }
 };
-struct TravCounts { uint64_t n_inner = 0, n_tri = 0, n_inst = 0; };
+struct TravCounts { uint64_t n_inner = 0, n_tri = 0, n_inst = 0; std::vector<uint32_t>* node_log = nullptr; std::vector<uint32_t>* entry_log = nullptr; };   // logs (flattened Q4 traversal only): which node / leaf entry each step looked at (orc_packet_union_probe)
 
 // Math/MathFunc.h:443-444 — integer min/max on float bit patterns; for tmin >= 0 and non-NaN inputs the decision
 // `cmax >= cmin` is the same as with float min/max (negative entries lose against d >= 0 in spanBegin and make
@@ -255,6 +255,7 @@ inline bool traceRayFlat(const Scene& S, V3 ori, V3 dir, float tmin_tri, float t
     while (node != EntrypointSentinel) {
         if (node >= 0) {
             if (cnt) cnt->n_inner++;
+            if (cnt && cnt->node_log) cnt->node_log->push_back((uint32_t)node >> 2);
             if (cnt && g_slab_probe) { const uint32_t ni = (uint32_t)node >> 2; for (int b = 0; b < 8; b++) if (ni < g_top_probe_limits[b]) g_top_probe[b].fetch_add(1, std::memory_order_relaxed); }
             const float* p = nodes + (size_t)node * 4;
             float dd[4]; int c[4]; int width = 4;
@@ -331,6 +332,7 @@ inline bool traceRayFlat(const Scene& S, V3 ori, V3 dir, float tmin_tri, float t
             const uint32_t* e = leaves + (size_t)(uint32_t)(~node) * 32;   // 128 B: Woop rows a, b, c, {globalTri << 1 | last, node, 0, 0}, then a copy of the node's inverse transform
             const uint32_t index = e[12], nodeIdx = e[13];
             if (cnt) cnt->n_tri++;
+            if (cnt && cnt->entry_log) cnt->entry_log->push_back((uint32_t)(~node));
             ctl_woop_tri w; std::memcpy(&w, e, 48);
             M44 modl; std::memcpy(modl.d, g.node_inv_transforms[nodeIdx].m, 64);
             const V3 d = transformDir(modl, dir), o = transformPoint(modl, ori);   // TraceHelper.cu:526-560 (per entry here; per instance there)

@@ -408,6 +408,33 @@ void orc_image_add_samples(ctl_pixel_data* pixels, uint32_t W, uint32_t H, int n
     for (int i = 0; i < n; i++) addSample(pixels, (int)W, (int)H, samples[5 * i], samples[5 * i + 1], Spec(samples[5 * i + 2], samples[5 * i + 3], samples[5 * i + 4]));
 }
 
+// What would a PACKET traversal of the coherent first bounce look at?  (tools/packet_union_probe.py; a feasibility probe, not a product path.)  For `n_blocks` 8 x 8 pixel blocks
+// spread over the frame — the 64 primary rays a wave of k_raygen's order holds — the closest-hit traversal of the flattened Q4 tree (orc_set_flat_bvh) is run ray by ray with a
+// visit log: out = { rays, sum of node steps, sum of entry tests, sum over blocks of the UNION of nodes looked at, ... of entries, blocks }.
+void orc_packet_union_probe(const ctl_scene_desc* desc, uint32_t W, uint32_t H, uint32_t n_blocks, uint64_t* out6) {
+    Scene S; S.d = *desc; S.flat = g_flat;
+    PerspectiveSensor sensor; sensor.update(desc->camera);
+    for (int i = 0; i < 6; i++) out6[i] = 0;
+    if (!g_flat) return;
+    const uint32_t bx = W / 8, by = H / 8, total = bx * by, step = total / (n_blocks ? n_blocks : 1) ? total / n_blocks : 1;
+    std::vector<uint32_t> nodes, entries, un, ue;
+    for (uint32_t b = 0; b < total; b += step) {
+        un.clear(); ue.clear();
+        for (uint32_t p = 0; p < 64; p++) {
+            const float x = (float)((b % bx) * 8 + (p & 7)) + 0.5f, y = (float)((b / bx) * 8 + (p >> 3)) + 0.5f;
+            V3 o, d; sensor.sampleRay(V2{ x, y }, V2{ 0.5f, 0.5f }, o, d);
+            nodes.clear(); entries.clear();
+            TravCounts tc; tc.node_log = &nodes; tc.entry_log = &entries;
+            Hit h; traceRayFlat(S, o, d, S.d.ray_trace_eps, FLT_MAX, false, S.d.ray_trace_eps, h, &tc);
+            out6[0]++; out6[1] += nodes.size(); out6[2] += entries.size();
+            un.insert(un.end(), nodes.begin(), nodes.end()); ue.insert(ue.end(), entries.begin(), entries.end());
+        }
+        std::sort(un.begin(), un.end()); un.erase(std::unique(un.begin(), un.end()), un.end());
+        std::sort(ue.begin(), ue.end()); ue.erase(std::unique(ue.begin(), ue.end()), ue.end());
+        out6[3] += un.size(); out6[4] += ue.size(); out6[5]++;
+    }
+}
+
 // debugging aid (tools/fuzz_diag.py): the path of ONE sample of orc_render — pixel (x, y), one pair of sampler tables — vertex by vertex (ocore.h pathLog: 26 floats per vertex);
 // returns the number of floats written, rgb = the sample's radiance
 int orc_path_log(const ctl_scene_desc* desc, uint32_t W, uint32_t H, const float* t1, const float* t2, uint32_t x, uint32_t y, int direct, int maxPathLength, int rrStart, float* out, int cap, float* rgb) {
